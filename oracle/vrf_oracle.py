@@ -1,0 +1,455 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) for the EC-VRF hot path of ark-ec-vrfs / ark-vrf.
+
+This file is the checker, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+
+Parity status
+-------------
+The reference checkout (/root/reference) is a 17-line deprecated re-export shim:
+``src/lib.rs:13-17`` re-exports ``ark_vrf::{codec, ietf, pedersen, ring, suites, utils,
+Input, Output, Public, Secret, Suite, ...}`` and ``src/lib.rs:9-11`` is an unconditional
+``compile_error!``.  The arithmetic lives in the un-vendored third-party crate ``ark-vrf``
+(``Cargo.toml:11-12``: ``ark-vrf = "0.1.0"``, caret requirement, Cargo.lock git-ignored
+at ``.gitignore:8`` => exact version unpinned) and its arkworks dependencies (ark-ec,
+ark-ff, ark-serialize, ark-ed-on-bls12-381-bandersnatch, sha2), none of which is on this
+machine.  By the reference's *own* contents parity is therefore **unpinned**: it holds no
+test, golden vector or fixture for this path.
+
+What pins this oracle instead: it restates the published algorithms the upstream crate
+implements (RFC 9381 section 5 ECVRF with additional data, RFC 9380 section 5.3.1
+expand_message_xmd / section 6.7.1 + 6.8.2 Elligator 2 and the Montgomery->Edwards map,
+RFC 8032-style deterministic nonce, arkworks' compressed twisted-Edwards serialisation)
+exactly as written down in SURVEY.md Appendix A, and is checked field by field against
+the upstream ``bandersnatch_sha-512_ell2`` IETF vectors 1-3 and Pedersen vector 1
+reproduced in SURVEY.md Appendix B (tests/golden/bandersnatch_sha512_ell2_kat.json).
+
+Each function names the reference interface it stands in for as
+``[ref src/lib.rs:LINE name]`` (the only place that name exists in /root/reference).
+"""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+# --------------------------------------------------------------------------------------
+# Suite descriptors  [ref src/lib.rs:14 `suites`, src/lib.rs:16 `Suite`]
+# --------------------------------------------------------------------------------------
+
+Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001  # BLS12-381 Fr
+
+
+@dataclass(frozen=True)
+class SuiteParams:
+    name: str
+    suite_id: bytes
+    q: int            # base field modulus
+    a: int            # TE coefficient a (mod q)
+    d: int            # TE coefficient d (mod q)
+    r: int            # prime subgroup order
+    cofactor: int
+    gx: int
+    gy: int
+    bx: int           # Pedersen blinding base
+    by: int
+    h2c: str          # "ell2" | "tai"
+    h2c_dst: bytes = b""
+    # Elligator-2 constants on the birationally equivalent Montgomery curve
+    mont_j: int = 0
+    mont_k: int = 0
+    ell2_z: int = 0
+    challenge_len: int = 32
+
+
+BANDERSNATCH = SuiteParams(
+    name="bandersnatch_sha512_ell2",
+    suite_id=b"Bandersnatch_SHA-512_ELL2",
+    q=Q,
+    a=Q - 5,
+    d=45022363124591815672509500913686876175488063829319466900776701791074614335719,
+    r=0x1CFB69D4CA675F520CCE760202687600FF8F87007419047174FD06B52876E7E1,
+    cofactor=4,
+    gx=18886178867200960497001835917649091219057080094937609519140440539760939937304,
+    gy=19188667384257783945677642223292697773471335439753913231509108946878080696678,
+    bx=6150229251051246713677296363717454238956877613358614224171740096471278798312,
+    by=28442734166467795856797249030329035618871580593056783094884474814923353898473,
+    h2c="ell2",
+    h2c_dst=b"ECVRF_" + b"Bandersnatch_XMD:SHA-512_ELL2_RO_" + b"Bandersnatch_SHA-512_ELL2",
+    mont_j=29978822694968839326280996386011761570173833766074948509196803838190355340952,
+    mont_k=25465760566081946422412445027709227188579564747101592991722834452325077642517,
+    ell2_z=5,
+)
+
+# JubJub: SURVEY.md Appendix A.6 -- [RECALL], parity unpinned (suite id / TAI details /
+# blinding base are not authenticated by any vector).  The blinding base below is NOT an
+# upstream constant: it is derived deterministically in `jubjub_params()` and travels to
+# the device through the suite descriptor, exactly as SURVEY.md section 8b prescribes.
+_JUBJUB_D = 19257038036680949359750312669786877991949435402254120286184196891950884077233
+_JUBJUB_R = 6554484396890773809930967563523245729705921265872317281365359162392183254199
+_JUBJUB_GX = 8076246640662884909881801758704306714034609987455869804520522091855516602923
+_JUBJUB_GY = 13262374693698910701929044844600465831413122818447359594527400194675274060458
+
+
+# --------------------------------------------------------------------------------------
+# Field helpers  [ref src/lib.rs:15 `BaseField`, `ScalarField`] (ark-ff Fp semantics)
+# --------------------------------------------------------------------------------------
+
+def finv(x: int, p: int) -> int:
+    return pow(x, p - 2, p)
+
+
+def legendre(x: int, p: int) -> int:
+    """1 if x is a non-zero square, 0 if x == 0, -1 otherwise."""
+    x %= p
+    if x == 0:
+        return 0
+    return 1 if pow(x, (p - 1) // 2, p) == 1 else -1
+
+
+def fsqrt(x: int, p: int) -> Optional[int]:
+    """Tonelli-Shanks; returns *a* root (caller fixes the sign) or None."""
+    x %= p
+    if x == 0:
+        return 0
+    if legendre(x, p) != 1:
+        return None
+    s, t = 0, p - 1
+    while t % 2 == 0:
+        s += 1
+        t //= 2
+    z = 2
+    while legendre(z, p) != -1:
+        z += 1
+    m, c, tt, rr = s, pow(z, t, p), pow(x, t, p), pow(x, (t + 1) // 2, p)
+    while tt != 1:
+        i, t2 = 0, tt
+        while t2 != 1:
+            t2 = t2 * t2 % p
+            i += 1
+        b = pow(c, 1 << (m - i - 1), p)
+        m, c = i, b * b % p
+        tt, rr = tt * c % p, rr * b % p
+    return rr
+
+
+# --------------------------------------------------------------------------------------
+# Twisted Edwards group  [ref src/lib.rs:15 `AffinePoint`] (ark-ec TE model semantics)
+# Points are affine tuples (x, y); identity = (0, 1).
+# --------------------------------------------------------------------------------------
+
+Point = Tuple[int, int]
+
+
+def te_identity() -> Point:
+    return (0, 1)
+
+
+def te_is_on_curve(S: SuiteParams, P: Point) -> bool:
+    x, y = P
+    q = S.q
+    return (S.a * x * x + y * y - 1 - S.d * x * x % q * y * y) % q == 0
+
+
+def te_add(S: SuiteParams, P: Point, Qp: Point) -> Point:
+    x1, y1 = P
+    x2, y2 = Qp
+    q = S.q
+    dxy = S.d * x1 % q * x2 % q * y1 % q * y2 % q
+    x3 = (x1 * y2 + y1 * x2) * finv((1 + dxy) % q, q) % q
+    y3 = (y1 * y2 - S.a * x1 % q * x2) * finv((1 - dxy) % q, q) % q
+    return (x3 % q, y3 % q)
+
+
+def te_neg(S: SuiteParams, P: Point) -> Point:
+    return ((-P[0]) % S.q, P[1])
+
+
+def _ext_add(S, P, Qe):
+    # extended coordinates, add-2008-hwcd (unified)
+    q = S.q
+    X1, Y1, Z1, T1 = P
+    X2, Y2, Z2, T2 = Qe
+    A = X1 * X2 % q
+    B = Y1 * Y2 % q
+    C = S.d * T1 % q * T2 % q
+    D = Z1 * Z2 % q
+    E = ((X1 + Y1) * (X2 + Y2) - A - B) % q
+    F = (D - C) % q
+    G = (D + C) % q
+    H = (B - S.a * A) % q
+    return (E * F % q, G * H % q, F * G % q, E * H % q)
+
+
+def te_mul(S: SuiteParams, k: int, P: Point) -> Point:
+    """k*P by left-to-right double-and-add on extended coordinates (any k >= 0)."""
+    q = S.q
+    acc = (0, 1, 1, 0)
+    base = (P[0], P[1], 1, P[0] * P[1] % q)
+    for bit in bin(k)[2:] if k else "":
+        acc = _ext_add(S, acc, acc)
+        if bit == "1":
+            acc = _ext_add(S, acc, base)
+    X, Y, Z, _ = acc
+    zi = finv(Z, q)
+    return (X * zi % q, Y * zi % q)
+
+
+def te_in_prime_subgroup(S: SuiteParams, P: Point) -> bool:
+    return te_is_on_curve(S, P) and te_mul(S, S.r, P) == (0, 1)
+
+
+# --------------------------------------------------------------------------------------
+# Codec  [ref src/lib.rs:14 `codec`] (ArkworksCodec: LE scalars, compressed TE points)
+# SURVEY.md Appendix A.1
+# --------------------------------------------------------------------------------------
+
+def scalar_encode(k: int) -> bytes:
+    return int(k).to_bytes(32, "little")
+
+
+def scalar_decode(b: bytes, r: int) -> Optional[int]:
+    v = int.from_bytes(b, "little")
+    return v if v < r else None
+
+
+def point_encode(S: SuiteParams, P: Point) -> bytes:
+    x, y = P
+    out = bytearray(y.to_bytes(32, "little"))
+    if x > (S.q - x) % S.q:
+        out[31] |= 0x80
+    return bytes(out)
+
+
+def point_decode(S: SuiteParams, b: bytes) -> Optional[Point]:
+    """Decompress; no subgroup check (that is `point_decode_checked`)."""
+    if len(b) != 32:
+        return None
+    raw = bytearray(b)
+    flag = bool(raw[31] & 0x80)
+    raw[31] &= 0x7F
+    y = int.from_bytes(raw, "little")
+    q = S.q
+    if y >= q:
+        return None
+    y2 = y * y % q
+    den = (S.a - S.d * y2) % q
+    if den == 0:
+        return None
+    x2 = (1 - y2) * finv(den, q) % q
+    x = fsqrt(x2, q)
+    if x is None:
+        return None
+    neg = (q - x) % q
+    lo, hi = (x, neg) if x <= neg else (neg, x)
+    x = hi if flag else lo
+    if x == 0 and flag:
+        return None
+    return (x, y)
+
+
+def point_decode_checked(S: SuiteParams, b: bytes) -> Optional[Point]:
+    P = point_decode(S, b)
+    if P is None or not te_in_prime_subgroup(S, P):
+        return None
+    return P
+
+
+# --------------------------------------------------------------------------------------
+# SHA-512 / expand_message_xmd  [ref src/lib.rs:14 `utils`] (ark-ec::hashing quirk:
+# Z_pad = 48 bytes)
+# --------------------------------------------------------------------------------------
+
+def sha512(b: bytes) -> bytes:
+    return hashlib.sha512(b).digest()
+
+
+def xmd_sha512_96(msg: bytes, dst: bytes, z_pad_len: int = 48) -> bytes:
+    assert len(dst) <= 255
+    dst_prime = dst + bytes([len(dst)])
+    b0 = sha512(bytes(z_pad_len) + msg + b"\x00\x60" + b"\x00" + dst_prime)
+    b1 = sha512(b0 + b"\x01" + dst_prime)
+    b2 = sha512(bytes(x ^ y for x, y in zip(b0, b1)) + b"\x02" + dst_prime)
+    return (b1 + b2)[:96]
+
+
+def hash_to_field2(S: SuiteParams, msg: bytes) -> Tuple[int, int]:
+    u = xmd_sha512_96(msg, S.h2c_dst)
+    return int.from_bytes(u[:48], "big") % S.q, int.from_bytes(u[48:], "big") % S.q
+
+
+# --------------------------------------------------------------------------------------
+# Elligator 2 -> twisted Edwards  [ref src/lib.rs:14 `utils::hash_to_curve_ell2_rfc_9380`]
+# SURVEY.md Appendix A.3
+# --------------------------------------------------------------------------------------
+
+def elligator2_te(S: SuiteParams, u: int) -> Point:
+    q = S.q
+    J, K, Z = S.mont_j, S.mont_k, S.ell2_z
+    jk = J * finv(K, q) % q            # J/K
+    k2i = finv(K * K % q, q)            # 1/K^2
+    den = (1 + Z * u % q * u) % q
+    if den == 0:
+        den = 1
+    x1 = (-jk) * finv(den, q) % q
+    gx1 = (x1 * x1 % q * x1 + jk * x1 % q * x1 + x1 * k2i) % q
+    x2 = (-x1 - jk) % q
+    gx2 = (x2 * x2 % q * x2 + jk * x2 % q * x2 + x2 * k2i) % q
+    if legendre(gx1, q) >= 0:          # gx1 square (zero counts as square)
+        x = x1
+        y = fsqrt(gx1, q)
+        if y % 2 == 0:                  # want y odd
+            y = (q - y) % q
+    else:
+        x = x2
+        y = fsqrt(gx2, q)
+        if y % 2 == 1:                  # want y even
+            y = (q - y) % q
+    s = x * K % q
+    t = y * K % q
+    if t * (s + 1) % q == 0:
+        return (0, 1)
+    v = s * finv(t, q) % q
+    w = (s - 1) * finv((s + 1) % q, q) % q
+    return (v, w)
+
+
+def hash_to_curve_ell2(S: SuiteParams, data: bytes) -> Point:
+    u0, u1 = hash_to_field2(S, data)
+    q0 = elligator2_te(S, u0)
+    q1 = elligator2_te(S, u1)
+    return te_mul(S, S.cofactor, te_add(S, q0, q1))
+
+
+def hash_to_curve_tai(S: SuiteParams, data: bytes) -> Optional[Point]:
+    """RFC 9381 5.4.1.1 try-and-increment as SURVEY.md A.6 recalls it [unpinned]."""
+    for ctr in range(256):
+        h = sha512(S.suite_id + b"\x01" + data + bytes([ctr]) + b"\x00")
+        P = point_decode(S, h[:32])
+        if P is None:
+            continue
+        P = te_mul(S, S.cofactor, P)
+        if P != (0, 1):
+            return P
+    return None
+
+
+def data_to_point(S: SuiteParams, data: bytes) -> Optional[Point]:
+    """[ref src/lib.rs:15-16 `Input::new` / `Suite::data_to_point`]"""
+    if S.h2c == "ell2":
+        return hash_to_curve_ell2(S, data)
+    return hash_to_curve_tai(S, data)
+
+
+# --------------------------------------------------------------------------------------
+# Secret / nonce / challenge / output hash
+# [ref src/lib.rs:16 `Secret`, `Suite::nonce`, `Suite::challenge`; src/lib.rs:15 `Output`]
+# SURVEY.md Appendix A.2, A.4
+# --------------------------------------------------------------------------------------
+
+def secret_from_seed(S: SuiteParams, seed: bytes) -> int:
+    return int.from_bytes(sha512(seed), "little") % S.r
+
+
+def public_from_secret(S: SuiteParams, sk: int) -> Point:
+    return te_mul(S, sk, (S.gx, S.gy))
+
+
+def nonce_rfc8032(S: SuiteParams, sk: int, H: Point) -> int:
+    hsk = sha512(scalar_encode(sk))
+    return int.from_bytes(sha512(hsk[32:64] + point_encode(S, H)), "little") % S.r
+
+
+def challenge_rfc9381(S: SuiteParams, pts, ad: bytes) -> int:
+    buf = S.suite_id + b"\x02" + b"".join(point_encode(S, P) for P in pts) + ad + b"\x00"
+    return int.from_bytes(sha512(buf)[: S.challenge_len], "big") % S.r
+
+
+def output_hash(S: SuiteParams, gamma: Point) -> bytes:
+    """[ref src/lib.rs:15 `Output::hash`] point_to_hash_rfc_9381, no cofactor clearing."""
+    return sha512(S.suite_id + b"\x03" + point_encode(S, gamma) + b"\x00")
+
+
+# --------------------------------------------------------------------------------------
+# IETF VRF  [ref src/lib.rs:14 `ietf`]  SURVEY.md Appendix A.4
+# --------------------------------------------------------------------------------------
+
+def ietf_prove(S: SuiteParams, sk: int, H: Point, ad: bytes):
+    """Returns (gamma, c, s). [ref src/lib.rs:14 `ietf::Prover::prove`]"""
+    G = (S.gx, S.gy)
+    pk = te_mul(S, sk, G)
+    gamma = te_mul(S, sk, H)
+    k = nonce_rfc8032(S, sk, H)
+    kG = te_mul(S, k, G)
+    kH = te_mul(S, k, H)
+    c = challenge_rfc9381(S, [pk, H, gamma, kG, kH], ad)
+    s = (k + c * sk) % S.r
+    return gamma, c, s
+
+
+def ietf_verify(S: SuiteParams, pk: Point, H: Point, gamma: Point, ad: bytes, c: int, s: int) -> bool:
+    """[ref src/lib.rs:14 `ietf::Verifier::verify`]"""
+    G = (S.gx, S.gy)
+    U = te_add(S, te_mul(S, s, G), te_neg(S, te_mul(S, c, pk)))
+    V = te_add(S, te_mul(S, s, H), te_neg(S, te_mul(S, c, gamma)))
+    return challenge_rfc9381(S, [pk, H, gamma, U, V], ad) == c
+
+
+# --------------------------------------------------------------------------------------
+# Pedersen VRF  [ref src/lib.rs:14 `pedersen`]  SURVEY.md Appendix A.5
+# --------------------------------------------------------------------------------------
+
+def pedersen_blinding(S: SuiteParams, sk: int, H: Point, ad: bytes) -> int:
+    buf = S.suite_id + b"\xCC" + scalar_encode(sk) + point_encode(S, H) + ad + b"\x00"
+    return int.from_bytes(sha512(buf), "big") % S.r
+
+
+def pedersen_prove(S: SuiteParams, sk: int, H: Point, ad: bytes):
+    """Returns (gamma, (pk_com, R, Ok, s, sb), blinding)."""
+    G, B = (S.gx, S.gy), (S.bx, S.by)
+    gamma = te_mul(S, sk, H)
+    b = pedersen_blinding(S, sk, H, ad)
+    k = nonce_rfc8032(S, sk, H)
+    kb = nonce_rfc8032(S, b, H)
+    pk_com = te_add(S, te_mul(S, sk, G), te_mul(S, b, B))
+    R = te_add(S, te_mul(S, k, G), te_mul(S, kb, B))
+    Ok = te_mul(S, k, H)
+    c = challenge_rfc9381(S, [pk_com, H, gamma, R, Ok], ad)
+    s = (k + c * sk) % S.r
+    sb = (kb + c * b) % S.r
+    return gamma, (pk_com, R, Ok, s, sb), b
+
+
+def pedersen_verify(S: SuiteParams, H: Point, gamma: Point, ad: bytes, proof) -> bool:
+    pk_com, R, Ok, s, sb = proof
+    G, B = (S.gx, S.gy), (S.bx, S.by)
+    c = challenge_rfc9381(S, [pk_com, H, gamma, R, Ok], ad)
+    if te_add(S, Ok, te_mul(S, c, gamma)) != te_mul(S, s, H):
+        return False
+    lhs = te_add(S, R, te_mul(S, c, pk_com))
+    rhs = te_add(S, te_mul(S, s, G), te_mul(S, sb, B))
+    return lhs == rhs
+
+
+# --------------------------------------------------------------------------------------
+# JubJub descriptor (unpinned, see note above)
+# --------------------------------------------------------------------------------------
+
+def jubjub_params() -> SuiteParams:
+    base = SuiteParams(
+        name="jubjub_sha512_tai", suite_id=b"JubJub_SHA-512_TAI", q=Q, a=Q - 1, d=_JUBJUB_D,
+        r=_JUBJUB_R, cofactor=8, gx=_JUBJUB_GX, gy=_JUBJUB_GY, bx=0, by=1, h2c="tai")
+    # host-supplied blinding base: TAI hash of a fixed label (nothing-up-my-sleeve)
+    B = hash_to_curve_tai(base, b"vrfhip-jubjub-blinding-base")
+    return SuiteParams(**{**base.__dict__, "bx": B[0], "by": B[1]})
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic benchmark inputs
+# --------------------------------------------------------------------------------------
+
+def synth_seed(i: int) -> bytes:
+    return int(i).to_bytes(8, "little")
+
+
+def synth_msg(i: int) -> bytes:
+    return sha512(b"vrfhip-msg" + int(i).to_bytes(8, "little"))[:32]
