@@ -1,0 +1,418 @@
+// fe.cuh -- Fq arithmetic for gfx950: 9 limbs x 29 bits, Montgomery radix R = 2^261.
+//
+// Replaces ark_ff::Fp<MontBackend, 4> (the type behind `BaseField`, /root/reference
+// src/lib.rs:15) on the VRF hot path.  Design notes:
+//
+//  * gfx950 has a full-rate 32x32+64 multiply-add (v_mad_u64_u32, measured at the same issue
+//    rate as v_add: profiles/r01_instr_rate_microbench.jsonl) but that instruction has no
+//    carry-IN.  A saturated 2^32 radix therefore pays an add-with-carry per product.  With
+//    29-bit limbs nine products plus nine reduction products fit a 64-bit accumulator with
+//    no carry handling at all: a field multiplication is 81 + 72 v_mad_u64_u32 plus one
+//    shift/mask per column.
+//  * Limbs are *lazy*: additions and subtractions are nine independent 32-bit adds with no
+//    carry propagation and no modular reduction.  Every value carries two compile-time
+//    bounds: L (each limb < L * (2^29 + 2^13)) and V (value < V * q).  fe_mul static_asserts
+//    that its 64-bit column accumulators cannot overflow (L1 * L2 <= 6) and derives the
+//    output bound, so an overflow is a compile error, not a wrong proof.
+//  * q = 1 (mod 2^32) => -q^-1 = -1 (mod 2^29) and q's low limb is 1: the Montgomery
+//    quotient digit is (-acc) & mask, no multiply.
+//
+// Everything is __host__ __device__ so the same source can be unit-tested on the CPU by
+// tests/hostsim (test tooling only; never linked into libvrfhip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "constants.gen.h"
+
+#define VRF_HD __host__ __device__ __forceinline__
+
+namespace vrf {
+
+using vrfk::LMASK;
+constexpr int NL = 9;
+constexpr int LW = 29;
+
+// out value bound of a Montgomery product: (a*b + m*q)/R < q * (1 + Va*Vb*q/R), q/R = 0.014152
+constexpr int mul_v(int v1, int v2) { return 1 + (v1 * v2 * 1416 + 99999) / 100000; }
+
+template <int L, int V>
+struct Fe {
+  static_assert(L >= 1 && L <= 7, "limb bound out of range");
+  static_assert(V >= 1 && V <= 64, "value bound out of range (top limb must stay < 2^29)");
+  uint32_t v[NL];
+  Fe() = default;
+  template <int L2, int V2>
+  VRF_HD Fe(const Fe<L2, V2>& o) {
+    static_assert(L2 <= L && V2 <= V, "narrowing Fe conversion");
+#pragma unroll
+    for (int i = 0; i < NL; ++i) v[i] = o.v[i];
+  }
+};
+
+using FeN = Fe<1, 2>;   // storage type: a Montgomery product (limbs < 2^29, value < 2q)
+using FeP = Fe<1, 5>;   // point-coordinate type (closure bound of the TE formulas, te.cuh)
+
+template <int L, int V>
+VRF_HD Fe<L, V> fe_load(const uint32_t* p) {
+  Fe<L, V> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.v[i] = p[i];
+  return r;
+}
+VRF_HD FeN fe_const(const uint32_t (&c)[NL]) {
+  FeN r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.v[i] = c[i];
+  return r;
+}
+template <int L, int V>
+VRF_HD void fe_store(uint32_t* p, const Fe<L, V>& a) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) p[i] = a.v[i];
+}
+
+VRF_HD FeN fe_zero() {
+  FeN r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.v[i] = 0;
+  return r;
+}
+VRF_HD FeN fe_one() { return fe_const(vrfk::ONE_M); }
+
+// ------------------------------------------------------------------ lazy add / sub
+template <int L1, int V1, int L2, int V2>
+VRF_HD Fe<L1 + L2, V1 + V2> fe_add(const Fe<L1, V1>& a, const Fe<L2, V2>& b) {
+  Fe<L1 + L2, V1 + V2> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.v[i] = a.v[i] + b.v[i];
+  return r;
+}
+
+template <int K, int LB>
+struct Bias;
+#define VRF_BIAS(K_, LB_)                                            \
+  template <>                                                        \
+  struct Bias<K_, LB_> {                                             \
+    static VRF_HD uint32_t at(int i) { return vrfk::BIAS_L##LB_##_K##K_[i]; } \
+  };
+VRF_BIAS(4, 1) VRF_BIAS(8, 1) VRF_BIAS(16, 1) VRF_BIAS(32, 1) VRF_BIAS(64, 1)
+VRF_BIAS(4, 2) VRF_BIAS(8, 2) VRF_BIAS(16, 2) VRF_BIAS(32, 2) VRF_BIAS(64, 2)
+#undef VRF_BIAS
+
+constexpr int bias_k(int v) { return v < 4 ? 4 : v < 8 ? 8 : v < 16 ? 16 : v < 32 ? 32 : 64; }
+
+// a - b (mod q) computed as a + K*q - b limb-wise.  The bias word has limbs >= LB*(2^29+2^13)
+// and a top limb >= V2*q / 2^232, so no limb ever borrows.
+template <int L1, int V1, int L2, int V2>
+VRF_HD Fe<L1 + L2 + 1, V1 + bias_k(V2)> fe_sub(const Fe<L1, V1>& a, const Fe<L2, V2>& b) {
+  static_assert(L2 <= 2, "subtrahend must have L <= 2 (normalise first)");
+  constexpr int K = bias_k(V2);   // K >= V2 + 1
+  Fe<L1 + L2 + 1, V1 + K> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.v[i] = a.v[i] + (Bias<K, L2>::at(i) - b.v[i]);
+  return r;
+}
+
+template <int L, int V>
+VRF_HD Fe<L + 1, bias_k(V)> fe_neg(const Fe<L, V>& b) {
+  static_assert(L <= 2, "fe_neg operand must have L <= 2");
+  constexpr int K = bias_k(V);
+  Fe<L + 1, K> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.v[i] = Bias<K, L>::at(i) - b.v[i];
+  return r;
+}
+
+// small multiples (shift-adds, one v_lshl_add_u32 per limb)
+template <int L, int V>
+VRF_HD Fe<2 * L, 2 * V> fe_dbl(const Fe<L, V>& a) {
+  Fe<2 * L, 2 * V> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.v[i] = a.v[i] << 1;
+  return r;
+}
+template <int L, int V>
+VRF_HD Fe<5 * L, 5 * V> fe_mul5(const Fe<L, V>& a) {
+  Fe<5 * L, 5 * V> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.v[i] = (a.v[i] << 2) + a.v[i];
+  return r;
+}
+
+// weak normalisation: one parallel carry pass; limbs < 2^29 + 8 afterwards (L = 1).
+template <int L, int V>
+VRF_HD Fe<1, V> fe_norm(const Fe<L, V>& a) {
+  Fe<1, V> r;
+  r.v[0] = a.v[0] & LMASK;
+#pragma unroll
+  for (int i = 1; i < NL - 1; ++i) r.v[i] = (a.v[i] & LMASK) + (a.v[i - 1] >> LW);
+  r.v[NL - 1] = a.v[NL - 1] + (a.v[NL - 2] >> LW);
+  return r;
+}
+
+template <int L, int V>
+VRF_HD Fe<L, V> fe_select(bool c, const Fe<L, V>& a, const Fe<L, V>& b) {   // c ? a : b
+  Fe<L, V> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+
+// ------------------------------------------------------------------ Montgomery multiply
+VRF_HD uint64_t mad(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+
+template <int L1, int V1, int L2, int V2>
+VRF_HD Fe<1, mul_v(V1, V2)> fe_mul(const Fe<L1, V1>& a, const Fe<L2, V2>& b) {
+  static_assert(L1 * L2 <= 6, "fe_mul: 64-bit column accumulator could overflow");
+  Fe<1, mul_v(V1, V2)> r;
+  uint32_t m[NL];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc = mad(a.v[i], b.v[k - i], acc);
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc = mad(m[i], vrfk::Q29[k - i], acc);
+    m[k] = (0u - (uint32_t)acc) & LMASK;
+    acc += m[k];                       // m[k] * Q29[0], Q29[0] == 1
+    acc >>= LW;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc = mad(a.v[i], b.v[k - i], acc);
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc = mad(m[i], vrfk::Q29[k - i], acc);
+    r.v[k - NL] = (uint32_t)acc & LMASK;
+    acc >>= LW;
+  }
+  r.v[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+template <int L, int V>
+VRF_HD Fe<1, mul_v(V, V)> fe_sqr(const Fe<L, V>& a) {
+  static_assert(L * L <= 6, "fe_sqr: 64-bit column accumulator could overflow");
+  Fe<1, mul_v(V, V)> r;
+  uint32_t m[NL], a2[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) a2[i] = a.v[i] << 1;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+#pragma unroll
+    for (int i = 0; 2 * i < k; ++i) acc = mad(a2[i], a.v[k - i], acc);
+    if ((k & 1) == 0) acc = mad(a.v[k / 2], a.v[k / 2], acc);
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc = mad(m[i], vrfk::Q29[k - i], acc);
+    m[k] = (0u - (uint32_t)acc) & LMASK;
+    acc += m[k];
+    acc >>= LW;
+  }
+#pragma unroll
+  for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+    for (int i = k - NL + 1; 2 * i < k; ++i) acc = mad(a2[i], a.v[k - i], acc);
+    if ((k & 1) == 0) acc = mad(a.v[k / 2], a.v[k / 2], acc);
+#pragma unroll
+    for (int i = k - NL + 1; i < NL; ++i) acc = mad(m[i], vrfk::Q29[k - i], acc);
+    r.v[k - NL] = (uint32_t)acc & LMASK;
+    acc >>= LW;
+  }
+  r.v[NL - 1] = (uint32_t)acc;
+  return r;
+}
+
+// ------------------------------------------------------------------ canonical forms
+// Exact carry propagation + one conditional subtraction of q.  Input value must be < 2q.
+template <int L>
+VRF_HD void fe_reduce_once(uint32_t out[NL], const Fe<L, 2>& a) {
+  uint32_t x[NL], d[NL];
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL - 1; ++i) {
+    uint32_t t = a.v[i] + c;
+    x[i] = t & LMASK;
+    c = t >> LW;
+  }
+  x[NL - 1] = a.v[NL - 1] + c;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    uint32_t t = x[i] - vrfk::Q29[i] - borrow;
+    borrow = t >> 31;
+    d[i] = (i < NL - 1) ? (t & LMASK) : t;
+  }
+#pragma unroll
+  for (int i = 0; i < NL; ++i) out[i] = borrow ? x[i] : d[i];
+}
+
+// canonical Montgomery image: the unique representative in [0, q) of the same residue.
+template <int L, int V>
+VRF_HD FeN fe_canon(const Fe<L, V>& a) {
+  static_assert(L <= 6, "");
+  FeN t = fe_mul(a, fe_one());     // a * R / R = a, value < q(1 + V*0.0142) < 2q
+  FeN r;
+  fe_reduce_once(r.v, t);
+  return r;
+}
+
+template <int L, int V>
+VRF_HD bool fe_is_zero(const Fe<L, V>& a) {
+  FeN c = fe_canon(a);
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) o |= c.v[i];
+  return o == 0;
+}
+
+template <int L1, int V1, int L2, int V2>
+VRF_HD bool fe_eq(const Fe<L1, V1>& a, const Fe<L2, V2>& b) {
+  FeN x = fe_canon(a), y = fe_canon(b);
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) o |= x.v[i] ^ y.v[i];
+  return o == 0;
+}
+
+// 8 x u32 little-endian integer (< 2^256) -> 9 x 29 plain limbs
+VRF_HD void u256_to_limbs(uint32_t out[NL], const uint32_t w[8]) {
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int bit = i * LW, j = bit >> 5, s = bit & 31;
+    uint32_t lo = w[j] >> s;
+    if (s > 3 && j + 1 < 8) lo |= w[j + 1] << (32 - s);
+    out[i] = (i < NL - 1) ? (lo & LMASK) : lo;
+  }
+}
+// 9 x 29 exact limbs (value < 2^256) -> 8 x u32
+VRF_HD void limbs_to_u256(uint32_t w[8], const uint32_t x[NL]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int bit = j * 32, i = bit / LW, s = bit % LW;
+    uint32_t v = x[i] >> s;
+    if (i + 1 < NL) v |= x[i + 1] << (LW - s);
+    if (LW - s + LW < 32 && i + 2 < NL) v |= x[i + 2] << (2 * LW - s);
+    w[j] = v;
+  }
+}
+
+// integer < 2^256 (need not be < q) -> Montgomery
+VRF_HD FeN fe_from_u256(const uint32_t w[8]) {
+  Fe<1, 3> t;                         // 2^256 < 2.21 q
+  u256_to_limbs(t.v, w);
+  return fe_mul(t, fe_const(vrfk::R2_29));
+}
+// Montgomery -> canonical integer in [0, q) as 8 x u32
+template <int L, int V>
+VRF_HD void fe_to_u256(uint32_t w[8], const Fe<L, V>& a) {
+  static_assert(L <= 6, "");
+  FeN one;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) one.v[i] = (i == 0);
+  FeN t = fe_mul(a, one);             // a / R, value < q + tiny
+  uint32_t c[NL];
+  fe_reduce_once(c, t);
+  limbs_to_u256(w, c);
+}
+
+// 512-bit integer (16 x u32 LE) mod q -> Montgomery (hash_to_field, 48-byte inputs fit)
+VRF_HD Fe<1, 4> fe_from_u512(const uint32_t w[16]) {
+  Fe<1, 3> lo, hi;
+  u256_to_limbs(lo.v, w);
+  u256_to_limbs(hi.v, w + 8);
+  FeN a = fe_mul(lo, fe_const(vrfk::R2_29));
+  FeN b = fe_mul(hi, fe_const(vrfk::TWO256_R2));
+  return fe_norm(fe_add(a, b));
+}
+
+// ------------------------------------------------------------------ fixed exponentiation
+// x^e for a compile-time exponent (little-endian u32 words).  The exponent is uniform across
+// the wave, so the 3-bit window loop is scalar control flow: no divergence.
+template <int NBITS>
+VRF_HD FeN fe_pow_const(const FeN& x, const uint32_t (&e)[8]) {
+  FeN t[8];
+  t[1] = x;
+  t[2] = fe_sqr(x);
+#pragma unroll
+  for (int i = 3; i < 8; ++i) t[i] = fe_mul(t[i - 1], x);
+  constexpr int NW = (NBITS + 2) / 3;
+  FeN acc = fe_one();
+  bool started = false;
+  for (int w = NW - 1; w >= 0; --w) {
+    const int bit = 3 * w;
+    uint32_t d = (e[bit >> 5] >> (bit & 31));
+    if ((bit & 31) > 29 && (bit >> 5) + 1 < 8) d |= e[(bit >> 5) + 1] << (32 - (bit & 31));
+    d &= 7;
+    if (started) {
+      acc = fe_sqr(acc);
+      acc = fe_sqr(acc);
+      acc = fe_sqr(acc);
+    }
+    if (d != 0) {
+      FeN s = t[1];
+#pragma unroll
+      for (int j = 2; j < 8; ++j)
+        if (d == (uint32_t)j) s = t[j];
+      acc = started ? fe_mul(acc, s) : s;
+      started = true;
+    }
+  }
+  return acc;
+}
+
+template <int L, int V>
+VRF_HD FeN fe_inv(const Fe<L, V>& a) {   // a^(q-2); 0 -> 0
+  FeN x = fe_mul(a, fe_one());
+  return fe_pow_const<255>(x, vrfk::EXP_INV);
+}
+
+// ------------------------------------------------------------------ square root
+// Table-driven Tonelli-Shanks for 2-adicity 32.  tbl = SQRT_P (4 x 256 x 9 words, h^(j 2^(8k))),
+// lut = SQRT_LUT.  Returns is_square(w) and sets `root` to sqrt(w) if w is a square, else to
+// sqrt(Z*w) (Z = 5, the suite's Elligator non-residue).  Constant shape: 222 + 24 squarings.
+struct SqrtTables {
+  const uint32_t* P;     // [4][256][9]
+  const uint8_t* lut;    // [1 << SQRT_LUT_BITS]
+};
+
+VRF_HD uint32_t sqrt_lut_index(const SqrtTables& T, const FeN& y) {
+  FeN c = fe_canon(y);
+  uint32_t h = (c.v[0] * vrfk::SQRT_LUT_MULT) >> (32 - vrfk::SQRT_LUT_BITS);
+  return T.lut[h];
+}
+VRF_HD FeN sqrt_tbl(const SqrtTables& T, int k, uint32_t j) {
+  return fe_load<1, 2>(T.P + ((size_t)k * 256 + j) * NL);
+}
+
+template <int L, int V>
+VRF_HD bool fe_sqrt_or_zsqrt(FeN& root, const Fe<L, V>& w_in, const SqrtTables& T) {
+  FeN w = fe_mul(w_in, fe_one());
+  FeN v = fe_pow_const<222>(w, vrfk::EXP_SQRT);     // w^((t-1)/2)
+  FeN x0 = fe_mul(w, v);                            // w^((t+1)/2)
+  FeN b = fe_mul(x0, v);                            // w^t, in the 2^32-torsion
+  FeN b8 = b;
+  for (int i = 0; i < 8; ++i) b8 = fe_sqr(b8);
+  FeN b16 = b8;
+  for (int i = 0; i < 8; ++i) b16 = fe_sqr(b16);
+  FeN b24 = b16;
+  for (int i = 0; i < 8; ++i) b24 = fe_sqr(b24);
+  // b = g^e, e = e0 + e1 2^8 + e2 2^16 + e3 2^24
+  uint32_t e0 = sqrt_lut_index(T, b24);
+  uint32_t e1 = sqrt_lut_index(T, fe_mul(b16, sqrt_tbl(T, 2, e0)));
+  uint32_t e2 = sqrt_lut_index(T, fe_mul(fe_mul(b8, sqrt_tbl(T, 1, e0)), sqrt_tbl(T, 2, e1)));
+  uint32_t e3 = sqrt_lut_index(
+      T, fe_mul(fe_mul(fe_mul(b, sqrt_tbl(T, 0, e0)), sqrt_tbl(T, 1, e1)), sqrt_tbl(T, 2, e2)));
+  uint32_t e = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+  bool odd = e & 1;
+  uint32_t half = (e >> 1) + (e & 1);               // in [0, 2^31]
+  FeN r = fe_mul(x0, sqrt_tbl(T, 0, half & 255));
+  r = fe_mul(r, sqrt_tbl(T, 1, (half >> 8) & 255));
+  r = fe_mul(r, sqrt_tbl(T, 2, (half >> 16) & 255));
+  r = fe_mul(r, sqrt_tbl(T, 3, half >> 24));
+  FeN rz = fe_mul(r, fe_const(vrfk::SQRT_CZ_M));
+  root = fe_select(odd, rz, r);
+  return !odd;    // w == 0: b = 0, lut garbage, but x0 = 0 => root = 0; caller treats 0 as square
+}
+
+}  // namespace vrf

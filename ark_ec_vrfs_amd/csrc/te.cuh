@@ -1,0 +1,200 @@
+// te.cuh -- twisted Edwards group law a*x^2 + y^2 = 1 + d*x^2*y^2 in extended coordinates.
+//
+// Replaces ark_ec::twisted_edwards::{Affine, Projective} add / double / mul_bigint behind
+// `AffinePoint` (/root/reference src/lib.rs:15) for the two suites on the hot path:
+// Bandersnatch (a = -5) and JubJub (a = -1).  Formulas: add-2008-hwcd (unified) and
+// dbl-2008-hwcd, rewritten so that a = -ANEG never needs a negation.  Every intermediate
+// carries its (L, V) bound (fe.cuh); the closure bound for point coordinates is FeP = Fe<1,5>.
+//
+// Exceptional cases: a is a non-square for both curves, so the unified law is complete on the
+// prime-order subgroup (and on the identity); inputs are required to lie in it, exactly as the
+// reference's `AffinePoint` values do after arkworks' checked deserialisation.
+#pragma once
+#include "fe.cuh"
+
+namespace vrf {
+
+struct CurveBS {   // Bandersnatch
+  static constexpr int ANEG = 5;
+  static constexpr int COFACTOR_LOG2 = 2;
+  static VRF_HD FeN d() { return fe_const(vrfk::BS_D_M); }
+  static VRF_HD FeN aneg_m() { return fe_const(vrfk::FIVE_M); }
+  static VRF_HD FeN gx() { return fe_const(vrfk::BS_GX_M); }
+  static VRF_HD FeN gy() { return fe_const(vrfk::BS_GY_M); }
+  static VRF_HD FeN bx() { return fe_const(vrfk::BS_BX_M); }
+  static VRF_HD FeN by() { return fe_const(vrfk::BS_BY_M); }
+  template <int L, int V>
+  static VRF_HD Fe<5 * L, 5 * V> mul_aneg(const Fe<L, V>& a) { return fe_mul5(a); }
+  static VRF_HD uint32_t r32(int i) { return vrfk::BS_R32[i]; }
+  static VRF_HD uint32_t r_r1(int i) { return vrfk::BS_R_R1[i]; }
+  static VRF_HD uint32_t r_r2(int i) { return vrfk::BS_R_R2[i]; }
+  static constexpr uint32_t R_NINV32 = vrfk::BS_R_NINV32;
+};
+
+struct PtE {   // extended projective: x = X/Z, y = Y/Z, T = X*Y/Z
+  FeP X, Y, Z, T;
+};
+struct PtC {   // cached table entry: (X, Y, Z, d*T)
+  FeP X, Y, Z;
+  FeN dT;
+};
+constexpr int PTC_WORDS = 4 * NL;   // 36 words = 144 bytes
+
+VRF_HD PtE te_identity() {
+  PtE r;
+  r.X = fe_zero(); r.Y = fe_one(); r.Z = fe_one(); r.T = fe_zero();
+  return r;
+}
+VRF_HD PtC te_identity_cached() {
+  PtC r;
+  r.X = fe_zero(); r.Y = fe_one(); r.Z = fe_one(); r.dT = fe_zero();
+  return r;
+}
+VRF_HD PtE te_from_affine(const FeP& x, const FeP& y) {
+  PtE r;
+  r.X = x; r.Y = y; r.Z = fe_one(); r.T = fe_mul(x, y);
+  return r;
+}
+
+template <class C>
+VRF_HD PtC te_to_cached(const PtE& p) {
+  PtC r;
+  r.X = p.X; r.Y = p.Y; r.Z = p.Z;
+  r.dT = fe_mul(p.T, C::d());
+  return r;
+}
+VRF_HD void ptc_store(uint32_t* m, const PtC& c) {
+  fe_store(m, c.X); fe_store(m + NL, c.Y); fe_store(m + 2 * NL, c.Z); fe_store(m + 3 * NL, c.dT);
+}
+VRF_HD PtC ptc_load(const uint32_t* m) {
+  PtC c;
+  c.X = fe_load<1, 5>(m); c.Y = fe_load<1, 5>(m + NL); c.Z = fe_load<1, 5>(m + 2 * NL);
+  c.dT = fe_load<1, 2>(m + 3 * NL);
+  return c;
+}
+
+// 2P.  NEED_T = false skips the T coordinate (legal when the next operation is a doubling).
+template <class C, bool NEED_T>
+VRF_HD PtE te_dbl(const PtE& p) {
+  auto A = fe_sqr(p.X);                               // (1,2)
+  auto B = fe_sqr(p.Y);                               // (1,2)
+  auto S = fe_sqr(fe_add(p.X, p.Y));                  // (1,3)
+  auto ZZ = fe_sqr(p.Z);                              // (1,2)
+  auto E = fe_norm(fe_sub(fe_add(A, B), S));          // A + B - S            (1,8)
+  auto aA = C::mul_aneg(A);                           // -a*A
+  auto H = fe_add(aA, B);                             // -a*A + B             (<=6,12)
+  auto G = fe_norm(fe_sub(aA, B));                    // -a*A - B             (1,14)
+  auto F = fe_add(G, fe_dbl(ZZ));                     // G + 2Z^2             (3,18)
+  PtE r;
+  r.X = fe_mul(E, F);
+  r.Y = fe_mul(G, H);
+  r.Z = fe_mul(F, G);
+  if (NEED_T) r.T = fe_mul(E, H); else r.T = fe_zero();
+  return r;
+}
+
+// conditional negation of a storage-type element; result type covers both branches
+template <int L, int V>
+VRF_HD Fe<L + 1, (V > bias_k(V) ? V : bias_k(V))> fe_cneg(bool neg, const Fe<L, V>& a) {
+  using R = Fe<L + 1, (V > bias_k(V) ? V : bias_k(V))>;
+  R n = fe_neg(a);
+  R p = a;
+  return fe_select(neg, n, p);
+}
+
+// P + (+/-)Q with Q a cached entry (projective).  Unified: also correct for P == Q and for
+// either operand being the identity.
+template <class C>
+VRF_HD PtE te_add_cached(const PtE& p, const PtC& q, bool neg) {
+  auto X2 = fe_cneg(neg, q.X);                        // (2,8)
+  auto dT2 = fe_cneg(neg, q.dT);                      // (2,4)
+  auto A = fe_mul(p.X, X2);                           // (1,2)
+  auto B = fe_mul(p.Y, q.Y);                          // (1,2)
+  auto Cc = fe_mul(p.T, dT2);                         // (1,2)
+  auto D = fe_mul(p.Z, q.Z);                          // (1,2)
+  auto S = fe_mul(fe_add(p.X, p.Y), fe_add(X2, q.Y)); // (2,10)x(3,13) -> (1,3)
+  auto E = fe_norm(fe_sub(S, fe_add(A, B)));          // (1,11)
+  auto F = fe_sub(D, Cc);                             // (3,6)
+  auto G = fe_add(D, Cc);                             // (2,4)
+  auto H = fe_norm(fe_add(B, C::mul_aneg(A)));        // B - a*A              (1,12)
+  PtE r;
+  r.X = fe_mul(E, F);
+  r.Y = fe_mul(G, H);
+  r.Z = fe_mul(F, G);
+  r.T = fe_mul(E, H);
+  return r;
+}
+
+// P + (+/-)Q with Q affine: (x, y, d*x*y), Z2 = 1.
+struct PtA {
+  FeN x, y, dt;
+};
+constexpr int PTA_WORDS = 3 * NL;   // 27 words = 108 bytes
+VRF_HD PtA pta_load(const uint32_t* m) {
+  PtA a;
+  a.x = fe_load<1, 2>(m); a.y = fe_load<1, 2>(m + NL); a.dt = fe_load<1, 2>(m + 2 * NL);
+  return a;
+}
+VRF_HD void pta_store(uint32_t* m, const PtA& a) {
+  fe_store(m, a.x); fe_store(m + NL, a.y); fe_store(m + 2 * NL, a.dt);
+}
+VRF_HD PtA pta_identity() {
+  PtA a;
+  a.x = fe_zero(); a.y = fe_one(); a.dt = fe_zero();
+  return a;
+}
+
+template <class C>
+VRF_HD PtE te_add_affine(const PtE& p, const PtA& q, bool neg) {
+  auto X2 = fe_cneg(neg, q.x);                        // (2,4)
+  auto dT2 = fe_cneg(neg, q.dt);                      // (2,4)
+  auto A = fe_mul(p.X, X2);
+  auto B = fe_mul(p.Y, q.y);
+  auto Cc = fe_mul(p.T, dT2);
+  auto S = fe_mul(fe_add(p.X, p.Y), fe_add(X2, q.y));
+  auto E = fe_norm(fe_sub(S, fe_add(A, B)));
+  auto F = fe_sub(p.Z, Cc);                           // (3,9)
+  auto G = fe_add(p.Z, Cc);                           // (2,7)
+  auto H = fe_norm(fe_add(B, C::mul_aneg(A)));
+  PtE r;
+  r.X = fe_mul(E, F);
+  r.Y = fe_mul(G, H);
+  r.Z = fe_mul(F, G);
+  r.T = fe_mul(E, H);
+  return r;
+}
+
+// general extended + extended (used off the hot loop: table building, h2c)
+template <class C>
+VRF_HD PtE te_add(const PtE& p, const PtE& q) {
+  return te_add_cached<C>(p, te_to_cached<C>(q), false);
+}
+
+// -------------------------------------------------------------------------------- codec
+// ArkworksCodec: y little-endian, bit 255 = (x > q - x).
+VRF_HD bool u256_gt(const uint32_t a[8], const uint32_t (&b)[8]) {   // a > b
+  bool gt = false, decided = false;
+#pragma unroll
+  for (int i = 7; i >= 0; --i) {
+    if (!decided && a[i] != b[i]) { gt = a[i] > b[i]; decided = true; }
+  }
+  return gt;
+}
+VRF_HD bool u256_ge(const uint32_t a[8], const uint32_t (&b)[8]) {   // a >= b
+  bool gt = true, decided = false;
+#pragma unroll
+  for (int i = 7; i >= 0; --i) {
+    if (!decided && a[i] != b[i]) { gt = a[i] > b[i]; decided = true; }
+  }
+  return gt;
+}
+
+// affine (Montgomery) -> 32-byte compressed encoding as 8 LE u32 words
+VRF_HD void te_encode_affine(uint32_t out[8], const FeN& x, const FeN& y) {
+  uint32_t xw[8];
+  fe_to_u256(xw, x);
+  fe_to_u256(out, y);
+  if (u256_gt(xw, vrfk::QM1H32)) out[7] |= 0x80000000u;
+}
+
+}  // namespace vrf
