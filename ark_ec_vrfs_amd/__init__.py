@@ -1,0 +1,11 @@
+"""ark_ec_vrfs_amd -- MI355X-native batch EC-VRF prove/verify behind the ark-ec-vrfs API.
+
+Host-side mirror (Python) of the Rust surface re-exported at /root/reference src/lib.rs:13-17
+(`Suite`, `Secret`, `Public`, `Input`, `Output`, `ietf::{Prover, Verifier, Proof}`, `Error`)
+over the C ABI of ``csrc/libvrfhip.so``.  All arithmetic runs in hand-written HIP kernels.
+"""
+from .api import (  # noqa: F401
+    BandersnatchSha512Ell2, Context, Error, IetfProof, Input, Output, Public, Secret, Suite,
+    VerificationFailure, InvalidData, ietf, default_context,
+)
+from ._lib import VrfHipError, LIB_PATH  # noqa: F401

@@ -1,0 +1,91 @@
+"""ctypes binding of libvrfhip.so (include/vrfhip.h).
+
+There is no CPU path: if the HIP library cannot be loaded, or no MI355X is visible, every
+entry point raises.  The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C ark_ec_vrfs_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_int32, c_size_t, c_uint8, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvrfhip.so")
+
+# Every symbol include/vrfhip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "vrfhip_abi_version", "vrfhip_last_error", "vrfhip_ctx_create", "vrfhip_ctx_destroy",
+    "vrfhip_ctx_reserve", "vrfhip_ctx_workspace_bytes",
+    "vrfhip_ietf_verify_batch", "vrfhip_ietf_verify_batch_dev",
+    "vrfhip_ietf_prove_batch", "vrfhip_ietf_prove_batch_dev",
+    "vrfhip_hash_to_curve_batch", "vrfhip_hash_to_curve_batch_dev",
+    "vrfhip_output_hash_batch", "vrfhip_output_hash_batch_dev",
+    "vrfhip_secret_from_seed_batch", "vrfhip_secret_from_seed_batch_dev",
+    "vrfhip_point_validate_batch", "vrfhip_point_validate_batch_dev",
+    "vrfhip_fq_mul_batch",
+]
+
+
+class VrfHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libvrfhip.so (once).  torch is imported first when present so that the library
+    binds to the HIP runtime already in the process (same SONAME libamdhip64.so.7) and device
+    pointers of torch tensors are valid in our launches."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VrfHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 first)
+    except Exception:
+        pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    u8p, u32p = POINTER(c_uint8), POINTER(c_uint32)
+    lib.vrfhip_abi_version.restype = c_int32
+    lib.vrfhip_last_error.restype = c_char_p
+    lib.vrfhip_ctx_create.argtypes = [c_int32, c_int32, POINTER(c_void_p)]
+    lib.vrfhip_ctx_create.restype = c_int32
+    lib.vrfhip_ctx_destroy.argtypes = [c_void_p]
+    lib.vrfhip_ctx_destroy.restype = None
+    lib.vrfhip_ctx_reserve.argtypes = [c_void_p, c_size_t]
+    lib.vrfhip_ctx_reserve.restype = c_int32
+    lib.vrfhip_ctx_workspace_bytes.argtypes = [c_void_p]
+    lib.vrfhip_ctx_workspace_bytes.restype = c_size_t
+    P = c_void_p  # raw addresses (host buffers or device pointers)
+    lib.vrfhip_ietf_verify_batch.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P]
+    lib.vrfhip_ietf_verify_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P, c_void_p]
+    lib.vrfhip_ietf_prove_batch.argtypes = [c_void_p, c_size_t, P, P, P, c_uint32, P, P, P, c_uint32,
+                                            P, P, P, P, P, P]
+    lib.vrfhip_ietf_prove_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, c_uint32, P, P, P, c_uint32,
+                                                P, P, P, P, P, P, c_void_p]
+    lib.vrfhip_hash_to_curve_batch.argtypes = [c_void_p, c_size_t, P, P, c_uint32, P]
+    lib.vrfhip_hash_to_curve_batch_dev.argtypes = [c_void_p, c_size_t, P, P, c_uint32, P, c_void_p]
+    lib.vrfhip_output_hash_batch.argtypes = [c_void_p, c_size_t, P, P]
+    lib.vrfhip_output_hash_batch_dev.argtypes = [c_void_p, c_size_t, P, P, c_void_p]
+    lib.vrfhip_secret_from_seed_batch.argtypes = [c_void_p, c_size_t, P, c_uint32, P, P]
+    lib.vrfhip_secret_from_seed_batch_dev.argtypes = [c_void_p, c_size_t, P, c_uint32, P, P, c_void_p]
+    lib.vrfhip_point_validate_batch.argtypes = [c_void_p, c_size_t, P, P, P]
+    lib.vrfhip_point_validate_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, c_void_p]
+    lib.vrfhip_fq_mul_batch.argtypes = [c_void_p, c_size_t, P, P, P]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("vrfhip_last_error", "vrfhip_ctx_destroy", "vrfhip_ctx_workspace_bytes"):
+            fn.restype = c_int32
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().vrfhip_last_error().decode("utf-8", "replace")
+        raise VrfHipError(f"{what} failed with {rc}: {msg}")

@@ -1,0 +1,324 @@
+"""Python mirror of the ark-ec-vrfs / ark-vrf API for the IETF VRF hot path.
+
+Rust name (src/lib.rs:13-17)            here
+--------------------------------------  -------------------------------------------------
+Suite (suites::bandersnatch)            BandersnatchSha512Ell2 (class attribute constants)
+Secret::from_seed / from_scalar/public  Secret.from_seed / Secret.from_scalar / .public()
+Input::new(data) -> Option<Input>       Input.new(data)
+Secret::output(input)                   Secret.output(input)
+Output::hash()                          Output.hash()
+ietf::Prover::prove(&sk, in, out, ad)   ietf.Prover.prove(secret, input, output, ad)
+ietf::Verifier::verify(&pk, ...)        ietf.Verifier.verify(public, input, output, ad, proof)
+Error::{VerificationFailure,InvalidData} exceptions VerificationFailure / InvalidData
+(batch forms, no Rust counterpart)      Context.ietf_prove_batch / ietf_verify_batch / ...
+
+Single-item methods are batches of one; the batch methods are the product.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+ST_OK, ST_VERIFICATION_FAILURE, ST_INVALID_DATA = 0, 1, 2
+
+
+class Error(Exception):
+    """`Error` (src/lib.rs:15)."""
+
+
+class VerificationFailure(Error):
+    pass
+
+
+class InvalidData(Error):
+    pass
+
+
+class Suite:
+    """`Suite` (src/lib.rs:16): compile-time constants of a cipher suite."""
+    SUITE_ID: bytes = b""
+    CHALLENGE_LEN: int = 32
+    SUITE_ENUM: int = 0
+
+
+class BandersnatchSha512Ell2(Suite):
+    SUITE_ID = b"Bandersnatch_SHA-512_ELL2"
+    CHALLENGE_LEN = 32
+    SUITE_ENUM = 1
+
+
+def _np_u8(b, n_bytes: Optional[int] = None) -> np.ndarray:
+    a = np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else b
+    a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+    if n_bytes is not None and a.size != n_bytes:
+        raise ValueError(f"expected {n_bytes} bytes, got {a.size}")
+    return a
+
+
+def _ptr(a: Optional[np.ndarray]) -> Optional[int]:
+    return None if a is None else a.ctypes.data
+
+
+def _pack_var(items: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
+    off = np.zeros(len(items) + 1, dtype=np.uint32)
+    off[1:] = np.cumsum([len(x) for x in items], dtype=np.uint64).astype(np.uint32)
+    blob = np.frombuffer(b"".join(items) + b"\x00", dtype=np.uint8).copy()
+    return blob, off
+
+
+class Context:
+    """One GPU + one suite: owns the device tables and HBM workspace (vrfhip_ctx)."""
+
+    def __init__(self, device: int = 0, suite: type = BandersnatchSha512Ell2):
+        self._lib = _lib.load()
+        self.suite = suite
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.vrfhip_ctx_create(suite.SUITE_ENUM, device, ctypes.byref(h)), "vrfhip_ctx_create")
+        self._h = h
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.vrfhip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self) -> ctypes.c_void_p:
+        return self._h
+
+    def reserve(self, max_items: int) -> None:
+        _lib.check(self._lib.vrfhip_ctx_reserve(self._h, max_items), "vrfhip_ctx_reserve")
+
+    def workspace_bytes(self) -> int:
+        return int(self._lib.vrfhip_ctx_workspace_bytes(self._h))
+
+    # ---- host-buffer batch API (numpy uint8 arrays of shape (n, 32)) -------------------
+    @staticmethod
+    def _ad_args(ad, n):
+        """ad: bytes (shared) or a sequence of n byte strings (per item)."""
+        if ad is None:
+            ad = b""
+        if isinstance(ad, (bytes, bytearray, memoryview)):
+            blob = np.frombuffer(bytes(ad) + b"\x00", dtype=np.uint8).copy()
+            return blob, None, len(ad)
+        if len(ad) != n:
+            raise ValueError("per-item ad must have n entries")
+        blob, off = _pack_var([bytes(x) for x in ad])
+        return blob, off, 0
+
+    def ietf_verify_batch(self, pk, inp, out, c, s, ad=b"") -> np.ndarray:
+        pk, inp, out, c, s = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (pk, inp, out, c, s))
+        n = pk.shape[0]
+        if not all(x.shape[0] == n for x in (inp, out, c, s)):
+            raise ValueError("ragged batch")
+        status = np.empty(n, dtype=np.uint8)
+        blob, off, ad_len = self._ad_args(ad, n)
+        _lib.check(self._lib.vrfhip_ietf_verify_batch(
+            self._h, n, _ptr(pk), _ptr(inp), _ptr(out), _ptr(c), _ptr(s), _ptr(blob), _ptr(off), ad_len,
+            _ptr(status)), "vrfhip_ietf_verify_batch")
+        return status
+
+    def ietf_prove_batch(self, sk, msgs=None, inputs=None, ad=b""):
+        """Returns dict(output, c, s, pk, input, status).  Either `msgs` (sequence of byte strings
+        or an (n, L) uint8 array) or `inputs` (n x 32 pre-hashed points) must be given."""
+        sk = np.ascontiguousarray(sk, dtype=np.uint8).reshape(-1, 32)
+        n = sk.shape[0]
+        msg_blob = msg_off = inp = None
+        msg_len = 0
+        if inputs is not None:
+            inp = np.ascontiguousarray(inputs, dtype=np.uint8).reshape(-1, 32)
+            if inp.shape[0] != n:
+                raise ValueError("ragged batch")
+        elif isinstance(msgs, np.ndarray):
+            m = np.ascontiguousarray(msgs, dtype=np.uint8).reshape(n, -1)
+            msg_len = m.shape[1]
+            msg_blob = np.concatenate([m.reshape(-1), np.zeros(1, np.uint8)])
+        else:
+            if msgs is None or len(msgs) != n:
+                raise ValueError("msgs must have n entries")
+            msg_blob, msg_off = _pack_var([bytes(x) for x in msgs])
+        res = {k: np.empty((n, 32), dtype=np.uint8) for k in ("output", "c", "s", "pk", "input")}
+        status = np.empty(n, dtype=np.uint8)
+        blob, off, ad_len = self._ad_args(ad, n)
+        _lib.check(self._lib.vrfhip_ietf_prove_batch(
+            self._h, n, _ptr(sk), _ptr(msg_blob), _ptr(msg_off), msg_len, _ptr(inp), _ptr(blob), _ptr(off),
+            ad_len, _ptr(res["output"]), _ptr(res["c"]), _ptr(res["s"]), _ptr(res["pk"]), _ptr(res["input"]),
+            _ptr(status)), "vrfhip_ietf_prove_batch")
+        res["status"] = status
+        return res
+
+    def hash_to_curve_batch(self, msgs) -> np.ndarray:
+        if isinstance(msgs, np.ndarray):
+            m = np.ascontiguousarray(msgs, dtype=np.uint8)
+            n, msg_len = m.shape
+            blob, off = np.concatenate([m.reshape(-1), np.zeros(1, np.uint8)]), None
+        else:
+            n, msg_len = len(msgs), 0
+            blob, off = _pack_var([bytes(x) for x in msgs])
+        pts = np.empty((n, 32), dtype=np.uint8)
+        _lib.check(self._lib.vrfhip_hash_to_curve_batch(self._h, n, _ptr(blob), _ptr(off), msg_len, _ptr(pts)),
+                   "vrfhip_hash_to_curve_batch")
+        return pts
+
+    def output_hash_batch(self, outputs) -> np.ndarray:
+        o = np.ascontiguousarray(outputs, dtype=np.uint8).reshape(-1, 32)
+        h = np.empty((o.shape[0], 64), dtype=np.uint8)
+        _lib.check(self._lib.vrfhip_output_hash_batch(self._h, o.shape[0], _ptr(o), _ptr(h)),
+                   "vrfhip_output_hash_batch")
+        return h
+
+    def secret_from_seed_batch(self, seeds: np.ndarray, with_public: bool = True):
+        sd = np.ascontiguousarray(seeds, dtype=np.uint8)
+        n, seed_len = sd.shape
+        sk = np.empty((n, 32), dtype=np.uint8)
+        pk = np.empty((n, 32), dtype=np.uint8) if with_public else None
+        _lib.check(self._lib.vrfhip_secret_from_seed_batch(self._h, n, _ptr(sd), seed_len, _ptr(sk), _ptr(pk)),
+                   "vrfhip_secret_from_seed_batch")
+        return sk, pk
+
+    def point_validate_batch(self, points, want_xy: bool = False):
+        p = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, 32)
+        n = p.shape[0]
+        st = np.empty(n, dtype=np.uint8)
+        xy = np.empty((n, 64), dtype=np.uint8) if want_xy else None
+        _lib.check(self._lib.vrfhip_point_validate_batch(self._h, n, _ptr(p), _ptr(xy), _ptr(st)),
+                   "vrfhip_point_validate_batch")
+        return (st, xy) if want_xy else st
+
+    def fq_mul_batch(self, a, b) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, 32)
+        r = np.empty_like(a)
+        _lib.check(self._lib.vrfhip_fq_mul_batch(self._h, a.shape[0], _ptr(a), _ptr(b), _ptr(r)),
+                   "vrfhip_fq_mul_batch")
+        return r
+
+    # ---- device-pointer batch API (torch CUDA uint8 tensors, current stream) -----------
+    def ietf_verify_batch_dev(self, pk, inp, out, c, s, status, ad=None, ad_off=None, ad_len=0, stream=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        n = pk.shape[0]
+        _lib.check(self._lib.vrfhip_ietf_verify_batch_dev(
+            self._h, n, pk.data_ptr(), inp.data_ptr(), out.data_ptr(), c.data_ptr(), s.data_ptr(),
+            None if ad is None else ad.data_ptr(), None if ad_off is None else ad_off.data_ptr(), ad_len,
+            status.data_ptr(), st), "vrfhip_ietf_verify_batch_dev")
+
+    def ietf_prove_batch_dev(self, sk, msg, msg_len, out, c, s, pk_out=None, input_out=None, status=None,
+                             msg_off=None, inputs=None, ad=None, ad_off=None, ad_len=0, stream=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        n = sk.shape[0]
+        dp = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self._lib.vrfhip_ietf_prove_batch_dev(
+            self._h, n, sk.data_ptr(), dp(msg), dp(msg_off), msg_len, dp(inputs), dp(ad), dp(ad_off), ad_len,
+            out.data_ptr(), c.data_ptr(), s.data_ptr(), dp(pk_out), dp(input_out), dp(status), st),
+            "vrfhip_ietf_prove_batch_dev")
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# ---- single-item mirror of the Rust types --------------------------------------------------
+
+@dataclass(frozen=True)
+class Public:
+    """`Public` (src/lib.rs:15): a public key point, ArkworksCodec encoding."""
+    encoded: bytes
+
+
+@dataclass(frozen=True)
+class Input:
+    """`Input` (src/lib.rs:15): VRF input point."""
+    encoded: bytes
+
+    @staticmethod
+    def new(data: bytes, ctx: Optional[Context] = None) -> Optional["Input"]:
+        ctx = ctx or default_context()
+        return Input(bytes(ctx.hash_to_curve_batch([bytes(data)])[0]))
+
+
+@dataclass(frozen=True)
+class Output:
+    """`Output` (src/lib.rs:15): VRF output point (Gamma)."""
+    encoded: bytes
+
+    def hash(self, ctx: Optional[Context] = None) -> bytes:
+        ctx = ctx or default_context()
+        return bytes(ctx.output_hash_batch(np.frombuffer(self.encoded, dtype=np.uint8))[0])
+
+
+@dataclass(frozen=True)
+class IetfProof:
+    """`ietf::Proof { c, s }` (src/lib.rs:14)."""
+    c: bytes
+    s: bytes
+
+
+@dataclass(frozen=True)
+class Secret:
+    """`Secret` (src/lib.rs:16): secret scalar (32 B little-endian) with its cached public key."""
+    scalar: bytes
+    _public: bytes
+
+    @staticmethod
+    def from_seed(seed: bytes, ctx: Optional[Context] = None) -> "Secret":
+        ctx = ctx or default_context()
+        sk, pk = ctx.secret_from_seed_batch(np.frombuffer(bytes(seed), dtype=np.uint8).reshape(1, -1))
+        return Secret(bytes(sk[0]), bytes(pk[0]))
+
+    def public(self) -> Public:
+        return Public(self._public)
+
+    def output(self, inp: Input, ctx: Optional[Context] = None) -> Output:
+        ctx = ctx or default_context()
+        r = ctx.ietf_prove_batch(np.frombuffer(self.scalar, dtype=np.uint8), inputs=np.frombuffer(inp.encoded, dtype=np.uint8))
+        if r["status"][0] != ST_OK:
+            raise InvalidData()
+        return Output(bytes(r["output"][0]))
+
+
+class ietf:  # noqa: N801  (mirrors the Rust module name)
+    """`ietf` module (src/lib.rs:14)."""
+    Proof = IetfProof
+
+    class Prover:
+        @staticmethod
+        def prove(secret: Secret, inp: Input, out: Output, ad: bytes = b"", ctx: Optional[Context] = None) -> IetfProof:
+            ctx = ctx or default_context()
+            r = ctx.ietf_prove_batch(np.frombuffer(secret.scalar, dtype=np.uint8),
+                                     inputs=np.frombuffer(inp.encoded, dtype=np.uint8), ad=bytes(ad))
+            if r["status"][0] != ST_OK:
+                raise InvalidData()
+            return IetfProof(bytes(r["c"][0]), bytes(r["s"][0]))
+
+    class Verifier:
+        @staticmethod
+        def verify(public: Public, inp: Input, out: Output, ad: bytes, proof: IetfProof,
+                   ctx: Optional[Context] = None) -> None:
+            """Returns None on success (Rust `Ok(())`), raises `VerificationFailure` / `InvalidData`."""
+            ctx = ctx or default_context()
+            f = lambda b: np.frombuffer(b, dtype=np.uint8)
+            st = ctx.ietf_verify_batch(f(public.encoded), f(inp.encoded), f(out.encoded), f(proof.c), f(proof.s),
+                                       ad=bytes(ad))[0]
+            if st == ST_VERIFICATION_FAILURE:
+                raise VerificationFailure()
+            if st != ST_OK:
+                raise InvalidData()

@@ -1,0 +1,577 @@
+// api.hip -- the C ABI of libvrfhip (include/vrfhip.h): context, HBM workspace, launches.
+// Host code only orchestrates; every field / curve / hash operation runs in the HIP kernels.
+#include "../../include/vrfhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace vrf;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int32_t fail(int32_t code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e__ = (expr);                                                               \
+    if (e__ != hipSuccess)                                                                 \
+      return fail(e__ == hipErrorOutOfMemory ? VRFHIP_ERR_OOM : VRFHIP_ERR_HIP,            \
+                  std::string(#expr) + ": " + hipGetErrorString(e__));                     \
+  } while (0)
+
+constexpr size_t DEFAULT_CHUNK = size_t(1) << 20;
+
+}  // namespace
+
+struct vrfhip_ctx {
+  int device = 0;
+  vrfhip_suite suite = VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2;
+  hipStream_t stream = nullptr;      // used by the host-pointer entry points
+  std::recursive_mutex mu;
+  // shared tables
+  uint32_t* d_sqrt_p = nullptr;
+  uint8_t* d_sqrt_lut = nullptr;
+  uint32_t* d_g_win = nullptr;
+  uint32_t* d_g_comb = nullptr;
+  uint32_t* d_b_comb = nullptr;
+  DevTables T{};
+  // workspace
+  void* d_ws = nullptr;
+  size_t ws_cap = 0;                 // items
+  size_t ws_bytes = 0;
+  Workspace ws{};
+  // staging for the host-pointer entry points
+  void* d_stage = nullptr;
+  size_t stage_bytes = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+int32_t alloc_workspace(vrfhip_ctx* ctx, size_t cap) {
+  if (ctx->d_ws) {
+    HIP_TRY(hipFree(ctx->d_ws));
+    ctx->d_ws = nullptr;
+    ctx->ws_cap = 0;
+    ctx->ws_bytes = 0;
+  }
+  size_t tabs_b = cap * 3 * WIN_TABLE_WORDS * sizeof(uint32_t);
+  size_t pts_b = cap * PROVE_PTS_WORDS * sizeof(uint32_t);
+  size_t aux_b = cap * 16 * sizeof(uint32_t);
+  size_t flags_b = (cap + 255) & ~size_t(255);
+  size_t total = tabs_b + pts_b + aux_b + flags_b;
+  HIP_TRY(hipMalloc(&ctx->d_ws, total));
+  uint8_t* p = static_cast<uint8_t*>(ctx->d_ws);
+  ctx->ws.tabs = reinterpret_cast<uint32_t*>(p); p += tabs_b;
+  ctx->ws.pts = reinterpret_cast<uint32_t*>(p); p += pts_b;
+  ctx->ws.aux = reinterpret_cast<uint32_t*>(p); p += aux_b;
+  ctx->ws.flags = p;
+  ctx->ws_cap = cap;
+  ctx->ws_bytes = total;
+  return VRFHIP_SUCCESS;
+}
+
+// workspace for a batch of `items`: at most max(DEFAULT_CHUNK, reserved) items, larger batches
+// are processed in chunks of ws_cap
+int32_t ensure_workspace(vrfhip_ctx* ctx, size_t items) {
+  size_t want = std::min(items, std::max<size_t>(DEFAULT_CHUNK, ctx->ws_cap));
+  if (want <= ctx->ws_cap) return VRFHIP_SUCCESS;
+  return alloc_workspace(ctx, want);
+}
+
+int32_t ensure_stage(vrfhip_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->stage_bytes) return VRFHIP_SUCCESS;
+  if (ctx->d_stage) {
+    HIP_TRY(hipFree(ctx->d_stage));
+    ctx->d_stage = nullptr;
+    ctx->stage_bytes = 0;
+  }
+  HIP_TRY(hipMalloc(&ctx->d_stage, bytes));
+  ctx->stage_bytes = bytes;
+  return VRFHIP_SUCCESS;
+}
+
+// bump allocator over the staging buffer
+struct Stage {
+  uint8_t* base;
+  size_t off = 0;
+  explicit Stage(void* b) : base(static_cast<uint8_t*>(b)) {}
+  static size_t pad(size_t n) { return (n + 255) & ~size_t(255); }
+  uint8_t* take(size_t n) {
+    uint8_t* p = base + off;
+    off += pad(n);
+    return p;
+  }
+};
+
+BytesView make_view(const uint8_t* blob, const uint32_t* off, uint32_t len, bool shared) {
+  BytesView v;
+  v.blob = blob;
+  v.off = off;
+  v.len = len;
+  v.stride = shared ? 0u : len;
+  return v;
+}
+
+// size in bytes of a host-side variable-length blob
+size_t blob_bytes(size_t n, const uint32_t* off, uint32_t len, bool shared) {
+  if (off) return off[n];
+  return shared ? len : n * (size_t)len;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vrfhip_abi_version(void) { return 100; }
+
+const char* vrfhip_last_error(void) { return g_last_error.c_str(); }
+
+int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out) {
+  if (!out) return fail(VRFHIP_ERR_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  if (suite != VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2)
+    return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported suite");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(VRFHIP_ERR_NO_DEVICE, "no HIP device visible: libvrfhip has no CPU path");
+  if (device < 0 || device >= count) return fail(VRFHIP_ERR_BAD_ARG, "device index out of range");
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(VRFHIP_ERR_HIP, "hipSetDevice failed");
+  vrfhip_ctx* ctx = new vrfhip_ctx();
+  ctx->device = device;
+  ctx->suite = suite;
+  auto cleanup = [&](int32_t rc) {
+    vrfhip_ctx_destroy(ctx);
+    return rc;
+  };
+#define HIP_TRY_C(expr)                                                                   \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      return cleanup(fail(VRFHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__))); \
+  } while (0)
+  HIP_TRY_C(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  const size_t sqrt_p_bytes = sizeof(vrfk_tables::SQRT_P);
+  const size_t lut_bytes = sizeof(vrfk_tables::SQRT_LUT);
+  const size_t comb_bytes = (size_t)32 * 255 * PTA_WORDS * sizeof(uint32_t);
+  HIP_TRY_C(hipMalloc(&ctx->d_sqrt_p, sqrt_p_bytes));
+  HIP_TRY_C(hipMalloc(&ctx->d_sqrt_lut, lut_bytes));
+  HIP_TRY_C(hipMalloc(&ctx->d_g_win, WIN_TABLE_WORDS * sizeof(uint32_t)));
+  HIP_TRY_C(hipMalloc(&ctx->d_g_comb, comb_bytes));
+  HIP_TRY_C(hipMalloc(&ctx->d_b_comb, comb_bytes));
+  HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_p, vrfk_tables::SQRT_P, sqrt_p_bytes, hipMemcpyHostToDevice,
+                           ctx->stream));
+  HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_lut, vrfk_tables::SQRT_LUT, lut_bytes, hipMemcpyHostToDevice,
+                           ctx->stream));
+  launch_init_tables(ctx->d_g_win, ctx->d_g_comb, ctx->d_b_comb, ctx->stream);
+  HIP_TRY_C(hipGetLastError());
+  HIP_TRY_C(hipStreamSynchronize(ctx->stream));
+#undef HIP_TRY_C
+  ctx->T.sq.P = ctx->d_sqrt_p;
+  ctx->T.sq.lut = ctx->d_sqrt_lut;
+  ctx->T.g_win = ctx->d_g_win;
+  ctx->T.g_comb = ctx->d_g_comb;
+  ctx->T.b_comb = ctx->d_b_comb;
+  *out = ctx;
+  return VRFHIP_SUCCESS;
+}
+
+void vrfhip_ctx_destroy(vrfhip_ctx* ctx) {
+  if (!ctx) return;
+  {
+    DeviceGuard guard(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_sqrt_p) (void)hipFree(ctx->d_sqrt_p);
+    if (ctx->d_sqrt_lut) (void)hipFree(ctx->d_sqrt_lut);
+    if (ctx->d_g_win) (void)hipFree(ctx->d_g_win);
+    if (ctx->d_g_comb) (void)hipFree(ctx->d_g_comb);
+    if (ctx->d_b_comb) (void)hipFree(ctx->d_b_comb);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  }
+  delete ctx;
+}
+
+int32_t vrfhip_ctx_reserve(vrfhip_ctx* ctx, size_t max_items) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  if (max_items > ctx->ws_cap) return alloc_workspace(ctx, max_items);
+  return VRFHIP_SUCCESS;
+}
+
+size_t vrfhip_ctx_workspace_bytes(const vrfhip_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
+
+// ------------------------------------------------------------------------- IETF verify
+int32_t vrfhip_ietf_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_pk,
+                                     const uint8_t* d_input, const uint8_t* d_output,
+                                     const uint8_t* d_c, const uint8_t* d_s, const uint8_t* d_ad,
+                                     const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_status,
+                                     void* stream) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!d_pk || !d_input || !d_output || !d_c || !d_s || !d_status)
+    return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if ((ad_len || d_ad_off) && !d_ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_workspace(ctx, n);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (size_t base = 0; base < n; base += ctx->ws_cap) {
+    size_t m = std::min(ctx->ws_cap, n - base);
+    VerifyArgs a;
+    a.n = m;
+    a.pk = d_pk + base * 32; a.h = d_input + base * 32; a.gamma = d_output + base * 32;
+    a.c = d_c + base * 32; a.s = d_s + base * 32;
+    a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
+    a.status = d_status + base;
+    a.ws = ctx->ws;
+    a.T = ctx->T;
+    launch_ietf_verify(a, st);
+  }
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_ietf_verify_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* input,
+                                 const uint8_t* output, const uint8_t* c, const uint8_t* s,
+                                 const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                 uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!pk || !input || !output || !c || !s || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  size_t adb = blob_bytes(n, ad_off, ad_len, true);
+  uint8_t *d_pk, *d_h, *d_g, *d_c, *d_s, *d_ad, *d_st;
+  uint32_t* d_off = nullptr;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  {
+    size_t need = 5 * Stage::pad(n * 32) + Stage::pad(adb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n);
+    int32_t rc = ensure_stage(ctx, need);
+    if (rc) return rc;
+    Stage sg(ctx->d_stage);
+    d_pk = sg.take(n * 32); d_h = sg.take(n * 32); d_g = sg.take(n * 32);
+    d_c = sg.take(n * 32); d_s = sg.take(n * 32);
+    d_ad = sg.take(adb + 1);
+    d_off = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+    d_st = sg.take(n);
+    HIP_TRY(hipMemcpyAsync(d_pk, pk, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_h, input, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_g, output, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_c, c, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_s, s, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (adb) HIP_TRY(hipMemcpyAsync(d_ad, ad, adb, hipMemcpyHostToDevice, ctx->stream));
+    if (ad_off) HIP_TRY(hipMemcpyAsync(d_off, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  int32_t rc = vrfhip_ietf_verify_batch_dev(ctx, n, d_pk, d_h, d_g, d_c, d_s, d_ad,
+                                            ad_off ? d_off : nullptr, ad_len, d_st, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
+// ------------------------------------------------------------------------- IETF prove
+int32_t vrfhip_ietf_prove_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_sk,
+                                    const uint8_t* d_msg, const uint32_t* d_msg_off,
+                                    uint32_t msg_len, const uint8_t* d_input, const uint8_t* d_ad,
+                                    const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_output,
+                                    uint8_t* d_c, uint8_t* d_s, uint8_t* d_pk_out,
+                                    uint8_t* d_input_out, uint8_t* d_status, void* stream) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!d_sk || !d_output || !d_c || !d_s) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if (!d_input && !d_msg && (msg_len || d_msg_off)) return fail(VRFHIP_ERR_BAD_ARG, "msg is NULL");
+  if ((ad_len || d_ad_off) && !d_ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_workspace(ctx, n);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (size_t base = 0; base < n; base += ctx->ws_cap) {
+    size_t m = std::min(ctx->ws_cap, n - base);
+    ProveArgs a;
+    a.n = m;
+    a.sk = d_sk + base * 32;
+    if (d_msg_off) a.msg = make_view(d_msg, d_msg_off + base, 0, false);
+    else a.msg = make_view(d_msg ? d_msg + base * (size_t)msg_len : nullptr, nullptr, msg_len, false);
+    a.h_given = d_input ? d_input + base * 32 : nullptr;
+    a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
+    a.gamma = d_output + base * 32; a.c = d_c + base * 32; a.s = d_s + base * 32;
+    a.pk_out = d_pk_out ? d_pk_out + base * 32 : nullptr;
+    a.h_out = d_input_out ? d_input_out + base * 32 : nullptr;
+    a.status = d_status ? d_status + base : nullptr;
+    a.ws = ctx->ws;
+    a.T = ctx->T;
+    launch_ietf_prove(a, st);
+  }
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_ietf_prove_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* sk, const uint8_t* msg,
+                                const uint32_t* msg_off, uint32_t msg_len, const uint8_t* input,
+                                const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                uint8_t* output, uint8_t* c, uint8_t* s, uint8_t* pk_out,
+                                uint8_t* input_out, uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!sk || !output || !c || !s) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if (!input && !msg && (msg_len || msg_off)) return fail(VRFHIP_ERR_BAD_ARG, "msg is NULL");
+  if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  size_t adb = blob_bytes(n, ad_off, ad_len, true);
+  size_t msgb = input ? 0 : blob_bytes(n, msg_off, msg_len, false);
+  uint8_t *d_sk, *d_msg, *d_in, *d_ad, *d_g, *d_c, *d_s, *d_pk, *d_h, *d_st;
+  uint32_t *d_moff, *d_aoff;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  {
+    size_t need = 7 * Stage::pad(n * 32) + Stage::pad(msgb + 1) + Stage::pad(adb + 1) +
+                  2 * Stage::pad((n + 1) * 4) + Stage::pad(n);
+    int32_t rc = ensure_stage(ctx, need);
+    if (rc) return rc;
+    Stage sg(ctx->d_stage);
+    d_sk = sg.take(n * 32); d_in = sg.take(n * 32);
+    d_g = sg.take(n * 32); d_c = sg.take(n * 32); d_s = sg.take(n * 32);
+    d_pk = sg.take(n * 32); d_h = sg.take(n * 32);
+    d_msg = sg.take(msgb + 1); d_ad = sg.take(adb + 1);
+    d_moff = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+    d_aoff = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+    d_st = sg.take(n);
+    HIP_TRY(hipMemcpyAsync(d_sk, sk, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (input) HIP_TRY(hipMemcpyAsync(d_in, input, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (msgb) HIP_TRY(hipMemcpyAsync(d_msg, msg, msgb, hipMemcpyHostToDevice, ctx->stream));
+    if (adb) HIP_TRY(hipMemcpyAsync(d_ad, ad, adb, hipMemcpyHostToDevice, ctx->stream));
+    if (msg_off && !input)
+      HIP_TRY(hipMemcpyAsync(d_moff, msg_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (ad_off) HIP_TRY(hipMemcpyAsync(d_aoff, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  int32_t rc = vrfhip_ietf_prove_batch_dev(ctx, n, d_sk, d_msg, (msg_off && !input) ? d_moff : nullptr,
+                                           msg_len, input ? d_in : nullptr, d_ad,
+                                           ad_off ? d_aoff : nullptr, ad_len, d_g, d_c, d_s, d_pk, d_h,
+                                           d_st, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(output, d_g, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(c, d_c, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(s, d_s, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (pk_out) HIP_TRY(hipMemcpyAsync(pk_out, d_pk, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (input_out) HIP_TRY(hipMemcpyAsync(input_out, d_h, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (status) HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
+// ------------------------------------------------------------------------- building blocks
+int32_t vrfhip_hash_to_curve_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_msg,
+                                       const uint32_t* d_msg_off, uint32_t msg_len,
+                                       uint8_t* d_points, void* stream) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!d_points || (!d_msg && (msg_len || d_msg_off))) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  launch_hash_to_curve(n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T,
+                       static_cast<hipStream_t>(stream));
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_hash_to_curve_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* msg,
+                                   const uint32_t* msg_off, uint32_t msg_len, uint8_t* points) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!points || (!msg && (msg_len || msg_off))) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  size_t msgb = blob_bytes(n, msg_off, msg_len, false);
+  uint8_t *d_msg, *d_pts;
+  uint32_t* d_off;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  {
+    int32_t rc = ensure_stage(ctx, Stage::pad(msgb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n * 32));
+    if (rc) return rc;
+    Stage sg(ctx->d_stage);
+    d_msg = sg.take(msgb + 1);
+    d_off = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+    d_pts = sg.take(n * 32);
+    if (msgb) HIP_TRY(hipMemcpyAsync(d_msg, msg, msgb, hipMemcpyHostToDevice, ctx->stream));
+    if (msg_off) HIP_TRY(hipMemcpyAsync(d_off, msg_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  int32_t rc = vrfhip_hash_to_curve_batch_dev(ctx, n, d_msg, msg_off ? d_off : nullptr, msg_len, d_pts,
+                                              ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(points, d_pts, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_output_hash_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_output,
+                                     uint8_t* d_hash, void* stream) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!d_output || !d_hash) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  launch_output_hash(n, d_output, d_hash, static_cast<hipStream_t>(stream));
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_output_hash_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* output, uint8_t* hash) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!output || !hash) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  uint8_t *d_in, *d_out;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  {
+    int32_t rc = ensure_stage(ctx, Stage::pad(n * 32) + Stage::pad(n * 64));
+    if (rc) return rc;
+    Stage sg(ctx->d_stage);
+    d_in = sg.take(n * 32);
+    d_out = sg.take(n * 64);
+    HIP_TRY(hipMemcpyAsync(d_in, output, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  }
+  int32_t rc = vrfhip_output_hash_batch_dev(ctx, n, d_in, d_out, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(hash, d_out, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_secret_from_seed_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_seeds,
+                                          uint32_t seed_len, uint8_t* d_sk_out, uint8_t* d_pk_out,
+                                          void* stream) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!d_sk_out || (!d_seeds && seed_len)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  launch_secret_from_seed(n, d_seeds, seed_len, d_sk_out, d_pk_out, ctx->T,
+                          static_cast<hipStream_t>(stream));
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_secret_from_seed_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* seeds,
+                                      uint32_t seed_len, uint8_t* sk_out, uint8_t* pk_out) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!sk_out || (!seeds && seed_len)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  uint8_t *d_seed, *d_sk, *d_pk;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  {
+    int32_t rc = ensure_stage(ctx, Stage::pad(n * (size_t)seed_len + 1) + 2 * Stage::pad(n * 32));
+    if (rc) return rc;
+    Stage sg(ctx->d_stage);
+    d_seed = sg.take(n * (size_t)seed_len + 1);
+    d_sk = sg.take(n * 32);
+    d_pk = sg.take(n * 32);
+    if (seed_len)
+      HIP_TRY(hipMemcpyAsync(d_seed, seeds, n * (size_t)seed_len, hipMemcpyHostToDevice, ctx->stream));
+  }
+  int32_t rc = vrfhip_secret_from_seed_batch_dev(ctx, n, d_seed, seed_len, d_sk, pk_out ? d_pk : nullptr,
+                                                 ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(sk_out, d_sk, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (pk_out) HIP_TRY(hipMemcpyAsync(pk_out, d_pk, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_point_validate_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_points,
+                                        uint8_t* d_xy_out, uint8_t* d_status, void* stream) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!d_points || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_workspace(ctx, n);
+  if (rc) return rc;
+  // one window table per item: the tabs region holds 3 per workspace item
+  size_t cap = ctx->ws_cap * 3;
+  for (size_t base = 0; base < n; base += cap) {
+    size_t m = std::min(cap, n - base);
+    launch_point_validate(m, d_points + base * 32, d_xy_out ? d_xy_out + base * 64 : nullptr,
+                          d_status + base, ctx->ws.tabs, ctx->T, static_cast<hipStream_t>(stream));
+  }
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_point_validate_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* points,
+                                    uint8_t* xy_out, uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!points || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  uint8_t *d_in, *d_xy, *d_st;
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  {
+    int32_t rc = ensure_stage(ctx, Stage::pad(n * 32) + Stage::pad(n * 64) + Stage::pad(n));
+    if (rc) return rc;
+    Stage sg(ctx->d_stage);
+    d_in = sg.take(n * 32);
+    d_xy = sg.take(n * 64);
+    d_st = sg.take(n);
+    HIP_TRY(hipMemcpyAsync(d_in, points, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  }
+  int32_t rc = vrfhip_point_validate_batch_dev(ctx, n, d_in, xy_out ? d_xy : nullptr, d_st, ctx->stream);
+  if (rc) return rc;
+  if (xy_out) HIP_TRY(hipMemcpyAsync(xy_out, d_xy, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_fq_mul_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b,
+                            uint8_t* r) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!a || !b || !r) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_stage(ctx, 3 * Stage::pad(n * 32));
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t* d_a = sg.take(n * 32);
+  uint8_t* d_b = sg.take(n * 32);
+  uint8_t* d_r = sg.take(n * 32);
+  HIP_TRY(hipMemcpyAsync(d_a, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_b, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  launch_fq_mul(n, d_a, d_b, d_r, ctx->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(r, d_r, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
+}  // extern "C"

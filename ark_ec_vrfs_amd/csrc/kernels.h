@@ -1,0 +1,85 @@
+// kernels.h -- launch interface between the C ABI (api.hip) and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include "vrf_core.cuh"
+
+namespace vrf {
+
+// variable-length byte strings: shared blob, per-item offsets, or fixed stride
+struct BytesView {
+  const uint8_t* blob;
+  const uint32_t* off;   // n+1 offsets, or nullptr
+  uint32_t len;          // off == nullptr: length of every item
+  uint32_t stride;       // off == nullptr: distance between items (0 = all items share blob)
+};
+VRF_HD void bytes_get(const BytesView& v, size_t i, const uint8_t*& p, uint32_t& n) {
+  if (v.off) {
+    uint32_t a = v.off[i], b = v.off[i + 1];
+    p = v.blob + a;
+    n = b - a;
+  } else {
+    p = v.blob + i * (size_t)v.stride;
+    n = v.len;
+  }
+}
+
+// per-context device workspace (capacity `cap` items)
+struct Workspace {
+  uint32_t* tabs;    // [cap][3][WIN_TABLE_WORDS]   window tables
+  uint32_t* pts;     // [cap][PROVE_PTS_WORDS]      projective intermediates (verify uses 2*UV_WORDS)
+  uint32_t* aux;     // [cap][16]                   prove: enc(H) (8) || nonce k (8)
+  uint8_t* flags;    // [cap]                       validity of decoded inputs
+};
+constexpr size_t WS_BYTES_PER_ITEM =
+    (3 * WIN_TABLE_WORDS + PROVE_PTS_WORDS + 16) * sizeof(uint32_t) + 1;
+
+struct VerifyArgs {
+  size_t n;
+  const uint8_t *pk, *h, *gamma, *c, *s;
+  BytesView ad;
+  uint8_t* status;
+  Workspace ws;
+  DevTables T;
+};
+
+struct ProveArgs {
+  size_t n;
+  const uint8_t* sk;
+  BytesView msg;
+  const uint8_t* h_given;     // nullable
+  BytesView ad;
+  uint8_t *gamma, *c, *s, *pk_out, *h_out, *status;
+  Workspace ws;
+  DevTables T;
+};
+
+// launchers (each defined next to its kernels)
+void launch_init_tables(uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, hipStream_t st);
+void launch_ietf_verify(const VerifyArgs& a, hipStream_t st);
+void launch_ietf_prove(const ProveArgs& a, hipStream_t st);
+void launch_hash_to_curve(size_t n, BytesView msg, uint8_t* points, DevTables T, hipStream_t st);
+void launch_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash, hipStream_t st);
+void launch_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk,
+                             uint8_t* pk, DevTables T, hipStream_t st);
+void launch_point_validate(size_t n, const uint8_t* pts, uint8_t* xy, uint8_t* status,
+                           uint32_t* tabs, DevTables T, hipStream_t st);
+void launch_fq_mul(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* r, hipStream_t st);
+
+// 32-byte item <-> registers
+VRF_HD void load32(uint32_t w[8], const uint8_t* base, size_t i) {
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(base + i * 32);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = p[k];
+}
+VRF_HD void store32(uint8_t* base, size_t i, const uint32_t w[8]) {
+  uint32_t* p = reinterpret_cast<uint32_t*>(base + i * 32);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) p[k] = w[k];
+}
+
+constexpr int BLOCK = 128;
+inline dim3 grid_for(size_t threads) { return dim3((unsigned)((threads + BLOCK - 1) / BLOCK)); }
+
+}  // namespace vrf

@@ -73,9 +73,10 @@ VRF_HD PtC ptc_load(const uint32_t* m) {
   return c;
 }
 
-// 2P.  NEED_T = false skips the T coordinate (legal when the next operation is a doubling).
-template <class C, bool NEED_T>
-VRF_HD PtE te_dbl(const PtE& p) {
+// 2P.  need_t = false skips the T coordinate (legal when the next operation is a doubling);
+// it is wave-uniform at every call site, so the branch is scalar.
+template <class C>
+VRF_HD PtE te_dbl(const PtE& p, bool need_t) {
   auto A = fe_sqr(p.X);                               // (1,2)
   auto B = fe_sqr(p.Y);                               // (1,2)
   auto S = fe_sqr(fe_add(p.X, p.Y));                  // (1,3)
@@ -89,7 +90,8 @@ VRF_HD PtE te_dbl(const PtE& p) {
   r.X = fe_mul(E, F);
   r.Y = fe_mul(G, H);
   r.Z = fe_mul(F, G);
-  if (NEED_T) r.T = fe_mul(E, H); else r.T = fe_zero();
+  r.T = fe_zero();
+  if (need_t) r.T = fe_mul(E, H);
   return r;
 }
 

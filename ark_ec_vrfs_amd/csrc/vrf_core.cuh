@@ -107,26 +107,18 @@ VRF_HD bool decode_phase_b(Fe<1, 4>& x_out, const DecodeA& a, const FeN& den_inv
 }
 
 // ------------------------------------------------------------------------ window tables
-// multiples 1..8 of an affine point, cached form, written to `tab` (WIN_TABLE_WORDS words)
+// multiples 1..8 of an affine point, cached form, written to `tab` (WIN_TABLE_WORDS words).
+// One unified-add call site in a loop (the unified law also doubles).
 template <class C>
 VRF_HD void build_win_table(uint32_t* tab, const FeP& x, const FeP& y) {
-  PtE p1 = te_from_affine(x, y);
-  PtC c1 = te_to_cached<C>(p1);
-  ptc_store(tab + 0 * PTC_WORDS, c1);
-  PtE p2 = te_dbl<C, true>(p1);
-  ptc_store(tab + 1 * PTC_WORDS, te_to_cached<C>(p2));
-  PtE p3 = te_add_cached<C>(p2, c1, false);
-  ptc_store(tab + 2 * PTC_WORDS, te_to_cached<C>(p3));
-  PtE p4 = te_dbl<C, true>(p2);
-  ptc_store(tab + 3 * PTC_WORDS, te_to_cached<C>(p4));
-  PtE p6 = te_dbl<C, true>(p3);
-  ptc_store(tab + 5 * PTC_WORDS, te_to_cached<C>(p6));
-  PtE p5 = te_add_cached<C>(p4, c1, false);
-  ptc_store(tab + 4 * PTC_WORDS, te_to_cached<C>(p5));
-  PtE p7 = te_add_cached<C>(p6, c1, false);
-  ptc_store(tab + 6 * PTC_WORDS, te_to_cached<C>(p7));
-  PtE p8 = te_dbl<C, true>(p4);
-  ptc_store(tab + 7 * PTC_WORDS, te_to_cached<C>(p8));
+  PtE acc = te_from_affine(x, y);
+  PtC c1 = te_to_cached<C>(acc);
+  ptc_store(tab, c1);
+#pragma unroll 1
+  for (int j = 1; j < WIN_ENTRIES; ++j) {
+    acc = te_add_cached<C>(acc, c1, false);
+    ptc_store(tab + j * PTC_WORDS, te_to_cached<C>(acc));
+  }
 }
 
 VRF_HD PtC win_lookup(const uint32_t* tab, int digit) {   // |digit| in 0..8
@@ -142,33 +134,45 @@ VRF_HD PtC win_lookup(const uint32_t* tab, int digit) {   // |digit| in 0..8
   return e;
 }
 
+VRF_HD void sel8(uint32_t out[8], bool c, const uint32_t a[8], const uint32_t b[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = c ? a[i] : b[i];
+}
+
 // sa*A + sb*B by Straus with signed radix-16 digits; negB flips the sign of the B terms.
-// reca / recb are recoded scalars (scalar_recode_signed4).
+// reca / recb are recoded scalars (scalar_recode_signed4).  One te_dbl and one te_add call
+// site: the loop body is the whole hot path of IETF verification.
 template <class C>
 VRF_HD PtE straus2(const uint32_t* tabA, const uint32_t reca[8], const uint32_t* tabB,
                    const uint32_t recb[8], bool negB) {
   PtE acc = te_identity();
+#pragma unroll 1
   for (int w = 63; w >= 0; --w) {
     if (w != 63) {
-      for (int j = 0; j < 3; ++j) acc = te_dbl<C, false>(acc);
-      acc = te_dbl<C, true>(acc);
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) acc = te_dbl<C>(acc, j == 3);
     }
-    int da = scalar_digit4(reca, w);
-    int db = scalar_digit4(recb, w);
-    acc = te_add_cached<C>(acc, win_lookup(tabA, da), da < 0);
-    acc = te_add_cached<C>(acc, win_lookup(tabB, db), (db < 0) != negB);
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+      uint32_t rec[8];
+      sel8(rec, t != 0, recb, reca);
+      const uint32_t* tab = t ? tabB : tabA;
+      int d = scalar_digit4(rec, w);
+      acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != (t != 0 && negB));
+    }
   }
   return acc;
 }
 
-// k*P for one window table (used by prove: Gamma = sk*H, kH)
+// k*P for one window table (prove: Gamma = sk*H, kH)
 template <class C>
 VRF_HD PtE win_mul(const uint32_t* tab, const uint32_t rec[8]) {
   PtE acc = te_identity();
+#pragma unroll 1
   for (int w = 63; w >= 0; --w) {
     if (w != 63) {
-      for (int j = 0; j < 3; ++j) acc = te_dbl<C, false>(acc);
-      acc = te_dbl<C, true>(acc);
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) acc = te_dbl<C>(acc, j == 3);
     }
     int d = scalar_digit4(rec, w);
     acc = te_add_cached<C>(acc, win_lookup(tab, d), d < 0);
@@ -180,6 +184,7 @@ VRF_HD PtE win_mul(const uint32_t* tab, const uint32_t rec[8]) {
 template <class C>
 VRF_HD PtE comb_mul(const uint32_t* comb, const uint32_t k[8]) {
   PtE acc = te_identity();
+#pragma unroll 1
   for (int w = 0; w < 32; ++w) {
     uint32_t word = k[0];
 #pragma unroll
@@ -204,8 +209,9 @@ template <class C>
 VRF_HD PtE te_mul_slow(const PtE& base, const uint32_t k[8]) {
   PtE acc = te_identity();
   PtC bc = te_to_cached<C>(base);
+#pragma unroll 1
   for (int i = 255; i >= 0; --i) {
-    acc = te_dbl<C, true>(acc);
+    acc = te_dbl<C>(acc, true);
     uint32_t word = k[0];
 #pragma unroll
     for (int j = 1; j < 8; ++j)
@@ -256,41 +262,70 @@ VRF_HD void challenge5(uint32_t c_out[8], const uint32_t (&pts)[5][8], const uin
 
 // ------------------------------------------------------------------------ IETF verify
 // [ref src/lib.rs:14 `ietf::Verifier::verify`]  U = s*G - c*Y, V = s*H - c*Gamma, accept iff
-// challenge(Y, H, Gamma, U, V, ad) == c.   `scratch`: 3 * WIN_TABLE_WORDS words, private.
+// challenge(Y, H, Gamma, U, V, ad) == c.  Three stages (three kernels):
+//   decode : decompress Y, H, Gamma with one shared inversion; radix-16 window tables -> HBM
+//   straus : U and V, one lane each (2 lanes per proof)                               -> HBM
+//   finish : shared inversion of Z_U, Z_V; encode; SHA-512 challenge; compare.
+constexpr int UV_WORDS = 3 * NL;          // X, Y, Z of one projective result
+
+VRF_HD FeN fe_sel3(int p, const FeN& a, const FeN& b, const FeN& c) {
+  return fe_select(p == 0, a, fe_select(p == 1, b, c));
+}
+
+// tabs: 3 * WIN_TABLE_WORDS words (tables of Y, H, Gamma).  Returns validity of the encodings.
 template <class S>
-VRF_HD uint32_t ietf_verify_item(const DevTables& T, const uint32_t pk[8], const uint32_t hh[8],
-                                 const uint32_t gamma[8], const uint32_t c[8], const uint32_t s[8],
-                                 const uint8_t* ad, uint32_t ad_len, uint32_t* scratch) {
-  bool valid = fr_is_canonical<S>(c) && fr_is_canonical<S>(s);
-  // decode the three points with one shared inversion
+VRF_HD bool verify_decode_item(const DevTables& T, const uint32_t pk[8], const uint32_t hh[8],
+                               const uint32_t gamma[8], uint32_t* tabs) {
   DecodeA a0 = decode_phase_a<S>(pk), a1 = decode_phase_a<S>(hh), a2 = decode_phase_a<S>(gamma);
   FeN dens[3] = {a0.den, a1.den, a2.den}, dinv[3];
   fe_batch_inv(dinv, dens);
-  Fe<1, 4> x;
-  uint32_t* tabY = scratch;
-  uint32_t* tabH = scratch + WIN_TABLE_WORDS;
-  uint32_t* tabG = scratch + 2 * WIN_TABLE_WORDS;
-  valid = decode_phase_b<S>(x, a0, dinv[0], T.sq) && valid;
-  build_win_table<S>(tabY, x, a0.y);
-  valid = decode_phase_b<S>(x, a1, dinv[1], T.sq) && valid;
-  build_win_table<S>(tabH, x, a1.y);
-  valid = decode_phase_b<S>(x, a2, dinv[2], T.sq) && valid;
-  build_win_table<S>(tabG, x, a2.y);
+  bool valid = true;
+#pragma unroll 1
+  for (int p = 0; p < 3; ++p) {
+    DecodeA a;
+    a.y = fe_sel3(p, a0.y, a1.y, a2.y);
+    a.den = fe_sel3(p, a0.den, a1.den, a2.den);
+    a.num = fe_select(p == 0, a0.num, fe_select(p == 1, a1.num, a2.num));
+    a.flag = p == 0 ? a0.flag : (p == 1 ? a1.flag : a2.flag);
+    a.ok = p == 0 ? a0.ok : (p == 1 ? a1.ok : a2.ok);
+    FeN di = fe_sel3(p, dinv[0], dinv[1], dinv[2]);
+    Fe<1, 4> x;
+    valid = decode_phase_b<S>(x, a, di, T.sq) && valid;
+    build_win_table<S>(tabs + p * WIN_TABLE_WORDS, x, a.y);
+  }
+  return valid;
+}
 
+// half 0: U = s*G - c*Y (tables: g_win, tabs[0]) ; half 1: V = s*H - c*Gamma (tabs[1], tabs[2])
+template <class S>
+VRF_HD void verify_straus_item(uint32_t* out_uv, const DevTables& T, const uint32_t* tabs,
+                               const uint32_t c[8], const uint32_t s[8], int half) {
   uint32_t recs[8], recc[8];
   scalar_recode_signed4(recs, s);
   scalar_recode_signed4(recc, c);
-  PtE U = straus2<S>(T.g_win, recs, tabY, recc, true);
-  PtE V = straus2<S>(tabH, recs, tabG, recc, true);
+  const uint32_t* tabA = half ? tabs + WIN_TABLE_WORDS : T.g_win;
+  const uint32_t* tabB = half ? tabs + 2 * WIN_TABLE_WORDS : tabs;
+  PtE r = straus2<S>(tabA, recs, tabB, recc, true);
+  fe_store(out_uv, r.X);
+  fe_store(out_uv + NL, r.Y);
+  fe_store(out_uv + 2 * NL, r.Z);
+}
 
-  FeP zin[2] = {U.Z, V.Z};
+template <class S>
+VRF_HD uint32_t verify_finish_item(const uint32_t* uv, const uint32_t pk[8], const uint32_t hh[8],
+                                   const uint32_t gamma[8], const uint32_t c[8],
+                                   const uint32_t s[8], bool valid, const uint8_t* ad,
+                                   uint32_t ad_len) {
+  valid = valid && fr_is_canonical<S>(c) && fr_is_canonical<S>(s);
+  FeP zin[2] = {fe_load<1, 5>(uv + 2 * NL), fe_load<1, 5>(uv + UV_WORDS + 2 * NL)};
   FeN zi[2];
   fe_batch_inv(zi, zin);
   uint32_t pts[5][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { pts[0][i] = pk[i]; pts[1][i] = hh[i]; pts[2][i] = gamma[i]; }
-  te_encode_affine(pts[3], fe_mul(U.X, zi[0]), fe_mul(U.Y, zi[0]));
-  te_encode_affine(pts[4], fe_mul(V.X, zi[1]), fe_mul(V.Y, zi[1]));
+  te_encode_affine(pts[3], fe_mul(fe_load<1, 5>(uv), zi[0]), fe_mul(fe_load<1, 5>(uv + NL), zi[0]));
+  te_encode_affine(pts[4], fe_mul(fe_load<1, 5>(uv + UV_WORDS), zi[1]),
+                   fe_mul(fe_load<1, 5>(uv + UV_WORDS + NL), zi[1]));
   uint32_t c2[8];
   challenge5<S>(c2, pts, ad, ad_len);
   uint32_t diff = 0;
@@ -323,28 +358,35 @@ VRF_HD void hash_to_field2(Fe<1, 4>& u0, Fe<1, 4>& u1, const uint8_t* msg, uint3
   sha512_put_byte(b0, 0x00);
   put_dst_prime<S>(b0);
   sha512_final(b0);
-  Sha512 b1;
-  sha512_init(b1);
+  uint64_t h0[8], h1[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) sha512_put(b1, b0.h[i], 8);
-  sha512_put_byte(b1, 0x01);
-  put_dst_prime<S>(b1);
-  sha512_final(b1);
-  Sha512 b2;
-  sha512_init(b2);
+  for (int i = 0; i < 8; ++i) h0[i] = b0.h[i];
+  // b1 = H(b0 || 0x01 || DST'), b2 = H((b0 ^ b1) || 0x02 || DST'): one hashing site, two trips
+  uint64_t hb[2][8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) sha512_put(b2, b0.h[i] ^ b1.h[i], 8);
-  sha512_put_byte(b2, 0x02);
-  put_dst_prime<S>(b2);
-  sha512_final(b2);
-  // uniform = b1 (64 B) || b2[0..32].  u0 = BE(uniform[0..48]) = b1.h[0..6] ; u1 = BE(b1.h[6..8] || b2.h[0..4])
+  for (int i = 0; i < 8; ++i) h1[i] = 0;
+#pragma unroll 1
+  for (int t = 0; t < 2; ++t) {
+    Sha512 b;
+    sha512_init(b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sha512_put(b, h0[i] ^ h1[i], 8);
+    sha512_put_byte(b, (uint8_t)(t + 1));
+    put_dst_prime<S>(b);
+    sha512_final(b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (t == 0) { h1[i] = b.h[i]; hb[0][i] = b.h[i]; } else { hb[1][i] = b.h[i]; }
+    }
+  }
+  // uniform = b1 (64 B) || b2[0..32];  u0 = BE(b1.h[0..6]);  u1 = BE(b1.h[6..8] || b2.h[0..4])
   uint32_t w0[16], w1[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { w0[i] = 0; w1[i] = 0; }
 #pragma unroll
   for (int j = 0; j < 6; ++j) {          // 64-bit BE words, most significant first
-    uint64_t a = b1.h[j];
-    uint64_t b = (j < 2) ? b1.h[6 + j] : b2.h[j - 2];
+    uint64_t a = hb[0][j];
+    uint64_t b = (j < 2) ? hb[0][6 + j] : hb[1][j - 2];
     w0[2 * (5 - j)] = (uint32_t)a; w0[2 * (5 - j) + 1] = (uint32_t)(a >> 32);
     w1[2 * (5 - j)] = (uint32_t)b; w1[2 * (5 - j) + 1] = (uint32_t)(b >> 32);
   }
@@ -352,34 +394,19 @@ VRF_HD void hash_to_field2(Fe<1, 4>& u0, Fe<1, 4>& u1, const uint8_t* msg, uint3
   u1 = fe_from_u512(w1);
 }
 
-struct Ell2A {           // Elligator-2 phase a: everything before the inversion of D
-  Fe<1, 4> u;
-  FeN D;
-};
-template <class S>
-VRF_HD Ell2A ell2_phase_a(const Fe<1, 4>& u) {
-  Ell2A r;
-  r.u = u;
-  FeN u2 = fe_sqr(u);
-  FeN D = fe_canon(fe_add(fe_mul5(u2), fe_one()));       // 1 + Z*u^2, Z = 5
-  bool dz = true;
-#pragma unroll
-  for (int i = 0; i < NL; ++i) dz = dz && (D.v[i] == 0);
-  r.D = fe_select(dz, fe_one(), D);
-  return r;
-}
 VRF_HD bool fe_parity(const FeN& a) {       // canonical integer is odd
   uint32_t w[8];
   fe_to_u256(w, a);
   return w[0] & 1;
 }
+
+// Elligator 2 for one u, given D = 1 + Z*u^2 (already replaced by 1 if zero) and 1/D.
 template <class S>
-VRF_HD PtE ell2_phase_b(const Ell2A& a, const FeN& Dinv, const SqrtTables& T) {
+VRF_HD PtE ell2_map(const Fe<1, 4>& u, const FeN& Dinv, const SqrtTables& T) {
   const FeN JK = fe_const(vrfk::BS_ELL2_JK_M), K2I = fe_const(vrfk::BS_ELL2_K2I_M);
   const FeN K = fe_const(vrfk::BS_ELL2_K_M);
   FeN x1 = fe_mul(fe_const(vrfk::BS_ELL2_NJK_M), Dinv);              // -(J/K) / D
-  // gx1 = ((x1 + J/K) * x1 + 1/K^2) * x1
-  FeN t = fe_mul(fe_add(x1, JK), x1);
+  FeN t = fe_mul(fe_add(x1, JK), x1);                                // gx1 = ((x1+J/K)x1 + 1/K^2)x1
   FeN gx1 = fe_mul(fe_add(t, K2I), x1);
   FeN root;
   bool sq = fe_sqrt_or_zsqrt(root, gx1, T);
@@ -390,7 +417,7 @@ VRF_HD PtE ell2_phase_b(const Ell2A& a, const FeN& Dinv, const SqrtTables& T) {
   for (int i = 0; i < 8; ++i) nz |= rw[i];
   sq = sq || (nz == 0);
   Fe<1, 8> x2 = fe_norm(fe_neg(fe_norm(fe_add(x1, JK))));           // -x1 - J/K
-  FeN y2 = fe_mul(root, a.u);                                        // sqrt(gx2) = u * sqrt(Z*gx1)
+  FeN y2 = fe_mul(root, u);                                          // sqrt(gx2) = u * sqrt(Z*gx1)
   Fe<1, 8> x1w = x1;
   Fe<1, 8> x = fe_select(sq, x1w, x2);
   FeN y = fe_select(sq, root, y2);
@@ -415,16 +442,30 @@ VRF_HD PtE ell2_phase_b(const Ell2A& a, const FeN& Dinv, const SqrtTables& T) {
 
 template <class S>
 VRF_HD PtE hash_to_curve_ell2(const uint8_t* msg, uint32_t msg_len, const SqrtTables& T) {
-  Fe<1, 4> u0, u1;
-  hash_to_field2<S>(u0, u1, msg, msg_len);
-  Ell2A a0 = ell2_phase_a<S>(u0), a1 = ell2_phase_a<S>(u1);
-  FeN ds[2] = {a0.D, a1.D}, di[2];
-  fe_batch_inv(di, ds);
-  PtE q0 = ell2_phase_b<S>(a0, di[0], T);
-  PtE q1 = ell2_phase_b<S>(a1, di[1], T);
-  PtE h = te_add<S>(q0, q1);
-  for (int i = 0; i < S::COFACTOR_LOG2; ++i) h = te_dbl<S, true>(h);
-  return h;
+  Fe<1, 4> u[2];
+  hash_to_field2<S>(u[0], u[1], msg, msg_len);
+  FeN D[2], Di[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    FeN d = fe_canon(fe_add(fe_mul5(fe_sqr(u[i])), fe_one()));       // 1 + Z*u^2, Z = 5
+    bool dz = true;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) dz = dz && (d.v[k] == 0);
+    D[i] = fe_select(dz, fe_one(), d);
+  }
+  fe_batch_inv(Di, D);
+  PtE q0 = te_identity();
+  PtE acc = te_identity();
+#pragma unroll 1
+  for (int i = 0; i < 2; ++i) {
+    Fe<1, 4> ui = fe_select(i == 0, u[0], u[1]);
+    FeN di = fe_select(i == 0, Di[0], Di[1]);
+    PtE q = ell2_map<S>(ui, di, T);
+    if (i == 0) q0 = q; else acc = te_add<S>(q0, q);
+  }
+#pragma unroll 1
+  for (int i = 0; i < S::COFACTOR_LOG2; ++i) acc = te_dbl<S>(acc, true);
+  return acc;
 }
 
 // ------------------------------------------------------------------------ nonce
@@ -447,53 +488,101 @@ VRF_HD void nonce_rfc8032(uint32_t k[8], const uint32_t sk[8], const uint32_t h_
   fr_reduce512<S>(k, le);
 }
 
-// ------------------------------------------------------------------------ IETF prove
-// [ref src/lib.rs:14 `ietf::Prover::prove` + src/lib.rs:16 `Secret::{public, output}`]
-// From (sk, H): pk = sk*G, Gamma = sk*H, k = nonce, c = challenge(pk, H, Gamma, kG, kH), s = k + c*sk.
-// H is given projective (from hash-to-curve) or decoded by the caller.  scratch: WIN_TABLE_WORDS.
-template <class S>
-VRF_HD void ietf_prove_core(uint32_t gamma_out[8], uint32_t c_out[8], uint32_t s_out[8],
-                            uint32_t h_out[8], uint32_t pk_out[8], const DevTables& T,
-                            const uint32_t sk[8], const FeN& hx, const FeN& hy,
-                            const uint8_t* ad, uint32_t ad_len, uint32_t* scratch) {
-  uint32_t h_enc[8];
-  te_encode_affine(h_enc, hx, hy);
-  uint32_t k[8];
-  nonce_rfc8032<S>(k, sk, h_enc);
-  build_win_table<S>(scratch, hx, hy);
-  uint32_t rec[8];
-  scalar_recode_signed4(rec, sk);
-  PtE G1 = win_mul<S>(scratch, rec);            // Gamma = sk*H
-  scalar_recode_signed4(rec, k);
-  PtE KH = win_mul<S>(scratch, rec);            // k*H
-  PtE PK = comb_mul<S>(T.g_comb, sk);           // sk*G
-  PtE KG = comb_mul<S>(T.g_comb, k);            // k*G
-  FeP zin[4] = {G1.Z, KH.Z, PK.Z, KG.Z};
-  FeN zi[4];
-  fe_batch_inv(zi, zin);
-  uint32_t pts[5][8];
-  te_encode_affine(pts[0], fe_mul(PK.X, zi[2]), fe_mul(PK.Y, zi[2]));
-#pragma unroll
-  for (int i = 0; i < 8; ++i) pts[1][i] = h_enc[i];
-  te_encode_affine(pts[2], fe_mul(G1.X, zi[0]), fe_mul(G1.Y, zi[0]));
-  te_encode_affine(pts[3], fe_mul(KG.X, zi[3]), fe_mul(KG.Y, zi[3]));
-  te_encode_affine(pts[4], fe_mul(KH.X, zi[1]), fe_mul(KH.Y, zi[1]));
-  uint32_t c[8], cs[8], s[8];
-  challenge5<S>(c, pts, ad, ad_len);
-  fr_mul<S>(cs, c, sk);
-  fr_add<S>(s, cs, k);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    gamma_out[i] = pts[2][i]; c_out[i] = c[i]; s_out[i] = s[i]; h_out[i] = h_enc[i];
-    pk_out[i] = pts[0][i];
-  }
-}
-
 // affine coordinates of a projective point (one inversion)
 VRF_HD void te_to_affine(FeN& x, FeN& y, const PtE& p) {
   FeN zi = fe_inv(p.Z);
   x = fe_mul(p.X, zi);
   y = fe_mul(p.Y, zi);
+}
+
+// ------------------------------------------------------------------------ IETF prove
+// [ref src/lib.rs:14 `ietf::Prover::prove` + src/lib.rs:16 `Secret::{public, output}`]
+// From (sk, msg): H = hash_to_curve(msg), pk = sk*G, Gamma = sk*H, k = nonce(sk, H),
+// c = challenge(pk, H, Gamma, kG, kH), s = k + c*sk.  Three stages:
+//   prepare: H (hash-to-curve or decode), enc(H), nonce k, window table of H     -> HBM
+//   mul    : lane 0: (sk*H, sk*G) ; lane 1: (k*H, k*G)                           -> HBM
+//   finish : shared inversion of the four Z, encodings, challenge, s.
+constexpr int PROVE_PTS_WORDS = 4 * UV_WORDS;   // [half][win|comb][X,Y,Z]
+
+// returns validity (always true for the hash-to-curve path; decode may fail)
+template <class S>
+VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, const DevTables& T,
+                               const uint32_t sk[8], const uint8_t* msg, uint32_t msg_len,
+                               const uint32_t* h_given) {
+  FeN x, y;
+  bool valid = fr_is_canonical<S>(sk);
+  if (h_given) {
+    DecodeA a = decode_phase_a<S>(h_given);
+    FeN di = fe_inv(a.den);
+    Fe<1, 4> xx;
+    valid = decode_phase_b<S>(xx, a, di, T.sq) && valid;
+    x = fe_mul(xx, fe_one());
+    y = a.y;
+  } else {
+    PtE hp = hash_to_curve_ell2<S>(msg, msg_len, T.sq);
+    te_to_affine(x, y, hp);
+  }
+  te_encode_affine(h_enc, x, y);
+  nonce_rfc8032<S>(k, sk, h_enc);
+  build_win_table<S>(tab, x, y);
+  return valid;
+}
+
+template <class S>
+VRF_HD void prove_mul_item(uint32_t* out /*2*UV_WORDS*/, const DevTables& T, const uint32_t* tab,
+                           const uint32_t scalar[8]) {
+  uint32_t rec[8];
+  scalar_recode_signed4(rec, scalar);
+  PtE w = win_mul<S>(tab, rec);
+  fe_store(out, w.X); fe_store(out + NL, w.Y); fe_store(out + 2 * NL, w.Z);
+  PtE c = comb_mul<S>(T.g_comb, scalar);
+  fe_store(out + UV_WORDS, c.X); fe_store(out + UV_WORDS + NL, c.Y);
+  fe_store(out + UV_WORDS + 2 * NL, c.Z);
+}
+
+// pts: [sk*H, sk*G, k*H, k*G] projective.  Writes gamma, c, s (and pk).
+template <class S>
+VRF_HD void prove_finish_item(uint32_t gamma_out[8], uint32_t c_out[8], uint32_t s_out[8],
+                              uint32_t pk_out[8], const uint32_t* pts_in, const uint32_t h_enc[8],
+                              const uint32_t sk[8], const uint32_t k[8], const uint8_t* ad,
+                              uint32_t ad_len) {
+  FeP zin[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) zin[i] = fe_load<1, 5>(pts_in + i * UV_WORDS + 2 * NL);
+  FeN zi[4];
+  fe_batch_inv(zi, zin);
+  uint32_t enc[4][8];
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    FeN z = fe_select(i == 0, zi[0], fe_select(i == 1, zi[1], fe_select(i == 2, zi[2], zi[3])));
+    uint32_t e[8];
+    te_encode_affine(e, fe_mul(fe_load<1, 5>(pts_in + i * UV_WORDS), z),
+                     fe_mul(fe_load<1, 5>(pts_in + i * UV_WORDS + NL), z));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (i == 0) enc[0][j] = e[j];
+      if (i == 1) enc[1][j] = e[j];
+      if (i == 2) enc[2][j] = e[j];
+      if (i == 3) enc[3][j] = e[j];
+    }
+  }
+  uint32_t pts[5][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    pts[0][j] = enc[1][j];      // pk = sk*G
+    pts[1][j] = h_enc[j];
+    pts[2][j] = enc[0][j];      // Gamma = sk*H
+    pts[3][j] = enc[3][j];      // k*G
+    pts[4][j] = enc[2][j];      // k*H
+  }
+  uint32_t c[8], cs[8], s[8];
+  challenge5<S>(c, pts, ad, ad_len);
+  fr_mul<S>(cs, c, sk);
+  fr_add<S>(s, cs, k);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    gamma_out[j] = pts[2][j]; c_out[j] = c[j]; s_out[j] = s[j]; pk_out[j] = pts[0][j];
+  }
 }
 
 // [ref src/lib.rs:15 `Output::hash` / utils::point_to_hash_rfc_9381]  SURVEY.md A.4:
@@ -521,6 +610,15 @@ VRF_HD void secret_from_seed_item(uint32_t sk[8], const uint8_t* seed, uint32_t 
   uint32_t le[16];
   sha512_le512(le, h);
   fr_reduce512<S>(sk, le);
+}
+
+// [ref src/lib.rs:16 `Secret::public`]  pk = sk*G via the fixed-base comb, encoded.
+template <class S>
+VRF_HD void public_from_secret_item(uint32_t pk[8], const DevTables& T, const uint32_t sk[8]) {
+  PtE p = comb_mul<S>(T.g_comb, sk);
+  FeN x, y;
+  te_to_affine(x, y, p);
+  te_encode_affine(pk, x, y);
 }
 
 }  // namespace vrf

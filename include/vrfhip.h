@@ -1,0 +1,155 @@
+/* vrfhip.h -- C ABI of libvrfhip: MI355X-native batch EC-VRF prove / verify.
+ *
+ * This is the drop-in boundary for the hot path of the `ark-ec-vrfs` / `ark-vrf` Rust API.
+ * The reference (/root/reference) has no FFI of its own: its whole surface is the re-export
+ * list at src/lib.rs:13-17.  Each entry point below names the Rust item of that list it
+ * replaces; INTEGRATION.md shows the `extern "C"` block and the safe Rust wrapper a maintainer
+ * would add to route batches through this library.
+ *
+ * Conventions
+ *  - All arrays are struct-of-arrays, item-major, caller-allocated.
+ *  - Points travel in the ArkworksCodec wire format (`codec`, src/lib.rs:14): 32 bytes,
+ *    y little-endian, bit 255 = (x > q - x).  Scalars: 32 bytes little-endian, canonical (< r).
+ *  - `*_dev` entry points take DEVICE pointers (hipMalloc'ed / torch CUDA tensors) and a
+ *    hipStream_t passed as void*; they enqueue work and return without synchronising.
+ *    The plain entry points take HOST pointers, copy in, run, copy out and synchronise.
+ *  - `ad` (additional data): one blob.  If `ad_off` is NULL every item uses the whole blob
+ *    (`ad_len` bytes); otherwise item i uses blob[ad_off[i] .. ad_off[i+1]) (n+1 offsets).
+ *  - Return value: 0 on success, negative vrfhip_error on API / runtime failure (no partial
+ *    output guarantee).  Per-item outcomes go to a status byte array mirroring `Error`
+ *    (src/lib.rs:15): 0 = Ok, 1 = VerificationFailure, 2 = InvalidData.
+ *  - Thread safety: a context may be shared; calls on one context serialise internally.
+ *  - Precondition (as for the reference's `AffinePoint` values, which arkworks validates on
+ *    deserialisation): input points lie in the prime-order subgroup.  Undecodable encodings
+ *    and non-canonical scalars are reported as InvalidData; subgroup membership is checked by
+ *    vrfhip_point_validate_batch (`codec`), not inside verify.
+ */
+#ifndef VRFHIP_H
+#define VRFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRFHIP_POINT_BYTES 32
+#define VRFHIP_SCALAR_BYTES 32
+#define VRFHIP_HASH_BYTES 64
+
+typedef enum vrfhip_suite {
+  VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2 = 1 /* `suites::bandersnatch` (src/lib.rs:14) */
+} vrfhip_suite;
+
+typedef enum vrfhip_status {
+  VRFHIP_ST_OK = 0,
+  VRFHIP_ST_VERIFICATION_FAILURE = 1, /* Error::VerificationFailure */
+  VRFHIP_ST_INVALID_DATA = 2          /* Error::InvalidData */
+} vrfhip_status;
+
+typedef enum vrfhip_error {
+  VRFHIP_SUCCESS = 0,
+  VRFHIP_ERR_BAD_ARG = -1,
+  VRFHIP_ERR_HIP = -2,
+  VRFHIP_ERR_NO_DEVICE = -3,
+  VRFHIP_ERR_OOM = -4,
+  VRFHIP_ERR_UNSUPPORTED = -5
+} vrfhip_error;
+
+typedef struct vrfhip_ctx vrfhip_ctx;
+
+/* Library / context ------------------------------------------------------------------- */
+
+/* ABI version of this header (major*100 + minor). */
+int32_t vrfhip_abi_version(void);
+
+/* Last error text for this thread ("" if none). */
+const char* vrfhip_last_error(void);
+
+/* Create a context on HIP device `device` for `suite`: uploads the square-root tables and
+ * builds the fixed-base tables of G (and of the Pedersen blinding base) on the GPU.
+ * Replaces the compile-time `Suite` selection (src/lib.rs:16). */
+int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out);
+void vrfhip_ctx_destroy(vrfhip_ctx* ctx);
+
+/* Pre-size the internal HBM workspace for batches of up to `max_items` (optional; the
+ * workspace otherwise grows on demand; batches larger than the workspace are chunked). */
+int32_t vrfhip_ctx_reserve(vrfhip_ctx* ctx, size_t max_items);
+
+/* Bytes of device workspace currently held by the context. */
+size_t vrfhip_ctx_workspace_bytes(const vrfhip_ctx* ctx);
+
+/* IETF VRF ---------------------------------------------------------------------------- */
+
+/* `ietf::Verifier::verify(&public, input, output, ad, &proof)` for n items (src/lib.rs:14).
+ * pk, input (H), output (Gamma): n x 32 B points; c, s: n x 32 B proof scalars.
+ * status: n bytes (vrfhip_status). */
+int32_t vrfhip_ietf_verify_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* input,
+                                 const uint8_t* output, const uint8_t* c, const uint8_t* s,
+                                 const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                 uint8_t* status);
+int32_t vrfhip_ietf_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_pk,
+                                     const uint8_t* d_input, const uint8_t* d_output,
+                                     const uint8_t* d_c, const uint8_t* d_s, const uint8_t* d_ad,
+                                     const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_status,
+                                     void* stream);
+
+/* `Input::new(msg)` + `Secret::output` + `ietf::Prover::prove` for n items (src/lib.rs:14-16).
+ * sk: n x 32 B secret scalars.  Messages: blob `msg`; if msg_off is NULL item i is
+ * msg[i*msg_len .. (i+1)*msg_len), else msg[msg_off[i] .. msg_off[i+1]).
+ * If `input` is non-NULL it holds n pre-hashed inputs H (32 B points) and msg is ignored.
+ * Outputs (each n x 32 B; any of pk_out / input_out may be NULL): output (Gamma), proof c,
+ * proof s, the public key sk*G and the input point H.  status: n bytes. */
+int32_t vrfhip_ietf_prove_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* sk, const uint8_t* msg,
+                                const uint32_t* msg_off, uint32_t msg_len, const uint8_t* input,
+                                const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                uint8_t* output, uint8_t* c, uint8_t* s, uint8_t* pk_out,
+                                uint8_t* input_out, uint8_t* status);
+int32_t vrfhip_ietf_prove_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_sk,
+                                    const uint8_t* d_msg, const uint32_t* d_msg_off,
+                                    uint32_t msg_len, const uint8_t* d_input, const uint8_t* d_ad,
+                                    const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_output,
+                                    uint8_t* d_c, uint8_t* d_s, uint8_t* d_pk_out,
+                                    uint8_t* d_input_out, uint8_t* d_status, void* stream);
+
+/* Building blocks --------------------------------------------------------------------- */
+
+/* `Input::new(data)` = Suite::data_to_point = hash_to_curve_ell2_rfc_9380 (src/lib.rs:14-16):
+ * n messages -> n x 32 B points. */
+int32_t vrfhip_hash_to_curve_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* msg,
+                                   const uint32_t* msg_off, uint32_t msg_len, uint8_t* points);
+int32_t vrfhip_hash_to_curve_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_msg,
+                                       const uint32_t* d_msg_off, uint32_t msg_len,
+                                       uint8_t* d_points, void* stream);
+
+/* `Output::hash()` = point_to_hash_rfc_9381 (src/lib.rs:15): n x 32 B Gamma -> n x 64 B. */
+int32_t vrfhip_output_hash_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* output, uint8_t* hash);
+int32_t vrfhip_output_hash_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_output,
+                                     uint8_t* d_hash, void* stream);
+
+/* `Secret::from_seed(seed)` + `Secret::public()` (src/lib.rs:16): seeds are fixed-stride
+ * (seed_len bytes each).  sk_out, pk_out: n x 32 B (pk_out may be NULL). */
+int32_t vrfhip_secret_from_seed_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* seeds,
+                                      uint32_t seed_len, uint8_t* sk_out, uint8_t* pk_out);
+int32_t vrfhip_secret_from_seed_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_seeds,
+                                          uint32_t seed_len, uint8_t* d_sk_out, uint8_t* d_pk_out,
+                                          void* stream);
+
+/* `codec::point_decode` with arkworks' checked-deserialisation semantics (src/lib.rs:14):
+ * status[i] = 0 if points[i] decodes to a curve point of the prime-order subgroup, else 2.
+ * If xy_out is non-NULL it receives n x 64 B affine coordinates (x || y, little-endian). */
+int32_t vrfhip_point_validate_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* points,
+                                    uint8_t* xy_out, uint8_t* status);
+int32_t vrfhip_point_validate_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_points,
+                                        uint8_t* d_xy_out, uint8_t* d_status, void* stream);
+
+/* Test-only primitive: r[i] = a[i] * b[i] mod q on n x 32 B little-endian field elements
+ * (exercises ark_ff::Fp mul through the 29-bit Montgomery pipeline). */
+int32_t vrfhip_fq_mul_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b,
+                            uint8_t* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRFHIP_H */

@@ -84,8 +84,11 @@ uint32_t hs_ietf_verify(const uint8_t* pk, const uint8_t* h, const uint8_t* g, c
                         const uint8_t* s, const uint8_t* ad, uint32_t ad_len) {
   uint32_t w[5][8];
   memcpy(w[0], pk, 32); memcpy(w[1], h, 32); memcpy(w[2], g, 32); memcpy(w[3], c, 32); memcpy(w[4], s, 32);
-  std::vector<uint32_t> scratch(3 * WIN_TABLE_WORDS);
-  return ietf_verify_item<SuiteBS>(HT().t, w[0], w[1], w[2], w[3], w[4], ad, ad_len, scratch.data());
+  std::vector<uint32_t> tabs(3 * WIN_TABLE_WORDS), uv(2 * UV_WORDS);
+  bool valid = verify_decode_item<SuiteBS>(HT().t, w[0], w[1], w[2], tabs.data());
+  for (int half = 0; half < 2; ++half)
+    verify_straus_item<SuiteBS>(uv.data() + half * UV_WORDS, HT().t, tabs.data(), w[3], w[4], half);
+  return verify_finish_item<SuiteBS>(uv.data(), w[0], w[1], w[2], w[3], w[4], valid, ad, ad_len);
 }
 void hs_hash_to_curve(const uint8_t* msg, uint32_t len, uint8_t* out) {
   PtE h = hash_to_curve_ell2<SuiteBS>(msg, len, HT().t.sq);
@@ -95,15 +98,22 @@ void hs_hash_to_curve(const uint8_t* msg, uint32_t len, uint8_t* out) {
 void hs_h2f(const uint8_t* msg, uint32_t len, uint8_t* u0, uint8_t* u1) {
   Fe<1,4> a, b; hash_to_field2<SuiteBS>(a, b, msg, len); out(u0, a); out(u1, b);
 }
-void hs_ietf_prove(const uint8_t* sk, const uint8_t* msg, uint32_t len, const uint8_t* ad, uint32_t ad_len,
-                   uint8_t* gamma, uint8_t* c, uint8_t* s, uint8_t* h, uint8_t* pk) {
-  PtE hp = hash_to_curve_ell2<SuiteBS>(msg, len, HT().t.sq);
-  FeN x, y; te_to_affine(x, y, hp);
+int hs_ietf_prove(const uint8_t* sk, const uint8_t* msg, uint32_t len, const uint8_t* h_given,
+                  const uint8_t* ad, uint32_t ad_len,
+                  uint8_t* gamma, uint8_t* c, uint8_t* s, uint8_t* h, uint8_t* pk) {
   uint32_t skw[8]; memcpy(skw, sk, 32);
-  uint32_t o[5][8];
-  std::vector<uint32_t> scratch(WIN_TABLE_WORDS);
-  ietf_prove_core<SuiteBS>(o[0], o[1], o[2], o[3], o[4], HT().t, skw, x, y, ad, ad_len, scratch.data());
-  memcpy(gamma, o[0], 32); memcpy(c, o[1], 32); memcpy(s, o[2], 32); memcpy(h, o[3], 32); memcpy(pk, o[4], 32);
+  uint32_t hg[8]; if (h_given) memcpy(hg, h_given, 32);
+  uint32_t h_enc[8], k[8], o[4][8];
+  std::vector<uint32_t> tab(WIN_TABLE_WORDS), pts(PROVE_PTS_WORDS);
+  bool valid = prove_prepare_item<SuiteBS>(h_enc, k, tab.data(), HT().t, skw, msg, len, h_given ? hg : nullptr);
+  prove_mul_item<SuiteBS>(pts.data(), HT().t, tab.data(), skw);
+  prove_mul_item<SuiteBS>(pts.data() + 2 * UV_WORDS, HT().t, tab.data(), k);
+  prove_finish_item<SuiteBS>(o[0], o[1], o[2], o[3], pts.data(), h_enc, skw, k, ad, ad_len);
+  memcpy(gamma, o[0], 32); memcpy(c, o[1], 32); memcpy(s, o[2], 32); memcpy(h, h_enc, 32); memcpy(pk, o[3], 32);
+  return valid;
+}
+void hs_public(const uint8_t* sk, uint8_t* pk) {
+  uint32_t skw[8], o[8]; memcpy(skw, sk, 32); public_from_secret_item<SuiteBS>(o, HT().t, skw); memcpy(pk, o, 32);
 }
 void hs_sha512(const uint8_t* msg, uint32_t len, uint8_t* out) {
   Sha512 h; sha512_init(h); sha512_put_bytes(h, msg, len); sha512_final(h);
