@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvrfhip.so")
 # Every symbol include/vrfhip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "vrfhip_abi_version", "vrfhip_last_error", "vrfhip_ctx_create", "vrfhip_ctx_destroy",
-    "vrfhip_ctx_reserve", "vrfhip_ctx_workspace_bytes",
+    "vrfhip_ctx_reserve", "vrfhip_ctx_workspace_bytes", "vrfhip_ctx_profile", "vrfhip_ctx_profile_read",
     "vrfhip_ietf_verify_batch", "vrfhip_ietf_verify_batch_dev",
     "vrfhip_ietf_prove_batch", "vrfhip_ietf_prove_batch_dev",
     "vrfhip_hash_to_curve_batch", "vrfhip_hash_to_curve_batch_dev",
@@ -61,6 +61,8 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_ctx_reserve.restype = c_int32
     lib.vrfhip_ctx_workspace_bytes.argtypes = [c_void_p]
     lib.vrfhip_ctx_workspace_bytes.restype = c_size_t
+    lib.vrfhip_ctx_profile.argtypes = [c_void_p, c_int32]
+    lib.vrfhip_ctx_profile_read.argtypes = [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_uint64)]
     P = c_void_p  # raw addresses (host buffers or device pointers)
     lib.vrfhip_ietf_verify_batch.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P]
     lib.vrfhip_ietf_verify_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P, c_void_p]

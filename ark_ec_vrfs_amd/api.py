@@ -100,6 +100,17 @@ class Context:
     def reserve(self, max_items: int) -> None:
         _lib.check(self._lib.vrfhip_ctx_reserve(self._h, max_items), "vrfhip_ctx_reserve")
 
+    def profile(self, enable: bool) -> None:
+        """Record hipEvents around the three kernels of every prove/verify launch group."""
+        _lib.check(self._lib.vrfhip_ctx_profile(self._h, int(enable)), "vrfhip_ctx_profile")
+
+    def profile_read(self):
+        """-> ([ms_stage1, ms_stage2, ms_stage3] summed over launch groups, n_launch_groups)."""
+        ms = (ctypes.c_double * 3)()
+        n = ctypes.c_uint64()
+        _lib.check(self._lib.vrfhip_ctx_profile_read(self._h, ms, ctypes.byref(n)), "vrfhip_ctx_profile_read")
+        return [ms[0], ms[1], ms[2]], int(n.value)
+
     def workspace_bytes(self) -> int:
         return int(self._lib.vrfhip_ctx_workspace_bytes(self._h))
 

@@ -51,8 +51,12 @@ struct vrfhip_ctx {
   // workspace
   void* d_ws = nullptr;
   size_t ws_cap = 0;                 // items
+  size_t chunk_limit = DEFAULT_CHUNK; // largest number of items processed per launch group
   size_t ws_bytes = 0;
   Workspace ws{};
+  // optional per-stage timing (hipEvents on the launch stream), see vrfhip_ctx_profile
+  bool prof = false;
+  std::vector<hipEvent_t> prof_ev;   // 4 per launch group
   // staging for the host-pointer entry points
   void* d_stage = nullptr;
   size_t stage_bytes = 0;
@@ -95,10 +99,10 @@ int32_t alloc_workspace(vrfhip_ctx* ctx, size_t cap) {
   return VRFHIP_SUCCESS;
 }
 
-// workspace for a batch of `items`: at most max(DEFAULT_CHUNK, reserved) items, larger batches
-// are processed in chunks of ws_cap
+// workspace for a batch of `items`: at most chunk_limit items; larger batches are processed in
+// chunks of ws_cap
 int32_t ensure_workspace(vrfhip_ctx* ctx, size_t items) {
-  size_t want = std::min(items, std::max<size_t>(DEFAULT_CHUNK, ctx->ws_cap));
+  size_t want = std::min(items, ctx->chunk_limit);
   if (want <= ctx->ws_cap) return VRFHIP_SUCCESS;
   return alloc_workspace(ctx, want);
 }
@@ -127,6 +131,19 @@ struct Stage {
     return p;
   }
 };
+
+// four fresh events for one launch group when profiling is on, else nullptr
+hipEvent_t* prof_events(vrfhip_ctx* ctx) {
+  if (!ctx->prof) return nullptr;
+  size_t base = ctx->prof_ev.size();
+  ctx->prof_ev.resize(base + 4);
+  for (int i = 0; i < 4; ++i)
+    if (hipEventCreate(&ctx->prof_ev[base + i]) != hipSuccess) {
+      ctx->prof_ev.resize(base);
+      return nullptr;
+    }
+  return ctx->prof_ev.data() + base;
+}
 
 BytesView make_view(const uint8_t* blob, const uint32_t* off, uint32_t len, bool shared) {
   BytesView v;
@@ -206,6 +223,7 @@ void vrfhip_ctx_destroy(vrfhip_ctx* ctx) {
   {
     DeviceGuard guard(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_sqrt_p) (void)hipFree(ctx->d_sqrt_p);
@@ -222,11 +240,39 @@ int32_t vrfhip_ctx_reserve(vrfhip_ctx* ctx, size_t max_items) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  if (max_items > ctx->ws_cap) return alloc_workspace(ctx, max_items);
+  if (max_items == 0) return fail(VRFHIP_ERR_BAD_ARG, "max_items is 0");
+  ctx->chunk_limit = max_items;
+  if (max_items != ctx->ws_cap) return alloc_workspace(ctx, max_items);
   return VRFHIP_SUCCESS;
 }
 
 size_t vrfhip_ctx_workspace_bytes(const vrfhip_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
+
+int32_t vrfhip_ctx_profile(vrfhip_ctx* ctx, int32_t enable) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  ctx->prof = enable != 0;
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_ctx_profile_read(vrfhip_ctx* ctx, double stage_ms[3], uint64_t* launches) {
+  if (!ctx || !stage_ms || !launches) return fail(VRFHIP_ERR_BAD_ARG, "NULL argument");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  stage_ms[0] = stage_ms[1] = stage_ms[2] = 0.0;
+  *launches = ctx->prof_ev.size() / 4;
+  for (size_t g = 0; g + 3 < ctx->prof_ev.size(); g += 4) {
+    HIP_TRY(hipEventSynchronize(ctx->prof_ev[g + 3]));
+    for (int k = 0; k < 3; ++k) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_ev[g + k], ctx->prof_ev[g + k + 1]));
+      stage_ms[k] += ms;
+    }
+  }
+  for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+  ctx->prof_ev.clear();
+  return VRFHIP_SUCCESS;
+}
 
 // ------------------------------------------------------------------------- IETF verify
 int32_t vrfhip_ietf_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_pk,
@@ -254,7 +300,7 @@ int32_t vrfhip_ietf_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d
     a.status = d_status + base;
     a.ws = ctx->ws;
     a.T = ctx->T;
-    launch_ietf_verify(a, st);
+    launch_ietf_verify(a, st, prof_events(ctx));
   }
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
@@ -331,7 +377,7 @@ int32_t vrfhip_ietf_prove_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_
     a.status = d_status ? d_status + base : nullptr;
     a.ws = ctx->ws;
     a.T = ctx->T;
-    launch_ietf_prove(a, st);
+    launch_ietf_prove(a, st, prof_events(ctx));
   }
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;

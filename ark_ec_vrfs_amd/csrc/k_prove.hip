@@ -64,11 +64,15 @@ __global__ void __launch_bounds__(BLOCK) k_prove_finish(ProveArgs a) {
   if (a.status) a.status[i] = ok ? ST_OK : ST_INVALID_DATA;
 }
 
-void launch_ietf_prove(const ProveArgs& a, hipStream_t st) {
+void launch_ietf_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (a.n == 0) return;
+  if (ev) (void)hipEventRecord(ev[0], st);
   hipLaunchKernelGGL(k_prove_prepare, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[1], st);
   hipLaunchKernelGGL(k_prove_mul, grid_for(2 * a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[2], st);
   hipLaunchKernelGGL(k_prove_finish, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[3], st);
 }
 
 }  // namespace vrf

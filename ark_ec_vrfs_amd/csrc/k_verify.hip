@@ -40,11 +40,15 @@ __global__ void __launch_bounds__(BLOCK) k_verify_finish(VerifyArgs a) {
   a.status[i] = (uint8_t)st;
 }
 
-void launch_ietf_verify(const VerifyArgs& a, hipStream_t st) {
+void launch_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (a.n == 0) return;
+  if (ev) (void)hipEventRecord(ev[0], st);
   hipLaunchKernelGGL(k_verify_decode, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[1], st);
   hipLaunchKernelGGL(k_verify_straus, grid_for(2 * a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[2], st);
   hipLaunchKernelGGL(k_verify_finish, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[3], st);
 }
 
 }  // namespace vrf

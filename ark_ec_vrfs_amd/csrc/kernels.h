@@ -57,8 +57,9 @@ struct ProveArgs {
 
 // launchers (each defined next to its kernels)
 void launch_init_tables(uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, hipStream_t st);
-void launch_ietf_verify(const VerifyArgs& a, hipStream_t st);
-void launch_ietf_prove(const ProveArgs& a, hipStream_t st);
+// ev: optional 4 events recorded on `st` before stage 1 and after stages 1, 2, 3 (profiling)
+void launch_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
+void launch_ietf_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
 void launch_hash_to_curve(size_t n, BytesView msg, uint8_t* points, DevTables T, hipStream_t st);
 void launch_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash, hipStream_t st);
 void launch_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk,

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: batch 2^20 Bandersnatch IETF-ECVRF verification on MI355X.
+
+A "step" is one pass of the verify hot path (vrfhip_ietf_verify_batch_dev: decode -> Straus ->
+finish) over one batch of 2^20 synthetic proofs per GPU that already sit in HBM (SURVEY.md
+section 8d: seed_i = u64_le(i), sk_i = from_seed, msg_i = SHA512("vrfhip-msg" || u64_le(i))[..32],
+ad = "").  The proofs themselves are produced by the GPU prove path before the timed region.
+N > 1: one process per GPU (torch.distributed / RCCL); every rank verifies its own 2^20 items
+(weak scaling), the only collective is the gather of the status bytes.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_verify_straus) against
+HBM as the contract asks -- the path is VALU-integer bound, so `valu` gives the meaningful
+ceiling: executed vector instructions per second against the measured v_mad_u64_u32 issue peak.
+`cpu_baseline` times the plain-C oracle (oracle/c, kind "port") on this box's host cores.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOG2_BATCH = 20
+BYTES_PER_VERIFY = 161            # pk 32 + H 32 + Gamma 32 + c 32 + s 32 in, 1 status byte out
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s
+VALU_INT_PEAK = 256 * 4 * 16 * 2.4e9   # lanes/s: 256 CU x 4 SIMD x 16 int lanes/clk x 2.4 GHz (microbench: profiles/r01_instr_rate_microbench.jsonl)
+
+
+def synth_msgs(lo, n):
+    out = np.empty((n, 32), dtype=np.uint8)
+    pre = b"vrfhip-msg"
+    for k in range(n):
+        out[k] = np.frombuffer(hashlib.sha512(pre + int(lo + k).to_bytes(8, "little")).digest()[:32], np.uint8)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2-batch", type=int, default=LOG2_BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ark_ec_vrfs_amd import Context, _lib
+    from ark_ec_vrfs_amd.sharding import gather_results
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n = 1 << args.log2_batch
+    lo = rank * n                                  # weak scaling: rank g owns items [g*n, (g+1)*n)
+    ctx = Context(local)
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- synthetic inputs, produced on the GPU and left resident in HBM ----
+    seeds = (torch.arange(n, dtype=torch.int64, device=dev) + lo).view(torch.uint8).reshape(n, 8)
+    sk = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    _lib.check(lib.vrfhip_secret_from_seed_batch_dev(ctx.handle, n, seeds.data_ptr(), 8, sk.data_ptr(), None, stream), "seed")
+    msg = torch.from_numpy(synth_msgs(lo, n)).to(dev)
+    mk = lambda: torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    gamma, c, s, pk, hh = mk(), mk(), mk(), mk(), mk()
+    pst = torch.empty(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.ietf_prove_batch_dev(sk, msg, 32, gamma, c, s, pk, hh, pst)
+    torch.cuda.synchronize()
+    prove_s = time.perf_counter() - t0             # includes first-touch of the workspace
+    t0 = time.perf_counter()
+    ctx.ietf_prove_batch_dev(sk, msg, 32, gamma, c, s, pk, hh, pst)
+    torch.cuda.synchronize()
+    prove_s = min(prove_s, time.perf_counter() - t0)
+    assert int(pst.sum()) == 0
+    status = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+
+    def step():
+        ctx.ietf_verify_batch_dev(pk, hh, gamma, c, s, status)
+        if world > 1:
+            return gather_results(status, world * n, rank, world)   # RCCL: result gather only
+        return status
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx.profile(False)
+    stage_ms, groups = ctx.profile_read()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_bad = int((full != 0).sum())
+    assert n_bad == 0, f"{n_bad} synthetic proofs failed to verify"
+
+    if rank == 0:
+        total_items = world * n * args.steps
+        value = total_items / elapsed
+        straus_s = stage_ms[1] / max(groups, 1) / 1e3          # average launch duration of k_verify_straus
+        achieved_gbs = BYTES_PER_VERIFY * n / straus_s / 1e9
+        # measured constants of the same command line (rocprofv3 --pmc passes, see profiles/)
+        traffic = None
+        valu = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_k_verify_straus.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+            if pmc.get("log2_batch") == args.log2_batch:
+                traffic = pmc.get("hbm_bytes_per_launch")
+                lanes = pmc.get("valu_lane_instructions_per_launch")
+                if lanes:
+                    valu = {"bound": "valu_int", "achieved": lanes / straus_s, "peak": VALU_INT_PEAK,
+                            "unit": "lane-instr/s", "frac": lanes / straus_s / VALU_INT_PEAK,
+                            "source": pmc.get("source")}
+        out = {
+            "metric": "Bandersnatch IETF-ECVRF verifies/sec, 2^%d batch per GPU" % args.log2_batch,
+            "value": value, "unit": "verifies/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "IETF ECVRF verify, Bandersnatch_SHA-512_ELL2, batch 2^%d per GPU, compressed "
+                                   "points (161 B/verify), ad=\"\" (BASELINE.json configs[2])" % args.log2_batch,
+                       "global_batch": world * n, "parallelism": "items sharded x%d, result gather only" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_verify_straus", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": straus_s * 1e3, "launches_timed": groups},
+            "valu": valu,
+            "stage_ms_per_step": {"decode": stage_ms[0] / max(groups, 1), "straus": stage_ms[1] / max(groups, 1),
+                                  "finish": stage_ms[2] / max(groups, 1)},
+            "proofs_per_sec": n / prove_s,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, pk, hh, gamma, c, s, status)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def cpu_baseline(args, pk, hh, gamma, c, s, status):
+    """The plain-C oracle (a port, not arkworks) on this box's host cores, bounded sample of the same batch."""
+    from oracle import c_oracle as co
+    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    host = lambda t, m: t[:m].cpu().numpy()
+    probe = 64 * cores
+    t0 = time.perf_counter()
+    st = co.ietf_verify_batch(host(pk, probe), host(hh, probe), host(gamma, probe), host(c, probe), host(s, probe), b"", threads=cores)
+    rate = probe / (time.perf_counter() - t0)
+    m = int(min(1 << 16, max(probe, rate * args.cpu_seconds)))
+    t0 = time.perf_counter()
+    st = co.ietf_verify_batch(host(pk, m), host(hh, m), host(gamma, m), host(c, m), host(s, m), b"", threads=cores)
+    dt = time.perf_counter() - t0
+    assert (st == status[:m].cpu().numpy()).all(), "GPU statuses differ from the CPU oracle on the sample"
+    t0 = time.perf_counter()
+    m1 = max(64, int(m / cores / 8))
+    co.ietf_verify_batch(host(pk, m1), host(hh, m1), host(gamma, m1), host(c, m1), host(s, m1), b"", threads=1)
+    dt1 = time.perf_counter() - t0
+    return {"value": m / dt, "unit": "verifies/s", "cores": cores, "kind": "port",
+            "sample": "first %d items of the same 2^%d batch, %.1f s wall on %d threads; statuses equal the GPU's" % (m, args.log2_batch, dt, cores),
+            "single_core": m1 / dt1,
+            "note": "CPU restatement in C (oracle/c/oracle_vrf.c), not arkworks: no Rust toolchain on this box"}
+
+
+if __name__ == "__main__":
+    main()

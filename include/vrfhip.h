@@ -73,12 +73,20 @@ const char* vrfhip_last_error(void);
 int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out);
 void vrfhip_ctx_destroy(vrfhip_ctx* ctx);
 
-/* Pre-size the internal HBM workspace for batches of up to `max_items` (optional; the
- * workspace otherwise grows on demand; batches larger than the workspace are chunked). */
+/* Size the internal HBM workspace for exactly `max_items` items per launch group (optional).
+ * Larger batches are processed in chunks of `max_items`.  Without this call the workspace
+ * grows on demand up to 2^20 items (about 3.7 KiB of HBM per item). */
 int32_t vrfhip_ctx_reserve(vrfhip_ctx* ctx, size_t max_items);
 
 /* Bytes of device workspace currently held by the context. */
 size_t vrfhip_ctx_workspace_bytes(const vrfhip_ctx* ctx);
+
+/* Per-stage device timing.  While enabled, every prove / verify launch group records hipEvents
+ * on its launch stream around its three kernels (decode|prepare, straus|mul, finish).
+ * vrfhip_ctx_profile_read waits for the recorded events, returns the summed milliseconds per
+ * stage and the number of launch groups, and clears the record. */
+int32_t vrfhip_ctx_profile(vrfhip_ctx* ctx, int32_t enable);
+int32_t vrfhip_ctx_profile_read(vrfhip_ctx* ctx, double stage_ms[3], uint64_t* launches);
 
 /* IETF VRF ---------------------------------------------------------------------------- */
 

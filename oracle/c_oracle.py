@@ -1,0 +1,129 @@
+"""ctypes wrapper of oracle/c/liboracle_vrf.so (plain-C CPU restatement).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_int, c_size_t, c_void_p
+
+import numpy as np
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c")
+LIB_PATH = os.path.join(_DIR, "liboracle_vrf.so")
+_lib = None
+
+
+def build() -> None:
+    subprocess.run(["make", "-C", _DIR], check=True, stdout=subprocess.DEVNULL)
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        lib = ctypes.CDLL(LIB_PATH)
+        P = c_void_p
+        lib.oracle_ietf_verify_batch.argtypes = [c_size_t, P, P, P, P, P, P, c_size_t, P, c_int]
+        lib.oracle_ietf_verify_batch.restype = None
+        lib.oracle_ietf_prove_batch.argtypes = [c_size_t, P, P, c_size_t, P, P, c_size_t, P, P, P, P, P, P, c_int]
+        lib.oracle_ietf_prove_batch.restype = None
+        lib.oracle_hash_to_curve.argtypes = [P, c_size_t, P]
+        lib.oracle_output_hash.argtypes = [P, P]
+        lib.oracle_secret_from_seed.argtypes = [P, c_size_t, P]
+        lib.oracle_public_from_secret.argtypes = [P, P]
+        lib.oracle_point_decode.argtypes = [P, c_int, P]
+        lib.oracle_point_decode.restype = c_int
+        lib.oracle_fq_mul.argtypes = [P, P, P]
+        lib.oracle_sha512.argtypes = [P, c_size_t, P]
+        _lib = lib
+    return _lib
+
+
+def _a(x):
+    return np.ascontiguousarray(x, dtype=np.uint8)
+
+
+def ietf_verify_batch(pk, h, gamma, c, s, ad: bytes = b"", threads: int = 1) -> np.ndarray:
+    pk, h, gamma, c, s = (_a(x).reshape(-1, 32) for x in (pk, h, gamma, c, s))
+    n = pk.shape[0]
+    st = np.empty(n, dtype=np.uint8)
+    adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
+    load().oracle_ietf_verify_batch(n, pk.ctypes.data, h.ctypes.data, gamma.ctypes.data, c.ctypes.data,
+                                    s.ctypes.data, adb.ctypes.data, len(ad), st.ctypes.data, threads)
+    return st
+
+
+def ietf_prove_batch(sk, msgs: np.ndarray = None, inputs=None, ad: bytes = b"", threads: int = 1):
+    sk = _a(sk).reshape(-1, 32)
+    n = sk.shape[0]
+    res = {k: np.empty((n, 32), dtype=np.uint8) for k in ("output", "c", "s", "pk", "input")}
+    st = np.empty(n, dtype=np.uint8)
+    adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
+    mp, ml, ip = None, 0, None
+    if inputs is not None:
+        inputs = _a(inputs).reshape(n, 32)
+        ip = inputs.ctypes.data
+    else:
+        msgs = _a(msgs).reshape(n, -1)
+        ml = msgs.shape[1]
+        msgs = np.concatenate([msgs.reshape(-1), np.zeros(1, np.uint8)])
+        mp = msgs.ctypes.data
+    load().oracle_ietf_prove_batch(n, sk.ctypes.data, mp, ml, ip, adb.ctypes.data, len(ad),
+                                   res["output"].ctypes.data, res["c"].ctypes.data, res["s"].ctypes.data,
+                                   res["pk"].ctypes.data, res["input"].ctypes.data, st.ctypes.data, threads)
+    res["status"] = st
+    return res
+
+
+def hash_to_curve(msg: bytes) -> bytes:
+    out = np.empty(32, np.uint8)
+    m = np.frombuffer(bytes(msg) + b"\0", np.uint8)
+    load().oracle_hash_to_curve(m.ctypes.data, len(msg), out.ctypes.data)
+    return out.tobytes()
+
+
+def output_hash(gamma: bytes) -> bytes:
+    out = np.empty(64, np.uint8)
+    g = np.frombuffer(bytes(gamma), np.uint8)
+    load().oracle_output_hash(g.ctypes.data, out.ctypes.data)
+    return out.tobytes()
+
+
+def secret_from_seed(seed: bytes) -> bytes:
+    out = np.empty(32, np.uint8)
+    m = np.frombuffer(bytes(seed) + b"\0", np.uint8)
+    load().oracle_secret_from_seed(m.ctypes.data, len(seed), out.ctypes.data)
+    return out.tobytes()
+
+
+def public_from_secret(sk: bytes) -> bytes:
+    out = np.empty(32, np.uint8)
+    m = np.frombuffer(bytes(sk), np.uint8)
+    load().oracle_public_from_secret(m.ctypes.data, out.ctypes.data)
+    return out.tobytes()
+
+
+def point_decode(enc: bytes, subgroup: bool = False):
+    """Returns (x, y) ints or None."""
+    out = np.empty(64, np.uint8)
+    m = np.frombuffer(bytes(enc), np.uint8)
+    rc = load().oracle_point_decode(m.ctypes.data, int(subgroup), out.ctypes.data)
+    if rc != 0:
+        return None
+    return int.from_bytes(out[:32].tobytes(), "little"), int.from_bytes(out[32:].tobytes(), "little")
+
+
+def fq_mul(a: bytes, b: bytes) -> bytes:
+    out = np.empty(32, np.uint8)
+    x, y = np.frombuffer(bytes(a), np.uint8), np.frombuffer(bytes(b), np.uint8)
+    load().oracle_fq_mul(x.ctypes.data, y.ctypes.data, out.ctypes.data)
+    return out.tobytes()
+
+
+def sha512(m: bytes) -> bytes:
+    out = np.empty(64, np.uint8)
+    x = np.frombuffer(bytes(m) + b"\0", np.uint8)
+    load().oracle_sha512(x.ctypes.data, len(m), out.ctypes.data)
+    return out.tobytes()

@@ -241,9 +241,7 @@ def point_decode(S: SuiteParams, b: bytes) -> Optional[Point]:
         return None
     neg = (q - x) % q
     lo, hi = (x, neg) if x <= neg else (neg, x)
-    x = hi if flag else lo
-    if x == 0 and flag:
-        return None
+    x = hi if flag else lo          # x == 0 with the flag set is accepted, as arkworks does
     return (x, y)
 
 

@@ -2,8 +2,9 @@
 // Compiles the __host__ __device__ arithmetic headers of ark_ec_vrfs_amd/csrc for the host so
 // that the exact device source can be unit-tested on a machine without a GPU.  It is never
 // linked into libvrfhip.so and nothing in the product path can reach it.
-#include "../../ark_ec_vrfs_amd/csrc/fe.cuh"
+#include "../../ark_ec_vrfs_amd/csrc/vrf_core.cuh"
 #include <cstring>
+#include <vector>
 using namespace vrf;
 
 static SqrtTables host_tables() {
@@ -11,36 +12,6 @@ static SqrtTables host_tables() {
 }
 static FeN in(const uint8_t* b) { uint32_t w[8]; memcpy(w, b, 32); return fe_from_u256(w); }
 template <int L, int V> static void out(uint8_t* b, const Fe<L, V>& a) { uint32_t w[8]; fe_to_u256(w, a); memcpy(b, w, 32); }
-
-extern "C" {
-void hs_fe_mul(const uint8_t* a, const uint8_t* b, uint8_t* r) { out(r, fe_mul(in(a), in(b))); }
-void hs_fe_sqr(const uint8_t* a, uint8_t* r) { out(r, fe_sqr(in(a))); }
-void hs_fe_add(const uint8_t* a, const uint8_t* b, uint8_t* r) { out(r, fe_add(in(a), in(b))); }
-void hs_fe_sub(const uint8_t* a, const uint8_t* b, uint8_t* r) { out(r, fe_sub(in(a), in(b))); }
-void hs_fe_inv(const uint8_t* a, uint8_t* r) { out(r, fe_inv(in(a))); }
-// stress the lazy bounds: ((a+b)*(a-b) + 5*a*b - b) * (a - (a*b + b)) etc.
-void hs_fe_lazy(const uint8_t* a_, const uint8_t* b_, uint8_t* r) {
-  FeN a = in(a_), b = in(b_);
-  auto s = fe_add(a, b);              // (2,4)
-  auto d = fe_sub(a, b);              // (3,6)
-  auto p = fe_mul(s, d);              // L 6
-  auto ab = fe_mul(a, b);
-  auto t = fe_add(fe_mul5(ab), p);    // (6,12)
-  auto tn = fe_norm(t);
-  auto u2 = fe_sub(tn, b);            // (3, 16)
-  auto w = fe_sub(a, fe_add(ab, b));  // subtrahend L=2: (4, 2+8)
-  out(r, fe_mul(fe_norm(u2), w));
-}
-int hs_fe_sqrt(const uint8_t* a, uint8_t* r) {
-  FeN root; bool sq = fe_sqrt_or_zsqrt(root, in(a), host_tables()); out(r, root); return sq;
-}
-int hs_fe_eq(const uint8_t* a, const uint8_t* b) { return fe_eq(in(a), fe_norm(fe_add(in(b), fe_zero()))); }
-}
-
-// ---------------------------------------------------------------- scheme-level host simulation
-#include "../../ark_ec_vrfs_amd/csrc/vrf_core.cuh"
-#include <vector>
-#include <mutex>
 namespace {
 struct HostTables {
   std::vector<uint32_t> g_win, g_comb;
@@ -80,23 +51,10 @@ int hs_comb_entry_check(int w, int j) {
     if (!fe_eq(fe_load<1, 2>(e + c * NL), fe_load<1, 2>(ref + c * NL))) return 0;
   return 1;
 }
-uint32_t hs_ietf_verify(const uint8_t* pk, const uint8_t* h, const uint8_t* g, const uint8_t* c,
-                        const uint8_t* s, const uint8_t* ad, uint32_t ad_len) {
-  uint32_t w[5][8];
-  memcpy(w[0], pk, 32); memcpy(w[1], h, 32); memcpy(w[2], g, 32); memcpy(w[3], c, 32); memcpy(w[4], s, 32);
-  std::vector<uint32_t> tabs(3 * WIN_TABLE_WORDS), uv(2 * UV_WORDS);
-  bool valid = verify_decode_item<SuiteBS>(HT().t, w[0], w[1], w[2], tabs.data());
-  for (int half = 0; half < 2; ++half)
-    verify_straus_item<SuiteBS>(uv.data() + half * UV_WORDS, HT().t, tabs.data(), w[3], w[4], half);
-  return verify_finish_item<SuiteBS>(uv.data(), w[0], w[1], w[2], w[3], w[4], valid, ad, ad_len);
-}
 void hs_hash_to_curve(const uint8_t* msg, uint32_t len, uint8_t* out) {
   PtE h = hash_to_curve_ell2<SuiteBS>(msg, len, HT().t.sq);
   FeN x, y; te_to_affine(x, y, h);
   uint32_t e[8]; te_encode_affine(e, x, y); memcpy(out, e, 32);
-}
-void hs_h2f(const uint8_t* msg, uint32_t len, uint8_t* u0, uint8_t* u1) {
-  Fe<1,4> a, b; hash_to_field2<SuiteBS>(a, b, msg, len); out(u0, a); out(u1, b);
 }
 int hs_ietf_prove(const uint8_t* sk, const uint8_t* msg, uint32_t len, const uint8_t* h_given,
                   const uint8_t* ad, uint32_t ad_len,
@@ -114,22 +72,5 @@ int hs_ietf_prove(const uint8_t* sk, const uint8_t* msg, uint32_t len, const uin
 }
 void hs_public(const uint8_t* sk, uint8_t* pk) {
   uint32_t skw[8], o[8]; memcpy(skw, sk, 32); public_from_secret_item<SuiteBS>(o, HT().t, skw); memcpy(pk, o, 32);
-}
-void hs_sha512(const uint8_t* msg, uint32_t len, uint8_t* out) {
-  Sha512 h; sha512_init(h); sha512_put_bytes(h, msg, len); sha512_final(h);
-  for (int j = 0; j < 16; ++j) { uint32_t w = sha512_word_mem(h, j); memcpy(out + 4 * j, &w, 4); }
-}
-void hs_output_hash(const uint8_t* g, uint8_t* out) {
-  uint32_t gw[8], o[16]; memcpy(gw, g, 32); output_hash_item<SuiteBS>(o, gw); memcpy(out, o, 64);
-}
-void hs_secret_from_seed(const uint8_t* seed, uint32_t len, uint8_t* out) {
-  uint32_t sk[8]; secret_from_seed_item<SuiteBS>(sk, seed, len); memcpy(out, sk, 32);
-}
-int hs_decode(const uint8_t* enc, uint8_t* x, uint8_t* y) {
-  uint32_t w[8]; memcpy(w, enc, 32);
-  DecodeA a = decode_phase_a<SuiteBS>(w);
-  FeN di = fe_inv(a.den);
-  Fe<1,4> xx; bool ok = decode_phase_b<SuiteBS>(xx, a, di, HT().t.sq);
-  out(x, xx); out(y, a.y); return ok;
 }
 }

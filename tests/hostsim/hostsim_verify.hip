@@ -1,0 +1,39 @@
+// tests/hostsim -- TEST TOOLING ONLY.
+// Compiles the __host__ __device__ arithmetic headers of ark_ec_vrfs_amd/csrc for the host so
+// that the exact device source can be unit-tested on a machine without a GPU.  It is never
+// linked into libvrfhip.so and nothing in the product path can reach it.
+#include "../../ark_ec_vrfs_amd/csrc/vrf_core.cuh"
+#include <cstring>
+#include <vector>
+using namespace vrf;
+
+static SqrtTables host_tables() {
+  SqrtTables t; t.P = vrfk_tables::SQRT_P; t.lut = vrfk_tables::SQRT_LUT; return t;
+}
+static FeN in(const uint8_t* b) { uint32_t w[8]; memcpy(w, b, 32); return fe_from_u256(w); }
+template <int L, int V> static void out(uint8_t* b, const Fe<L, V>& a) { uint32_t w[8]; fe_to_u256(w, a); memcpy(b, w, 32); }
+
+namespace {
+struct HostTables {
+  std::vector<uint32_t> g_win;
+  DevTables t;
+  HostTables() {
+    g_win.resize(WIN_TABLE_WORDS);
+    build_win_table<SuiteBS>(g_win.data(), SuiteBS::gx(), SuiteBS::gy());
+    t.sq = host_tables(); t.g_win = g_win.data(); t.g_comb = nullptr; t.b_comb = nullptr;
+  }
+};
+HostTables& HT() { static HostTables h; return h; }
+}
+extern "C" {
+uint32_t hs_ietf_verify(const uint8_t* pk, const uint8_t* h, const uint8_t* g, const uint8_t* c,
+                        const uint8_t* s, const uint8_t* ad, uint32_t ad_len) {
+  uint32_t w[5][8];
+  memcpy(w[0], pk, 32); memcpy(w[1], h, 32); memcpy(w[2], g, 32); memcpy(w[3], c, 32); memcpy(w[4], s, 32);
+  std::vector<uint32_t> tabs(3 * WIN_TABLE_WORDS), uv(2 * UV_WORDS);
+  bool valid = verify_decode_item<SuiteBS>(HT().t, w[0], w[1], w[2], tabs.data());
+  for (int half = 0; half < 2; ++half)
+    verify_straus_item<SuiteBS>(uv.data() + half * UV_WORDS, HT().t, tabs.data(), w[3], w[4], half);
+  return verify_finish_item<SuiteBS>(uv.data(), w[0], w[1], w[2], w[3], w[4], valid, ad, ad_len);
+}
+}

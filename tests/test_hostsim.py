@@ -1,0 +1,134 @@
+"""CPU: the device headers (fe.cuh, te.cuh, sha512.cuh, fr.cuh, vrf_core.cuh) compiled for the
+host (tests/hostsim) against Python big ints, the oracle and the golden vectors.  This checks
+the exact kernel source without a GPU; the GPU parity tests proper are in test_gpu_parity.py."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+from oracle import vrf_oracle as o
+
+S = o.BANDERSNATCH
+Q = S.q
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+
+
+@pytest.fixture(scope="module")
+def hs():
+    so = os.path.join(HERE, "libhostsim.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", HERE, "-j3"], check=True, stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(so)
+    lib.hs_init()
+    return lib
+
+
+def _b(x):
+    return x.to_bytes(32, "little")
+
+
+def _call(f, *a):
+    r = ctypes.create_string_buffer(32)
+    ret = f(*[_b(x) for x in a], r)
+    return int.from_bytes(r.raw, "little"), ret
+
+
+EDGE = [0, 1, 2, Q - 1, Q - 2, (1 << 255) - 1, (1 << 256) - 1, Q, Q + 1, (1 << 29) - 1, 1 << 232]
+
+
+def test_field_ops_against_python_ints(hs):
+    rnd = random.Random(1)
+    for it in range(2000):
+        x = rnd.choice(EDGE) if it % 7 == 0 else rnd.getrandbits(256)
+        y = rnd.choice(EDGE) if it % 11 == 0 else rnd.getrandbits(256)
+        assert _call(hs.hs_fe_mul, x, y)[0] == x * y % Q
+        assert _call(hs.hs_fe_sqr, x)[0] == x * x % Q
+        assert _call(hs.hs_fe_add, x, y)[0] == (x + y) % Q
+        assert _call(hs.hs_fe_sub, x, y)[0] == (x - y) % Q
+        a, b = x % Q, y % Q
+        s, d, ab = a + b, a - b, a * b
+        u2, w = 5 * ab + s * d - b, a - (ab + b)
+        assert _call(hs.hs_fe_lazy, x, y)[0] == (u2 * w) % Q      # lazy-limb bound stress
+
+
+def test_inverse_and_table_driven_sqrt(hs):
+    rnd = random.Random(2)
+    for it in range(200):
+        x = rnd.choice(EDGE) if it % 7 == 0 else rnd.getrandbits(256)
+        assert _call(hs.hs_fe_inv, x)[0] == pow(x % Q, Q - 2, Q)
+        r, sq = _call(hs.hs_fe_sqrt, x)
+        xm = x % Q
+        if xm == 0:
+            assert r == 0
+        elif o.legendre(xm, Q) == 1:
+            assert sq == 1 and r * r % Q == xm
+        else:
+            assert sq == 0 and r * r % Q == 5 * xm % Q            # sqrt(Z * w), Z = 5
+
+
+def test_sha512_all_padding_boundaries(hs):
+    rnd = random.Random(3)
+    for n in list(range(0, 20)) + [55, 111, 112, 113, 119, 120, 127, 128, 129, 239, 240, 241, 255, 256, 257, 300]:
+        m = bytes(rnd.getrandbits(8) for _ in range(n))
+        out = ctypes.create_string_buffer(64)
+        hs.hs_sha512(m, n, out)
+        assert out.raw == o.sha512(m), n
+
+
+def test_stage_and_scheme_kats(hs, kat):
+    buf = lambda n=32: ctypes.create_string_buffer(n)
+    for v in kat["stages"]:
+        a = bytes.fromhex(v["alpha"]); u0, u1 = buf(), buf()
+        hs.hs_h2f(a, len(a), u0, u1)
+        assert u0.raw.hex() == v["u0"] and u1.raw.hex() == v["u1"]
+    for v in kat["ietf"]:
+        a, ad = bytes.fromhex(v["alpha"]), bytes.fromhex(v["ad"])
+        h = buf(); hs.hs_hash_to_curve(a, len(a), h); assert h.raw.hex() == v["h"]
+        sd = bytes.fromhex(v["seed"]); sk = buf(); hs.hs_secret_from_seed(sd, len(sd), sk); assert sk.raw.hex() == v["sk"]
+        pk = buf(); hs.hs_public(bytes.fromhex(v["sk"]), pk); assert pk.raw.hex() == v["pk"]
+        b = buf(64); hs.hs_output_hash(bytes.fromhex(v["gamma"]), b); assert b.raw.hex() == v["beta"]
+        args = [bytes.fromhex(v[k]) for k in ("pk", "h", "gamma", "c", "s")]
+        assert hs.hs_ietf_verify(*args, ad, len(ad)) == 0
+        bad = bytearray(args[4]); bad[0] ^= 1
+        assert hs.hs_ietf_verify(*args[:4], bytes(bad), ad, len(ad)) == 1
+        g, c, s, hh, pk = buf(), buf(), buf(), buf(), buf()
+        assert hs.hs_ietf_prove(bytes.fromhex(v["sk"]), a, len(a), None, ad, len(ad), g, c, s, hh, pk) == 1
+        assert (g.raw.hex(), c.raw.hex(), s.raw.hex(), hh.raw.hex(), pk.raw.hex()) == \
+               (v["gamma"], v["c"], v["s"], v["h"], v["pk"])
+        # pre-hashed input path
+        assert hs.hs_ietf_prove(bytes.fromhex(v["sk"]), None, 0, bytes.fromhex(v["h"]), ad, len(ad), g, c, s, hh, pk) == 1
+        assert (g.raw.hex(), c.raw.hex(), s.raw.hex()) == (v["gamma"], v["c"], v["s"])
+
+
+def test_decode_and_verify_status_against_oracle(hs):
+    rnd = random.Random(5)
+    x, y = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    cases = [bytes(32), (Q - 1).to_bytes(32, "little"), Q.to_bytes(32, "little"), b"\xff" * 32]
+    cases += [rnd.getrandbits(256).to_bytes(32, "little") for _ in range(40)]
+    for enc in cases:
+        ok = hs.hs_decode(enc, x, y)
+        p = o.point_decode(S, enc)
+        assert bool(ok) == (p is not None), enc.hex()
+        if p:
+            assert (int.from_bytes(x.raw, "little"), int.from_bytes(y.raw, "little")) == p
+    # random proofs with long / empty ad, verified and tampered
+    for i in range(3):
+        sk = o.secret_from_seed(S, o.synth_seed(50 + i))
+        H = o.data_to_point(S, o.synth_msg(50 + i))
+        ad = bytes(rnd.getrandbits(8) for _ in range([0, 70, 200][i]))
+        g, c, s = o.ietf_prove(S, sk, H, ad)
+        enc = [o.point_encode(S, o.public_from_secret(S, sk)), o.point_encode(S, H), o.point_encode(S, g),
+               o.scalar_encode(c), o.scalar_encode(s)]
+        assert hs.hs_ietf_verify(*enc, ad, len(ad)) == 0
+        assert hs.hs_ietf_verify(*enc, ad + b"!", len(ad) + 1) == 1
+        bad = list(enc); bad[3] = S.r.to_bytes(32, "little")        # non-canonical scalar
+        assert hs.hs_ietf_verify(*bad, ad, len(ad)) == 2
+        bad = list(enc); bad[0] = Q.to_bytes(32, "little")          # y >= q
+        assert hs.hs_ietf_verify(*bad, ad, len(ad)) == 2
+
+
+def test_comb_entries_match_additive_construction(hs):
+    for (w, j) in [(0, 1), (0, 255), (3, 17), (31, 1), (31, 7)]:
+        assert hs.hs_comb_entry_check(w, j) == 1
