@@ -167,13 +167,14 @@ def main():
 def cpu_baseline(args, pk, hh, gamma, c, s, status):
     """The plain-C oracle (a port, not arkworks) on this box's host cores, bounded sample of the same batch."""
     from oracle import c_oracle as co
-    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    # a one-GPU box's CPU share is 16 cores (more threads than that only oversubscribe the cgroup)
+    cores = min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0)))
     host = lambda t, m: t[:m].cpu().numpy()
     probe = 64 * cores
     t0 = time.perf_counter()
     st = co.ietf_verify_batch(host(pk, probe), host(hh, probe), host(gamma, probe), host(c, probe), host(s, probe), b"", threads=cores)
     rate = probe / (time.perf_counter() - t0)
-    m = int(min(1 << 16, max(probe, rate * args.cpu_seconds)))
+    m = int(min(1 << 18, max(probe, rate * args.cpu_seconds)))
     t0 = time.perf_counter()
     st = co.ietf_verify_batch(host(pk, m), host(hh, m), host(gamma, m), host(c, m), host(s, m), b"", threads=cores)
     dt = time.perf_counter() - t0
