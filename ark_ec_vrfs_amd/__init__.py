@@ -6,6 +6,6 @@ over the C ABI of ``csrc/libvrfhip.so``.  All arithmetic runs in hand-written HI
 """
 from .api import (  # noqa: F401
     BandersnatchSha512Ell2, Context, Error, IetfProof, Input, Output, Public, Secret, Suite,
-    VerificationFailure, InvalidData, ietf, default_context,
+    VerificationFailure, InvalidData, ietf, pedersen, PedersenProof, default_context,
 )
 from ._lib import VrfHipError, LIB_PATH  # noqa: F401

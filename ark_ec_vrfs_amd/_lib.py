@@ -19,6 +19,8 @@ SYMBOLS = [
     "vrfhip_ctx_reserve", "vrfhip_ctx_workspace_bytes", "vrfhip_ctx_profile", "vrfhip_ctx_profile_read",
     "vrfhip_ietf_verify_batch", "vrfhip_ietf_verify_batch_dev",
     "vrfhip_ietf_prove_batch", "vrfhip_ietf_prove_batch_dev",
+    "vrfhip_pedersen_prove_batch", "vrfhip_pedersen_prove_batch_dev",
+    "vrfhip_pedersen_verify_batch", "vrfhip_pedersen_verify_batch_dev",
     "vrfhip_hash_to_curve_batch", "vrfhip_hash_to_curve_batch_dev",
     "vrfhip_output_hash_batch", "vrfhip_output_hash_batch_dev",
     "vrfhip_secret_from_seed_batch", "vrfhip_secret_from_seed_batch_dev",
@@ -70,6 +72,13 @@ def load() -> ctypes.CDLL:
                                             P, P, P, P, P, P]
     lib.vrfhip_ietf_prove_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, c_uint32, P, P, P, c_uint32,
                                                 P, P, P, P, P, P, c_void_p]
+    lib.vrfhip_pedersen_prove_batch.argtypes = [c_void_p, c_size_t, P, P, P, c_uint32, P, P, P, c_uint32,
+                                                P, P, P, P, P, P, P, P, P]
+    lib.vrfhip_pedersen_prove_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, c_uint32, P, P, P, c_uint32,
+                                                    P, P, P, P, P, P, P, P, P, c_void_p]
+    lib.vrfhip_pedersen_verify_batch.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, P, P, c_uint32, P]
+    lib.vrfhip_pedersen_verify_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, P, P, c_uint32, P,
+                                                     c_void_p]
     lib.vrfhip_hash_to_curve_batch.argtypes = [c_void_p, c_size_t, P, P, c_uint32, P]
     lib.vrfhip_hash_to_curve_batch_dev.argtypes = [c_void_p, c_size_t, P, P, c_uint32, P, c_void_p]
     lib.vrfhip_output_hash_batch.argtypes = [c_void_p, c_size_t, P, P]

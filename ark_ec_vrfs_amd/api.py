@@ -169,6 +169,71 @@ class Context:
         res["status"] = status
         return res
 
+    def _msg_args(self, n, msgs, inputs):
+        msg_blob = msg_off = inp = None
+        msg_len = 0
+        if inputs is not None:
+            inp = np.ascontiguousarray(inputs, dtype=np.uint8).reshape(-1, 32)
+            if inp.shape[0] != n:
+                raise ValueError("ragged batch")
+        elif isinstance(msgs, np.ndarray):
+            m = np.ascontiguousarray(msgs, dtype=np.uint8).reshape(n, -1)
+            msg_len = m.shape[1]
+            msg_blob = np.concatenate([m.reshape(-1), np.zeros(1, np.uint8)])
+        else:
+            if msgs is None or len(msgs) != n:
+                raise ValueError("msgs must have n entries")
+            msg_blob, msg_off = _pack_var([bytes(x) for x in msgs])
+        return msg_blob, msg_off, msg_len, inp
+
+    def pedersen_prove_batch(self, sk, msgs=None, inputs=None, ad=b""):
+        """`pedersen::Prover::prove`.  Returns dict(output, pk_com, r, ok, s, sb, blinding, input, status)."""
+        sk = np.ascontiguousarray(sk, dtype=np.uint8).reshape(-1, 32)
+        n = sk.shape[0]
+        msg_blob, msg_off, msg_len, inp = self._msg_args(n, msgs, inputs)
+        res = {k: np.empty((n, 32), dtype=np.uint8) for k in ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input")}
+        status = np.empty(n, dtype=np.uint8)
+        blob, off, ad_len = self._ad_args(ad, n)
+        _lib.check(self._lib.vrfhip_pedersen_prove_batch(
+            self._h, n, _ptr(sk), _ptr(msg_blob), _ptr(msg_off), msg_len, _ptr(inp), _ptr(blob), _ptr(off), ad_len,
+            _ptr(res["output"]), _ptr(res["pk_com"]), _ptr(res["r"]), _ptr(res["ok"]), _ptr(res["s"]),
+            _ptr(res["sb"]), _ptr(res["blinding"]), _ptr(res["input"]), _ptr(status)), "vrfhip_pedersen_prove_batch")
+        res["status"] = status
+        return res
+
+    def pedersen_verify_batch(self, inp, out, pk_com, r, ok, s, sb, ad=b"") -> np.ndarray:
+        """`pedersen::Verifier::verify`."""
+        arrs = [np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (inp, out, pk_com, r, ok, s, sb)]
+        n = arrs[0].shape[0]
+        if not all(x.shape[0] == n for x in arrs):
+            raise ValueError("ragged batch")
+        status = np.empty(n, dtype=np.uint8)
+        blob, off, ad_len = self._ad_args(ad, n)
+        _lib.check(self._lib.vrfhip_pedersen_verify_batch(
+            self._h, n, *[_ptr(x) for x in arrs], _ptr(blob), _ptr(off), ad_len, _ptr(status)),
+            "vrfhip_pedersen_verify_batch")
+        return status
+
+    def pedersen_prove_batch_dev(self, sk, msg, msg_len, out, pk_com, r, ok, s, sb, blinding=None, input_out=None,
+                                 status=None, inputs=None, ad=None, ad_off=None, ad_len=0, stream=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        dp = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self._lib.vrfhip_pedersen_prove_batch_dev(
+            self._h, sk.shape[0], sk.data_ptr(), dp(msg), None, msg_len, dp(inputs), dp(ad), dp(ad_off), ad_len,
+            out.data_ptr(), pk_com.data_ptr(), r.data_ptr(), ok.data_ptr(), s.data_ptr(), sb.data_ptr(),
+            dp(blinding), dp(input_out), dp(status), st), "vrfhip_pedersen_prove_batch_dev")
+
+    def pedersen_verify_batch_dev(self, inp, out, pk_com, r, ok, s, sb, status, ad=None, ad_off=None, ad_len=0,
+                                  stream=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        dp = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self._lib.vrfhip_pedersen_verify_batch_dev(
+            self._h, inp.shape[0], inp.data_ptr(), out.data_ptr(), pk_com.data_ptr(), r.data_ptr(), ok.data_ptr(),
+            s.data_ptr(), sb.data_ptr(), dp(ad), dp(ad_off), ad_len, status.data_ptr(), st),
+            "vrfhip_pedersen_verify_batch_dev")
+
     def hash_to_curve_batch(self, msgs) -> np.ndarray:
         if isinstance(msgs, np.ndarray):
             m = np.ascontiguousarray(msgs, dtype=np.uint8)
@@ -304,6 +369,45 @@ class Secret:
         if r["status"][0] != ST_OK:
             raise InvalidData()
         return Output(bytes(r["output"][0]))
+
+
+@dataclass(frozen=True)
+class PedersenProof:
+    """`pedersen::Proof { pk_com, r, ok, s, sb }` (src/lib.rs:14)."""
+    pk_com: bytes
+    r: bytes
+    ok: bytes
+    s: bytes
+    sb: bytes
+
+
+class pedersen:  # noqa: N801  (mirrors the Rust module name)
+    """`pedersen` module (src/lib.rs:14)."""
+    Proof = PedersenProof
+
+    class Prover:
+        @staticmethod
+        def prove(secret: "Secret", inp: "Input", out: "Output", ad: bytes = b"", ctx: Optional[Context] = None):
+            """-> (proof, blinding), as the Rust `prove` returns `(Proof, ScalarField)`."""
+            ctx = ctx or default_context()
+            r = ctx.pedersen_prove_batch(np.frombuffer(secret.scalar, dtype=np.uint8),
+                                         inputs=np.frombuffer(inp.encoded, dtype=np.uint8), ad=bytes(ad))
+            if r["status"][0] != ST_OK:
+                raise InvalidData()
+            g = lambda k: bytes(r[k][0])
+            return PedersenProof(g("pk_com"), g("r"), g("ok"), g("s"), g("sb")), g("blinding")
+
+    class Verifier:
+        @staticmethod
+        def verify(inp: "Input", out: "Output", ad: bytes, proof: PedersenProof, ctx: Optional[Context] = None) -> None:
+            ctx = ctx or default_context()
+            f = lambda b: np.frombuffer(b, dtype=np.uint8)
+            st = ctx.pedersen_verify_batch(f(inp.encoded), f(out.encoded), f(proof.pk_com), f(proof.r), f(proof.ok),
+                                           f(proof.s), f(proof.sb), ad=bytes(ad))[0]
+            if st == ST_VERIFICATION_FAILURE:
+                raise VerificationFailure()
+            if st != ST_OK:
+                raise InvalidData()
 
 
 class ietf:  # noqa: N801  (mirrors the Rust module name)

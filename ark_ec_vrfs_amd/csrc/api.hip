@@ -85,7 +85,7 @@ int32_t alloc_workspace(vrfhip_ctx* ctx, size_t cap) {
   }
   size_t tabs_b = cap * 3 * WIN_TABLE_WORDS * sizeof(uint32_t);
   size_t pts_b = cap * PROVE_PTS_WORDS * sizeof(uint32_t);
-  size_t aux_b = cap * 16 * sizeof(uint32_t);
+  size_t aux_b = cap * AUX_WORDS * sizeof(uint32_t);
   size_t flags_b = (cap + 255) & ~size_t(255);
   size_t total = tabs_b + pts_b + aux_b + flags_b;
   HIP_TRY(hipMalloc(&ctx->d_ws, total));
@@ -346,15 +346,21 @@ int32_t vrfhip_ietf_verify_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* pk, c
 }
 
 // ------------------------------------------------------------------------- IETF prove
-int32_t vrfhip_ietf_prove_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_sk,
-                                    const uint8_t* d_msg, const uint32_t* d_msg_off,
-                                    uint32_t msg_len, const uint8_t* d_input, const uint8_t* d_ad,
-                                    const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_output,
-                                    uint8_t* d_c, uint8_t* d_s, uint8_t* d_pk_out,
-                                    uint8_t* d_input_out, uint8_t* d_status, void* stream) {
+}  // extern "C"
+
+namespace {
+struct ProveOut {
+  uint8_t *output, *c, *s, *pk, *input, *status;
+  uint8_t *r, *ok, *sb, *blinding;     // Pedersen only
+};
+int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* d_sk,
+                       const uint8_t* d_msg, const uint32_t* d_msg_off, uint32_t msg_len,
+                       const uint8_t* d_input, const uint8_t* d_ad, const uint32_t* d_ad_off,
+                       uint32_t ad_len, const ProveOut& o, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (n == 0) return VRFHIP_SUCCESS;
-  if (!d_sk || !d_output || !d_c || !d_s) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if (!d_sk || !o.output || !o.s) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if (pedersen ? (!o.pk || !o.r || !o.ok || !o.sb) : !o.c) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if (!d_input && !d_msg && (msg_len || d_msg_off)) return fail(VRFHIP_ERR_BAD_ARG, "msg is NULL");
   if ((ad_len || d_ad_off) && !d_ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -362,6 +368,7 @@ int32_t vrfhip_ietf_prove_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_
   int32_t rc = ensure_workspace(ctx, n);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  auto at = [](uint8_t* p, size_t base, size_t w) -> uint8_t* { return p ? p + base * w : nullptr; };
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     size_t m = std::min(ctx->ws_cap, n - base);
     ProveArgs a;
@@ -371,10 +378,13 @@ int32_t vrfhip_ietf_prove_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_
     else a.msg = make_view(d_msg ? d_msg + base * (size_t)msg_len : nullptr, nullptr, msg_len, false);
     a.h_given = d_input ? d_input + base * 32 : nullptr;
     a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
-    a.gamma = d_output + base * 32; a.c = d_c + base * 32; a.s = d_s + base * 32;
-    a.pk_out = d_pk_out ? d_pk_out + base * 32 : nullptr;
-    a.h_out = d_input_out ? d_input_out + base * 32 : nullptr;
-    a.status = d_status ? d_status + base : nullptr;
+    a.gamma = at(o.output, base, 32); a.c = at(o.c, base, 32); a.s = at(o.s, base, 32);
+    a.pk_out = at(o.pk, base, 32);
+    a.h_out = at(o.input, base, 32);
+    a.status = at(o.status, base, 1);
+    a.pedersen = pedersen ? 1 : 0;
+    a.r_out = at(o.r, base, 32); a.ok_out = at(o.ok, base, 32); a.sb_out = at(o.sb, base, 32);
+    a.blinding_out = at(o.blinding, base, 32);
     a.ws = ctx->ws;
     a.T = ctx->T;
     launch_ietf_prove(a, st, prof_events(ctx));
@@ -383,54 +393,183 @@ int32_t vrfhip_ietf_prove_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_
   return VRFHIP_SUCCESS;
 }
 
+// host-pointer form shared by the IETF and Pedersen provers
+int32_t prove_host_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* sk, const uint8_t* msg,
+                        const uint32_t* msg_off, uint32_t msg_len, const uint8_t* input,
+                        const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len, const ProveOut& h) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!sk || !h.output || !h.s) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if (pedersen ? (!h.pk || !h.r || !h.ok || !h.sb) : !h.c) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if (!input && !msg && (msg_len || msg_off)) return fail(VRFHIP_ERR_BAD_ARG, "msg is NULL");
+  if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  size_t adb = blob_bytes(n, ad_off, ad_len, true);
+  size_t msgb = input ? 0 : blob_bytes(n, msg_off, msg_len, false);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  size_t need = 11 * Stage::pad(n * 32) + Stage::pad(msgb + 1) + Stage::pad(adb + 1) +
+                2 * Stage::pad((n + 1) * 4) + Stage::pad(n);
+  int32_t rc = ensure_stage(ctx, need);
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t* d_sk = sg.take(n * 32);
+  uint8_t* d_in = sg.take(n * 32);
+  ProveOut d{};
+  d.output = sg.take(n * 32); d.c = sg.take(n * 32); d.s = sg.take(n * 32);
+  d.pk = sg.take(n * 32); d.input = sg.take(n * 32);
+  d.r = sg.take(n * 32); d.ok = sg.take(n * 32); d.sb = sg.take(n * 32); d.blinding = sg.take(n * 32);
+  uint8_t* d_msg = sg.take(msgb + 1);
+  uint8_t* d_ad = sg.take(adb + 1);
+  uint32_t* d_moff = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+  uint32_t* d_aoff = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+  d.status = sg.take(n);
+  HIP_TRY(hipMemcpyAsync(d_sk, sk, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (input) HIP_TRY(hipMemcpyAsync(d_in, input, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (msgb) HIP_TRY(hipMemcpyAsync(d_msg, msg, msgb, hipMemcpyHostToDevice, ctx->stream));
+  if (adb) HIP_TRY(hipMemcpyAsync(d_ad, ad, adb, hipMemcpyHostToDevice, ctx->stream));
+  if (msg_off && !input)
+    HIP_TRY(hipMemcpyAsync(d_moff, msg_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (ad_off) HIP_TRY(hipMemcpyAsync(d_aoff, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = prove_dev_impl(ctx, n, pedersen, d_sk, d_msg, (msg_off && !input) ? d_moff : nullptr, msg_len,
+                      input ? d_in : nullptr, d_ad, ad_off ? d_aoff : nullptr, ad_len, d, ctx->stream);
+  if (rc) return rc;
+  auto back = [&](uint8_t* dst, const uint8_t* src, size_t bytes) -> hipError_t {
+    return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+  };
+  HIP_TRY(back(h.output, d.output, n * 32));
+  HIP_TRY(back(h.s, d.s, n * 32));
+  HIP_TRY(back(h.pk, d.pk, n * 32));
+  HIP_TRY(back(h.input, d.input, n * 32));
+  HIP_TRY(back(h.status, d.status, n));
+  if (pedersen) {
+    HIP_TRY(back(h.r, d.r, n * 32));
+    HIP_TRY(back(h.ok, d.ok, n * 32));
+    HIP_TRY(back(h.sb, d.sb, n * 32));
+    HIP_TRY(back(h.blinding, d.blinding, n * 32));
+  } else {
+    HIP_TRY(back(h.c, d.c, n * 32));
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t vrfhip_ietf_prove_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_sk,
+                                    const uint8_t* d_msg, const uint32_t* d_msg_off,
+                                    uint32_t msg_len, const uint8_t* d_input, const uint8_t* d_ad,
+                                    const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_output,
+                                    uint8_t* d_c, uint8_t* d_s, uint8_t* d_pk_out,
+                                    uint8_t* d_input_out, uint8_t* d_status, void* stream) {
+  ProveOut o{};
+  o.output = d_output; o.c = d_c; o.s = d_s; o.pk = d_pk_out; o.input = d_input_out; o.status = d_status;
+  return prove_dev_impl(ctx, n, false, d_sk, d_msg, d_msg_off, msg_len, d_input, d_ad, d_ad_off, ad_len, o,
+                        stream);
+}
+
+int32_t vrfhip_pedersen_prove_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_sk,
+                                        const uint8_t* d_msg, const uint32_t* d_msg_off,
+                                        uint32_t msg_len, const uint8_t* d_input,
+                                        const uint8_t* d_ad, const uint32_t* d_ad_off,
+                                        uint32_t ad_len, uint8_t* d_output, uint8_t* d_pk_com,
+                                        uint8_t* d_r, uint8_t* d_ok, uint8_t* d_s, uint8_t* d_sb,
+                                        uint8_t* d_blinding_out, uint8_t* d_input_out,
+                                        uint8_t* d_status, void* stream) {
+  ProveOut o{};
+  o.output = d_output; o.s = d_s; o.pk = d_pk_com; o.input = d_input_out; o.status = d_status;
+  o.r = d_r; o.ok = d_ok; o.sb = d_sb; o.blinding = d_blinding_out;
+  return prove_dev_impl(ctx, n, true, d_sk, d_msg, d_msg_off, msg_len, d_input, d_ad, d_ad_off, ad_len, o,
+                        stream);
+}
+
 int32_t vrfhip_ietf_prove_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* sk, const uint8_t* msg,
                                 const uint32_t* msg_off, uint32_t msg_len, const uint8_t* input,
                                 const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
                                 uint8_t* output, uint8_t* c, uint8_t* s, uint8_t* pk_out,
                                 uint8_t* input_out, uint8_t* status) {
+  ProveOut h{};
+  h.output = output; h.c = c; h.s = s; h.pk = pk_out; h.input = input_out; h.status = status;
+  return prove_host_impl(ctx, n, false, sk, msg, msg_off, msg_len, input, ad, ad_off, ad_len, h);
+}
+
+int32_t vrfhip_pedersen_prove_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* sk, const uint8_t* msg,
+                                    const uint32_t* msg_off, uint32_t msg_len, const uint8_t* input,
+                                    const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                    uint8_t* output, uint8_t* pk_com, uint8_t* r, uint8_t* ok,
+                                    uint8_t* s, uint8_t* sb, uint8_t* blinding_out,
+                                    uint8_t* input_out, uint8_t* status) {
+  ProveOut h{};
+  h.output = output; h.s = s; h.pk = pk_com; h.input = input_out; h.status = status;
+  h.r = r; h.ok = ok; h.sb = sb; h.blinding = blinding_out;
+  return prove_host_impl(ctx, n, true, sk, msg, msg_off, msg_len, input, ad, ad_off, ad_len, h);
+}
+
+// ------------------------------------------------------------------------- Pedersen verify
+int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_input,
+                                         const uint8_t* d_output, const uint8_t* d_pk_com,
+                                         const uint8_t* d_r, const uint8_t* d_ok, const uint8_t* d_s,
+                                         const uint8_t* d_sb, const uint8_t* d_ad,
+                                         const uint32_t* d_ad_off, uint32_t ad_len,
+                                         uint8_t* d_status, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (n == 0) return VRFHIP_SUCCESS;
-  if (!sk || !output || !c || !s) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
-  if (!input && !msg && (msg_len || msg_off)) return fail(VRFHIP_ERR_BAD_ARG, "msg is NULL");
-  if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
-  size_t adb = blob_bytes(n, ad_off, ad_len, true);
-  size_t msgb = input ? 0 : blob_bytes(n, msg_off, msg_len, false);
-  uint8_t *d_sk, *d_msg, *d_in, *d_ad, *d_g, *d_c, *d_s, *d_pk, *d_h, *d_st;
-  uint32_t *d_moff, *d_aoff;
+  if (!d_input || !d_output || !d_pk_com || !d_r || !d_ok || !d_s || !d_sb || !d_status)
+    return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if ((ad_len || d_ad_off) && !d_ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  {
-    size_t need = 7 * Stage::pad(n * 32) + Stage::pad(msgb + 1) + Stage::pad(adb + 1) +
-                  2 * Stage::pad((n + 1) * 4) + Stage::pad(n);
-    int32_t rc = ensure_stage(ctx, need);
-    if (rc) return rc;
-    Stage sg(ctx->d_stage);
-    d_sk = sg.take(n * 32); d_in = sg.take(n * 32);
-    d_g = sg.take(n * 32); d_c = sg.take(n * 32); d_s = sg.take(n * 32);
-    d_pk = sg.take(n * 32); d_h = sg.take(n * 32);
-    d_msg = sg.take(msgb + 1); d_ad = sg.take(adb + 1);
-    d_moff = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
-    d_aoff = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
-    d_st = sg.take(n);
-    HIP_TRY(hipMemcpyAsync(d_sk, sk, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    if (input) HIP_TRY(hipMemcpyAsync(d_in, input, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    if (msgb) HIP_TRY(hipMemcpyAsync(d_msg, msg, msgb, hipMemcpyHostToDevice, ctx->stream));
-    if (adb) HIP_TRY(hipMemcpyAsync(d_ad, ad, adb, hipMemcpyHostToDevice, ctx->stream));
-    if (msg_off && !input)
-      HIP_TRY(hipMemcpyAsync(d_moff, msg_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (ad_off) HIP_TRY(hipMemcpyAsync(d_aoff, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  }
-  int32_t rc = vrfhip_ietf_prove_batch_dev(ctx, n, d_sk, d_msg, (msg_off && !input) ? d_moff : nullptr,
-                                           msg_len, input ? d_in : nullptr, d_ad,
-                                           ad_off ? d_aoff : nullptr, ad_len, d_g, d_c, d_s, d_pk, d_h,
-                                           d_st, ctx->stream);
+  int32_t rc = ensure_workspace(ctx, n);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(output, d_g, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(c, d_c, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(s, d_s, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-  if (pk_out) HIP_TRY(hipMemcpyAsync(pk_out, d_pk, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-  if (input_out) HIP_TRY(hipMemcpyAsync(input_out, d_h, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-  if (status) HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (size_t base = 0; base < n; base += ctx->ws_cap) {
+    size_t m = std::min(ctx->ws_cap, n - base);
+    PedersenVerifyArgs a;
+    a.n = m;
+    a.h = d_input + base * 32; a.gamma = d_output + base * 32; a.pk_com = d_pk_com + base * 32;
+    a.r = d_r + base * 32; a.ok = d_ok + base * 32; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
+    a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
+    a.status = d_status + base;
+    a.ws = ctx->ws;
+    a.T = ctx->T;
+    launch_pedersen_verify(a, st, prof_events(ctx));
+  }
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_pedersen_verify_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* input,
+                                     const uint8_t* output, const uint8_t* pk_com, const uint8_t* r,
+                                     const uint8_t* ok, const uint8_t* s, const uint8_t* sb,
+                                     const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                     uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!input || !output || !pk_com || !r || !ok || !s || !sb || !status)
+    return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  size_t adb = blob_bytes(n, ad_off, ad_len, true);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  size_t need = 7 * Stage::pad(n * 32) + Stage::pad(adb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n);
+  int32_t rc = ensure_stage(ctx, need);
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  const uint8_t* src[7] = {input, output, pk_com, r, ok, s, sb};
+  uint8_t* d[7];
+  for (int i = 0; i < 7; ++i) {
+    d[i] = sg.take(n * 32);
+    HIP_TRY(hipMemcpyAsync(d[i], src[i], n * 32, hipMemcpyHostToDevice, ctx->stream));
+  }
+  uint8_t* d_ad = sg.take(adb + 1);
+  uint32_t* d_off = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+  uint8_t* d_st = sg.take(n);
+  if (adb) HIP_TRY(hipMemcpyAsync(d_ad, ad, adb, hipMemcpyHostToDevice, ctx->stream));
+  if (ad_off) HIP_TRY(hipMemcpyAsync(d_off, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = vrfhip_pedersen_verify_batch_dev(ctx, n, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d_ad,
+                                        ad_off ? d_off : nullptr, ad_len, d_st, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return VRFHIP_SUCCESS;
 }

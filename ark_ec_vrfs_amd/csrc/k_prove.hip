@@ -14,9 +14,18 @@ __global__ void __launch_bounds__(BLOCK) k_prove_prepare(ProveArgs a) {
   if (a.h_given) load32(hg, a.h_given, i); else bytes_get(a.msg, i, msg, msg_len);
   bool ok = prove_prepare_item<SuiteBS>(h_enc, k, a.ws.tabs + i * WIN_TABLE_WORDS, a.T, sk, msg,
                                         msg_len, a.h_given ? hg : nullptr);
-  uint32_t* aux = a.ws.aux + i * 16;
+  uint32_t* aux = a.ws.aux + i * AUX_WORDS;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { aux[j] = h_enc[j]; aux[8 + j] = k[j]; }
+  if (a.pedersen) {
+    const uint8_t* ad; uint32_t ad_len;
+    bytes_get(a.ad, i, ad, ad_len);
+    uint32_t b[8], kb[8];
+    pedersen_blinding<SuiteBS>(b, sk, h_enc, ad, ad_len);
+    nonce_rfc8032<SuiteBS>(kb, b, h_enc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { aux[16 + j] = b[j]; aux[24 + j] = kb[j]; }
+  }
   a.ws.flags[i] = ok ? 1 : 0;
 }
 
@@ -31,7 +40,7 @@ __global__ void __launch_bounds__(BLOCK) k_prove_mul(ProveArgs a) {
     load32(sc, a.sk, i);
   } else {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sc[j] = a.ws.aux[i * 16 + 8 + j];
+    for (int j = 0; j < 8; ++j) sc[j] = a.ws.aux[i * AUX_WORDS + 8 + j];
   }
   // a non-canonical secret is reported InvalidData by stage 3; keep the digits in range here
   if (!fr_is_canonical<SuiteBS>(sc)) {
@@ -39,26 +48,42 @@ __global__ void __launch_bounds__(BLOCK) k_prove_mul(ProveArgs a) {
     for (int j = 0; j < 8; ++j) sc[j] = 0;
   }
   prove_mul_item<SuiteBS>(a.ws.pts + i * PROVE_PTS_WORDS + half * 2 * UV_WORDS, a.T,
-                          a.ws.tabs + i * WIN_TABLE_WORDS, sc);
+                          a.ws.tabs + i * WIN_TABLE_WORDS, sc,
+                          a.pedersen ? a.ws.aux + i * AUX_WORDS + 16 + half * 8 : nullptr);
 }
 
 // stage 3: encodings, challenge, s = k + c*sk
 __global__ void __launch_bounds__(BLOCK) k_prove_finish(ProveArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
-  uint32_t sk[8], h_enc[8], k[8], g[8], c[8], s[8], pk[8];
+  uint32_t sk[8], h_enc[8], k[8], g[8], c[8], s[8], pk[8], rr[8], okp[8];
   load32(sk, a.sk, i);
+  const uint32_t* aux = a.ws.aux + i * AUX_WORDS;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { h_enc[j] = a.ws.aux[i * 16 + j]; k[j] = a.ws.aux[i * 16 + 8 + j]; }
+  for (int j = 0; j < 8; ++j) { h_enc[j] = aux[j]; k[j] = aux[8 + j]; }
   const uint8_t* ad; uint32_t ad_len;
   bytes_get(a.ad, i, ad, ad_len);
-  prove_finish_item<SuiteBS>(g, c, s, pk, a.ws.pts + i * PROVE_PTS_WORDS, h_enc, sk, k, ad, ad_len);
+  prove_finish_item<SuiteBS>(g, c, s, pk, rr, okp, a.ws.pts + i * PROVE_PTS_WORDS, h_enc, sk, k, ad, ad_len);
   bool ok = a.ws.flags[i] != 0;
+  if (a.pedersen) {
+    uint32_t b[8], kb[8], cb[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { b[j] = aux[16 + j]; kb[j] = aux[24 + j]; }
+    fr_mul<SuiteBS>(cb, c, b);
+    fr_add<SuiteBS>(sb, cb, kb);                    // sb = kb + c*b
+    if (!ok) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sb[j] = 0; b[j] = 0; rr[j] = 0; okp[j] = 0; }
+    }
+    store32(a.r_out, i, rr); store32(a.ok_out, i, okp); store32(a.sb_out, i, sb);
+    if (a.blinding_out) store32(a.blinding_out, i, b);
+  }
   if (!ok) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { g[j] = 0; c[j] = 0; s[j] = 0; pk[j] = 0; }
   }
-  store32(a.gamma, i, g); store32(a.c, i, c); store32(a.s, i, s);
+  store32(a.gamma, i, g); store32(a.s, i, s);
+  if (a.c) store32(a.c, i, c);
   if (a.pk_out) store32(a.pk_out, i, pk);
   if (a.h_out) store32(a.h_out, i, h_enc);
   if (a.status) a.status[i] = ok ? ST_OK : ST_INVALID_DATA;

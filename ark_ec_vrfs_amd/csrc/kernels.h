@@ -25,15 +25,17 @@ VRF_HD void bytes_get(const BytesView& v, size_t i, const uint8_t*& p, uint32_t&
   }
 }
 
+constexpr int AUX_WORDS = 32;
+
 // per-context device workspace (capacity `cap` items)
 struct Workspace {
   uint32_t* tabs;    // [cap][3][WIN_TABLE_WORDS]   window tables
   uint32_t* pts;     // [cap][PROVE_PTS_WORDS]      projective intermediates (verify uses 2*UV_WORDS)
-  uint32_t* aux;     // [cap][16]                   prove: enc(H) (8) || nonce k (8)
+  uint32_t* aux;     // [cap][32]   prove: enc(H) | k | blinding b | kb ; Pedersen verify: challenge c
   uint8_t* flags;    // [cap]                       validity of decoded inputs
 };
 constexpr size_t WS_BYTES_PER_ITEM =
-    (3 * WIN_TABLE_WORDS + PROVE_PTS_WORDS + 16) * sizeof(uint32_t) + 1;
+    (3 * WIN_TABLE_WORDS + PROVE_PTS_WORDS + AUX_WORDS) * sizeof(uint32_t) + 1;
 
 struct VerifyArgs {
   size_t n;
@@ -51,6 +53,18 @@ struct ProveArgs {
   const uint8_t* h_given;     // nullable
   BytesView ad;
   uint8_t *gamma, *c, *s, *pk_out, *h_out, *status;
+  // Pedersen (pedersen != 0): c is unused; pk_out receives pk_com; extra outputs below
+  int pedersen;
+  uint8_t *r_out, *ok_out, *sb_out, *blinding_out;
+  Workspace ws;
+  DevTables T;
+};
+
+struct PedersenVerifyArgs {
+  size_t n;
+  const uint8_t *h, *gamma, *pk_com, *r, *ok, *s, *sb;
+  BytesView ad;
+  uint8_t* status;
   Workspace ws;
   DevTables T;
 };
@@ -60,6 +74,7 @@ void launch_init_tables(uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, hip
 // ev: optional 4 events recorded on `st` before stage 1 and after stages 1, 2, 3 (profiling)
 void launch_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
 void launch_ietf_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
+void launch_pedersen_verify(const PedersenVerifyArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
 void launch_hash_to_curve(size_t n, BytesView msg, uint8_t* points, DevTables T, hipStream_t st);
 void launch_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash, hipStream_t st);
 void launch_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk,

@@ -203,6 +203,41 @@ VRF_HD PtE comb_mul(const uint32_t* comb, const uint32_t k[8]) {
   return acc;
 }
 
+// acc + k*Base from a comb table (continues an accumulator)
+template <class C>
+VRF_HD PtE comb_add(PtE acc, const uint32_t* comb, const uint32_t k[8]) {
+#pragma unroll 1
+  for (int w = 0; w < 32; ++w) {
+    uint32_t word = k[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+      if ((w >> 2) == i) word = k[i];
+    uint32_t d = (word >> ((w & 3) * 8)) & 255u;
+    uint32_t idx = d ? d - 1 : 0;
+    PtA e = pta_load(comb + ((size_t)w * 255 + idx) * PTA_WORDS);
+    PtA id = pta_identity();
+    bool z = d == 0;
+    e.x = fe_select(z, id.x, e.x);
+    e.y = fe_select(z, id.y, e.y);
+    e.dt = fe_select(z, id.dt, e.dt);
+    acc = te_add_affine<C>(acc, e, false);
+  }
+  return acc;
+}
+// k1*G + k2*B from the two fixed-base combs (one add call site)
+template <class C>
+VRF_HD PtE comb_mul2(const uint32_t* comb1, const uint32_t k1[8], const uint32_t* comb2,
+                     const uint32_t k2[8]) {
+  PtE acc = te_identity();
+#pragma unroll 1
+  for (int t = 0; t < 2; ++t) {
+    uint32_t k[8];
+    sel8(k, t != 0, k2, k1);
+    acc = comb_add<C>(acc, t ? comb2 : comb1, k);
+  }
+  return acc;
+}
+
 // ------------------------------------------------------------------------ table init helpers
 // k*P by branch-free double-and-add (one-time table construction only)
 template <class C>
@@ -505,6 +540,25 @@ VRF_HD void te_to_affine(FeN& x, FeN& y, const PtE& p) {
 constexpr int PROVE_PTS_WORDS = 4 * UV_WORDS;   // [half][win|comb][X,Y,Z]
 
 // returns validity (always true for the hash-to-curve path; decode may fail)
+// [ref src/lib.rs:14 `pedersen::PedersenSuite::blinding`]  SURVEY.md A.5:
+// b = int_be(SHA512(suite_id || 0xCC || sk_le32 || enc(H) || ad || 0x00)) mod r  (all 64 bytes)
+template <class S>
+VRF_HD void pedersen_blinding(uint32_t b[8], const uint32_t sk[8], const uint32_t h_enc[8],
+                              const uint8_t* ad, uint32_t ad_len) {
+  Sha512 h;
+  sha512_init(h);
+  put_suite_id<S>(h);
+  sha512_put_byte(h, 0xCC);
+  sha512_put_le32x8(h, sk);
+  sha512_put_le32x8(h, h_enc);
+  sha512_put_bytes(h, ad, ad_len);
+  sha512_put_byte(h, 0x00);
+  sha512_final(h);
+  uint32_t be[16];
+  sha512_be512(be, h);
+  fr_reduce512<S>(b, be);
+}
+
 template <class S>
 VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, const DevTables& T,
                                const uint32_t sk[8], const uint8_t* msg, uint32_t msg_len,
@@ -528,22 +582,33 @@ VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, 
   return valid;
 }
 
+// scalar2 != nullptr (Pedersen): the fixed-base part is scalar*G + scalar2*B
 template <class S>
 VRF_HD void prove_mul_item(uint32_t* out /*2*UV_WORDS*/, const DevTables& T, const uint32_t* tab,
-                           const uint32_t scalar[8]) {
+                           const uint32_t scalar[8], const uint32_t* scalar2) {
   uint32_t rec[8];
   scalar_recode_signed4(rec, scalar);
   PtE w = win_mul<S>(tab, rec);
   fe_store(out, w.X); fe_store(out + NL, w.Y); fe_store(out + 2 * NL, w.Z);
-  PtE c = comb_mul<S>(T.g_comb, scalar);
+  PtE c;
+  if (scalar2) {
+    uint32_t k2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k2[i] = scalar2[i];
+    c = comb_mul2<S>(T.g_comb, scalar, T.b_comb, k2);
+  } else {
+    c = comb_mul<S>(T.g_comb, scalar);
+  }
   fe_store(out + UV_WORDS, c.X); fe_store(out + UV_WORDS + NL, c.Y);
   fe_store(out + UV_WORDS + 2 * NL, c.Z);
 }
 
-// pts: [sk*H, sk*G, k*H, k*G] projective.  Writes gamma, c, s (and pk).
+// pts: [sk*H, sk*G (+b*B), k*H, k*G (+kb*B)] projective.  Writes gamma, c, s, pk (= pk_com for
+// Pedersen) and the encodings of k*G (+kb*B) = R and k*H = Ok.
 template <class S>
 VRF_HD void prove_finish_item(uint32_t gamma_out[8], uint32_t c_out[8], uint32_t s_out[8],
-                              uint32_t pk_out[8], const uint32_t* pts_in, const uint32_t h_enc[8],
+                              uint32_t pk_out[8], uint32_t r_out[8], uint32_t ok_out[8],
+                              const uint32_t* pts_in, const uint32_t h_enc[8],
                               const uint32_t sk[8], const uint32_t k[8], const uint8_t* ad,
                               uint32_t ad_len) {
   FeP zin[4];
@@ -582,7 +647,101 @@ VRF_HD void prove_finish_item(uint32_t gamma_out[8], uint32_t c_out[8], uint32_t
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     gamma_out[j] = pts[2][j]; c_out[j] = c[j]; s_out[j] = s[j]; pk_out[j] = pts[0][j];
+    r_out[j] = pts[3][j]; ok_out[j] = pts[4][j];
   }
+}
+
+// ------------------------------------------------------------------------ Pedersen verify
+// [ref src/lib.rs:14 `pedersen::Verifier::verify`]  SURVEY.md A.5:
+//   c = challenge(pk_com, H, Gamma, R, Ok, ad);  accept iff  s*H - c*Gamma == Ok  and
+//   s*G + sb*B - c*pk_com == R.
+// decode : decompress H, Gamma, pk_com, R, Ok (one shared inversion), tables of H, Gamma, pk_com,
+//          challenge c                                                             -> HBM
+// straus : lane A: s*H - c*Gamma ; lane B: s*G - c*pk_com + sb*B                   -> HBM
+// finish : projective equality with the affine Ok and R.
+constexpr int PED_OK_OFF = 2 * UV_WORDS;            // affine Ok (x, y) in the pts region
+constexpr int PED_R_OFF = 2 * UV_WORDS + 2 * NL;    // affine R (x, y)
+
+VRF_HD FeN fe_sel5(int p, const FeN (&a)[5]) {
+  return fe_select(p == 0, a[0], fe_select(p == 1, a[1], fe_select(p == 2, a[2], fe_select(p == 3, a[3], a[4]))));
+}
+
+// enc: [H, Gamma, pk_com, R, Ok].  tabs: tables of H, Gamma, pk_com.  pts: receives affine Ok, R.
+template <class S>
+VRF_HD bool pedersen_verify_decode_item(uint32_t c_out[8], const DevTables& T,
+                                        const uint32_t (&enc)[5][8], const uint8_t* ad,
+                                        uint32_t ad_len, uint32_t* tabs, uint32_t* pts) {
+  FeN ys[5], dens[5], dinv[5];
+  Fe<1, 6> nums[5];
+  bool flags[5], oks[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    DecodeA a = decode_phase_a<S>(enc[i]);
+    ys[i] = a.y; dens[i] = a.den; nums[i] = a.num; flags[i] = a.flag; oks[i] = a.ok;
+  }
+  fe_batch_inv(dinv, dens);
+  bool valid = true;
+#pragma unroll 1
+  for (int p = 0; p < 5; ++p) {
+    DecodeA a;
+    a.y = fe_sel5(p, ys);
+    a.den = fe_sel5(p, dens);
+    a.num = fe_select(p == 0, nums[0], fe_select(p == 1, nums[1], fe_select(p == 2, nums[2],
+                      fe_select(p == 3, nums[3], nums[4]))));
+    a.flag = p == 0 ? flags[0] : p == 1 ? flags[1] : p == 2 ? flags[2] : p == 3 ? flags[3] : flags[4];
+    a.ok = p == 0 ? oks[0] : p == 1 ? oks[1] : p == 2 ? oks[2] : p == 3 ? oks[3] : oks[4];
+    FeN di = fe_sel5(p, dinv);
+    Fe<1, 4> x;
+    valid = decode_phase_b<S>(x, a, di, T.sq) && valid;
+    if (p < 3) {
+      build_win_table<S>(tabs + p * WIN_TABLE_WORDS, x, a.y);
+    } else {
+      uint32_t* dst = pts + (p == 3 ? PED_R_OFF : PED_OK_OFF);
+      fe_store(dst, x);
+      fe_store(dst + NL, a.y);
+    }
+  }
+  uint32_t cp[5][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    cp[0][j] = enc[2][j]; cp[1][j] = enc[0][j]; cp[2][j] = enc[1][j]; cp[3][j] = enc[3][j]; cp[4][j] = enc[4][j];
+  }
+  challenge5<S>(c_out, cp, ad, ad_len);
+  return valid;
+}
+
+// half 0: s*H - c*Gamma ; half 1: s*G - c*pk_com + sb*B
+template <class S>
+VRF_HD void pedersen_verify_straus_item(uint32_t* out_uv, const DevTables& T, const uint32_t* tabs,
+                                        const uint32_t c[8], const uint32_t s[8],
+                                        const uint32_t sb[8], int half) {
+  uint32_t recs[8], recc[8];
+  scalar_recode_signed4(recs, s);
+  scalar_recode_signed4(recc, c);
+  const uint32_t* tabA = half ? T.g_win : tabs;
+  const uint32_t* tabB = half ? tabs + 2 * WIN_TABLE_WORDS : tabs + WIN_TABLE_WORDS;
+  PtE r = straus2<S>(tabA, recs, tabB, recc, true);
+  if (half) r = comb_add<S>(r, T.b_comb, sb);
+  fe_store(out_uv, r.X);
+  fe_store(out_uv + NL, r.Y);
+  fe_store(out_uv + 2 * NL, r.Z);
+}
+
+// projective P (X, Y, Z) equals affine (x, y)
+VRF_HD bool proj_eq_affine(const uint32_t* P, const uint32_t* xy) {
+  FeP X = fe_load<1, 5>(P), Y = fe_load<1, 5>(P + NL), Z = fe_load<1, 5>(P + 2 * NL);
+  Fe<1, 4> x = fe_load<1, 4>(xy);
+  FeN y = fe_load<1, 2>(xy + NL);
+  return fe_eq(X, fe_mul(x, Z)) && fe_eq(Y, fe_mul(y, Z)) && !fe_is_zero(Z);
+}
+
+template <class S>
+VRF_HD uint32_t pedersen_verify_finish_item(const uint32_t* pts, const uint32_t s[8],
+                                            const uint32_t sb[8], bool valid) {
+  valid = valid && fr_is_canonical<S>(s) && fr_is_canonical<S>(sb);
+  bool ok = proj_eq_affine(pts, pts + PED_OK_OFF) && proj_eq_affine(pts + UV_WORDS, pts + PED_R_OFF);
+  if (!valid) return ST_INVALID_DATA;
+  return ok ? ST_OK : ST_VERIFICATION_FAILURE;
 }
 
 // [ref src/lib.rs:15 `Output::hash` / utils::point_to_hash_rfc_9381]  SURVEY.md A.4:

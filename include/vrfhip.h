@@ -121,6 +121,40 @@ int32_t vrfhip_ietf_prove_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_
                                     uint8_t* d_c, uint8_t* d_s, uint8_t* d_pk_out,
                                     uint8_t* d_input_out, uint8_t* d_status, void* stream);
 
+/* Pedersen VRF ------------------------------------------------------------------------ */
+
+/* `Input::new` + `Secret::output` + `pedersen::Prover::prove` for n items (src/lib.rs:14).
+ * Inputs as for vrfhip_ietf_prove_batch.  Outputs (n x 32 B each): output (Gamma); the proof
+ * `pedersen::Proof { pk_com, r, ok, s, sb }`; the secret blinding factor the Rust API returns
+ * next to the proof (blinding_out, may be NULL); the input point (input_out, may be NULL). */
+int32_t vrfhip_pedersen_prove_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* sk, const uint8_t* msg,
+                                    const uint32_t* msg_off, uint32_t msg_len, const uint8_t* input,
+                                    const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                    uint8_t* output, uint8_t* pk_com, uint8_t* r, uint8_t* ok,
+                                    uint8_t* s, uint8_t* sb, uint8_t* blinding_out,
+                                    uint8_t* input_out, uint8_t* status);
+int32_t vrfhip_pedersen_prove_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_sk,
+                                        const uint8_t* d_msg, const uint32_t* d_msg_off,
+                                        uint32_t msg_len, const uint8_t* d_input,
+                                        const uint8_t* d_ad, const uint32_t* d_ad_off,
+                                        uint32_t ad_len, uint8_t* d_output, uint8_t* d_pk_com,
+                                        uint8_t* d_r, uint8_t* d_ok, uint8_t* d_s, uint8_t* d_sb,
+                                        uint8_t* d_blinding_out, uint8_t* d_input_out,
+                                        uint8_t* d_status, void* stream);
+
+/* `pedersen::Verifier::verify(input, output, ad, &proof)` for n items (src/lib.rs:14). */
+int32_t vrfhip_pedersen_verify_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* input,
+                                     const uint8_t* output, const uint8_t* pk_com, const uint8_t* r,
+                                     const uint8_t* ok, const uint8_t* s, const uint8_t* sb,
+                                     const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                     uint8_t* status);
+int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_input,
+                                         const uint8_t* d_output, const uint8_t* d_pk_com,
+                                         const uint8_t* d_r, const uint8_t* d_ok, const uint8_t* d_s,
+                                         const uint8_t* d_sb, const uint8_t* d_ad,
+                                         const uint32_t* d_ad_off, uint32_t ad_len,
+                                         uint8_t* d_status, void* stream);
+
 /* Building blocks --------------------------------------------------------------------- */
 
 /* `Input::new(data)` = Suite::data_to_point = hash_to_curve_ell2_rfc_9380 (src/lib.rs:14-16):

@@ -493,6 +493,78 @@ int oracle_ietf_verify(const uint8_t pk[32], const uint8_t h[32], const uint8_t 
   return cmp4(c, c2) == 0 ? 0 : 1;
 }
 
+/* [ref src/lib.rs:14 `pedersen::PedersenSuite::blinding`] SURVEY.md A.5 */
+static void blinding(uint64_t b[4], const uint8_t sk_le[32], const uint8_t h_enc[32], const uint8_t* ad, size_t ad_len) {
+  uint8_t h[64], cc = 0xCC, zero = 0; sha512_ctx c;
+  sha512_init(&c); sha512_update(&c, SUITE_ID, 25); sha512_update(&c, &cc, 1); sha512_update(&c, sk_le, 32);
+  sha512_update(&c, h_enc, 32); sha512_update(&c, ad, ad_len); sha512_update(&c, &zero, 1); sha512_final(&c, h);
+  r_from_bytes_wide(b, h, 64, 1);
+}
+/* [ref src/lib.rs:14 `pedersen::Prover::prove`]; proof160 = pk_com | R | Ok | s | sb */
+int oracle_pedersen_prove(const uint8_t sk_le[32], const uint8_t* msg, size_t msg_len, const uint8_t* h_given,
+                          const uint8_t* ad, size_t ad_len, uint8_t gamma_out[32], uint8_t proof160[160],
+                          uint8_t blinding_out[32], uint8_t h_out[32]) {
+  ensure_init();
+  uint64_t sk[4]; load_le(sk, sk_le);
+  if (cmp4(sk, FR.m) >= 0) return 2;
+  pt H, G, B, t0, t1, P; fp x, y;
+  uint8_t pts[5][32];
+  if (h_given) {
+    if (!point_decode(&x, &y, h_given)) return 2;
+    memcpy(pts[1], h_given, 32);
+  } else { hash_to_curve(&H, msg, msg_len); pt_to_affine(&x, &y, &H); point_encode(pts[1], &x, &y); }
+  pt_from_affine(&H, &x, &y);
+  pt_from_affine(&G, &BS_GX_M, &BS_GY_M); pt_from_affine(&B, &BS_BX_M, &BS_BY_M);
+  uint64_t b[4], k[4], kb[4], c[4], s[4], sb[4]; uint8_t b_le[32];
+  blinding(b, sk_le, pts[1], ad, ad_len); store_le(b_le, b);
+  nonce(k, sk_le, pts[1]); nonce(kb, b_le, pts[1]);
+  pt_mul(&P, &H, sk); pt_to_affine(&x, &y, &P); point_encode(pts[2], &x, &y);                       /* Gamma */
+  pt_mul(&t0, &G, sk); pt_mul(&t1, &B, b); pt_add(&P, &t0, &t1); pt_to_affine(&x, &y, &P); point_encode(pts[0], &x, &y); /* pk_com */
+  pt_mul(&t0, &G, k); pt_mul(&t1, &B, kb); pt_add(&P, &t0, &t1); pt_to_affine(&x, &y, &P); point_encode(pts[3], &x, &y); /* R */
+  pt_mul(&P, &H, k); pt_to_affine(&x, &y, &P); point_encode(pts[4], &x, &y);                        /* Ok */
+  challenge(c, pts, ad, ad_len);
+  r_muladd(s, c, sk, k); r_muladd(sb, c, b, kb);
+  memcpy(gamma_out, pts[2], 32);
+  memcpy(proof160, pts[0], 32); memcpy(proof160 + 32, pts[3], 32); memcpy(proof160 + 64, pts[4], 32);
+  store_le(proof160 + 96, s); store_le(proof160 + 128, sb);
+  if (blinding_out) memcpy(blinding_out, b_le, 32);
+  if (h_out) memcpy(h_out, pts[1], 32);
+  return 0;
+}
+/* [ref src/lib.rs:14 `pedersen::Verifier::verify`] */
+int oracle_pedersen_verify(const uint8_t h[32], const uint8_t gamma[32], const uint8_t proof160[160],
+                           const uint8_t* ad, size_t ad_len) {
+  ensure_init();
+  uint64_t s[4], sb[4], c[4];
+  load_le(s, proof160 + 96); load_le(sb, proof160 + 128);
+  if (cmp4(s, FR.m) >= 0 || cmp4(sb, FR.m) >= 0) return 2;
+  fp x, y; pt H, Gm, PC, R, Ok, G, B, l, r1, t0, t1;
+  if (!point_decode(&x, &y, h)) return 2;
+  pt_from_affine(&H, &x, &y);
+  if (!point_decode(&x, &y, gamma)) return 2;
+  pt_from_affine(&Gm, &x, &y);
+  if (!point_decode(&x, &y, proof160)) return 2;
+  pt_from_affine(&PC, &x, &y);
+  if (!point_decode(&x, &y, proof160 + 32)) return 2;
+  pt_from_affine(&R, &x, &y);
+  if (!point_decode(&x, &y, proof160 + 64)) return 2;
+  pt_from_affine(&Ok, &x, &y);
+  uint8_t pts[5][32];
+  memcpy(pts[0], proof160, 32); memcpy(pts[1], h, 32); memcpy(pts[2], gamma, 32);
+  memcpy(pts[3], proof160 + 32, 32); memcpy(pts[4], proof160 + 64, 32);
+  challenge(c, pts, ad, ad_len);
+  pt_from_affine(&G, &BS_GX_M, &BS_GY_M); pt_from_affine(&B, &BS_BX_M, &BS_BY_M);
+  /* Ok + c*Gamma == s*H */
+  pt_mul(&t0, &Gm, c); pt_add(&l, &Ok, &t0); pt_mul(&r1, &H, s);
+  fp ax, ay, bx, by; pt_to_affine(&ax, &ay, &l); pt_to_affine(&bx, &by, &r1);
+  if (!q_eq(&ax, &bx) || !q_eq(&ay, &by)) return 1;
+  /* R + c*pk_com == s*G + sb*B */
+  pt_mul(&t0, &PC, c); pt_add(&l, &R, &t0); pt_mul(&t0, &G, s); pt_mul(&t1, &B, sb); pt_add(&r1, &t0, &t1);
+  pt_to_affine(&ax, &ay, &l); pt_to_affine(&bx, &by, &r1);
+  if (!q_eq(&ax, &bx) || !q_eq(&ay, &by)) return 1;
+  return 0;
+}
+
 /* ---- batch drivers (static partition over pthreads; threads <= 1 runs inline) ---- */
 typedef struct {
   int kind; size_t lo, hi;
@@ -505,6 +577,13 @@ static void* run_job(void* arg) {
     if (j->kind == 0) {
       j->st[i] = (uint8_t)oracle_ietf_verify(j->a0 + 32 * i, j->a1 + 32 * i, j->a2 + 32 * i, j->a3 + 32 * i,
                                              j->a4 + 32 * i, j->ad, j->ad_len);
+    } else if (j->kind == 2) {
+      j->st[i] = (uint8_t)oracle_pedersen_verify(j->a0 + 32 * i, j->a1 + 32 * i, j->a2 + 160 * i, j->ad, j->ad_len);
+    } else if (j->kind == 3) {
+      int rc = oracle_pedersen_prove(j->a0 + 32 * i, j->a1 ? j->a1 + j->msg_len * i : NULL, j->msg_len,
+                                     j->a2 ? j->a2 + 32 * i : NULL, j->ad, j->ad_len, j->o0 + 32 * i,
+                                     j->o1 + 160 * i, j->o2 ? j->o2 + 32 * i : NULL, j->o4 ? j->o4 + 32 * i : NULL);
+      if (j->st) j->st[i] = (uint8_t)rc;
     } else {
       int rc = oracle_ietf_prove(j->a0 + 32 * i, j->a1 ? j->a1 + j->msg_len * i : NULL, j->msg_len,
                                  j->a2 ? j->a2 + 32 * i : NULL, j->ad, j->ad_len, j->o0 + 32 * i, j->o1 + 32 * i,
@@ -540,6 +619,20 @@ void oracle_ietf_prove_batch(size_t n, const uint8_t* sk, const uint8_t* msg, si
   job j; memset(&j, 0, sizeof j);
   j.kind = 1; j.a0 = sk; j.a1 = msg; j.msg_len = msg_len; j.a2 = h_given; j.ad = ad; j.ad_len = ad_len;
   j.o0 = gamma; j.o1 = c; j.o2 = s; j.o3 = pk_out; j.o4 = h_out; j.st = status;
+  run_batch(j, n, threads);
+}
+void oracle_pedersen_verify_batch(size_t n, const uint8_t* h, const uint8_t* gamma, const uint8_t* proof160,
+                                  const uint8_t* ad, size_t ad_len, uint8_t* status, int threads) {
+  job j; memset(&j, 0, sizeof j);
+  j.kind = 2; j.a0 = h; j.a1 = gamma; j.a2 = proof160; j.ad = ad; j.ad_len = ad_len; j.st = status;
+  run_batch(j, n, threads);
+}
+void oracle_pedersen_prove_batch(size_t n, const uint8_t* sk, const uint8_t* msg, size_t msg_len, const uint8_t* h_given,
+                                 const uint8_t* ad, size_t ad_len, uint8_t* gamma, uint8_t* proof160,
+                                 uint8_t* blinding_out, uint8_t* h_out, uint8_t* status, int threads) {
+  job j; memset(&j, 0, sizeof j);
+  j.kind = 3; j.a0 = sk; j.a1 = msg; j.msg_len = msg_len; j.a2 = h_given; j.ad = ad; j.ad_len = ad_len;
+  j.o0 = gamma; j.o1 = proof160; j.o2 = blinding_out; j.o4 = h_out; j.st = status;
   run_batch(j, n, threads);
 }
 /* test hooks for the field layer */

@@ -29,6 +29,10 @@ def load() -> ctypes.CDLL:
         lib.oracle_ietf_verify_batch.restype = None
         lib.oracle_ietf_prove_batch.argtypes = [c_size_t, P, P, c_size_t, P, P, c_size_t, P, P, P, P, P, P, c_int]
         lib.oracle_ietf_prove_batch.restype = None
+        lib.oracle_pedersen_verify_batch.argtypes = [c_size_t, P, P, P, P, c_size_t, P, c_int]
+        lib.oracle_pedersen_verify_batch.restype = None
+        lib.oracle_pedersen_prove_batch.argtypes = [c_size_t, P, P, c_size_t, P, P, c_size_t, P, P, P, P, P, c_int]
+        lib.oracle_pedersen_prove_batch.restype = None
         lib.oracle_hash_to_curve.argtypes = [P, c_size_t, P]
         lib.oracle_output_hash.argtypes = [P, P]
         lib.oracle_secret_from_seed.argtypes = [P, c_size_t, P]
@@ -75,6 +79,39 @@ def ietf_prove_batch(sk, msgs: np.ndarray = None, inputs=None, ad: bytes = b"", 
                                    res["pk"].ctypes.data, res["input"].ctypes.data, st.ctypes.data, threads)
     res["status"] = st
     return res
+
+
+def pedersen_prove_batch(sk, msgs: np.ndarray = None, inputs=None, ad: bytes = b"", threads: int = 1):
+    """-> dict(output, pk_com, r, ok, s, sb, blinding, input, status)"""
+    sk = _a(sk).reshape(-1, 32)
+    n = sk.shape[0]
+    gamma = np.empty((n, 32), np.uint8); proof = np.empty((n, 160), np.uint8)
+    bl = np.empty((n, 32), np.uint8); hh = np.empty((n, 32), np.uint8); st = np.empty(n, np.uint8)
+    adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
+    mp, ml, ip = None, 0, None
+    if inputs is not None:
+        inputs = _a(inputs).reshape(n, 32)
+        ip = inputs.ctypes.data
+    else:
+        msgs = _a(msgs).reshape(n, -1)
+        ml = msgs.shape[1]
+        msgs = np.concatenate([msgs.reshape(-1), np.zeros(1, np.uint8)])
+        mp = msgs.ctypes.data
+    load().oracle_pedersen_prove_batch(n, sk.ctypes.data, mp, ml, ip, adb.ctypes.data, len(ad), gamma.ctypes.data,
+                                       proof.ctypes.data, bl.ctypes.data, hh.ctypes.data, st.ctypes.data, threads)
+    return dict(output=gamma, pk_com=proof[:, 0:32].copy(), r=proof[:, 32:64].copy(), ok=proof[:, 64:96].copy(),
+                s=proof[:, 96:128].copy(), sb=proof[:, 128:160].copy(), blinding=bl, input=hh, status=st)
+
+
+def pedersen_verify_batch(h, gamma, pk_com, r, ok, s, sb, ad: bytes = b"", threads: int = 1) -> np.ndarray:
+    arrs = [_a(x).reshape(-1, 32) for x in (h, gamma, pk_com, r, ok, s, sb)]
+    n = arrs[0].shape[0]
+    proof = np.ascontiguousarray(np.concatenate(arrs[2:], axis=1))
+    st = np.empty(n, np.uint8)
+    adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
+    load().oracle_pedersen_verify_batch(n, arrs[0].ctypes.data, arrs[1].ctypes.data, proof.ctypes.data,
+                                        adb.ctypes.data, len(ad), st.ctypes.data, threads)
+    return st
 
 
 def hash_to_curve(msg: bytes) -> bytes:

@@ -14,27 +14,31 @@ static FeN in(const uint8_t* b) { uint32_t w[8]; memcpy(w, b, 32); return fe_fro
 template <int L, int V> static void out(uint8_t* b, const Fe<L, V>& a) { uint32_t w[8]; fe_to_u256(w, a); memcpy(b, w, 32); }
 namespace {
 struct HostTables {
-  std::vector<uint32_t> g_win, g_comb;
+  std::vector<uint32_t> g_win, g_comb, b_comb;
   DevTables t;
   HostTables() {
     g_win.resize(WIN_TABLE_WORDS);
     build_win_table<SuiteBS>(g_win.data(), SuiteBS::gx(), SuiteBS::gy());
     g_comb.resize((size_t)32 * 255 * PTA_WORDS);
+    b_comb.resize((size_t)32 * 255 * PTA_WORDS);
     // comb by repeated addition instead of 8160 scalar multiplications (host is slow):
+    for (int which = 0; which < 2; ++which)
     for (int w = 0; w < 32; ++w) {
+      uint32_t* comb = which ? b_comb.data() : g_comb.data();
       uint32_t k[8] = {0}; k[w >> 2] = 1u << ((w & 3) * 8);
-      PtE base = te_mul_slow<SuiteBS>(te_from_affine(SuiteBS::gx(), SuiteBS::gy()), k);
+      PtE base = te_mul_slow<SuiteBS>(which ? te_from_affine(SuiteBS::bx(), SuiteBS::by())
+                                            : te_from_affine(SuiteBS::gx(), SuiteBS::gy()), k);
       PtC bc = te_to_cached<SuiteBS>(base);
       PtE acc = base;
       for (int j = 1; j <= 255; ++j) {
         FeN zi = fe_inv(acc.Z);
         PtA a; a.x = fe_mul(acc.X, zi); a.y = fe_mul(acc.Y, zi);
         a.dt = fe_mul(fe_mul(a.x, a.y), SuiteBS::d());
-        pta_store(g_comb.data() + ((size_t)w * 255 + (j - 1)) * PTA_WORDS, a);
+        pta_store(comb + ((size_t)w * 255 + (j - 1)) * PTA_WORDS, a);
         acc = te_add_cached<SuiteBS>(acc, bc, false);
       }
     }
-    t.sq = host_tables(); t.g_win = g_win.data(); t.g_comb = g_comb.data(); t.b_comb = nullptr;
+    t.sq = host_tables(); t.g_win = g_win.data(); t.g_comb = g_comb.data(); t.b_comb = b_comb.data();
   }
 };
 HostTables& HT() { static HostTables h; return h; }
@@ -56,21 +60,52 @@ void hs_hash_to_curve(const uint8_t* msg, uint32_t len, uint8_t* out) {
   FeN x, y; te_to_affine(x, y, h);
   uint32_t e[8]; te_encode_affine(e, x, y); memcpy(out, e, 32);
 }
+static int prove_any(bool pedersen, const uint8_t* sk, const uint8_t* msg, uint32_t len, const uint8_t* h_given,
+                     const uint8_t* ad, uint32_t ad_len, uint32_t o[6][8], uint32_t h_enc[8], uint32_t sb[8], uint32_t b[8]) {
+  uint32_t skw[8]; memcpy(skw, sk, 32);
+  uint32_t hg[8]; if (h_given) memcpy(hg, h_given, 32);
+  uint32_t k[8], kb[8];
+  std::vector<uint32_t> tab(WIN_TABLE_WORDS), pts(PROVE_PTS_WORDS);
+  bool valid = prove_prepare_item<SuiteBS>(h_enc, k, tab.data(), HT().t, skw, msg, len, h_given ? hg : nullptr);
+  if (pedersen) { pedersen_blinding<SuiteBS>(b, skw, h_enc, ad, ad_len); nonce_rfc8032<SuiteBS>(kb, b, h_enc); }
+  prove_mul_item<SuiteBS>(pts.data(), HT().t, tab.data(), skw, pedersen ? b : nullptr);
+  prove_mul_item<SuiteBS>(pts.data() + 2 * UV_WORDS, HT().t, tab.data(), k, pedersen ? kb : nullptr);
+  // o: gamma, c, s, pk, r, ok
+  prove_finish_item<SuiteBS>(o[0], o[1], o[2], o[3], o[4], o[5], pts.data(), h_enc, skw, k, ad, ad_len);
+  if (pedersen) { uint32_t cb[8]; fr_mul<SuiteBS>(cb, o[1], b); fr_add<SuiteBS>(sb, cb, kb); }
+  return valid;
+}
 int hs_ietf_prove(const uint8_t* sk, const uint8_t* msg, uint32_t len, const uint8_t* h_given,
                   const uint8_t* ad, uint32_t ad_len,
                   uint8_t* gamma, uint8_t* c, uint8_t* s, uint8_t* h, uint8_t* pk) {
-  uint32_t skw[8]; memcpy(skw, sk, 32);
-  uint32_t hg[8]; if (h_given) memcpy(hg, h_given, 32);
-  uint32_t h_enc[8], k[8], o[4][8];
-  std::vector<uint32_t> tab(WIN_TABLE_WORDS), pts(PROVE_PTS_WORDS);
-  bool valid = prove_prepare_item<SuiteBS>(h_enc, k, tab.data(), HT().t, skw, msg, len, h_given ? hg : nullptr);
-  prove_mul_item<SuiteBS>(pts.data(), HT().t, tab.data(), skw);
-  prove_mul_item<SuiteBS>(pts.data() + 2 * UV_WORDS, HT().t, tab.data(), k);
-  prove_finish_item<SuiteBS>(o[0], o[1], o[2], o[3], pts.data(), h_enc, skw, k, ad, ad_len);
+  uint32_t o[6][8], h_enc[8], sb[8], b[8];
+  int valid = prove_any(false, sk, msg, len, h_given, ad, ad_len, o, h_enc, sb, b);
   memcpy(gamma, o[0], 32); memcpy(c, o[1], 32); memcpy(s, o[2], 32); memcpy(h, h_enc, 32); memcpy(pk, o[3], 32);
+  return valid;
+}
+// out: gamma | pk_com | r | ok | s | sb | blinding  (7 x 32 B)
+int hs_pedersen_prove(const uint8_t* sk, const uint8_t* msg, uint32_t len, const uint8_t* ad, uint32_t ad_len,
+                      uint8_t* out) {
+  uint32_t o[6][8], h_enc[8], sb[8], b[8];
+  int valid = prove_any(true, sk, msg, len, nullptr, ad, ad_len, o, h_enc, sb, b);
+  memcpy(out, o[0], 32); memcpy(out + 32, o[3], 32); memcpy(out + 64, o[4], 32); memcpy(out + 96, o[5], 32);
+  memcpy(out + 128, o[2], 32); memcpy(out + 160, sb, 32); memcpy(out + 192, b, 32);
   return valid;
 }
 void hs_public(const uint8_t* sk, uint8_t* pk) {
   uint32_t skw[8], o[8]; memcpy(skw, sk, 32); public_from_secret_item<SuiteBS>(o, HT().t, skw); memcpy(pk, o, 32);
+}
+uint32_t hs_pedersen_verify(const uint8_t* h, const uint8_t* g, const uint8_t* proof160, const uint8_t* ad, uint32_t ad_len) {
+  uint32_t enc[5][8], s[8], sb[8], c[8];
+  memcpy(enc[0], h, 32); memcpy(enc[1], g, 32); memcpy(enc[2], proof160, 32); memcpy(enc[3], proof160 + 32, 32);
+  memcpy(enc[4], proof160 + 64, 32); memcpy(s, proof160 + 96, 32); memcpy(sb, proof160 + 128, 32);
+  std::vector<uint32_t> tabs(3 * WIN_TABLE_WORDS), pts(PROVE_PTS_WORDS);
+  bool valid = pedersen_verify_decode_item<SuiteBS>(c, HT().t, enc, ad, ad_len, tabs.data(), pts.data());
+  uint32_t s2[8], sb2[8];
+  bool canon = fr_is_canonical<SuiteBS>(s) && fr_is_canonical<SuiteBS>(sb);
+  for (int j = 0; j < 8; ++j) { s2[j] = canon ? s[j] : 0; sb2[j] = canon ? sb[j] : 0; }
+  for (int half = 0; half < 2; ++half)
+    pedersen_verify_straus_item<SuiteBS>(pts.data() + half * UV_WORDS, HT().t, tabs.data(), c, s2, sb2, half);
+  return pedersen_verify_finish_item<SuiteBS>(pts.data(), s, sb, valid);
 }
 }

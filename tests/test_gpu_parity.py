@@ -259,3 +259,45 @@ def test_chunked_batches_equal_unchunked(ctx, synth):
     for k in ("output", "c", "s", "pk", "input"):
         assert (a[k] == b[k]).all(), k
     assert (st == 0).all()
+
+
+def test_pedersen_kat_and_mirror(ctx, kat):
+    from ark_ec_vrfs_amd import Input, Secret, VerificationFailure, pedersen
+    v, iv = kat["pedersen"][0], kat["ietf"][0]
+    secret = Secret.from_seed(bytes.fromhex(v["seed"]), ctx=ctx)
+    inp = Input.new(bytes.fromhex(v["alpha"]), ctx=ctx)
+    out = secret.output(inp, ctx=ctx)
+    proof, blinding = pedersen.Prover.prove(secret, inp, out, bytes.fromhex(v["ad"]), ctx=ctx)
+    assert blinding.hex() == v["blinding"] and out.encoded.hex() == iv["gamma"]
+    assert (proof.pk_com.hex(), proof.r.hex(), proof.ok.hex(), proof.s.hex(), proof.sb.hex()) == \
+           (v["pk_com"], v["r"], v["ok"], v["s"], v["sb"])
+    assert pedersen.Verifier.verify(inp, out, bytes.fromhex(v["ad"]), proof, ctx=ctx) is None
+    with pytest.raises(VerificationFailure):
+        pedersen.Verifier.verify(inp, out, b"x", proof, ctx=ctx)
+
+
+@pytest.mark.parametrize("ad", [b"", bytes(range(100))])
+def test_pedersen_matches_c_oracle_at_2048(ctx, synth, ad):
+    n = 2048
+    sk, msg = synth(n, start=20000)
+    ref = co.pedersen_prove_batch(sk, msgs=msg, ad=ad, threads=NCPU)
+    got = ctx.pedersen_prove_batch(sk, msgs=msg, ad=ad)
+    for k in ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input"):
+        assert (got[k] == ref[k]).all(), k
+    assert (got["status"] == 0).all()
+    rnd = np.random.default_rng(2)
+    a = {k: ref[k].copy() for k in ("input", "output", "pk_com", "r", "ok", "s", "sb")}
+    kinds = rnd.integers(0, 9, n)
+    names = [None, "s", "sb", "pk_com", "r", "ok", "output", "input"]
+    for i in range(n):
+        k = kinds[i]
+        if 1 <= k <= 2:
+            a[names[k]][i, rnd.integers(0, 31)] ^= 1 << rnd.integers(0, 8)
+        elif 3 <= k <= 7:
+            a[names[k]][i] = ref[names[k]][(i + 1) % n]
+        elif k == 8:
+            a["s"][i] = np.frombuffer(int(R).to_bytes(32, "little"), np.uint8)      # non-canonical -> InvalidData
+    want = co.pedersen_verify_batch(a["input"], a["output"], a["pk_com"], a["r"], a["ok"], a["s"], a["sb"], ad, threads=NCPU)
+    got = ctx.pedersen_verify_batch(a["input"], a["output"], a["pk_com"], a["r"], a["ok"], a["s"], a["sb"], ad=ad)
+    assert (got == want).all()
+    assert (want[kinds == 0] == 0).all() and (want[kinds == 8] == 2).all() and (want[(kinds >= 1) & (kinds <= 7)] != 0).all()

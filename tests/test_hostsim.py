@@ -132,3 +132,26 @@ def test_decode_and_verify_status_against_oracle(hs):
 def test_comb_entries_match_additive_construction(hs):
     for (w, j) in [(0, 1), (0, 255), (3, 17), (31, 1), (31, 7)]:
         assert hs.hs_comb_entry_check(w, j) == 1
+
+
+def test_pedersen_kat_and_oracle(hs, kat):
+    v, iv = kat["pedersen"][0], kat["ietf"][0]
+    out = ctypes.create_string_buffer(224)
+    a, ad = bytes.fromhex(v["alpha"]), bytes.fromhex(v["ad"])
+    assert hs.hs_pedersen_prove(bytes.fromhex(iv["sk"]), a, len(a), ad, len(ad), out) == 1
+    parts = [out.raw[32 * i:32 * i + 32].hex() for i in range(7)]
+    assert parts == [iv["gamma"], v["pk_com"], v["r"], v["ok"], v["s"], v["sb"], v["blinding"]]
+    proof = out.raw[32:192]
+    h, g = bytes.fromhex(iv["h"]), bytes.fromhex(iv["gamma"])
+    assert hs.hs_pedersen_verify(h, g, proof, ad, len(ad)) == 0
+    for pos in (5, 40, 70, 100, 130):                    # pk_com, R, Ok, s, sb
+        bad = bytearray(proof); bad[pos] ^= 1
+        assert hs.hs_pedersen_verify(h, g, bytes(bad), ad, len(ad)) in (1, 2)
+    sk = o.secret_from_seed(S, o.synth_seed(3)); msg = o.synth_msg(3); ad = bytes(range(90))
+    H = o.data_to_point(S, msg)
+    gm, (pc, R, Ok, s, sb), b = o.pedersen_prove(S, sk, H, ad)
+    assert hs.hs_pedersen_prove(o.scalar_encode(sk), msg, len(msg), ad, len(ad), out) == 1
+    exp = b"".join([o.point_encode(S, gm), o.point_encode(S, pc), o.point_encode(S, R), o.point_encode(S, Ok),
+                    o.scalar_encode(s), o.scalar_encode(sb), o.scalar_encode(b)])
+    assert out.raw == exp
+    assert hs.hs_pedersen_verify(o.point_encode(S, H), o.point_encode(S, gm), out.raw[32:192], ad, len(ad)) == 0

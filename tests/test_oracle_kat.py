@@ -143,3 +143,25 @@ def test_small_order_points_fail_subgroup_check():
     assert o.point_decode(S, enc) == (0, S.q - 1)
     assert co.point_decode(enc, subgroup=False) is not None
     assert co.point_decode(enc, subgroup=True) is None
+
+
+def test_c_oracle_pedersen_kat_and_python(kat, synth):
+    v, iv = kat["pedersen"][0], kat["ietf"][0]
+    r = co.pedersen_prove_batch(hx(iv["sk"]), inputs=hx(iv["h"]), ad=bytes.fromhex(v["ad"]))
+    got = {k: r[k][0].tobytes().hex() for k in ("pk_com", "r", "ok", "s", "sb", "blinding")}
+    assert got == {k: v[k] for k in got} and r["output"][0].tobytes().hex() == iv["gamma"]
+    assert co.pedersen_verify_batch(hx(iv["h"]), r["output"], r["pk_com"], r["r"], r["ok"], r["s"], r["sb"])[0] == 0
+    sk, msg = synth(4, start=40)
+    r = co.pedersen_prove_batch(sk, msgs=msg, ad=b"pedersen ad", threads=2)
+    for i in range(4):
+        skv = int.from_bytes(sk[i].tobytes(), "little")
+        H = o.data_to_point(S, msg[i].tobytes())
+        g, (pc, R, Ok, s, sb), b = o.pedersen_prove(S, skv, H, b"pedersen ad")
+        exp = [o.point_encode(S, g), o.point_encode(S, pc), o.point_encode(S, R), o.point_encode(S, Ok),
+               o.scalar_encode(s), o.scalar_encode(sb), o.scalar_encode(b)]
+        assert [r[k][i].tobytes() for k in ("output", "pk_com", "r", "ok", "s", "sb", "blinding")] == exp
+    st = co.pedersen_verify_batch(r["input"], r["output"], r["pk_com"], r["r"], r["ok"], r["s"], r["sb"], b"pedersen ad")
+    assert (st == 0).all()
+    bad = r["sb"].copy(); bad[1, 0] ^= 1
+    st = co.pedersen_verify_batch(r["input"], r["output"], r["pk_com"], r["r"], r["ok"], r["s"], bad, b"pedersen ad")
+    assert list(st) == [0, 1, 0, 0]
