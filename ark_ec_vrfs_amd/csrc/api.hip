@@ -83,7 +83,7 @@ int32_t alloc_workspace(vrfhip_ctx* ctx, size_t cap) {
     ctx->ws_cap = 0;
     ctx->ws_bytes = 0;
   }
-  size_t tabs_b = cap * 3 * WIN_TABLE_WORDS * sizeof(uint32_t);
+  size_t tabs_b = cap * WS_TABS * WIN_TABLE_WORDS * sizeof(uint32_t);
   size_t pts_b = cap * PROVE_PTS_WORDS * sizeof(uint32_t);
   size_t aux_b = cap * AUX_WORDS * sizeof(uint32_t);
   size_t flags_b = (cap + 255) & ~size_t(255);
@@ -198,7 +198,7 @@ int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out) 
   const size_t comb_bytes = (size_t)32 * 255 * PTA_WORDS * sizeof(uint32_t);
   HIP_TRY_C(hipMalloc(&ctx->d_sqrt_p, sqrt_p_bytes));
   HIP_TRY_C(hipMalloc(&ctx->d_sqrt_lut, lut_bytes));
-  HIP_TRY_C(hipMalloc(&ctx->d_g_win, WIN_TABLE_WORDS * sizeof(uint32_t)));
+  HIP_TRY_C(hipMalloc(&ctx->d_g_win, 2 * WIN_TABLE_WORDS * sizeof(uint32_t)));
   HIP_TRY_C(hipMalloc(&ctx->d_g_comb, comb_bytes));
   HIP_TRY_C(hipMalloc(&ctx->d_b_comb, comb_bytes));
   HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_p, vrfk_tables::SQRT_P, sqrt_p_bytes, hipMemcpyHostToDevice,
@@ -701,8 +701,8 @@ int32_t vrfhip_point_validate_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t
   DeviceGuard guard(ctx->device);
   int32_t rc = ensure_workspace(ctx, n);
   if (rc) return rc;
-  // one window table per item: the tabs region holds 3 per workspace item
-  size_t cap = ctx->ws_cap * 3;
+  // one window table per item: the tabs region holds WS_TABS per workspace item
+  size_t cap = ctx->ws_cap * WS_TABS;
   for (size_t base = 0; base < n; base += cap) {
     size_t m = std::min(cap, n - base);
     launch_point_validate(m, d_points + base * 32, d_xy_out ? d_xy_out + base * 64 : nullptr,

@@ -5,7 +5,7 @@ namespace vrf {
 
 // ---- one-time table construction (context creation) ----
 __global__ void k_init_gwin(uint32_t* g_win) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) build_win_table<SuiteBS>(g_win, SuiteBS::gx(), SuiteBS::gy());
+  if (blockIdx.x == 0 && threadIdx.x == 0) build_glv_tables<SuiteBS>(g_win, SuiteBS::gx(), SuiteBS::gy());
 }
 __global__ void __launch_bounds__(BLOCK) k_init_comb(uint32_t* comb, int which) {
   int t = blockIdx.x * BLOCK + threadIdx.x;

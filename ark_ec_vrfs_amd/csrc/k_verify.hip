@@ -10,7 +10,7 @@ __global__ void __launch_bounds__(BLOCK) k_verify_decode(VerifyArgs a) {
   if (i >= a.n) return;
   uint32_t pk[8], h[8], g[8];
   load32(pk, a.pk, i); load32(h, a.h, i); load32(g, a.gamma, i);
-  bool ok = verify_decode_item<SuiteBS>(a.T, pk, h, g, a.ws.tabs + i * (3 * WIN_TABLE_WORDS));
+  bool ok = verify_decode_item<SuiteBS>(a.T, pk, h, g, a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS));
   a.ws.flags[i] = ok ? 1 : 0;
 }
 
@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(BLOCK) k_verify_straus(VerifyArgs a) {
   uint32_t c[8], s[8];
   load32(c, a.c, i); load32(s, a.s, i);
   verify_straus_item<SuiteBS>(a.ws.pts + i * (2 * UV_WORDS) + half * UV_WORDS, a.T,
-                              a.ws.tabs + i * (3 * WIN_TABLE_WORDS), c, s, half);
+                              a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), c, s, half);
 }
 
 // stage 3: one lane per proof.  Affine U, V; challenge hash; compare.

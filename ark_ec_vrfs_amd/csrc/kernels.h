@@ -26,16 +26,17 @@ VRF_HD void bytes_get(const BytesView& v, size_t i, const uint8_t*& p, uint32_t&
 }
 
 constexpr int AUX_WORDS = 32;
+constexpr int WS_TABS = 6;
 
 // per-context device workspace (capacity `cap` items)
 struct Workspace {
-  uint32_t* tabs;    // [cap][3][WIN_TABLE_WORDS]   window tables
+  uint32_t* tabs;    // [cap][WS_TABS][WIN_TABLE_WORDS]  window tables (verify: 6 GLV tables per proof)
   uint32_t* pts;     // [cap][PROVE_PTS_WORDS]      projective intermediates (verify uses 2*UV_WORDS)
   uint32_t* aux;     // [cap][32]   prove: enc(H) | k | blinding b | kb ; Pedersen verify: challenge c
   uint8_t* flags;    // [cap]                       validity of decoded inputs
 };
 constexpr size_t WS_BYTES_PER_ITEM =
-    (3 * WIN_TABLE_WORDS + PROVE_PTS_WORDS + AUX_WORDS) * sizeof(uint32_t) + 1;
+    (WS_TABS * WIN_TABLE_WORDS + PROVE_PTS_WORDS + AUX_WORDS) * sizeof(uint32_t) + 1;
 
 struct VerifyArgs {
   size_t n;

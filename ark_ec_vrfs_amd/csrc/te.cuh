@@ -166,6 +166,35 @@ VRF_HD PtE te_add_affine(const PtE& p, const PtA& q, bool neg) {
   return r;
 }
 
+// Bandersnatch GLV endomorphism psi(x, y) = (c(1 - y^2)/(xy), b(y^2 + b)/(y^2 - b)); on the
+// prime-order subgroup psi(P) = LAMBDA * P.  Projective: 2S + 8M.  x*y = 0 happens in the
+// subgroup only for the identity, which maps to the identity.
+template <class C>
+VRF_HD PtE te_psi(const PtE& p) {
+  const FeN b = fe_const(vrfk::BS_PSI_B_M), c = fe_const(vrfk::BS_PSI_C_M);
+  auto YY = fe_sqr(p.Y);                      // (1,2)
+  auto ZZ = fe_sqr(p.Z);
+  auto XY = fe_mul(p.X, p.Y);
+  auto bZZ = fe_mul(ZZ, b);
+  auto A = fe_sub(ZZ, YY);                    // Z^2 - Y^2            (3,6)
+  auto Bv = fe_sub(YY, bZZ);                  // Y^2 - b Z^2          (3,6)
+  auto Cv = fe_add(YY, bZZ);                  // Y^2 + b Z^2          (2,4)
+  auto cA = fe_mul(A, c);
+  auto bC = fe_mul(Cv, b);
+  PtE r;
+  r.X = fe_mul(cA, Bv);
+  r.Y = fe_mul(bC, XY);
+  r.Z = fe_mul(XY, Bv);
+  r.T = fe_mul(cA, bC);
+  bool exc = fe_is_zero(r.Z);
+  PtE id = te_identity();
+  r.X = fe_select(exc, id.X, r.X);
+  r.Y = fe_select(exc, id.Y, r.Y);
+  r.Z = fe_select(exc, id.Z, r.Z);
+  r.T = fe_select(exc, id.T, r.T);
+  return r;
+}
+
 // general extended + extended (used off the hot loop: table building, h2c)
 template <class C>
 VRF_HD PtE te_add(const PtE& p, const PtE& q) {

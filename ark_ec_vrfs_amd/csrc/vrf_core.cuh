@@ -16,7 +16,7 @@ enum : uint32_t { ST_OK = 0, ST_VERIFICATION_FAILURE = 1, ST_INVALID_DATA = 2 };
 // Shared, read-only device tables (built once per context, see kernels.hip: k_init_tables)
 struct DevTables {
   SqrtTables sq;
-  const uint32_t* g_win;     // [8][PTC_WORDS]       j*G, j = 1..8, cached form (Straus table of G)
+  const uint32_t* g_win;     // [2][8][PTC_WORDS]    j*G and j*psi(G), j = 1..8, cached form
   const uint32_t* g_comb;    // [32][255][PTA_WORDS] j*256^w*G affine (fixed-base comb)
   const uint32_t* b_comb;    // same for the Pedersen blinding base
 };
@@ -110,6 +110,30 @@ VRF_HD bool decode_phase_b(Fe<1, 4>& x_out, const DecodeA& a, const FeN& den_inv
 // multiples 1..8 of an affine point, cached form, written to `tab` (WIN_TABLE_WORDS words).
 // One unified-add call site in a loop (the unified law also doubles).
 template <class C>
+VRF_HD void build_win_table_from(uint32_t* tab, PtE acc) {
+  PtC c1 = te_to_cached<C>(acc);
+  ptc_store(tab, c1);
+#pragma unroll 1
+  for (int j = 1; j < WIN_ENTRIES; ++j) {
+    acc = te_add_cached<C>(acc, c1, false);
+    ptc_store(tab + j * PTC_WORDS, te_to_cached<C>(acc));
+  }
+}
+// the pair of tables GLV needs: multiples of P and of psi(P) (2 * WIN_TABLE_WORDS words).
+// One add call site: a two-trip loop over {P, psi(P)}.
+template <class C>
+VRF_HD void build_glv_tables(uint32_t* tab, const FeP& x, const FeP& y) {
+  PtE p = te_from_affine(x, y);
+  PtE q = te_psi<C>(p);
+#pragma unroll 1
+  for (int t = 0; t < 2; ++t) {
+    PtE acc;
+    acc.X = fe_select(t == 0, p.X, q.X); acc.Y = fe_select(t == 0, p.Y, q.Y);
+    acc.Z = fe_select(t == 0, p.Z, q.Z); acc.T = fe_select(t == 0, p.T, q.T);
+    build_win_table_from<C>(tab + t * WIN_TABLE_WORDS, acc);
+  }
+}
+template <class C>
 VRF_HD void build_win_table(uint32_t* tab, const FeP& x, const FeP& y) {
   PtE acc = te_from_affine(x, y);
   PtC c1 = te_to_cached<C>(acc);
@@ -159,6 +183,37 @@ VRF_HD PtE straus2(const uint32_t* tabA, const uint32_t reca[8], const uint32_t*
       const uint32_t* tab = t ? tabB : tabA;
       int d = scalar_digit4(rec, w);
       acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != (t != 0 && negB));
+    }
+  }
+  return acc;
+}
+
+// GLV Straus: sum_{t<4} (+/-) k_t * P_t with 128-bit k_t, signed radix-16, 32 windows, 128
+// doublings.  tabs[t] are window tables, rec[t] recoded magnitudes, neg[t] the term's sign.
+struct Straus4 {
+  const uint32_t* tab[4];
+  uint32_t rec[4][4];
+  bool neg[4];
+};
+template <class C>
+VRF_HD PtE straus4(const Straus4& q) {
+  PtE acc = te_identity();
+#pragma unroll 1
+  for (int w = 31; w >= 0; --w) {
+    if (w != 31) {
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) acc = te_dbl<C>(acc, j == 3);
+    }
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+      uint32_t rec[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        rec[i] = t == 0 ? q.rec[0][i] : t == 1 ? q.rec[1][i] : t == 2 ? q.rec[2][i] : q.rec[3][i];
+      const uint32_t* tab = t == 0 ? q.tab[0] : t == 1 ? q.tab[1] : t == 2 ? q.tab[2] : q.tab[3];
+      bool neg = t == 0 ? q.neg[0] : t == 1 ? q.neg[1] : t == 2 ? q.neg[2] : q.neg[3];
+      int d = scalar_digit4_128(rec, w);
+      acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != neg);
     }
   }
   return acc;
@@ -307,7 +362,8 @@ VRF_HD FeN fe_sel3(int p, const FeN& a, const FeN& b, const FeN& c) {
   return fe_select(p == 0, a, fe_select(p == 1, b, c));
 }
 
-// tabs: 3 * WIN_TABLE_WORDS words (tables of Y, H, Gamma).  Returns validity of the encodings.
+constexpr int VERIFY_TABS = 6;   // Y, psi Y, H, psi H, Gamma, psi Gamma
+// tabs: 6 * WIN_TABLE_WORDS words (GLV table pairs of Y, H, Gamma).  Returns validity.
 template <class S>
 VRF_HD bool verify_decode_item(const DevTables& T, const uint32_t pk[8], const uint32_t hh[8],
                                const uint32_t gamma[8], uint32_t* tabs) {
@@ -326,21 +382,30 @@ VRF_HD bool verify_decode_item(const DevTables& T, const uint32_t pk[8], const u
     FeN di = fe_sel3(p, dinv[0], dinv[1], dinv[2]);
     Fe<1, 4> x;
     valid = decode_phase_b<S>(x, a, di, T.sq) && valid;
-    build_win_table<S>(tabs + p * WIN_TABLE_WORDS, x, a.y);
+    build_glv_tables<S>(tabs + p * 2 * WIN_TABLE_WORDS, x, a.y);
   }
   return valid;
 }
 
-// half 0: U = s*G - c*Y (tables: g_win, tabs[0]) ; half 1: V = s*H - c*Gamma (tabs[1], tabs[2])
+// half 0: U = s*G - c*Y (tables: g_win pair, tabs[0..1]) ; half 1: V = s*H - c*Gamma (tabs[2..5]).
+// GLV: s = s1 + s2*lambda, c = c1 + c2*lambda; four 128-bit scalars over {P, psi P, Q, psi Q}.
 template <class S>
 VRF_HD void verify_straus_item(uint32_t* out_uv, const DevTables& T, const uint32_t* tabs,
                                const uint32_t c[8], const uint32_t s[8], int half) {
-  uint32_t recs[8], recc[8];
-  scalar_recode_signed4(recs, s);
-  scalar_recode_signed4(recc, c);
-  const uint32_t* tabA = half ? tabs + WIN_TABLE_WORDS : T.g_win;
-  const uint32_t* tabB = half ? tabs + 2 * WIN_TABLE_WORDS : tabs;
-  PtE r = straus2<S>(tabA, recs, tabB, recc, true);
+  GlvHalf h[4];
+  glv_decompose_bs(h[0], h[1], s);
+  glv_decompose_bs(h[2], h[3], c);
+  Straus4 q;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    scalar_recode_signed4_128(q.rec[t], h[t].mag);
+    q.neg[t] = h[t].neg != (t >= 2);            // the c terms are subtracted
+  }
+  const uint32_t* base_s = half ? tabs + 2 * WIN_TABLE_WORDS : T.g_win;
+  const uint32_t* base_c = half ? tabs + 4 * WIN_TABLE_WORDS : tabs;
+  q.tab[0] = base_s; q.tab[1] = base_s + WIN_TABLE_WORDS;
+  q.tab[2] = base_c; q.tab[3] = base_c + WIN_TABLE_WORDS;
+  PtE r = straus4<S>(q);
   fe_store(out_uv, r.X);
   fe_store(out_uv + NL, r.Y);
   fe_store(out_uv + 2 * NL, r.Z);

@@ -17,8 +17,8 @@ struct HostTables {
   std::vector<uint32_t> g_win, g_comb, b_comb;
   DevTables t;
   HostTables() {
-    g_win.resize(WIN_TABLE_WORDS);
-    build_win_table<SuiteBS>(g_win.data(), SuiteBS::gx(), SuiteBS::gy());
+    g_win.resize(2 * WIN_TABLE_WORDS);
+    build_glv_tables<SuiteBS>(g_win.data(), SuiteBS::gx(), SuiteBS::gy());
     g_comb.resize((size_t)32 * 255 * PTA_WORDS);
     b_comb.resize((size_t)32 * 255 * PTA_WORDS);
     // comb by repeated addition instead of 8160 scalar multiplications (host is slow):

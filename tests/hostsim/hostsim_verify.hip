@@ -18,8 +18,8 @@ struct HostTables {
   std::vector<uint32_t> g_win;
   DevTables t;
   HostTables() {
-    g_win.resize(WIN_TABLE_WORDS);
-    build_win_table<SuiteBS>(g_win.data(), SuiteBS::gx(), SuiteBS::gy());
+    g_win.resize(2 * WIN_TABLE_WORDS);
+    build_glv_tables<SuiteBS>(g_win.data(), SuiteBS::gx(), SuiteBS::gy());
     t.sq = host_tables(); t.g_win = g_win.data(); t.g_comb = nullptr; t.b_comb = nullptr;
   }
 };
@@ -30,10 +30,26 @@ uint32_t hs_ietf_verify(const uint8_t* pk, const uint8_t* h, const uint8_t* g, c
                         const uint8_t* s, const uint8_t* ad, uint32_t ad_len) {
   uint32_t w[5][8];
   memcpy(w[0], pk, 32); memcpy(w[1], h, 32); memcpy(w[2], g, 32); memcpy(w[3], c, 32); memcpy(w[4], s, 32);
-  std::vector<uint32_t> tabs(3 * WIN_TABLE_WORDS), uv(2 * UV_WORDS);
+  std::vector<uint32_t> tabs(VERIFY_TABS * WIN_TABLE_WORDS), uv(2 * UV_WORDS);
   bool valid = verify_decode_item<SuiteBS>(HT().t, w[0], w[1], w[2], tabs.data());
   for (int half = 0; half < 2; ++half)
     verify_straus_item<SuiteBS>(uv.data() + half * UV_WORDS, HT().t, tabs.data(), w[3], w[4], half);
   return verify_finish_item<SuiteBS>(uv.data(), w[0], w[1], w[2], w[3], w[4], valid, ad, ad_len);
+}
+// GLV pieces: k -> (k1, k2) as 2 x (16 B magnitude, 1 B sign) ; psi(P) encoded
+void hs_glv_decompose(const uint8_t* k, uint8_t* out34) {
+  uint32_t kw[8]; memcpy(kw, k, 32);
+  GlvHalf a, b; glv_decompose_bs(a, b, kw);
+  memcpy(out34, a.mag, 16); out34[16] = a.neg; memcpy(out34 + 17, b.mag, 16); out34[33] = b.neg;
+}
+int hs_psi(const uint8_t* enc, uint8_t* out) {
+  uint32_t w[8]; memcpy(w, enc, 32);
+  DecodeA a = decode_phase_a<SuiteBS>(w);
+  FeN di = fe_inv(a.den);
+  Fe<1,4> x; bool ok = decode_phase_b<SuiteBS>(x, a, di, HT().t.sq);
+  PtE q = te_psi<SuiteBS>(te_from_affine(x, a.y));
+  FeN qx, qy; te_to_affine(qx, qy, q);
+  uint32_t e[8]; te_encode_affine(e, qx, qy); memcpy(out, e, 32);
+  return ok;
 }
 }

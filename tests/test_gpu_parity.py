@@ -301,3 +301,16 @@ def test_pedersen_matches_c_oracle_at_2048(ctx, synth, ad):
     got = ctx.pedersen_verify_batch(a["input"], a["output"], a["pk_com"], a["r"], a["ok"], a["s"], a["sb"], ad=ad)
     assert (got == want).all()
     assert (want[kinds == 0] == 0).all() and (want[kinds == 8] == 2).all() and (want[(kinds >= 1) & (kinds <= 7)] != 0).all()
+
+
+def test_identity_points_zero_secret(ctx):
+    """sk = 0 gives pk = Gamma = identity; arkworks accepts such a proof, so must the GLV path."""
+    zero = np.zeros((1, 32), np.uint8)
+    msg = np.frombuffer(b"zero-key-message-0123456789abcdef"[:32], np.uint8).reshape(1, 32)
+    ref = co.ietf_prove_batch(zero, msgs=msg, ad=b"")
+    got = ctx.ietf_prove_batch(zero, msgs=msg, ad=b"")
+    for k in ("output", "c", "s", "pk"):
+        assert (got[k] == ref[k]).all(), k
+    assert got["pk"][0].tobytes() == (1).to_bytes(32, "little")
+    assert co.ietf_verify_batch(ref["pk"], ref["input"], ref["output"], ref["c"], ref["s"], b"")[0] == 0
+    assert ctx.ietf_verify_batch(ref["pk"], ref["input"], ref["output"], ref["c"], ref["s"], ad=b"")[0] == 0

@@ -155,3 +155,36 @@ def test_pedersen_kat_and_oracle(hs, kat):
                     o.scalar_encode(s), o.scalar_encode(sb), o.scalar_encode(b)])
     assert out.raw == exp
     assert hs.hs_pedersen_verify(o.point_encode(S, H), o.point_encode(S, gm), out.raw[32:192], ad, len(ad)) == 0
+
+
+def test_glv_decomposition_and_endomorphism(hs):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "..", "tools"))
+    import gen_constants as gc
+    lam = gc.glv_constants()["lam"]
+    r = S.r
+    rnd = random.Random(8)
+    out = ctypes.create_string_buffer(34)
+    for it in range(5000):
+        k = [0, 1, r - 1, r - 2, lam, r - lam, (r - 1) // 2][it] if it < 7 else rnd.randrange(r)
+        hs.hs_glv_decompose(k.to_bytes(32, "little"), out)
+        k1 = int.from_bytes(out.raw[0:16], "little") * (-1 if out.raw[16] else 1)
+        k2 = int.from_bytes(out.raw[17:33], "little") * (-1 if out.raw[33] else 1)
+        assert (k1 + k2 * lam - k) % r == 0
+        assert abs(k1) < (1 << 127) - (1 << 123) and abs(k2) < (1 << 127) - (1 << 123)   # 32 signed nibbles suffice
+    buf = ctypes.create_string_buffer(32)
+    G = (S.gx, S.gy)
+    for i in (1, 2, 3, 77, 12345):
+        P = o.te_mul(S, i, G)
+        assert hs.hs_psi(o.point_encode(S, P), buf) == 1
+        assert buf.raw == o.point_encode(S, o.te_mul(S, lam, P))
+    assert hs.hs_psi(o.point_encode(S, (0, 1)), buf) == 1 and buf.raw == o.point_encode(S, (0, 1))
+
+
+def test_zero_secret_proof_is_accepted(hs):
+    """sk = 0: pk and Gamma are the identity (a subgroup point on which psi's formula degenerates)."""
+    H = o.data_to_point(S, b"zero-key")
+    g, c, s = o.ietf_prove(S, 0, H, b"")
+    assert o.ietf_verify(S, (0, 1), H, g, b"", c, s)
+    enc = [o.point_encode(S, (0, 1)), o.point_encode(S, H), o.point_encode(S, g), o.scalar_encode(c), o.scalar_encode(s)]
+    assert hs.hs_ietf_verify(*enc, b"", 0) == 0
