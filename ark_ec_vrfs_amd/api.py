@@ -234,6 +234,27 @@ class Context:
             s.data_ptr(), sb.data_ptr(), dp(ad), dp(ad_off), ad_len, status.data_ptr(), st),
             "vrfhip_pedersen_verify_batch_dev")
 
+    def msm(self, bases_xy, scalars):
+        """`VariableBaseMSM::msm`: sum_i scalars[i] * bases[i].  bases_xy: (n, 64) affine x||y LE;
+        scalars: (n, 32) LE.  Returns (point32, xy64); raises InvalidData on bad inputs."""
+        b = np.ascontiguousarray(bases_xy, dtype=np.uint8).reshape(-1, 64)
+        k = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        if b.shape[0] != k.shape[0]:
+            raise ValueError("ragged batch")
+        out, xy, st = np.empty(32, np.uint8), np.empty(64, np.uint8), np.empty(1, np.uint8)
+        _lib.check(self._lib.vrfhip_msm(self._h, b.shape[0], _ptr(b) if b.size else None, _ptr(k) if k.size else None,
+                                        _ptr(out), _ptr(xy), _ptr(st)), "vrfhip_msm")
+        if st[0] != ST_OK:
+            raise InvalidData()
+        return out.tobytes(), xy.tobytes()
+
+    def msm_dev(self, bases_xy, scalars, out_point, out_xy, status, stream=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _lib.check(self._lib.vrfhip_msm_dev(self._h, bases_xy.shape[0], bases_xy.data_ptr(), scalars.data_ptr(),
+                                            out_point.data_ptr(), None if out_xy is None else out_xy.data_ptr(),
+                                            status.data_ptr(), st), "vrfhip_msm_dev")
+
     def hash_to_curve_batch(self, msgs) -> np.ndarray:
         if isinstance(msgs, np.ndarray):
             m = np.ascontiguousarray(msgs, dtype=np.uint8)

@@ -54,6 +54,10 @@ struct vrfhip_ctx {
   size_t chunk_limit = DEFAULT_CHUNK; // largest number of items processed per launch group
   size_t ws_bytes = 0;
   Workspace ws{};
+  // MSM workspace (grown on demand) and device facts
+  void* d_msm_ws = nullptr;
+  size_t msm_ws_bytes = 0;
+  int cus = 256;
   // optional per-stage timing (hipEvents on the launch stream), see vrfhip_ctx_profile
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;   // 4 per launch group
@@ -193,6 +197,11 @@ int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out) 
       return cleanup(fail(VRFHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__))); \
   } while (0)
   HIP_TRY_C(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+      ctx->cus = cus;
+  }
   const size_t sqrt_p_bytes = sizeof(vrfk_tables::SQRT_P);
   const size_t lut_bytes = sizeof(vrfk_tables::SQRT_LUT);
   const size_t comb_bytes = (size_t)32 * 255 * PTA_WORDS * sizeof(uint32_t);
@@ -226,6 +235,7 @@ void vrfhip_ctx_destroy(vrfhip_ctx* ctx) {
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_msm_ws) (void)hipFree(ctx->d_msm_ws);
     if (ctx->d_sqrt_p) (void)hipFree(ctx->d_sqrt_p);
     if (ctx->d_sqrt_lut) (void)hipFree(ctx->d_sqrt_lut);
     if (ctx->d_g_win) (void)hipFree(ctx->d_g_win);
@@ -570,6 +580,67 @@ int32_t vrfhip_pedersen_verify_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* i
                                         ad_off ? d_off : nullptr, ad_len, d_st, ctx->stream);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
+// ------------------------------------------------------------------------- MSM
+int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, const uint8_t* d_scalars,
+                       uint8_t* d_out_point, uint8_t* d_out_xy, uint8_t* d_status, void* stream) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (!d_out_point || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
+  if (n && (!d_bases_xy || !d_scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n == 0) {                       // empty sum: the identity (0, 1)
+    uint8_t id[64] = {0};
+    id[32] = 1;
+    uint8_t enc[32] = {1};
+    HIP_TRY(hipMemcpyAsync(d_out_point, enc, 32, hipMemcpyHostToDevice, st));
+    if (d_out_xy) HIP_TRY(hipMemcpyAsync(d_out_xy, id, 64, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_status, 0, 1, st));
+    HIP_TRY(hipStreamSynchronize(st));     // the sources above are stack buffers
+    return VRFHIP_SUCCESS;
+  }
+  int groups = msm_groups(n, ctx->cus);
+  size_t need = msm_workspace_bytes(n, groups);
+  if (need > ctx->msm_ws_bytes) {
+    if (ctx->d_msm_ws) HIP_TRY(hipFree(ctx->d_msm_ws));
+    ctx->d_msm_ws = nullptr;
+    ctx->msm_ws_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx->d_msm_ws, need));
+    ctx->msm_ws_bytes = need;
+  }
+  launch_msm(n, d_bases_xy, d_scalars, d_out_point, d_out_xy, d_status, ctx->d_msm_ws, groups, st);
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases_xy, const uint8_t* scalars,
+                   uint8_t* out_point, uint8_t* out_xy, uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (!out_point || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
+  if (n && (!bases_xy || !scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_stage(ctx, Stage::pad(n * 64 + 1) + Stage::pad(n * 32 + 1) + 3 * 256);
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t* d_xy = sg.take(n * 64 + 1);
+  uint8_t* d_k = sg.take(n * 32 + 1);
+  uint8_t* d_out = sg.take(32);
+  uint8_t* d_oxy = sg.take(64);
+  uint8_t* d_st = sg.take(1);
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(d_xy, bases_xy, n * 64, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_k, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  }
+  rc = vrfhip_msm_dev(ctx, n, d_xy, d_k, d_out, d_oxy, d_st, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out_point, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_xy) HIP_TRY(hipMemcpyAsync(out_xy, d_oxy, 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(status, d_st, 1, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return VRFHIP_SUCCESS;
 }

@@ -155,6 +155,20 @@ int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_
                                          const uint32_t* d_ad_off, uint32_t ad_len,
                                          uint8_t* d_status, void* stream);
 
+/* Multi-scalar multiplication ---------------------------------------------------------- */
+
+/* `VariableBaseMSM::msm(bases, scalars)` on the suite curve (ark_ec, named in BASELINE.json;
+ * reached through `reexports`, src/lib.rs:14): result = sum_i scalars[i] * bases[i].
+ * bases_xy: n x 64 B affine points (x || y, 32-byte little-endian canonical each -- what
+ * vrfhip_point_validate_batch emits); scalars: n x 32 B LE canonical.
+ * out_point: 32 B compressed result; out_xy: 64 B affine result (may be NULL);
+ * status: 1 byte, 0 = Ok, 2 = InvalidData (a coordinate >= q, a point off the curve, or a
+ * scalar >= r; the outputs are then zeroed).  n = 0 gives the identity. */
+int32_t vrfhip_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases_xy, const uint8_t* scalars,
+                   uint8_t* out_point, uint8_t* out_xy, uint8_t* status);
+int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, const uint8_t* d_scalars,
+                       uint8_t* d_out_point, uint8_t* d_out_xy, uint8_t* d_status, void* stream);
+
 /* Building blocks --------------------------------------------------------------------- */
 
 /* `Input::new(data)` = Suite::data_to_point = hash_to_curve_ell2_rfc_9380 (src/lib.rs:14-16):

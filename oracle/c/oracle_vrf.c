@@ -635,6 +635,27 @@ void oracle_pedersen_prove_batch(size_t n, const uint8_t* sk, const uint8_t* msg
   j.o0 = gamma; j.o1 = proof160; j.o2 = blinding_out; j.o4 = h_out; j.st = status;
   run_batch(j, n, threads);
 }
+/* [ark_ec VariableBaseMSM::msm] naive reference: sum_i k_i * P_i, affine x||y inputs (64 B LE each).
+ * Returns 0 / 2 (coordinate >= q, off-curve point or scalar >= r). */
+int oracle_msm(size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t out_enc[32], uint8_t out_xy[64]) {
+  ensure_init();
+  pt acc; pt_identity(&acc);
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t xi[4], yi[4], k[4];
+    load_le(xi, xy + 64 * i); load_le(yi, xy + 64 * i + 32); load_le(k, scalars + 32 * i);
+    if (cmp4(xi, FQ.m) >= 0 || cmp4(yi, FQ.m) >= 0 || cmp4(k, FR.m) >= 0) return 2;
+    fp x, y, x2, y2, l, r1, one; q_from_int(&x, xi); q_from_int(&y, yi); q_one(&one);
+    q_sqr(&x2, &x); q_sqr(&y2, &y);
+    q_mul(&l, &BS_A_M, &x2); q_add(&l, &l, &y2);
+    q_mul(&r1, &x2, &y2); q_mul(&r1, &r1, &BS_D_M); q_add(&r1, &r1, &one);
+    if (!q_eq(&l, &r1)) return 2;
+    pt p, kp; pt_from_affine(&p, &x, &y); pt_mul(&kp, &p, k); pt_add(&acc, &acc, &kp);
+  }
+  fp x, y; pt_to_affine(&x, &y, &acc);
+  point_encode(out_enc, &x, &y);
+  if (out_xy) { uint64_t t[4]; q_to_int(t, &x); store_le(out_xy, t); q_to_int(t, &y); store_le(out_xy + 32, t); }
+  return 0;
+}
 /* test hooks for the field layer */
 void oracle_fq_mul(const uint8_t a[32], const uint8_t b[32], uint8_t r[32]) {
   ensure_init();

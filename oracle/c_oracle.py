@@ -33,6 +33,8 @@ def load() -> ctypes.CDLL:
         lib.oracle_pedersen_verify_batch.restype = None
         lib.oracle_pedersen_prove_batch.argtypes = [c_size_t, P, P, c_size_t, P, P, c_size_t, P, P, P, P, P, c_int]
         lib.oracle_pedersen_prove_batch.restype = None
+        lib.oracle_msm.argtypes = [c_size_t, P, P, P, P]
+        lib.oracle_msm.restype = c_int
         lib.oracle_hash_to_curve.argtypes = [P, c_size_t, P]
         lib.oracle_output_hash.argtypes = [P, P]
         lib.oracle_secret_from_seed.argtypes = [P, c_size_t, P]
@@ -112,6 +114,17 @@ def pedersen_verify_batch(h, gamma, pk_com, r, ok, s, sb, ad: bytes = b"", threa
     load().oracle_pedersen_verify_batch(n, arrs[0].ctypes.data, arrs[1].ctypes.data, proof.ctypes.data,
                                         adb.ctypes.data, len(ad), st.ctypes.data, threads)
     return st
+
+
+def msm(bases_xy, scalars):
+    """Naive sum_i k_i * P_i.  Returns (point32, xy64) or None on invalid input."""
+    b = _a(bases_xy).reshape(-1, 64)
+    k = _a(scalars).reshape(-1, 32)
+    out, xy = np.empty(32, np.uint8), np.empty(64, np.uint8)
+    b2 = np.concatenate([b.reshape(-1), np.zeros(1, np.uint8)])
+    k2 = np.concatenate([k.reshape(-1), np.zeros(1, np.uint8)])
+    rc = load().oracle_msm(b.shape[0], b2.ctypes.data, k2.ctypes.data, out.ctypes.data, xy.ctypes.data)
+    return None if rc else (out.tobytes(), xy.tobytes())
 
 
 def hash_to_curve(msg: bytes) -> bytes:

@@ -314,3 +314,77 @@ def test_identity_points_zero_secret(ctx):
     assert got["pk"][0].tobytes() == (1).to_bytes(32, "little")
     assert co.ietf_verify_batch(ref["pk"], ref["input"], ref["output"], ref["c"], ref["s"], b"")[0] == 0
     assert ctx.ietf_verify_batch(ref["pk"], ref["input"], ref["output"], ref["c"], ref["s"], ad=b"")[0] == 0
+
+
+def _xy_of(ctx, enc):
+    st, xy = ctx.point_validate_batch(enc, want_xy=True)
+    assert (st == 0).all()
+    return xy
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 1000, 5000])
+def test_msm_matches_naive_oracle(ctx, n):
+    rnd = np.random.default_rng(n)
+    seeds = rnd.integers(0, 256, (n, 8), dtype=np.uint8)
+    sk, pk = ctx.secret_from_seed_batch(seeds)
+    xy = _xy_of(ctx, pk)
+    k, _ = ctx.secret_from_seed_batch(rnd.integers(0, 256, (n, 9), dtype=np.uint8), with_public=False)
+    if n >= 3:
+        k[0] = 0                                              # zero scalar
+        k[1] = np.frombuffer(int(R - 1).to_bytes(32, "little"), np.uint8)
+        xy[2] = xy[1]                                         # repeated base
+    got = ctx.msm(xy, k)
+    want = co.msm(xy, k)
+    assert got == want
+
+
+def test_msm_edge_cases(ctx):
+    from ark_ec_vrfs_amd import InvalidData
+    out, xy = ctx.msm(np.empty((0, 64), np.uint8), np.empty((0, 32), np.uint8))
+    assert out == (1).to_bytes(32, "little") and xy == bytes(32) + (1).to_bytes(32, "little")
+    sk, pk = ctx.secret_from_seed_batch(np.arange(16, dtype=np.uint8).reshape(4, 4))
+    xy4 = _xy_of(ctx, pk)
+    one = np.zeros((4, 32), np.uint8); one[:, 0] = 1
+    # P - P + Q - Q = identity (buckets that cancel)
+    neg = xy4.copy()
+    for i in (1, 3):
+        x = int.from_bytes(xy4[i - 1, :32].tobytes(), "little")
+        neg[i, :32] = np.frombuffer(((Q - x) % Q).to_bytes(32, "little"), np.uint8)
+        neg[i, 32:] = xy4[i - 1, 32:]
+    assert ctx.msm(neg, one)[0] == (1).to_bytes(32, "little")
+    bad = xy4.copy(); bad[2, 0] ^= 1                          # off the curve
+    with pytest.raises(InvalidData):
+        ctx.msm(bad, one)
+    bigk = one.copy(); bigk[0] = np.frombuffer(int(R).to_bytes(32, "little"), np.uint8)
+    with pytest.raises(InvalidData):
+        ctx.msm(xy4, bigk)
+
+
+def test_msm_full_size_2_20_linearity(ctx):
+    """bases a_i*G with known a_i: MSM(bases, k) must equal (sum a_i k_i mod r)*G."""
+    import torch
+    from ark_ec_vrfs_amd import _lib
+    n = 1 << 20
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    st0 = torch.cuda.current_stream().cuda_stream
+    seeds = torch.arange(n, dtype=torch.int64, device=dev).view(torch.uint8).reshape(n, 8)
+    a = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    pk = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    _lib.check(lib.vrfhip_secret_from_seed_batch_dev(ctx.handle, n, seeds.data_ptr(), 8, a.data_ptr(), pk.data_ptr(), st0), "seed")
+    xy = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+    vst = torch.empty(n, dtype=torch.uint8, device=dev)
+    _lib.check(lib.vrfhip_point_validate_batch_dev(ctx.handle, n, pk.data_ptr(), xy.data_ptr(), vst.data_ptr(), st0), "validate")
+    seeds2 = (torch.arange(n, dtype=torch.int64, device=dev) + (1 << 40)).view(torch.uint8).reshape(n, 8)
+    k = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    _lib.check(lib.vrfhip_secret_from_seed_batch_dev(ctx.handle, n, seeds2.data_ptr(), 8, k.data_ptr(), None, st0), "seed2")
+    out = torch.empty(32, dtype=torch.uint8, device=dev); st = torch.empty(1, dtype=torch.uint8, device=dev)
+    ctx.msm_dev(xy, k, out, None, st)
+    torch.cuda.synchronize()
+    assert int(vst.sum()) == 0 and int(st[0]) == 0
+    an = a.cpu().numpy(); kn = k.cpu().numpy()
+    tot = 0
+    for i in range(n):
+        tot += int.from_bytes(an[i].tobytes(), "little") * int.from_bytes(kn[i].tobytes(), "little")
+    want = co.public_from_secret((tot % R).to_bytes(32, "little"))
+    assert out.cpu().numpy().tobytes() == want

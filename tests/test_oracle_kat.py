@@ -165,3 +165,19 @@ def test_c_oracle_pedersen_kat_and_python(kat, synth):
     bad = r["sb"].copy(); bad[1, 0] ^= 1
     st = co.pedersen_verify_batch(r["input"], r["output"], r["pk_com"], r["r"], r["ok"], r["s"], bad, b"pedersen ad")
     assert list(st) == [0, 1, 0, 0]
+
+
+def test_c_oracle_msm_against_python(synth):
+    G = (S.gx, S.gy)
+    pts = [o.te_mul(S, 3 + 5 * i, G) for i in range(5)]
+    ks = [7, 0, S.r - 1, 123456789, 2 ** 200 + 17]
+    acc = (0, 1)
+    for P, k in zip(pts, ks):
+        acc = o.te_add(S, acc, o.te_mul(S, k, P))
+    xy = np.frombuffer(b"".join(P[0].to_bytes(32, "little") + P[1].to_bytes(32, "little") for P in pts), np.uint8)
+    kk = np.frombuffer(b"".join(k.to_bytes(32, "little") for k in ks), np.uint8)
+    enc, out_xy = co.msm(xy, kk)
+    assert enc == o.point_encode(S, acc)
+    assert out_xy == acc[0].to_bytes(32, "little") + acc[1].to_bytes(32, "little")
+    bad = xy.copy(); bad[0] ^= 1
+    assert co.msm(bad, kk) is None
