@@ -3,7 +3,9 @@
 // (named in BASELINE.json north_star; reached from /root/reference through `reexports`,
 // src/lib.rs:14).
 //
-// Pippenger with signed 11-bit windows (24 windows x 1024 buckets):
+// Pippenger with signed 11-bit windows (23 windows x 1024 buckets).  Scalars k > r/2 are replaced
+// by r - k with the point's sign flipped, so k < 2^252 and the top window never carries out (a
+// 24th carry-only window would put half of all points into a single bucket).
 //   k_msm_prep    : bases -> Montgomery affine-cached (x, y, d*x*y); scalars -> signed digits
 //   k_msm_buckets : one workgroup per (window, point-group).  Per slice of 16384 points the
 //                   workgroup counting-sorts the slice by bucket in LDS (LDS atomics, block scan),
@@ -13,11 +15,12 @@
 //                   a tree reduction over 512 lanes staged through LDS.
 //   k_msm_final   : sums the groups of every window, then Horner over the 24 windows.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace vrf {
 
 constexpr int MSM_C = 11;                         // window bits
-constexpr int MSM_W = 24;                         // windows: 11*24 = 264 >= 254
+constexpr int MSM_W = 23;                         // windows: 11*23 = 253 bits; scalars are folded to < r/2
 constexpr int MSM_BUCKETS = 1 << (MSM_C - 1);     // 1024 signed buckets
 constexpr int MSM_BLOCK = 512;                    // lanes per workgroup; each owns 2 buckets
 constexpr int MSM_SLICE = 16384;                  // points sorted per pass
@@ -44,6 +47,24 @@ __global__ void __launch_bounds__(BLOCK) k_msm_prep(size_t n, const uint8_t* xy,
   ok = ok && fe_eq(lhs, fe_mul(a.dt, xy_));
   pta_store(pts + i * PTA_WORDS, a);
   if (!ok) flags[0] = 1;
+  // fold: k > r - k  ->  use r - k and flip the sign of every digit
+  uint32_t nk[8];
+  {
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint64_t d = (uint64_t)SuiteBS::r32(j) - k[j] - borrow;
+      nk[j] = (uint32_t)d;
+      borrow = (uint32_t)(d >> 63);
+    }
+  }
+  bool flip = false, decided = false;
+#pragma unroll
+  for (int j = 7; j >= 0; --j)
+    if (!decided && nk[j] != k[j]) { flip = nk[j] < k[j]; decided = true; }
+  flip = flip && ok;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) k[j] = flip ? nk[j] : k[j];
   // signed radix-2^11 digits in [-1023, 1024]
   uint32_t carry = 0;
 #pragma unroll 1
@@ -61,7 +82,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_prep(size_t n, const uint8_t* xy,
     int d = (int)v;
     carry = 0;
     if (v > (uint32_t)MSM_BUCKETS) { d = (int)v - (1 << MSM_C); carry = 1; }
-    digits[(size_t)w * n + i] = (int16_t)d;
+    digits[(size_t)w * n + i] = (int16_t)(flip ? -d : d);
   }
 }
 
@@ -77,7 +98,7 @@ VRF_HD PtE lds_load_pt(const uint32_t* src) {
 }
 
 __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(size_t n, const uint32_t* pts, const int16_t* digits,
-                                                            uint32_t* lists, uint32_t* out, int groups) {
+                                                            uint32_t* lists, uint32_t* out, int groups, int dbg) {
   extern __shared__ uint32_t lds[];
   uint32_t* bucket = lds;                                   // [1024][36] bucket accumulators (147,456 B)
   uint32_t* counts = lds + MSM_BUCKETS * MSM_PT_WORDS;      // [1024] bucket sizes, then exclusive offsets
@@ -136,7 +157,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(size_t n, const uint3
       const uint32_t q0 = b ? excl + c0 : excl, q1 = b ? excl + c0 + c1 : excl + c0;
       uint32_t* slot = bucket + (2 * t + b) * MSM_PT_WORDS;
       PtE acc = lds_load_pt(slot);
-      for (uint32_t q = q0; q < q1; ++q) {
+      for (uint32_t q = q0; q < q1 && !(dbg & 1); ++q) {
         uint32_t ent = list[q];
         PtA pa = pta_load(pts + (base + (ent & 0x7fffffffu)) * PTA_WORDS);
         acc = te_add_affine<SuiteBS>(acc, pa, (ent >> 31) != 0);
@@ -158,7 +179,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(size_t n, const uint3
   uint32_t* stage = lds;                          // [512][36]
   // pass 0: suffix scan of S (Hillis-Steele);  pass 1: tree reduction of V = L + 2*Suf
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < 2 && !(dbg & 2); ++pass) {
     PtE cur = pass == 0 ? S : V;
 #pragma unroll 1
     for (int k = 0; k < 9; ++k) {
@@ -181,21 +202,27 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(size_t n, const uint3
 // ------------------------------------------------------------------------------- final
 __global__ void __launch_bounds__(64) k_msm_final(const uint32_t* part, int groups, uint8_t* out_enc,
                                                    uint8_t* out_xy, const uint8_t* flags, uint8_t* status) {
-  __shared__ uint32_t win[MSM_W * MSM_PT_WORDS];
-  int t = threadIdx.x;
+  __shared__ uint32_t stage[32 * MSM_PT_WORDS];
+  const int t = threadIdx.x;
+  // lane w < 23: R_w = sum over groups, then 2^(11 w) * R_w by 11 w doublings (lanes run in lockstep,
+  // the critical path is the top window's 242 doublings instead of a serial 253-doubling Horner)
+  PtE acc = te_identity();
   if (t < MSM_W) {
-    PtE acc = lds_load_pt(part + (size_t)t * groups * MSM_PT_WORDS);
+    acc = lds_load_pt(part + (size_t)t * groups * MSM_PT_WORDS);
     for (int g = 1; g < groups; ++g)
       acc = te_add<SuiteBS>(acc, lds_load_pt(part + ((size_t)t * groups + g) * MSM_PT_WORDS));
-    lds_store_pt(win + t * MSM_PT_WORDS, acc);
+    const int nd = MSM_C * t;
+    for (int j = 0; j < nd; ++j) acc = te_dbl<SuiteBS>(acc, j == nd - 1);
   }
-  __syncthreads();
+  // tree-sum of 32 lanes through LDS
+#pragma unroll 1
+  for (int s = 16; s >= 1; s >>= 1) {
+    __syncthreads();
+    if (t < 32) lds_store_pt(stage + t * MSM_PT_WORDS, acc);
+    __syncthreads();
+    if (t < s) acc = te_add<SuiteBS>(acc, lds_load_pt(stage + (t + s) * MSM_PT_WORDS));
+  }
   if (t == 0) {
-    PtE acc = lds_load_pt(win + (MSM_W - 1) * MSM_PT_WORDS);
-    for (int w = MSM_W - 2; w >= 0; --w) {
-      for (int j = 0; j < MSM_C; ++j) acc = te_dbl<SuiteBS>(acc, j == MSM_C - 1);
-      acc = te_add<SuiteBS>(acc, lds_load_pt(win + w * MSM_PT_WORDS));
-    }
     FeN x, y;
     te_to_affine(x, y, acc);
     uint32_t e[8], xw[8], yw[8];
@@ -251,7 +278,7 @@ void launch_msm(size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t* ou
     g_msm_attr_set = true;
   }
   hipLaunchKernelGGL(k_msm_buckets, dim3(MSM_W, groups), dim3(MSM_BLOCK), lds_bytes, st, n, pts, digits, lists,
-                     part, groups);
+                     part, groups, getenv("VRFHIP_MSM_DBG") ? atoi(getenv("VRFHIP_MSM_DBG")) : 0);
   hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, st, part, groups, out_enc, out_xy, flags, status);
 }
 
