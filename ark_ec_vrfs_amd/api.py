@@ -255,6 +255,25 @@ class Context:
                                             out_point.data_ptr(), None if out_xy is None else out_xy.data_ptr(),
                                             status.data_ptr(), st), "vrfhip_msm_dev")
 
+    def pairing_check_batch(self, g1, g2, g2_shared: bool = False) -> np.ndarray:
+        """BLS12-381: e(P0,Q0) e(P1,Q1) == 1 per item.  g1: (n, 192) bytes; g2: (n, 384) or (384,) if shared."""
+        a = np.ascontiguousarray(g1, dtype=np.uint8).reshape(-1, 192)
+        b = np.ascontiguousarray(g2, dtype=np.uint8).reshape(-1, 384)
+        n = a.shape[0]
+        if (g2_shared and b.shape[0] != 1) or (not g2_shared and b.shape[0] != n):
+            raise ValueError("ragged batch")
+        st = np.empty(n, dtype=np.uint8)
+        _lib.check(self._lib.vrfhip_pairing_check_batch(self._h, n, _ptr(a), _ptr(b), int(g2_shared), _ptr(st)),
+                   "vrfhip_pairing_check_batch")
+        return st
+
+    def pairing_check_batch_dev(self, g1, g2, status, g2_shared: bool = False, stream=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _lib.check(self._lib.vrfhip_pairing_check_batch_dev(self._h, g1.shape[0], g1.data_ptr(), g2.data_ptr(),
+                                                            int(g2_shared), status.data_ptr(), st),
+                   "vrfhip_pairing_check_batch_dev")
+
     def hash_to_curve_batch(self, msgs) -> np.ndarray:
         if isinstance(msgs, np.ndarray):
             m = np.ascontiguousarray(msgs, dtype=np.uint8)

@@ -645,6 +645,43 @@ int32_t vrfhip_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases_xy, const uin
   return VRFHIP_SUCCESS;
 }
 
+// ------------------------------------------------------------------------- pairing check
+int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_g1,
+                                       const uint8_t* d_g2, int32_t g2_shared, uint8_t* d_status,
+                                       void* stream) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!d_g1 || !d_g2 || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  launch_pairing_check2(n, d_g1, d_g2, g2_shared ? 0 : 384, d_status, static_cast<hipStream_t>(stream));
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_pairing_check_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2,
+                                   int32_t g2_shared, uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!g1 || !g2 || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  size_t g2b = g2_shared ? 384 : n * 384;
+  int32_t rc = ensure_stage(ctx, Stage::pad(n * 192) + Stage::pad(g2b) + Stage::pad(n));
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t* d_g1 = sg.take(n * 192);
+  uint8_t* d_g2 = sg.take(g2b);
+  uint8_t* d_st = sg.take(n);
+  HIP_TRY(hipMemcpyAsync(d_g1, g1, n * 192, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_g2, g2, g2b, hipMemcpyHostToDevice, ctx->stream));
+  rc = vrfhip_pairing_check_batch_dev(ctx, n, d_g1, d_g2, g2_shared, d_st, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
 // ------------------------------------------------------------------------- building blocks
 int32_t vrfhip_hash_to_curve_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_msg,
                                        const uint32_t* d_msg_off, uint32_t msg_len,

@@ -169,6 +169,23 @@ int32_t vrfhip_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases_xy, const uin
 int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, const uint8_t* d_scalars,
                        uint8_t* d_out_point, uint8_t* d_out_xy, uint8_t* d_status, void* stream);
 
+/* Pairing check (ring-VRF tail) ------------------------------------------------------- */
+
+/* `Pairing::multi_miller_loop` over two (G1, G2) pairs + `final_exponentiation` == 1 on
+ * BLS12-381, per item: the KZG equation that ends `ring::Verifier::verify` (src/lib.rs:14).
+ * g1: n x 2 x 96 B, each point x || y as 48-byte little-endian canonical integers;
+ * g2: n x 2 x 192 B, each point x.c0 || x.c1 || y.c0 || y.c1 (48-byte LE each); if g2_shared
+ * is non-zero, g2 holds a single pair of points (384 B) used by every item (the SRS case).
+ * An all-zero encoding is the point at infinity.  status[i]: 0 = product is one,
+ * 1 = VerificationFailure, 2 = InvalidData (coordinate >= p or point off its curve).
+ * Subgroup membership of the inputs is the caller's precondition, as for arkworks' prepared
+ * points. */
+int32_t vrfhip_pairing_check_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2,
+                                   int32_t g2_shared, uint8_t* status);
+int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_g1,
+                                       const uint8_t* d_g2, int32_t g2_shared, uint8_t* d_status,
+                                       void* stream);
+
 /* Building blocks --------------------------------------------------------------------- */
 
 /* `Input::new(data)` = Suite::data_to_point = hash_to_curve_ell2_rfc_9380 (src/lib.rs:14-16):

@@ -1,0 +1,56 @@
+// tests/hostsim -- TEST TOOLING ONLY: host build of the BLS12-381 pairing headers.
+#include "../../ark_ec_vrfs_amd/csrc/bls12.cuh"
+#include <cstring>
+using namespace bls;
+static FpS inw(const uint8_t* b) { uint32_t w[12]; memcpy(w, b, 48); FpS r; fp_from_words(r, w); return r; }
+template <class A> static void outw(uint8_t* b, const A& a) { uint32_t w[12]; fp_to_words(w, a); memcpy(b, w, 48); }
+static Fp2 in2(const uint8_t* b) { Fp2 r; r.a = inw(b); r.b = inw(b + 48); return r; }
+static void out2(uint8_t* b, const Fp2& x) { outw(b, x.a); outw(b + 48, x.b); }
+static void in12(Fp12* f, const uint8_t* b) {
+  Fp2* c[6] = {&f->c0.c0, &f->c0.c1, &f->c0.c2, &f->c1.c0, &f->c1.c1, &f->c1.c2};
+  for (int i = 0; i < 6; ++i) *c[i] = in2(b + 96 * i);
+}
+static void out12(uint8_t* b, const Fp12* f) {
+  const Fp2* c[6] = {&f->c0.c0, &f->c0.c1, &f->c0.c2, &f->c1.c0, &f->c1.c1, &f->c1.c2};
+  for (int i = 0; i < 6; ++i) out2(b + 96 * i, *c[i]);
+}
+extern "C" {
+void hb_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* r) { outw(r, fp_mul(inw(a), inw(b))); }
+void hb_fp_sqr(const uint8_t* a, uint8_t* r) { outw(r, fp_sqr(inw(a))); }
+void hb_fp_lazy(const uint8_t* a_, const uint8_t* b_, uint8_t* r) {     // ((a-b)*(a+b) - 3ab) reduced, times (b - a - a)
+  FpS a = inw(a_), b = inw(b_);
+  auto d = fp_sub(a, b), s = fp_add(a, b);
+  auto p = fp_mul(d, s);
+  auto ab = fp_mul(a, b);
+  auto t = fp_sub(p, fp_add(fp_dbl(ab), ab));
+  auto u = fp_reduce(t);
+  auto w = fp_sub(fp_sub(b, a), a);
+  outw(r, fp_mul(u, fp_norm(w)));
+}
+void hb_fp_inv(const uint8_t* a, uint8_t* r) { FpS x = inw(a), y; fp_inv(&y, &x); outw(r, y); }
+int hb_fp_eq(const uint8_t* a, const uint8_t* b) { return fp_eq(inw(a), fp_add(inw(b), fp_zero())); }
+void hb_fp12_mul(const uint8_t* a, const uint8_t* b, uint8_t* r) { Fp12 x, y, z; in12(&x, a); in12(&y, b); fp12_mul(&z, &x, &y); out12(r, &z); }
+void hb_fp12_sqr(const uint8_t* a, uint8_t* r) { Fp12 x, z; in12(&x, a); fp12_sqr(&z, &x); out12(r, &z); }
+void hb_fp12_inv(const uint8_t* a, uint8_t* r) { Fp12 x, z; in12(&x, a); fp12_inv(&z, &x); out12(r, &z); }
+void hb_fp12_frob(const uint8_t* a, uint8_t* r) { Fp12 x, z; in12(&x, a); fp12_frob(&z, &x); out12(r, &z); }
+void hb_fp12_mul014(const uint8_t* a, const uint8_t* c, uint8_t* r) {
+  Fp12 x; in12(&x, a); Fp2 c0 = in2(c), c1 = in2(c + 96), c4 = in2(c + 192); fp12_mul_by_014(&x, &c0, &c1, &c4); out12(r, &x);
+}
+// g1: 96 B, g2: 192 B -> Miller loop value (576 B) and final exponentiation (576 B)
+int hb_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* ml, uint8_t* fe) {
+  uint32_t w1[24], w2[48]; memcpy(w1, g1, 96); memcpy(w2, g2, 192);
+  G1Aff P; G2Aff Q; bool i1, i2;
+  bool ok = g1_load(P, i1, w1) & g2_load(Q, i2, w2);
+  bool skip = i1 || i2;
+  Fp12 f, e;
+  miller_loop<1>(&f, &P, &Q, &skip);
+  out12(ml, &f);
+  final_exponentiation(&e, &f);
+  out12(fe, &e);
+  return ok;
+}
+uint32_t hb_pairing_check2(const uint8_t* g1x2, const uint8_t* g2x2) {
+  uint32_t w1[48], w2[96]; memcpy(w1, g1x2, 192); memcpy(w2, g2x2, 384);
+  return pairing_check2_item(w1, w2);
+}
+}

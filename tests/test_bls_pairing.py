@@ -1,0 +1,175 @@
+"""BLS12-381 pairing check: the Python oracle's own algebraic pins,
+the device source compiled for the host against it, and (gpu) the kernel through the C ABI."""
+import ctypes
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import bls_oracle as b
+
+P = b.P
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+
+
+def w(x):
+    return int(x).to_bytes(48, "little")
+
+
+def enc_g1(p):
+    return bytes(96) if p is None else w(p[0]) + w(p[1])
+
+
+def enc_g2(q):
+    return bytes(192) if q is None else w(q[0].a) + w(q[0].b) + w(q[1].a) + w(q[1].b)
+
+
+def kzg_like_items(n, seed=1):
+    """n valid items (a1 G1, b1 G2), (a2 G1, b2 G2) with a1 b1 + a2 b2 = 0 mod r, then corrupted copies."""
+    rnd = random.Random(seed)
+    items = []
+    for _ in range(n):
+        a1, b1, b2 = (rnd.randrange(1, b.R) for _ in range(3))
+        a2 = (-a1 * b1 * pow(b2, -1, b.R)) % b.R
+        items.append(((b.g1_mul(a1, b.G1), b.g2_mul(b1, b.G2)), (b.g1_mul(a2, b.G1), b.g2_mul(b2, b.G2))))
+    return items
+
+
+def pack(items):
+    g1 = b"".join(enc_g1(p0) + enc_g1(p1) for (p0, _), (p1, _) in items)
+    g2 = b"".join(enc_g2(q0) + enc_g2(q1) for (_, q0), (_, q1) in items)
+    return np.frombuffer(g1, np.uint8).reshape(-1, 192), np.frombuffer(g2, np.uint8).reshape(-1, 384)
+
+
+def test_oracle_algebra():
+    b.selfcheck()
+    e = b.pairing_reference(b.G1, b.G2)
+    assert e != b.F12_1 and b.fp12_pow(e, b.R) == b.F12_1            # non-degenerate, order r
+    a, c = 0x1234567, 0x89ABCDE
+    assert b.pairing_reference(b.g1_mul(a, b.G1), b.g2_mul(c, b.G2)) == b.fp12_pow(e, a * c)   # bilinear
+    e3 = b.final_exp_chain(b.miller_projective([(b.G1, b.G2)]))
+    assert e3 == e * e * e                                              # projective + x-chain == reference^3
+    items = kzg_like_items(2)
+    for it in items:
+        assert b.pairing_check(list(it))
+        (p0, q0), (p1, q1) = it
+        assert not b.pairing_check([(p0, q0), (b.g1_add(p1, b.G1), q1)])
+
+
+@pytest.fixture(scope="module")
+def hb():
+    so = os.path.join(HERE, "libhostsim_bls.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", HERE, "libhostsim_bls.so"], check=True, stdout=subprocess.DEVNULL)
+    return ctypes.CDLL(so)
+
+
+def _call(f, *a, n=48):
+    r = ctypes.create_string_buffer(n)
+    f(*a, r)
+    return r.raw
+
+
+def _enc12(f):
+    return b"".join(w(c) for c in f.coeffs())
+
+
+def _dec12(raw):
+    c = [int.from_bytes(raw[48 * i:48 * i + 48], "little") for i in range(12)]
+    f2 = [b.Fp2(c[2 * i], c[2 * i + 1]) for i in range(6)]
+    return b.Fp12(b.Fp6(*f2[:3]), b.Fp6(*f2[3:]))
+
+
+def test_hostsim_field_and_tower(hb):
+    rnd = random.Random(1)
+    edge = [0, 1, 2, P - 1, P - 2, (P - 1) // 2]
+    for it in range(1500):
+        x = rnd.choice(edge) if it % 7 == 0 else rnd.randrange(P)
+        y = rnd.choice(edge) if it % 11 == 0 else rnd.randrange(P)
+        assert int.from_bytes(_call(hb.hb_fp_mul, w(x), w(y)), "little") == x * y % P
+        assert int.from_bytes(_call(hb.hb_fp_sqr, w(x)), "little") == x * x % P
+        t, ww = ((x - y) * (x + y) - 3 * x * y) % P, (y - 2 * x) % P
+        assert int.from_bytes(_call(hb.hb_fp_lazy, w(x), w(y)), "little") == t * ww % P      # signed lazy limbs
+    for _ in range(30):
+        x = rnd.randrange(1, P)
+        assert int.from_bytes(_call(hb.hb_fp_inv, w(x)), "little") == pow(x, P - 2, P)
+    rf2 = lambda: b.Fp2(rnd.randrange(P), rnd.randrange(P))
+    rf12 = lambda: b.Fp12(b.Fp6(rf2(), rf2(), rf2()), b.Fp6(rf2(), rf2(), rf2()))
+    for _ in range(10):
+        x, y = rf12(), rf12()
+        assert _dec12(_call(hb.hb_fp12_mul, _enc12(x), _enc12(y), n=576)) == x * y
+        assert _dec12(_call(hb.hb_fp12_sqr, _enc12(x), n=576)) == x.sq()
+        assert _dec12(_call(hb.hb_fp12_frob, _enc12(x), n=576)) == b.fp12_frob(x)
+        c0, c1, c4 = rf2(), rf2(), rf2()
+        cc = b"".join(w(v) for v in (c0.a, c0.b, c1.a, c1.b, c4.a, c4.b))
+        assert _dec12(_call(hb.hb_fp12_mul014, _enc12(x), cc, n=576)) == x * b.fp12_from_014(c0, c1, c4)
+    x = rf12()
+    assert _dec12(_call(hb.hb_fp12_inv, _enc12(x), n=576)) == x.inv()
+
+
+def test_hostsim_pairing_values_and_checks(hb):
+    ml, fe = ctypes.create_string_buffer(576), ctypes.create_string_buffer(576)
+    a = 0x1234567
+    P1, Q2 = b.g1_mul(a, b.G1), b.g2_mul(a + 5, b.G2)
+    assert hb.hb_pairing(enc_g1(P1), enc_g2(Q2), ml, fe) == 1
+    f = b.miller_projective([(P1, Q2)])
+    assert _dec12(ml.raw) == f and _dec12(fe.raw) == b.final_exp_chain(f)
+    items = kzg_like_items(2, seed=5)
+    for (p0, q0), (p1, q1) in items:
+        assert hb.hb_pairing_check2(enc_g1(p0) + enc_g1(p1), enc_g2(q0) + enc_g2(q1)) == 0
+        assert hb.hb_pairing_check2(enc_g1(p0) + enc_g1(b.g1_add(p1, b.G1)), enc_g2(q0) + enc_g2(q1)) == 1
+        bad = bytearray(enc_g1(p0)); bad[3] ^= 1
+        assert hb.hb_pairing_check2(bytes(bad) + enc_g1(p1), enc_g2(q0) + enc_g2(q1)) == 2
+        assert hb.hb_pairing_check2(enc_g1(p0) + enc_g1(p1), enc_g2(q0) + w(P) + bytes(144)) == 2   # coordinate >= p
+    assert hb.hb_pairing_check2(bytes(192), enc_g2(b.G2) + enc_g2(b.G2)) == 0          # infinity pairs with anything
+
+
+@pytest.mark.gpu
+def test_gpu_pairing_check_matches_oracle(ctx):
+    items = kzg_like_items(6, seed=9)
+    g1, g2 = pack(items)
+    g1 = g1.copy(); g2 = g2.copy()
+    want = [0] * 6
+    # corrupt some items in oracle-checkable ways
+    (p0, q0), (p1, q1) = items[1]
+    g1[1] = np.frombuffer(enc_g1(p0) + enc_g1(b.g1_add(p1, b.G1)), np.uint8); want[1] = 1
+    g1[3, 5] ^= 1; want[3] = 2                                         # off the curve
+    g2[4, :48] = np.frombuffer(w(P), np.uint8); want[4] = 2            # coordinate >= p
+    g1[5] = 0                                                           # both G1 points at infinity: product is one
+    st = ctx.pairing_check_batch(g1, g2)
+    assert list(st) == want
+    for i in (0, 2):
+        assert b.pairing_check(list(items[i]))
+    # shared G2 pair (the SRS case): e(a G1, Q0) e(-(a c) G1, Q1) with Q1 = c^-1 ... built from one scalar relation
+    c = 0xABCDEF12345
+    Q0, Q1 = b.G2, b.g2_mul(c, b.G2)
+    rows = []
+    for a in (3, 5, 7, 11):
+        rows.append(enc_g1(b.g1_mul(a * c % b.R, b.G1)) + enc_g1(b.g1_neg(b.g1_mul(a, b.G1))))
+    rows.append(enc_g1(b.g1_mul(13, b.G1)) + enc_g1(b.g1_neg(b.g1_mul(13, b.G1))))       # wrong relation
+    sh = np.frombuffer(enc_g2(Q0) + enc_g2(Q1), np.uint8)
+    st = ctx.pairing_check_batch(np.frombuffer(b"".join(rows), np.uint8).reshape(-1, 192), sh, g2_shared=True)
+    assert list(st) == [0, 0, 0, 0, 1]
+
+
+@pytest.mark.gpu
+def test_gpu_pairing_batch_2_14_tiled(ctx):
+    """BASELINE.json config 5 size: 2^14 checks (64 distinct oracle-made items tiled), every 97th corrupted."""
+    import torch
+    items = kzg_like_items(8, seed=21)
+    g1, g2 = pack(items)
+    n = 1 << 14
+    reps = n // 8
+    G1 = np.tile(g1, (reps, 1)).copy(); G2 = np.tile(g2, (reps, 1)).copy()
+    bad = np.arange(0, n, 97)
+    G1[bad, 96:] = G1[(bad + 1) % n, 96:]                               # swap in a different item's second G1 point
+    dev = torch.device("cuda:0")
+    d1, d2 = torch.from_numpy(G1).to(dev), torch.from_numpy(G2).to(dev)
+    st = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+    ctx.pairing_check_batch_dev(d1, d2, st)
+    torch.cuda.synchronize()
+    got = st.cpu().numpy()
+    want = np.zeros(n, np.uint8); want[bad] = 1
+    assert (got == want).all()
