@@ -18,6 +18,7 @@ SYMBOLS = [
     "vrfhip_abi_version", "vrfhip_last_error", "vrfhip_ctx_create", "vrfhip_ctx_destroy",
     "vrfhip_ctx_reserve", "vrfhip_ctx_workspace_bytes", "vrfhip_ctx_profile", "vrfhip_ctx_profile_read",
     "vrfhip_ietf_verify_batch", "vrfhip_ietf_verify_batch_dev",
+    "vrfhip_ietf_verify_batch_affine", "vrfhip_ietf_verify_batch_affine_dev",
     "vrfhip_ietf_prove_batch", "vrfhip_ietf_prove_batch_dev",
     "vrfhip_pedersen_prove_batch", "vrfhip_pedersen_prove_batch_dev",
     "vrfhip_pedersen_verify_batch", "vrfhip_pedersen_verify_batch_dev",
@@ -70,6 +71,8 @@ def load() -> ctypes.CDLL:
     P = c_void_p  # raw addresses (host buffers or device pointers)
     lib.vrfhip_ietf_verify_batch.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P]
     lib.vrfhip_ietf_verify_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P, c_void_p]
+    lib.vrfhip_ietf_verify_batch_affine.argtypes = lib.vrfhip_ietf_verify_batch.argtypes
+    lib.vrfhip_ietf_verify_batch_affine_dev.argtypes = lib.vrfhip_ietf_verify_batch_dev.argtypes
     lib.vrfhip_ietf_prove_batch.argtypes = [c_void_p, c_size_t, P, P, P, c_uint32, P, P, P, c_uint32,
                                             P, P, P, P, P, P]
     lib.vrfhip_ietf_prove_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, c_uint32, P, P, P, c_uint32,

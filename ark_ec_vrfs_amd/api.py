@@ -140,6 +140,29 @@ class Context:
             _ptr(status)), "vrfhip_ietf_verify_batch")
         return status
 
+    def ietf_verify_batch_affine(self, pk_xy, inp_xy, out_xy, c, s, ad=b"") -> np.ndarray:
+        """Verification from in-memory affine points: (n, 64) arrays x || y (LE canonical)."""
+        pk, inp, out = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 64) for x in (pk_xy, inp_xy, out_xy))
+        c, s = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (c, s))
+        n = pk.shape[0]
+        if not all(x.shape[0] == n for x in (inp, out, c, s)):
+            raise ValueError("ragged batch")
+        status = np.empty(n, dtype=np.uint8)
+        blob, off, ad_len = self._ad_args(ad, n)
+        _lib.check(self._lib.vrfhip_ietf_verify_batch_affine(
+            self._h, n, _ptr(pk), _ptr(inp), _ptr(out), _ptr(c), _ptr(s), _ptr(blob), _ptr(off), ad_len,
+            _ptr(status)), "vrfhip_ietf_verify_batch_affine")
+        return status
+
+    def ietf_verify_batch_affine_dev(self, pk_xy, inp_xy, out_xy, c, s, status, ad=None, ad_off=None, ad_len=0,
+                                     stream=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _lib.check(self._lib.vrfhip_ietf_verify_batch_affine_dev(
+            self._h, pk_xy.shape[0], pk_xy.data_ptr(), inp_xy.data_ptr(), out_xy.data_ptr(), c.data_ptr(),
+            s.data_ptr(), None if ad is None else ad.data_ptr(), None if ad_off is None else ad_off.data_ptr(),
+            ad_len, status.data_ptr(), st), "vrfhip_ietf_verify_batch_affine_dev")
+
     def ietf_prove_batch(self, sk, msgs=None, inputs=None, ad=b""):
         """Returns dict(output, c, s, pk, input, status).  Either `msgs` (sequence of byte strings
         or an (n, L) uint8 array) or `inputs` (n x 32 pre-hashed points) must be given."""

@@ -285,11 +285,12 @@ int32_t vrfhip_ctx_profile_read(vrfhip_ctx* ctx, double stage_ms[3], uint64_t* l
 }
 
 // ------------------------------------------------------------------------- IETF verify
-int32_t vrfhip_ietf_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_pk,
-                                     const uint8_t* d_input, const uint8_t* d_output,
-                                     const uint8_t* d_c, const uint8_t* d_s, const uint8_t* d_ad,
-                                     const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_status,
-                                     void* stream) {
+}  // extern "C"
+
+namespace {
+int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_pk, const uint8_t* d_input,
+                        const uint8_t* d_output, const uint8_t* d_c, const uint8_t* d_s, const uint8_t* d_ad,
+                        const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_status, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!d_pk || !d_input || !d_output || !d_c || !d_s || !d_status)
@@ -300,11 +301,13 @@ int32_t vrfhip_ietf_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d
   int32_t rc = ensure_workspace(ctx, n);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t pw = affine ? 64 : 32;
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     size_t m = std::min(ctx->ws_cap, n - base);
     VerifyArgs a;
     a.n = m;
-    a.pk = d_pk + base * 32; a.h = d_input + base * 32; a.gamma = d_output + base * 32;
+    a.pk = d_pk + base * pw; a.h = d_input + base * pw; a.gamma = d_output + base * pw;
+    a.affine_in = affine ? 1 : 0;
     a.c = d_c + base * 32; a.s = d_s + base * 32;
     a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
     a.status = d_status + base;
@@ -316,43 +319,75 @@ int32_t vrfhip_ietf_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d
   return VRFHIP_SUCCESS;
 }
 
-int32_t vrfhip_ietf_verify_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* input,
-                                 const uint8_t* output, const uint8_t* c, const uint8_t* s,
-                                 const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
-                                 uint8_t* status) {
+int32_t verify_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* pk, const uint8_t* input,
+                         const uint8_t* output, const uint8_t* c, const uint8_t* s, const uint8_t* ad,
+                         const uint32_t* ad_off, uint32_t ad_len, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!pk || !input || !output || !c || !s || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
   size_t adb = blob_bytes(n, ad_off, ad_len, true);
-  uint8_t *d_pk, *d_h, *d_g, *d_c, *d_s, *d_ad, *d_st;
-  uint32_t* d_off = nullptr;
+  const size_t pw = affine ? 64 : 32;
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  {
-    size_t need = 5 * Stage::pad(n * 32) + Stage::pad(adb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n);
-    int32_t rc = ensure_stage(ctx, need);
-    if (rc) return rc;
-    Stage sg(ctx->d_stage);
-    d_pk = sg.take(n * 32); d_h = sg.take(n * 32); d_g = sg.take(n * 32);
-    d_c = sg.take(n * 32); d_s = sg.take(n * 32);
-    d_ad = sg.take(adb + 1);
-    d_off = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
-    d_st = sg.take(n);
-    HIP_TRY(hipMemcpyAsync(d_pk, pk, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_h, input, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_g, output, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_c, c, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_s, s, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    if (adb) HIP_TRY(hipMemcpyAsync(d_ad, ad, adb, hipMemcpyHostToDevice, ctx->stream));
-    if (ad_off) HIP_TRY(hipMemcpyAsync(d_off, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  }
-  int32_t rc = vrfhip_ietf_verify_batch_dev(ctx, n, d_pk, d_h, d_g, d_c, d_s, d_ad,
-                                            ad_off ? d_off : nullptr, ad_len, d_st, ctx->stream);
+  size_t need = 3 * Stage::pad(n * pw) + 2 * Stage::pad(n * 32) + Stage::pad(adb + 1) +
+                Stage::pad((n + 1) * 4) + Stage::pad(n);
+  int32_t rc = ensure_stage(ctx, need);
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t* d_pk = sg.take(n * pw);
+  uint8_t* d_h = sg.take(n * pw);
+  uint8_t* d_g = sg.take(n * pw);
+  uint8_t* d_c = sg.take(n * 32);
+  uint8_t* d_s = sg.take(n * 32);
+  uint8_t* d_ad = sg.take(adb + 1);
+  uint32_t* d_off = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+  uint8_t* d_st = sg.take(n);
+  HIP_TRY(hipMemcpyAsync(d_pk, pk, n * pw, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_h, input, n * pw, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_g, output, n * pw, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_c, c, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_s, s, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (adb) HIP_TRY(hipMemcpyAsync(d_ad, ad, adb, hipMemcpyHostToDevice, ctx->stream));
+  if (ad_off) HIP_TRY(hipMemcpyAsync(d_off, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = verify_dev_impl(ctx, n, affine, d_pk, d_h, d_g, d_c, d_s, d_ad, ad_off ? d_off : nullptr, ad_len, d_st,
+                       ctx->stream);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return VRFHIP_SUCCESS;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t vrfhip_ietf_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_pk,
+                                     const uint8_t* d_input, const uint8_t* d_output,
+                                     const uint8_t* d_c, const uint8_t* d_s, const uint8_t* d_ad,
+                                     const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_status,
+                                     void* stream) {
+  return verify_dev_impl(ctx, n, false, d_pk, d_input, d_output, d_c, d_s, d_ad, d_ad_off, ad_len, d_status,
+                         stream);
+}
+int32_t vrfhip_ietf_verify_batch_affine_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_pk_xy,
+                                            const uint8_t* d_input_xy, const uint8_t* d_output_xy,
+                                            const uint8_t* d_c, const uint8_t* d_s, const uint8_t* d_ad,
+                                            const uint32_t* d_ad_off, uint32_t ad_len,
+                                            uint8_t* d_status, void* stream) {
+  return verify_dev_impl(ctx, n, true, d_pk_xy, d_input_xy, d_output_xy, d_c, d_s, d_ad, d_ad_off, ad_len,
+                         d_status, stream);
+}
+int32_t vrfhip_ietf_verify_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* input,
+                                 const uint8_t* output, const uint8_t* c, const uint8_t* s,
+                                 const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                 uint8_t* status) {
+  return verify_host_impl(ctx, n, false, pk, input, output, c, s, ad, ad_off, ad_len, status);
+}
+int32_t vrfhip_ietf_verify_batch_affine(vrfhip_ctx* ctx, size_t n, const uint8_t* pk_xy,
+                                        const uint8_t* input_xy, const uint8_t* output_xy,
+                                        const uint8_t* c, const uint8_t* s, const uint8_t* ad,
+                                        const uint32_t* ad_off, uint32_t ad_len, uint8_t* status) {
+  return verify_host_impl(ctx, n, true, pk_xy, input_xy, output_xy, c, s, ad, ad_off, ad_len, status);
 }
 
 // ------------------------------------------------------------------------- IETF prove

@@ -40,7 +40,8 @@ constexpr size_t WS_BYTES_PER_ITEM =
 
 struct VerifyArgs {
   size_t n;
-  const uint8_t *pk, *h, *gamma, *c, *s;
+  const uint8_t *pk, *h, *gamma, *c, *s;   // affine_in != 0: pk, h, gamma are 64-byte x || y
+  int affine_in;
   BytesView ad;
   uint8_t* status;
   Workspace ws;

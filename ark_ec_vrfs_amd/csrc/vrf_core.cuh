@@ -195,7 +195,7 @@ struct Straus4 {
   uint32_t rec[4][4];
   bool neg[4];
 };
-template <class C>
+template <class C, int NT = 4>
 VRF_HD PtE straus4(const Straus4& q) {
   PtE acc = te_identity();
 #pragma unroll 1
@@ -205,7 +205,7 @@ VRF_HD PtE straus4(const Straus4& q) {
       for (int j = 0; j < 4; ++j) acc = te_dbl<C>(acc, j == 3);
     }
 #pragma unroll 1
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT; ++t) {
       uint32_t rec[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -387,25 +387,76 @@ VRF_HD bool verify_decode_item(const DevTables& T, const uint32_t pk[8], const u
   return valid;
 }
 
-// half 0: U = s*G - c*Y (tables: g_win pair, tabs[0..1]) ; half 1: V = s*H - c*Gamma (tabs[2..5]).
-// GLV: s = s1 + s2*lambda, c = c1 + c2*lambda; four 128-bit scalars over {P, psi P, Q, psi Q}.
+// Same stage for callers that hold affine points in memory (arkworks `Affine { x, y }`): x || y as
+// 32-byte little-endian canonical integers, no square roots.  Validity = coordinates < q and the
+// point is on the curve.
 template <class S>
-VRF_HD void verify_straus_item(uint32_t* out_uv, const DevTables& T, const uint32_t* tabs,
-                               const uint32_t c[8], const uint32_t s[8], int half) {
-  GlvHalf h[4];
-  glv_decompose_bs(h[0], h[1], s);
-  glv_decompose_bs(h[2], h[3], c);
-  Straus4 q;
+VRF_HD bool verify_decode_affine_item(uint32_t enc_out[3][8], const uint32_t (&xy)[3][16], uint32_t* tabs) {
+  bool valid = true;
+#pragma unroll 1
+  for (int p = 0; p < 3; ++p) {
+    uint32_t xw[8], yw[8];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    scalar_recode_signed4_128(q.rec[t], h[t].mag);
-    q.neg[t] = h[t].neg != (t >= 2);            // the c terms are subtracted
+    for (int j = 0; j < 8; ++j) {
+      xw[j] = p == 0 ? xy[0][j] : p == 1 ? xy[1][j] : xy[2][j];
+      yw[j] = p == 0 ? xy[0][8 + j] : p == 1 ? xy[1][8 + j] : xy[2][8 + j];
+    }
+    valid = valid && !u256_ge(xw, vrfk::Q32) && !u256_ge(yw, vrfk::Q32);
+    FeN x = fe_from_u256(xw), y = fe_from_u256(yw);
+    // a x^2 + y^2 = 1 + d x^2 y^2   <=>   y^2 - ANEG x^2 - 1 = d (x y)^2
+    FeN x2 = fe_sqr(x), y2 = fe_sqr(y), xyv = fe_mul(x, y);
+    auto lhs = fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(S::mul_aneg(x2), fe_one())))));
+    valid = fe_eq(lhs, fe_mul(fe_mul(fe_sqr(xyv), S::d()), fe_one())) && valid;
+    build_glv_tables<S>(tabs + p * 2 * WIN_TABLE_WORDS, x, y);
+    uint32_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = yw[j];
+    if (u256_gt(xw, vrfk::QM1H32)) e[7] |= 0x80000000u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (p == 0) enc_out[0][j] = e[j];
+      if (p == 1) enc_out[1][j] = e[j];
+      if (p == 2) enc_out[2][j] = e[j];
+    }
   }
-  const uint32_t* base_s = half ? tabs + 2 * WIN_TABLE_WORDS : T.g_win;
-  const uint32_t* base_c = half ? tabs + 4 * WIN_TABLE_WORDS : tabs;
-  q.tab[0] = base_s; q.tab[1] = base_s + WIN_TABLE_WORDS;
-  q.tab[2] = base_c; q.tab[3] = base_c + WIN_TABLE_WORDS;
-  PtE r = straus4<S>(q);
+  return valid;
+}
+
+// HALF 0: U = s*G - c*Y = comb(G, s) - (c1*Y + c2*psi Y)   (2-table GLV Straus + 8-bit fixed-base comb)
+// HALF 1: V = s*H - c*Gamma                                 (4-table GLV Straus over tabs[2..5])
+// GLV: k = k1 + k2*lambda with 128-bit halves; the c terms are subtracted.  The two halves run as
+// separate launches so that every wave executes one shape.
+template <class S, int HALF>
+VRF_HD void verify_straus_item(uint32_t* out_uv, const DevTables& T, const uint32_t* tabs,
+                               const uint32_t c[8], const uint32_t s[8]) {
+  Straus4 q;
+  GlvHalf h[4];
+  glv_decompose_bs(h[0], h[1], c);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    scalar_recode_signed4_128(q.rec[t], h[t].mag);
+    q.neg[t] = !h[t].neg;
+  }
+  PtE r;
+  if (HALF == 0) {
+    q.tab[0] = tabs; q.tab[1] = tabs + WIN_TABLE_WORDS;
+    q.tab[2] = tabs; q.tab[3] = tabs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { q.rec[2][i] = 0; q.rec[3][i] = 0; }
+    q.neg[2] = false; q.neg[3] = false;
+    r = straus4<S, 2>(q);
+    r = comb_add<S>(r, T.g_comb, s);
+  } else {
+    glv_decompose_bs(h[2], h[3], s);
+#pragma unroll
+    for (int t = 2; t < 4; ++t) {
+      scalar_recode_signed4_128(q.rec[t], h[t].mag);
+      q.neg[t] = h[t].neg;
+    }
+    q.tab[0] = tabs + 4 * WIN_TABLE_WORDS; q.tab[1] = tabs + 5 * WIN_TABLE_WORDS;
+    q.tab[2] = tabs + 2 * WIN_TABLE_WORDS; q.tab[3] = tabs + 3 * WIN_TABLE_WORDS;
+    r = straus4<S, 4>(q);
+  }
   fe_store(out_uv, r.X);
   fe_store(out_uv + NL, r.Y);
   fe_store(out_uv + 2 * NL, r.Z);

@@ -103,6 +103,20 @@ int32_t vrfhip_ietf_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d
                                      const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_status,
                                      void* stream);
 
+/* The same verification for callers that hold the points in memory as arkworks `Affine { x, y }`
+ * (the form `Public`, `Input`, `Output` wrap): pk_xy, input_xy, output_xy are n x 64 B, x || y as
+ * 32-byte little-endian canonical integers.  No square roots are needed; InvalidData = coordinate
+ * >= q or point off the curve. */
+int32_t vrfhip_ietf_verify_batch_affine(vrfhip_ctx* ctx, size_t n, const uint8_t* pk_xy,
+                                        const uint8_t* input_xy, const uint8_t* output_xy,
+                                        const uint8_t* c, const uint8_t* s, const uint8_t* ad,
+                                        const uint32_t* ad_off, uint32_t ad_len, uint8_t* status);
+int32_t vrfhip_ietf_verify_batch_affine_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_pk_xy,
+                                            const uint8_t* d_input_xy, const uint8_t* d_output_xy,
+                                            const uint8_t* d_c, const uint8_t* d_s, const uint8_t* d_ad,
+                                            const uint32_t* d_ad_off, uint32_t ad_len,
+                                            uint8_t* d_status, void* stream);
+
 /* `Input::new(msg)` + `Secret::output` + `ietf::Prover::prove` for n items (src/lib.rs:14-16).
  * sk: n x 32 B secret scalars.  Messages: blob `msg`; if msg_off is NULL item i is
  * msg[i*msg_len .. (i+1)*msg_len), else msg[msg_off[i] .. msg_off[i+1]).

@@ -14,6 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _ensure_native_built():
+    """The .so files are git-ignored: build them in-tree when a fresh checkout runs the tests."""
+    import subprocess
+    lib = os.path.join(ROOT, "ark_ec_vrfs_amd", "csrc", "libvrfhip.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", os.path.dirname(lib), "-j", "6"], check=True, stdout=subprocess.DEVNULL)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def native_built():
+    _ensure_native_built()
+
+
 @pytest.fixture(scope="session")
 def kat():
     with open(os.path.join(ROOT, "tests", "golden", "bandersnatch_sha512_ell2_kat.json")) as f:

@@ -15,12 +15,26 @@ template <int L, int V> static void out(uint8_t* b, const Fe<L, V>& a) { uint32_
 
 namespace {
 struct HostTables {
-  std::vector<uint32_t> g_win;
+  std::vector<uint32_t> g_win, g_comb;
   DevTables t;
   HostTables() {
     g_win.resize(2 * WIN_TABLE_WORDS);
     build_glv_tables<SuiteBS>(g_win.data(), SuiteBS::gx(), SuiteBS::gy());
-    t.sq = host_tables(); t.g_win = g_win.data(); t.g_comb = nullptr; t.b_comb = nullptr;
+    g_comb.resize((size_t)32 * 255 * PTA_WORDS);
+    for (int w = 0; w < 32; ++w) {
+      uint32_t k[8] = {0}; k[w >> 2] = 1u << ((w & 3) * 8);
+      PtE base = te_mul_slow<SuiteBS>(te_from_affine(SuiteBS::gx(), SuiteBS::gy()), k);
+      PtC bc = te_to_cached<SuiteBS>(base);
+      PtE acc = base;
+      for (int j = 1; j <= 255; ++j) {
+        FeN zi = fe_inv(acc.Z);
+        PtA a; a.x = fe_mul(acc.X, zi); a.y = fe_mul(acc.Y, zi);
+        a.dt = fe_mul(fe_mul(a.x, a.y), SuiteBS::d());
+        pta_store(g_comb.data() + ((size_t)w * 255 + (j - 1)) * PTA_WORDS, a);
+        acc = te_add_cached<SuiteBS>(acc, bc, false);
+      }
+    }
+    t.sq = host_tables(); t.g_win = g_win.data(); t.g_comb = g_comb.data(); t.b_comb = nullptr;
   }
 };
 HostTables& HT() { static HostTables h; return h; }
@@ -32,8 +46,8 @@ uint32_t hs_ietf_verify(const uint8_t* pk, const uint8_t* h, const uint8_t* g, c
   memcpy(w[0], pk, 32); memcpy(w[1], h, 32); memcpy(w[2], g, 32); memcpy(w[3], c, 32); memcpy(w[4], s, 32);
   std::vector<uint32_t> tabs(VERIFY_TABS * WIN_TABLE_WORDS), uv(2 * UV_WORDS);
   bool valid = verify_decode_item<SuiteBS>(HT().t, w[0], w[1], w[2], tabs.data());
-  for (int half = 0; half < 2; ++half)
-    verify_straus_item<SuiteBS>(uv.data() + half * UV_WORDS, HT().t, tabs.data(), w[3], w[4], half);
+  verify_straus_item<SuiteBS, 0>(uv.data(), HT().t, tabs.data(), w[3], w[4]);
+  verify_straus_item<SuiteBS, 1>(uv.data() + UV_WORDS, HT().t, tabs.data(), w[3], w[4]);
   return verify_finish_item<SuiteBS>(uv.data(), w[0], w[1], w[2], w[3], w[4], valid, ad, ad_len);
 }
 // GLV pieces: k -> (k1, k2) as 2 x (16 B magnitude, 1 B sign) ; psi(P) encoded
@@ -51,5 +65,15 @@ int hs_psi(const uint8_t* enc, uint8_t* out) {
   FeN qx, qy; te_to_affine(qx, qy, q);
   uint32_t e[8]; te_encode_affine(e, qx, qy); memcpy(out, e, 32);
   return ok;
+}
+uint32_t hs_ietf_verify_affine(const uint8_t* pk_xy, const uint8_t* h_xy, const uint8_t* g_xy, const uint8_t* c,
+                               const uint8_t* s, const uint8_t* ad, uint32_t ad_len) {
+  uint32_t xy[3][16], enc[3][8], cw[8], sw[8];
+  memcpy(xy[0], pk_xy, 64); memcpy(xy[1], h_xy, 64); memcpy(xy[2], g_xy, 64); memcpy(cw, c, 32); memcpy(sw, s, 32);
+  std::vector<uint32_t> tabs(VERIFY_TABS * WIN_TABLE_WORDS), uv(2 * UV_WORDS);
+  bool valid = verify_decode_affine_item<SuiteBS>(enc, xy, tabs.data());
+  verify_straus_item<SuiteBS, 0>(uv.data(), HT().t, tabs.data(), cw, sw);
+  verify_straus_item<SuiteBS, 1>(uv.data() + UV_WORDS, HT().t, tabs.data(), cw, sw);
+  return verify_finish_item<SuiteBS>(uv.data(), enc[0], enc[1], enc[2], cw, sw, valid, ad, ad_len);
 }
 }

@@ -388,3 +388,24 @@ def test_msm_full_size_2_20_linearity(ctx):
         tot += int.from_bytes(an[i].tobytes(), "little") * int.from_bytes(kn[i].tobytes(), "little")
     want = co.public_from_secret((tot % R).to_bytes(32, "little"))
     assert out.cpu().numpy().tobytes() == want
+
+
+def test_affine_input_verify_matches_compressed(ctx, synth):
+    n = 1024
+    sk, msg = synth(n, start=91000)
+    pr = ctx.ietf_prove_batch(sk, msgs=msg, ad=b"aff")
+    xy = {}
+    for k in ("pk", "input", "output"):
+        st, v = ctx.point_validate_batch(pr[k], want_xy=True)
+        assert (st == 0).all()
+        xy[k] = v
+    s_bad = pr["s"].copy(); s_bad[::5, 1] ^= 4
+    want = ctx.ietf_verify_batch(pr["pk"], pr["input"], pr["output"], pr["c"], s_bad, ad=b"aff")
+    got = ctx.ietf_verify_batch_affine(xy["pk"], xy["input"], xy["output"], pr["c"], s_bad, ad=b"aff")
+    assert (got == want).all() and (want[::5] == 1).all() and want.sum() == len(want[::5])
+    ref = co.ietf_verify_batch(pr["pk"], pr["input"], pr["output"], pr["c"], s_bad, b"aff", threads=NCPU)
+    assert (ref == want).all()
+    off = xy["pk"].copy(); off[3, 0] ^= 1                                  # off the curve
+    big = xy["output"].copy(); big[4, :32] = np.frombuffer(int(Q).to_bytes(32, "little"), np.uint8)   # x >= q
+    got = ctx.ietf_verify_batch_affine(off, xy["input"], big, pr["c"], pr["s"], ad=b"aff")
+    assert got[3] == 2 and got[4] == 2 and (np.delete(got, [3, 4]) == 0).all()

@@ -19,7 +19,7 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
 def hs():
     so = os.path.join(HERE, "libhostsim.so")
     if not os.path.exists(so):
-        subprocess.run(["make", "-C", HERE, "-j3"], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-C", HERE, "-j4", "libhostsim.so"], check=True, stdout=subprocess.DEVNULL)
     lib = ctypes.CDLL(so)
     lib.hs_init()
     return lib
@@ -188,3 +188,17 @@ def test_zero_secret_proof_is_accepted(hs):
     assert o.ietf_verify(S, (0, 1), H, g, b"", c, s)
     enc = [o.point_encode(S, (0, 1)), o.point_encode(S, H), o.point_encode(S, g), o.scalar_encode(c), o.scalar_encode(s)]
     assert hs.hs_ietf_verify(*enc, b"", 0) == 0
+
+
+def test_affine_input_verify(hs, kat):
+    def xy(enc):
+        Pt = o.point_decode(S, bytes.fromhex(enc))
+        return Pt[0].to_bytes(32, "little") + Pt[1].to_bytes(32, "little")
+    for v in kat["ietf"]:
+        ad = bytes.fromhex(v["ad"])
+        c, s = bytes.fromhex(v["c"]), bytes.fromhex(v["s"])
+        assert hs.hs_ietf_verify_affine(xy(v["pk"]), xy(v["h"]), xy(v["gamma"]), c, s, ad, len(ad)) == 0
+        bad = bytearray(s); bad[0] ^= 1
+        assert hs.hs_ietf_verify_affine(xy(v["pk"]), xy(v["h"]), xy(v["gamma"]), c, bytes(bad), ad, len(ad)) == 1
+        off = bytearray(xy(v["pk"])); off[0] ^= 1
+        assert hs.hs_ietf_verify_affine(bytes(off), xy(v["h"]), xy(v["gamma"]), c, s, ad, len(ad)) == 2
