@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2-batch", type=int, default=LOG2_BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--secondary", action="store_true",
+                    help="also time the other BASELINE.json configs (prove 2^16, Pedersen 2^20, MSM 2^20, "
+                         "pairing 2^14, affine-input verify) and attach them under \"secondary\"")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -157,11 +160,75 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, pk, hh, gamma, c, s, status)
+        if args.secondary and world == 1:
+            out["secondary"] = secondary(ctx, lib, dev, sk, msg, pk, hh, gamma, c, s)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def _time(fn, reps=3):
+    import torch
+    best = 1e30
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def secondary(ctx, lib, dev, sk, msg, pk, hh, gamma, c, s):
+    """Other configs of BASELINE.json, same synthetic items, device-resident; best of 3."""
+    import torch
+    from ark_ec_vrfs_amd import _lib
+    n = sk.shape[0]
+    res = {}
+    stream = torch.cuda.current_stream().cuda_stream
+    mk = lambda m=n, w=32: torch.empty((m, w), dtype=torch.uint8, device=dev)
+    # config 1: IETF prove at 2^16 (160 B/proof)
+    m = min(n, 1 << 16)
+    o1, o2, o3, o4, o5 = mk(m), mk(m), mk(m), mk(m), mk(m)
+    st = torch.empty(m, dtype=torch.uint8, device=dev)
+    t = _time(lambda: ctx.ietf_prove_batch_dev(sk[:m], msg[:m], 32, o1, o2, o3, o4, o5, st))
+    res["ietf_prove_2^16"] = {"proofs_per_s": m / t, "ms": t * 1e3, "bytes_per_item": 160}
+    # affine-input verify (257 B/verify)
+    xy = [mk(n, 64) for _ in range(3)]
+    vst = torch.empty(n, dtype=torch.uint8, device=dev)
+    for src, dst in zip((pk, hh, gamma), xy):
+        _lib.check(lib.vrfhip_point_validate_batch_dev(ctx.handle, n, src.data_ptr(), dst.data_ptr(), vst.data_ptr(), stream), "validate")
+    t = _time(lambda: ctx.ietf_verify_batch_affine_dev(xy[0], xy[1], xy[2], c, s, vst))
+    assert int(vst.sum()) == 0
+    res["ietf_verify_affine_2^%d" % (n.bit_length() - 1)] = {"verifies_per_s": n / t, "ms": t * 1e3, "bytes_per_item": 257}
+    # config 3: Pedersen prove + verify (Bandersnatch; 288 / 225 B)
+    g, pc, r, ok, ss, sb = (mk() for _ in range(6))
+    pst = torch.empty(n, dtype=torch.uint8, device=dev)
+    tp = _time(lambda: ctx.pedersen_prove_batch_dev(sk, msg, 32, g, pc, r, ok, ss, sb, None, None, pst))
+    tv = _time(lambda: ctx.pedersen_verify_batch_dev(hh, g, pc, r, ok, ss, sb, pst))
+    assert int(pst.sum()) == 0
+    res["pedersen_2^%d" % (n.bit_length() - 1)] = {"proofs_per_s": n / tp, "verifies_per_s": n / tv,
+                                                   "bytes_per_proof": 288, "bytes_per_verify": 225}
+    # MSM over the public keys with the secrets as scalars (96 B/term)
+    out = torch.empty(32, dtype=torch.uint8, device=dev); mst = torch.empty(1, dtype=torch.uint8, device=dev)
+    t = _time(lambda: ctx.msm_dev(xy[0], sk, out, None, mst))
+    assert int(mst[0]) == 0
+    res["msm_2^%d" % (n.bit_length() - 1)] = {"points_per_s": n / t, "ms": t * 1e3, "bytes_per_item": 96}
+    # config 4: pairing checks at 2^14 (577 B/check); 8 oracle-made items tiled
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_bls_pairing import kzg_like_items, pack
+        g1, g2 = pack(kzg_like_items(8, seed=21))
+        k = 1 << 14
+        d1 = torch.from_numpy(np.tile(g1, (k // 8, 1)).copy()).to(dev)
+        d2 = torch.from_numpy(np.tile(g2, (k // 8, 1)).copy()).to(dev)
+        pstat = torch.empty(k, dtype=torch.uint8, device=dev)
+        t = _time(lambda: ctx.pairing_check_batch_dev(d1, d2, pstat))
+        assert int(pstat.sum()) == 0
+        res["pairing_check_2^14"] = {"checks_per_s": k / t, "ms": t * 1e3, "bytes_per_item": 577}
+    except Exception as e:                                      # the headline number must not depend on this leg
+        res["pairing_check_2^14"] = {"error": repr(e)}
+    return res
 
 
 def cpu_baseline(args, pk, hh, gamma, c, s, status):
