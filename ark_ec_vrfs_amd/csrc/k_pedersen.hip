@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(BLOCK) k_ped_verify_decode(PedersenVerifyArgs 
   bytes_get(a.ad, i, ad, ad_len);
   uint32_t c[8];
   bool ok = pedersen_verify_decode_item<SuiteBS>(c, a.T, enc, ad, ad_len,
-                                                 a.ws.tabs + i * (3 * WIN_TABLE_WORDS),
+                                                 a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS),
                                                  a.ws.pts + i * PROVE_PTS_WORDS);
   uint32_t* aux = a.ws.aux + i * AUX_WORDS;
 #pragma unroll
@@ -37,8 +37,8 @@ __global__ void __launch_bounds__(BLOCK) k_ped_verify_straus(PedersenVerifyArgs 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0; sb[j] = 0; }
   }
-  pedersen_verify_straus_item<SuiteBS>(a.ws.pts + i * PROVE_PTS_WORDS + HALF * UV_WORDS, a.T,
-                                       a.ws.tabs + i * (3 * WIN_TABLE_WORDS), c, s, sb, HALF);
+  pedersen_verify_straus_item<SuiteBS, HALF>(a.ws.pts + i * PROVE_PTS_WORDS + HALF * UV_WORDS, a.T,
+                                             a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), c, s, sb);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_ped_verify_finish(PedersenVerifyArgs a) {

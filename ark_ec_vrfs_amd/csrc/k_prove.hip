@@ -12,7 +12,7 @@ __global__ void __launch_bounds__(BLOCK) k_prove_prepare(ProveArgs a) {
   load32(sk, a.sk, i);
   const uint8_t* msg = nullptr; uint32_t msg_len = 0;
   if (a.h_given) load32(hg, a.h_given, i); else bytes_get(a.msg, i, msg, msg_len);
-  bool ok = prove_prepare_item<SuiteBS>(h_enc, k, a.ws.tabs + i * WIN_TABLE_WORDS, a.T, sk, msg,
+  bool ok = prove_prepare_item<SuiteBS>(h_enc, k, a.ws.tabs + i * (2 * WIN_TABLE_WORDS), a.T, sk, msg,
                                         msg_len, a.h_given ? hg : nullptr);
   uint32_t* aux = a.ws.aux + i * AUX_WORDS;
 #pragma unroll
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(BLOCK) k_prove_mul(ProveArgs a) {
     for (int j = 0; j < 8; ++j) sc[j] = 0;
   }
   prove_mul_item<SuiteBS>(a.ws.pts + i * PROVE_PTS_WORDS + half * 2 * UV_WORDS, a.T,
-                          a.ws.tabs + i * WIN_TABLE_WORDS, sc,
+                          a.ws.tabs + i * (2 * WIN_TABLE_WORDS), sc,
                           a.pedersen ? a.ws.aux + i * AUX_WORDS + 16 + half * 8 : nullptr);
 }
 

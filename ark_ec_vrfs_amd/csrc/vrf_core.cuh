@@ -694,7 +694,7 @@ VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, 
   }
   te_encode_affine(h_enc, x, y);
   nonce_rfc8032<S>(k, sk, h_enc);
-  build_win_table<S>(tab, x, y);
+  build_glv_tables<S>(tab, x, y);          // {H, psi H}: 2 * WIN_TABLE_WORDS
   return valid;
 }
 
@@ -702,9 +702,20 @@ VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, 
 template <class S>
 VRF_HD void prove_mul_item(uint32_t* out /*2*UV_WORDS*/, const DevTables& T, const uint32_t* tab,
                            const uint32_t scalar[8], const uint32_t* scalar2) {
-  uint32_t rec[8];
-  scalar_recode_signed4(rec, scalar);
-  PtE w = win_mul<S>(tab, rec);
+  // scalar * H by GLV: k = k1 + k2*lambda over the table pair {H, psi H}
+  Straus4 q;
+  GlvHalf h[2];
+  glv_decompose_bs(h[0], h[1], scalar);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    scalar_recode_signed4_128(q.rec[t], h[t].mag);
+    q.neg[t] = h[t].neg;
+  }
+  q.tab[0] = tab; q.tab[1] = tab + WIN_TABLE_WORDS; q.tab[2] = tab; q.tab[3] = tab;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { q.rec[2][i] = 0; q.rec[3][i] = 0; }
+  q.neg[2] = false; q.neg[3] = false;
+  PtE w = straus4<S, 2>(q);
   fe_store(out, w.X); fe_store(out + NL, w.Y); fe_store(out + 2 * NL, w.Z);
   PtE c;
   if (scalar2) {
@@ -782,7 +793,7 @@ VRF_HD FeN fe_sel5(int p, const FeN (&a)[5]) {
   return fe_select(p == 0, a[0], fe_select(p == 1, a[1], fe_select(p == 2, a[2], fe_select(p == 3, a[3], a[4]))));
 }
 
-// enc: [H, Gamma, pk_com, R, Ok].  tabs: tables of H, Gamma, pk_com.  pts: receives affine Ok, R.
+// enc: [H, Gamma, pk_com, R, Ok].  tabs: GLV table pairs of H, Gamma, pk_com (6 tables).  pts: receives affine Ok, R.
 template <class S>
 VRF_HD bool pedersen_verify_decode_item(uint32_t c_out[8], const DevTables& T,
                                         const uint32_t (&enc)[5][8], const uint8_t* ad,
@@ -810,7 +821,7 @@ VRF_HD bool pedersen_verify_decode_item(uint32_t c_out[8], const DevTables& T,
     Fe<1, 4> x;
     valid = decode_phase_b<S>(x, a, di, T.sq) && valid;
     if (p < 3) {
-      build_win_table<S>(tabs + p * WIN_TABLE_WORDS, x, a.y);
+      build_glv_tables<S>(tabs + p * 2 * WIN_TABLE_WORDS, x, a.y);
     } else {
       uint32_t* dst = pts + (p == 3 ? PED_R_OFF : PED_OK_OFF);
       fe_store(dst, x);
@@ -826,18 +837,41 @@ VRF_HD bool pedersen_verify_decode_item(uint32_t c_out[8], const DevTables& T,
   return valid;
 }
 
-// half 0: s*H - c*Gamma ; half 1: s*G - c*pk_com + sb*B
-template <class S>
+// half 0: s*H - c*Gamma (4-table GLV Straus) ; half 1: -c*pk_com (2-table GLV Straus) + s*G + sb*B
+// (two fixed-base combs).  tabs: GLV table pairs of H, Gamma, pk_com.
+template <class S, int HALF>
 VRF_HD void pedersen_verify_straus_item(uint32_t* out_uv, const DevTables& T, const uint32_t* tabs,
                                         const uint32_t c[8], const uint32_t s[8],
-                                        const uint32_t sb[8], int half) {
-  uint32_t recs[8], recc[8];
-  scalar_recode_signed4(recs, s);
-  scalar_recode_signed4(recc, c);
-  const uint32_t* tabA = half ? T.g_win : tabs;
-  const uint32_t* tabB = half ? tabs + 2 * WIN_TABLE_WORDS : tabs + WIN_TABLE_WORDS;
-  PtE r = straus2<S>(tabA, recs, tabB, recc, true);
-  if (half) r = comb_add<S>(r, T.b_comb, sb);
+                                        const uint32_t sb[8]) {
+  Straus4 q;
+  GlvHalf h[4];
+  glv_decompose_bs(h[0], h[1], c);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    scalar_recode_signed4_128(q.rec[t], h[t].mag);
+    q.neg[t] = !h[t].neg;                      // the c terms are subtracted
+  }
+  PtE r;
+  if (HALF == 0) {
+    glv_decompose_bs(h[2], h[3], s);
+#pragma unroll
+    for (int t = 2; t < 4; ++t) {
+      scalar_recode_signed4_128(q.rec[t], h[t].mag);
+      q.neg[t] = h[t].neg;
+    }
+    q.tab[0] = tabs + 2 * WIN_TABLE_WORDS; q.tab[1] = tabs + 3 * WIN_TABLE_WORDS;   // Gamma pair
+    q.tab[2] = tabs; q.tab[3] = tabs + WIN_TABLE_WORDS;                             // H pair
+    r = straus4<S, 4>(q);
+  } else {
+    q.tab[0] = tabs + 4 * WIN_TABLE_WORDS; q.tab[1] = tabs + 5 * WIN_TABLE_WORDS;   // pk_com pair
+    q.tab[2] = tabs; q.tab[3] = tabs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { q.rec[2][i] = 0; q.rec[3][i] = 0; }
+    q.neg[2] = false; q.neg[3] = false;
+    r = straus4<S, 2>(q);
+    r = comb_add<S>(r, T.g_comb, s);
+    r = comb_add<S>(r, T.b_comb, sb);
+  }
   fe_store(out_uv, r.X);
   fe_store(out_uv + NL, r.Y);
   fe_store(out_uv + 2 * NL, r.Z);

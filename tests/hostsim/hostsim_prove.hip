@@ -65,7 +65,7 @@ static int prove_any(bool pedersen, const uint8_t* sk, const uint8_t* msg, uint3
   uint32_t skw[8]; memcpy(skw, sk, 32);
   uint32_t hg[8]; if (h_given) memcpy(hg, h_given, 32);
   uint32_t k[8], kb[8];
-  std::vector<uint32_t> tab(WIN_TABLE_WORDS), pts(PROVE_PTS_WORDS);
+  std::vector<uint32_t> tab(2 * WIN_TABLE_WORDS), pts(PROVE_PTS_WORDS);
   bool valid = prove_prepare_item<SuiteBS>(h_enc, k, tab.data(), HT().t, skw, msg, len, h_given ? hg : nullptr);
   if (pedersen) { pedersen_blinding<SuiteBS>(b, skw, h_enc, ad, ad_len); nonce_rfc8032<SuiteBS>(kb, b, h_enc); }
   prove_mul_item<SuiteBS>(pts.data(), HT().t, tab.data(), skw, pedersen ? b : nullptr);
@@ -99,13 +99,13 @@ uint32_t hs_pedersen_verify(const uint8_t* h, const uint8_t* g, const uint8_t* p
   uint32_t enc[5][8], s[8], sb[8], c[8];
   memcpy(enc[0], h, 32); memcpy(enc[1], g, 32); memcpy(enc[2], proof160, 32); memcpy(enc[3], proof160 + 32, 32);
   memcpy(enc[4], proof160 + 64, 32); memcpy(s, proof160 + 96, 32); memcpy(sb, proof160 + 128, 32);
-  std::vector<uint32_t> tabs(3 * WIN_TABLE_WORDS), pts(PROVE_PTS_WORDS);
+  std::vector<uint32_t> tabs(VERIFY_TABS * WIN_TABLE_WORDS), pts(PROVE_PTS_WORDS);
   bool valid = pedersen_verify_decode_item<SuiteBS>(c, HT().t, enc, ad, ad_len, tabs.data(), pts.data());
   uint32_t s2[8], sb2[8];
   bool canon = fr_is_canonical<SuiteBS>(s) && fr_is_canonical<SuiteBS>(sb);
   for (int j = 0; j < 8; ++j) { s2[j] = canon ? s[j] : 0; sb2[j] = canon ? sb[j] : 0; }
-  for (int half = 0; half < 2; ++half)
-    pedersen_verify_straus_item<SuiteBS>(pts.data() + half * UV_WORDS, HT().t, tabs.data(), c, s2, sb2, half);
+  pedersen_verify_straus_item<SuiteBS, 0>(pts.data(), HT().t, tabs.data(), c, s2, sb2);
+  pedersen_verify_straus_item<SuiteBS, 1>(pts.data() + UV_WORDS, HT().t, tabs.data(), c, s2, sb2);
   return pedersen_verify_finish_item<SuiteBS>(pts.data(), s, sb, valid);
 }
 }
