@@ -52,6 +52,13 @@ class BandersnatchSha512Ell2(Suite):
     SUITE_ENUM = 1
 
 
+class JubJubSha512Tai(Suite):
+    """`suites::jubjub` as SURVEY.md A.6 recalls it (parity unpinned)."""
+    SUITE_ID = b"JubJub_SHA-512_TAI"
+    CHALLENGE_LEN = 32
+    SUITE_ENUM = 2
+
+
 def _np_u8(b, n_bytes: Optional[int] = None) -> np.ndarray:
     a = np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else b
     a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
@@ -105,11 +112,11 @@ class Context:
         _lib.check(self._lib.vrfhip_ctx_profile(self._h, int(enable)), "vrfhip_ctx_profile")
 
     def profile_read(self):
-        """-> ([ms_stage1, ms_stage2, ms_stage3] summed over launch groups, n_launch_groups)."""
-        ms = (ctypes.c_double * 3)()
+        """-> ([ms per stage: decode|prepare, straus V|mul, straus U, finish] summed over launch groups, n)."""
+        ms = (ctypes.c_double * 4)()
         n = ctypes.c_uint64()
         _lib.check(self._lib.vrfhip_ctx_profile_read(self._h, ms, ctypes.byref(n)), "vrfhip_ctx_profile_read")
-        return [ms[0], ms[1], ms[2]], int(n.value)
+        return [ms[0], ms[1], ms[2], ms[3]], int(n.value)
 
     def workspace_bytes(self) -> int:
         return int(self._lib.vrfhip_ctx_workspace_bytes(self._h))

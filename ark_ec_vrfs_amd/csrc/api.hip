@@ -60,7 +60,7 @@ struct vrfhip_ctx {
   int cus = 256;
   // optional per-stage timing (hipEvents on the launch stream), see vrfhip_ctx_profile
   bool prof = false;
-  std::vector<hipEvent_t> prof_ev;   // 4 per launch group
+  std::vector<hipEvent_t> prof_ev;   // 5 per launch group
   // staging for the host-pointer entry points
   void* d_stage = nullptr;
   size_t stage_bytes = 0;
@@ -136,12 +136,12 @@ struct Stage {
   }
 };
 
-// four fresh events for one launch group when profiling is on, else nullptr
+// five fresh events for one launch group when profiling is on, else nullptr
 hipEvent_t* prof_events(vrfhip_ctx* ctx) {
   if (!ctx->prof) return nullptr;
   size_t base = ctx->prof_ev.size();
-  ctx->prof_ev.resize(base + 4);
-  for (int i = 0; i < 4; ++i)
+  ctx->prof_ev.resize(base + 5);
+  for (int i = 0; i < 5; ++i)
     if (hipEventCreate(&ctx->prof_ev[base + i]) != hipSuccess) {
       ctx->prof_ev.resize(base);
       return nullptr;
@@ -175,7 +175,7 @@ const char* vrfhip_last_error(void) { return g_last_error.c_str(); }
 int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out) {
   if (!out) return fail(VRFHIP_ERR_BAD_ARG, "out is NULL");
   *out = nullptr;
-  if (suite != VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2)
+  if (suite != VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2 && suite != VRFHIP_SUITE_JUBJUB_SHA512_TAI)
     return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported suite");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
@@ -214,7 +214,7 @@ int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out) 
                            ctx->stream));
   HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_lut, vrfk_tables::SQRT_LUT, lut_bytes, hipMemcpyHostToDevice,
                            ctx->stream));
-  launch_init_tables(ctx->d_g_win, ctx->d_g_comb, ctx->d_b_comb, ctx->stream);
+  launch_init_tables((int)suite, ctx->d_g_win, ctx->d_g_comb, ctx->d_b_comb, ctx->stream);
   HIP_TRY_C(hipGetLastError());
   HIP_TRY_C(hipStreamSynchronize(ctx->stream));
 #undef HIP_TRY_C
@@ -265,15 +265,15 @@ int32_t vrfhip_ctx_profile(vrfhip_ctx* ctx, int32_t enable) {
   return VRFHIP_SUCCESS;
 }
 
-int32_t vrfhip_ctx_profile_read(vrfhip_ctx* ctx, double stage_ms[3], uint64_t* launches) {
+int32_t vrfhip_ctx_profile_read(vrfhip_ctx* ctx, double stage_ms[4], uint64_t* launches) {
   if (!ctx || !stage_ms || !launches) return fail(VRFHIP_ERR_BAD_ARG, "NULL argument");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  stage_ms[0] = stage_ms[1] = stage_ms[2] = 0.0;
-  *launches = ctx->prof_ev.size() / 4;
-  for (size_t g = 0; g + 3 < ctx->prof_ev.size(); g += 4) {
-    HIP_TRY(hipEventSynchronize(ctx->prof_ev[g + 3]));
-    for (int k = 0; k < 3; ++k) {
+  stage_ms[0] = stage_ms[1] = stage_ms[2] = stage_ms[3] = 0.0;
+  *launches = ctx->prof_ev.size() / 5;
+  for (size_t g = 0; g + 4 < ctx->prof_ev.size(); g += 5) {
+    HIP_TRY(hipEventSynchronize(ctx->prof_ev[g + 4]));
+    for (int k = 0; k < 4; ++k) {
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_ev[g + k], ctx->prof_ev[g + k + 1]));
       stage_ms[k] += ms;
@@ -305,6 +305,7 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     size_t m = std::min(ctx->ws_cap, n - base);
     VerifyArgs a;
+    a.suite = (int)ctx->suite;
     a.n = m;
     a.pk = d_pk + base * pw; a.h = d_input + base * pw; a.gamma = d_output + base * pw;
     a.affine_in = affine ? 1 : 0;
@@ -417,6 +418,7 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     size_t m = std::min(ctx->ws_cap, n - base);
     ProveArgs a;
+    a.suite = (int)ctx->suite;
     a.n = m;
     a.sk = d_sk + base * 32;
     if (d_msg_off) a.msg = make_view(d_msg, d_msg_off + base, 0, false);
@@ -570,6 +572,7 @@ int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     size_t m = std::min(ctx->ws_cap, n - base);
     PedersenVerifyArgs a;
+    a.suite = (int)ctx->suite;
     a.n = m;
     a.h = d_input + base * 32; a.gamma = d_output + base * 32; a.pk_com = d_pk_com + base * 32;
     a.r = d_r + base * 32; a.ok = d_ok + base * 32; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
@@ -625,6 +628,8 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (!d_out_point || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!d_bases_xy || !d_scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if (ctx->suite != VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2)
+    return fail(VRFHIP_ERR_UNSUPPORTED, "vrfhip_msm is built for the Bandersnatch curve only");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -726,7 +731,7 @@ int32_t vrfhip_hash_to_curve_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
   if (!d_points || (!d_msg && (msg_len || d_msg_off))) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  launch_hash_to_curve(n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T,
+  launch_hash_to_curve((int)ctx->suite, n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T,
                        static_cast<hipStream_t>(stream));
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
@@ -767,7 +772,7 @@ int32_t vrfhip_output_hash_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d
   if (!d_output || !d_hash) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  launch_output_hash(n, d_output, d_hash, static_cast<hipStream_t>(stream));
+  launch_output_hash((int)ctx->suite, n, d_output, d_hash, static_cast<hipStream_t>(stream));
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
 }
@@ -802,7 +807,7 @@ int32_t vrfhip_secret_from_seed_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8
   if (!d_sk_out || (!d_seeds && seed_len)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  launch_secret_from_seed(n, d_seeds, seed_len, d_sk_out, d_pk_out, ctx->T,
+  launch_secret_from_seed((int)ctx->suite, n, d_seeds, seed_len, d_sk_out, d_pk_out, ctx->T,
                           static_cast<hipStream_t>(stream));
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
@@ -848,7 +853,7 @@ int32_t vrfhip_point_validate_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t
   size_t cap = ctx->ws_cap * WS_TABS;
   for (size_t base = 0; base < n; base += cap) {
     size_t m = std::min(cap, n - base);
-    launch_point_validate(m, d_points + base * 32, d_xy_out ? d_xy_out + base * 64 : nullptr,
+    launch_point_validate((int)ctx->suite, m, d_points + base * 32, d_xy_out ? d_xy_out + base * 64 : nullptr,
                           d_status + base, ctx->ws.tabs, ctx->T, static_cast<hipStream_t>(stream));
   }
   HIP_TRY(hipGetLastError());

@@ -4,92 +4,102 @@
 namespace vrf {
 
 // ---- one-time table construction (context creation) ----
+template <class S>
 __global__ void k_init_gwin(uint32_t* g_win) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) build_glv_tables<SuiteBS>(g_win, SuiteBS::gx(), SuiteBS::gy());
+  if (blockIdx.x == 0 && threadIdx.x == 0) build_glv_tables<S>(g_win, S::gx(), S::gy());
 }
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_init_comb(uint32_t* comb, int which) {
   int t = blockIdx.x * BLOCK + threadIdx.x;
   if (t >= 32 * 255) return;
   int w = t / 255, j = t % 255 + 1;
-  FeN bx = which ? SuiteBS::bx() : SuiteBS::gx();
-  FeN by = which ? SuiteBS::by() : SuiteBS::gy();
-  comb_entry<SuiteBS>(comb + (size_t)t * PTA_WORDS, bx, by, w, j);
+  FeN bx = which ? S::bx() : S::gx();
+  FeN by = which ? S::by() : S::gy();
+  comb_entry<S>(comb + (size_t)t * PTA_WORDS, bx, by, w, j);
 }
-void launch_init_tables(uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, hipStream_t st) {
-  hipLaunchKernelGGL(k_init_gwin, dim3(1), dim3(64), 0, st, g_win);
-  hipLaunchKernelGGL(k_init_comb, grid_for(32 * 255), dim3(BLOCK), 0, st, g_comb, 0);
-  hipLaunchKernelGGL(k_init_comb, grid_for(32 * 255), dim3(BLOCK), 0, st, b_comb, 1);
+template <class S>
+static void init_tables_t(uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, hipStream_t st) {
+  hipLaunchKernelGGL(k_init_gwin<S>, dim3(1), dim3(64), 0, st, g_win);
+  hipLaunchKernelGGL(k_init_comb<S>, grid_for(32 * 255), dim3(BLOCK), 0, st, g_comb, 0);
+  hipLaunchKernelGGL(k_init_comb<S>, grid_for(32 * 255), dim3(BLOCK), 0, st, b_comb, 1);
+}
+void launch_init_tables(int suite, uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, hipStream_t st) {
+  VRF_DISPATCH_SUITE(suite, init_tables_t<S>(g_win, g_comb, b_comb, st));
 }
 
 // ---- Input::new ----
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_hash_to_curve(size_t n, BytesView msg, uint8_t* points, DevTables T) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint8_t* m; uint32_t len;
   bytes_get(msg, i, m, len);
-  PtE h = hash_to_curve_ell2<SuiteBS>(m, len, T.sq);
+  PtE h = data_to_point<S>(m, len, T.sq);
   FeN x, y;
   te_to_affine(x, y, h);
   uint32_t e[8];
   te_encode_affine(e, x, y);
   store32(points, i, e);
 }
-void launch_hash_to_curve(size_t n, BytesView msg, uint8_t* points, DevTables T, hipStream_t st) {
-  if (n) hipLaunchKernelGGL(k_hash_to_curve, grid_for(n), dim3(BLOCK), 0, st, n, msg, points, T);
+void launch_hash_to_curve(int suite, size_t n, BytesView msg, uint8_t* points, DevTables T, hipStream_t st) {
+  if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_hash_to_curve<S>, grid_for(n), dim3(BLOCK), 0, st, n, msg, points, T));
 }
 
 // ---- Output::hash ----
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t g[8], o[16];
   load32(g, gamma, i);
-  output_hash_item<SuiteBS>(o, g);
+  output_hash_item<S>(o, g);
   uint32_t* p = reinterpret_cast<uint32_t*>(hash + i * 64);
 #pragma unroll
   for (int j = 0; j < 16; ++j) p[j] = o[j];
 }
-void launch_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash, hipStream_t st) {
-  if (n) hipLaunchKernelGGL(k_output_hash, grid_for(n), dim3(BLOCK), 0, st, n, gamma, hash);
+void launch_output_hash(int suite, size_t n, const uint8_t* gamma, uint8_t* hash, hipStream_t st) {
+  if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_output_hash<S>, grid_for(n), dim3(BLOCK), 0, st, n, gamma, hash));
 }
 
 // ---- Secret::from_seed / Secret::public ----
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len,
                                                              uint8_t* sk_out, uint8_t* pk_out, DevTables T) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t sk[8];
-  secret_from_seed_item<SuiteBS>(sk, seeds + i * (size_t)seed_len, seed_len);
+  secret_from_seed_item<S>(sk, seeds + i * (size_t)seed_len, seed_len);
   store32(sk_out, i, sk);
   if (pk_out) {
     uint32_t pk[8];
-    public_from_secret_item<SuiteBS>(pk, T, sk);
+    public_from_secret_item<S>(pk, T, sk);
     store32(pk_out, i, pk);
   }
 }
-void launch_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk,
+void launch_secret_from_seed(int suite, size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk,
                              uint8_t* pk, DevTables T, hipStream_t st) {
-  if (n) hipLaunchKernelGGL(k_secret_from_seed, grid_for(n), dim3(BLOCK), 0, st, n, seeds, seed_len, sk, pk, T);
+  if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_secret_from_seed<S>, grid_for(n), dim3(BLOCK), 0, st, n, seeds, seed_len, sk, pk, T));
 }
 
 // ---- codec: checked point decoding (on curve + prime-order subgroup) ----
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_point_validate(size_t n, const uint8_t* pts, uint8_t* xy,
                                                            uint8_t* status, uint32_t* tabs, DevTables T) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t e[8];
   load32(e, pts, i);
-  DecodeA a = decode_phase_a<SuiteBS>(e);
+  DecodeA a = decode_phase_a<S>(e);
   FeN di = fe_inv(a.den);
   Fe<1, 4> x;
-  bool ok = decode_phase_b<SuiteBS>(x, a, di, T.sq);
+  bool ok = decode_phase_b<S>(x, a, di, T.sq);
   uint32_t* tab = tabs + i * WIN_TABLE_WORDS;
-  build_win_table<SuiteBS>(tab, x, a.y);
+  build_win_table<S>(tab, x, a.y);
   uint32_t r[8], rec[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = SuiteBS::r32(j);
+  for (int j = 0; j < 8; ++j) r[j] = S::r32(j);
   scalar_recode_signed4(rec, r);
-  PtE rp = win_mul<SuiteBS>(tab, rec);
+  PtE rp = win_mul<S>(tab, rec);
   // identity <=> X == 0 and Y == Z
   bool is_id = fe_is_zero(rp.X) && fe_eq(rp.Y, rp.Z);
   ok = ok && is_id;
@@ -107,9 +117,9 @@ __global__ void __launch_bounds__(BLOCK) k_point_validate(size_t n, const uint8_
     for (int j = 0; j < 8; ++j) { p[j] = xw[j]; p[8 + j] = yw[j]; }
   }
 }
-void launch_point_validate(size_t n, const uint8_t* pts, uint8_t* xy, uint8_t* status,
+void launch_point_validate(int suite, size_t n, const uint8_t* pts, uint8_t* xy, uint8_t* status,
                            uint32_t* tabs, DevTables T, hipStream_t st) {
-  if (n) hipLaunchKernelGGL(k_point_validate, grid_for(n), dim3(BLOCK), 0, st, n, pts, xy, status, tabs, T);
+  if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_point_validate<S>, grid_for(n), dim3(BLOCK), 0, st, n, pts, xy, status, tabs, T));
 }
 
 // ---- test primitive: Fq multiplication ----

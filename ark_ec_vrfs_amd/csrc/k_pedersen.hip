@@ -5,6 +5,7 @@
 
 namespace vrf {
 
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_ped_verify_decode(PedersenVerifyArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
@@ -14,7 +15,7 @@ __global__ void __launch_bounds__(BLOCK) k_ped_verify_decode(PedersenVerifyArgs 
   const uint8_t* ad; uint32_t ad_len;
   bytes_get(a.ad, i, ad, ad_len);
   uint32_t c[8];
-  bool ok = pedersen_verify_decode_item<SuiteBS>(c, a.T, enc, ad, ad_len,
+  bool ok = pedersen_verify_decode_item<S>(c, a.T, enc, ad, ad_len,
                                                  a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS),
                                                  a.ws.pts + i * PROVE_PTS_WORDS);
   uint32_t* aux = a.ws.aux + i * AUX_WORDS;
@@ -24,7 +25,7 @@ __global__ void __launch_bounds__(BLOCK) k_ped_verify_decode(PedersenVerifyArgs 
 }
 
 // HALF 0: s*H - c*Gamma ; HALF 1: s*G - c*pk_com + sb*B.  Separate launches keep each wave uniform.
-template <int HALF>
+template <class S, int HALF>
 __global__ void __launch_bounds__(BLOCK) k_ped_verify_straus(PedersenVerifyArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
@@ -33,33 +34,39 @@ __global__ void __launch_bounds__(BLOCK) k_ped_verify_straus(PedersenVerifyArgs 
 #pragma unroll
   for (int j = 0; j < 8; ++j) c[j] = a.ws.aux[i * AUX_WORDS + j];
   // out-of-range scalars are reported InvalidData by the finish stage; keep digits in range here
-  if (!fr_is_canonical<SuiteBS>(s) || !fr_is_canonical<SuiteBS>(sb)) {
+  if (!fr_is_canonical<S>(s) || !fr_is_canonical<S>(sb)) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0; sb[j] = 0; }
   }
-  pedersen_verify_straus_item<SuiteBS, HALF>(a.ws.pts + i * PROVE_PTS_WORDS + HALF * UV_WORDS, a.T,
+  pedersen_verify_straus_item<S, HALF>(a.ws.pts + i * PROVE_PTS_WORDS + HALF * UV_WORDS, a.T,
                                              a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), c, s, sb);
 }
 
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_ped_verify_finish(PedersenVerifyArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
   uint32_t s[8], sb[8];
   load32(s, a.s, i); load32(sb, a.sb, i);
-  a.status[i] = (uint8_t)pedersen_verify_finish_item<SuiteBS>(a.ws.pts + i * PROVE_PTS_WORDS, s, sb,
+  a.status[i] = (uint8_t)pedersen_verify_finish_item<S>(a.ws.pts + i * PROVE_PTS_WORDS, s, sb,
                                                               a.ws.flags[i] != 0);
 }
 
+template <class S>
+static void launch_ped_t(const PedersenVerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
+  if (ev) (void)hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(k_ped_verify_decode<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  hipLaunchKernelGGL((k_ped_verify_straus<S, 0>), grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[2], st);
+  hipLaunchKernelGGL((k_ped_verify_straus<S, 1>), grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[3], st);
+  hipLaunchKernelGGL(k_ped_verify_finish<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[4], st);
+}
 void launch_pedersen_verify(const PedersenVerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (a.n == 0) return;
-  if (ev) (void)hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(k_ped_verify_decode, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  if (ev) (void)hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(k_ped_verify_straus<0>, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  hipLaunchKernelGGL(k_ped_verify_straus<1>, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  if (ev) (void)hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL(k_ped_verify_finish, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  if (ev) (void)hipEventRecord(ev[3], st);
+  VRF_DISPATCH_SUITE(a.suite, launch_ped_t<S>(a, st, ev));
 }
 
 }  // namespace vrf

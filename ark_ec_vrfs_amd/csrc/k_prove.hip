@@ -5,6 +5,7 @@
 namespace vrf {
 
 // stage 1: H = hash_to_curve(msg) (or decode a given H), enc(H), nonce, window table of H
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_prove_prepare(ProveArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
@@ -12,7 +13,7 @@ __global__ void __launch_bounds__(BLOCK) k_prove_prepare(ProveArgs a) {
   load32(sk, a.sk, i);
   const uint8_t* msg = nullptr; uint32_t msg_len = 0;
   if (a.h_given) load32(hg, a.h_given, i); else bytes_get(a.msg, i, msg, msg_len);
-  bool ok = prove_prepare_item<SuiteBS>(h_enc, k, a.ws.tabs + i * (2 * WIN_TABLE_WORDS), a.T, sk, msg,
+  bool ok = prove_prepare_item<S>(h_enc, k, a.ws.tabs + i * (2 * WIN_TABLE_WORDS), a.T, sk, msg,
                                         msg_len, a.h_given ? hg : nullptr);
   uint32_t* aux = a.ws.aux + i * AUX_WORDS;
 #pragma unroll
@@ -21,8 +22,8 @@ __global__ void __launch_bounds__(BLOCK) k_prove_prepare(ProveArgs a) {
     const uint8_t* ad; uint32_t ad_len;
     bytes_get(a.ad, i, ad, ad_len);
     uint32_t b[8], kb[8];
-    pedersen_blinding<SuiteBS>(b, sk, h_enc, ad, ad_len);
-    nonce_rfc8032<SuiteBS>(kb, b, h_enc);
+    pedersen_blinding<S>(b, sk, h_enc, ad, ad_len);
+    nonce_rfc8032<S>(kb, b, h_enc);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { aux[16 + j] = b[j]; aux[24 + j] = kb[j]; }
   }
@@ -30,6 +31,7 @@ __global__ void __launch_bounds__(BLOCK) k_prove_prepare(ProveArgs a) {
 }
 
 // stage 2: two lanes per proof: lane 0 -> (sk*H, sk*G), lane 1 -> (k*H, k*G)
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_prove_mul(ProveArgs a) {
   size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   size_t i = t >> 1;
@@ -43,16 +45,17 @@ __global__ void __launch_bounds__(BLOCK) k_prove_mul(ProveArgs a) {
     for (int j = 0; j < 8; ++j) sc[j] = a.ws.aux[i * AUX_WORDS + 8 + j];
   }
   // a non-canonical secret is reported InvalidData by stage 3; keep the digits in range here
-  if (!fr_is_canonical<SuiteBS>(sc)) {
+  if (!fr_is_canonical<S>(sc)) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) sc[j] = 0;
   }
-  prove_mul_item<SuiteBS>(a.ws.pts + i * PROVE_PTS_WORDS + half * 2 * UV_WORDS, a.T,
+  prove_mul_item<S>(a.ws.pts + i * PROVE_PTS_WORDS + half * 2 * UV_WORDS, a.T,
                           a.ws.tabs + i * (2 * WIN_TABLE_WORDS), sc,
                           a.pedersen ? a.ws.aux + i * AUX_WORDS + 16 + half * 8 : nullptr);
 }
 
 // stage 3: encodings, challenge, s = k + c*sk
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_prove_finish(ProveArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
@@ -63,14 +66,14 @@ __global__ void __launch_bounds__(BLOCK) k_prove_finish(ProveArgs a) {
   for (int j = 0; j < 8; ++j) { h_enc[j] = aux[j]; k[j] = aux[8 + j]; }
   const uint8_t* ad; uint32_t ad_len;
   bytes_get(a.ad, i, ad, ad_len);
-  prove_finish_item<SuiteBS>(g, c, s, pk, rr, okp, a.ws.pts + i * PROVE_PTS_WORDS, h_enc, sk, k, ad, ad_len);
+  prove_finish_item<S>(g, c, s, pk, rr, okp, a.ws.pts + i * PROVE_PTS_WORDS, h_enc, sk, k, ad, ad_len);
   bool ok = a.ws.flags[i] != 0;
   if (a.pedersen) {
     uint32_t b[8], kb[8], cb[8], sb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { b[j] = aux[16 + j]; kb[j] = aux[24 + j]; }
-    fr_mul<SuiteBS>(cb, c, b);
-    fr_add<SuiteBS>(sb, cb, kb);                    // sb = kb + c*b
+    fr_mul<S>(cb, c, b);
+    fr_add<S>(sb, cb, kb);                    // sb = kb + c*b
     if (!ok) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { sb[j] = 0; b[j] = 0; rr[j] = 0; okp[j] = 0; }
@@ -89,15 +92,19 @@ __global__ void __launch_bounds__(BLOCK) k_prove_finish(ProveArgs a) {
   if (a.status) a.status[i] = ok ? ST_OK : ST_INVALID_DATA;
 }
 
+template <class S>
+static void launch_prove_t(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
+  if (ev) (void)hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(k_prove_prepare<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  hipLaunchKernelGGL(k_prove_mul<S>, grid_for(2 * a.n), dim3(BLOCK), 0, st, a);
+  if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
+  hipLaunchKernelGGL(k_prove_finish<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[4], st);
+}
 void launch_ietf_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (a.n == 0) return;
-  if (ev) (void)hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(k_prove_prepare, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  if (ev) (void)hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(k_prove_mul, grid_for(2 * a.n), dim3(BLOCK), 0, st, a);
-  if (ev) (void)hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL(k_prove_finish, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  if (ev) (void)hipEventRecord(ev[3], st);
+  VRF_DISPATCH_SUITE(a.suite, launch_prove_t<S>(a, st, ev));
 }
 
 }  // namespace vrf

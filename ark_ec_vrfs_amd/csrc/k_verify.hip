@@ -5,17 +5,19 @@
 namespace vrf {
 
 // stage 1: one lane per proof.  Decompress pk, H, Gamma; build their GLV window-table pairs.
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_verify_decode(VerifyArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
   uint32_t pk[8], h[8], g[8];
   load32(pk, a.pk, i); load32(h, a.h, i); load32(g, a.gamma, i);
-  bool ok = verify_decode_item<SuiteBS>(a.T, pk, h, g, a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS));
+  bool ok = verify_decode_item<S>(a.T, pk, h, g, a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS));
   a.ws.flags[i] = ok ? 1 : 0;
 }
 
 // stage 1 for affine inputs (x || y, 64 bytes per point): no square roots.  The compressed encodings
 // the challenge hash needs are written to the aux region.
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_verify_decode_affine(VerifyArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
@@ -25,7 +27,7 @@ __global__ void __launch_bounds__(BLOCK) k_verify_decode_affine(VerifyArgs a) {
   const uint32_t* p2 = reinterpret_cast<const uint32_t*>(a.gamma + i * 64);
 #pragma unroll
   for (int j = 0; j < 16; ++j) { xy[0][j] = p0[j]; xy[1][j] = p1[j]; xy[2][j] = p2[j]; }
-  bool ok = verify_decode_affine_item<SuiteBS>(enc, xy, a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS));
+  bool ok = verify_decode_affine_item<S>(enc, xy, a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS));
   uint32_t* aux = a.ws.aux + i * AUX_WORDS;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { aux[j] = enc[0][j]; aux[8 + j] = enc[1][j]; aux[16 + j] = enc[2][j]; }
@@ -33,22 +35,23 @@ __global__ void __launch_bounds__(BLOCK) k_verify_decode_affine(VerifyArgs a) {
 }
 
 // stage 2: one lane per proof and half (U, V in separate launches).  The Straus loops: ~65 % of the work.
-template <int HALF>
+template <class S, int HALF>
 __global__ void __launch_bounds__(BLOCK) k_verify_straus(VerifyArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
   uint32_t c[8], s[8];
   load32(c, a.c, i); load32(s, a.s, i);
   // non-canonical scalars are reported InvalidData by stage 3; keep the comb digits in range here
-  if (!fr_is_canonical<SuiteBS>(c) || !fr_is_canonical<SuiteBS>(s)) {
+  if (!fr_is_canonical<S>(c) || !fr_is_canonical<S>(s)) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { c[j] = 0; s[j] = 0; }
   }
-  verify_straus_item<SuiteBS, HALF>(a.ws.pts + i * (2 * UV_WORDS) + HALF * UV_WORDS, a.T,
+  verify_straus_item<S, HALF>(a.ws.pts + i * (2 * UV_WORDS) + HALF * UV_WORDS, a.T,
                                     a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), c, s);
 }
 
 // stage 3: one lane per proof.  Affine U, V; challenge hash; compare.
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_verify_finish(VerifyArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
@@ -63,22 +66,27 @@ __global__ void __launch_bounds__(BLOCK) k_verify_finish(VerifyArgs a) {
   load32(c, a.c, i); load32(s, a.s, i);
   const uint8_t* ad; uint32_t ad_len;
   bytes_get(a.ad, i, ad, ad_len);
-  uint32_t st = verify_finish_item<SuiteBS>(a.ws.pts + i * (2 * UV_WORDS), pk, h, g, c, s,
+  uint32_t st = verify_finish_item<S>(a.ws.pts + i * (2 * UV_WORDS), pk, h, g, c, s,
                                             a.ws.flags[i] != 0, ad, ad_len);
   a.status[i] = (uint8_t)st;
 }
 
+template <class S>
+static void launch_verify_t(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
+  if (ev) (void)hipEventRecord(ev[0], st);
+  if (a.affine_in) hipLaunchKernelGGL(k_verify_decode_affine<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL(k_verify_decode<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  hipLaunchKernelGGL((k_verify_straus<S, 1>), grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[2], st);
+  hipLaunchKernelGGL((k_verify_straus<S, 0>), grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[3], st);
+  hipLaunchKernelGGL(k_verify_finish<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[4], st);
+}
 void launch_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (a.n == 0) return;
-  if (ev) (void)hipEventRecord(ev[0], st);
-  if (a.affine_in) hipLaunchKernelGGL(k_verify_decode_affine, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  else hipLaunchKernelGGL(k_verify_decode, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  if (ev) (void)hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(k_verify_straus<1>, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  hipLaunchKernelGGL(k_verify_straus<0>, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  if (ev) (void)hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL(k_verify_finish, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  if (ev) (void)hipEventRecord(ev[3], st);
+  VRF_DISPATCH_SUITE(a.suite, launch_verify_t<S>(a, st, ev));
 }
 
 }  // namespace vrf

@@ -38,7 +38,16 @@ struct Workspace {
 constexpr size_t WS_BYTES_PER_ITEM =
     (WS_TABS * WIN_TABLE_WORDS + PROVE_PTS_WORDS + AUX_WORDS) * sizeof(uint32_t) + 1;
 
+// suite ids follow vrfhip_suite (include/vrfhip.h)
+constexpr int SUITE_BS = 1, SUITE_JJ = 2;
+#define VRF_DISPATCH_SUITE(suite, CALL)                 \
+  do {                                                  \
+    if ((suite) == SUITE_JJ) { using S = SuiteJJ; CALL; } \
+    else { using S = SuiteBS; CALL; }                   \
+  } while (0)
+
 struct VerifyArgs {
+  int suite;
   size_t n;
   const uint8_t *pk, *h, *gamma, *c, *s;   // affine_in != 0: pk, h, gamma are 64-byte x || y
   int affine_in;
@@ -49,6 +58,7 @@ struct VerifyArgs {
 };
 
 struct ProveArgs {
+  int suite;
   size_t n;
   const uint8_t* sk;
   BytesView msg;
@@ -63,6 +73,7 @@ struct ProveArgs {
 };
 
 struct PedersenVerifyArgs {
+  int suite;
   size_t n;
   const uint8_t *h, *gamma, *pk_com, *r, *ok, *s, *sb;
   BytesView ad;
@@ -72,16 +83,16 @@ struct PedersenVerifyArgs {
 };
 
 // launchers (each defined next to its kernels)
-void launch_init_tables(uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, hipStream_t st);
-// ev: optional 4 events recorded on `st` before stage 1 and after stages 1, 2, 3 (profiling)
+void launch_init_tables(int suite, uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, hipStream_t st);
+// ev: optional 5 events recorded on `st` before stage 1 and after stages 1, 2a, 2b, 3 (profiling)
 void launch_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
 void launch_ietf_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
 void launch_pedersen_verify(const PedersenVerifyArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
-void launch_hash_to_curve(size_t n, BytesView msg, uint8_t* points, DevTables T, hipStream_t st);
-void launch_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash, hipStream_t st);
-void launch_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk,
+void launch_hash_to_curve(int suite, size_t n, BytesView msg, uint8_t* points, DevTables T, hipStream_t st);
+void launch_output_hash(int suite, size_t n, const uint8_t* gamma, uint8_t* hash, hipStream_t st);
+void launch_secret_from_seed(int suite, size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk,
                              uint8_t* pk, DevTables T, hipStream_t st);
-void launch_point_validate(size_t n, const uint8_t* pts, uint8_t* xy, uint8_t* status,
+void launch_point_validate(int suite, size_t n, const uint8_t* pts, uint8_t* xy, uint8_t* status,
                            uint32_t* tabs, DevTables T, hipStream_t st);
 // MSM: ws must hold msm_workspace_bytes(n, groups) bytes; groups = msm_groups(n, #CUs)
 size_t msm_workspace_bytes(size_t n, int groups);

@@ -31,6 +31,23 @@ struct CurveBS {   // Bandersnatch
   static constexpr uint32_t R_NINV32 = vrfk::BS_R_NINV32;
 };
 
+struct CurveJJ {   // JubJub (a = -1)
+  static constexpr int ANEG = 1;
+  static constexpr int COFACTOR_LOG2 = 3;
+  static VRF_HD FeN d() { return fe_const(vrfk::JJ_D_M); }
+  static VRF_HD FeN aneg_m() { return fe_const(vrfk::ONE_M); }
+  static VRF_HD FeN gx() { return fe_const(vrfk::JJ_GX_M); }
+  static VRF_HD FeN gy() { return fe_const(vrfk::JJ_GY_M); }
+  static VRF_HD FeN bx() { return fe_const(vrfk::JJ_BX_M); }
+  static VRF_HD FeN by() { return fe_const(vrfk::JJ_BY_M); }
+  template <int L, int V>
+  static VRF_HD Fe<L, V> mul_aneg(const Fe<L, V>& a) { return a; }
+  static VRF_HD uint32_t r32(int i) { return vrfk::JJ_R32[i]; }
+  static VRF_HD uint32_t r_r1(int i) { return vrfk::JJ_R_R1[i]; }
+  static VRF_HD uint32_t r_r2(int i) { return vrfk::JJ_R_R2[i]; }
+  static constexpr uint32_t R_NINV32 = vrfk::JJ_R_NINV32;
+};
+
 struct PtE {   // extended projective: x = X/Z, y = Y/Z, T = X*Y/Z
   FeP X, Y, Z, T;
 };

@@ -26,6 +26,8 @@ constexpr int WIN_TABLE_WORDS = WIN_ENTRIES * PTC_WORDS;   // 288 words = 1152 B
 
 // ------------------------------------------------------------------------ suite byte strings
 struct SuiteBS : CurveBS {
+  static constexpr bool HAS_GLV = true;        // Bandersnatch endomorphism (te_psi, glv_decompose_bs)
+  static constexpr bool H2C_ELL2 = true;       // Input::new = Elligator 2 (else try-and-increment)
   static constexpr int SUITE_ID_LEN = 25;
   static VRF_HD uint8_t suite_id(int i) {
     constexpr char s[] = "Bandersnatch_SHA-512_ELL2";
@@ -36,6 +38,20 @@ struct SuiteBS : CurveBS {
     constexpr char s[] = "ECVRF_Bandersnatch_XMD:SHA-512_ELL2_RO_Bandersnatch_SHA-512_ELL2";
     return (uint8_t)s[i];
   }
+};
+
+// JubJub_SHA-512_TAI (suite string, TAI details and blinding base are [RECALL]-level,
+// parity unpinned): a = -1, cofactor 8, try-and-increment hash-to-curve, no GLV.
+struct SuiteJJ : CurveJJ {
+  static constexpr bool HAS_GLV = false;
+  static constexpr bool H2C_ELL2 = false;
+  static constexpr int SUITE_ID_LEN = 18;
+  static VRF_HD uint8_t suite_id(int i) {
+    constexpr char s[] = "JubJub_SHA-512_TAI";
+    return (uint8_t)s[i];
+  }
+  static constexpr int DST_LEN = 1;
+  static VRF_HD uint8_t dst(int) { return 0; }
 };
 
 template <class S>
@@ -124,6 +140,10 @@ VRF_HD void build_win_table_from(uint32_t* tab, PtE acc) {
 template <class C>
 VRF_HD void build_glv_tables(uint32_t* tab, const FeP& x, const FeP& y) {
   PtE p = te_from_affine(x, y);
+  if constexpr (!C::HAS_GLV) {
+    build_win_table_from<C>(tab, p);            // suites without an endomorphism: one 253-bit table
+    return;
+  }
   PtE q = te_psi<C>(p);
 #pragma unroll 1
   for (int t = 0; t < 2; ++t) {
@@ -221,7 +241,7 @@ VRF_HD PtE straus4(const Straus4& q) {
 
 // k*P for one window table (prove: Gamma = sk*H, kH)
 template <class C>
-VRF_HD PtE win_mul(const uint32_t* tab, const uint32_t rec[8]) {
+VRF_HD PtE win_mul(const uint32_t* tab, const uint32_t rec[8], bool negate = false) {
   PtE acc = te_identity();
 #pragma unroll 1
   for (int w = 63; w >= 0; --w) {
@@ -230,7 +250,7 @@ VRF_HD PtE win_mul(const uint32_t* tab, const uint32_t rec[8]) {
       for (int j = 0; j < 4; ++j) acc = te_dbl<C>(acc, j == 3);
     }
     int d = scalar_digit4(rec, w);
-    acc = te_add_cached<C>(acc, win_lookup(tab, d), d < 0);
+    acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != negate);
   }
   return acc;
 }
@@ -429,6 +449,23 @@ VRF_HD bool verify_decode_affine_item(uint32_t enc_out[3][8], const uint32_t (&x
 template <class S, int HALF>
 VRF_HD void verify_straus_item(uint32_t* out_uv, const DevTables& T, const uint32_t* tabs,
                                const uint32_t c[8], const uint32_t s[8]) {
+  if constexpr (!S::HAS_GLV) {
+    // plain 253-bit Straus: U = comb(G, s) - c*Y ; V = s*H - c*Gamma (tables at slots 0, 2, 4)
+    uint32_t recs[8], recc[8];
+    scalar_recode_signed4(recs, s);
+    scalar_recode_signed4(recc, c);
+    PtE r;
+    if (HALF == 0) {
+      r = win_mul<S>(tabs, recc, true);
+      r = comb_add<S>(r, T.g_comb, s);
+    } else {
+      r = straus2<S>(tabs + 2 * WIN_TABLE_WORDS, recs, tabs + 4 * WIN_TABLE_WORDS, recc, true);
+    }
+    fe_store(out_uv, r.X);
+    fe_store(out_uv + NL, r.Y);
+    fe_store(out_uv + 2 * NL, r.Z);
+    return;
+  } else {
   Straus4 q;
   GlvHalf h[4];
   glv_decompose_bs(h[0], h[1], c);
@@ -460,6 +497,7 @@ VRF_HD void verify_straus_item(uint32_t* out_uv, const DevTables& T, const uint3
   fe_store(out_uv, r.X);
   fe_store(out_uv + NL, r.Y);
   fe_store(out_uv + 2 * NL, r.Z);
+  }
 }
 
 template <class S>
@@ -619,6 +657,49 @@ VRF_HD PtE hash_to_curve_ell2(const uint8_t* msg, uint32_t msg_len, const SqrtTa
   return acc;
 }
 
+// [ref src/lib.rs:14 `utils::hash_to_curve_tai_rfc_9381`]  SURVEY.md A.6 (unpinned): for ctr = 0..255:
+// h = SHA512(suite_id || 0x01 || data || ctr || 0x00); decode h[0..32] as a point; clear the
+// cofactor; first non-identity result wins.  Lanes iterate until they succeed (about two trips).
+template <class S>
+VRF_HD PtE hash_to_curve_tai(const uint8_t* msg, uint32_t msg_len, const SqrtTables& T) {
+  PtE res = te_identity();
+  bool done = false;
+#pragma unroll 1
+  for (uint32_t ctr = 0; ctr < 256 && !done; ++ctr) {
+    Sha512 h;
+    sha512_init(h);
+    put_suite_id<S>(h);
+    sha512_put_byte(h, 0x01);
+    sha512_put_bytes(h, msg, msg_len);
+    sha512_put_byte(h, (uint8_t)ctr);
+    sha512_put_byte(h, 0x00);
+    sha512_final(h);
+    uint32_t enc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) enc[j] = sha512_word_mem(h, j);
+    DecodeA a = decode_phase_a<S>(enc);
+    FeN di = fe_inv(a.den);
+    Fe<1, 4> x;
+    bool ok = decode_phase_b<S>(x, a, di, T);
+    PtE p = te_from_affine(x, a.y);
+#pragma unroll 1
+    for (int i = 0; i < S::COFACTOR_LOG2; ++i) p = te_dbl<S>(p, true);
+    bool is_id = fe_is_zero(p.X) && fe_eq(p.Y, p.Z);
+    if (ok && !is_id) {
+      res = p;
+      done = true;
+    }
+  }
+  return res;
+}
+
+// [ref src/lib.rs:15-16 `Input::new` / `Suite::data_to_point`]
+template <class S>
+VRF_HD PtE data_to_point(const uint8_t* msg, uint32_t msg_len, const SqrtTables& T) {
+  if constexpr (S::H2C_ELL2) return hash_to_curve_ell2<S>(msg, msg_len, T);
+  else return hash_to_curve_tai<S>(msg, msg_len, T);
+}
+
 // ------------------------------------------------------------------------ nonce
 // [ref src/lib.rs:14,16 `Suite::nonce` / utils::nonce_rfc_8032]  SURVEY.md A.4:
 // k = int_le(SHA512(SHA512(sk_le32)[32..64] || enc(H))) mod r
@@ -689,7 +770,7 @@ VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, 
     x = fe_mul(xx, fe_one());
     y = a.y;
   } else {
-    PtE hp = hash_to_curve_ell2<S>(msg, msg_len, T.sq);
+    PtE hp = data_to_point<S>(msg, msg_len, T.sq);
     te_to_affine(x, y, hp);
   }
   te_encode_affine(h_enc, x, y);
@@ -702,20 +783,27 @@ VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, 
 template <class S>
 VRF_HD void prove_mul_item(uint32_t* out /*2*UV_WORDS*/, const DevTables& T, const uint32_t* tab,
                            const uint32_t scalar[8], const uint32_t* scalar2) {
-  // scalar * H by GLV: k = k1 + k2*lambda over the table pair {H, psi H}
-  Straus4 q;
-  GlvHalf h[2];
-  glv_decompose_bs(h[0], h[1], scalar);
+  PtE w;
+  if constexpr (S::HAS_GLV) {
+    // scalar * H by GLV: k = k1 + k2*lambda over the table pair {H, psi H}
+    Straus4 q;
+    GlvHalf h[2];
+    glv_decompose_bs(h[0], h[1], scalar);
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    scalar_recode_signed4_128(q.rec[t], h[t].mag);
-    q.neg[t] = h[t].neg;
+    for (int t = 0; t < 2; ++t) {
+      scalar_recode_signed4_128(q.rec[t], h[t].mag);
+      q.neg[t] = h[t].neg;
+    }
+    q.tab[0] = tab; q.tab[1] = tab + WIN_TABLE_WORDS; q.tab[2] = tab; q.tab[3] = tab;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { q.rec[2][i] = 0; q.rec[3][i] = 0; }
+    q.neg[2] = false; q.neg[3] = false;
+    w = straus4<S, 2>(q);
+  } else {
+    uint32_t rec[8];
+    scalar_recode_signed4(rec, scalar);
+    w = win_mul<S>(tab, rec);
   }
-  q.tab[0] = tab; q.tab[1] = tab + WIN_TABLE_WORDS; q.tab[2] = tab; q.tab[3] = tab;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { q.rec[2][i] = 0; q.rec[3][i] = 0; }
-  q.neg[2] = false; q.neg[3] = false;
-  PtE w = straus4<S, 2>(q);
   fe_store(out, w.X); fe_store(out + NL, w.Y); fe_store(out + 2 * NL, w.Z);
   PtE c;
   if (scalar2) {
@@ -843,6 +931,23 @@ template <class S, int HALF>
 VRF_HD void pedersen_verify_straus_item(uint32_t* out_uv, const DevTables& T, const uint32_t* tabs,
                                         const uint32_t c[8], const uint32_t s[8],
                                         const uint32_t sb[8]) {
+  if constexpr (!S::HAS_GLV) {
+    uint32_t recs[8], recc[8];
+    scalar_recode_signed4(recs, s);
+    scalar_recode_signed4(recc, c);
+    PtE r;
+    if (HALF == 0) {
+      r = straus2<S>(tabs, recs, tabs + 2 * WIN_TABLE_WORDS, recc, true);      // s*H - c*Gamma
+    } else {
+      r = win_mul<S>(tabs + 4 * WIN_TABLE_WORDS, recc, true);                   // -c*pk_com
+      r = comb_add<S>(r, T.g_comb, s);
+      r = comb_add<S>(r, T.b_comb, sb);
+    }
+    fe_store(out_uv, r.X);
+    fe_store(out_uv + NL, r.Y);
+    fe_store(out_uv + 2 * NL, r.Z);
+    return;
+  } else {
   Straus4 q;
   GlvHalf h[4];
   glv_decompose_bs(h[0], h[1], c);
@@ -875,6 +980,7 @@ VRF_HD void pedersen_verify_straus_item(uint32_t* out_uv, const DevTables& T, co
   fe_store(out_uv, r.X);
   fe_store(out_uv + NL, r.Y);
   fe_store(out_uv + 2 * NL, r.Z);
+  }
 }
 
 // projective P (X, Y, Z) equals affine (x, y)

@@ -8,7 +8,7 @@ ad = "").  The proofs themselves are produced by the GPU prove path before the t
 N > 1: one process per GPU (torch.distributed / RCCL); every rank verifies its own 2^20 items
 (weak scaling), the only collective is the gather of the status bytes.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_verify_straus) against
+Prints ONE JSON line (rank 0).  `roofline` prices the longest kernel (k_verify_straus<1>) against
 HBM as the contract asks -- the path is VALU-integer bound, so `valu` gives the meaningful
 ceiling: executed vector instructions per second against the measured v_mad_u64_u32 issue peak.
 `cpu_baseline` times the plain-C oracle (oracle/c, kind "port") on this box's host cores.
@@ -127,7 +127,7 @@ def main():
     if rank == 0:
         total_items = world * n * args.steps
         value = total_items / elapsed
-        straus_s = stage_ms[1] / max(groups, 1) / 1e3          # average launch duration of k_verify_straus
+        straus_s = stage_ms[1] / max(groups, 1) / 1e3          # average launch duration of k_verify_straus<1>
         achieved_gbs = BYTES_PER_VERIFY * n / straus_s / 1e9
         # measured constants of the same command line (rocprofv3 --pmc passes, see profiles/)
         traffic = None
@@ -150,12 +150,12 @@ def main():
             "config": {"workload": "IETF ECVRF verify, Bandersnatch_SHA-512_ELL2, batch 2^%d per GPU, compressed "
                                    "points (161 B/verify), ad=\"\" (BASELINE.json configs[2])" % args.log2_batch,
                        "global_batch": world * n, "parallelism": "items sharded x%d, result gather only" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_verify_straus", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_verify_straus<1> (V = s*H - c*Gamma, the longest kernel)", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": straus_s * 1e3, "launches_timed": groups},
             "valu": valu,
-            "stage_ms_per_step": {"decode": stage_ms[0] / max(groups, 1), "straus": stage_ms[1] / max(groups, 1),
-                                  "finish": stage_ms[2] / max(groups, 1)},
+            "stage_ms_per_step": {"decode": stage_ms[0] / max(groups, 1), "straus_v": stage_ms[1] / max(groups, 1),
+                                  "straus_u": stage_ms[2] / max(groups, 1), "finish": stage_ms[3] / max(groups, 1)},
             "proofs_per_sec": n / prove_s,
         }
         if not args.no_cpu_baseline and world == 1:

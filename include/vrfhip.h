@@ -39,7 +39,11 @@ extern "C" {
 #define VRFHIP_HASH_BYTES 64
 
 typedef enum vrfhip_suite {
-  VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2 = 1 /* `suites::bandersnatch` (src/lib.rs:14) */
+  VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2 = 1, /* `suites::bandersnatch` (src/lib.rs:14) */
+  /* `suites::jubjub`: a = -1, cofactor 8, try-and-increment hash-to-curve.  Suite string, TAI
+   * details and the Pedersen blinding base are recollections: parity unpinned;
+   * the blinding base is the TAI hash of "vrfhip-jubjub-blinding-base". */
+  VRFHIP_SUITE_JUBJUB_SHA512_TAI = 2
 } vrfhip_suite;
 
 typedef enum vrfhip_status {
@@ -82,11 +86,12 @@ int32_t vrfhip_ctx_reserve(vrfhip_ctx* ctx, size_t max_items);
 size_t vrfhip_ctx_workspace_bytes(const vrfhip_ctx* ctx);
 
 /* Per-stage device timing.  While enabled, every prove / verify launch group records hipEvents
- * on its launch stream around its three kernels (decode|prepare, straus|mul, finish).
+ * on its launch stream around its kernels: verify = {decode, straus V, straus U, finish},
+ * Pedersen verify = {decode, straus A, straus B, finish}, prove = {prepare, mul, (empty), finish}.
  * vrfhip_ctx_profile_read waits for the recorded events, returns the summed milliseconds per
  * stage and the number of launch groups, and clears the record. */
 int32_t vrfhip_ctx_profile(vrfhip_ctx* ctx, int32_t enable);
-int32_t vrfhip_ctx_profile_read(vrfhip_ctx* ctx, double stage_ms[3], uint64_t* launches);
+int32_t vrfhip_ctx_profile_read(vrfhip_ctx* ctx, double stage_ms[4], uint64_t* launches);
 
 /* IETF VRF ---------------------------------------------------------------------------- */
 

@@ -29,8 +29,25 @@ typedef unsigned __int128 u128;
 typedef struct { uint64_t v[4]; } fp;          /* Montgomery form */
 typedef struct { uint64_t m[4]; uint64_t ninv; uint64_t r2[4]; uint64_t one[4]; } field;
 
-static field FQ, FR;
-static fp BS_D_M, BS_A_M, BS_GX_M, BS_GY_M, BS_BX_M, BS_BY_M, ELL_J_M, ELL_K_M, ELL_Z_M, ELL_JK_M, ELL_K2I_M;
+/* Suite descriptor [ref src/lib.rs:16 `Suite`]: Bandersnatch_SHA-512_ELL2 (pinned by the KATs) and
+ * JubJub_SHA-512_TAI (recollection only: parity unpinned). */
+typedef struct {
+  field fr;                      /* scalar field */
+  fp d, a, gx, gy, bx, by;       /* curve a x^2 + y^2 = 1 + d x^2 y^2, generator, blinding base */
+  const char* suite_id; size_t suite_id_len;
+  int h2c_tai, cofactor_log2;
+} suite_t;
+static suite_t SUITE_BS, SUITE_JJ;
+static suite_t* S_ = &SUITE_BS;   /* current suite (tests select it with oracle_set_suite) */
+#define FR (S_->fr)
+#define BS_D_M (S_->d)
+#define BS_A_M (S_->a)
+#define BS_GX_M (S_->gx)
+#define BS_GY_M (S_->gy)
+#define BS_BX_M (S_->bx)
+#define BS_BY_M (S_->by)
+static field FQ;
+static fp ELL_J_M, ELL_K_M, ELL_Z_M, ELL_JK_M, ELL_K2I_M;
 static fp TS_C_M;                 /* 5^t, generator of the 2^32-torsion (Tonelli-Shanks) */
 static uint64_t TS_T[4], TS_E[4];  /* t = (q-1)/2^32, (t+1)/2 */
 static int g_init_done = 0;
@@ -318,15 +335,23 @@ static void r_muladd(uint64_t out[4], const uint64_t a[4], const uint64_t b[4], 
 }
 
 /* ------------------------------------------------------------------ suite glue */
-static const char SUITE_ID[] = "Bandersnatch_SHA-512_ELL2";
+#define SUITE_ID (S_->suite_id)
+#define SUITE_ID_LEN (S_->suite_id_len)
 static const char H2C_DST[] = "ECVRF_Bandersnatch_XMD:SHA-512_ELL2_RO_Bandersnatch_SHA-512_ELL2";
 
 static void do_init(void) {
-  field_init(&FQ, P_Q); field_init(&FR, P_R_ORDER);
-  q_from_int(&BS_D_M, P_BS_D);
-  fp five; q_from_u64(&five, 5); q_neg(&BS_A_M, &five);
-  q_from_int(&BS_GX_M, P_BS_GX); q_from_int(&BS_GY_M, P_BS_GY);
-  q_from_int(&BS_BX_M, P_BS_BX); q_from_int(&BS_BY_M, P_BS_BY);
+  field_init(&FQ, P_Q);
+  fp five, fone; q_from_u64(&five, 5); q_from_u64(&fone, 1);
+  field_init(&SUITE_BS.fr, P_R_ORDER);
+  q_from_int(&SUITE_BS.d, P_BS_D); q_neg(&SUITE_BS.a, &five);
+  q_from_int(&SUITE_BS.gx, P_BS_GX); q_from_int(&SUITE_BS.gy, P_BS_GY);
+  q_from_int(&SUITE_BS.bx, P_BS_BX); q_from_int(&SUITE_BS.by, P_BS_BY);
+  SUITE_BS.suite_id = "Bandersnatch_SHA-512_ELL2"; SUITE_BS.suite_id_len = 25; SUITE_BS.h2c_tai = 0; SUITE_BS.cofactor_log2 = 2;
+  field_init(&SUITE_JJ.fr, P_JJ_R_ORDER);
+  q_from_int(&SUITE_JJ.d, P_JJ_D); q_neg(&SUITE_JJ.a, &fone);
+  q_from_int(&SUITE_JJ.gx, P_JJ_GX); q_from_int(&SUITE_JJ.gy, P_JJ_GY);
+  q_from_int(&SUITE_JJ.bx, P_JJ_BX); q_from_int(&SUITE_JJ.by, P_JJ_BY);
+  SUITE_JJ.suite_id = "JubJub_SHA-512_TAI"; SUITE_JJ.suite_id_len = 18; SUITE_JJ.h2c_tai = 1; SUITE_JJ.cofactor_log2 = 3;
   q_from_int(&ELL_J_M, P_BS_J); q_from_int(&ELL_K_M, P_BS_K); q_from_u64(&ELL_Z_M, 5);
   fp ki; q_inv(&ki, &ELL_K_M); q_mul(&ELL_JK_M, &ELL_J_M, &ki); q_sqr(&ELL_K2I_M, &ki);
   uint64_t one[4] = {1, 0, 0, 0};
@@ -367,7 +392,28 @@ static void elligator2(pt* out, const fp* u) {
   q_inv(&ti, &sp1); q_mul(&w, &sm1, &ti);
   pt_from_affine(out, &v, &w);
 }
+static int point_decode(fp* x, fp* y, const uint8_t in[32]);
+static void pt_double(pt* r, const pt* p);
+static int pt_is_identity(const pt* p);
+/* [ref src/lib.rs:14 `utils::hash_to_curve_tai_rfc_9381`] SURVEY.md A.6 (unpinned) */
+static int hash_to_curve_tai(pt* out, const uint8_t* msg, size_t len) {
+  for (int ctr = 0; ctr < 256; ++ctr) {
+    uint8_t h[64], one = 1, cb = (uint8_t)ctr, zero = 0; sha512_ctx c;
+    sha512_init(&c); sha512_update(&c, SUITE_ID, SUITE_ID_LEN); sha512_update(&c, &one, 1);
+    sha512_update(&c, msg, len); sha512_update(&c, &cb, 1); sha512_update(&c, &zero, 1); sha512_final(&c, h);
+    fp x, y;
+    if (!point_decode(&x, &y, h)) continue;
+    pt p; pt_from_affine(&p, &x, &y);
+    for (int i = 0; i < S_->cofactor_log2; ++i) pt_double(&p, &p);
+    if (pt_is_identity(&p)) continue;
+    *out = p;
+    return 1;
+  }
+  pt_identity(out);
+  return 0;
+}
 static void hash_to_curve(pt* out, const uint8_t* msg, size_t len) {
+  if (S_->h2c_tai) { hash_to_curve_tai(out, msg, len); return; }
   uint8_t dstp[65]; memcpy(dstp, H2C_DST, 64); dstp[64] = 64;
   uint8_t zpad[48] = {0}, lib[3] = {0x00, 0x60, 0x00}, b0[64], b1[64], b2[64], x[64];
   sha512_ctx c;
@@ -399,13 +445,19 @@ static void nonce(uint64_t k[4], const uint8_t sk_le[32], const uint8_t h_enc[32
 /* [ref src/lib.rs:14,16 `Suite::challenge`] SURVEY.md A.4 */
 static void challenge(uint64_t c_out[4], const uint8_t pts[5][32], const uint8_t* ad, size_t ad_len) {
   uint8_t h[64], two = 2, zero = 0; sha512_ctx c;
-  sha512_init(&c); sha512_update(&c, SUITE_ID, 25); sha512_update(&c, &two, 1);
+  sha512_init(&c); sha512_update(&c, SUITE_ID, SUITE_ID_LEN); sha512_update(&c, &two, 1);
   for (int i = 0; i < 5; ++i) sha512_update(&c, pts[i], 32);
   sha512_update(&c, ad, ad_len); sha512_update(&c, &zero, 1); sha512_final(&c, h);
   r_from_bytes_wide(c_out, h, 32, 1);
 }
 
 /* ------------------------------------------------------------------ exported API */
+/* 1 = Bandersnatch_SHA-512_ELL2 (default), 2 = JubJub_SHA-512_TAI.  Process-global: tests only. */
+int oracle_set_suite(int id) {
+  ensure_init();
+  if (id == 1) S_ = &SUITE_BS; else if (id == 2) S_ = &SUITE_JJ; else return -1;
+  return 0;
+}
 int oracle_secret_from_seed(const uint8_t* seed, size_t len, uint8_t sk_out[32]) {
   ensure_init();
   uint8_t h[64]; sha512_ctx c; sha512_init(&c); sha512_update(&c, seed, len); sha512_final(&c, h);
@@ -428,7 +480,7 @@ int oracle_hash_to_curve(const uint8_t* msg, size_t len, uint8_t out[32]) {
 int oracle_output_hash(const uint8_t gamma[32], uint8_t out[64]) {
   ensure_init();
   uint8_t three = 3, zero = 0; sha512_ctx c;
-  sha512_init(&c); sha512_update(&c, SUITE_ID, 25); sha512_update(&c, &three, 1); sha512_update(&c, gamma, 32);
+  sha512_init(&c); sha512_update(&c, SUITE_ID, SUITE_ID_LEN); sha512_update(&c, &three, 1); sha512_update(&c, gamma, 32);
   sha512_update(&c, &zero, 1); sha512_final(&c, out);
   return 0;
 }
@@ -496,7 +548,7 @@ int oracle_ietf_verify(const uint8_t pk[32], const uint8_t h[32], const uint8_t 
 /* [ref src/lib.rs:14 `pedersen::PedersenSuite::blinding`] SURVEY.md A.5 */
 static void blinding(uint64_t b[4], const uint8_t sk_le[32], const uint8_t h_enc[32], const uint8_t* ad, size_t ad_len) {
   uint8_t h[64], cc = 0xCC, zero = 0; sha512_ctx c;
-  sha512_init(&c); sha512_update(&c, SUITE_ID, 25); sha512_update(&c, &cc, 1); sha512_update(&c, sk_le, 32);
+  sha512_init(&c); sha512_update(&c, SUITE_ID, SUITE_ID_LEN); sha512_update(&c, &cc, 1); sha512_update(&c, sk_le, 32);
   sha512_update(&c, h_enc, 32); sha512_update(&c, ad, ad_len); sha512_update(&c, &zero, 1); sha512_final(&c, h);
   r_from_bytes_wide(b, h, 64, 1);
 }

@@ -47,6 +47,12 @@ def load() -> ctypes.CDLL:
     return _lib
 
 
+def set_suite(suite_id: int) -> None:
+    """1 = Bandersnatch_SHA-512_ELL2 (default), 2 = JubJub_SHA-512_TAI (process-global selection)."""
+    if load().oracle_set_suite(int(suite_id)) != 0:
+        raise ValueError("unknown suite")
+
+
 def _a(x):
     return np.ascontiguousarray(x, dtype=np.uint8)
 

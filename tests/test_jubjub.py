@@ -1,0 +1,162 @@
+"""JubJub suite (BASELINE.json config 4 curve; SURVEY.md A.6: suite string, TAI details and blinding
+base are recollections, parity UNPINNED).  What is checked: the two oracles agree, the device source
+(host build) equals them byte for byte, algebraic round trips, and (gpu) the kernels equal the C
+oracle on thousands of items."""
+import ctypes
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import vrf_oracle as o
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+NCPU = min(16, os.cpu_count() or 1)
+
+
+@pytest.fixture(scope="module")
+def J():
+    return o.jubjub_params()
+
+
+@pytest.fixture()
+def c_jj():
+    co.set_suite(2)
+    yield co
+    co.set_suite(1)
+
+
+def test_jubjub_parameters(J):
+    assert o.te_in_prime_subgroup(J, (J.gx, J.gy)) and o.te_in_prime_subgroup(J, (J.bx, J.by))
+    assert (J.bx, J.by) != (J.gx, J.gy) and J.cofactor == 8
+
+
+def test_oracles_agree_on_jubjub(J, c_jj):
+    for i in range(4):
+        sk = o.secret_from_seed(J, o.synth_seed(i)); msg = o.synth_msg(i); ad = b"jj" * i
+        H = o.data_to_point(J, msg)
+        assert c_jj.hash_to_curve(msg) == o.point_encode(J, H)
+        g, c, s = o.ietf_prove(J, sk, H, ad)
+        skb = np.frombuffer(o.scalar_encode(sk), np.uint8)
+        r = c_jj.ietf_prove_batch(skb, msgs=np.frombuffer(msg, np.uint8).reshape(1, -1), ad=ad)
+        assert (r["output"][0].tobytes(), r["c"][0].tobytes(), r["s"][0].tobytes()) == \
+               (o.point_encode(J, g), o.scalar_encode(c), o.scalar_encode(s))
+        assert o.ietf_verify(J, o.public_from_secret(J, sk), H, g, ad, c, s)
+        assert c_jj.ietf_verify_batch(r["pk"], r["input"], r["output"], r["c"], r["s"], ad)[0] == 0
+        gm, (pc, R, Ok, ss, sb), b = o.pedersen_prove(J, sk, H, ad)
+        pr = c_jj.pedersen_prove_batch(skb, msgs=np.frombuffer(msg, np.uint8).reshape(1, -1), ad=ad)
+        assert [pr[k][0].tobytes() for k in ("pk_com", "r", "ok", "s", "sb", "blinding")] == \
+               [o.point_encode(J, pc), o.point_encode(J, R), o.point_encode(J, Ok), o.scalar_encode(ss),
+                o.scalar_encode(sb), o.scalar_encode(b)]
+        assert o.pedersen_verify(J, H, gm, ad, (pc, R, Ok, ss, sb))
+
+
+@pytest.fixture(scope="module")
+def hj():
+    so = os.path.join(HERE, "libhostsim_jj.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", HERE, "libhostsim_jj.so"], check=True, stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(so)
+    lib.hj_init()
+    return lib
+
+
+def test_hostsim_jubjub_equals_oracle(hj, J):
+    rnd = random.Random(4)
+    buf = ctypes.create_string_buffer(32)
+    out = ctypes.create_string_buffer(224)
+    for i in range(4):
+        sk = o.secret_from_seed(J, o.synth_seed(100 + i)); msg = o.synth_msg(100 + i)
+        ad = bytes(rnd.getrandbits(8) for _ in range([0, 5, 70, 130][i]))
+        H = o.data_to_point(J, msg)
+        hj.hj_hash_to_curve(msg, len(msg), buf)
+        assert buf.raw == o.point_encode(J, H)
+        g, c, s = o.ietf_prove(J, sk, H, ad)
+        pk = o.public_from_secret(J, sk)
+        assert hj.hj_prove(0, o.scalar_encode(sk), msg, len(msg), ad, len(ad), out) == 1
+        assert out.raw[:160] == b"".join([o.point_encode(J, g), o.scalar_encode(c), o.scalar_encode(s),
+                                          o.point_encode(J, pk), o.point_encode(J, H)])
+        enc = [o.point_encode(J, pk), o.point_encode(J, H), o.point_encode(J, g), o.scalar_encode(c), o.scalar_encode(s)]
+        assert hj.hj_ietf_verify(*enc, ad, len(ad)) == 0
+        assert hj.hj_ietf_verify(*enc, ad + b"x", len(ad) + 1) == 1
+        bad = list(enc); bad[4] = J.r.to_bytes(32, "little")
+        assert hj.hj_ietf_verify(*bad, ad, len(ad)) == 2
+        gm, (pc, R, Ok, ss, sb), b = o.pedersen_prove(J, sk, H, ad)
+        assert hj.hj_prove(1, o.scalar_encode(sk), msg, len(msg), ad, len(ad), out) == 1
+        exp = b"".join([o.point_encode(J, gm), o.point_encode(J, pc), o.point_encode(J, R), o.point_encode(J, Ok),
+                        o.scalar_encode(ss), o.scalar_encode(sb), o.scalar_encode(b)])
+        assert out.raw == exp
+        assert hj.hj_pedersen_verify(o.point_encode(J, H), o.point_encode(J, gm), out.raw[32:192], ad, len(ad)) == 0
+        tam = bytearray(out.raw[32:192]); tam[140] ^= 1
+        assert hj.hj_pedersen_verify(o.point_encode(J, H), o.point_encode(J, gm), bytes(tam), ad, len(ad)) == 1
+
+
+@pytest.fixture(scope="module")
+def ctx_jj():
+    from ark_ec_vrfs_amd import Context, JubJubSha512Tai
+    c = Context(0, suite=JubJubSha512Tai)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ad", [b"", bytes(range(70))])
+def test_gpu_jubjub_matches_c_oracle(ctx_jj, c_jj, synth, ad):
+    n = 2048
+    seeds = np.arange(n, dtype=np.uint64).view(np.uint8).reshape(n, 8)
+    sk, pk = ctx_jj.secret_from_seed_batch(seeds)
+    for i in range(0, n, 97):
+        assert sk[i].tobytes() == c_jj.secret_from_seed(seeds[i].tobytes())
+        assert pk[i].tobytes() == c_jj.public_from_secret(sk[i].tobytes())
+    _, msg = synth(n, start=0)
+    ref = c_jj.ietf_prove_batch(sk, msgs=msg, ad=ad, threads=NCPU)
+    got = ctx_jj.ietf_prove_batch(sk, msgs=msg, ad=ad)
+    for k in ("output", "c", "s", "pk", "input"):
+        assert (got[k] == ref[k]).all(), k
+    s_bad = ref["s"].copy(); s_bad[::7, 2] ^= 1
+    want = c_jj.ietf_verify_batch(ref["pk"], ref["input"], ref["output"], ref["c"], s_bad, ad, threads=NCPU)
+    st = ctx_jj.ietf_verify_batch(ref["pk"], ref["input"], ref["output"], ref["c"], s_bad, ad=ad)
+    assert (st == want).all() and (want[::7] == 1).all() and want.sum() == len(want[::7])
+    # Pedersen (config 4 shape)
+    pref = c_jj.pedersen_prove_batch(sk, msgs=msg, ad=ad, threads=NCPU)
+    pgot = ctx_jj.pedersen_prove_batch(sk, msgs=msg, ad=ad)
+    for k in ("output", "pk_com", "r", "ok", "s", "sb", "blinding"):
+        assert (pgot[k] == pref[k]).all(), k
+    sb_bad = pref["sb"].copy(); sb_bad[::5, 0] ^= 2
+    want = c_jj.pedersen_verify_batch(pref["input"], pref["output"], pref["pk_com"], pref["r"], pref["ok"], pref["s"], sb_bad, ad, threads=NCPU)
+    st = ctx_jj.pedersen_verify_batch(pref["input"], pref["output"], pref["pk_com"], pref["r"], pref["ok"], pref["s"], sb_bad, ad=ad)
+    assert (st == want).all() and (want[::5] == 1).all()
+    # point validation: hashed points are in the subgroup, random encodings mostly are not
+    assert (ctx_jj.point_validate_batch(ref["input"][:64]) == 0).all()
+
+
+@pytest.mark.gpu
+def test_gpu_jubjub_pedersen_2_20_round_trip(ctx_jj):
+    """BASELINE.json config 4 size on one GPU: 2^20 Pedersen proofs verify; tampered ones do not."""
+    import torch
+    from ark_ec_vrfs_amd import _lib
+    n = 1 << 20
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    st0 = torch.cuda.current_stream().cuda_stream
+    seeds = torch.arange(n, dtype=torch.int64, device=dev).view(torch.uint8).reshape(n, 8)
+    sk = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    _lib.check(lib.vrfhip_secret_from_seed_batch_dev(ctx_jj.handle, n, seeds.data_ptr(), 8, sk.data_ptr(), None, st0), "seed")
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    msg = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    mk = lambda: torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    out, pc, r, ok, s, sb, hh = mk(), mk(), mk(), mk(), mk(), mk(), mk()
+    st = torch.empty(n, dtype=torch.uint8, device=dev)
+    ctx_jj.pedersen_prove_batch_dev(sk, msg, 32, out, pc, r, ok, s, sb, None, hh, st)
+    torch.cuda.synchronize()
+    assert int(st.sum()) == 0
+    ctx_jj.pedersen_verify_batch_dev(hh, out, pc, r, ok, s, sb, st)
+    torch.cuda.synchronize()
+    assert int(st.sum()) == 0
+    s2 = s.clone(); s2[::4096, 3] ^= 1
+    ctx_jj.pedersen_verify_batch_dev(hh, out, pc, r, ok, s2, sb, st)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nonzero(st).flatten(), torch.arange(0, n, 4096, device=dev)) and int(st.max()) == 1
