@@ -209,6 +209,22 @@ def secondary(ctx, lib, dev, sk, msg, pk, hh, gamma, c, s):
     assert int(pst.sum()) == 0
     res["pedersen_2^%d" % (n.bit_length() - 1)] = {"proofs_per_s": n / tp, "verifies_per_s": n / tv,
                                                    "bytes_per_proof": 288, "bytes_per_verify": 225}
+    # config 3 as BASELINE.json words it: Pedersen on JubJub (suite parity unpinned)
+    try:
+        from ark_ec_vrfs_amd import Context, JubJubSha512Tai
+        cj = Context(dev.index or 0, suite=JubJubSha512Tai)
+        skj = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+        seeds = torch.arange(n, dtype=torch.int64, device=dev).view(torch.uint8).reshape(n, 8)
+        _lib.check(lib.vrfhip_secret_from_seed_batch_dev(cj.handle, n, seeds.data_ptr(), 8, skj.data_ptr(), None, stream), "seed")
+        hj = mk()
+        tp = _time(lambda: cj.pedersen_prove_batch_dev(skj, msg, 32, g, pc, r, ok, ss, sb, None, hj, pst))
+        tv = _time(lambda: cj.pedersen_verify_batch_dev(hj, g, pc, r, ok, ss, sb, pst))
+        assert int(pst.sum()) == 0
+        res["pedersen_jubjub_2^%d" % (n.bit_length() - 1)] = {"proofs_per_s": n / tp, "verifies_per_s": n / tv,
+                                                              "bytes_per_proof": 288, "bytes_per_verify": 225}
+        cj.close()
+    except Exception as e:
+        res["pedersen_jubjub"] = {"error": repr(e)}
     # MSM over the public keys with the secrets as scalars (96 B/term)
     out = torch.empty(32, dtype=torch.uint8, device=dev); mst = torch.empty(1, dtype=torch.uint8, device=dev)
     t = _time(lambda: ctx.msm_dev(xy[0], sk, out, None, mst))
