@@ -62,11 +62,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # rehearsal hook: VRFHIP_BENCH_BACKEND=gloo lets several ranks share the GPUs that exist
+    # (rank -> device modulo device_count, status gather through host memory)
+    backend = os.environ.get("VRFHIP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n = 1 << args.log2_batch
     lo = rank * n                                  # weak scaling: rank g owns items [g*n, (g+1)*n)
@@ -97,7 +105,9 @@ def main():
     def step():
         ctx.ietf_verify_batch_dev(pk, hh, gamma, c, s, status)
         if world > 1:
-            return gather_results(status, world * n, rank, world)   # RCCL: result gather only
+            if backend == "nccl":
+                return gather_results(status, world * n, rank, world)   # RCCL: result gather only
+            return gather_results(status.cpu(), world * n, rank, world).to(dev)
         return status
 
     for _ in range(args.warmup):
@@ -118,7 +128,7 @@ def main():
     ctx.profile(False)
     stage_ms, groups = ctx.profile_read()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_bad = int((full != 0).sum())
