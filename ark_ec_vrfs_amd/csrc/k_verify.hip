@@ -5,14 +5,12 @@
 namespace vrf {
 
 // stage 1: one lane per proof.  Decompress pk, H, Gamma; build their GLV window-table pairs.
+// VERIFY_K proofs per lane share one inversion (3K decompression denominators).
 template <class S>
 __global__ void __launch_bounds__(BLOCK) k_verify_decode(VerifyArgs a) {
-  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= a.n) return;
-  uint32_t pk[8], h[8], g[8];
-  load32(pk, a.pk, i); load32(h, a.h, i); load32(g, a.gamma, i);
-  bool ok = verify_decode_item<S>(a.T, pk, h, g, a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS));
-  a.ws.flags[i] = ok ? 1 : 0;
+  size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * VERIFY_K;
+  if (first >= a.n) return;
+  verify_decode_multi<S>(a.T, first, a.n, a.pk, a.h, a.gamma, a.ws.tabs, a.ws.pts, a.ws.flags);
 }
 
 // stage 1 for affine inputs (x || y, 64 bytes per point): no square roots.  The compressed encodings
@@ -46,42 +44,31 @@ __global__ void __launch_bounds__(BLOCK) k_verify_straus(VerifyArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { c[j] = 0; s[j] = 0; }
   }
-  verify_straus_item<S, HALF>(a.ws.pts + i * (2 * UV_WORDS) + HALF * UV_WORDS, a.T,
+  verify_straus_item<S, HALF>(a.ws.pts + i * PROVE_PTS_WORDS + HALF * UV_WORDS, a.T,
                                     a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), c, s);
 }
 
-// stage 3: one lane per proof.  Affine U, V; challenge hash; compare.
+// stage 3: VERIFY_K proofs per lane share one inversion (2K Z coordinates).  Affine U, V; challenge
+// hash; compare.
 template <class S>
 __global__ void __launch_bounds__(BLOCK) k_verify_finish(VerifyArgs a) {
-  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= a.n) return;
-  uint32_t pk[8], h[8], g[8], c[8], s[8];
-  if (a.affine_in) {
-    const uint32_t* aux = a.ws.aux + i * AUX_WORDS;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { pk[j] = aux[j]; h[j] = aux[8 + j]; g[j] = aux[16 + j]; }
-  } else {
-    load32(pk, a.pk, i); load32(h, a.h, i); load32(g, a.gamma, i);
-  }
-  load32(c, a.c, i); load32(s, a.s, i);
-  const uint8_t* ad; uint32_t ad_len;
-  bytes_get(a.ad, i, ad, ad_len);
-  uint32_t st = verify_finish_item<S>(a.ws.pts + i * (2 * UV_WORDS), pk, h, g, c, s,
-                                            a.ws.flags[i] != 0, ad, ad_len);
-  a.status[i] = (uint8_t)st;
+  size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * VERIFY_K;
+  if (first >= a.n) return;
+  verify_finish_multi<S>(first, a.n, a.ws.pts, PROVE_PTS_WORDS, a.pk, a.h, a.gamma,
+                         a.affine_in ? a.ws.aux : nullptr, AUX_WORDS, a.c, a.s, a.ad, a.ws.flags, a.status);
 }
 
 template <class S>
 static void launch_verify_t(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], st);
   if (a.affine_in) hipLaunchKernelGGL(k_verify_decode_affine<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  else hipLaunchKernelGGL(k_verify_decode<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL(k_verify_decode<S>, grid_for((a.n + VERIFY_K - 1) / VERIFY_K), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
   hipLaunchKernelGGL((k_verify_straus<S, 1>), grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[2], st);
   hipLaunchKernelGGL((k_verify_straus<S, 0>), grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[3], st);
-  hipLaunchKernelGGL(k_verify_finish<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  hipLaunchKernelGGL(k_verify_finish<S>, grid_for((a.n + VERIFY_K - 1) / VERIFY_K), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[4], st);
 }
 void launch_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {

@@ -7,23 +7,8 @@
 
 namespace vrf {
 
-// variable-length byte strings: shared blob, per-item offsets, or fixed stride
-struct BytesView {
-  const uint8_t* blob;
-  const uint32_t* off;   // n+1 offsets, or nullptr
-  uint32_t len;          // off == nullptr: length of every item
-  uint32_t stride;       // off == nullptr: distance between items (0 = all items share blob)
-};
-VRF_HD void bytes_get(const BytesView& v, size_t i, const uint8_t*& p, uint32_t& n) {
-  if (v.off) {
-    uint32_t a = v.off[i], b = v.off[i + 1];
-    p = v.blob + a;
-    n = b - a;
-  } else {
-    p = v.blob + i * (size_t)v.stride;
-    n = v.len;
-  }
-}
+using BytesView = BytesViewLite;
+VRF_HD void bytes_get(const BytesView& v, size_t i, const uint8_t*& p, uint32_t& n) { bytes_lite_get(v, i, p, n); }
 
 constexpr int AUX_WORDS = 32;
 constexpr int WS_TABS = 6;

@@ -13,6 +13,24 @@ namespace vrf {
 
 enum : uint32_t { ST_OK = 0, ST_VERIFICATION_FAILURE = 1, ST_INVALID_DATA = 2 };
 
+// variable-length byte strings: shared blob, per-item offsets, or fixed stride
+struct BytesViewLite {
+  const uint8_t* blob;
+  const uint32_t* off;   // n+1 offsets, or nullptr
+  uint32_t len;          // off == nullptr: length of every item
+  uint32_t stride;       // off == nullptr: distance between items (0 = all items share blob)
+};
+VRF_HD void bytes_lite_get(const BytesViewLite& v, size_t i, const uint8_t*& p, uint32_t& n) {
+  if (v.off) {
+    uint32_t a = v.off[i], b = v.off[i + 1];
+    p = v.blob + a;
+    n = b - a;
+  } else {
+    p = v.blob + i * (size_t)v.stride;
+    n = v.len;
+  }
+}
+
 // Shared, read-only device tables (built once per context, see kernels.hip: k_init_tables)
 struct DevTables {
   SqrtTables sq;
@@ -405,6 +423,139 @@ VRF_HD bool verify_decode_item(const DevTables& T, const uint32_t pk[8], const u
     build_glv_tables<S>(tabs + p * 2 * WIN_TABLE_WORDS, x, a.y);
   }
   return valid;
+}
+
+// ---- several proofs per lane: the inversion of decode and of finish is shared by K proofs ----
+// (Montgomery's trick across 3K denominators / 2K Z coordinates; prefix products are parked in the
+// lane's own slice of the HBM workspace, so the loops are rolled and register use stays low.)
+constexpr int VERIFY_K = 8;                 // proofs per lane in decode and finish
+constexpr int DEC_SLOT = 4 * NL;            // per point: y | num | den | prefix  (36 words)
+
+// points: base pointers of the pk / H / Gamma arrays; items [first, first + K) ∩ [0, n).
+// tabs_base / scratch_base / flags: workspace arrays indexed by item.
+template <class S>
+VRF_HD void verify_decode_multi(const DevTables& T, size_t first, size_t n, const uint8_t* pk,
+                                const uint8_t* hh, const uint8_t* gamma, uint32_t* tabs_base,
+                                uint32_t* scratch_base, uint8_t* flags) {
+  // scratch: K * 108 words owned by this lane = 3K point slots of 36 words
+  uint32_t* scr = scratch_base + first * (3 * DEC_SLOT);
+  FeN run = fe_one();
+  uint64_t bits = 0;                         // per point: bit 2j = sign flag, bit 2j+1 = ok
+#pragma unroll 1
+  for (int j = 0; j < 3 * VERIFY_K; ++j) {
+    const size_t item = first + j / 3;
+    const int p = j % 3;
+    if (item < n) {
+      const uint8_t* src = p == 0 ? pk : (p == 1 ? hh : gamma);
+      uint32_t enc[8];
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(src + item * 32);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) enc[k] = w[k];
+      DecodeA a = decode_phase_a<S>(enc);
+      uint32_t* slot = scr + j * DEC_SLOT;
+      fe_store(slot, a.y);
+      fe_store(slot + NL, a.num);
+      fe_store(slot + 2 * NL, a.den);
+      fe_store(slot + 3 * NL, run);
+      run = fe_mul(run, a.den);
+      bits |= (uint64_t)((a.flag ? 1u : 0u) | (a.ok ? 2u : 0u)) << (2 * j);
+    }
+  }
+  FeN inv = fe_inv(run);
+  uint32_t valid_mask = 0xffffffffu;
+#pragma unroll 1
+  for (int j = 3 * VERIFY_K - 1; j >= 0; --j) {
+    const size_t item = first + j / 3;
+    const int p = j % 3;
+    if (item < n) {
+      const uint32_t* slot = scr + j * DEC_SLOT;
+      DecodeA a;
+      a.y = fe_load<1, 2>(slot);
+      a.num = fe_load<1, 6>(slot + NL);
+      a.den = fe_load<1, 2>(slot + 2 * NL);
+      FeN prefix = fe_load<1, 2>(slot + 3 * NL);
+      a.flag = (bits >> (2 * j)) & 1;
+      a.ok = (bits >> (2 * j + 1)) & 1;
+      FeN di = fe_mul(inv, prefix);
+      inv = fe_mul(inv, a.den);
+      Fe<1, 4> x;
+      bool ok = decode_phase_b<S>(x, a, di, T.sq);
+      if (!ok) valid_mask &= ~(1u << (j / 3));
+      build_glv_tables<S>(tabs_base + item * (VERIFY_TABS * WIN_TABLE_WORDS) + p * 2 * WIN_TABLE_WORDS, x, a.y);
+    }
+  }
+#pragma unroll 1
+  for (int k = 0; k < VERIFY_K; ++k)
+    if (first + k < n) flags[first + k] = (valid_mask >> k) & 1;
+}
+
+// finish for K proofs per lane: one inversion for 2K Z coordinates.  uv_base: [item][2][27] words inside
+// the pts region; the 54 spare words of each item's pts slot hold the prefix products.
+template <class S>
+VRF_HD void verify_finish_multi(size_t first, size_t n, uint32_t* pts_base, int pts_stride,
+                                const uint8_t* pk, const uint8_t* hh, const uint8_t* gamma,
+                                const uint32_t* enc_aux, int aux_stride, const uint8_t* c_arr,
+                                const uint8_t* s_arr, const BytesViewLite& ad, const uint8_t* flags,
+                                uint8_t* status) {
+  FeN run = fe_one();
+#pragma unroll 1
+  for (int j = 0; j < 2 * VERIFY_K; ++j) {
+    const size_t item = first + j / 2;
+    if (item < n) {
+      uint32_t* slot = pts_base + item * pts_stride;
+      FeP z = fe_load<1, 5>(slot + (j & 1) * UV_WORDS + 2 * NL);
+      fe_store(slot + 2 * UV_WORDS + (j & 1) * NL, run);
+      run = fe_mul(run, z);
+    }
+  }
+  FeN inv = fe_inv(run);
+  uint32_t encv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) encv[k] = 0;
+#pragma unroll 1
+  for (int j = 2 * VERIFY_K - 1; j >= 0; --j) {
+    const size_t item = first + j / 2;
+    if (item < n) {
+      const uint32_t* slot = pts_base + item * pts_stride;
+      const uint32_t* uv = slot + (j & 1) * UV_WORDS;
+      FeN prefix = fe_load<1, 2>(slot + 2 * UV_WORDS + (j & 1) * NL);
+      FeP z = fe_load<1, 5>(uv + 2 * NL);
+      FeN zi = fe_mul(inv, prefix);
+      inv = fe_mul(inv, z);
+      uint32_t e[8];
+      te_encode_affine(e, fe_mul(fe_load<1, 5>(uv), zi), fe_mul(fe_load<1, 5>(uv + NL), zi));
+      if (j & 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) encv[k] = e[k];          // V first (reverse order), U completes the item
+      } else {
+        uint32_t pts[5][8], c[8], sc[8];
+        if (enc_aux) {
+          const uint32_t* aux = enc_aux + item * aux_stride;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { pts[0][k] = aux[k]; pts[1][k] = aux[8 + k]; pts[2][k] = aux[16 + k]; }
+        } else {
+          const uint32_t* w0 = reinterpret_cast<const uint32_t*>(pk + item * 32);
+          const uint32_t* w1 = reinterpret_cast<const uint32_t*>(hh + item * 32);
+          const uint32_t* w2 = reinterpret_cast<const uint32_t*>(gamma + item * 32);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { pts[0][k] = w0[k]; pts[1][k] = w1[k]; pts[2][k] = w2[k]; }
+        }
+        const uint32_t* wc = reinterpret_cast<const uint32_t*>(c_arr + item * 32);
+        const uint32_t* ws = reinterpret_cast<const uint32_t*>(s_arr + item * 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { pts[3][k] = e[k]; pts[4][k] = encv[k]; c[k] = wc[k]; sc[k] = ws[k]; }
+        const uint8_t* adp; uint32_t adl;
+        bytes_lite_get(ad, item, adp, adl);
+        uint32_t c2[8];
+        challenge5<S>(c2, pts, adp, adl);
+        uint32_t diff = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) diff |= c2[k] ^ c[k];
+        bool valid = flags[item] != 0 && fr_is_canonical<S>(c) && fr_is_canonical<S>(sc);
+        status[item] = (uint8_t)(!valid ? ST_INVALID_DATA : (diff == 0 ? ST_OK : ST_VERIFICATION_FAILURE));
+      }
+    }
+  }
 }
 
 // Same stage for callers that hold affine points in memory (arkworks `Affine { x, y }`): x || y as

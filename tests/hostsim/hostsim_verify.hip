@@ -76,4 +76,22 @@ uint32_t hs_ietf_verify_affine(const uint8_t* pk_xy, const uint8_t* h_xy, const 
   verify_straus_item<SuiteBS, 1>(uv.data() + UV_WORDS, HT().t, tabs.data(), cw, sw);
   return verify_finish_item<SuiteBS>(uv.data(), enc[0], enc[1], enc[2], cw, sw, valid, ad, ad_len);
 }
+// the K-proofs-per-lane pipeline exactly as the kernels run it (decode_multi -> straus -> finish_multi)
+void hs_ietf_verify_multi(uint32_t n, const uint8_t* pk, const uint8_t* h, const uint8_t* g, const uint8_t* c,
+                          const uint8_t* s, const uint8_t* ad, uint32_t ad_len, uint8_t* status) {
+  std::vector<uint32_t> tabs((size_t)n * VERIFY_TABS * WIN_TABLE_WORDS), pts((size_t)n * PROVE_PTS_WORDS);
+  std::vector<uint8_t> flags(n);
+  for (size_t first = 0; first < n; first += VERIFY_K)
+    verify_decode_multi<SuiteBS>(HT().t, first, n, pk, h, g, tabs.data(), pts.data(), flags.data());
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t cw[8], sw[8]; memcpy(cw, c + 32 * i, 32); memcpy(sw, s + 32 * i, 32);
+    if (!fr_is_canonical<SuiteBS>(cw) || !fr_is_canonical<SuiteBS>(sw)) { memset(cw, 0, 32); memset(sw, 0, 32); }
+    const uint32_t* t = tabs.data() + i * VERIFY_TABS * WIN_TABLE_WORDS;
+    verify_straus_item<SuiteBS, 1>(pts.data() + i * PROVE_PTS_WORDS + UV_WORDS, HT().t, t, cw, sw);
+    verify_straus_item<SuiteBS, 0>(pts.data() + i * PROVE_PTS_WORDS, HT().t, t, cw, sw);
+  }
+  BytesViewLite adv; adv.blob = ad; adv.off = nullptr; adv.len = ad_len; adv.stride = 0;
+  for (size_t first = 0; first < n; first += VERIFY_K)
+    verify_finish_multi<SuiteBS>(first, n, pts.data(), PROVE_PTS_WORDS, pk, h, g, nullptr, 0, c, s, adv, flags.data(), status);
+}
 }

@@ -202,3 +202,24 @@ def test_affine_input_verify(hs, kat):
         assert hs.hs_ietf_verify_affine(xy(v["pk"]), xy(v["h"]), xy(v["gamma"]), c, bytes(bad), ad, len(ad)) == 1
         off = bytearray(xy(v["pk"])); off[0] ^= 1
         assert hs.hs_ietf_verify_affine(bytes(off), xy(v["h"]), xy(v["gamma"]), c, s, ad, len(ad)) == 2
+
+
+def test_multi_proof_lanes_match_oracle(hs):
+    """The K-proofs-per-lane decode/finish (shared inversions) on a ragged batch with bad items."""
+    import numpy as np
+    from oracle import c_oracle as co
+    n = 19                                           # not a multiple of VERIFY_K = 8
+    sk = np.stack([np.frombuffer(co.secret_from_seed(o.synth_seed(700 + i)), np.uint8) for i in range(n)])
+    msg = np.stack([np.frombuffer(o.synth_msg(700 + i), np.uint8) for i in range(n)])
+    r = co.ietf_prove_batch(sk, msgs=msg, ad=b"multi", threads=4)
+    a = {k: r[k].copy() for k in ("pk", "input", "output", "c", "s")}
+    a["s"][3, 0] ^= 1
+    a["pk"][9] = np.frombuffer(Q.to_bytes(32, "little"), np.uint8)            # y >= q in the middle of a lane group
+    a["output"][10] = r["output"][11]
+    a["c"][17] = np.frombuffer(S.r.to_bytes(32, "little"), np.uint8)
+    want = co.ietf_verify_batch(a["pk"], a["input"], a["output"], a["c"], a["s"], b"multi", threads=4)
+    st = (ctypes.c_uint8 * n)()
+    hs.hs_ietf_verify_multi(n, a["pk"].tobytes(), a["input"].tobytes(), a["output"].tobytes(), a["c"].tobytes(),
+                            a["s"].tobytes(), b"multi", 5, st)
+    assert list(st) == list(want)
+    assert list(want[[3, 9, 10, 17]]) == [1, 2, 1, 2] and want.sum() == 6
