@@ -306,6 +306,7 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
     size_t m = std::min(ctx->ws_cap, n - base);
     VerifyArgs a;
     a.suite = (int)ctx->suite;
+    a.k_lane = lanes_k(m, VERIFY_K);
     a.n = m;
     a.pk = d_pk + base * pw; a.h = d_input + base * pw; a.gamma = d_output + base * pw;
     a.affine_in = affine ? 1 : 0;
@@ -419,6 +420,7 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
     size_t m = std::min(ctx->ws_cap, n - base);
     ProveArgs a;
     a.suite = (int)ctx->suite;
+    a.k_lane = lanes_k(m, PROVE_K);
     a.n = m;
     a.sk = d_sk + base * 32;
     if (d_msg_off) a.msg = make_view(d_msg, d_msg_off + base, 0, false);

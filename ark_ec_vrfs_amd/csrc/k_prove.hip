@@ -30,6 +30,35 @@ __global__ void __launch_bounds__(BLOCK) k_prove_prepare(ProveArgs a) {
   a.ws.flags[i] = ok ? 1 : 0;
 }
 
+// stage 1 for the common case (Elligator suite, H from messages): PROVE_K proofs per lane share the two
+// inversions of hash-to-curve.  The Pedersen extras (blinding, second nonce) are added per item.
+template <class S>
+__global__ void __launch_bounds__(BLOCK) k_prove_prepare_multi(ProveArgs a) {
+  if constexpr (S::H2C_ELL2) {
+    size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
+    if (first >= a.n) return;
+    prove_prepare_multi<S>(a.k_lane, a.T, first, a.n, a.sk, a.msg, a.ws.tabs, a.ws.pts, a.ws.aux, AUX_WORDS, a.ws.flags);
+    if (a.pedersen) {
+#pragma unroll 1
+      for (int j = 0; j < a.k_lane; ++j) {
+        size_t i = first + j;
+        if (i >= a.n) break;
+        uint32_t sk[8], h_enc[8], b[8], kb[8];
+        load32(sk, a.sk, i);
+        uint32_t* aux = a.ws.aux + i * AUX_WORDS;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) h_enc[t] = aux[t];
+        const uint8_t* ad; uint32_t ad_len;
+        bytes_get(a.ad, i, ad, ad_len);
+        pedersen_blinding<S>(b, sk, h_enc, ad, ad_len);
+        nonce_rfc8032<S>(kb, b, h_enc);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { aux[16 + t] = b[t]; aux[24 + t] = kb[t]; }
+      }
+    }
+  }
+}
+
 // stage 2: two lanes per proof: lane 0 -> (sk*H, sk*G), lane 1 -> (k*H, k*G)
 template <class S>
 __global__ void __launch_bounds__(BLOCK) k_prove_mul(ProveArgs a) {
@@ -54,52 +83,67 @@ __global__ void __launch_bounds__(BLOCK) k_prove_mul(ProveArgs a) {
                           a.pedersen ? a.ws.aux + i * AUX_WORDS + 16 + half * 8 : nullptr);
 }
 
-// stage 3: encodings, challenge, s = k + c*sk
+// stage 3: PROVE_K proofs per lane share the inversion of their 4K projective Z; then per item the
+// challenge and s = k + c*sk (Pedersen: also sb = kb + c*b).
 template <class S>
 __global__ void __launch_bounds__(BLOCK) k_prove_finish(ProveArgs a) {
-  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= a.n) return;
-  uint32_t sk[8], h_enc[8], k[8], g[8], c[8], s[8], pk[8], rr[8], okp[8];
-  load32(sk, a.sk, i);
-  const uint32_t* aux = a.ws.aux + i * AUX_WORDS;
+  size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
+  if (first >= a.n) return;
+  const int tstride = 2 * WIN_TABLE_WORDS;
+  prove_encode_multi<S>(a.k_lane, first, a.n, a.ws.pts, a.ws.tabs, tstride);
+#pragma unroll 1
+  for (int jj = 0; jj < a.k_lane; ++jj) {
+    size_t i = first + jj;
+    if (i >= a.n) break;
+    uint32_t sk[8], h_enc[8], k[8], g[8], c[8], s[8], pk[8], rr[8], okp[8];
+    load32(sk, a.sk, i);
+    const uint32_t* aux = a.ws.aux + i * AUX_WORDS;
+    const uint32_t* enc = a.ws.tabs + i * tstride + PROVE_ENC_OFF;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { h_enc[j] = aux[j]; k[j] = aux[8 + j]; }
-  const uint8_t* ad; uint32_t ad_len;
-  bytes_get(a.ad, i, ad, ad_len);
-  prove_finish_item<S>(g, c, s, pk, rr, okp, a.ws.pts + i * PROVE_PTS_WORDS, h_enc, sk, k, ad, ad_len);
-  bool ok = a.ws.flags[i] != 0;
-  if (a.pedersen) {
-    uint32_t b[8], kb[8], cb[8], sb[8];
+    for (int j = 0; j < 8; ++j) {
+      h_enc[j] = aux[j]; k[j] = aux[8 + j];
+      g[j] = enc[j]; pk[j] = enc[8 + j]; okp[j] = enc[16 + j]; rr[j] = enc[24 + j];
+    }
+    const uint8_t* ad; uint32_t ad_len;
+    bytes_get(a.ad, i, ad, ad_len);
+    prove_respond_item<S>(c, s, enc, h_enc, sk, k, ad, ad_len);
+    bool ok = a.ws.flags[i] != 0;
+    if (a.pedersen) {
+      uint32_t b[8], kb[8], cb[8], sb[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { b[j] = aux[16 + j]; kb[j] = aux[24 + j]; }
-    fr_mul<S>(cb, c, b);
-    fr_add<S>(sb, cb, kb);                    // sb = kb + c*b
+      for (int j = 0; j < 8; ++j) { b[j] = aux[16 + j]; kb[j] = aux[24 + j]; }
+      fr_mul<S>(cb, c, b);
+      fr_add<S>(sb, cb, kb);                    // sb = kb + c*b
+      if (!ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sb[j] = 0; b[j] = 0; rr[j] = 0; okp[j] = 0; }
+      }
+      store32(a.r_out, i, rr); store32(a.ok_out, i, okp); store32(a.sb_out, i, sb);
+      if (a.blinding_out) store32(a.blinding_out, i, b);
+    }
     if (!ok) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { sb[j] = 0; b[j] = 0; rr[j] = 0; okp[j] = 0; }
+      for (int j = 0; j < 8; ++j) { g[j] = 0; c[j] = 0; s[j] = 0; pk[j] = 0; }
     }
-    store32(a.r_out, i, rr); store32(a.ok_out, i, okp); store32(a.sb_out, i, sb);
-    if (a.blinding_out) store32(a.blinding_out, i, b);
+    store32(a.gamma, i, g); store32(a.s, i, s);
+    if (a.c) store32(a.c, i, c);
+    if (a.pk_out) store32(a.pk_out, i, pk);
+    if (a.h_out) store32(a.h_out, i, h_enc);
+    if (a.status) a.status[i] = ok ? ST_OK : ST_INVALID_DATA;
   }
-  if (!ok) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { g[j] = 0; c[j] = 0; s[j] = 0; pk[j] = 0; }
-  }
-  store32(a.gamma, i, g); store32(a.s, i, s);
-  if (a.c) store32(a.c, i, c);
-  if (a.pk_out) store32(a.pk_out, i, pk);
-  if (a.h_out) store32(a.h_out, i, h_enc);
-  if (a.status) a.status[i] = ok ? ST_OK : ST_INVALID_DATA;
 }
 
 template <class S>
 static void launch_prove_t(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(k_prove_prepare<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (S::H2C_ELL2 && !a.h_given)
+    hipLaunchKernelGGL(k_prove_prepare_multi<S>, grid_for((a.n + a.k_lane - 1) / a.k_lane), dim3(BLOCK), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_prove_prepare<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
   hipLaunchKernelGGL(k_prove_mul<S>, grid_for(2 * a.n), dim3(BLOCK), 0, st, a);
   if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
-  hipLaunchKernelGGL(k_prove_finish<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  hipLaunchKernelGGL(k_prove_finish<S>, grid_for((a.n + a.k_lane - 1) / a.k_lane), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[4], st);
 }
 void launch_ietf_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {

@@ -8,9 +8,9 @@ namespace vrf {
 // VERIFY_K proofs per lane share one inversion (3K decompression denominators).
 template <class S>
 __global__ void __launch_bounds__(BLOCK) k_verify_decode(VerifyArgs a) {
-  size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * VERIFY_K;
+  size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   if (first >= a.n) return;
-  verify_decode_multi<S>(a.T, first, a.n, a.pk, a.h, a.gamma, a.ws.tabs, a.ws.pts, a.ws.flags);
+  verify_decode_multi<S>(a.k_lane, a.T, first, a.n, a.pk, a.h, a.gamma, a.ws.tabs, a.ws.pts, a.ws.flags);
 }
 
 // stage 1 for affine inputs (x || y, 64 bytes per point): no square roots.  The compressed encodings
@@ -52,9 +52,9 @@ __global__ void __launch_bounds__(BLOCK) k_verify_straus(VerifyArgs a) {
 // hash; compare.
 template <class S>
 __global__ void __launch_bounds__(BLOCK) k_verify_finish(VerifyArgs a) {
-  size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * VERIFY_K;
+  size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   if (first >= a.n) return;
-  verify_finish_multi<S>(first, a.n, a.ws.pts, PROVE_PTS_WORDS, a.pk, a.h, a.gamma,
+  verify_finish_multi<S>(a.k_lane, first, a.n, a.ws.pts, PROVE_PTS_WORDS, a.pk, a.h, a.gamma,
                          a.affine_in ? a.ws.aux : nullptr, AUX_WORDS, a.c, a.s, a.ad, a.ws.flags, a.status);
 }
 
@@ -62,13 +62,13 @@ template <class S>
 static void launch_verify_t(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], st);
   if (a.affine_in) hipLaunchKernelGGL(k_verify_decode_affine<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  else hipLaunchKernelGGL(k_verify_decode<S>, grid_for((a.n + VERIFY_K - 1) / VERIFY_K), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL(k_verify_decode<S>, grid_for((a.n + a.k_lane - 1) / a.k_lane), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
   hipLaunchKernelGGL((k_verify_straus<S, 1>), grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[2], st);
   hipLaunchKernelGGL((k_verify_straus<S, 0>), grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[3], st);
-  hipLaunchKernelGGL(k_verify_finish<S>, grid_for((a.n + VERIFY_K - 1) / VERIFY_K), dim3(BLOCK), 0, st, a);
+  hipLaunchKernelGGL(k_verify_finish<S>, grid_for((a.n + a.k_lane - 1) / a.k_lane), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[4], st);
 }
 void launch_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {

@@ -31,8 +31,17 @@ constexpr int SUITE_BS = 1, SUITE_JJ = 2;
     else { using S = SuiteBS; CALL; }                   \
   } while (0)
 
+// proofs per lane for the inversion-sharing stages: 8 for big batches, fewer when that would leave the
+// chip short of waves (the stages are latency-bound below ~2 waves per SIMD)
+inline int lanes_k(size_t n, int kmax) {
+  int k = kmax;
+  while (k > 1 && n / k < (size_t)131072) k >>= 1;
+  return k;
+}
+
 struct VerifyArgs {
   int suite;
+  int k_lane;
   size_t n;
   const uint8_t *pk, *h, *gamma, *c, *s;   // affine_in != 0: pk, h, gamma are 64-byte x || y
   int affine_in;
@@ -44,6 +53,7 @@ struct VerifyArgs {
 
 struct ProveArgs {
   int suite;
+  int k_lane;
   size_t n;
   const uint8_t* sk;
   BytesView msg;

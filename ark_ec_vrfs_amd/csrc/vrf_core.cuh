@@ -428,13 +428,13 @@ VRF_HD bool verify_decode_item(const DevTables& T, const uint32_t pk[8], const u
 // ---- several proofs per lane: the inversion of decode and of finish is shared by K proofs ----
 // (Montgomery's trick across 3K denominators / 2K Z coordinates; prefix products are parked in the
 // lane's own slice of the HBM workspace, so the loops are rolled and register use stays low.)
-constexpr int VERIFY_K = 8;                 // proofs per lane in decode and finish
+constexpr int VERIFY_K = 8;                 // max proofs per lane in decode and finish (runtime K <= this)
 constexpr int DEC_SLOT = 4 * NL;            // per point: y | num | den | prefix  (36 words)
 
 // points: base pointers of the pk / H / Gamma arrays; items [first, first + K) ∩ [0, n).
 // tabs_base / scratch_base / flags: workspace arrays indexed by item.
 template <class S>
-VRF_HD void verify_decode_multi(const DevTables& T, size_t first, size_t n, const uint8_t* pk,
+VRF_HD void verify_decode_multi(int K, const DevTables& T, size_t first, size_t n, const uint8_t* pk,
                                 const uint8_t* hh, const uint8_t* gamma, uint32_t* tabs_base,
                                 uint32_t* scratch_base, uint8_t* flags) {
   // scratch: K * 108 words owned by this lane = 3K point slots of 36 words
@@ -442,7 +442,7 @@ VRF_HD void verify_decode_multi(const DevTables& T, size_t first, size_t n, cons
   FeN run = fe_one();
   uint64_t bits = 0;                         // per point: bit 2j = sign flag, bit 2j+1 = ok
 #pragma unroll 1
-  for (int j = 0; j < 3 * VERIFY_K; ++j) {
+  for (int j = 0; j < 3 * K; ++j) {
     const size_t item = first + j / 3;
     const int p = j % 3;
     if (item < n) {
@@ -464,7 +464,7 @@ VRF_HD void verify_decode_multi(const DevTables& T, size_t first, size_t n, cons
   FeN inv = fe_inv(run);
   uint32_t valid_mask = 0xffffffffu;
 #pragma unroll 1
-  for (int j = 3 * VERIFY_K - 1; j >= 0; --j) {
+  for (int j = 3 * K - 1; j >= 0; --j) {
     const size_t item = first + j / 3;
     const int p = j % 3;
     if (item < n) {
@@ -485,21 +485,21 @@ VRF_HD void verify_decode_multi(const DevTables& T, size_t first, size_t n, cons
     }
   }
 #pragma unroll 1
-  for (int k = 0; k < VERIFY_K; ++k)
+  for (int k = 0; k < K; ++k)
     if (first + k < n) flags[first + k] = (valid_mask >> k) & 1;
 }
 
 // finish for K proofs per lane: one inversion for 2K Z coordinates.  uv_base: [item][2][27] words inside
 // the pts region; the 54 spare words of each item's pts slot hold the prefix products.
 template <class S>
-VRF_HD void verify_finish_multi(size_t first, size_t n, uint32_t* pts_base, int pts_stride,
+VRF_HD void verify_finish_multi(int K, size_t first, size_t n, uint32_t* pts_base, int pts_stride,
                                 const uint8_t* pk, const uint8_t* hh, const uint8_t* gamma,
                                 const uint32_t* enc_aux, int aux_stride, const uint8_t* c_arr,
                                 const uint8_t* s_arr, const BytesViewLite& ad, const uint8_t* flags,
                                 uint8_t* status) {
   FeN run = fe_one();
 #pragma unroll 1
-  for (int j = 0; j < 2 * VERIFY_K; ++j) {
+  for (int j = 0; j < 2 * K; ++j) {
     const size_t item = first + j / 2;
     if (item < n) {
       uint32_t* slot = pts_base + item * pts_stride;
@@ -513,7 +513,7 @@ VRF_HD void verify_finish_multi(size_t first, size_t n, uint32_t* pts_base, int 
 #pragma unroll
   for (int k = 0; k < 8; ++k) encv[k] = 0;
 #pragma unroll 1
-  for (int j = 2 * VERIFY_K - 1; j >= 0; --j) {
+  for (int j = 2 * K - 1; j >= 0; --j) {
     const size_t item = first + j / 2;
     if (item < n) {
       const uint32_t* slot = pts_base + item * pts_stride;
@@ -871,6 +871,15 @@ VRF_HD void nonce_rfc8032(uint32_t k[8], const uint32_t sk[8], const uint32_t h_
   fr_reduce512<S>(k, le);
 }
 
+// Elligator-2 denominator D = 1 + Z*u^2 (replaced by 1 if zero)
+VRF_HD FeN ell2_den(const Fe<1, 4>& u) {
+  FeN d = fe_canon(fe_add(fe_mul5(fe_sqr(u)), fe_one()));
+  bool dz = true;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) dz = dz && (d.v[k] == 0);
+  return fe_select(dz, fe_one(), d);
+}
+
 // affine coordinates of a projective point (one inversion)
 VRF_HD void te_to_affine(FeN& x, FeN& y, const PtE& p) {
   FeN zi = fe_inv(p.Z);
@@ -931,6 +940,94 @@ VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, 
 }
 
 // scalar2 != nullptr (Pedersen): the fixed-base part is scalar*G + scalar2*B
+// prepare for K proofs per lane (hash-to-curve path): two shared inversions per lane instead of 2K
+// (the 2K Elligator denominators, then the K projective Z of H).  scratch: the lane's K pts slots
+// (108 words per item): u0 | u1 | D0 | D1 | pre0 | pre1 | X | Y | Z | preZ.
+constexpr int PROVE_K = 8;
+template <class S>
+VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t n, const uint8_t* sk_arr,
+                                const BytesViewLite& msgs, uint32_t* tabs_base, uint32_t* pts_base,
+                                uint32_t* aux_base, int aux_stride, uint8_t* flags) {
+  static_assert(S::H2C_ELL2, "multi-proof prepare is the Elligator path");
+  FeN run = fe_one();
+#pragma unroll 1
+  for (int j = 0; j < K; ++j) {
+    const size_t item = first + j;
+    if (item < n) {
+      const uint8_t* m; uint32_t len;
+      bytes_lite_get(msgs, item, m, len);
+      Fe<1, 4> u0, u1;
+      hash_to_field2<S>(u0, u1, m, len);
+      uint32_t* slot = pts_base + item * PROVE_PTS_WORDS;
+#pragma unroll 1
+      for (int t = 0; t < 2; ++t) {
+        Fe<1, 4> u = fe_select(t == 0, u0, u1);
+        FeN D = ell2_den(u);
+        fe_store(slot + t * NL, u);
+        fe_store(slot + (2 + t) * NL, D);
+        fe_store(slot + (4 + t) * NL, run);
+        run = fe_mul(run, D);
+      }
+    }
+  }
+  FeN inv = fe_inv(run);
+  FeN runz = fe_one();
+#pragma unroll 1
+  for (int j = K - 1; j >= 0; --j) {
+    const size_t item = first + j;
+    if (item < n) {
+      uint32_t* slot = pts_base + item * PROVE_PTS_WORDS;
+      PtE q1 = te_identity(), acc = te_identity();
+#pragma unroll 1
+      for (int t = 1; t >= 0; --t) {
+        Fe<1, 4> u = fe_load<1, 4>(slot + t * NL);
+        FeN D = fe_load<1, 2>(slot + (2 + t) * NL);
+        FeN pre = fe_load<1, 2>(slot + (4 + t) * NL);
+        FeN di = fe_mul(inv, pre);
+        inv = fe_mul(inv, D);
+        PtE q = ell2_map<S>(u, di, T.sq);
+        if (t == 1) q1 = q; else acc = te_add<S>(q, q1);
+      }
+#pragma unroll 1
+      for (int i = 0; i < S::COFACTOR_LOG2; ++i) acc = te_dbl<S>(acc, true);
+      fe_store(slot + 6 * NL, acc.X); fe_store(slot + 7 * NL, acc.Y); fe_store(slot + 8 * NL, acc.Z);
+    }
+  }
+  // second shared inversion: the Z coordinates (forward prefix, backward unwind)
+#pragma unroll 1
+  for (int j = 0; j < K; ++j) {
+    const size_t item = first + j;
+    if (item < n) {
+      uint32_t* slot = pts_base + item * PROVE_PTS_WORDS;
+      fe_store(slot + 9 * NL, runz);
+      runz = fe_mul(runz, fe_load<1, 5>(slot + 8 * NL));
+    }
+  }
+  FeN invz = fe_inv(runz);
+#pragma unroll 1
+  for (int j = K - 1; j >= 0; --j) {
+    const size_t item = first + j;
+    if (item < n) {
+      uint32_t* slot = pts_base + item * PROVE_PTS_WORDS;
+      FeP Z = fe_load<1, 5>(slot + 8 * NL);
+      FeN zi = fe_mul(invz, fe_load<1, 2>(slot + 9 * NL));
+      invz = fe_mul(invz, Z);
+      FeN x = fe_mul(fe_load<1, 5>(slot + 6 * NL), zi), y = fe_mul(fe_load<1, 5>(slot + 7 * NL), zi);
+      uint32_t sk[8], h_enc[8], k[8];
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(sk_arr + item * 32);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sk[i] = w[i];
+      te_encode_affine(h_enc, x, y);
+      nonce_rfc8032<S>(k, sk, h_enc);
+      build_glv_tables<S>(tabs_base + item * (2 * WIN_TABLE_WORDS), x, y);
+      uint32_t* aux = aux_base + item * aux_stride;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { aux[i] = h_enc[i]; aux[8 + i] = k[i]; }
+      flags[item] = fr_is_canonical<S>(sk) ? 1 : 0;
+    }
+  }
+}
+
 template <class S>
 VRF_HD void prove_mul_item(uint32_t* out /*2*UV_WORDS*/, const DevTables& T, const uint32_t* tab,
                            const uint32_t scalar[8], const uint32_t* scalar2) {
@@ -1149,6 +1246,59 @@ VRF_HD uint32_t pedersen_verify_finish_item(const uint32_t* pts, const uint32_t 
   bool ok = proj_eq_affine(pts, pts + PED_OK_OFF) && proj_eq_affine(pts + UV_WORDS, pts + PED_R_OFF);
   if (!valid) return ST_INVALID_DATA;
   return ok ? ST_OK : ST_VERIFICATION_FAILURE;
+}
+
+// Shared inversion of the 4K projective Z of K proofs: writes the affine encodings of the four points
+// of every item (sk*H, sk*G(+bB), k*H, k*G(+kbB)) to enc_out[item][4][8].  Prefix products are parked in
+// the items' (now idle) table slots.
+constexpr int PROVE_ENC_OFF = 64;     // word offset of the 4 x 8-word encodings inside an item's table slot
+template <class S>
+VRF_HD void prove_encode_multi(int K, size_t first, size_t n, const uint32_t* pts_base, uint32_t* tabs_base,
+                               int tabs_stride) {
+  FeN run = fe_one();
+#pragma unroll 1
+  for (int j = 0; j < 4 * K; ++j) {
+    const size_t item = first + j / 4;
+    if (item < n) {
+      fe_store(tabs_base + item * tabs_stride + (j & 3) * NL, run);
+      run = fe_mul(run, fe_load<1, 5>(pts_base + item * PROVE_PTS_WORDS + (j & 3) * UV_WORDS + 2 * NL));
+    }
+  }
+  FeN inv = fe_inv(run);
+#pragma unroll 1
+  for (int j = 4 * K - 1; j >= 0; --j) {
+    const size_t item = first + j / 4;
+    if (item < n) {
+      const uint32_t* pt = pts_base + item * PROVE_PTS_WORDS + (j & 3) * UV_WORDS;
+      FeP Z = fe_load<1, 5>(pt + 2 * NL);
+      FeN zi = fe_mul(inv, fe_load<1, 2>(tabs_base + item * tabs_stride + (j & 3) * NL));
+      inv = fe_mul(inv, Z);
+      uint32_t e[8];
+      te_encode_affine(e, fe_mul(fe_load<1, 5>(pt), zi), fe_mul(fe_load<1, 5>(pt + NL), zi));
+      uint32_t* dst = tabs_base + item * tabs_stride + PROVE_ENC_OFF + (j & 3) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dst[k] = e[k];
+    }
+  }
+}
+
+// challenge + response from already encoded points: enc = [sk*H, pk(_com), k*H, R]
+template <class S>
+VRF_HD void prove_respond_item(uint32_t c_out[8], uint32_t s_out[8], const uint32_t* enc, const uint32_t h_enc[8],
+                               const uint32_t sk[8], const uint32_t k[8], const uint8_t* ad, uint32_t ad_len) {
+  uint32_t pts[5][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    pts[0][j] = enc[8 + j];       // pk = sk*G (+ b*B)
+    pts[1][j] = h_enc[j];
+    pts[2][j] = enc[j];           // Gamma = sk*H
+    pts[3][j] = enc[24 + j];      // k*G (+ kb*B)
+    pts[4][j] = enc[16 + j];      // k*H
+  }
+  uint32_t cs[8];
+  challenge5<S>(c_out, pts, ad, ad_len);
+  fr_mul<S>(cs, c_out, sk);
+  fr_add<S>(s_out, cs, k);
 }
 
 // [ref src/lib.rs:15 `Output::hash` / utils::point_to_hash_rfc_9381]  SURVEY.md A.4:

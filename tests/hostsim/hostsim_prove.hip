@@ -108,4 +108,29 @@ uint32_t hs_pedersen_verify(const uint8_t* h, const uint8_t* g, const uint8_t* p
   pedersen_verify_straus_item<SuiteBS, 1>(pts.data() + UV_WORDS, HT().t, tabs.data(), c, s2, sb2);
   return pedersen_verify_finish_item<SuiteBS>(pts.data(), s, sb, valid);
 }
+// batch prove through the K-per-lane prepare, exactly as the kernels run it; out: n x (gamma | c | s | pk | h)
+void hs_ietf_prove_multi(uint32_t n, const uint8_t* sk, const uint8_t* msgs, uint32_t msg_len, const uint8_t* ad,
+                         uint32_t ad_len, uint8_t* out) {
+  std::vector<uint32_t> tabs((size_t)n * 2 * WIN_TABLE_WORDS), pts((size_t)n * PROVE_PTS_WORDS), aux((size_t)n * 32);
+  std::vector<uint8_t> flags(n);
+  BytesViewLite mv; mv.blob = msgs; mv.off = nullptr; mv.len = msg_len; mv.stride = msg_len;
+  for (size_t first = 0; first < n; first += PROVE_K)
+    prove_prepare_multi<SuiteBS>(PROVE_K, HT().t, first, n, sk, mv, tabs.data(), pts.data(), aux.data(), 32, flags.data());
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t skw[8], k[8];
+    memcpy(skw, sk + 32 * i, 32); memcpy(k, aux.data() + 32 * i + 8, 32);
+    prove_mul_item<SuiteBS>(pts.data() + i * PROVE_PTS_WORDS, HT().t, tabs.data() + i * 2 * WIN_TABLE_WORDS, skw, nullptr);
+    prove_mul_item<SuiteBS>(pts.data() + i * PROVE_PTS_WORDS + 2 * UV_WORDS, HT().t, tabs.data() + i * 2 * WIN_TABLE_WORDS, k, nullptr);
+  }
+  for (size_t first = 0; first < n; first += PROVE_K)
+    prove_encode_multi<SuiteBS>(PROVE_K, first, n, pts.data(), tabs.data(), 2 * WIN_TABLE_WORDS);
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t skw[8], h_enc[8], k[8], c[8], s2[8];
+    memcpy(skw, sk + 32 * i, 32); memcpy(h_enc, aux.data() + 32 * i, 32); memcpy(k, aux.data() + 32 * i + 8, 32);
+    const uint32_t* enc = tabs.data() + i * 2 * WIN_TABLE_WORDS + PROVE_ENC_OFF;
+    prove_respond_item<SuiteBS>(c, s2, enc, h_enc, skw, k, ad, ad_len);
+    memcpy(out + 160 * i, enc, 32); memcpy(out + 160 * i + 32, c, 32); memcpy(out + 160 * i + 64, s2, 32);
+    memcpy(out + 160 * i + 96, enc + 8, 32); memcpy(out + 160 * i + 128, h_enc, 32);
+  }
+}
 }

@@ -82,7 +82,7 @@ void hs_ietf_verify_multi(uint32_t n, const uint8_t* pk, const uint8_t* h, const
   std::vector<uint32_t> tabs((size_t)n * VERIFY_TABS * WIN_TABLE_WORDS), pts((size_t)n * PROVE_PTS_WORDS);
   std::vector<uint8_t> flags(n);
   for (size_t first = 0; first < n; first += VERIFY_K)
-    verify_decode_multi<SuiteBS>(HT().t, first, n, pk, h, g, tabs.data(), pts.data(), flags.data());
+    verify_decode_multi<SuiteBS>(VERIFY_K, HT().t, first, n, pk, h, g, tabs.data(), pts.data(), flags.data());
   for (size_t i = 0; i < n; ++i) {
     uint32_t cw[8], sw[8]; memcpy(cw, c + 32 * i, 32); memcpy(sw, s + 32 * i, 32);
     if (!fr_is_canonical<SuiteBS>(cw) || !fr_is_canonical<SuiteBS>(sw)) { memset(cw, 0, 32); memset(sw, 0, 32); }
@@ -92,6 +92,6 @@ void hs_ietf_verify_multi(uint32_t n, const uint8_t* pk, const uint8_t* h, const
   }
   BytesViewLite adv; adv.blob = ad; adv.off = nullptr; adv.len = ad_len; adv.stride = 0;
   for (size_t first = 0; first < n; first += VERIFY_K)
-    verify_finish_multi<SuiteBS>(first, n, pts.data(), PROVE_PTS_WORDS, pk, h, g, nullptr, 0, c, s, adv, flags.data(), status);
+    verify_finish_multi<SuiteBS>(VERIFY_K, first, n, pts.data(), PROVE_PTS_WORDS, pk, h, g, nullptr, 0, c, s, adv, flags.data(), status);
 }
 }

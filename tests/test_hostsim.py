@@ -223,3 +223,17 @@ def test_multi_proof_lanes_match_oracle(hs):
                             a["s"].tobytes(), b"multi", 5, st)
     assert list(st) == list(want)
     assert list(want[[3, 9, 10, 17]]) == [1, 2, 1, 2] and want.sum() == 6
+
+
+def test_multi_proof_prepare_matches_oracle(hs):
+    import numpy as np
+    from oracle import c_oracle as co
+    n = 11
+    sk = np.stack([np.frombuffer(co.secret_from_seed(o.synth_seed(900 + i)), np.uint8) for i in range(n)])
+    msg = np.stack([np.frombuffer(o.synth_msg(900 + i), np.uint8) for i in range(n)])
+    r = co.ietf_prove_batch(sk, msgs=msg, ad=b"pm", threads=4)
+    out = ctypes.create_string_buffer(160 * n)
+    hs.hs_ietf_prove_multi(n, sk.tobytes(), msg.tobytes(), 32, b"pm", 2, out)
+    for i in range(n):
+        row = out.raw[160 * i:160 * i + 160]
+        assert row == b"".join(r[k][i].tobytes() for k in ("output", "c", "s", "pk", "input")), i
