@@ -496,6 +496,31 @@ VRF_HD_NOINLINE void fp12_mul_by_014(Fp12* f, const Fp2* c0, const Fp2* c1, cons
   fp6_mul_v(&bb, &bb);
   fp6_add(&f->c0, &bb, &aa);
 }
+// Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part of the final
+// exponentiation): three Fp4 squarings, 6 Fp2 products instead of 12.
+template <int L1, int V1, int L2, int V2>
+VRF_HD void fp4_square(Fp2& t0, Fp2& t1, const Fp2T<L1, V1>& a, const Fp2T<L2, V2>& b) {
+  auto tmp = fp2_mul(a, b);
+  auto tn = fp2_norm(tmp);
+  auto s = fp2_mul(fp2_add(a, b), fp2_add(fp2_mul_xi(b), a));
+  t0 = fp2_fit(fp2_sub(fp2_sub(s, tn), fp2_mul_xi(tn)));
+  t1 = fp2_fit(fp2_dbl(tn));
+}
+VRF_HD_NOINLINE void fp12_cyclotomic_sqr(Fp12* r, const Fp12* x) {
+  const Fp2 r0 = x->c0.c0, r4 = x->c0.c1, r3 = x->c0.c2, r2 = x->c1.c0, r1 = x->c1.c1, r5 = x->c1.c2;
+  Fp2 t0, t1, t2, t3, t4, t5;
+  fp4_square(t0, t1, r0, r1);
+  fp4_square(t2, t3, r2, r3);
+  fp4_square(t4, t5, r4, r5);
+  auto three = [](const Fp2& t) { return fp2_add(fp2_dbl(t), t); };
+  r->c0.c0 = fp2_fit(fp2_sub(three(t0), fp2_dbl(r0)));                       // z0 = 3 t0 - 2 r0
+  r->c1.c1 = fp2_fit(fp2_add(three(t1), fp2_dbl(r1)));                       // z1 = 3 t1 + 2 r1
+  r->c1.c0 = fp2_fit(fp2_add(three(fp2_fit(fp2_mul_xi(t5))), fp2_dbl(r2)));  // z2 = 3 xi t5 + 2 r2
+  r->c0.c2 = fp2_fit(fp2_sub(three(t4), fp2_dbl(r3)));                       // z3 = 3 t4 - 2 r3
+  r->c0.c1 = fp2_fit(fp2_sub(three(t2), fp2_dbl(r4)));                       // z4 = 3 t2 - 2 r4
+  r->c1.c2 = fp2_fit(fp2_add(three(t3), fp2_dbl(r5)));                       // z5 = 3 t3 + 2 r5
+}
+
 VRF_HD void fp12_conj(Fp12* r, const Fp12* x) {
   r->c0 = x->c0;
   fp6_neg(&r->c1, &x->c1);
@@ -626,7 +651,7 @@ VRF_HD_NOINLINE void miller_loop(Fp12* f, const G1Aff* P, const G2Aff* Q, const 
 VRF_HD_NOINLINE void exp_by_x(Fp12* r, const Fp12* f) {
   Fp12 acc = *f, t;
   for (int bit = 62; bit >= 0; --bit) {
-    fp12_sqr(&t, &acc);
+    fp12_cyclotomic_sqr(&t, &acc);
     acc = t;
     if ((X_ABS >> bit) & 1) {
       fp12_mul(&t, &acc, f);
@@ -654,7 +679,7 @@ VRF_HD_NOINLINE void final_exponentiation(Fp12* r, const Fp12* f) {
   fp12_mul(&t0, &t1, &y3);
   fp12_conj(&t1, &y2);
   fp12_mul(&y3, &t0, &t1);                                                 // ^(x^2 + p^2 - 1)
-  fp12_sqr(&t0, &f2);
+  fp12_cyclotomic_sqr(&t0, &f2);
   fp12_mul(&t1, &t0, &f2);                                                 // f2^3
   fp12_mul(r, &y3, &t1);
 }
