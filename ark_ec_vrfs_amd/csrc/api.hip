@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "msm.cuh"
 
 using namespace vrf;
 
@@ -120,6 +121,16 @@ int32_t ensure_stage(vrfhip_ctx* ctx, size_t bytes) {
   }
   HIP_TRY(hipMalloc(&ctx->d_stage, bytes));
   ctx->stage_bytes = bytes;
+  return VRFHIP_SUCCESS;
+}
+
+int32_t ensure_msm_workspace(vrfhip_ctx* ctx, size_t need) {
+  if (need <= ctx->msm_ws_bytes) return VRFHIP_SUCCESS;
+  if (ctx->d_msm_ws) HIP_TRY(hipFree(ctx->d_msm_ws));
+  ctx->d_msm_ws = nullptr;
+  ctx->msm_ws_bytes = 0;
+  HIP_TRY(hipMalloc(&ctx->d_msm_ws, need));
+  ctx->msm_ws_bytes = need;
   return VRFHIP_SUCCESS;
 }
 
@@ -624,14 +635,109 @@ int32_t vrfhip_pedersen_verify_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* i
   return VRFHIP_SUCCESS;
 }
 
+// ------------------------------------------------------------------------- Pedersen verify, batched (RLC)
+int32_t vrfhip_pedersen_verify_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_input,
+                                             const uint8_t* d_output, const uint8_t* d_pk_com,
+                                             const uint8_t* d_r, const uint8_t* d_ok, const uint8_t* d_s,
+                                             const uint8_t* d_sb, const uint8_t* d_ad,
+                                             const uint32_t* d_ad_off, uint32_t ad_len,
+                                             const uint8_t seed[32], uint8_t* d_status,
+                                             uint8_t* d_fail_flag, void* stream) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (!d_fail_flag || !seed) return fail(VRFHIP_ERR_BAD_ARG, "NULL fail flag or seed");
+  if (n && (!d_input || !d_output || !d_pk_com || !d_r || !d_ok || !d_s || !d_sb || !d_status))
+    return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if ((ad_len || d_ad_off) && !d_ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemsetAsync(d_fail_flag, 0, 1, st));
+  if (n == 0) return VRFHIP_SUCCESS;
+  int32_t rc = ensure_workspace(ctx, n);
+  if (rc) return rc;
+  {
+    size_t m = std::min(ctx->ws_cap, n), N = 5 * m + 2;
+    rc = ensure_msm_workspace(ctx, msm_workspace_bytes(N, msm_groups(N, ctx->cus)));
+    if (rc) return rc;
+  }
+  for (size_t base = 0; base < n; base += ctx->ws_cap) {
+    size_t m = std::min(ctx->ws_cap, n - base), N = 5 * m + 2;
+    RlcArgs a;
+    a.suite = (int)ctx->suite;
+    a.k_lane = lanes_k(m, 8);
+    a.n = m;
+    a.index0 = base;
+    a.h = d_input + base * 32; a.gamma = d_output + base * 32; a.pk_com = d_pk_com + base * 32;
+    a.r = d_r + base * 32; a.ok = d_ok + base * 32; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
+    a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
+    a.status = d_status + base;
+    a.scratch = ctx->ws.tabs;
+    a.scratch_stride = WS_TABS * WIN_TABLE_WORDS;
+    a.L = msm_layout(N, msm_groups(N, ctx->cus), ctx->d_msm_ws);
+    a.fixed_cols = reinterpret_cast<uint64_t*>(a.L.flags + 128);
+    a.T = ctx->T;
+    std::memcpy(a.seed, seed, 32);
+    launch_pedersen_rlc(a, d_fail_flag, st, prof_events(ctx));
+  }
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_pedersen_verify_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t* input,
+                                         const uint8_t* output, const uint8_t* pk_com, const uint8_t* r,
+                                         const uint8_t* ok, const uint8_t* s, const uint8_t* sb,
+                                         const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                         const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (!seed) return fail(VRFHIP_ERR_BAD_ARG, "seed is NULL");
+  if (batch_ok) *batch_ok = 1;
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!input || !output || !pk_com || !r || !ok || !s || !sb || !status)
+    return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  size_t adb = blob_bytes(n, ad_off, ad_len, true);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  size_t need = 7 * Stage::pad(n * 32) + Stage::pad(adb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n) + 256;
+  int32_t rc = ensure_stage(ctx, need);
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  const uint8_t* src[7] = {input, output, pk_com, r, ok, s, sb};
+  uint8_t* d[7];
+  for (int i = 0; i < 7; ++i) {
+    d[i] = sg.take(n * 32);
+    HIP_TRY(hipMemcpyAsync(d[i], src[i], n * 32, hipMemcpyHostToDevice, ctx->stream));
+  }
+  uint8_t* d_ad = sg.take(adb + 1);
+  uint32_t* d_off = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+  uint8_t* d_st = sg.take(n);
+  uint8_t* d_flag = sg.take(1);
+  if (adb) HIP_TRY(hipMemcpyAsync(d_ad, ad, adb, hipMemcpyHostToDevice, ctx->stream));
+  if (ad_off) HIP_TRY(hipMemcpyAsync(d_off, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = vrfhip_pedersen_verify_batch_rlc_dev(ctx, n, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d_ad,
+                                            ad_off ? d_off : nullptr, ad_len, seed, d_st, d_flag, ctx->stream);
+  if (rc) return rc;
+  uint8_t flag = 0;
+  HIP_TRY(hipMemcpyAsync(&flag, d_flag, 1, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (flag) {
+    // some proof in the batch is wrong: the per-proof kernels say which
+    if (batch_ok) *batch_ok = 0;
+    rc = vrfhip_pedersen_verify_batch_dev(ctx, n, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d_ad,
+                                          ad_off ? d_off : nullptr, ad_len, d_st, ctx->stream);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
 // ------------------------------------------------------------------------- MSM
 int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, const uint8_t* d_scalars,
                        uint8_t* d_out_point, uint8_t* d_out_xy, uint8_t* d_status, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (!d_out_point || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!d_bases_xy || !d_scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
-  if (ctx->suite != VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2)
-    return fail(VRFHIP_ERR_UNSUPPORTED, "vrfhip_msm is built for the Bandersnatch curve only");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -646,15 +752,9 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
     return VRFHIP_SUCCESS;
   }
   int groups = msm_groups(n, ctx->cus);
-  size_t need = msm_workspace_bytes(n, groups);
-  if (need > ctx->msm_ws_bytes) {
-    if (ctx->d_msm_ws) HIP_TRY(hipFree(ctx->d_msm_ws));
-    ctx->d_msm_ws = nullptr;
-    ctx->msm_ws_bytes = 0;
-    HIP_TRY(hipMalloc(&ctx->d_msm_ws, need));
-    ctx->msm_ws_bytes = need;
-  }
-  launch_msm(n, d_bases_xy, d_scalars, d_out_point, d_out_xy, d_status, ctx->d_msm_ws, groups, st);
+  int32_t rc = ensure_msm_workspace(ctx, msm_workspace_bytes(n, groups));
+  if (rc) return rc;
+  launch_msm((int)ctx->suite, n, d_bases_xy, d_scalars, d_out_point, d_out_xy, d_status, ctx->d_msm_ws, groups, st);
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
 }

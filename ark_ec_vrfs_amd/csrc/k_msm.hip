@@ -3,30 +3,29 @@
 // (named in BASELINE.json north_star; reached from /root/reference through `reexports`,
 // src/lib.rs:14).
 //
-// Pippenger with signed 11-bit windows (23 windows x 1024 buckets).  Scalars k > r/2 are replaced
-// by r - k with the point's sign flipped, so k < 2^252 and the top window never carries out (a
-// 24th carry-only window would put half of all points into a single bucket).
+// Pippenger with signed 11-bit windows (msm.cuh).
 //   k_msm_prep    : bases -> Montgomery affine-cached (x, y, d*x*y); scalars -> signed digits
-//   k_msm_buckets : one workgroup per (window, point-group).  Per slice of 16384 points the
-//                   workgroup counting-sorts the slice by bucket in LDS (LDS atomics, block scan),
-//                   then every lane sums the lists of the two buckets it owns with its
-//                   accumulators kept in registers.  After the last slice the 1024 buckets are
-//                   reduced to sum_j j*B_j inside the workgroup: pair-local sums, a suffix scan and
-//                   a tree reduction over 512 lanes staged through LDS.
-//   k_msm_final   : sums the groups of every window, then Horner over the 24 windows.
+//   k_msm_buckets : one workgroup per (window, point-group); the 1024 buckets of the window live in LDS.
+//                   The workgroup counting-sorts its points by bucket (LDS atomics + wave-shuffle block
+//                   scan), then the sorted list is cut into 512 EQUAL chunks, one per lane: every lane
+//                   performs the same number of mixed additions whatever the digit distribution.  A
+//                   lane keeps the running sum of the current bucket in registers and flushes it when
+//                   the bucket changes: runs that start inside the chunk go straight to their LDS
+//                   bucket (exactly one lane owns the start of a bucket), the first run of a chunk --
+//                   possibly the continuation of the previous lane's bucket -- is parked as a "head"
+//                   and merged afterwards by the first lane of each chain.  Then the 1024 buckets are
+//                   reduced to sum_j j*B_j inside the workgroup: pair-local sums, a suffix scan and a
+//                   tree reduction over 512 lanes staged through LDS.
+//   k_msm_final   : sums the groups of every window, shifts window w by 11*w doublings (lanes in
+//                   lockstep), tree-sums the windows, encodes.
 #include "kernels.h"
+#include "msm.cuh"
 #include <cstdlib>
 
 namespace vrf {
 
-constexpr int MSM_C = 11;                         // window bits
-constexpr int MSM_W = 23;                         // windows: 11*23 = 253 bits; scalars are folded to < r/2
-constexpr int MSM_BUCKETS = 1 << (MSM_C - 1);     // 1024 signed buckets
-constexpr int MSM_BLOCK = 512;                    // lanes per workgroup; each owns 2 buckets
-constexpr int MSM_SLICE = 16384;                  // points sorted per pass
-constexpr int MSM_PT_WORDS = 4 * NL;              // extended point staged in LDS: X, Y, Z, T
-
 // ------------------------------------------------------------------------------- prep
+template <class S>
 __global__ void __launch_bounds__(BLOCK) k_msm_prep(size_t n, const uint8_t* xy, const uint8_t* scalars,
                                                      uint32_t* pts, int16_t* digits, uint8_t* flags) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -36,54 +35,18 @@ __global__ void __launch_bounds__(BLOCK) k_msm_prep(size_t n, const uint8_t* xy,
 #pragma unroll
   for (int j = 0; j < 8; ++j) { xw[j] = p[j]; yw[j] = p[8 + j]; }
   load32(k, scalars, i);
-  bool ok = !u256_ge(xw, vrfk::Q32) && !u256_ge(yw, vrfk::Q32) && fr_is_canonical<SuiteBS>(k);
+  bool ok = !u256_ge(xw, vrfk::Q32) && !u256_ge(yw, vrfk::Q32) && fr_is_canonical<S>(k);
   PtA a;
   a.x = fe_from_u256(xw);
   a.y = fe_from_u256(yw);
-  a.dt = fe_mul(fe_mul(a.x, a.y), SuiteBS::d());
-  // on-curve check: a*x^2 + y^2 == 1 + d*x^2*y^2  <=>  y^2 - 5 x^2 - 1 - (d x y) * (x y) == 0
+  a.dt = fe_mul(fe_mul(a.x, a.y), S::d());
+  // on-curve check: a*x^2 + y^2 == 1 + d*x^2*y^2  <=>  y^2 - ANEG x^2 - 1 - (d x y) * (x y) == 0
   FeN x2 = fe_sqr(a.x), y2 = fe_sqr(a.y), xy_ = fe_mul(a.x, a.y);
-  auto lhs = fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(fe_mul5(x2), fe_one())))));
+  auto lhs = fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(S::mul_aneg(x2), fe_one())))));
   ok = ok && fe_eq(lhs, fe_mul(a.dt, xy_));
   pta_store(pts + i * PTA_WORDS, a);
   if (!ok) flags[0] = 1;
-  // fold: k > r - k  ->  use r - k and flip the sign of every digit
-  uint32_t nk[8];
-  {
-    uint32_t borrow = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      uint64_t d = (uint64_t)SuiteBS::r32(j) - k[j] - borrow;
-      nk[j] = (uint32_t)d;
-      borrow = (uint32_t)(d >> 63);
-    }
-  }
-  bool flip = false, decided = false;
-#pragma unroll
-  for (int j = 7; j >= 0; --j)
-    if (!decided && nk[j] != k[j]) { flip = nk[j] < k[j]; decided = true; }
-  flip = flip && ok;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) k[j] = flip ? nk[j] : k[j];
-  // signed radix-2^11 digits in [-1023, 1024]
-  uint32_t carry = 0;
-#pragma unroll 1
-  for (int w = 0; w < MSM_W; ++w) {
-    int bit = w * MSM_C, wi = bit >> 5, sh = bit & 31;
-    uint32_t lo = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) if (j == wi) lo = k[j];
-    uint32_t hi = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) if (j == wi + 1) hi = k[j];
-    uint32_t v = (sh ? ((lo >> sh) | (hi << (32 - sh))) : lo) & ((1u << MSM_C) - 1);
-    if (wi >= 8) v = 0;
-    v += carry;
-    int d = (int)v;
-    carry = 0;
-    if (v > (uint32_t)MSM_BUCKETS) { d = (int)v - (1 << MSM_C); carry = 1; }
-    digits[(size_t)w * n + i] = (int16_t)(flip ? -d : d);
-  }
+  msm_write_digits<S>(digits, n, i, k, false, !ok);
 }
 
 // ------------------------------------------------------------------------------- buckets
@@ -97,35 +60,41 @@ VRF_HD PtE lds_load_pt(const uint32_t* src) {
   return p;
 }
 
-__global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(size_t n, const uint32_t* pts, const int16_t* digits,
-                                                            uint32_t* lists, uint32_t* out, int groups, int dbg) {
+constexpr uint32_t MSM_NONE = 0xffffffffu;
+
+template <class S>
+__global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
   extern __shared__ uint32_t lds[];
   uint32_t* bucket = lds;                                   // [1024][36] bucket accumulators (147,456 B)
-  uint32_t* counts = lds + MSM_BUCKETS * MSM_PT_WORDS;      // [1024] bucket sizes, then exclusive offsets
-  uint32_t* cursor = counts + MSM_BUCKETS;                  // [1024] scatter cursors
+  uint32_t* counts = lds + MSM_BUCKETS * MSM_PT_WORDS;      // [1024] bucket sizes
+  uint32_t* cursor = counts + MSM_BUCKETS;                  // [1024] scatter cursors, later head bucket ids
   uint32_t* wsum = cursor + MSM_BUCKETS;                    // [8] per-wave totals for the block scan
-  const int w = blockIdx.x, g = blockIdx.y, t = threadIdx.x;
-  const size_t per_group = (n + groups - 1) / groups;
-  const size_t lo = (size_t)g * per_group, hi = lo + per_group < n ? lo + per_group : n;
-  const int16_t* dig = digits + (size_t)w * n;
-  uint32_t* list = lists + ((size_t)w * groups + g) * MSM_SLICE;
-  // lane t owns buckets 2t and 2t+1 (digit magnitudes 2t+1 and 2t+2), resident in LDS
+  const int t = threadIdx.x;
+  // top windows first: their results wait longest in k_msm_final
+  const int wg = blockIdx.x, w = MSM_W - 1 - wg / L.groups, g = wg % L.groups;
+  const size_t lo = (size_t)g * L.per_group;
+  const size_t hi = lo + L.per_group < L.n ? lo + L.per_group : L.n;
+  const uint32_t cnt_all = lo < hi ? (uint32_t)(hi - lo) : 0u;
+  const int16_t* dig = L.digits + (size_t)w * L.n + lo;
+  const uint32_t* P = L.pts + lo * PTA_WORDS;
+  uint32_t* list = L.lists + (size_t)wg * L.list_cap;
+  uint32_t* heads = L.heads + (size_t)wg * MSM_BLOCK * MSM_PT_WORDS;
   {
     PtE id = te_identity();
     lds_store_pt(bucket + (2 * t) * MSM_PT_WORDS, id);
     lds_store_pt(bucket + (2 * t + 1) * MSM_PT_WORDS, id);
   }
-  for (size_t base = lo; base < hi; base += MSM_SLICE) {
-    const int m = (int)(hi - base < (size_t)MSM_SLICE ? hi - base : (size_t)MSM_SLICE);
-    // 1. histogram of the slice
-    counts[t] = 0; counts[t + MSM_BLOCK] = 0;
-    __syncthreads();
-    for (int j = t; j < m; j += MSM_BLOCK) {
-      int d = dig[base + j];
-      if (d != 0) atomicAdd(&counts[(d < 0 ? -d : d) - 1], 1u);
-    }
-    __syncthreads();
-    // 2. exclusive scan over 1024 counts: lane t scans its pair, waves scan by shuffles
+  // 1. histogram of the group's digits
+  counts[t] = 0; counts[t + MSM_BLOCK] = 0;
+  __syncthreads();
+  for (uint32_t j = t; j < cnt_all; j += MSM_BLOCK) {
+    int d = dig[j];
+    if (d != 0) atomicAdd(&counts[(d < 0 ? -d : d) - 1], 1u);
+  }
+  __syncthreads();
+  // 2. exclusive scan over 1024 counts: lane t scans its pair, waves scan by shuffles
+  uint32_t m;
+  {
     uint32_t c0 = counts[2 * t], c1 = counts[2 * t + 1];
     uint32_t v = c0 + c1, incl = v;
 #pragma unroll
@@ -135,52 +104,98 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(size_t n, const uint3
     }
     if ((t & 63) == 63) wsum[t >> 6] = incl;
     __syncthreads();
-    uint32_t wbase = 0;
-    for (int k = 0; k < (t >> 6); ++k) wbase += wsum[k];
+    uint32_t wbase = 0, total = 0;
+    for (int k = 0; k < MSM_BLOCK / 64; ++k) {
+      uint32_t x = wsum[k];
+      if (k < (t >> 6)) wbase += x;
+      total += x;
+    }
+    m = total;
     uint32_t excl = wbase + incl - v;
-    __syncthreads();
     cursor[2 * t] = excl; cursor[2 * t + 1] = excl + c0;
-    __syncthreads();
-    // 3. scatter point indices (sign in bit 31) into bucket order
-    for (int j = t; j < m; j += MSM_BLOCK) {
-      int d = dig[base + j];
-      if (d != 0) {
-        uint32_t pos = atomicAdd(&cursor[(d < 0 ? -d : d) - 1], 1u);
-        list[pos] = (uint32_t)j | (d < 0 ? 0x80000000u : 0u);
-      }
-    }
-    __threadfence_block();
-    __syncthreads();
-    // 4. each lane folds the lists of its two buckets into the LDS accumulators
-#pragma unroll 1
-    for (int b = 0; b < 2; ++b) {
-      const uint32_t q0 = b ? excl + c0 : excl, q1 = b ? excl + c0 + c1 : excl + c0;
-      uint32_t* slot = bucket + (2 * t + b) * MSM_PT_WORDS;
-      PtE acc = lds_load_pt(slot);
-      for (uint32_t q = q0; q < q1 && !(dbg & 1); ++q) {
-        uint32_t ent = list[q];
-        PtA pa = pta_load(pts + (base + (ent & 0x7fffffffu)) * PTA_WORDS);
-        acc = te_add_affine<SuiteBS>(acc, pa, (ent >> 31) != 0);
-      }
-      lds_store_pt(slot, acc);
-    }
-    __syncthreads();
   }
+  __syncthreads();
+  // 3. scatter into bucket order, transposed so that entry i of lane l sits at list[i*512 + l]
+  const uint32_t chunk = (m + MSM_BLOCK - 1) / MSM_BLOCK;
+  for (uint32_t j = t; j < cnt_all; j += MSM_BLOCK) {
+    int d = dig[j];
+    if (d != 0) {
+      uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+      uint32_t pos = atomicAdd(&cursor[b], 1u);
+      uint32_t lane = pos / chunk, i = pos - lane * chunk;
+      list[(size_t)i * MSM_BLOCK + lane] = j | (b << MSM_IDX_BITS) | (d < 0 ? 0x80000000u : 0u);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // 4. every lane folds its chunk; same trip count for all lanes
+  uint32_t head_b = MSM_NONE;
+  {
+    const uint32_t my0 = (uint32_t)t * chunk;
+    const uint32_t cnt = my0 >= m ? 0u : (m - my0 < chunk ? m - my0 : chunk);
+    PtE acc = te_identity();
+    uint32_t cur = MSM_NONE;
+    bool first_run = true;
+    uint32_t* myhead = heads + (size_t)t * MSM_PT_WORDS;
+    uint32_t ent_n = 0;
+    PtA pa_n = pta_identity();
+    if (cnt > 0) {
+      ent_n = list[t];
+      pa_n = pta_load(P + (size_t)(ent_n & MSM_IDX_MASK) * PTA_WORDS);
+    }
+#pragma unroll 1
+    for (uint32_t i = 0; i < chunk; ++i) {
+      if (i < cnt) {
+        const uint32_t ent = ent_n;
+        const PtA pa = pa_n;
+        if (i + 1 < cnt) {                       // prefetch the next entry and its point
+          ent_n = list[(size_t)(i + 1) * MSM_BLOCK + t];
+          pa_n = pta_load(P + (size_t)(ent_n & MSM_IDX_MASK) * PTA_WORDS);
+        }
+        const uint32_t b = (ent >> MSM_IDX_BITS) & (MSM_BUCKETS - 1);
+        if (b != cur) {
+          if (cur != MSM_NONE) {
+            if (first_run) { lds_store_pt(myhead, acc); head_b = cur; first_run = false; }
+            else lds_store_pt(bucket + cur * MSM_PT_WORDS, acc);
+          }
+          cur = b;
+          acc = te_identity();
+        }
+        acc = te_add_affine<S>(acc, pa, (ent >> 31) != 0);
+      }
+    }
+    if (cnt > 0) {
+      if (first_run) { lds_store_pt(myhead, acc); head_b = cur; }
+      else lds_store_pt(bucket + cur * MSM_PT_WORDS, acc);
+    }
+  }
+  cursor[t] = head_b;
+  __threadfence_block();
+  __syncthreads();
+  // 5. merge the heads: the first lane of each chain of equal head buckets adds the chain to the bucket
+  if (head_b != MSM_NONE && (t == 0 || cursor[t - 1] != head_b)) {
+    PtE h = lds_load_pt(heads + (size_t)t * MSM_PT_WORDS);
+    for (int k = t + 1; k < MSM_BLOCK && cursor[k] == head_b; ++k)
+      h = te_add<S>(h, lds_load_pt(heads + (size_t)k * MSM_PT_WORDS));
+    uint32_t* slot = bucket + head_b * MSM_PT_WORDS;
+    lds_store_pt(slot, te_add<S>(lds_load_pt(slot), h));
+  }
+  __syncthreads();
   // ---- bucket reduction: R = sum_j j*B_j over j = 1..1024, lane t holds B_{2t+1}, B_{2t+2} ----
   // S_t = B_{2t+1} + B_{2t+2};  L_t = S_t + B_{2t+2};  R = sum_t L_t + 2 sum_{t>=1} Suf_t,
   // Suf_t = sum_{u>=t} S_u.  The staging area re-uses the bucket storage, one slot per lane.
-  PtE S, V;
+  PtE Ssum, V;
   {
     PtE b1 = lds_load_pt(bucket + (2 * t + 1) * MSM_PT_WORDS);
-    S = te_add<SuiteBS>(lds_load_pt(bucket + (2 * t) * MSM_PT_WORDS), b1);
-    V = te_add<SuiteBS>(S, b1);                   // L_t
+    Ssum = te_add<S>(lds_load_pt(bucket + (2 * t) * MSM_PT_WORDS), b1);
+    V = te_add<S>(Ssum, b1);                      // L_t
   }
   __syncthreads();
   uint32_t* stage = lds;                          // [512][36]
   // pass 0: suffix scan of S (Hillis-Steele);  pass 1: tree reduction of V = L + 2*Suf
 #pragma unroll 1
-  for (int pass = 0; pass < 2 && !(dbg & 2); ++pass) {
-    PtE cur = pass == 0 ? S : V;
+  for (int pass = 0; pass < 2; ++pass) {
+    PtE cur = pass == 0 ? Ssum : V;
 #pragma unroll 1
     for (int k = 0; k < 9; ++k) {
       const int s = pass == 0 ? (1 << k) : (MSM_BLOCK >> (k + 1));
@@ -188,20 +203,22 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(size_t n, const uint3
       lds_store_pt(stage + t * MSM_PT_WORDS, cur);
       __syncthreads();
       const bool active = pass == 0 ? (t + s < MSM_BLOCK) : (t < s);
-      if (active) cur = te_add<SuiteBS>(cur, lds_load_pt(stage + (t + s) * MSM_PT_WORDS));
+      if (active) cur = te_add<S>(cur, lds_load_pt(stage + (t + s) * MSM_PT_WORDS));
     }
     if (pass == 0) {
-      if (t >= 1) V = te_add<SuiteBS>(V, te_dbl<SuiteBS>(cur, true));
+      if (t >= 1) V = te_add<S>(V, te_dbl<S>(cur, true));
     } else {
       V = cur;
     }
   }
-  if (t == 0) lds_store_pt(out + ((size_t)w * groups + g) * MSM_PT_WORDS, V);
+  if (t == 0) lds_store_pt(L.part + ((size_t)w * L.groups + g) * MSM_PT_WORDS, V);
 }
 
 // ------------------------------------------------------------------------------- final
+template <class S>
 __global__ void __launch_bounds__(64) k_msm_final(const uint32_t* part, int groups, uint8_t* out_enc,
-                                                   uint8_t* out_xy, const uint8_t* flags, uint8_t* status) {
+                                                   uint8_t* out_xy, const uint8_t* flags, uint8_t* status,
+                                                   uint8_t* fail_flag) {
   __shared__ uint32_t stage[32 * MSM_PT_WORDS];
   const int t = threadIdx.x;
   // lane w < 23: R_w = sum over groups, then 2^(11 w) * R_w by 11 w doublings (lanes run in lockstep,
@@ -210,9 +227,9 @@ __global__ void __launch_bounds__(64) k_msm_final(const uint32_t* part, int grou
   if (t < MSM_W) {
     acc = lds_load_pt(part + (size_t)t * groups * MSM_PT_WORDS);
     for (int g = 1; g < groups; ++g)
-      acc = te_add<SuiteBS>(acc, lds_load_pt(part + ((size_t)t * groups + g) * MSM_PT_WORDS));
+      acc = te_add<S>(acc, lds_load_pt(part + ((size_t)t * groups + g) * MSM_PT_WORDS));
     const int nd = MSM_C * t;
-    for (int j = 0; j < nd; ++j) acc = te_dbl<SuiteBS>(acc, j == nd - 1);
+    for (int j = 0; j < nd; ++j) acc = te_dbl<S>(acc, j == nd - 1);
   }
   // tree-sum of 32 lanes through LDS
 #pragma unroll 1
@@ -220,7 +237,7 @@ __global__ void __launch_bounds__(64) k_msm_final(const uint32_t* part, int grou
     __syncthreads();
     if (t < 32) lds_store_pt(stage + t * MSM_PT_WORDS, acc);
     __syncthreads();
-    if (t < s) acc = te_add<SuiteBS>(acc, lds_load_pt(stage + (t + s) * MSM_PT_WORDS));
+    if (t < s) acc = te_add<S>(acc, lds_load_pt(stage + (t + s) * MSM_PT_WORDS));
   }
   if (t == 0) {
     FeN x, y;
@@ -229,57 +246,94 @@ __global__ void __launch_bounds__(64) k_msm_final(const uint32_t* part, int grou
     te_encode_affine(e, x, y);
     fe_to_u256(xw, x); fe_to_u256(yw, y);
     bool bad = flags[0] != 0;
+    // neutral element: x == 0 and y == 1
+    uint32_t nz = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nz |= xw[j] | (yw[j] ^ (j == 0 ? 1u : 0u));
+    if (fail_flag && (nz != 0 || bad)) fail_flag[0] = 1;
     if (bad) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { e[j] = 0; xw[j] = 0; yw[j] = 0; }
     }
-    store32(out_enc, 0, e);
+    if (out_enc) store32(out_enc, 0, e);
     if (out_xy) {
       uint32_t* p = reinterpret_cast<uint32_t*>(out_xy);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { p[j] = xw[j]; p[8 + j] = yw[j]; }
     }
-    status[0] = bad ? ST_INVALID_DATA : ST_OK;
+    if (status) status[0] = bad ? ST_INVALID_DATA : ST_OK;
   }
 }
 
-size_t msm_workspace_bytes(size_t n, int groups) {
-  size_t pts = n * PTA_WORDS * 4, dig = (size_t)MSM_W * n * 2;
-  size_t lists = (size_t)MSM_W * groups * MSM_SLICE * 4, part = (size_t)MSM_W * groups * MSM_PT_WORDS * 4;
-  auto pad = [](size_t x) { return (x + 255) & ~size_t(255); };
-  return pad(pts) + pad(dig) + pad(lists) + pad(part) + 256;
-}
+// ------------------------------------------------------------------------------- host
+static size_t pad256(size_t x) { return (x + 255) & ~size_t(255); }
+
 int msm_groups(size_t n, int cus) {
-  // one workgroup per CU and window pass; at least one slice of work per group
+  // one workgroup per CU and window pass for mid-sized inputs; two rounds of workgroups for large
+  // inputs (the hardware dispatcher then evens out the tails); never more than 2^21 points per group
   int g = cus / MSM_W;
   if (g < 1) g = 1;
-  size_t max_g = (n + MSM_SLICE - 1) / MSM_SLICE;
+  if (n >= (size_t(1) << 22)) g *= 2;
+  size_t max_g = (n + 8191) / 8192;                       // at least 16 points per lane and group
   if ((size_t)g > max_g) g = (int)max_g;
   if (g < 1) g = 1;
+  size_t min_g = (n + MSM_MAX_PER_GROUP - 1) / MSM_MAX_PER_GROUP;
+  if ((size_t)g < min_g) g = (int)min_g;
   return g;
 }
 
-static bool g_msm_attr_set = false;
-void launch_msm(size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t* out_enc, uint8_t* out_xy,
-                uint8_t* status, void* ws, int groups, hipStream_t st) {
-  auto pad = [](size_t x) { return (x + 255) & ~size_t(255); };
+size_t msm_workspace_bytes(size_t n, int groups) {
+  size_t per_group = (n + groups - 1) / groups, list_cap = per_group + MSM_BLOCK, wgs = (size_t)MSM_W * groups;
+  return pad256(n * PTA_WORDS * 4) + pad256((size_t)MSM_W * n * 2) + pad256(wgs * list_cap * 4) +
+         pad256(wgs * MSM_BLOCK * MSM_PT_WORDS * 4) + pad256(wgs * MSM_PT_WORDS * 4) + 256;
+}
+
+MsmLayout msm_layout(size_t n, int groups, void* ws) {
+  MsmLayout L;
+  L.n = n;
+  L.groups = groups;
+  L.per_group = (n + groups - 1) / groups;
+  L.list_cap = L.per_group + MSM_BLOCK;
+  const size_t wgs = (size_t)MSM_W * groups;
   uint8_t* p = static_cast<uint8_t*>(ws);
-  uint32_t* pts = reinterpret_cast<uint32_t*>(p); p += pad(n * PTA_WORDS * 4);
-  int16_t* digits = reinterpret_cast<int16_t*>(p); p += pad((size_t)MSM_W * n * 2);
-  uint32_t* lists = reinterpret_cast<uint32_t*>(p); p += pad((size_t)MSM_W * groups * MSM_SLICE * 4);
-  uint32_t* part = reinterpret_cast<uint32_t*>(p); p += pad((size_t)MSM_W * groups * MSM_PT_WORDS * 4);
-  uint8_t* flags = p;
-  (void)hipMemsetAsync(flags, 0, 256, st);
-  hipLaunchKernelGGL(k_msm_prep, grid_for(n), dim3(BLOCK), 0, st, n, xy, scalars, pts, digits, flags);
-  size_t lds_bytes = ((size_t)MSM_BUCKETS * MSM_PT_WORDS + 2 * MSM_BUCKETS + 8) * 4;   // 155,680 B of 160 KiB
-  if (!g_msm_attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_buckets),
+  L.pts = reinterpret_cast<uint32_t*>(p); p += pad256(n * PTA_WORDS * 4);
+  L.digits = reinterpret_cast<int16_t*>(p); p += pad256((size_t)MSM_W * n * 2);
+  L.lists = reinterpret_cast<uint32_t*>(p); p += pad256(wgs * L.list_cap * 4);
+  L.heads = reinterpret_cast<uint32_t*>(p); p += pad256(wgs * MSM_BLOCK * MSM_PT_WORDS * 4);
+  L.part = reinterpret_cast<uint32_t*>(p); p += pad256(wgs * MSM_PT_WORDS * 4);
+  L.flags = p;
+  return L;
+}
+
+template <class S>
+static void launch_msm_core_t(const MsmLayout& L, uint8_t* out_enc, uint8_t* out_xy, uint8_t* status,
+                              uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev) {
+  const size_t lds_bytes = ((size_t)MSM_BUCKETS * MSM_PT_WORDS + 2 * MSM_BUCKETS + 16) * 4;   // 155,712 B of 160 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_buckets<S>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    g_msm_attr_set = true;
+    attr_set = true;
   }
-  hipLaunchKernelGGL(k_msm_buckets, dim3(MSM_W, groups), dim3(MSM_BLOCK), lds_bytes, st, n, pts, digits, lists,
-                     part, groups, getenv("VRFHIP_MSM_DBG") ? atoi(getenv("VRFHIP_MSM_DBG")) : 0);
-  hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, st, part, groups, out_enc, out_xy, flags, status);
+  hipLaunchKernelGGL(k_msm_buckets<S>, dim3(MSM_W * L.groups), dim3(MSM_BLOCK), lds_bytes, st, L);
+  if (ev) (void)hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(k_msm_final<S>, dim3(1), dim3(64), 0, st, L.part, L.groups, out_enc, out_xy, L.flags,
+                     status, fail_flag);
+  if (ev) { (void)hipEventRecord(ev[1], st); (void)hipEventRecord(ev[2], st); }
+}
+
+void launch_msm_core(int suite, const MsmLayout& L, uint8_t* out_enc, uint8_t* out_xy, uint8_t* status,
+                     uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev) {
+  VRF_DISPATCH_SUITE(suite, launch_msm_core_t<S>(L, out_enc, out_xy, status, fail_flag, st, ev));
+}
+
+void launch_msm(int suite, size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t* out_enc,
+                uint8_t* out_xy, uint8_t* status, void* ws, int groups, hipStream_t st) {
+  MsmLayout L = msm_layout(n, groups, ws);
+  (void)hipMemsetAsync(L.flags, 0, 256, st);
+  VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_msm_prep<S>, grid_for(n), dim3(BLOCK), 0, st, n, xy, scalars,
+                                               L.pts, L.digits, L.flags));
+  launch_msm_core(suite, L, out_enc, out_xy, status, nullptr, st);
 }
 
 }  // namespace vrf

@@ -1,0 +1,193 @@
+// k_rlc.hip -- batched Pedersen-VRF verification by random linear combination (SURVEY.md section 8
+// row f2): n proofs are checked with ONE multi-scalar multiplication instead of 4n scalar
+// multiplications.  Sits behind `pedersen::Verifier::verify` (/root/reference src/lib.rs:14) for callers
+// that verify whole batches.
+//
+// A Pedersen proof (pk_com, R, Ok, s, sb) for (H, Gamma) is valid iff, with c = challenge(pk_com, H,
+// Gamma, R, Ok, ad),
+//     D1 = s*H - c*Gamma - Ok = O      and      D2 = s*G + sb*B - c*pk_com - R = O.
+// c needs no curve arithmetic (every hashed point is part of the input), so for secret 128-bit weights
+// z_i, z'_i the single check  sum_i (z_i*D1_i + z'_i*D2_i) = O  accepts a batch containing an invalid
+// proof with probability <= 2^-128 (all points lie in the prime-order subgroup: the precondition of
+// every verify entry point).  That sum is an MSM over 5n variable points plus the two fixed bases:
+//     sum_i [ (z s)_i H_i - (z c)_i Gamma_i - (z' c)_i pk_com_i - z'_i R_i - z_i Ok_i ]
+//       + (sum_i z'_i s_i) G + (sum_i z'_i sb_i) B.
+//   k_rlc_decode : K proofs per lane share one inversion (5K decompression denominators); writes the
+//                  Montgomery affine-cached points and the signed window digits straight into the MSM
+//                  layout (point class p of proof i at index p*n + i); accumulates the two fixed-base
+//                  scalars as 64-bit limb columns (wave shuffles + one atomic per column and wave).
+//   k_rlc_fixed  : normalises the columns mod r and appends G and B with their digits.
+//   then k_msm_buckets / k_msm_final (k_msm.hip) and the verdict byte.
+// Weights: (z_i, z'_i) = the first two 16-byte little-endian halves of
+// SHA-512("vrfhip-rlc-v1" || seed[32] || u64_le(index of the proof in the caller's batch)); the seed
+// must be unpredictable to whoever produced the proofs.
+#include "kernels.h"
+#include "msm.cuh"
+
+namespace vrf {
+
+constexpr int RLC_SLOT = 4 * NL + 1;     // y | num | den | prefix | (flag, ok)
+
+template <class S>
+VRF_HD void rlc_weights(uint32_t z[8], uint32_t zp[8], const uint8_t* seed, uint64_t index) {
+  Sha512 h;
+  sha512_init(h);
+  constexpr char tag[] = "vrfhip-rlc-v1";
+#pragma unroll
+  for (int i = 0; i < 13; ++i) sha512_put_byte(h, (uint8_t)tag[i]);
+  sha512_put_bytes(h, seed, 32);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sha512_put_byte(h, (uint8_t)(index >> (8 * i)));
+  sha512_final(h);
+  uint32_t le[16];
+  sha512_le512(le, h);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { z[i] = le[i]; zp[i] = le[4 + i]; z[4 + i] = 0; zp[4 + i] = 0; }
+}
+
+template <class S>
+__global__ void __launch_bounds__(BLOCK) k_rlc_decode(RlcArgs a) {
+  const size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
+  const int K = a.k_lane;
+  const size_t n = a.n;
+  const size_t N = a.L.n;                                   // 5n + 2
+  uint64_t cols[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) cols[j] = 0;
+  if (first < n) {
+    // ---- phase a: y, y^2 - 1, d*y^2 - a of 5K points; running product of the denominators ----
+    FeN run = fe_one();
+#pragma unroll 1
+    for (int j = 0; j < 5 * K; ++j) {
+      const size_t item = first + j / 5;
+      const int p = j % 5;
+      if (item < n) {
+        const uint8_t* src = p == 0 ? a.h : p == 1 ? a.gamma : p == 2 ? a.pk_com : p == 3 ? a.r : a.ok;
+        uint32_t enc[8];
+        load32(enc, src, item);
+        DecodeA d = decode_phase_a<S>(enc);
+        uint32_t* slot = a.scratch + item * (size_t)a.scratch_stride + p * RLC_SLOT;
+        fe_store(slot, d.y);
+        fe_store(slot + NL, d.num);
+        fe_store(slot + 2 * NL, d.den);
+        fe_store(slot + 3 * NL, run);
+        slot[4 * NL] = (d.flag ? 1u : 0u) | (d.ok ? 2u : 0u);
+        run = fe_mul(run, d.den);
+      }
+    }
+    FeN inv = fe_inv(run);
+    uint32_t valid_mask = 0xffffffffu;
+    // ---- phase b: x by square root; Montgomery affine-cached point into the MSM layout ----
+#pragma unroll 1
+    for (int j = 5 * K - 1; j >= 0; --j) {
+      const size_t item = first + j / 5;
+      const int p = j % 5;
+      if (item < n) {
+        const uint32_t* slot = a.scratch + item * (size_t)a.scratch_stride + p * RLC_SLOT;
+        DecodeA d;
+        d.y = fe_load<1, 2>(slot);
+        d.num = fe_load<1, 6>(slot + NL);
+        d.den = fe_load<1, 2>(slot + 2 * NL);
+        FeN prefix = fe_load<1, 2>(slot + 3 * NL);
+        d.flag = slot[4 * NL] & 1u;
+        d.ok = (slot[4 * NL] >> 1) & 1u;
+        FeN di = fe_mul(inv, prefix);
+        inv = fe_mul(inv, d.den);
+        Fe<1, 4> x;
+        bool ok = decode_phase_b<S>(x, d, di, a.T.sq);
+        if (!ok) valid_mask &= ~(1u << (j / 5));
+        PtA pa;
+        pa.x = fe_mul(x, fe_one());
+        pa.y = d.y;
+        pa.dt = fe_mul(fe_mul(pa.x, pa.y), S::d());
+        pta_store(a.L.pts + ((size_t)p * n + item) * PTA_WORDS, pa);
+      }
+    }
+    // ---- challenge, weights, scalars, digits ----
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+      const size_t item = first + k;
+      if (item < n) {
+        uint32_t s[8], sb[8], cp[5][8];
+        load32(s, a.s, item); load32(sb, a.sb, item);
+        load32(cp[0], a.pk_com, item); load32(cp[1], a.h, item); load32(cp[2], a.gamma, item);
+        load32(cp[3], a.r, item); load32(cp[4], a.ok, item);
+        const bool valid = ((valid_mask >> k) & 1u) && fr_is_canonical<S>(s) && fr_is_canonical<S>(sb);
+        if (!valid) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s[j] = 0; sb[j] = 0; }
+        }
+        const uint8_t* adp; uint32_t adl;
+        bytes_get(a.ad, item, adp, adl);
+        uint32_t c[8], z[8], zp[8], t[8];
+        challenge5<S>(c, cp, adp, adl);
+        rlc_weights<S>(z, zp, a.seed, a.index0 + item);
+        fr_mul<S>(t, z, s);
+        msm_write_digits<S>(a.L.digits, N, 0 * n + item, t, false, !valid);     // + (z s) H
+        fr_mul<S>(t, z, c);
+        msm_write_digits<S>(a.L.digits, N, 1 * n + item, t, true, !valid);      // - (z c) Gamma
+        fr_mul<S>(t, zp, c);
+        msm_write_digits<S>(a.L.digits, N, 2 * n + item, t, true, !valid);      // - (z' c) pk_com
+        msm_write_digits<S>(a.L.digits, N, 3 * n + item, zp, true, !valid);     // - z' R
+        msm_write_digits<S>(a.L.digits, N, 4 * n + item, z, true, !valid);      // - z Ok
+        fr_mul<S>(t, zp, s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cols[j] += t[j];
+        fr_mul<S>(t, zp, sb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cols[8 + j] += t[j];
+        a.status[item] = (uint8_t)(valid ? ST_OK : ST_INVALID_DATA);
+      }
+    }
+  }
+  // fixed-base scalars: wave reduction of the limb columns, one atomic per column and wave
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    uint64_t v = cols[j];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_down(v, sft, 64);
+    if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.fixed_cols) + j, (unsigned long long)v);
+  }
+}
+
+// one lane: columns -> scalars mod r; G and B (entry 1*256^0 of the fixed-base combs) become points 5n, 5n+1
+template <class S>
+__global__ void k_rlc_fixed(RlcArgs a) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const size_t N = a.L.n;
+#pragma unroll 1
+  for (int f = 0; f < 2; ++f) {
+    uint32_t wide[16];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      uint64_t acc = (j < 8 ? a.fixed_cols[f * 8 + j] : 0) + carry;   // columns < 2^52, carry < 2^32
+      wide[j] = (uint32_t)acc;
+      carry = acc >> 32;
+    }
+    uint32_t k[8];
+    fr_reduce512<S>(k, wide);
+    const uint32_t* src = f == 0 ? a.T.g_comb : a.T.b_comb;
+    uint32_t* dst = a.L.pts + (5 * a.n + f) * PTA_WORDS;
+    for (int j = 0; j < PTA_WORDS; ++j) dst[j] = src[j];
+    msm_write_digits<S>(a.L.digits, N, 5 * a.n + f, k, false, false);
+  }
+}
+
+template <class S>
+static void launch_rlc_t(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev) {
+  (void)hipMemsetAsync(a.L.flags, 0, 256, st);
+  (void)hipMemsetAsync(a.fixed_cols, 0, 16 * sizeof(uint64_t), st);
+  if (ev) (void)hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(k_rlc_decode<S>, grid_for((a.n + a.k_lane - 1) / a.k_lane), dim3(BLOCK), 0, st, a);
+  hipLaunchKernelGGL(k_rlc_fixed<S>, dim3(1), dim3(64), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  launch_msm_core(a.suite, a.L, nullptr, nullptr, nullptr, fail_flag, st, ev ? ev + 2 : nullptr);
+}
+
+void launch_pedersen_rlc(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev) {
+  if (a.n == 0) return;
+  VRF_DISPATCH_SUITE(a.suite, launch_rlc_t<S>(a, fail_flag, st, ev));
+}
+
+}  // namespace vrf

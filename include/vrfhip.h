@@ -174,12 +174,39 @@ int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_
                                          const uint32_t* d_ad_off, uint32_t ad_len,
                                          uint8_t* d_status, void* stream);
 
+/* `pedersen::Verifier::verify` for a whole batch with ONE multi-scalar multiplication (random linear
+ * combination).  With c_i recomputed from the proof's own points, the batch is
+ * accepted iff  sum_i z_i (s_i H_i - c_i Gamma_i - Ok_i) + z'_i (s_i G + sb_i B - c_i pk_com_i - R_i)
+ * is the neutral element, (z_i, z'_i) = 2 x 128 bits of SHA-512("vrfhip-rlc-v1" || seed || u64_le(i)).
+ * `seed` (32 bytes, host memory) must be unpredictable to the provers (fresh randomness per call);
+ * a batch holding an invalid proof is then accepted with probability <= 2^-128.
+ *
+ * _dev form: enqueues the work and returns.  d_status[i] = 0 if proof i is part of the batch sum,
+ * 2 (InvalidData) if it does not decode (it is then left out of the sum).  d_fail_flag[0] = 0 if every
+ * proof with status 0 verifies, 1 if at least one does not (run vrfhip_pedersen_verify_batch_dev to
+ * find which).
+ * Host form: same inputs as vrfhip_pedersen_verify_batch and the same per-proof statuses: when the
+ * batch equation fails it re-runs the per-proof kernels.  *batch_ok (nullable) reports whether the
+ * single-MSM path sufficed. */
+int32_t vrfhip_pedersen_verify_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t* input,
+                                         const uint8_t* output, const uint8_t* pk_com, const uint8_t* r,
+                                         const uint8_t* ok, const uint8_t* s, const uint8_t* sb,
+                                         const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                         const uint8_t seed[32], uint8_t* status, int32_t* batch_ok);
+int32_t vrfhip_pedersen_verify_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_input,
+                                             const uint8_t* d_output, const uint8_t* d_pk_com,
+                                             const uint8_t* d_r, const uint8_t* d_ok, const uint8_t* d_s,
+                                             const uint8_t* d_sb, const uint8_t* d_ad,
+                                             const uint32_t* d_ad_off, uint32_t ad_len,
+                                             const uint8_t seed[32], uint8_t* d_status,
+                                             uint8_t* d_fail_flag, void* stream);
+
 /* Multi-scalar multiplication ---------------------------------------------------------- */
 
 /* `VariableBaseMSM::msm(bases, scalars)` on the suite curve (ark_ec, named in BASELINE.json;
  * reached through `reexports`, src/lib.rs:14): result = sum_i scalars[i] * bases[i].
  * bases_xy: n x 64 B affine points (x || y, 32-byte little-endian canonical each -- what
- * vrfhip_point_validate_batch emits); scalars: n x 32 B LE canonical.
+ * vrfhip_point_validate_batch emits); scalars: n x 32 B LE canonical.  Works for both suites.
  * out_point: 32 B compressed result; out_xy: 64 B affine result (may be NULL);
  * status: 1 byte, 0 = Ok, 2 = InvalidData (a coordinate >= q, a point off the curve, or a
  * scalar >= r; the outputs are then zeroed).  n = 0 gives the identity. */

@@ -687,6 +687,60 @@ void oracle_pedersen_prove_batch(size_t n, const uint8_t* sk, const uint8_t* msg
   j.o0 = gamma; j.o1 = proof160; j.o2 = blinding_out; j.o4 = h_out; j.st = status;
   run_batch(j, n, threads);
 }
+/* Batched Pedersen verification by random linear combination, the slow way:
+ * for every proof the two defects D1 = s*H - c*Gamma - Ok and D2 = s*G + sb*B - c*pk_com - R are
+ * computed by double-and-add, weighted by (z_i, z'_i) = the two little-endian 16-byte halves of
+ * SHA-512("vrfhip-rlc-v1" || seed || u64_le(index0 + i)) and summed.  status[i] = 0 (in the sum) or 2
+ * (undecodable: left out).  Returns 0 if the sum is the neutral element, else 1. */
+int oracle_pedersen_rlc_check(size_t n, const uint8_t* h, const uint8_t* gamma, const uint8_t* proof160,
+                              const uint8_t* ad, size_t ad_len, const uint8_t seed[32], uint64_t index0,
+                              uint8_t* status) {
+  ensure_init();
+  pt acc; pt_identity(&acc);
+  pt G, B; pt_from_affine(&G, &BS_GX_M, &BS_GY_M); pt_from_affine(&B, &BS_BX_M, &BS_BY_M);
+  for (size_t i = 0; i < n; ++i) {
+    const uint8_t* pr = proof160 + 160 * i;
+    uint64_t s[4], sb[4], c[4];
+    load_le(s, pr + 96); load_le(sb, pr + 128);
+    fp x, y; pt H, Gm, PC, R, Ok;
+    int ok = cmp4(s, FR.m) < 0 && cmp4(sb, FR.m) < 0;
+    ok = ok && point_decode(&x, &y, h + 32 * i);
+    if (ok) pt_from_affine(&H, &x, &y);
+    ok = ok && point_decode(&x, &y, gamma + 32 * i);
+    if (ok) pt_from_affine(&Gm, &x, &y);
+    ok = ok && point_decode(&x, &y, pr);
+    if (ok) pt_from_affine(&PC, &x, &y);
+    ok = ok && point_decode(&x, &y, pr + 32);
+    if (ok) pt_from_affine(&R, &x, &y);
+    ok = ok && point_decode(&x, &y, pr + 64);
+    if (ok) pt_from_affine(&Ok, &x, &y);
+    status[i] = ok ? 0 : 2;
+    if (!ok) continue;
+    uint8_t pts[5][32];
+    memcpy(pts[0], pr, 32); memcpy(pts[1], h + 32 * i, 32); memcpy(pts[2], gamma + 32 * i, 32);
+    memcpy(pts[3], pr + 32, 32); memcpy(pts[4], pr + 64, 32);
+    challenge(c, pts, ad, ad_len);
+    sha512_ctx hc; uint8_t dg[64], idx[8];
+    uint64_t gi = index0 + i;
+    for (int k = 0; k < 8; ++k) idx[k] = (uint8_t)(gi >> (8 * k));
+    sha512_init(&hc); sha512_update(&hc, "vrfhip-rlc-v1", 13); sha512_update(&hc, seed, 32);
+    sha512_update(&hc, idx, 8); sha512_final(&hc, dg);
+    uint64_t z[4] = {0, 0, 0, 0}, zp[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 8; ++k) {
+      z[0] |= (uint64_t)dg[k] << (8 * k); z[1] |= (uint64_t)dg[8 + k] << (8 * k);
+      zp[0] |= (uint64_t)dg[16 + k] << (8 * k); zp[1] |= (uint64_t)dg[24 + k] << (8 * k);
+    }
+    pt t0, t1, d1, d2, n0;
+    pt_mul(&t0, &H, s); pt_mul(&t1, &Gm, c); pt_neg(&n0, &t1); pt_add(&d1, &t0, &n0);
+    pt_neg(&n0, &Ok); pt_add(&d1, &d1, &n0);
+    pt_mul(&t0, &G, s); pt_mul(&t1, &B, sb); pt_add(&d2, &t0, &t1);
+    pt_mul(&t1, &PC, c); pt_neg(&n0, &t1); pt_add(&d2, &d2, &n0);
+    pt_neg(&n0, &R); pt_add(&d2, &d2, &n0);
+    pt_mul(&t0, &d1, z); pt_add(&acc, &acc, &t0);
+    pt_mul(&t0, &d2, zp); pt_add(&acc, &acc, &t0);
+  }
+  return pt_is_identity(&acc) ? 0 : 1;
+}
 /* [ark_ec VariableBaseMSM::msm] naive reference: sum_i k_i * P_i, affine x||y inputs (64 B LE each).
  * Returns 0 / 2 (coordinate >= q, off-curve point or scalar >= r). */
 int oracle_msm(size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t out_enc[32], uint8_t out_xy[64]) {

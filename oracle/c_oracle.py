@@ -33,6 +33,8 @@ def load() -> ctypes.CDLL:
         lib.oracle_pedersen_verify_batch.restype = None
         lib.oracle_pedersen_prove_batch.argtypes = [c_size_t, P, P, c_size_t, P, P, c_size_t, P, P, P, P, P, c_int]
         lib.oracle_pedersen_prove_batch.restype = None
+        lib.oracle_pedersen_rlc_check.argtypes = [c_size_t, P, P, P, P, c_size_t, P, ctypes.c_uint64, P]
+        lib.oracle_pedersen_rlc_check.restype = c_int
         lib.oracle_msm.argtypes = [c_size_t, P, P, P, P]
         lib.oracle_msm.restype = c_int
         lib.oracle_hash_to_curve.argtypes = [P, c_size_t, P]
@@ -120,6 +122,21 @@ def pedersen_verify_batch(h, gamma, pk_com, r, ok, s, sb, ad: bytes = b"", threa
     load().oracle_pedersen_verify_batch(n, arrs[0].ctypes.data, arrs[1].ctypes.data, proof.ctypes.data,
                                         adb.ctypes.data, len(ad), st.ctypes.data, threads)
     return st
+
+
+def pedersen_rlc_check(h, gamma, pk_com, r, ok, s, sb, seed: bytes, ad: bytes = b"", index0: int = 0):
+    """Batch equation of the random-linear-combination verifier, evaluated naively.
+    Returns (status, fail): status[i] in {0, 2}; fail = 1 if the weighted sum is not the identity."""
+    arrs = [_a(x).reshape(-1, 32) for x in (h, gamma, pk_com, r, ok, s, sb)]
+    n = arrs[0].shape[0]
+    proof = np.ascontiguousarray(np.concatenate(arrs[2:], axis=1))
+    st = np.empty(n, np.uint8)
+    adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
+    sd = np.frombuffer(bytes(seed), dtype=np.uint8)
+    assert sd.size == 32
+    fail = load().oracle_pedersen_rlc_check(n, arrs[0].ctypes.data, arrs[1].ctypes.data, proof.ctypes.data,
+                                            adb.ctypes.data, len(ad), sd.ctypes.data, index0, st.ctypes.data)
+    return st, int(fail)
 
 
 def msm(bases_xy, scalars):

@@ -390,6 +390,44 @@ def test_msm_full_size_2_20_linearity(ctx):
     assert out.cpu().numpy().tobytes() == want
 
 
+@pytest.mark.parametrize("shape", ["all_equal", "two_values", "short_128", "one_bucket_per_window"])
+def test_msm_skewed_digit_distributions(ctx, shape):
+    """Digit distributions that put long runs into few buckets (the balanced chunking splits them across
+    lanes) or leave the top windows empty: results still equal the naive sum."""
+    n = 6000
+    rnd = np.random.default_rng(77)
+    sk, pk = ctx.secret_from_seed_batch(rnd.integers(0, 256, (n, 8), dtype=np.uint8))
+    xy = _xy_of(ctx, pk)
+    k = np.zeros((n, 32), np.uint8)
+    if shape == "all_equal":
+        k[:] = np.frombuffer(int(R - 12345).to_bytes(32, "little"), np.uint8)
+    elif shape == "two_values":
+        k[::2] = np.frombuffer((0x0123456789abcdef0123456789abcdef0123456789abcdef01234567 % R).to_bytes(32, "little"), np.uint8)
+        k[1::2] = np.frombuffer((3).to_bytes(32, "little"), np.uint8)
+    elif shape == "short_128":
+        k[:, :16] = rnd.integers(0, 256, (n, 16), dtype=np.uint8)
+    else:
+        k[:, 0] = 1024 & 0xff; k[:, 1] = 1024 >> 8                # digit +1024 -> bucket 1023 of window 0 only
+    assert ctx.msm(xy, k) == co.msm(xy, k)
+
+
+def test_msm_jubjub_matches_naive_oracle():
+    from ark_ec_vrfs_amd import Context, JubJubSha512Tai
+    cj = Context(0, suite=JubJubSha512Tai)
+    co.set_suite(2)
+    try:
+        n = 3000
+        rnd = np.random.default_rng(9)
+        sk, pk = cj.secret_from_seed_batch(rnd.integers(0, 256, (n, 8), dtype=np.uint8))
+        st, xy = cj.point_validate_batch(pk, want_xy=True)
+        assert (st == 0).all()
+        k, _ = cj.secret_from_seed_batch(rnd.integers(0, 256, (n, 9), dtype=np.uint8), with_public=False)
+        assert cj.msm(xy, k) == co.msm(xy, k)
+    finally:
+        co.set_suite(1)
+        cj.close()
+
+
 def test_affine_input_verify_matches_compressed(ctx, synth):
     n = 1024
     sk, msg = synth(n, start=91000)
