@@ -23,6 +23,7 @@ SYMBOLS = [
     "vrfhip_pedersen_prove_batch", "vrfhip_pedersen_prove_batch_dev",
     "vrfhip_pedersen_verify_batch", "vrfhip_pedersen_verify_batch_dev",
     "vrfhip_pedersen_verify_batch_rlc", "vrfhip_pedersen_verify_batch_rlc_dev",
+    "vrfhip_pedersen_verify_batch_rlc_affine", "vrfhip_pedersen_verify_batch_rlc_affine_dev",
     "vrfhip_msm", "vrfhip_msm_dev",
     "vrfhip_pairing_check_batch", "vrfhip_pairing_check_batch_dev",
     "vrfhip_hash_to_curve_batch", "vrfhip_hash_to_curve_batch_dev",
@@ -89,6 +90,8 @@ def load() -> ctypes.CDLL:
                                                      POINTER(c_int32)]
     lib.vrfhip_pedersen_verify_batch_rlc_dev.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, P, P, c_uint32,
                                                          P, P, P, c_void_p]
+    lib.vrfhip_pedersen_verify_batch_rlc_affine.argtypes = lib.vrfhip_pedersen_verify_batch_rlc.argtypes
+    lib.vrfhip_pedersen_verify_batch_rlc_affine_dev.argtypes = lib.vrfhip_pedersen_verify_batch_rlc_dev.argtypes
     lib.vrfhip_msm.argtypes = [c_void_p, c_size_t, P, P, P, P, P]
     lib.vrfhip_msm_dev.argtypes = [c_void_p, c_size_t, P, P, P, P, P, c_void_p]
     lib.vrfhip_pairing_check_batch.argtypes = [c_void_p, c_size_t, P, P, c_int32, P]

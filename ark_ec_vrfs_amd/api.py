@@ -244,13 +244,17 @@ class Context:
             "vrfhip_pedersen_verify_batch")
         return status
 
-    def pedersen_verify_batch_rlc(self, inp, out, pk_com, r, ok, s, sb, ad=b"", seed: Optional[bytes] = None):
+    def pedersen_verify_batch_rlc(self, inp, out, pk_com, r, ok, s, sb, ad=b"", seed: Optional[bytes] = None,
+                                  affine: bool = False):
         """`pedersen::Verifier::verify` for a whole batch through one MSM (random linear combination).
         Returns (status, batch_ok): the same per-proof statuses as pedersen_verify_batch; batch_ok tells
         whether the single-MSM path sufficed (False: the per-proof kernels were run to locate failures).
-        seed: 32 secret random bytes (default os.urandom)."""
+        seed: 32 secret random bytes (default os.urandom).  affine: the five point arrays are (n, 64)
+        x || y little-endian (arkworks `Affine`) instead of compressed encodings."""
         import os
-        arrs = [np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (inp, out, pk_com, r, ok, s, sb)]
+        pw = 64 if affine else 32
+        arrs = [np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, pw) for x in (inp, out, pk_com, r, ok)]
+        arrs += [np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (s, sb)]
         n = arrs[0].shape[0]
         if not all(x.shape[0] == n for x in arrs):
             raise ValueError("ragged batch")
@@ -258,19 +262,20 @@ class Context:
         status = np.empty(n, dtype=np.uint8)
         blob, off, ad_len = self._ad_args(ad, n)
         okf = ctypes.c_int32(0)
-        _lib.check(self._lib.vrfhip_pedersen_verify_batch_rlc(
-            self._h, n, *[_ptr(x) for x in arrs], _ptr(blob), _ptr(off), ad_len, _ptr(seed_a), _ptr(status),
-            ctypes.byref(okf)), "vrfhip_pedersen_verify_batch_rlc")
+        fn = self._lib.vrfhip_pedersen_verify_batch_rlc_affine if affine else self._lib.vrfhip_pedersen_verify_batch_rlc
+        _lib.check(fn(self._h, n, *[_ptr(x) for x in arrs], _ptr(blob), _ptr(off), ad_len, _ptr(seed_a), _ptr(status),
+                      ctypes.byref(okf)), "vrfhip_pedersen_verify_batch_rlc")
         return status, bool(okf.value)
 
     def pedersen_verify_batch_rlc_dev(self, inp, out, pk_com, r, ok, s, sb, status, fail_flag, seed: bytes,
-                                      ad=None, ad_off=None, ad_len=0, stream=None):
+                                      ad=None, ad_off=None, ad_len=0, stream=None, affine: bool = False):
         """Device-pointer form: status[i] in {0, 2}; fail_flag[0] = 1 if the batch equation fails."""
         import torch
         st = torch.cuda.current_stream().cuda_stream if stream is None else stream
         dp = lambda t: None if t is None else t.data_ptr()
         seed_a = _np_u8(seed, 32)
-        _lib.check(self._lib.vrfhip_pedersen_verify_batch_rlc_dev(
+        fn = self._lib.vrfhip_pedersen_verify_batch_rlc_affine_dev if affine else self._lib.vrfhip_pedersen_verify_batch_rlc_dev
+        _lib.check(fn(
             self._h, inp.shape[0], inp.data_ptr(), out.data_ptr(), pk_com.data_ptr(), r.data_ptr(), ok.data_ptr(),
             s.data_ptr(), sb.data_ptr(), dp(ad), dp(ad_off), ad_len, _ptr(seed_a), status.data_ptr(),
             fail_flag.data_ptr(), st), "vrfhip_pedersen_verify_batch_rlc_dev")

@@ -636,13 +636,15 @@ int32_t vrfhip_pedersen_verify_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* i
 }
 
 // ------------------------------------------------------------------------- Pedersen verify, batched (RLC)
-int32_t vrfhip_pedersen_verify_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_input,
-                                             const uint8_t* d_output, const uint8_t* d_pk_com,
-                                             const uint8_t* d_r, const uint8_t* d_ok, const uint8_t* d_s,
-                                             const uint8_t* d_sb, const uint8_t* d_ad,
-                                             const uint32_t* d_ad_off, uint32_t ad_len,
-                                             const uint8_t seed[32], uint8_t* d_status,
-                                             uint8_t* d_fail_flag, void* stream) {
+}  // extern "C"
+namespace {
+int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_input,
+                     const uint8_t* d_output, const uint8_t* d_pk_com,
+                     const uint8_t* d_r, const uint8_t* d_ok, const uint8_t* d_s,
+                     const uint8_t* d_sb, const uint8_t* d_ad,
+                     const uint32_t* d_ad_off, uint32_t ad_len,
+                     const uint8_t seed[32], uint8_t* d_status,
+                     uint8_t* d_fail_flag, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (!d_fail_flag || !seed) return fail(VRFHIP_ERR_BAD_ARG, "NULL fail flag or seed");
   if (n && (!d_input || !d_output || !d_pk_com || !d_r || !d_ok || !d_s || !d_sb || !d_status))
@@ -657,7 +659,7 @@ int32_t vrfhip_pedersen_verify_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const ui
   if (rc) return rc;
   {
     size_t m = std::min(ctx->ws_cap, n), N = 5 * m + 2;
-    rc = ensure_msm_workspace(ctx, msm_workspace_bytes(N, msm_groups(N, ctx->cus)));
+    rc = ensure_msm_workspace(ctx, msm_workspace_bytes(N, msm_groups(N, 3 * m + 2, ctx->cus)));
     if (rc) return rc;
   }
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
@@ -667,13 +669,15 @@ int32_t vrfhip_pedersen_verify_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const ui
     a.k_lane = lanes_k(m, 8);
     a.n = m;
     a.index0 = base;
-    a.h = d_input + base * 32; a.gamma = d_output + base * 32; a.pk_com = d_pk_com + base * 32;
-    a.r = d_r + base * 32; a.ok = d_ok + base * 32; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
+    const size_t pw = affine ? 64 : 32;
+    a.h = d_input + base * pw; a.gamma = d_output + base * pw; a.pk_com = d_pk_com + base * pw;
+    a.r = d_r + base * pw; a.ok = d_ok + base * pw; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
+    a.affine_in = affine ? 1 : 0;
     a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
     a.status = d_status + base;
     a.scratch = ctx->ws.tabs;
     a.scratch_stride = WS_TABS * WIN_TABLE_WORDS;
-    a.L = msm_layout(N, msm_groups(N, ctx->cus), ctx->d_msm_ws);
+    a.L = msm_layout(N, 3 * m + 2, msm_groups(N, 3 * m + 2, ctx->cus), ctx->d_msm_ws);
     a.fixed_cols = reinterpret_cast<uint64_t*>(a.L.flags + 128);
     a.T = ctx->T;
     std::memcpy(a.seed, seed, 32);
@@ -683,11 +687,11 @@ int32_t vrfhip_pedersen_verify_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const ui
   return VRFHIP_SUCCESS;
 }
 
-int32_t vrfhip_pedersen_verify_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t* input,
-                                         const uint8_t* output, const uint8_t* pk_com, const uint8_t* r,
-                                         const uint8_t* ok, const uint8_t* s, const uint8_t* sb,
-                                         const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
-                                         const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
+int32_t rlc_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* input,
+                      const uint8_t* output, const uint8_t* pk_com, const uint8_t* r,
+                      const uint8_t* ok, const uint8_t* s, const uint8_t* sb,
+                      const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                      const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (!seed) return fail(VRFHIP_ERR_BAD_ARG, "seed is NULL");
   if (batch_ok) *batch_ok = 1;
@@ -698,15 +702,18 @@ int32_t vrfhip_pedersen_verify_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_
   size_t adb = blob_bytes(n, ad_off, ad_len, true);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  size_t need = 7 * Stage::pad(n * 32) + Stage::pad(adb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n) + 256;
+  const size_t pw = affine ? 64 : 32;
+  size_t need = 5 * Stage::pad(n * pw) + (affine ? 5 : 0) * Stage::pad(n * 32) + 2 * Stage::pad(n * 32) +
+                Stage::pad(adb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n) + 256;
   int32_t rc = ensure_stage(ctx, need);
   if (rc) return rc;
   Stage sg(ctx->d_stage);
   const uint8_t* src[7] = {input, output, pk_com, r, ok, s, sb};
   uint8_t* d[7];
   for (int i = 0; i < 7; ++i) {
-    d[i] = sg.take(n * 32);
-    HIP_TRY(hipMemcpyAsync(d[i], src[i], n * 32, hipMemcpyHostToDevice, ctx->stream));
+    const size_t w = i < 5 ? pw : 32;
+    d[i] = sg.take(n * w);
+    HIP_TRY(hipMemcpyAsync(d[i], src[i], n * w, hipMemcpyHostToDevice, ctx->stream));
   }
   uint8_t* d_ad = sg.take(adb + 1);
   uint32_t* d_off = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
@@ -714,22 +721,76 @@ int32_t vrfhip_pedersen_verify_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_
   uint8_t* d_flag = sg.take(1);
   if (adb) HIP_TRY(hipMemcpyAsync(d_ad, ad, adb, hipMemcpyHostToDevice, ctx->stream));
   if (ad_off) HIP_TRY(hipMemcpyAsync(d_off, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  rc = vrfhip_pedersen_verify_batch_rlc_dev(ctx, n, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d_ad,
-                                            ad_off ? d_off : nullptr, ad_len, seed, d_st, d_flag, ctx->stream);
+  rc = rlc_dev_impl(ctx, n, affine, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d_ad,
+                    ad_off ? d_off : nullptr, ad_len, seed, d_st, d_flag, ctx->stream);
   if (rc) return rc;
   uint8_t flag = 0;
   HIP_TRY(hipMemcpyAsync(&flag, d_flag, 1, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (flag) {
-    // some proof in the batch is wrong: the per-proof kernels say which
+    // some proof in the batch is wrong: the per-proof kernels say which.  Items the batch stage already
+    // rejected as InvalidData keep that status (an off-curve affine point has no compressed form).
     if (batch_ok) *batch_ok = 0;
+    if (affine) {
+      for (int i = 0; i < 5; ++i) {
+        uint8_t* enc = sg.take(n * 32);
+        launch_affine_compress(n, d[i], enc, ctx->stream);
+        d[i] = enc;
+      }
+    }
     rc = vrfhip_pedersen_verify_batch_dev(ctx, n, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d_ad,
                                           ad_off ? d_off : nullptr, ad_len, d_st, ctx->stream);
     if (rc) return rc;
+    std::vector<uint8_t> item(n);
+    HIP_TRY(hipMemcpyAsync(item.data(), d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < n; ++i)
+      if (status[i] != VRFHIP_ST_INVALID_DATA) status[i] = item[i];
   }
-  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
   return VRFHIP_SUCCESS;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t vrfhip_pedersen_verify_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_input,
+                                             const uint8_t* d_output, const uint8_t* d_pk_com,
+                                             const uint8_t* d_r, const uint8_t* d_ok, const uint8_t* d_s,
+                                             const uint8_t* d_sb, const uint8_t* d_ad,
+                                             const uint32_t* d_ad_off, uint32_t ad_len,
+                                             const uint8_t seed[32], uint8_t* d_status,
+                                             uint8_t* d_fail_flag, void* stream) {
+  return rlc_dev_impl(ctx, n, false, d_input, d_output, d_pk_com, d_r, d_ok, d_s, d_sb, d_ad, d_ad_off, ad_len,
+                      seed, d_status, d_fail_flag, stream);
+}
+int32_t vrfhip_pedersen_verify_batch_rlc_affine_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_input_xy,
+                                                    const uint8_t* d_output_xy, const uint8_t* d_pk_com_xy,
+                                                    const uint8_t* d_r_xy, const uint8_t* d_ok_xy,
+                                                    const uint8_t* d_s, const uint8_t* d_sb,
+                                                    const uint8_t* d_ad, const uint32_t* d_ad_off,
+                                                    uint32_t ad_len, const uint8_t seed[32],
+                                                    uint8_t* d_status, uint8_t* d_fail_flag, void* stream) {
+  return rlc_dev_impl(ctx, n, true, d_input_xy, d_output_xy, d_pk_com_xy, d_r_xy, d_ok_xy, d_s, d_sb, d_ad,
+                      d_ad_off, ad_len, seed, d_status, d_fail_flag, stream);
+}
+int32_t vrfhip_pedersen_verify_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t* input,
+                                         const uint8_t* output, const uint8_t* pk_com, const uint8_t* r,
+                                         const uint8_t* ok, const uint8_t* s, const uint8_t* sb,
+                                         const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                         const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
+  return rlc_host_impl(ctx, n, false, input, output, pk_com, r, ok, s, sb, ad, ad_off, ad_len, seed, status,
+                       batch_ok);
+}
+int32_t vrfhip_pedersen_verify_batch_rlc_affine(vrfhip_ctx* ctx, size_t n, const uint8_t* input_xy,
+                                                const uint8_t* output_xy, const uint8_t* pk_com_xy,
+                                                const uint8_t* r_xy, const uint8_t* ok_xy, const uint8_t* s,
+                                                const uint8_t* sb, const uint8_t* ad, const uint32_t* ad_off,
+                                                uint32_t ad_len, const uint8_t seed[32], uint8_t* status,
+                                                int32_t* batch_ok) {
+  return rlc_host_impl(ctx, n, true, input_xy, output_xy, pk_com_xy, r_xy, ok_xy, s, sb, ad, ad_off, ad_len,
+                       seed, status, batch_ok);
 }
 
 // ------------------------------------------------------------------------- MSM
@@ -751,7 +812,7 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
     HIP_TRY(hipStreamSynchronize(st));     // the sources above are stack buffers
     return VRFHIP_SUCCESS;
   }
-  int groups = msm_groups(n, ctx->cus);
+  int groups = msm_groups(n, n, ctx->cus);
   int32_t rc = ensure_msm_workspace(ctx, msm_workspace_bytes(n, groups));
   if (rc) return rc;
   launch_msm((int)ctx->suite, n, d_bases_xy, d_scalars, d_out_point, d_out_xy, d_status, ctx->d_msm_ws, groups, st);

@@ -327,36 +327,31 @@ VRF_HD Fe<1, 4> fe_from_u512(const uint32_t w[16]) {
 }
 
 // ------------------------------------------------------------------ fixed exponentiation
-// x^e for a compile-time exponent (little-endian u32 words).  The exponent is uniform across
-// the wave, so the 3-bit window loop is scalar control flow: no divergence.
-template <int NBITS>
-VRF_HD FeN fe_pow_const(const FeN& x, const uint32_t (&e)[8]) {
+// x^e by a generated sliding-window program (constants.gen.h POW_*_PROG, tools/gen_constants.py): word 0
+// selects the start value among the odd powers x^1..x^15, every later word is (squarings << 4) | index of
+// the odd power to multiply by (15 = none).  The program is the same for every lane: scalar control flow.
+// x^(q-2): 253 squarings + 60 multiplications; x^((t-1)/2): 220 + 52 (fixed 3-bit windows took 85 / 80).
+template <int LEN>
+VRF_HD FeN fe_pow_prog(const FeN& x, const uint16_t (&prog)[LEN]) {
   FeN t[8];
-  t[1] = x;
-  t[2] = fe_sqr(x);
+  t[0] = x;
+  const FeN x2 = fe_sqr(x);
 #pragma unroll
-  for (int i = 3; i < 8; ++i) t[i] = fe_mul(t[i - 1], x);
-  constexpr int NW = (NBITS + 2) / 3;
-  FeN acc = fe_one();
-  bool started = false;
-  for (int w = NW - 1; w >= 0; --w) {
-    const int bit = 3 * w;
-    uint32_t d = (e[bit >> 5] >> (bit & 31));
-    if ((bit & 31) > 29 && (bit >> 5) + 1 < 8) d |= e[(bit >> 5) + 1] << (32 - (bit & 31));
-    d &= 7;
-    if (started) {
-      acc = fe_sqr(acc);
-      acc = fe_sqr(acc);
-      acc = fe_sqr(acc);
-    }
-    if (d != 0) {
-      FeN s = t[1];
+  for (int i = 1; i < 8; ++i) t[i] = fe_mul(t[i - 1], x2);
+  auto pick = [&](uint32_t idx) {
+    FeN s = t[0];
 #pragma unroll
-      for (int j = 2; j < 8; ++j)
-        if (d == (uint32_t)j) s = t[j];
-      acc = started ? fe_mul(acc, s) : s;
-      started = true;
-    }
+    for (int j = 1; j < 8; ++j)
+      if (idx == (uint32_t)j) s = t[j];
+    return s;
+  };
+  FeN acc = pick(prog[0] & 15u);
+#pragma unroll 1
+  for (int i = 1; i < LEN; ++i) {
+    const uint32_t op = prog[i], nsq = op >> 4, idx = op & 15u;
+#pragma unroll 1
+    for (uint32_t k = 0; k < nsq; ++k) acc = fe_sqr(acc);
+    if (idx != 15u) acc = fe_mul(acc, pick(idx));
   }
   return acc;
 }
@@ -364,13 +359,13 @@ VRF_HD FeN fe_pow_const(const FeN& x, const uint32_t (&e)[8]) {
 template <int L, int V>
 VRF_HD FeN fe_inv(const Fe<L, V>& a) {   // a^(q-2); 0 -> 0
   FeN x = fe_mul(a, fe_one());
-  return fe_pow_const<255>(x, vrfk::EXP_INV);
+  return fe_pow_prog(x, vrfk::POW_INV_PROG);
 }
 
 // ------------------------------------------------------------------ square root
 // Table-driven Tonelli-Shanks for 2-adicity 32.  tbl = SQRT_P (4 x 256 x 9 words, h^(j 2^(8k))),
 // lut = SQRT_LUT.  Returns is_square(w) and sets `root` to sqrt(w) if w is a square, else to
-// sqrt(Z*w) (Z = 5, the suite's Elligator non-residue).  Constant shape: 222 + 24 squarings.
+// sqrt(Z*w) (Z = 5, the suite's Elligator non-residue).  Constant shape: 220 + 24 squarings.
 struct SqrtTables {
   const uint32_t* P;     // [4][256][9]
   const uint8_t* lut;    // [1 << SQRT_LUT_BITS]
@@ -388,7 +383,7 @@ VRF_HD FeN sqrt_tbl(const SqrtTables& T, int k, uint32_t j) {
 template <int L, int V>
 VRF_HD bool fe_sqrt_or_zsqrt(FeN& root, const Fe<L, V>& w_in, const SqrtTables& T) {
   FeN w = fe_mul(w_in, fe_one());
-  FeN v = fe_pow_const<222>(w, vrfk::EXP_SQRT);     // w^((t-1)/2)
+  FeN v = fe_pow_prog(w, vrfk::POW_SQRT_PROG);        // w^((t-1)/2)
   FeN x0 = fe_mul(w, v);                            // w^((t+1)/2)
   FeN b = fe_mul(x0, v);                            // w^t, in the 2^32-torsion
   FeN b8 = b;

@@ -70,10 +70,15 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
   uint32_t* cursor = counts + MSM_BUCKETS;                  // [1024] scatter cursors, later head bucket ids
   uint32_t* wsum = cursor + MSM_BUCKETS;                    // [8] per-wave totals for the block scan
   const int t = threadIdx.x;
-  // top windows first: their results wait longest in k_msm_final
-  const int wg = blockIdx.x, w = MSM_W - 1 - wg / L.groups, g = wg % L.groups;
-  const size_t lo = (size_t)g * L.per_group;
-  const size_t hi = lo + L.per_group < L.n ? lo + L.per_group : L.n;
+  // low windows (all points) first, then the high windows (only the points with full-size scalars)
+  const int wg = blockIdx.x;
+  const int n_lo_wgs = MSM_W_SHORT * L.groups;
+  const bool low = wg < n_lo_wgs;
+  const int w = low ? wg / L.groups : MSM_W_SHORT + (wg - n_lo_wgs) / L.groups_hi;
+  const int g = low ? wg % L.groups : (wg - n_lo_wgs) % L.groups_hi;
+  const size_t span = low ? L.per_group : L.per_group_hi, end = low ? L.n : L.n_long;
+  const size_t lo = (size_t)g * span;
+  const size_t hi = lo + span < end ? lo + span : end;
   const uint32_t cnt_all = lo < hi ? (uint32_t)(hi - lo) : 0u;
   const int16_t* dig = L.digits + (size_t)w * L.n + lo;
   const uint32_t* P = L.pts + lo * PTA_WORDS;
@@ -216,7 +221,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
 
 // ------------------------------------------------------------------------------- final
 template <class S>
-__global__ void __launch_bounds__(64) k_msm_final(const uint32_t* part, int groups, uint8_t* out_enc,
+__global__ void __launch_bounds__(64) k_msm_final(const uint32_t* part, int groups, int groups_hi, uint8_t* out_enc,
                                                    uint8_t* out_xy, const uint8_t* flags, uint8_t* status,
                                                    uint8_t* fail_flag) {
   __shared__ uint32_t stage[32 * MSM_PT_WORDS];
@@ -225,8 +230,9 @@ __global__ void __launch_bounds__(64) k_msm_final(const uint32_t* part, int grou
   // the critical path is the top window's 242 doublings instead of a serial 253-doubling Horner)
   PtE acc = te_identity();
   if (t < MSM_W) {
+    const int ng = t < MSM_W_SHORT ? groups : groups_hi;
     acc = lds_load_pt(part + (size_t)t * groups * MSM_PT_WORDS);
-    for (int g = 1; g < groups; ++g)
+    for (int g = 1; g < ng; ++g)
       acc = te_add<S>(acc, lds_load_pt(part + ((size_t)t * groups + g) * MSM_PT_WORDS));
     const int nd = MSM_C * t;
     for (int j = 0; j < nd; ++j) acc = te_dbl<S>(acc, j == nd - 1);
@@ -268,13 +274,25 @@ __global__ void __launch_bounds__(64) k_msm_final(const uint32_t* part, int grou
 // ------------------------------------------------------------------------------- host
 static size_t pad256(size_t x) { return (x + 255) & ~size_t(255); }
 
-int msm_groups(size_t n, int cus) {
-  // one workgroup per CU and window pass for mid-sized inputs; two rounds of workgroups for large
-  // inputs (the hardware dispatcher then evens out the tails); never more than 2^21 points per group
-  int g = cus / MSM_W;
+// high-window groups for `groups` low-window groups: proportional to the share of full-size scalars
+static int msm_groups_hi(size_t n, size_t n_long, int groups) {
+  if (n_long >= n) return groups;
+  int gh = (int)(((double)n_long / (double)n) * groups + 0.5);
+  size_t min_g = (n_long + MSM_MAX_PER_GROUP - 1) / MSM_MAX_PER_GROUP;
+  if ((size_t)gh < min_g) gh = (int)min_g;
+  return gh < 1 ? 1 : gh;
+}
+
+int msm_groups(size_t n, size_t n_long, int cus) {
+  // Workgroups = 12*g + 11*g_hi, each with the whole CU's LDS: aim at one full round of the chip for
+  // mid-sized inputs and two for large ones (the dispatcher evens out the tails), at least 16 points per
+  // lane and group, never more than 2^21 points per group.
+  const int rounds = n >= (size_t(1) << 22) ? 2 : 1;
+  const double share = n ? (double)n_long / (double)n : 1.0;
+  int g = (int)(rounds * cus / (MSM_W_SHORT + (MSM_W - MSM_W_SHORT) * share));
   if (g < 1) g = 1;
-  if (n >= (size_t(1) << 22)) g *= 2;
-  size_t max_g = (n + 8191) / 8192;                       // at least 16 points per lane and group
+  while (g > 1 && MSM_W_SHORT * g + (MSM_W - MSM_W_SHORT) * msm_groups_hi(n, n_long, g) > rounds * cus) --g;
+  size_t max_g = (n + 8191) / 8192;
   if ((size_t)g > max_g) g = (int)max_g;
   if (g < 1) g = 1;
   size_t min_g = (n + MSM_MAX_PER_GROUP - 1) / MSM_MAX_PER_GROUP;
@@ -283,16 +301,27 @@ int msm_groups(size_t n, int cus) {
 }
 
 size_t msm_workspace_bytes(size_t n, int groups) {
+  // sized for the worst case groups_hi == groups
   size_t per_group = (n + groups - 1) / groups, list_cap = per_group + MSM_BLOCK, wgs = (size_t)MSM_W * groups;
   return pad256(n * PTA_WORDS * 4) + pad256((size_t)MSM_W * n * 2) + pad256(wgs * list_cap * 4) +
          pad256(wgs * MSM_BLOCK * MSM_PT_WORDS * 4) + pad256(wgs * MSM_PT_WORDS * 4) + 256;
 }
 
-MsmLayout msm_layout(size_t n, int groups, void* ws) {
+MsmLayout msm_layout(size_t n, size_t n_long, int groups, void* ws) {
   MsmLayout L;
   L.n = n;
+  L.n_long = n_long < n ? n_long : n;
   L.groups = groups;
+  L.groups_hi = msm_groups_hi(n, L.n_long, groups);
+  if (L.groups_hi > groups) L.groups_hi = groups;
   L.per_group = (n + groups - 1) / groups;
+  L.per_group_hi = (L.n_long + L.groups_hi - 1) / L.groups_hi;
+  // groups_hi rounds to nearest, so a high-window group can be slightly larger than a low-window one;
+  // the list capacity was sized for per_group: keep within it
+  while (L.per_group_hi > L.per_group && L.groups_hi < groups) {
+    ++L.groups_hi;
+    L.per_group_hi = (L.n_long + L.groups_hi - 1) / L.groups_hi;
+  }
   L.list_cap = L.per_group + MSM_BLOCK;
   const size_t wgs = (size_t)MSM_W * groups;
   uint8_t* p = static_cast<uint8_t*>(ws);
@@ -315,9 +344,10 @@ static void launch_msm_core_t(const MsmLayout& L, uint8_t* out_enc, uint8_t* out
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_msm_buckets<S>, dim3(MSM_W * L.groups), dim3(MSM_BLOCK), lds_bytes, st, L);
+  const int wgs = MSM_W_SHORT * L.groups + (MSM_W - MSM_W_SHORT) * L.groups_hi;
+  hipLaunchKernelGGL(k_msm_buckets<S>, dim3(wgs), dim3(MSM_BLOCK), lds_bytes, st, L);
   if (ev) (void)hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(k_msm_final<S>, dim3(1), dim3(64), 0, st, L.part, L.groups, out_enc, out_xy, L.flags,
+  hipLaunchKernelGGL(k_msm_final<S>, dim3(1), dim3(64), 0, st, L.part, L.groups, L.groups_hi, out_enc, out_xy, L.flags,
                      status, fail_flag);
   if (ev) { (void)hipEventRecord(ev[1], st); (void)hipEventRecord(ev[2], st); }
 }
@@ -329,7 +359,7 @@ void launch_msm_core(int suite, const MsmLayout& L, uint8_t* out_enc, uint8_t* o
 
 void launch_msm(int suite, size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t* out_enc,
                 uint8_t* out_xy, uint8_t* status, void* ws, int groups, hipStream_t st) {
-  MsmLayout L = msm_layout(n, groups, ws);
+  MsmLayout L = msm_layout(n, n, groups, ws);
   (void)hipMemsetAsync(L.flags, 0, 256, st);
   VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_msm_prep<S>, grid_for(n), dim3(BLOCK), 0, st, n, xy, scalars,
                                                L.pts, L.digits, L.flags));

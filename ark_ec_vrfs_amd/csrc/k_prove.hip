@@ -146,9 +146,17 @@ static void launch_prove_t(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
   hipLaunchKernelGGL(k_prove_finish<S>, grid_for((a.n + a.k_lane - 1) / a.k_lane), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[4], st);
 }
+// This file is compiled once per suite (Makefile: -DVRF_PROVE_SUITE=1|2 -> k_prove_bs.o, k_prove_jj.o) so
+// that the two sets of kernels build in parallel; the dispatcher lives in the Bandersnatch object.
+#if VRF_PROVE_SUITE == 2
+void launch_ietf_prove_jj(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) { launch_prove_t<SuiteJJ>(a, st, ev); }
+#else
+void launch_ietf_prove_jj(const ProveArgs& a, hipStream_t st, hipEvent_t* ev);
 void launch_ietf_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (a.n == 0) return;
-  VRF_DISPATCH_SUITE(a.suite, launch_prove_t<S>(a, st, ev));
+  if (a.suite == SUITE_JJ) launch_ietf_prove_jj(a, st, ev);
+  else launch_prove_t<SuiteBS>(a, st, ev);
 }
+#endif
 
 }  // namespace vrf

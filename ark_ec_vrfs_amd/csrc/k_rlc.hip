@@ -14,7 +14,7 @@
 //       + (sum_i z'_i s_i) G + (sum_i z'_i sb_i) B.
 //   k_rlc_decode : K proofs per lane share one inversion (5K decompression denominators); writes the
 //                  Montgomery affine-cached points and the signed window digits straight into the MSM
-//                  layout (point class p of proof i at index p*n + i); accumulates the two fixed-base
+//                  layout (rlc_index); accumulates the two fixed-base
 //                  scalars as 64-bit limb columns (wave shuffles + one atomic per column and wave).
 //   k_rlc_fixed  : normalises the columns mod r and appends G and B with their digits.
 //   then k_msm_buckets / k_msm_final (k_msm.hip) and the verdict byte.
@@ -27,6 +27,10 @@
 namespace vrf {
 
 constexpr int RLC_SLOT = 4 * NL + 1;     // y | num | den | prefix | (flag, ok)
+
+// MSM index of point class p (H, Gamma, pk_com, R, Ok) of proof i: the classes with full-size scalars
+// come first, then G and B (3n, 3n+1), then the two classes whose scalars are the 128-bit weights.
+VRF_HD size_t rlc_index(int p, size_t n, size_t i) { return (size_t)p * n + i + (p >= 3 ? 2 : 0); }
 
 template <class S>
 VRF_HD void rlc_weights(uint32_t z[8], uint32_t zp[8], const uint8_t* seed, uint64_t index) {
@@ -45,12 +49,57 @@ VRF_HD void rlc_weights(uint32_t z[8], uint32_t zp[8], const uint8_t* seed, uint
   for (int i = 0; i < 4; ++i) { z[i] = le[i]; zp[i] = le[4 + i]; z[4 + i] = 0; zp[4 + i] = 0; }
 }
 
+// challenge, weights, scalars and window digits of one proof; cp = compressed (pk_com, H, Gamma, R, Ok)
+template <class S>
+VRF_HD void rlc_emit_item(const RlcArgs& a, size_t item, bool pts_valid, const uint32_t (&cp)[5][8],
+                          uint64_t (&cols)[16]) {
+  const size_t n = a.n, N = a.L.n;
+  uint32_t s[8], sb[8];
+  load32(s, a.s, item); load32(sb, a.sb, item);
+  const bool valid = pts_valid && fr_is_canonical<S>(s) && fr_is_canonical<S>(sb);
+  if (!valid) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0; sb[j] = 0; }
+  }
+  const uint8_t* adp; uint32_t adl;
+  bytes_get(a.ad, item, adp, adl);
+  uint32_t c[8], z[8], zp[8], t[8];
+  challenge5<S>(c, cp, adp, adl);
+  rlc_weights<S>(z, zp, a.seed, a.index0 + item);
+  fr_mul<S>(t, z, s);
+  msm_write_digits<S>(a.L.digits, N, rlc_index(0, n, item), t, false, !valid);     // + (z s) H
+  fr_mul<S>(t, z, c);
+  msm_write_digits<S>(a.L.digits, N, rlc_index(1, n, item), t, true, !valid);      // - (z c) Gamma
+  fr_mul<S>(t, zp, c);
+  msm_write_digits<S>(a.L.digits, N, rlc_index(2, n, item), t, true, !valid);      // - (z' c) pk_com
+  msm_write_digits<S>(a.L.digits, N, rlc_index(3, n, item), zp, true, !valid);     // - z' R   (128 bits)
+  msm_write_digits<S>(a.L.digits, N, rlc_index(4, n, item), z, true, !valid);      // - z Ok   (128 bits)
+  fr_mul<S>(t, zp, s);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cols[j] += t[j];
+  fr_mul<S>(t, zp, sb);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cols[8 + j] += t[j];
+  a.status[item] = (uint8_t)(valid ? ST_OK : ST_INVALID_DATA);
+}
+
+// wave reduction of the fixed-base limb columns, one atomic per column and wave
+VRF_HD void rlc_flush_cols(const RlcArgs& a, const uint64_t (&cols)[16]) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    uint64_t v = cols[j];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_down(v, sft, 64);
+    if ((threadIdx.x & 63) == 0 && v != 0)
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.fixed_cols) + j, (unsigned long long)v);
+  }
+}
+
 template <class S>
 __global__ void __launch_bounds__(BLOCK) k_rlc_decode(RlcArgs a) {
   const size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   const int K = a.k_lane;
   const size_t n = a.n;
-  const size_t N = a.L.n;                                   // 5n + 2
   uint64_t cols[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) cols[j] = 0;
@@ -100,7 +149,7 @@ __global__ void __launch_bounds__(BLOCK) k_rlc_decode(RlcArgs a) {
         pa.x = fe_mul(x, fe_one());
         pa.y = d.y;
         pa.dt = fe_mul(fe_mul(pa.x, pa.y), S::d());
-        pta_store(a.L.pts + ((size_t)p * n + item) * PTA_WORDS, pa);
+        pta_store(a.L.pts + rlc_index(p, n, item) * PTA_WORDS, pa);
       }
     }
     // ---- challenge, weights, scalars, digits ----
@@ -108,49 +157,66 @@ __global__ void __launch_bounds__(BLOCK) k_rlc_decode(RlcArgs a) {
     for (int k = 0; k < K; ++k) {
       const size_t item = first + k;
       if (item < n) {
-        uint32_t s[8], sb[8], cp[5][8];
-        load32(s, a.s, item); load32(sb, a.sb, item);
+        uint32_t cp[5][8];
         load32(cp[0], a.pk_com, item); load32(cp[1], a.h, item); load32(cp[2], a.gamma, item);
         load32(cp[3], a.r, item); load32(cp[4], a.ok, item);
-        const bool valid = ((valid_mask >> k) & 1u) && fr_is_canonical<S>(s) && fr_is_canonical<S>(sb);
-        if (!valid) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { s[j] = 0; sb[j] = 0; }
-        }
-        const uint8_t* adp; uint32_t adl;
-        bytes_get(a.ad, item, adp, adl);
-        uint32_t c[8], z[8], zp[8], t[8];
-        challenge5<S>(c, cp, adp, adl);
-        rlc_weights<S>(z, zp, a.seed, a.index0 + item);
-        fr_mul<S>(t, z, s);
-        msm_write_digits<S>(a.L.digits, N, 0 * n + item, t, false, !valid);     // + (z s) H
-        fr_mul<S>(t, z, c);
-        msm_write_digits<S>(a.L.digits, N, 1 * n + item, t, true, !valid);      // - (z c) Gamma
-        fr_mul<S>(t, zp, c);
-        msm_write_digits<S>(a.L.digits, N, 2 * n + item, t, true, !valid);      // - (z' c) pk_com
-        msm_write_digits<S>(a.L.digits, N, 3 * n + item, zp, true, !valid);     // - z' R
-        msm_write_digits<S>(a.L.digits, N, 4 * n + item, z, true, !valid);      // - z Ok
-        fr_mul<S>(t, zp, s);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) cols[j] += t[j];
-        fr_mul<S>(t, zp, sb);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) cols[8 + j] += t[j];
-        a.status[item] = (uint8_t)(valid ? ST_OK : ST_INVALID_DATA);
+        rlc_emit_item<S>(a, item, ((valid_mask >> k) & 1u) != 0, cp, cols);
       }
     }
   }
-  // fixed-base scalars: wave reduction of the limb columns, one atomic per column and wave
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    uint64_t v = cols[j];
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_down(v, sft, 64);
-    if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.fixed_cols) + j, (unsigned long long)v);
-  }
+  rlc_flush_cols(a, cols);
 }
 
-// one lane: columns -> scalars mod r; G and B (entry 1*256^0 of the fixed-base combs) become points 5n, 5n+1
+// The same stage for callers that hold the points in memory as arkworks `Affine { x, y }` (64 bytes per
+// point: x || y, 32-byte little-endian canonical): no square roots.  One lane per proof.  InvalidData =
+// coordinate >= q or point off the curve.
+template <class S>
+__global__ void __launch_bounds__(BLOCK) k_rlc_prep_affine(RlcArgs a) {
+  const size_t item = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t n = a.n;
+  uint64_t cols[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) cols[j] = 0;
+  if (item < n) {
+    uint32_t cp[5][8];
+    bool valid = true;
+#pragma unroll 1
+    for (int p = 0; p < 5; ++p) {
+      const uint8_t* src = p == 0 ? a.h : p == 1 ? a.gamma : p == 2 ? a.pk_com : p == 3 ? a.r : a.ok;
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(src + item * 64);
+      uint32_t xw[8], yw[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { xw[j] = w[j]; yw[j] = w[8 + j]; }
+      valid = valid && !u256_ge(xw, vrfk::Q32) && !u256_ge(yw, vrfk::Q32);
+      PtA pa;
+      pa.x = fe_from_u256(xw);
+      pa.y = fe_from_u256(yw);
+      FeN xyv = fe_mul(pa.x, pa.y);
+      pa.dt = fe_mul(xyv, S::d());
+      // a x^2 + y^2 = 1 + d x^2 y^2   <=>   y^2 - ANEG x^2 - 1 = (d x y)(x y)
+      FeN x2 = fe_sqr(pa.x), y2 = fe_sqr(pa.y);
+      auto lhs = fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(S::mul_aneg(x2), fe_one())))));
+      valid = fe_eq(lhs, fe_mul(pa.dt, xyv)) && valid;
+      pta_store(a.L.pts + rlc_index(p, n, item) * PTA_WORDS, pa);
+      // compressed encoding for the challenge: y, sign bit = (x > q - x); slot order pk_com, H, Gamma, R, Ok
+      uint32_t e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = yw[j];
+      if (u256_gt(xw, vrfk::QM1H32)) e[7] |= 0x80000000u;
+      const int slot = p == 0 ? 1 : p == 1 ? 2 : p == 2 ? 0 : p;
+#pragma unroll
+      for (int q = 0; q < 5; ++q)
+        if (q == slot) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cp[q][j] = e[j];
+        }
+    }
+    rlc_emit_item<S>(a, item, valid, cp, cols);
+  }
+  rlc_flush_cols(a, cols);
+}
+
+// one lane: columns -> scalars mod r; G and B (entry 1*256^0 of the fixed-base combs) become points 3n, 3n+1
 template <class S>
 __global__ void k_rlc_fixed(RlcArgs a) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -168,10 +234,32 @@ __global__ void k_rlc_fixed(RlcArgs a) {
     uint32_t k[8];
     fr_reduce512<S>(k, wide);
     const uint32_t* src = f == 0 ? a.T.g_comb : a.T.b_comb;
-    uint32_t* dst = a.L.pts + (5 * a.n + f) * PTA_WORDS;
+    uint32_t* dst = a.L.pts + (3 * a.n + f) * PTA_WORDS;
     for (int j = 0; j < PTA_WORDS; ++j) dst[j] = src[j];
-    msm_write_digits<S>(a.L.digits, N, 5 * a.n + f, k, false, false);
+    msm_write_digits<S>(a.L.digits, N, 3 * a.n + f, k, false, false);
   }
+}
+
+// x || y (64 B) -> ArkworksCodec compressed (32 B); used when a failed affine batch falls back to the
+// per-proof kernels
+__global__ void __launch_bounds__(BLOCK) k_affine_compress(size_t n, const uint8_t* xy, uint8_t* enc) {
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(xy + i * 64);
+  uint32_t xw[8], e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { xw[j] = w[j]; e[j] = w[8 + j]; }
+  // coordinates >= q cannot be encoded: poison the encoding (y = 2^255 - 1 >= q) so that decode rejects it
+  const bool bad = u256_ge(xw, vrfk::Q32) || u256_ge(e, vrfk::Q32);
+  if (u256_gt(xw, vrfk::QM1H32)) e[7] |= 0x80000000u;
+  if (bad) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = 0xffffffffu;
+  }
+  store32(enc, i, e);
+}
+void launch_affine_compress(size_t n, const uint8_t* xy, uint8_t* enc, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(k_affine_compress, grid_for(n), dim3(BLOCK), 0, st, n, xy, enc);
 }
 
 template <class S>
@@ -179,7 +267,8 @@ static void launch_rlc_t(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, h
   (void)hipMemsetAsync(a.L.flags, 0, 256, st);
   (void)hipMemsetAsync(a.fixed_cols, 0, 16 * sizeof(uint64_t), st);
   if (ev) (void)hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(k_rlc_decode<S>, grid_for((a.n + a.k_lane - 1) / a.k_lane), dim3(BLOCK), 0, st, a);
+  if (a.affine_in) hipLaunchKernelGGL(k_rlc_prep_affine<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL(k_rlc_decode<S>, grid_for((a.n + a.k_lane - 1) / a.k_lane), dim3(BLOCK), 0, st, a);
   hipLaunchKernelGGL(k_rlc_fixed<S>, dim3(1), dim3(64), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
   launch_msm_core(a.suite, a.L, nullptr, nullptr, nullptr, fail_flag, st, ev ? ev + 2 : nullptr);

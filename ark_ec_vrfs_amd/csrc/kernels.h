@@ -89,9 +89,7 @@ void launch_secret_from_seed(int suite, size_t n, const uint8_t* seeds, uint32_t
                              uint8_t* pk, DevTables T, hipStream_t st);
 void launch_point_validate(int suite, size_t n, const uint8_t* pts, uint8_t* xy, uint8_t* status,
                            uint32_t* tabs, DevTables T, hipStream_t st);
-// MSM: ws must hold msm_workspace_bytes(n, groups) bytes; groups = msm_groups(n, #CUs)  (msm.cuh)
-size_t msm_workspace_bytes(size_t n, int groups);
-int msm_groups(size_t n, int cus);
+// MSM: ws must hold msm_workspace_bytes(n, groups) bytes; groups = msm_groups(n, n, #CUs)  (msm.cuh)
 void launch_msm(int suite, size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t* out_enc,
                 uint8_t* out_xy, uint8_t* status, void* ws, int groups, hipStream_t st);
 void launch_pairing_check2(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status,

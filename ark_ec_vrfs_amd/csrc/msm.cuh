@@ -20,11 +20,19 @@ constexpr uint32_t MSM_IDX_MASK = (1u << MSM_IDX_BITS) - 1;
 constexpr size_t MSM_MAX_PER_GROUP = size_t(1) << MSM_IDX_BITS;
 
 // Device-side layout of one MSM over n points (all regions inside one workspace allocation).
+constexpr int MSM_W_SHORT = 12;                   // windows a scalar < 2^128 can reach (11*12 = 132 bits)
+
 struct MsmLayout {
   size_t n;
-  int groups;            // point groups per window; workgroups = MSM_W * groups
-  size_t per_group;      // points per group (<= MSM_MAX_PER_GROUP)
-  size_t list_cap;       // list entries reserved per workgroup (per_group + MSM_BLOCK)
+  // Points [0, n_long) carry full-size scalars, points [n_long, n) scalars < 2^128 whose digits in the
+  // windows >= MSM_W_SHORT are zero by construction: those windows only partition [0, n_long), with
+  // proportionally fewer groups, so that every workgroup sorts and folds about the same number of points.
+  size_t n_long;
+  int groups;            // point groups per low window (w < MSM_W_SHORT); also the stride of `part`
+  int groups_hi;         // point groups per high window
+  size_t per_group;      // points per group in the low windows (<= MSM_MAX_PER_GROUP)
+  size_t per_group_hi;   // points per group in the high windows
+  size_t list_cap;       // list entries reserved per workgroup (max per-group size + MSM_BLOCK)
   uint32_t* pts;         // [n][PTA_WORDS]   Montgomery affine-cached (x, y, d*x*y)
   int16_t* digits;       // [MSM_W][n]       signed digits in [-1024, 1024]
   uint32_t* lists;       // [MSM_W*groups][list_cap] bucket-sorted entries, lane-transposed
@@ -79,9 +87,9 @@ VRF_HD void msm_write_digits(int16_t* digits, size_t n, size_t i, const uint32_t
 }
 
 // host side (k_msm.hip)
-int msm_groups(size_t n, int cus);
+int msm_groups(size_t n, size_t n_long, int cus);
 size_t msm_workspace_bytes(size_t n, int groups);
-MsmLayout msm_layout(size_t n, int groups, void* ws);
+MsmLayout msm_layout(size_t n, size_t n_long, int groups, void* ws);
 // buckets + final over prepared points / digits.  out_enc: 32 B compressed sum (nullable); out_xy: 64 B
 // affine (nullable); status: 1 byte (nullable; 0 ok, 2 if flags[0] is set); fail_flag: 1 byte (nullable),
 // set to 1 unless the sum is the neutral element (never cleared here: callers OR several MSMs into it).
@@ -95,7 +103,8 @@ struct RlcArgs {
   int k_lane;                 // proofs per lane in the decode stage
   size_t n;                   // proofs in this launch group
   uint64_t index0;            // index of the first proof in the caller's batch (weights depend on it)
-  const uint8_t *h, *gamma, *pk_com, *r, *ok, *s, *sb;
+  const uint8_t *h, *gamma, *pk_com, *r, *ok, *s, *sb;   // affine_in: the five point arrays are 64-byte x || y
+  int affine_in;
   BytesViewLite ad;
   uint8_t* status;            // [n] 0 = part of the batch sum, 2 = InvalidData (left out of it)
   uint32_t* scratch;          // per-proof scratch, scratch_stride words each (>= 5 * 37)
@@ -108,5 +117,7 @@ struct RlcArgs {
 // enqueues decode + MSM; fail_flag[0] becomes 1 if the batch equation does not hold.
 // ev (nullable, 5 events): start | decode | buckets | final | final.
 void launch_pedersen_rlc(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev = nullptr);
+// n x 64 B affine x || y -> n x 32 B compressed encodings
+void launch_affine_compress(size_t n, const uint8_t* xy, uint8_t* enc, hipStream_t st);
 
 }  // namespace vrf

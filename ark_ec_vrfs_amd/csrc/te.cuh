@@ -122,9 +122,10 @@ VRF_HD Fe<L + 1, (V > bias_k(V) ? V : bias_k(V))> fe_cneg(bool neg, const Fe<L, 
 }
 
 // P + (+/-)Q with Q a cached entry (projective).  Unified: also correct for P == Q and for
-// either operand being the identity.
+// either operand being the identity.  need_t = false skips the T coordinate (legal when the next
+// operation is a doubling or the result is only read as X, Y, Z); wave-uniform at every call site.
 template <class C>
-VRF_HD PtE te_add_cached(const PtE& p, const PtC& q, bool neg) {
+VRF_HD PtE te_add_cached(const PtE& p, const PtC& q, bool neg, bool need_t = true) {
   auto X2 = fe_cneg(neg, q.X);                        // (2,8)
   auto dT2 = fe_cneg(neg, q.dT);                      // (2,4)
   auto A = fe_mul(p.X, X2);                           // (1,2)
@@ -140,7 +141,8 @@ VRF_HD PtE te_add_cached(const PtE& p, const PtC& q, bool neg) {
   r.X = fe_mul(E, F);
   r.Y = fe_mul(G, H);
   r.Z = fe_mul(F, G);
-  r.T = fe_mul(E, H);
+  r.T = fe_zero();
+  if (need_t) r.T = fe_mul(E, H);
   return r;
 }
 

@@ -220,7 +220,7 @@ VRF_HD PtE straus2(const uint32_t* tabA, const uint32_t reca[8], const uint32_t*
       sel8(rec, t != 0, recb, reca);
       const uint32_t* tab = t ? tabB : tabA;
       int d = scalar_digit4(rec, w);
-      acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != (t != 0 && negB));
+      acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != (t != 0 && negB), t == 0 || w == 0);
     }
   }
   return acc;
@@ -251,7 +251,7 @@ VRF_HD PtE straus4(const Straus4& q) {
       const uint32_t* tab = t == 0 ? q.tab[0] : t == 1 ? q.tab[1] : t == 2 ? q.tab[2] : q.tab[3];
       bool neg = t == 0 ? q.neg[0] : t == 1 ? q.neg[1] : t == 2 ? q.neg[2] : q.neg[3];
       int d = scalar_digit4_128(rec, w);
-      acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != neg);
+      acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != neg, t != NT - 1 || w == 0);   // doublings follow
     }
   }
   return acc;
@@ -268,7 +268,7 @@ VRF_HD PtE win_mul(const uint32_t* tab, const uint32_t rec[8], bool negate = fal
       for (int j = 0; j < 4; ++j) acc = te_dbl<C>(acc, j == 3);
     }
     int d = scalar_digit4(rec, w);
-    acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != negate);
+    acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != negate, w == 0);
   }
   return acc;
 }

@@ -201,6 +201,24 @@ int32_t vrfhip_pedersen_verify_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const ui
                                              const uint8_t seed[32], uint8_t* d_status,
                                              uint8_t* d_fail_flag, void* stream);
 
+/* The batched verifier for callers that hold the five points in memory as arkworks `Affine { x, y }`
+ * (what `Input`, `Output` and `pedersen::Proof` wrap): *_xy arrays are n x 64 B, x || y as 32-byte
+ * little-endian canonical integers; s, sb as above.  No square roots are needed.  InvalidData =
+ * coordinate >= q, point off the curve, or scalar >= r. */
+int32_t vrfhip_pedersen_verify_batch_rlc_affine(vrfhip_ctx* ctx, size_t n, const uint8_t* input_xy,
+                                                const uint8_t* output_xy, const uint8_t* pk_com_xy,
+                                                const uint8_t* r_xy, const uint8_t* ok_xy, const uint8_t* s,
+                                                const uint8_t* sb, const uint8_t* ad, const uint32_t* ad_off,
+                                                uint32_t ad_len, const uint8_t seed[32], uint8_t* status,
+                                                int32_t* batch_ok);
+int32_t vrfhip_pedersen_verify_batch_rlc_affine_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_input_xy,
+                                                    const uint8_t* d_output_xy, const uint8_t* d_pk_com_xy,
+                                                    const uint8_t* d_r_xy, const uint8_t* d_ok_xy,
+                                                    const uint8_t* d_s, const uint8_t* d_sb,
+                                                    const uint8_t* d_ad, const uint32_t* d_ad_off,
+                                                    uint32_t ad_len, const uint8_t seed[32],
+                                                    uint8_t* d_status, uint8_t* d_fail_flag, void* stream);
+
 /* Multi-scalar multiplication ---------------------------------------------------------- */
 
 /* `VariableBaseMSM::msm(bases, scalars)` on the suite curve (ark_ec, named in BASELINE.json;

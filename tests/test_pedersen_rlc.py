@@ -167,6 +167,35 @@ def test_gpu_rlc_per_item_ad_and_chunking(ctx, synth):
 
 
 @pytest.mark.gpu
+def test_gpu_rlc_affine_inputs(ctx, synth):
+    """x || y inputs (arkworks `Affine`): same verdicts and statuses as the compressed form; off-curve
+    points and coordinates >= q are InvalidData; a failed batch falls back to the per-proof kernels."""
+    n, ad = 600, b"affine"
+    a = _proofs(synth, n, 40000, ad)
+    xy = {}
+    for k in FIELDS[:5]:
+        st, xy[k] = ctx.point_validate_batch(a[k], want_xy=True)
+        assert (st == 0).all()
+    args = lambda d: [d[k] for k in FIELDS[:5]] + [a["s"], a["sb"]]
+    st, ok = ctx.pedersen_verify_batch_rlc(*args(xy), ad=ad, seed=SEED, affine=True)
+    assert ok and (st == 0).all()
+    bad = {k: v.copy() for k, v in xy.items()}
+    bad["ok"][17, 3] ^= 1                                              # off the curve
+    bad["r"][99, :32] = np.frombuffer(int(S.q).to_bytes(32, "little"), np.uint8)   # x = q: not canonical
+    st, ok = ctx.pedersen_verify_batch_rlc(*args(bad), ad=ad, seed=SEED, affine=True)
+    assert ok and st[17] == 2 and st[99] == 2 and st.sum() == 4
+    bad["output"][5] = xy["output"][6]                                 # a valid point, the wrong one
+    st, ok = ctx.pedersen_verify_batch_rlc(*args(bad), ad=ad, seed=SEED, affine=True)
+    assert not ok and st[5] == 1 and st[17] == 2 and st[99] == 2 and st.sum() == 5
+    # negated x: still on the curve, different compressed sign bit -> challenge changes -> rejected
+    neg = {k: v.copy() for k, v in xy.items()}
+    x = int.from_bytes(xy["pk_com"][8, :32].tobytes(), "little")
+    neg["pk_com"][8, :32] = np.frombuffer(((S.q - x) % S.q).to_bytes(32, "little"), np.uint8)
+    st, ok = ctx.pedersen_verify_batch_rlc(*args(neg), ad=ad, seed=SEED, affine=True)
+    assert not ok and st[8] == 1 and st.sum() == 1
+
+
+@pytest.mark.gpu
 def test_gpu_rlc_jubjub(synth):
     from ark_ec_vrfs_amd import Context, JubJubSha512Tai
     cj = Context(0, suite=JubJubSha512Tai)

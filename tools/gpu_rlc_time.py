@@ -30,10 +30,17 @@ for suite in (BandersnatchSha512Ell2, JubJubSha512Tai):
         assert int(st.max()) == 0
         t_rlc = best(lambda: ctx.pedersen_verify_batch_rlc_dev(hh, g, pc, r, ok, s, sb, st, flag, seed))
         assert int(flag[0]) == 0 and int(st.max()) == 0
+        xy = []
+        for src in (hh, g, pc, r, ok):
+            t = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+            _lib.check(lib.vrfhip_point_validate_batch_dev(ctx.handle, n, src.data_ptr(), t.data_ptr(), st.data_ptr(), st0), "validate")
+            xy.append(t)
+        t_aff = best(lambda: ctx.pedersen_verify_batch_rlc_dev(*xy, s, sb, st, flag, seed, affine=True))
+        assert int(flag[0]) == 0 and int(st.max()) == 0
         ctx.profile(True)
         ctx.pedersen_verify_batch_rlc_dev(hh, g, pc, r, ok, s, sb, st, flag, seed)
         torch.cuda.synchronize(); ctx.profile(False)
         ms, groups = ctx.profile_read()
-        print(f"{suite.__name__} n=2^{logn}: per-proof {n/t_item:.3e}/s ({t_item*1e3:.2f} ms)  rlc {n/t_rlc:.3e}/s ({t_rlc*1e3:.2f} ms)"
+        print(f"{suite.__name__} n=2^{logn}: per-proof {n/t_item:.3e}/s ({t_item*1e3:.2f} ms)  rlc {n/t_rlc:.3e}/s ({t_rlc*1e3:.2f} ms)  rlc-affine {n/t_aff:.3e}/s ({t_aff*1e3:.2f} ms)"
               f"  stages decode={ms[0]:.2f} buckets={ms[1]:.2f} final={ms[2]:.2f} ms", flush=True)
     ctx.close()
