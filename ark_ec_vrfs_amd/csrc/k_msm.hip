@@ -16,8 +16,8 @@
 //                   and merged afterwards by the first lane of each chain.  Then the 1024 buckets are
 //                   reduced to sum_j j*B_j inside the workgroup: pair-local sums, a suffix scan and a
 //                   tree reduction over 512 lanes staged through LDS.
-//   k_msm_final   : sums the groups of every window, shifts window w by 11*w doublings (lanes in
-//                   lockstep), tree-sums the windows, encodes.
+//   k_msm_final   : sums the groups of every window, shifts window w by 11*w doublings (one DPP quad per
+//                   window, the quad's lanes share each doubling), tree-sums the windows, encodes.
 #include "kernels.h"
 #include "msm.cuh"
 #include <cstdlib>
@@ -220,24 +220,105 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
 }
 
 // ------------------------------------------------------------------------------- final
-template <class S>
-__global__ void __launch_bounds__(64) k_msm_final(const uint32_t* part, int groups, int groups_hi, uint8_t* out_enc,
-                                                   uint8_t* out_xy, const uint8_t* flags, uint8_t* status,
-                                                   uint8_t* fail_flag) {
-  __shared__ uint32_t stage[32 * MSM_PT_WORDS];
-  const int t = threadIdx.x;
-  // lane w < 23: R_w = sum over groups, then 2^(11 w) * R_w by 11 w doublings (lanes run in lockstep,
-  // the critical path is the top window's 242 doublings instead of a serial 253-doubling Horner)
-  PtE acc = te_identity();
-  if (t < MSM_W) {
-    const int ng = t < MSM_W_SHORT ? groups : groups_hi;
-    acc = lds_load_pt(part + (size_t)t * groups * MSM_PT_WORDS);
-    for (int g = 1; g < ng; ++g)
-      acc = te_add<S>(acc, lds_load_pt(part + ((size_t)t * groups + g) * MSM_PT_WORDS));
-    const int nd = MSM_C * t;
-    for (int j = 0; j < nd; ++j) acc = te_dbl<S>(acc, j == nd - 1);
+// Quad-parallel point arithmetic: the four lanes of a DPP quad hold the same point and share one
+// doubling -- the four squarings, then the four products, of dbl-2008-hwcd run one per lane, and the
+// results travel inside the quad by DPP quad_perm broadcasts (VALU moves, no LDS).  The critical path of
+// a doubling drops from 4S + 4M to 1S + 1M; that path (242 doublings for the top window) is the whole
+// run time of this single-workgroup kernel.
+template <int K>
+VRF_HD uint32_t quad_bcast_u32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xf, 0xf, false);   // quad_perm:[K,K,K,K]
+#else
+  return v;
+#endif
+}
+template <int K, int L, int V>
+VRF_HD Fe<L, V> quad_bcast(const Fe<L, V>& a) {
+  Fe<L, V> r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) r.v[i] = quad_bcast_u32<K>(a.v[i]);
+  return r;
+}
+// bounds of the operands are proved per call site; the typed multiplier is bypassed
+template <int L, int V>
+VRF_HD const Fe<1, 1>& fe_unchecked(const Fe<L, V>& a) { return reinterpret_cast<const Fe<1, 1>&>(a); }
+template <int LO, int VO, int L, int V>
+VRF_HD const Fe<LO, VO>& fe_assume(const Fe<L, V>& a) { return reinterpret_cast<const Fe<LO, VO>&>(a); }
+
+// 2P with the work split over the quad; q = lane index inside the quad.  In: every lane holds (X, Y, Z).
+// Out: every lane holds (X, Y, Z, T) of 2P.
+template <class C>
+VRF_HD PtE te_dbl_quad(const PtE& p, int q) {
+  // lane q squares one of X, Y, X+Y, Z                              operand bound (2,10)
+  Fe<2, 10> xy = fe_add(p.X, p.Y), opnd = xy;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) opnd.v[i] = q == 0 ? p.X.v[i] : q == 1 ? p.Y.v[i] : q == 2 ? xy.v[i] : p.Z.v[i];
+  auto sq = fe_sqr(opnd);                                            // typed (1,3) for the widest operand
+  // lanes 0, 1, 3 squared a coordinate (value < 5q): their squares are < 2q, as in te_dbl
+  const FeN A = fe_assume<1, 2>(quad_bcast<0>(sq)), B = fe_assume<1, 2>(quad_bcast<1>(sq)),
+            ZZ = fe_assume<1, 2>(quad_bcast<3>(sq));
+  const auto Sx = quad_bcast<2>(sq);                                 // (X+Y)^2              (1,3)
+  auto E = fe_norm(fe_sub(fe_add(A, B), Sx));                        // A + B - S            (1,8)
+  auto aA = C::mul_aneg(A);
+  auto H = fe_norm(fe_add(aA, B));                                   // -a*A + B             (1,12)
+  auto G = fe_norm(fe_sub(aA, B));                                   // -a*A - B             (1,14)
+  auto F = fe_norm(fe_add(G, fe_dbl(ZZ)));                           // G + 2Z^2             (1,18)
+  static_assert(mul_v(8, 18) <= 5 && mul_v(14, 12) <= 5 && mul_v(18, 14) <= 5 && mul_v(8, 12) <= 5,
+                "quad doubling: products must stay inside FeP");
+  // lane 0: X = E*F, lane 1: Y = G*H, lane 2: Z = F*G, lane 3: T = E*H.  All four factors are normalised
+  // (L = 1) and each product obeys the value bounds of te_dbl, so the result fits FeP.
+  Fe<1, 1> lhs, rhs;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    lhs.v[i] = (q == 0 || q == 3) ? E.v[i] : q == 1 ? G.v[i] : F.v[i];
+    rhs.v[i] = q == 0 ? F.v[i] : q == 2 ? G.v[i] : H.v[i];
   }
-  // tree-sum of 32 lanes through LDS
+  FeP prod = fe_mul(fe_unchecked(lhs), fe_unchecked(rhs));
+  PtE r;
+  r.X = quad_bcast<0>(prod); r.Y = quad_bcast<1>(prod); r.Z = quad_bcast<2>(prod); r.T = quad_bcast<3>(prod);
+  return r;
+}
+
+constexpr int MSM_FINAL_BLOCK = 128;     // 23 windows x 4 lanes = 92 active lanes in two waves
+
+template <class S>
+__global__ void __launch_bounds__(MSM_FINAL_BLOCK) k_msm_final(const uint32_t* part, int groups, int groups_hi,
+                                                               uint8_t* out_enc, uint8_t* out_xy,
+                                                               const uint8_t* flags, uint8_t* status,
+                                                               uint8_t* fail_flag) {
+  __shared__ uint32_t stage[32 * MSM_PT_WORDS];
+  const int t = threadIdx.x, w = t >> 2, q = t & 3;
+  // quad w < 23: R_w = sum over the groups (lane q takes groups q, q+4, ...; two butterfly steps join
+  // them), then 2^(11 w) * R_w by 11 w quad-parallel doublings.  Quads run in lockstep: the critical path
+  // is the top window's 242 doublings instead of a serial 253-doubling Horner.
+  PtE acc = te_identity();
+  if (w < MSM_W) {
+    const int ng = w < MSM_W_SHORT ? groups : groups_hi;
+    for (int g = q; g < ng; g += 4)
+      acc = te_add<S>(acc, lds_load_pt(part + ((size_t)w * groups + g) * MSM_PT_WORDS));
+  }
+#pragma unroll 1
+  for (int step = 1; step <= 2; step <<= 1) {
+    PtE o;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      o.X.v[i] = __shfl_xor(acc.X.v[i], step, 64); o.Y.v[i] = __shfl_xor(acc.Y.v[i], step, 64);
+      o.Z.v[i] = __shfl_xor(acc.Z.v[i], step, 64); o.T.v[i] = __shfl_xor(acc.T.v[i], step, 64);
+    }
+    acc = te_add<S>(acc, o);
+  }
+  // one representation for the whole quad (a + b and b + a agree only modulo q)
+  acc.X = quad_bcast<0>(acc.X); acc.Y = quad_bcast<0>(acc.Y); acc.Z = quad_bcast<0>(acc.Z); acc.T = quad_bcast<0>(acc.T);
+  const int nd = w < MSM_W ? MSM_C * w : 0;
+#pragma unroll 1
+  for (int j = 0; j < MSM_C * (MSM_W - 1); ++j)
+    if (j < nd) acc = te_dbl_quad<S>(acc, q);
+  // tree-sum of the 23 window results through LDS
+  __syncthreads();
+  if (q == 0 && w < 32) lds_store_pt(stage + w * MSM_PT_WORDS, acc);     // quads 23..31 hold the identity
+  __syncthreads();
+  if (t < 32) acc = lds_load_pt(stage + t * MSM_PT_WORDS);
 #pragma unroll 1
   for (int s = 16; s >= 1; s >>= 1) {
     __syncthreads();
@@ -246,12 +327,19 @@ __global__ void __launch_bounds__(64) k_msm_final(const uint32_t* part, int grou
     if (t < s) acc = te_add<S>(acc, lds_load_pt(stage + (t + s) * MSM_PT_WORDS));
   }
   if (t == 0) {
+    const bool bad = flags[0] != 0;
+    if (!out_enc && !out_xy) {
+      // verdict only (batched verification): the neutral element is X == 0, Y == Z; no inversion
+      const bool neutral = fe_is_zero(acc.X) && fe_eq(acc.Y, acc.Z);
+      if (fail_flag && (!neutral || bad)) fail_flag[0] = 1;
+      if (status) status[0] = bad ? ST_INVALID_DATA : ST_OK;
+      return;
+    }
     FeN x, y;
     te_to_affine(x, y, acc);
     uint32_t e[8], xw[8], yw[8];
     te_encode_affine(e, x, y);
     fe_to_u256(xw, x); fe_to_u256(yw, y);
-    bool bad = flags[0] != 0;
     // neutral element: x == 0 and y == 1
     uint32_t nz = 0;
 #pragma unroll
@@ -347,7 +435,7 @@ static void launch_msm_core_t(const MsmLayout& L, uint8_t* out_enc, uint8_t* out
   const int wgs = MSM_W_SHORT * L.groups + (MSM_W - MSM_W_SHORT) * L.groups_hi;
   hipLaunchKernelGGL(k_msm_buckets<S>, dim3(wgs), dim3(MSM_BLOCK), lds_bytes, st, L);
   if (ev) (void)hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(k_msm_final<S>, dim3(1), dim3(64), 0, st, L.part, L.groups, L.groups_hi, out_enc, out_xy, L.flags,
+  hipLaunchKernelGGL(k_msm_final<S>, dim3(1), dim3(MSM_FINAL_BLOCK), 0, st, L.part, L.groups, L.groups_hi, out_enc, out_xy, L.flags,
                      status, fail_flag);
   if (ev) { (void)hipEventRecord(ev[1], st); (void)hipEventRecord(ev[2], st); }
 }

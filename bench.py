@@ -217,8 +217,20 @@ def secondary(ctx, lib, dev, sk, msg, pk, hh, gamma, c, s):
     tp = _time(lambda: ctx.pedersen_prove_batch_dev(sk, msg, 32, g, pc, r, ok, ss, sb, None, None, pst))
     tv = _time(lambda: ctx.pedersen_verify_batch_dev(hh, g, pc, r, ok, ss, sb, pst))
     assert int(pst.sum()) == 0
+    # batched verification: one MSM over 5n + 2 points (random linear combination), compressed and affine inputs
+    flag = torch.empty(1, dtype=torch.uint8, device=dev)
+    seed = os.urandom(32)
+    tb = _time(lambda: ctx.pedersen_verify_batch_rlc_dev(hh, g, pc, r, ok, ss, sb, pst, flag, seed))
+    assert int(flag[0]) == 0 and int(pst.sum()) == 0
+    pxy = [mk(n, 64) for _ in range(5)]
+    for src, dst in zip((hh, g, pc, r, ok), pxy):
+        _lib.check(lib.vrfhip_point_validate_batch_dev(ctx.handle, n, src.data_ptr(), dst.data_ptr(), vst.data_ptr(), stream), "validate")
+    ta = _time(lambda: ctx.pedersen_verify_batch_rlc_dev(*pxy, ss, sb, pst, flag, seed, affine=True))
+    assert int(flag[0]) == 0 and int(pst.sum()) == 0
     res["pedersen_2^%d" % (n.bit_length() - 1)] = {"proofs_per_s": n / tp, "verifies_per_s": n / tv,
-                                                   "bytes_per_proof": 288, "bytes_per_verify": 225}
+                                                   "batched_verifies_per_s": n / tb, "batched_affine_verifies_per_s": n / ta,
+                                                   "bytes_per_proof": 288, "bytes_per_verify": 225,
+                                                   "bytes_per_verify_affine": 385}
     # config 3 as BASELINE.json words it: Pedersen on JubJub (suite parity unpinned)
     try:
         from ark_ec_vrfs_amd import Context, JubJubSha512Tai
@@ -230,7 +242,10 @@ def secondary(ctx, lib, dev, sk, msg, pk, hh, gamma, c, s):
         tp = _time(lambda: cj.pedersen_prove_batch_dev(skj, msg, 32, g, pc, r, ok, ss, sb, None, hj, pst))
         tv = _time(lambda: cj.pedersen_verify_batch_dev(hj, g, pc, r, ok, ss, sb, pst))
         assert int(pst.sum()) == 0
+        tb = _time(lambda: cj.pedersen_verify_batch_rlc_dev(hj, g, pc, r, ok, ss, sb, pst, flag, seed))
+        assert int(flag[0]) == 0 and int(pst.sum()) == 0
         res["pedersen_jubjub_2^%d" % (n.bit_length() - 1)] = {"proofs_per_s": n / tp, "verifies_per_s": n / tv,
+                                                              "batched_verifies_per_s": n / tb,
                                                               "bytes_per_proof": 288, "bytes_per_verify": 225}
         cj.close()
     except Exception as e:
