@@ -411,6 +411,54 @@ def test_msm_skewed_digit_distributions(ctx, shape):
     assert ctx.msm(xy, k) == co.msm(xy, k)
 
 
+def test_msm_2_22_two_rounds_and_extreme_skew(ctx):
+    """2^22 points (two rounds of workgroups, 22 groups per window): random scalars against the discrete-log
+    identity, then every scalar equal (all points of a window in ONE bucket): k * sum(P) two ways."""
+    import torch
+    from ark_ec_vrfs_amd import _lib
+    n = 1 << 22
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    st0 = torch.cuda.current_stream().cuda_stream
+    seeds = torch.arange(n, dtype=torch.int64, device=dev).view(torch.uint8).reshape(n, 8)
+    a = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    pk = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    _lib.check(lib.vrfhip_secret_from_seed_batch_dev(ctx.handle, n, seeds.data_ptr(), 8, a.data_ptr(), pk.data_ptr(), st0), "seed")
+    xy = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+    vst = torch.empty(n, dtype=torch.uint8, device=dev)
+    _lib.check(lib.vrfhip_point_validate_batch_dev(ctx.handle, n, pk.data_ptr(), xy.data_ptr(), vst.data_ptr(), st0), "validate")
+    k = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    seeds2 = (torch.arange(n, dtype=torch.int64, device=dev) + (1 << 41)).view(torch.uint8).reshape(n, 8)
+    _lib.check(lib.vrfhip_secret_from_seed_batch_dev(ctx.handle, n, seeds2.data_ptr(), 8, k.data_ptr(), None, st0), "seed2")
+    out = torch.empty(32, dtype=torch.uint8, device=dev); st = torch.empty(1, dtype=torch.uint8, device=dev)
+    ctx.msm_dev(xy, k, out, None, st)
+    torch.cuda.synchronize()
+    assert int(vst.sum()) == 0 and int(st[0]) == 0
+    le = lambda t: [int.from_bytes(row.tobytes(), "little") for row in t.cpu().numpy()]
+    av, kv = le(a), le(k)
+    want = co.public_from_secret((sum(x * y for x, y in zip(av, kv)) % R).to_bytes(32, "little"))
+    assert out.cpu().numpy().tobytes() == want
+    # all scalars equal: one bucket per window holds all 2^22 points
+    kc = 0x1234567890abcdef1234567890abcdef1234567890abcdef1234567890abcd % R
+    keq = torch.from_numpy(np.frombuffer(kc.to_bytes(32, "little"), np.uint8).copy()).to(dev).repeat(n, 1)
+    ctx.msm_dev(xy, keq, out, None, st)
+    torch.cuda.synchronize()
+    want = co.public_from_secret((sum(av) % R * kc % R).to_bytes(32, "little"))
+    assert int(st[0]) == 0 and out.cpu().numpy().tobytes() == want
+
+
+@pytest.mark.parametrize("n", [511, 513, 8191, 8193, 16385, 70001])
+def test_msm_group_boundaries(ctx, n):
+    """Sizes around the points-per-group and lanes-per-workgroup boundaries, discrete-log identity."""
+    rnd = np.random.default_rng(n)
+    a, pk = ctx.secret_from_seed_batch(rnd.integers(0, 256, (n, 8), dtype=np.uint8))
+    xy = _xy_of(ctx, pk)
+    k, _ = ctx.secret_from_seed_batch(rnd.integers(0, 256, (n, 9), dtype=np.uint8), with_public=False)
+    le = lambda t: [int.from_bytes(row.tobytes(), "little") for row in t]
+    want = co.public_from_secret((sum(x * y for x, y in zip(le(a), le(k))) % R).to_bytes(32, "little"))
+    assert ctx.msm(xy, k)[0] == want
+
+
 def test_msm_jubjub_matches_naive_oracle():
     from ark_ec_vrfs_amd import Context, JubJubSha512Tai
     cj = Context(0, suite=JubJubSha512Tai)
