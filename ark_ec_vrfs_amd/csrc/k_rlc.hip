@@ -28,27 +28,6 @@ namespace vrf {
 
 constexpr int RLC_SLOT = 4 * NL + 1;     // y | num | den | prefix | (flag, ok)
 
-// MSM index of point class p (H, Gamma, pk_com, R, Ok) of proof i: the classes with full-size scalars
-// come first, then G and B (3n, 3n+1), then the two classes whose scalars are the 128-bit weights.
-VRF_HD size_t rlc_index(int p, size_t n, size_t i) { return (size_t)p * n + i + (p >= 3 ? 2 : 0); }
-
-template <class S>
-VRF_HD void rlc_weights(uint32_t z[8], uint32_t zp[8], const uint8_t* seed, uint64_t index) {
-  Sha512 h;
-  sha512_init(h);
-  constexpr char tag[] = "vrfhip-rlc-v1";
-#pragma unroll
-  for (int i = 0; i < 13; ++i) sha512_put_byte(h, (uint8_t)tag[i]);
-  sha512_put_bytes(h, seed, 32);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) sha512_put_byte(h, (uint8_t)(index >> (8 * i)));
-  sha512_final(h);
-  uint32_t le[16];
-  sha512_le512(le, h);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { z[i] = le[i]; zp[i] = le[4 + i]; z[4 + i] = 0; zp[4 + i] = 0; }
-}
-
 // challenge, weights, scalars and window digits of one proof; cp = compressed (pk_com, H, Gamma, R, Ok)
 template <class S>
 VRF_HD void rlc_emit_item(const RlcArgs& a, size_t item, bool pts_valid, const uint32_t (&cp)[5][8],

@@ -95,3 +95,22 @@ void hs_ietf_verify_multi(uint32_t n, const uint8_t* pk, const uint8_t* h, const
     verify_finish_multi<SuiteBS>(VERIFY_K, first, n, pts.data(), PROVE_PTS_WORDS, pk, h, g, nullptr, 0, c, s, adv, flags.data(), status);
 }
 }
+
+// ---- MSM digit recoding and batched-verification weights (msm.cuh) ----
+#include "../../ark_ec_vrfs_amd/csrc/msm.cuh"
+extern "C" {
+void hs_msm_digits(int suite, const uint8_t* k, int negate, int zero, int16_t* out23) {
+  uint32_t w[8]; memcpy(w, k, 32);
+  int16_t d[MSM_W];
+  if (suite == 2) msm_write_digits<SuiteJJ>(d, 1, 0, w, negate != 0, zero != 0);
+  else msm_write_digits<SuiteBS>(d, 1, 0, w, negate != 0, zero != 0);
+  memcpy(out23, d, sizeof d);
+}
+void hs_rlc_weights(const uint8_t* seed, uint64_t index, uint8_t* z32, uint8_t* zp32) {
+  uint32_t z[8], zp[8];
+  rlc_weights<SuiteBS>(z, zp, seed, index);
+  memcpy(z32, z, 32); memcpy(zp32, zp, 32);
+}
+uint64_t hs_rlc_index(int p, uint64_t n, uint64_t i) { return rlc_index(p, n, i); }
+}
+

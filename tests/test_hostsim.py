@@ -237,3 +237,39 @@ def test_multi_proof_prepare_matches_oracle(hs):
     for i in range(n):
         row = out.raw[160 * i:160 * i + 160]
         assert row == b"".join(r[k][i].tobytes() for k in ("output", "c", "s", "pk", "input")), i
+
+
+def test_msm_digit_recoding_and_rlc_weights(hs):
+    """msm.cuh: signed radix-2^11 digits (folded at r/2) rebuild +-k mod r, stay in [-1024, 1024], leave the
+    windows >= 12 empty for 128-bit scalars; the batched-verification weights are the two 16-byte halves of
+    SHA-512("vrfhip-rlc-v1" || seed || u64_le(i)); the MSM index map puts G and B after the three classes
+    with full-size scalars."""
+    import hashlib
+    rnd = random.Random(11)
+    jj_r = o.jubjub_params().r
+    for suite, r in ((1, S.r), (2, jj_r)):
+        cases = [0, 1, 2, 1024, 1025, 2047, 2048, r - 1, r - 2, (r - 1) // 2, (r + 1) // 2, (1 << 128) - 1, 1 << 127,
+                 (1 << 132) - 1] + [rnd.randrange(r) for _ in range(300)] + [rnd.randrange(1 << 128) for _ in range(100)]
+        for k in cases:
+            for negate in (0, 1):
+                d = (ctypes.c_int16 * 23)()
+                hs.hs_msm_digits(suite, _b(k), negate, 0, d)
+                digs = list(d)
+                assert all(-1024 <= x <= 1024 for x in digs)
+                val = sum(x << (11 * w) for w, x in enumerate(digs))
+                assert val % r == (-k if negate else k) % r
+                if k < (1 << 128):
+                    assert all(x == 0 for x in digs[12:])
+        d = (ctypes.c_int16 * 23)()
+        hs.hs_msm_digits(suite, _b(r - 5), 0, 1, d)
+        assert not any(d)
+    seed = bytes(range(100, 132))
+    for idx in (0, 1, 255, 1 << 20, (1 << 63) + 12345):
+        z, zp = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+        hs.hs_rlc_weights(seed, ctypes.c_uint64(idx), z, zp)
+        dg = hashlib.sha512(b"vrfhip-rlc-v1" + seed + idx.to_bytes(8, "little")).digest()
+        assert z.raw == dg[:16] + bytes(16) and zp.raw == dg[16:32] + bytes(16)
+    hs.hs_rlc_index.restype = ctypes.c_uint64
+    n = 1000
+    idx = sorted(hs.hs_rlc_index(p, ctypes.c_uint64(n), ctypes.c_uint64(i)) for p in range(5) for i in range(n))
+    assert idx == list(range(3 * n)) + list(range(3 * n + 2, 5 * n + 2))          # 3n, 3n+1 are G and B
