@@ -1,0 +1,17 @@
+"""One profiled pass of 2^N (argv[1], default 16) pairing checks: for rocprofv3."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+from ark_ec_vrfs_amd import Context
+from test_bls_pairing import kzg_like_items, pack
+ctx = Context(0); dev = torch.device('cuda:0')
+g1, g2 = pack(kzg_like_items(8, seed=21))
+n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 16)
+d1 = torch.from_numpy(np.tile(g1, (n // 8, 1)).copy()).to(dev)
+d2 = torch.from_numpy(np.tile(g2, (n // 8, 1)).copy()).to(dev)
+st = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+for _ in range(2):
+    ctx.pairing_check_batch_dev(d1, d2, st)
+torch.cuda.synchronize()
+assert int(st.sum()) == 0
