@@ -30,7 +30,7 @@ SYMBOLS = [
     "vrfhip_output_hash_batch", "vrfhip_output_hash_batch_dev",
     "vrfhip_secret_from_seed_batch", "vrfhip_secret_from_seed_batch_dev",
     "vrfhip_point_validate_batch", "vrfhip_point_validate_batch_dev",
-    "vrfhip_fq_mul_batch",
+    "vrfhip_fq_mul_batch", "vrfhip_test_pairing_quad_ops",
 ]
 
 
@@ -105,6 +105,7 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_point_validate_batch.argtypes = [c_void_p, c_size_t, P, P, P]
     lib.vrfhip_point_validate_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, c_void_p]
     lib.vrfhip_fq_mul_batch.argtypes = [c_void_p, c_size_t, P, P, P]
+    lib.vrfhip_test_pairing_quad_ops.argtypes = [c_void_p, c_size_t, P, P]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("vrfhip_last_error", "vrfhip_ctx_destroy", "vrfhip_ctx_workspace_bytes"):

@@ -885,6 +885,26 @@ int32_t vrfhip_pairing_check_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* g1,
   return VRFHIP_SUCCESS;
 }
 
+// Test-only: quad-distributed Fp12 tower operations against the one-lane operations (k_pairing.hip)
+int32_t vrfhip_test_pairing_quad_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp12_pairs, uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!fp12_pairs || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_stage(ctx, Stage::pad(n * 1152) + Stage::pad(n));
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t* d_in = sg.take(n * 1152);
+  uint8_t* d_st = sg.take(n);
+  HIP_TRY(hipMemcpyAsync(d_in, fp12_pairs, n * 1152, hipMemcpyHostToDevice, ctx->stream));
+  launch_pairing_quad_selftest(n, d_in, d_st, ctx->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
 // ------------------------------------------------------------------------- building blocks
 int32_t vrfhip_hash_to_curve_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_msg,
                                        const uint32_t* d_msg_off, uint32_t msg_len,

@@ -94,6 +94,7 @@ void launch_msm(int suite, size_t n, const uint8_t* xy, const uint8_t* scalars, 
                 uint8_t* out_xy, uint8_t* status, void* ws, int groups, hipStream_t st);
 void launch_pairing_check2(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status,
                            hipStream_t st);
+void launch_pairing_quad_selftest(size_t n, const uint8_t* in, uint8_t* status, hipStream_t st);
 void launch_fq_mul(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* r, hipStream_t st);
 
 // 32-byte item <-> registers

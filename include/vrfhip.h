@@ -281,6 +281,12 @@ int32_t vrfhip_point_validate_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* po
 int32_t vrfhip_point_validate_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_points,
                                         uint8_t* d_xy_out, uint8_t* d_status, void* stream);
 
+/* Test-only primitive: the quad-distributed Fp12 operations of the pairing kernel (one item per DPP quad)
+ * against the one-lane tower operations on the same operands.  fp12_pairs: n x 2 x 12 field elements of
+ * 48 bytes, little-endian (reduced mod p by the loader).  status[i] = bit mask of differing operations
+ * (1 mul, 2 sqr, 4 cyclotomic sqr, 8 mul_by_014, 16 frobenius, 32 conj / gather-scatter); 0 = all equal. */
+int32_t vrfhip_test_pairing_quad_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp12_pairs, uint8_t* status);
+
 /* Test-only primitive: r[i] = a[i] * b[i] mod q on n x 32 B little-endian field elements
  * (exercises ark_ff::Fp mul through the 29-bit Montgomery pipeline). */
 int32_t vrfhip_fq_mul_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b,

@@ -173,3 +173,24 @@ def test_gpu_pairing_batch_2_14_tiled(ctx):
     got = st.cpu().numpy()
     want = np.zeros(n, np.uint8); want[bad] = 1
     assert (got == want).all()
+
+
+@pytest.mark.gpu
+def test_gpu_quad_tower_ops_match_one_lane_ops(ctx):
+    """The pairing kernel spreads one item over a DPP quad (bls12_quad.cuh); its Fp12 operations must equal the
+    one-lane operations of bls12.cuh (themselves pinned against the oracle by the hostsim tests) on random
+    operands, in every quad of a wave and with edge values (0, 1, p-1)."""
+    from ark_ec_vrfs_amd import _lib
+    lib = _lib.load()
+    rnd = np.random.default_rng(3)
+    n = 300
+    raw = rnd.integers(0, 256, (n, 2, 12, 48), dtype=np.uint8)
+    raw[..., 47] &= 0x0f                                   # < 2^380 < p: canonical inputs
+    raw[0] = 0
+    raw[1, :, :, :] = 0; raw[1, :, 0, 0] = 1               # x = y = 1
+    pm1 = np.frombuffer(int(P - 1).to_bytes(48, "little"), np.uint8)
+    raw[2, :, :, :] = pm1
+    raw[3, 0] = 0                                          # x = 0
+    st = np.full(n, 255, np.uint8)
+    _lib.check(lib.vrfhip_test_pairing_quad_ops(ctx.handle, n, raw.ctypes.data, st.ctypes.data), "quad selftest")
+    assert (st == 0).all(), {int(i): int(v) for i, v in enumerate(st) if v}
