@@ -25,7 +25,7 @@
 #ifndef VRF_HD
 #define VRF_HD __host__ __device__ __forceinline__
 #endif
-#define VRF_HD_NOINLINE __host__ __device__ __attribute__((noinline))
+#define VRF_HD_NOINLINE static __host__ __device__ __attribute__((noinline))
 
 namespace bls {
 

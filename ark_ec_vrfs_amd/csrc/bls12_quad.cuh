@@ -17,8 +17,8 @@
 //   Fp12 = Fp6[w]/(w^2 - v): both halves of a column sit in the same lane, so the Karatsuba sums of
 //   fp12 mul / sqr are local; *v is a rotation of the columns with xi applied in lane 0.
 //   Granger-Scott cyclotomic squaring: the three Fp4 squarings run one per lane.
-//   Frobenius is column-local.  The line functions of the Miller loop are computed by lanes 0 and 1 (one
-//   (P, Q) pair each, scratch-resident G2 state, the single-lane step functions of bls12.cuh) and
+//   Frobenius is column-local.  The line functions of the Miller loop are computed two lanes per (P, Q)
+//   pair (g2_step_q: five rounds of one Fp2 product per lane for a doubling, seven for an addition) and
 //   broadcast to the quad.  Code is kept small (the I-cache holds ~64 KB and one Fp2 product is ~14 KB):
 //   every level loops over ONE instance of the level below, operands picked by selects.
 #pragma once
@@ -260,19 +260,108 @@ __device__ __forceinline__ Q12 final_exponentiation_q(const Q12& f, int q) {
   return fp12_mul_q(y, t, q);
 }
 
-// One item per quad.  g1: 2 x 24 words, g2: 2 x 48 words (formats of pairing_check2_item).  Lanes 0 and 1
-// own pair 0 and pair 1 (lanes 2 and 3 mirror them so that every lane runs the same code up to the G2
-// steps).  Returns the status in every lane.
+// ---- Miller loop steps, two lanes per (P, Q) pair: lanes 0,1 of the quad own pair 0, lanes 2,3 pair 1; the
+// G2 state T = (X, Y, Z) is replicated in both lanes, h = lane & 1 says which product of a round a lane forms.
+// Each round both lanes of a pair form one Fp2 product (operands chosen by h) and swap the results inside the
+// pair: five rounds for a doubling, seven for an addition.  Homogeneous projective formulas of bls12.cuh (g2_double_step / g2_add_step) with
+// the halvings scaled away: T3 is multiplied by 4 (projective point: harmless) and the lines keep their
+// scale up to factors of Fp2, which the final exponentiation kills.
+constexpr int QP_PAIRSWAP = 1 | (0 << 2) | (3 << 4) | (2 << 6);
+struct G2Line { Fp2 c0, c1, c4; };
+
+__device__ __forceinline__ Fp2 fp2_small12(const Fp2& x) {    // 12 x, storage form
+  const Fp2 t = fp2_fit(fp2_add(fp2_dbl(x), x));              // 3x
+  return fp2_fit(fp2_dbl(fp2_dbl(t)));
+}
+
+// one round: this lane multiplies (u, v); returns the product of half 0 in pa and of half 1 in pb
+template <int L1, int V1, int L2, int V2>
+__device__ __forceinline__ void pair_round(Fp2& pa, Fp2& pb, const Fp2T<L1, V1>& u, const Fp2T<L2, V2>& v, bool hb) {
+  const Fp2 m = fp2_fit(fp2_mul(u, v));
+  const Fp2 mo = qperm<QP_PAIRSWAP>(m);
+  pa = fp2_sel(hb, mo, m);
+  pb = fp2_sel(hb, m, mo);
+}
+
+// T <- 2T and the tangent line at T, scaled by the G1 coordinates of this lane's pair
+__device__ __forceinline__ G2Line g2_double_q(G2Proj& T, const G1Aff& P, int h) {
+  const bool hb = h != 0;
+  const Fp2 X = T.X, Y = T.Y, Z = T.Z;
+  Fp2 pyc;                                                 // (Py, 0) as an Fp2 factor
+  pyc.a = P.y; pyc.b = fp_zero();
+  Fp2 xy, b, c, syz, j, e2, t1, t2, t3, c4s;
+  pair_round(xy, b, fp2_sel(hb, Y, X), Y, hb);                                   // XY | Y^2
+  {
+    const auto yz = fp2_add(Y, Z);
+    const auto u = fp2_sel(hb, yz, fp2_widen<2, 2 * STORE_V>(Z));
+    pair_round(c, syz, u, u, hb);                                                // Z^2 | (Y+Z)^2
+  }
+  const Fp2 e = fp2_fit(fp2_mul_xi(fp2_small12(c)));                             // b' * 3c = 12 xi c
+  const Fp2 hh = fp2_fit(fp2_sub(syz, fp2_add(b, c)));                           // (Y+Z)^2 - b - c
+  {
+    const Fp2 u = fp2_sel(hb, e, X);
+    pair_round(j, e2, u, u, hb);                                                 // X^2 | e^2
+  }
+  {
+    const Fp2 f3 = fp2_fit(fp2_add(fp2_dbl(e), e));
+    const Fp2 bmf = fp2_fit(fp2_sub(b, f3)), bpf = fp2_fit(fp2_add(b, f3));
+    pair_round(t1, t2, fp2_sel(hb, bpf, xy), fp2_sel(hb, bpf, bmf), hb);         // XY (b - f) | (b + f)^2
+  }
+  pair_round(t3, c4s, fp2_sel(hb, hh, b), fp2_sel(hb, pyc, hh), hb);             // b h | h Py
+  T.X = fp2_fit(fp2_dbl(t1));                                   // 2 XY (b - f)            (x4 overall)
+  T.Y = fp2_fit(fp2_sub(t2, fp2_small12(e2)));                  // (b + f)^2 - 12 e^2
+  T.Z = fp2_fit(fp2_dbl(fp2_dbl(t3)));                          // 4 b h
+  G2Line L;
+  L.c0 = fp2_fit(fp2_sub(b, e));
+  L.c1 = fp2_fit(fp2_mul_fp(fp2_neg(fp2_add(fp2_dbl(j), j)), P.x));              // -3 X^2 Px
+  L.c4 = c4s;
+  return L;
+}
+
+// T <- T + Q and the line through T and Q, scaled by the G1 coordinates
+__device__ __forceinline__ G2Line g2_add_q(G2Proj& T, const G2Aff& Q, const G1Aff& P, int h) {
+  const bool hb = h != 0;
+  const Fp2 X = T.X, Y = T.Y, Z = T.Z;
+  Fp2 pyc;
+  pyc.a = P.y; pyc.b = fp_zero();
+  Fp2 yz, xz, c, d, e, f, g, tq, lq, z3, x3, y3a, ey, c4s;
+  pair_round(yz, xz, fp2_sel(hb, Q.x, Q.y), Z, hb);                              // Qy Z | Qx Z
+  const Fp2 th = fp2_fit(fp2_sub(Y, yz)), lam = fp2_fit(fp2_sub(X, xz));
+  {
+    const Fp2 u = fp2_sel(hb, lam, th);
+    pair_round(c, d, u, u, hb);                                                  // theta^2 | lambda^2
+  }
+  pair_round(e, f, fp2_sel(hb, Z, lam), fp2_sel(hb, c, d), hb);                  // lambda d | Z c
+  pair_round(g, tq, fp2_sel(hb, th, X), fp2_sel(hb, Q.x, d), hb);                // X d | theta Qx
+  pair_round(lq, z3, fp2_sel(hb, Z, lam), fp2_sel(hb, e, Q.y), hb);              // lambda Qy | Z e
+  {
+    const Fp2 hv = fp2_fit(fp2_sub(fp2_add(e, f), fp2_dbl(g)));
+    const Fp2 gmh = fp2_fit(fp2_sub(g, hv));
+    pair_round(x3, y3a, fp2_sel(hb, th, lam), fp2_sel(hb, gmh, hv), hb);         // lambda h | theta (g - h)
+  }
+  pair_round(ey, c4s, fp2_sel(hb, lam, e), fp2_sel(hb, pyc, Y), hb);             // e Y | lambda Py
+  T.X = x3;
+  T.Y = fp2_fit(fp2_sub(y3a, ey));
+  T.Z = z3;
+  G2Line L;
+  L.c0 = fp2_fit(fp2_sub(tq, lq));                                               // theta Qx - lambda Qy
+  L.c1 = fp2_fit(fp2_mul_fp(fp2_neg(th), P.x));
+  L.c4 = c4s;
+  return L;
+}
+
+// One item per quad.  g1: 2 x 24 words, g2: 2 x 48 words (formats of pairing_check2_item).  Returns the
+// status in every lane.
 __device__ __attribute__((noinline)) uint32_t pairing_check2_quad(const uint32_t* g1, const uint32_t* g2, int q) {
-  const int pi = q & 1;
+  const int pi = q >> 1, h = q & 1;
   G1Aff P;
   G2Aff Q;
   bool i1, i2;
   bool ok = g1_load(P, i1, g1 + 24 * pi);
   ok = g2_load(Q, i2, g2 + 48 * pi) && ok;
   const int my_skip = (i1 || i2) ? 1 : 0, my_ok = ok ? 1 : 0;
-  const int skip0 = qperm_i32<QP_BC0>(my_skip), skip1 = qperm_i32<QP_BC1>(my_skip);
-  const bool all_ok = qperm_i32<QP_BC0>(my_ok) != 0 && qperm_i32<QP_BC1>(my_ok) != 0;
+  const int skip0 = qperm_i32<QP_BC0>(my_skip), skip1 = qperm_i32<QP_BC2>(my_skip);
+  const bool all_ok = qperm_i32<QP_BC0>(my_ok) != 0 && qperm_i32<QP_BC2>(my_ok) != 0;
   G2Proj T;
   T.X = Q.x; T.Y = Q.y; T.Z = fp2_one();
   Q12 f = q12_one(q);
@@ -282,18 +371,14 @@ __device__ __attribute__((noinline)) uint32_t pairing_check2_quad(const uint32_t
     const int nsteps = ((X_ABS >> bit) & 1) ? 2 : 1;
 #pragma unroll 1
     for (int step = 0; step < nsteps; ++step) {
-      Fp2 c0 = fp2_zero(), c1 = fp2_zero(), c4 = fp2_zero();
-      if (q < 2) {
-        if (step == 0) g2_double_step(&T, &c0, &c1, &c4);
-        else g2_add_step(&T, &Q, &c0, &c1, &c4);
-        c1 = fp2_fit(fp2_mul_fp(c1, P.x));
-        c4 = fp2_fit(fp2_mul_fp(c4, P.y));
-      }
+      G2Line L;
+      if (step == 0) L = g2_double_q(T, P, h);
+      else L = g2_add_q(T, Q, P, h);
 #pragma unroll 1
       for (int i = 0; i < 2; ++i) {
-        const Fp2 l0 = fp2_sel(i == 0, qperm<QP_BC0>(c0), qperm<QP_BC1>(c0));
-        const Fp2 l1 = fp2_sel(i == 0, qperm<QP_BC0>(c1), qperm<QP_BC1>(c1));
-        const Fp2 l4 = fp2_sel(i == 0, qperm<QP_BC0>(c4), qperm<QP_BC1>(c4));
+        const Fp2 l0 = fp2_sel(i == 0, qperm<QP_BC0>(L.c0), qperm<QP_BC2>(L.c0));
+        const Fp2 l1 = fp2_sel(i == 0, qperm<QP_BC0>(L.c1), qperm<QP_BC2>(L.c1));
+        const Fp2 l4 = fp2_sel(i == 0, qperm<QP_BC0>(L.c4), qperm<QP_BC2>(L.c4));
         const bool skip = (i == 0 ? skip0 : skip1) != 0;
         if (!skip) f = fp12_mul_by_014_q(f, l0, l1, l4, q);
       }
