@@ -23,6 +23,7 @@
 //   every level loops over ONE instance of the level below, operands picked by selects.
 #pragma once
 #include "bls12.cuh"
+#include <type_traits>
 
 namespace bls {
 
@@ -75,26 +76,35 @@ __device__ __forceinline__ Fp2 fp6_mul_v_q(const Fp2& x, int q) {
   return fp2_sel(q == 0, xu, u);
 }
 
-// column-distributed Fp6 product
+// column-distributed Fp6 product.  Intermediates keep their natural bounds (normalised limbs, values up to
+// 54 p); only the result is brought back to storage form: one quotient-estimate reduction per component.
 __device__ __forceinline__ Fp2 fp6_mul_q(const Fp2& x, const Fp2& y, int q) {
   using W = Fp2T<2, 2 * STORE_V>;
   const W xo = fp2_add(qperm<QP_ROT1>(x), qperm<QP_ROT2>(x));     // the other two columns
   const W yo = fp2_add(qperm<QP_ROT1>(y), qperm<QP_ROT2>(y));
-  Fp2 p = fp2_zero(), cr = fp2_zero();
+  using M = decltype(fp2_norm(fp2_mul(xo, yo)));
+  M p, cr;
+  p.a = fp_zero(); p.b = fp_zero(); cr = p;
 #pragma unroll 1
   for (int r = 0; r < 2; ++r) {
     const W a = fp2_sel(r != 0, xo, fp2_widen<2, 2 * STORE_V>(x));
     const W b = fp2_sel(r != 0, yo, fp2_widen<2, 2 * STORE_V>(y));
-    const Fp2 m = fp2_fit(fp2_mul(a, b));
+    const M m = fp2_norm(fp2_mul(a, b));
     p = fp2_sel(r == 0, m, p);
     cr = fp2_sel(r != 0, m, cr);
   }
-  const Fp2 c = fp2_fit(fp2_sub(fp2_sub(cr, qperm<QP_ROT1>(p)), qperm<QP_ROT2>(p)));
-  const Fp2 ps = qperm<QP_SWAP12>(p), cs = qperm<QP_SWAP12>(c);
+  const auto c = fp2_norm(fp2_sub(fp2_sub(cr, qperm<QP_ROT1>(p)), qperm<QP_ROT2>(p)));
+  using C = std::remove_const_t<decltype(c)>;
+  C pw;
+  pw.a = p.a; pw.b = p.b;                                          // widening
+  const C ps = qperm<QP_SWAP12>(pw), cs = qperm<QP_SWAP12>(c);
   // lane 0: ps + xi cs ; lane 1: cs + xi ps ; lane 2: cs + ps
-  const Fp2 A = fp2_sel(q == 0, ps, cs), B = fp2_sel(q == 0, cs, ps);
-  const Fp2 xiB = fp2_fit(fp2_mul_xi(B));
-  return fp2_fit(fp2_add(A, fp2_sel(q == 2, B, xiB)));
+  const C A = fp2_sel(q == 0, ps, cs), B = fp2_sel(q == 0, cs, ps);
+  const auto xiB = fp2_mul_xi(B);
+  using X = std::remove_const_t<decltype(xiB)>;
+  X Bw;
+  Bw.a = B.a; Bw.b = B.b;                                          // widening
+  return fp2_fit(fp2_add(A, fp2_sel(q == 2, Bw, xiB)));
 }
 
 __device__ __forceinline__ Q12 fp12_mul_q(const Q12& x, const Q12& y, int q) {
@@ -133,24 +143,24 @@ __device__ __forceinline__ Q12 fp12_sqr_q(const Q12& x, int q) {
   return o;
 }
 
-// f * (c0 + c1 v + c4 v w); the line coefficients are replicated in the quad
+// f * (c0 + c1 v + c4 v w); the line coefficients are replicated in the quad.  Five products per lane:
+// two sparse Fp6 products (c0, c1, 0) and f.c1 * (c4 v) = v * (f.c1 scaled by c4), column-local.
 __device__ __forceinline__ Q12 fp12_mul_by_014_q(const Q12& f, const Fp2& c0, const Fp2& c1, const Fp2& c4, int q) {
   const Fp2 z = fp2_zero();
   const Fp2 o = fp2_fit(fp2_add(c1, c4));
   const Fp2 y01 = fp2_sel(q == 0, c0, fp2_sel(q == 1, c1, z));   // (c0, c1, 0)
   const Fp2 y0o = fp2_sel(q == 0, c0, fp2_sel(q == 1, o, z));    // (c0, c1 + c4, 0)
-  const Fp2 y4 = fp2_sel(q == 1, c4, z);                         // (0, c4, 0)
   const Fp2 fs = fp2_fit(fp2_add(f.c0, f.c1));
-  Fp2 aa = z, bb = z, s = z;
+  Fp2 aa = z, s = z;
 #pragma unroll 1
-  for (int r = 0; r < 3; ++r) {
-    const Fp2 a = fp2_sel(r == 0, f.c0, fp2_sel(r == 1, f.c1, fs));
-    const Fp2 b = fp2_sel(r == 0, y01, fp2_sel(r == 1, y4, y0o));
+  for (int r = 0; r < 2; ++r) {
+    const Fp2 a = fp2_sel(r == 0, f.c0, fs);
+    const Fp2 b = fp2_sel(r == 0, y01, y0o);
     const Fp2 m = fp6_mul_q(a, b, q);
     aa = fp2_sel(r == 0, m, aa);
-    bb = fp2_sel(r == 1, m, bb);
-    s = fp2_sel(r == 2, m, s);
+    s = fp2_sel(r != 0, m, s);
   }
+  const Fp2 bb = fp6_mul_v_q(fp2_fit(fp2_mul(f.c1, c4)), q);
   Q12 r;
   r.c1 = fp2_fit(fp2_sub(fp2_sub(s, aa), bb));
   r.c0 = fp2_fit(fp2_add(fp6_mul_v_q(bb, q), aa));
@@ -274,6 +284,14 @@ __device__ __forceinline__ Fp2 fp2_small12(const Fp2& x) {    // 12 x, storage f
   return fp2_fit(fp2_dbl(fp2_dbl(t)));
 }
 
+// squaring round: both halves square their operand
+template <int L1, int V1>
+__device__ __forceinline__ void pair_round_sqr(Fp2& pa, Fp2& pb, const Fp2T<L1, V1>& u, bool hb) {
+  const Fp2 m = fp2_fit(fp2_sqr(u));
+  const Fp2 mo = qperm<QP_PAIRSWAP>(m);
+  pa = fp2_sel(hb, mo, m);
+  pb = fp2_sel(hb, m, mo);
+}
 // one round: this lane multiplies (u, v); returns the product of half 0 in pa and of half 1 in pb
 template <int L1, int V1, int L2, int V2>
 __device__ __forceinline__ void pair_round(Fp2& pa, Fp2& pb, const Fp2T<L1, V1>& u, const Fp2T<L2, V2>& v, bool hb) {
@@ -294,13 +312,13 @@ __device__ __forceinline__ G2Line g2_double_q(G2Proj& T, const G1Aff& P, int h) 
   {
     const auto yz = fp2_add(Y, Z);
     const auto u = fp2_sel(hb, yz, fp2_widen<2, 2 * STORE_V>(Z));
-    pair_round(c, syz, u, u, hb);                                                // Z^2 | (Y+Z)^2
+    pair_round_sqr(c, syz, u, hb);                                               // Z^2 | (Y+Z)^2
   }
   const Fp2 e = fp2_fit(fp2_mul_xi(fp2_small12(c)));                             // b' * 3c = 12 xi c
   const Fp2 hh = fp2_fit(fp2_sub(syz, fp2_add(b, c)));                           // (Y+Z)^2 - b - c
   {
     const Fp2 u = fp2_sel(hb, e, X);
-    pair_round(j, e2, u, u, hb);                                                 // X^2 | e^2
+    pair_round_sqr(j, e2, u, hb);                                                // X^2 | e^2
   }
   {
     const Fp2 f3 = fp2_fit(fp2_add(fp2_dbl(e), e));
@@ -329,7 +347,7 @@ __device__ __forceinline__ G2Line g2_add_q(G2Proj& T, const G2Aff& Q, const G1Af
   const Fp2 th = fp2_fit(fp2_sub(Y, yz)), lam = fp2_fit(fp2_sub(X, xz));
   {
     const Fp2 u = fp2_sel(hb, lam, th);
-    pair_round(c, d, u, u, hb);                                                  // theta^2 | lambda^2
+    pair_round_sqr(c, d, u, hb);                                                 // theta^2 | lambda^2
   }
   pair_round(e, f, fp2_sel(hb, Z, lam), fp2_sel(hb, c, d), hb);                  // lambda d | Z c
   pair_round(g, tq, fp2_sel(hb, th, X), fp2_sel(hb, Q.x, d), hb);                // X d | theta Qx
