@@ -58,6 +58,7 @@ struct vrfhip_ctx {
   // MSM workspace (grown on demand) and device facts
   void* d_msm_ws = nullptr;
   size_t msm_ws_bytes = 0;
+  unsigned long long* d_queue = nullptr;   // work-queue counter of k_tai_find
   int cus = 256;
   // optional per-stage timing (hipEvents on the launch stream), see vrfhip_ctx_profile
   bool prof = false;
@@ -221,6 +222,7 @@ int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out) 
   HIP_TRY_C(hipMalloc(&ctx->d_g_win, 2 * WIN_TABLE_WORDS * sizeof(uint32_t)));
   HIP_TRY_C(hipMalloc(&ctx->d_g_comb, comb_bytes));
   HIP_TRY_C(hipMalloc(&ctx->d_b_comb, comb_bytes));
+  HIP_TRY_C(hipMalloc(&ctx->d_queue, 256));
   HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_p, vrfk_tables::SQRT_P, sqrt_p_bytes, hipMemcpyHostToDevice,
                            ctx->stream));
   HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_lut, vrfk_tables::SQRT_LUT, lut_bytes, hipMemcpyHostToDevice,
@@ -252,6 +254,7 @@ void vrfhip_ctx_destroy(vrfhip_ctx* ctx) {
     if (ctx->d_g_win) (void)hipFree(ctx->d_g_win);
     if (ctx->d_g_comb) (void)hipFree(ctx->d_g_comb);
     if (ctx->d_b_comb) (void)hipFree(ctx->d_b_comb);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   }
   delete ctx;
@@ -437,6 +440,7 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
     if (d_msg_off) a.msg = make_view(d_msg, d_msg_off + base, 0, false);
     else a.msg = make_view(d_msg ? d_msg + base * (size_t)msg_len : nullptr, nullptr, msg_len, false);
     a.h_given = d_input ? d_input + base * 32 : nullptr;
+    a.tai_queue = ctx->d_queue;
     a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
     a.gamma = at(o.output, base, 32); a.c = at(o.c, base, 32); a.s = at(o.s, base, 32);
     a.pk_out = at(o.pk, base, 32);

@@ -1,6 +1,7 @@
 // k_prove.hip -- IETF ECVRF batch proving kernels.
 // Replaces `Input::new`, `Secret::output` and `ietf::Prover::prove` (/root/reference src/lib.rs:14-16).
 #include "kernels.h"
+#include <algorithm>
 
 namespace vrf {
 
@@ -13,8 +14,10 @@ __global__ void __launch_bounds__(BLOCK) k_prove_prepare(ProveArgs a) {
   load32(sk, a.sk, i);
   const uint8_t* msg = nullptr; uint32_t msg_len = 0;
   if (a.h_given) load32(hg, a.h_given, i); else bytes_get(a.msg, i, msg, msg_len);
+  // try-and-increment suites: k_tai_find left the first decodable counter in the item's flag byte
+  const uint32_t tai_start = (!S::H2C_ELL2 && !a.h_given) ? a.ws.flags[i] : 0u;
   bool ok = prove_prepare_item<S>(h_enc, k, a.ws.tabs + i * (2 * WIN_TABLE_WORDS), a.T, sk, msg,
-                                        msg_len, a.h_given ? hg : nullptr);
+                                        msg_len, a.h_given ? hg : nullptr, tai_start);
   uint32_t* aux = a.ws.aux + i * AUX_WORDS;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { aux[j] = h_enc[j]; aux[8 + j] = k[j]; }
@@ -28,6 +31,45 @@ __global__ void __launch_bounds__(BLOCK) k_prove_prepare(ProveArgs a) {
     for (int j = 0; j < 8; ++j) { aux[16 + j] = b[j]; aux[24 + j] = kb[j]; }
   }
   a.ws.flags[i] = ok ? 1 : 0;
+}
+
+// stage 0 for try-and-increment suites: find every item's first counter whose candidate decodes.  A lane that
+// loops until ITS item succeeds makes the wave pay the maximum over 64 geometric trials (about 7 attempts for
+// an expected 2).  Here the lanes of a persistent wave draw items from a global queue: a lane whose attempt
+// succeeded records the counter and takes the next item at once, so a wave performs about two attempts per
+// item and the only idle lanes are those of the last few iterations of the whole grid.
+template <class S>
+__global__ void __launch_bounds__(64) k_tai_find(size_t n, BytesView msg, uint8_t* ctr_out, SqrtTables T,
+                                                 unsigned long long* queue) {
+  constexpr size_t NONE = ~size_t(0);
+  const int lane = threadIdx.x;
+  size_t item = NONE;
+  uint32_t ctr = 0;
+  bool drained = false;                                    // the queue has no items left (wave-uniform)
+  while (true) {
+    const bool need = item == NONE && !drained;
+    const unsigned long long mask = __ballot(need);
+    if (mask) {
+      const uint32_t cnt = (uint32_t)__popcll(mask);
+      const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(queue, (unsigned long long)cnt);
+      base = __shfl(base, 0, 64);
+      if (need && base + rank < n) { item = (size_t)(base + rank); ctr = 0; }
+      if (base + cnt >= n) drained = true;
+    }
+    if (!__any(item != NONE)) break;                       // every lane idle and nothing left to draw
+    if (item != NONE) {
+      const uint8_t* m; uint32_t len;
+      bytes_get(msg, item, m, len);
+      if (tai_attempt_decodes<S>(m, len, ctr, T) || ctr == 255) {
+        ctr_out[item] = (uint8_t)ctr;
+        item = NONE;
+      } else {
+        ++ctr;
+      }
+    }
+  }
 }
 
 // stage 1 for the common case (Elligator suite, H from messages): PROVE_K proofs per lane share the two
@@ -136,10 +178,17 @@ __global__ void __launch_bounds__(BLOCK) k_prove_finish(ProveArgs a) {
 template <class S>
 static void launch_prove_t(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], st);
-  if (S::H2C_ELL2 && !a.h_given)
+  if (S::H2C_ELL2 && !a.h_given) {
     hipLaunchKernelGGL(k_prove_prepare_multi<S>, grid_for((a.n + a.k_lane - 1) / a.k_lane), dim3(BLOCK), 0, st, a);
-  else
+  } else {
+    if (!S::H2C_ELL2 && !a.h_given) {
+      (void)hipMemsetAsync(a.tai_queue, 0, sizeof(unsigned long long), st);
+      const size_t waves = std::min<size_t>((a.n + 63) / 64, 4096);        // persistent: 4 waves per SIMD
+      hipLaunchKernelGGL(k_tai_find<S>, dim3((unsigned)waves), dim3(64), 0, st, a.n, a.msg, a.ws.flags, a.T.sq,
+                         a.tai_queue);
+    }
     hipLaunchKernelGGL(k_prove_prepare<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  }
   if (ev) (void)hipEventRecord(ev[1], st);
   hipLaunchKernelGGL(k_prove_mul<S>, grid_for(2 * a.n), dim3(BLOCK), 0, st, a);
   if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }

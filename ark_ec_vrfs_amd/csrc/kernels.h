@@ -63,6 +63,7 @@ struct ProveArgs {
   // Pedersen (pedersen != 0): c is unused; pk_out receives pk_com; extra outputs below
   int pedersen;
   uint8_t *r_out, *ok_out, *sb_out, *blinding_out;
+  unsigned long long* tai_queue;   // 8-byte device counter for k_tai_find (try-and-increment suites)
   Workspace ws;
   DevTables T;
 };

@@ -811,23 +811,43 @@ VRF_HD PtE hash_to_curve_ell2(const uint8_t* msg, uint32_t msg_len, const SqrtTa
 // [ref src/lib.rs:14 `utils::hash_to_curve_tai_rfc_9381`]  SURVEY.md A.6 (unpinned): for ctr = 0..255:
 // h = SHA512(suite_id || 0x01 || data || ctr || 0x00); decode h[0..32] as a point; clear the
 // cofactor; first non-identity result wins.  Lanes iterate until they succeed (about two trips).
+// candidate encoding of attempt `ctr`: the first 32 bytes of SHA512(suite_id || 0x01 || data || ctr || 0x00)
 template <class S>
-VRF_HD PtE hash_to_curve_tai(const uint8_t* msg, uint32_t msg_len, const SqrtTables& T) {
+VRF_HD void tai_candidate(uint32_t enc[8], const uint8_t* msg, uint32_t msg_len, uint32_t ctr) {
+  Sha512 h;
+  sha512_init(h);
+  put_suite_id<S>(h);
+  sha512_put_byte(h, 0x01);
+  sha512_put_bytes(h, msg, msg_len);
+  sha512_put_byte(h, (uint8_t)ctr);
+  sha512_put_byte(h, 0x00);
+  sha512_final(h);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) enc[j] = sha512_word_mem(h, j);
+}
+// Does attempt `ctr` decode to a curve point?  (y < q, denominator non-zero, (y^2-1)(d y^2-a) a square: the
+// same verdict as decode_phase_b on (y^2-1)/(d y^2-a), without the inversion.)  k_tai_find uses it to hand
+// hash_to_curve_tai a starting counter; a candidate of small order passes here and is rejected there.
+template <class S>
+VRF_HD bool tai_attempt_decodes(const uint8_t* msg, uint32_t msg_len, uint32_t ctr, const SqrtTables& T) {
+  uint32_t enc[8];
+  tai_candidate<S>(enc, msg, msg_len, ctr);
+  DecodeA a = decode_phase_a<S>(enc);
+  FeN root;
+  bool sq = fe_sqrt_or_zsqrt(root, fe_mul(a.num, a.den), T);
+  sq = sq || fe_is_zero(root);
+  return a.ok && sq;
+}
+
+// start: first counter to try (0, or the hint of k_tai_find: every smaller counter is known not to decode)
+template <class S>
+VRF_HD PtE hash_to_curve_tai(const uint8_t* msg, uint32_t msg_len, const SqrtTables& T, uint32_t start = 0) {
   PtE res = te_identity();
   bool done = false;
 #pragma unroll 1
-  for (uint32_t ctr = 0; ctr < 256 && !done; ++ctr) {
-    Sha512 h;
-    sha512_init(h);
-    put_suite_id<S>(h);
-    sha512_put_byte(h, 0x01);
-    sha512_put_bytes(h, msg, msg_len);
-    sha512_put_byte(h, (uint8_t)ctr);
-    sha512_put_byte(h, 0x00);
-    sha512_final(h);
+  for (uint32_t ctr = start; ctr < 256 && !done; ++ctr) {
     uint32_t enc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) enc[j] = sha512_word_mem(h, j);
+    tai_candidate<S>(enc, msg, msg_len, ctr);
     DecodeA a = decode_phase_a<S>(enc);
     FeN di = fe_inv(a.den);
     Fe<1, 4> x;
@@ -846,9 +866,9 @@ VRF_HD PtE hash_to_curve_tai(const uint8_t* msg, uint32_t msg_len, const SqrtTab
 
 // [ref src/lib.rs:15-16 `Input::new` / `Suite::data_to_point`]
 template <class S>
-VRF_HD PtE data_to_point(const uint8_t* msg, uint32_t msg_len, const SqrtTables& T) {
+VRF_HD PtE data_to_point(const uint8_t* msg, uint32_t msg_len, const SqrtTables& T, uint32_t tai_start = 0) {
   if constexpr (S::H2C_ELL2) return hash_to_curve_ell2<S>(msg, msg_len, T);
-  else return hash_to_curve_tai<S>(msg, msg_len, T);
+  else return hash_to_curve_tai<S>(msg, msg_len, T, tai_start);
 }
 
 // ------------------------------------------------------------------------ nonce
@@ -919,7 +939,7 @@ VRF_HD void pedersen_blinding(uint32_t b[8], const uint32_t sk[8], const uint32_
 template <class S>
 VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, const DevTables& T,
                                const uint32_t sk[8], const uint8_t* msg, uint32_t msg_len,
-                               const uint32_t* h_given) {
+                               const uint32_t* h_given, uint32_t tai_start = 0) {
   FeN x, y;
   bool valid = fr_is_canonical<S>(sk);
   if (h_given) {
@@ -930,7 +950,7 @@ VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, 
     x = fe_mul(xx, fe_one());
     y = a.y;
   } else {
-    PtE hp = data_to_point<S>(msg, msg_len, T.sq);
+    PtE hp = data_to_point<S>(msg, msg_len, T.sq, tai_start);
     te_to_affine(x, y, hp);
   }
   te_encode_affine(h_enc, x, y);

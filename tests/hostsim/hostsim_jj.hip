@@ -41,6 +41,20 @@ void hj_hash_to_curve(const uint8_t* msg, uint32_t len, uint8_t* out) {
   uint32_t e[8]; te_encode_affine(e, x, y); memcpy(out, e, 32);
 }
 // out: gamma | c | s | pk | h  (IETF, pedersen = 0)  or  gamma | pk_com | r | ok | s | sb | blinding (pedersen = 1)
+// first counter whose candidate decodes (the verdict k_tai_find uses), and hash-to-curve started from a hint
+int hj_tai_first_decodable(const uint8_t* msg, uint32_t len) {
+  for (uint32_t ctr = 0; ctr < 256; ++ctr)
+    if (tai_attempt_decodes<SuiteJJ>(msg, len, ctr, HJ().t.sq)) return (int)ctr;
+  return 255;
+}
+void hj_hash_to_curve_from(const uint8_t* msg, uint32_t len, uint32_t start, uint8_t* out) {
+  PtE h = hash_to_curve_tai<SuiteJJ>(msg, len, HJ().t.sq, start);
+  FeN x, y;
+  te_to_affine(x, y, h);
+  uint32_t e[8];
+  te_encode_affine(e, x, y);
+  memcpy(out, e, 32);
+}
 int hj_prove(int pedersen, const uint8_t* sk, const uint8_t* msg, uint32_t len, const uint8_t* ad, uint32_t ad_len, uint8_t* out) {
   uint32_t skw[8]; memcpy(skw, sk, 32);
   uint32_t h_enc[8], k[8], kb[8], b[8], o[6][8], sb[8];

@@ -94,6 +94,27 @@ def test_hostsim_jubjub_equals_oracle(hj, J):
         assert hj.hj_pedersen_verify(o.point_encode(J, H), o.point_encode(J, gm), bytes(tam), ad, len(ad)) == 1
 
 
+def test_tai_counter_hint_is_exact(hj, J):
+    """k_tai_find's verdict (candidate decodes, judged without the inversion) picks the counter try-and-increment
+    stops at: hashing from the hint equals hashing from 0 and the oracle, and no smaller counter decodes."""
+    buf = ctypes.create_string_buffer(32)
+    hist = {}
+    for i in range(120):
+        msg = o.synth_msg(5000 + i) + bytes([i]) * (i % 5)
+        h = hj.hj_tai_first_decodable(msg, len(msg))
+        hist[h] = hist.get(h, 0) + 1
+        want = o.point_encode(J, o.data_to_point(J, msg))
+        hj.hj_hash_to_curve_from(msg, len(msg), h, buf)
+        assert buf.raw == want
+        hj.hj_hash_to_curve_from(msg, len(msg), 0, buf)
+        assert buf.raw == want
+        # the oracle's own candidates: every counter below the hint fails to decode
+        for ctr in range(h):
+            cand = o.sha512(J.suite_id + b"\x01" + msg + bytes([ctr]) + b"\x00")[:32]
+            assert o.point_decode(J, cand) is None
+    assert len(hist) >= 3 and hist.get(0, 0) > 30          # about half succeed at once, a tail beyond
+
+
 @pytest.fixture(scope="module")
 def ctx_jj():
     from ark_ec_vrfs_amd import Context, JubJubSha512Tai
