@@ -1,0 +1,282 @@
+// vrfhip.hpp -- C++ host-side mirror of the `ark-ec-vrfs` / `ark-vrf` API over the C ABI (vrfhip.h).
+//
+// The reference is a Rust crate whose whole surface is the re-export list at /root/reference src/lib.rs:13-17
+// (`Suite`, `Secret`, `Public`, `Input`, `Output`, `ietf`, `pedersen`, `Error`, `codec`).  There is no Rust
+// toolchain in this image, so the host side above the C ABI is written in C++ with the reference's names,
+// argument order and error behaviour; INTEGRATION.md shows the equivalent Rust binding.  Header-only; every
+// call forwards to libvrfhip.so (hand-written HIP kernels) -- there is no CPU path.
+//
+//   Rust (ark-vrf)                                         here (namespace ark_vrf_hip)
+//   Secret::<S>::from_seed(seed)                           Secret<S>::from_seed(ctx, seed)
+//   secret.public()                                        secret.public_key()
+//   Input::<S>::new(data) -> Option<Input>                 Input<S>::new_(ctx, data) -> std::optional<Input<S>>
+//   secret.output(input)                                   secret.output(ctx, input)
+//   output.hash()                                          output.hash(ctx)
+//   ietf::Prover::prove(&secret, input, output, ad)        ietf::prove(ctx, secret, input, output, ad)
+//   ietf::Verifier::verify(&public, input, output, ad, &p) ietf::verify(ctx, public, input, output, ad, p) -> Result
+//   pedersen::Prover::prove(..) -> (Proof, blinding)       pedersen::prove(..) -> std::pair<Proof, Scalar>
+//   pedersen::Verifier::verify(input, output, ad, &p)      pedersen::verify(ctx, input, output, ad, p) -> Result
+//   Error::{VerificationFailure, InvalidData}              enum class Error; Result = std::optional<Error> (nullopt = Ok(()))
+// Batch forms (what the GPU is for) take std::vector of the same types: ietf::verify_batch, ietf::prove_batch,
+// pedersen::verify_batch (single-MSM random-linear-combination path with automatic per-proof fallback).
+#ifndef VRFHIP_HPP
+#define VRFHIP_HPP
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <optional>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "vrfhip.h"
+
+namespace ark_vrf_hip {
+
+using Bytes32 = std::array<uint8_t, 32>;
+using Scalar = Bytes32;                       // `ScalarField`, 32-byte little-endian canonical
+using Bytes = std::vector<uint8_t>;
+
+// `Error` (src/lib.rs:15)
+enum class Error { VerificationFailure = VRFHIP_ST_VERIFICATION_FAILURE, InvalidData = VRFHIP_ST_INVALID_DATA };
+using Result = std::optional<Error>;          // std::nullopt == Ok(())
+
+inline Result result_of(uint8_t status) {
+  if (status == VRFHIP_ST_OK) return std::nullopt;
+  return status == VRFHIP_ST_VERIFICATION_FAILURE ? Error::VerificationFailure : Error::InvalidData;
+}
+
+// `Suite` (src/lib.rs:16): compile-time suite tags
+struct BandersnatchSha512Ell2 {
+  static constexpr vrfhip_suite ID = VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2;
+  static constexpr const char* SUITE_ID = "Bandersnatch_SHA-512_ELL2";
+};
+struct JubJubSha512Tai {
+  static constexpr vrfhip_suite ID = VRFHIP_SUITE_JUBJUB_SHA512_TAI;
+  static constexpr const char* SUITE_ID = "JubJub_SHA-512_TAI";
+};
+
+// API / runtime failure of the library (negative vrfhip_error): not a per-item outcome
+struct ApiError : std::runtime_error {
+  int code;
+  ApiError(int c, const std::string& what) : std::runtime_error(what + ": " + vrfhip_last_error()), code(c) {}
+};
+inline void check(int32_t rc, const char* what) {
+  if (rc != VRFHIP_SUCCESS) throw ApiError(rc, what);
+}
+
+// one GPU, one suite: owns the device tables and workspace
+template <class S>
+class Context {
+ public:
+  explicit Context(int device = 0) { check(vrfhip_ctx_create(S::ID, device, &h_), "vrfhip_ctx_create"); }
+  ~Context() { vrfhip_ctx_destroy(h_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  vrfhip_ctx* handle() const { return h_; }
+
+ private:
+  vrfhip_ctx* h_ = nullptr;
+};
+
+template <class S> struct Public { Bytes32 encoded; };     // `Public`: compressed point (ArkworksCodec)
+template <class S> struct Output;
+
+template <class S>
+struct Input {                                              // `Input`
+  Bytes32 encoded;
+  // `Input::new(data)`: hash-to-curve (Elligator 2 / try-and-increment); None never happens for these suites
+  static std::optional<Input> new_(const Context<S>& ctx, const Bytes& data) {
+    Input in;
+    check(vrfhip_hash_to_curve_batch(ctx.handle(), 1, data.empty() ? in.encoded.data() : data.data(), nullptr,
+                                     (uint32_t)data.size(), in.encoded.data()), "vrfhip_hash_to_curve_batch");
+    return in;
+  }
+};
+
+template <class S>
+struct Output {                                             // `Output`
+  Bytes32 encoded;
+  std::array<uint8_t, 64> hash(const Context<S>& ctx) const {   // `Output::hash()`
+    std::array<uint8_t, 64> h;
+    check(vrfhip_output_hash_batch(ctx.handle(), 1, encoded.data(), h.data()), "vrfhip_output_hash_batch");
+    return h;
+  }
+};
+
+template <class S>
+struct Secret {                                             // `Secret`
+  Scalar scalar;
+  Bytes32 pk;
+  static Secret from_seed(const Context<S>& ctx, const Bytes& seed) {          // `Secret::from_seed`
+    Secret s;
+    uint8_t dummy = 0;
+    check(vrfhip_secret_from_seed_batch(ctx.handle(), 1, seed.empty() ? &dummy : seed.data(), (uint32_t)seed.size(),
+                                        s.scalar.data(), s.pk.data()), "vrfhip_secret_from_seed_batch");
+    return s;
+  }
+  Public<S> public_key() const { return Public<S>{pk}; }                       // `Secret::public`
+  Output<S> output(const Context<S>& ctx, const Input<S>& in) const;           // `Secret::output`
+};
+
+namespace detail {
+inline const uint8_t* ad_ptr(const Bytes& ad) {
+  static const uint8_t zero = 0;
+  return ad.empty() ? &zero : ad.data();
+}
+template <class T, class F>
+Bytes column(const std::vector<T>& v, F field) {
+  Bytes out(v.size() * 32);
+  for (size_t i = 0; i < v.size(); ++i) std::memcpy(out.data() + 32 * i, field(v[i]).data(), 32);
+  return out;
+}
+}  // namespace detail
+
+// -------------------------------------------------------------------------------- `ietf` (src/lib.rs:14)
+namespace ietf {
+template <class S> struct Proof { Scalar c, s; };
+
+template <class S>
+struct Item { Public<S> pub; Input<S> input; Output<S> output; Proof<S> proof; };
+
+// `ietf::Prover::prove`
+template <class S>
+Proof<S> prove(const Context<S>& ctx, const Secret<S>& sk, const Input<S>& in, const Output<S>& out, const Bytes& ad) {
+  Proof<S> p;
+  Bytes32 gamma;
+  uint8_t st = 0;
+  check(vrfhip_ietf_prove_batch(ctx.handle(), 1, sk.scalar.data(), nullptr, nullptr, 0, in.encoded.data(),
+                                detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), gamma.data(), p.c.data(), p.s.data(),
+                                nullptr, nullptr, &st), "vrfhip_ietf_prove_batch");
+  if (st != VRFHIP_ST_OK || gamma != out.encoded) throw std::invalid_argument("ietf::prove: secret/input/output mismatch");
+  return p;
+}
+// `ietf::Verifier::verify`
+template <class S>
+Result verify(const Context<S>& ctx, const Public<S>& pub, const Input<S>& in, const Output<S>& out, const Bytes& ad,
+              const Proof<S>& p) {
+  uint8_t st = 0;
+  check(vrfhip_ietf_verify_batch(ctx.handle(), 1, pub.encoded.data(), in.encoded.data(), out.encoded.data(),
+                                 p.c.data(), p.s.data(), detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), &st),
+        "vrfhip_ietf_verify_batch");
+  return result_of(st);
+}
+// n x verify, one launch group
+template <class S>
+std::vector<Result> verify_batch(const Context<S>& ctx, const std::vector<Item<S>>& items, const Bytes& ad) {
+  const size_t n = items.size();
+  Bytes pk = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.pub.encoded; });
+  Bytes h = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.input.encoded; });
+  Bytes g = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.output.encoded; });
+  Bytes c = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.c; });
+  Bytes s = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.s; });
+  Bytes st(n);
+  check(vrfhip_ietf_verify_batch(ctx.handle(), n, pk.data(), h.data(), g.data(), c.data(), s.data(), detail::ad_ptr(ad),
+                                 nullptr, (uint32_t)ad.size(), st.data()), "vrfhip_ietf_verify_batch");
+  std::vector<Result> r(n);
+  for (size_t i = 0; i < n; ++i) r[i] = result_of(st[i]);
+  return r;
+}
+// n x (Input::new + Secret::output + prove) from fixed-length messages
+template <class S>
+std::vector<Item<S>> prove_batch(const Context<S>& ctx, const std::vector<Secret<S>>& sks, const std::vector<Bytes>& msgs,
+                                 const Bytes& ad) {
+  const size_t n = sks.size();
+  if (msgs.size() != n) throw std::invalid_argument("prove_batch: ragged batch");
+  Bytes sk = detail::column(sks, [](const Secret<S>& t) -> const Scalar& { return t.scalar; });
+  Bytes blob;
+  std::vector<uint32_t> off(n + 1, 0);
+  for (size_t i = 0; i < n; ++i) { blob.insert(blob.end(), msgs[i].begin(), msgs[i].end()); off[i + 1] = (uint32_t)blob.size(); }
+  blob.push_back(0);
+  Bytes g(32 * n), c(32 * n), s(32 * n), pk(32 * n), h(32 * n), st(n);
+  check(vrfhip_ietf_prove_batch(ctx.handle(), n, sk.data(), blob.data(), off.data(), 0, nullptr, detail::ad_ptr(ad), nullptr,
+                                (uint32_t)ad.size(), g.data(), c.data(), s.data(), pk.data(), h.data(), st.data()),
+        "vrfhip_ietf_prove_batch");
+  std::vector<Item<S>> items(n);
+  for (size_t i = 0; i < n; ++i) {
+    if (st[i] != VRFHIP_ST_OK) throw std::invalid_argument("prove_batch: invalid secret");
+    std::memcpy(items[i].pub.encoded.data(), pk.data() + 32 * i, 32);
+    std::memcpy(items[i].input.encoded.data(), h.data() + 32 * i, 32);
+    std::memcpy(items[i].output.encoded.data(), g.data() + 32 * i, 32);
+    std::memcpy(items[i].proof.c.data(), c.data() + 32 * i, 32);
+    std::memcpy(items[i].proof.s.data(), s.data() + 32 * i, 32);
+  }
+  return items;
+}
+}  // namespace ietf
+
+template <class S>
+Output<S> Secret<S>::output(const Context<S>& ctx, const Input<S>& in) const {
+  Output<S> out;
+  Scalar c, s;
+  uint8_t st = 0;
+  check(vrfhip_ietf_prove_batch(ctx.handle(), 1, scalar.data(), nullptr, nullptr, 0, in.encoded.data(), detail::ad_ptr({}),
+                                nullptr, 0, out.encoded.data(), c.data(), s.data(), nullptr, nullptr, &st),
+        "vrfhip_ietf_prove_batch");
+  if (st != VRFHIP_ST_OK) throw std::invalid_argument("Secret::output: invalid secret or input");
+  return out;
+}
+
+// -------------------------------------------------------------------------------- `pedersen` (src/lib.rs:14)
+namespace pedersen {
+template <class S> struct Proof { Bytes32 pk_com, r, ok; Scalar s, sb; };
+template <class S> struct Item { Input<S> input; Output<S> output; Proof<S> proof; };
+
+// `pedersen::Prover::prove` -> (proof, blinding factor)
+template <class S>
+std::pair<Proof<S>, Scalar> prove(const Context<S>& ctx, const Secret<S>& sk, const Input<S>& in, const Output<S>& out,
+                                  const Bytes& ad) {
+  Proof<S> p;
+  Scalar blinding;
+  Bytes32 gamma;
+  uint8_t st = 0;
+  check(vrfhip_pedersen_prove_batch(ctx.handle(), 1, sk.scalar.data(), nullptr, nullptr, 0, in.encoded.data(),
+                                    detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), gamma.data(), p.pk_com.data(),
+                                    p.r.data(), p.ok.data(), p.s.data(), p.sb.data(), blinding.data(), nullptr, &st),
+        "vrfhip_pedersen_prove_batch");
+  if (st != VRFHIP_ST_OK || gamma != out.encoded) throw std::invalid_argument("pedersen::prove: secret/input/output mismatch");
+  return {p, blinding};
+}
+// `pedersen::Verifier::verify`
+template <class S>
+Result verify(const Context<S>& ctx, const Input<S>& in, const Output<S>& out, const Bytes& ad, const Proof<S>& p) {
+  uint8_t st = 0;
+  check(vrfhip_pedersen_verify_batch(ctx.handle(), 1, in.encoded.data(), out.encoded.data(), p.pk_com.data(), p.r.data(),
+                                     p.ok.data(), p.s.data(), p.sb.data(), detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(),
+                                     &st), "vrfhip_pedersen_verify_batch");
+  return result_of(st);
+}
+// n x verify through ONE multi-scalar multiplication (random linear combination); a failed batch is re-checked
+// per proof inside the library, so the results are those of n calls of verify().  *fast_path (optional) tells
+// whether the single MSM sufficed.
+template <class S>
+std::vector<Result> verify_batch(const Context<S>& ctx, const std::vector<Item<S>>& items, const Bytes& ad,
+                                 bool* fast_path = nullptr) {
+  const size_t n = items.size();
+  Bytes h = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.input.encoded; });
+  Bytes g = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.output.encoded; });
+  Bytes pc = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.pk_com; });
+  Bytes r = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.r; });
+  Bytes ok = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.ok; });
+  Bytes s = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.s; });
+  Bytes sb = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.sb; });
+  std::array<uint8_t, 32> seed;
+  std::random_device rd;                                   // must be unpredictable to the provers
+  for (auto& b : seed) b = (uint8_t)rd();
+  Bytes st(n);
+  int32_t fast = 1;
+  check(vrfhip_pedersen_verify_batch_rlc(ctx.handle(), n, h.data(), g.data(), pc.data(), r.data(), ok.data(), s.data(),
+                                         sb.data(), detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), seed.data(), st.data(),
+                                         &fast), "vrfhip_pedersen_verify_batch_rlc");
+  if (fast_path) *fast_path = fast != 0;
+  std::vector<Result> res(n);
+  for (size_t i = 0; i < n; ++i) res[i] = result_of(st[i]);
+  return res;
+}
+}  // namespace pedersen
+
+}  // namespace ark_vrf_hip
+#endif  // VRFHIP_HPP

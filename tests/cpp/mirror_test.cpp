@@ -1,0 +1,110 @@
+// tests/cpp/mirror_test.cpp -- the C++ host-side mirror (include/vrfhip.hpp) exercised the way upstream's own
+// tests drive the Rust API: from_seed -> Input::new -> output -> prove -> verify, against the golden vector
+// handed over by tests/test_cpp_mirror.py (hex on the command line), then batches through the GPU.
+//   mirror_test <seed> <alpha> <ad> <pk> <h> <gamma> <beta> <c> <s>   <ped_ad> <blinding> <pk_com> <r> <ok> <ps> <psb>
+// Exit code 0 = every check passed; prints the first failing check otherwise.
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "vrfhip.hpp"
+
+using namespace ark_vrf_hip;
+using S = BandersnatchSha512Ell2;
+
+static Bytes unhex(const std::string& h) {
+  Bytes b(h.size() / 2);
+  for (size_t i = 0; i < b.size(); ++i) b[i] = (uint8_t)std::stoul(h.substr(2 * i, 2), nullptr, 16);
+  return b;
+}
+template <class A>
+static std::string hex(const A& a) {
+  static const char* d = "0123456789abcdef";
+  std::string s;
+  for (uint8_t v : a) { s.push_back(d[v >> 4]); s.push_back(d[v & 15]); }
+  return s;
+}
+#define CHECK(cond)                                                        \
+  do {                                                                     \
+    if (!(cond)) { std::printf("FAILED: %s (line %d)\n", #cond, __LINE__); return 1; } \
+  } while (0)
+
+int main(int argc, char** argv) {
+  if (argc != 17) { std::printf("usage: mirror_test <16 hex fields>\n"); return 2; }
+  const std::string seed = argv[1], alpha = argv[2], ad = argv[3], pk = argv[4], h = argv[5], gamma = argv[6],
+                    beta = argv[7], c = argv[8], s = argv[9], ped_ad = argv[10], blinding = argv[11], pk_com = argv[12],
+                    pr = argv[13], pok = argv[14], ps = argv[15], psb = argv[16];
+  Context<S> ctx(0);
+
+  // ---- IETF VRF, single items (upstream: ietf::tests / testing::ietf_prove_verify) ----
+  const auto secret = Secret<S>::from_seed(ctx, unhex(seed));
+  const auto pub = secret.public_key();
+  CHECK(hex(pub.encoded) == pk);
+  const auto input = Input<S>::new_(ctx, unhex(alpha));
+  CHECK(input.has_value() && hex(input->encoded) == h);
+  const auto output = secret.output(ctx, *input);
+  CHECK(hex(output.encoded) == gamma);
+  CHECK(hex(output.hash(ctx)) == beta);
+  const auto proof = ietf::prove(ctx, secret, *input, output, unhex(ad));
+  CHECK(hex(proof.c) == c && hex(proof.s) == s);
+  CHECK(!ietf::verify(ctx, pub, *input, output, unhex(ad), proof).has_value());                       // Ok(())
+  Bytes other_ad = unhex(ad);
+  other_ad.push_back(0x5a);
+  CHECK(ietf::verify(ctx, pub, *input, output, other_ad, proof) == Error::VerificationFailure);
+  auto bad = proof;
+  for (auto& b : bad.s) b = 0xff;                                                                      // s >= r
+  CHECK(ietf::verify(ctx, pub, *input, output, unhex(ad), bad) == Error::InvalidData);
+
+  // ---- Pedersen VRF, single item (upstream: pedersen::tests) ----
+  const auto [pproof, blind] = pedersen::prove(ctx, secret, *input, output, unhex(ped_ad));
+  CHECK(hex(blind) == blinding && hex(pproof.pk_com) == pk_com && hex(pproof.r) == pr && hex(pproof.ok) == pok);
+  CHECK(hex(pproof.s) == ps && hex(pproof.sb) == psb);
+  CHECK(!pedersen::verify(ctx, *input, output, unhex(ped_ad), pproof).has_value());
+  CHECK(pedersen::verify(ctx, *input, output, other_ad, pproof) == Error::VerificationFailure);
+
+  // ---- batches ----
+  const size_t n = 2000;
+  std::vector<Secret<S>> sks;
+  std::vector<Bytes> msgs;
+  for (size_t i = 0; i < n; ++i) {
+    Bytes sd(8);
+    for (int k = 0; k < 8; ++k) sd[k] = (uint8_t)(i >> (8 * k));
+    sks.push_back(Secret<S>::from_seed(ctx, sd));
+    msgs.push_back(Bytes(1 + i % 40, (uint8_t)i));                                                      // ragged messages
+  }
+  auto items = ietf::prove_batch(ctx, sks, msgs, unhex(ad));
+  for (size_t i = 0; i < n; i += 97) {                               // batch == single-item path
+    const auto in_i = Input<S>::new_(ctx, msgs[i]);
+    CHECK(in_i->encoded == items[i].input.encoded && sks[i].pk == items[i].pub.encoded);
+    const auto out_i = sks[i].output(ctx, *in_i);
+    CHECK(out_i.encoded == items[i].output.encoded);
+    const auto p_i = ietf::prove(ctx, sks[i], *in_i, out_i, unhex(ad));
+    CHECK(p_i.c == items[i].proof.c && p_i.s == items[i].proof.s);
+  }
+  items[7].proof.s[0] ^= 1;
+  items[1234].output = items[1235].output;
+  for (auto& b : items[1999].proof.c) b = 0xff;
+  const auto res = ietf::verify_batch(ctx, items, unhex(ad));
+  for (size_t i = 0; i < n; ++i) {
+    if (i == 7 || i == 1234) CHECK(res[i] == Error::VerificationFailure);
+    else if (i == 1999) CHECK(res[i] == Error::InvalidData);
+    else CHECK(!res[i].has_value());
+  }
+  // batched Pedersen verification: fast path on a valid batch, per-proof verdicts on a tampered one
+  std::vector<pedersen::Item<S>> pitems;
+  for (size_t i = 0; i < 300; ++i) {
+    const auto in_i = Input<S>::new_(ctx, msgs[i]);
+    const auto out_i = sks[i].output(ctx, *in_i);
+    pitems.push_back({*in_i, out_i, pedersen::prove(ctx, sks[i], *in_i, out_i, unhex(ped_ad)).first});
+  }
+  bool fast = false;
+  auto pres = pedersen::verify_batch(ctx, pitems, unhex(ped_ad), &fast);
+  CHECK(fast);
+  for (const auto& r : pres) CHECK(!r.has_value());
+  pitems[42].proof.sb[3] ^= 8;
+  pres = pedersen::verify_batch(ctx, pitems, unhex(ped_ad), &fast);
+  CHECK(!fast);
+  for (size_t i = 0; i < pitems.size(); ++i) CHECK(i == 42 ? pres[i] == Error::VerificationFailure : !pres[i].has_value());
+  std::printf("mirror_test ok: KAT, %zu IETF proofs, %zu Pedersen proofs\n", n, pitems.size());
+  return 0;
+}
