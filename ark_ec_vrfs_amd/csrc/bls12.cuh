@@ -693,7 +693,8 @@ VRF_HD bool g1_load(G1Aff& P, bool& inf, const uint32_t* w /*24 words*/) {
   uint32_t any = 0;
   for (int i = 0; i < 24; ++i) any |= w[i];
   inf = any == 0;
-  bool ok = fp_from_words(P.x, w) & fp_from_words(P.y, w + 12);
+  const bool okx = fp_from_words(P.x, w), oky = fp_from_words(P.y, w + 12);
+  bool ok = okx && oky;
   // y^2 = x^3 + 4
   auto four = fp_dbl(fp_dbl(fp_one()));
   auto rhs = fp_add(fp_mul(fp_sqr(P.x), P.x), four);
@@ -704,8 +705,9 @@ VRF_HD bool g2_load(G2Aff& Q, bool& inf, const uint32_t* w /*48 words*/) {
   uint32_t any = 0;
   for (int i = 0; i < 48; ++i) any |= w[i];
   inf = any == 0;
-  bool ok = fp_from_words(Q.x.a, w) & fp_from_words(Q.x.b, w + 12) & fp_from_words(Q.y.a, w + 24) &
-            fp_from_words(Q.y.b, w + 36);
+  const bool ok0 = fp_from_words(Q.x.a, w), ok1 = fp_from_words(Q.x.b, w + 12);
+  const bool ok2 = fp_from_words(Q.y.a, w + 24), ok3 = fp_from_words(Q.y.b, w + 36);
+  bool ok = ok0 && ok1 && ok2 && ok3;
   auto rhs = fp2_add(fp2_mul(fp2_sqr(Q.x), Q.x), twist_b());
   ok = ok && (inf || fp2_eq(fp2_sqr(Q.y), rhs));
   return ok;

@@ -93,16 +93,20 @@ __global__ void __launch_bounds__(BLOCK) k_point_validate(size_t n, const uint8_
   FeN di = fe_inv(a.den);
   Fe<1, 4> x;
   bool ok = decode_phase_b<S>(x, a, di, T.sq);
-  uint32_t* tab = tabs + i * WIN_TABLE_WORDS;
-  build_win_table<S>(tab, x, a.y);
-  uint32_t r[8], rec[8];
+  if constexpr (S::SUBGROUP_2DESCENT) {
+    ok = ok && subgroup_by_2descent<S>(a.y, T.sq);
+  } else {
+    uint32_t* tab = tabs + i * WIN_TABLE_WORDS;
+    build_win_table<S>(tab, x, a.y);
+    uint32_t r[8], rec[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = S::r32(j);
-  scalar_recode_signed4(rec, r);
-  PtE rp = win_mul<S>(tab, rec);
-  // identity <=> X == 0 and Y == Z
-  bool is_id = fe_is_zero(rp.X) && fe_eq(rp.Y, rp.Z);
-  ok = ok && is_id;
+    for (int j = 0; j < 8; ++j) r[j] = S::r32(j);
+    scalar_recode_signed4(rec, r);
+    PtE rp = win_mul<S>(tab, rec);
+    // identity <=> X == 0 and Y == Z
+    bool is_id = fe_is_zero(rp.X) && fe_eq(rp.Y, rp.Z);
+    ok = ok && is_id;
+  }
   status[i] = ok ? ST_OK : ST_INVALID_DATA;
   if (xy) {
     uint32_t xw[8], yw[8];

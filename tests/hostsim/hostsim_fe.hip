@@ -48,6 +48,15 @@ void hs_output_hash(const uint8_t* g, uint8_t* out) {
 void hs_secret_from_seed(const uint8_t* seed, uint32_t len, uint8_t* out) {
   uint32_t sk[8]; secret_from_seed_item<SuiteBS>(sk, seed, len); memcpy(out, sk, 32);
 }
+// decode + subgroup test by 2-descent: 0 = in the prime-order subgroup, 2 = not decodable or not in it
+int hs_decode_checked(const uint8_t* enc) {
+  uint32_t w[8]; memcpy(w, enc, 32);
+  DecodeA a = decode_phase_a<SuiteBS>(w);
+  FeN di = fe_inv(a.den);
+  Fe<1,4> xx; bool ok = decode_phase_b<SuiteBS>(xx, a, di, host_tables());
+  ok = ok && subgroup_by_2descent<SuiteBS>(a.y, host_tables());
+  return ok ? 0 : 2;
+}
 int hs_decode(const uint8_t* enc, uint8_t* x, uint8_t* y) {
   uint32_t w[8]; memcpy(w, enc, 32);
   DecodeA a = decode_phase_a<SuiteBS>(w);

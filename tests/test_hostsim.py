@@ -273,3 +273,26 @@ def test_msm_digit_recoding_and_rlc_weights(hs):
     n = 1000
     idx = sorted(hs.hs_rlc_index(p, ctypes.c_uint64(n), ctypes.c_uint64(i)) for p in range(5) for i in range(n))
     assert idx == list(range(3 * n)) + list(range(3 * n + 2, 5 * n + 2))          # 3n, 3n+1 are G and B
+
+
+def test_subgroup_by_2descent_equals_r_times_p(hs):
+    """codec checked decode: the two-square-roots subgroup test (vrf_core.cuh subgroup_by_2descent) against
+    r*P = O (C oracle) on decodable encodings of every coset of the cofactor-4 group, and on the special
+    points: identity, the point of order 2, y = 0."""
+    from oracle import c_oracle as co
+    rnd = random.Random(21)
+    cases = [(1).to_bytes(32, "little"), (Q - 1).to_bytes(32, "little"), bytes(32)]
+    while len(cases) < 1200:
+        enc = bytearray(rnd.randrange(Q).to_bytes(32, "little"))
+        enc[31] |= 0x80 * rnd.randrange(2)
+        cases.append(bytes(enc))
+    cases += [co.hash_to_curve(bytes([i, 7])) for i in range(60)]
+    seen = {0: 0, 2: 0}
+    n_decodable_outside = 0
+    for enc in cases:
+        want = 0 if co.point_decode(enc, subgroup=True) is not None else 2
+        assert hs.hs_decode_checked(enc) == want, enc.hex()
+        seen[want] += 1
+        if want == 2 and co.point_decode(enc, subgroup=False) is not None:
+            n_decodable_outside += 1
+    assert seen[0] > 150 and n_decodable_outside > 300        # members, and curve points outside the subgroup
