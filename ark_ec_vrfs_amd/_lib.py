@@ -19,6 +19,8 @@ SYMBOLS = [
     "vrfhip_ctx_reserve", "vrfhip_ctx_workspace_bytes", "vrfhip_ctx_profile", "vrfhip_ctx_profile_read",
     "vrfhip_ietf_verify_batch", "vrfhip_ietf_verify_batch_dev",
     "vrfhip_ietf_verify_batch_affine", "vrfhip_ietf_verify_batch_affine_dev",
+    "vrfhip_keyset_create", "vrfhip_keyset_destroy", "vrfhip_keyset_bytes",
+    "vrfhip_ietf_verify_batch_keyed", "vrfhip_ietf_verify_batch_keyed_dev",
     "vrfhip_ietf_prove_batch", "vrfhip_ietf_prove_batch_dev",
     "vrfhip_pedersen_prove_batch", "vrfhip_pedersen_prove_batch_dev",
     "vrfhip_pedersen_verify_batch", "vrfhip_pedersen_verify_batch_dev",
@@ -75,6 +77,14 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_ietf_verify_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P, c_void_p]
     lib.vrfhip_ietf_verify_batch_affine.argtypes = lib.vrfhip_ietf_verify_batch.argtypes
     lib.vrfhip_ietf_verify_batch_affine_dev.argtypes = lib.vrfhip_ietf_verify_batch_dev.argtypes
+    lib.vrfhip_keyset_create.argtypes = [c_void_p, c_size_t, P, P, POINTER(c_void_p)]
+    lib.vrfhip_keyset_destroy.argtypes = [c_void_p]
+    lib.vrfhip_keyset_destroy.restype = None
+    lib.vrfhip_keyset_bytes.argtypes = [c_void_p]
+    lib.vrfhip_keyset_bytes.restype = c_size_t
+    lib.vrfhip_ietf_verify_batch_keyed.argtypes = [c_void_p, c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P]
+    lib.vrfhip_ietf_verify_batch_keyed_dev.argtypes = [c_void_p, c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P,
+                                                       c_void_p]
     lib.vrfhip_ietf_prove_batch.argtypes = [c_void_p, c_size_t, P, P, P, c_uint32, P, P, P, c_uint32,
                                             P, P, P, P, P, P]
     lib.vrfhip_ietf_prove_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, c_uint32, P, P, P, c_uint32,
@@ -108,7 +118,8 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_test_pairing_quad_ops.argtypes = [c_void_p, c_size_t, P, P]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("vrfhip_last_error", "vrfhip_ctx_destroy", "vrfhip_ctx_workspace_bytes"):
+        if name not in ("vrfhip_last_error", "vrfhip_ctx_destroy", "vrfhip_ctx_workspace_bytes",
+                        "vrfhip_keyset_destroy", "vrfhip_keyset_bytes"):
             fn.restype = c_int32
     _lib = lib
     return lib

@@ -147,6 +147,40 @@ class Context:
             _ptr(status)), "vrfhip_ietf_verify_batch")
         return status
 
+    # ---- keyed verification: public keys with context-resident fixed-base tables --------------
+    def keyset_create(self, pks):
+        """`Public` keys -> KeySet (validated points + one 881 KB comb each, resident in HBM).  Returns
+        (keyset, status): status[i] = 0, or 2 if key i is not a point of the prime-order subgroup."""
+        k = np.ascontiguousarray(pks, dtype=np.uint8).reshape(-1, 32)
+        st = np.empty(k.shape[0], dtype=np.uint8)
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.vrfhip_keyset_create(self._h, k.shape[0], _ptr(k), _ptr(st), ctypes.byref(h)),
+                   "vrfhip_keyset_create")
+        return KeySet(self, h, k.shape[0]), st
+
+    def ietf_verify_batch_keyed(self, keyset, key_index, inp, out, c, s, ad=b"") -> np.ndarray:
+        """`ietf::Verifier::verify` against keys of a KeySet; key_index[i] names the key of proof i."""
+        idx = np.ascontiguousarray(key_index, dtype=np.uint32).reshape(-1)
+        inp, out, c, s = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (inp, out, c, s))
+        n = idx.shape[0]
+        if not all(x.shape[0] == n for x in (inp, out, c, s)):
+            raise ValueError("ragged batch")
+        status = np.empty(n, dtype=np.uint8)
+        blob, off, ad_len = self._ad_args(ad, n)
+        _lib.check(self._lib.vrfhip_ietf_verify_batch_keyed(
+            self._h, keyset.handle, n, _ptr(idx), _ptr(inp), _ptr(out), _ptr(c), _ptr(s), _ptr(blob), _ptr(off), ad_len,
+            _ptr(status)), "vrfhip_ietf_verify_batch_keyed")
+        return status
+
+    def ietf_verify_batch_keyed_dev(self, keyset, key_index, inp, out, c, s, status, ad=None, ad_off=None, ad_len=0,
+                                    stream=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _lib.check(self._lib.vrfhip_ietf_verify_batch_keyed_dev(
+            self._h, keyset.handle, inp.shape[0], key_index.data_ptr(), inp.data_ptr(), out.data_ptr(), c.data_ptr(),
+            s.data_ptr(), None if ad is None else ad.data_ptr(), None if ad_off is None else ad_off.data_ptr(), ad_len,
+            status.data_ptr(), st), "vrfhip_ietf_verify_batch_keyed_dev")
+
     def ietf_verify_batch_affine(self, pk_xy, inp_xy, out_xy, c, s, ad=b"") -> np.ndarray:
         """Verification from in-memory affine points: (n, 64) arrays x || y (LE canonical)."""
         pk, inp, out = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 64) for x in (pk_xy, inp_xy, out_xy))
@@ -406,6 +440,21 @@ class Context:
             self._h, n, sk.data_ptr(), dp(msg), dp(msg_off), msg_len, dp(inputs), dp(ad), dp(ad_off), ad_len,
             out.data_ptr(), c.data_ptr(), s.data_ptr(), dp(pk_out), dp(input_out), dp(status), st),
             "vrfhip_ietf_prove_batch_dev")
+
+
+class KeySet:
+    """Device-resident tables of a set of public keys (vrfhip_keyset); destroy before its Context."""
+
+    def __init__(self, ctx: Context, handle, n_keys: int):
+        self._ctx, self.handle, self.n_keys = ctx, handle, n_keys
+
+    def bytes(self) -> int:
+        return int(self._ctx._lib.vrfhip_keyset_bytes(self.handle))
+
+    def close(self) -> None:
+        if self.handle:
+            self._ctx._lib.vrfhip_keyset_destroy(self.handle)
+            self.handle = None
 
 
 _default_ctx: Optional[Context] = None

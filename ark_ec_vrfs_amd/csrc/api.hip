@@ -68,6 +68,16 @@ struct vrfhip_ctx {
   size_t stage_bytes = 0;
 };
 
+// `Public` keys with context-resident fixed-base tables (keyed verification)
+struct vrfhip_keyset {
+  vrfhip_ctx* ctx = nullptr;
+  size_t n_keys = 0;
+  uint8_t* d_enc = nullptr;       // [n_keys][32] encodings (hashed by the challenge)
+  uint8_t* d_valid = nullptr;     // [n_keys]
+  uint32_t* d_combs = nullptr;    // [n_keys][32][255][27]
+  size_t bytes = 0;
+};
+
 namespace {
 
 struct DeviceGuard {
@@ -304,9 +314,12 @@ int32_t vrfhip_ctx_profile_read(vrfhip_ctx* ctx, double stage_ms[4], uint64_t* l
 namespace {
 int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_pk, const uint8_t* d_input,
                         const uint8_t* d_output, const uint8_t* d_c, const uint8_t* d_s, const uint8_t* d_ad,
-                        const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_status, void* stream) {
+                        const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_status, void* stream,
+                        const vrfhip_keyset* ks = nullptr, const uint32_t* d_key_index = nullptr) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ks && (ks->ctx != ctx || !d_key_index)) return fail(VRFHIP_ERR_BAD_ARG, "key set of another context, or NULL key index");
   if (n == 0) return VRFHIP_SUCCESS;
+  if (ks) d_pk = ks->d_enc;
   if (!d_pk || !d_input || !d_output || !d_c || !d_s || !d_status)
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if ((ad_len || d_ad_off) && !d_ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
@@ -322,8 +335,12 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
     a.suite = (int)ctx->suite;
     a.k_lane = lanes_k(m, VERIFY_K);
     a.n = m;
-    a.pk = d_pk + base * pw; a.h = d_input + base * pw; a.gamma = d_output + base * pw;
+    a.pk = ks ? d_pk : d_pk + base * pw; a.h = d_input + base * pw; a.gamma = d_output + base * pw;
     a.affine_in = affine ? 1 : 0;
+    a.key_index = ks ? d_key_index + base : nullptr;
+    a.key_combs = ks ? ks->d_combs : nullptr;
+    a.key_valid = ks ? ks->d_valid : nullptr;
+    a.n_keys = ks ? ks->n_keys : 0;
     a.c = d_c + base * 32; a.s = d_s + base * 32;
     a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
     a.status = d_status + base;
@@ -404,6 +421,119 @@ int32_t vrfhip_ietf_verify_batch_affine(vrfhip_ctx* ctx, size_t n, const uint8_t
                                         const uint8_t* c, const uint8_t* s, const uint8_t* ad,
                                         const uint32_t* ad_off, uint32_t ad_len, uint8_t* status) {
   return verify_host_impl(ctx, n, true, pk_xy, input_xy, output_xy, c, s, ad, ad_off, ad_len, status);
+}
+
+// ------------------------------------------------------------------------- key sets, keyed verification
+int32_t vrfhip_keyset_create(vrfhip_ctx* ctx, size_t n_keys, const uint8_t* pks, uint8_t* status,
+                             vrfhip_keyset** out) {
+  if (!out) return fail(VRFHIP_ERR_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n_keys == 0 || !pks) return fail(VRFHIP_ERR_BAD_ARG, "no keys");
+  if (n_keys > (size_t(1) << 24)) return fail(VRFHIP_ERR_BAD_ARG, "too many keys");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  vrfhip_keyset* ks = new vrfhip_keyset();
+  ks->ctx = ctx;
+  ks->n_keys = n_keys;
+  const size_t comb_bytes = n_keys * COMB_WORDS * sizeof(uint32_t);
+  const size_t prefix_bytes = n_keys * COMB_ROWS * (size_t)COMB_COLS * NL * sizeof(uint32_t);
+  uint32_t *d_xy = nullptr, *d_prefix = nullptr;
+  auto bail = [&](int32_t rc) {
+    if (d_xy) (void)hipFree(d_xy);
+    if (d_prefix) (void)hipFree(d_prefix);
+    vrfhip_keyset_destroy(ks);
+    return rc;
+  };
+#define HIP_TRY_K(expr)                                                                            \
+  do {                                                                                             \
+    hipError_t e__ = (expr);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return bail(fail(e__ == hipErrorOutOfMemory ? VRFHIP_ERR_OOM : VRFHIP_ERR_HIP,               \
+                       std::string(#expr) + ": " + hipGetErrorString(e__)));                       \
+  } while (0)
+  HIP_TRY_K(hipMalloc(&ks->d_enc, n_keys * 32));
+  HIP_TRY_K(hipMalloc(&ks->d_valid, (n_keys + 255) & ~size_t(255)));
+  HIP_TRY_K(hipMalloc(&ks->d_combs, comb_bytes));
+  HIP_TRY_K(hipMalloc(&d_xy, n_keys * 2 * NL * sizeof(uint32_t)));
+  HIP_TRY_K(hipMalloc(&d_prefix, prefix_bytes));
+  ks->bytes = n_keys * 32 + n_keys + comb_bytes;
+  HIP_TRY_K(hipMemcpyAsync(ks->d_enc, pks, n_keys * 32, hipMemcpyHostToDevice, ctx->stream));
+  launch_keyset_build((int)ctx->suite, n_keys, ks->d_enc, d_xy, ks->d_valid, ks->d_combs, d_prefix, ctx->T, ctx->stream);
+  HIP_TRY_K(hipGetLastError());
+  if (status) {
+    std::vector<uint8_t> valid(n_keys);
+    HIP_TRY_K(hipMemcpyAsync(valid.data(), ks->d_valid, n_keys, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY_K(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < n_keys; ++i) status[i] = valid[i] ? VRFHIP_ST_OK : VRFHIP_ST_INVALID_DATA;
+  } else {
+    HIP_TRY_K(hipStreamSynchronize(ctx->stream));
+  }
+#undef HIP_TRY_K
+  (void)hipFree(d_xy);
+  (void)hipFree(d_prefix);
+  *out = ks;
+  return VRFHIP_SUCCESS;
+}
+
+void vrfhip_keyset_destroy(vrfhip_keyset* ks) {
+  if (!ks) return;
+  if (ks->ctx) {
+    DeviceGuard guard(ks->ctx->device);
+    if (ks->d_enc) (void)hipFree(ks->d_enc);
+    if (ks->d_valid) (void)hipFree(ks->d_valid);
+    if (ks->d_combs) (void)hipFree(ks->d_combs);
+  }
+  delete ks;
+}
+
+size_t vrfhip_keyset_bytes(const vrfhip_keyset* ks) { return ks ? ks->bytes : 0; }
+
+int32_t vrfhip_ietf_verify_batch_keyed_dev(vrfhip_ctx* ctx, const vrfhip_keyset* keys, size_t n,
+                                           const uint32_t* d_key_index, const uint8_t* d_input,
+                                           const uint8_t* d_output, const uint8_t* d_c, const uint8_t* d_s,
+                                           const uint8_t* d_ad, const uint32_t* d_ad_off, uint32_t ad_len,
+                                           uint8_t* d_status, void* stream) {
+  if (!keys) return fail(VRFHIP_ERR_BAD_ARG, "key set is NULL");
+  return verify_dev_impl(ctx, n, false, nullptr, d_input, d_output, d_c, d_s, d_ad, d_ad_off, ad_len, d_status, stream,
+                         keys, d_key_index);
+}
+
+int32_t vrfhip_ietf_verify_batch_keyed(vrfhip_ctx* ctx, const vrfhip_keyset* keys, size_t n,
+                                       const uint32_t* key_index, const uint8_t* input, const uint8_t* output,
+                                       const uint8_t* c, const uint8_t* s, const uint8_t* ad,
+                                       const uint32_t* ad_off, uint32_t ad_len, uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (!keys) return fail(VRFHIP_ERR_BAD_ARG, "key set is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!key_index || !input || !output || !c || !s || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  size_t adb = blob_bytes(n, ad_off, ad_len, true);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  size_t need = 4 * Stage::pad(n * 32) + Stage::pad(n * 4) + Stage::pad(adb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n);
+  int32_t rc = ensure_stage(ctx, need);
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  const uint8_t* src[4] = {input, output, c, s};
+  uint8_t* d[4];
+  for (int i = 0; i < 4; ++i) {
+    d[i] = sg.take(n * 32);
+    HIP_TRY(hipMemcpyAsync(d[i], src[i], n * 32, hipMemcpyHostToDevice, ctx->stream));
+  }
+  uint32_t* d_idx = reinterpret_cast<uint32_t*>(sg.take(n * 4));
+  uint8_t* d_ad = sg.take(adb + 1);
+  uint32_t* d_off = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+  uint8_t* d_st = sg.take(n);
+  HIP_TRY(hipMemcpyAsync(d_idx, key_index, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (adb) HIP_TRY(hipMemcpyAsync(d_ad, ad, adb, hipMemcpyHostToDevice, ctx->stream));
+  if (ad_off) HIP_TRY(hipMemcpyAsync(d_off, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = vrfhip_ietf_verify_batch_keyed_dev(ctx, keys, n, d_idx, d[0], d[1], d[2], d[3], d_ad, ad_off ? d_off : nullptr,
+                                          ad_len, d_st, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
 }
 
 // ------------------------------------------------------------------------- IETF prove

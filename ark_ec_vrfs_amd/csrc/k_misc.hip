@@ -126,6 +126,55 @@ void launch_point_validate(int suite, size_t n, const uint8_t* pts, uint8_t* xy,
   if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_point_validate<S>, grid_for(n), dim3(BLOCK), 0, st, n, pts, xy, status, tabs, T));
 }
 
+// ---- key sets (keyed verification): validated keys and their fixed-base combs, context resident ----
+template <class S>
+__global__ void __launch_bounds__(BLOCK) k_keyset_decode(size_t n, const uint8_t* pks, uint32_t* xy, uint8_t* valid,
+                                                          DevTables T) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t e[8];
+  load32(e, pks, i);
+  DecodeA a = decode_phase_a<S>(e);
+  FeN di = fe_inv(a.den);
+  Fe<1, 4> x;
+  bool ok = decode_phase_b<S>(x, a, di, T.sq);
+  FeN xn = fe_mul(x, fe_one());
+  if constexpr (S::SUBGROUP_2DESCENT) {
+    ok = ok && subgroup_by_2descent<S>(a.y, T.sq);
+  } else {
+    // r * P = O by the branch-free ladder (one-time cost per key)
+    uint32_t r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = S::r32(j);
+    PtE rp = te_mul_slow<S>(te_from_affine(xn, a.y), r);
+    ok = ok && fe_is_zero(rp.X) && fe_eq(rp.Y, rp.Z);
+  }
+  // an invalid key gets the identity's tables: every proof that names it is reported InvalidData anyway
+  FeN ky = fe_select(ok, a.y, fe_one());
+  xn = fe_select(ok, xn, fe_zero());
+  fe_store(xy + i * 2 * NL, xn);
+  fe_store(xy + i * 2 * NL + NL, ky);
+  valid[i] = ok ? 1 : 0;
+}
+template <class S>
+__global__ void __launch_bounds__(64) k_keyset_comb(size_t n_keys, const uint32_t* xy, uint32_t* combs, uint32_t* prefix) {
+  size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;           // one lane per (key, row)
+  if (t >= n_keys * COMB_ROWS) return;
+  const size_t key = t / COMB_ROWS;
+  const int w = (int)(t % COMB_ROWS);
+  const FeN x = fe_load<1, 2>(xy + key * 2 * NL), y = fe_load<1, 2>(xy + key * 2 * NL + NL);
+  comb_build_row<S>(combs + key * COMB_WORDS + (size_t)w * COMB_COLS * PTA_WORDS, prefix + t * COMB_COLS * NL, x, y, w);
+}
+void launch_keyset_build(int suite, size_t n_keys, const uint8_t* pks, uint32_t* xy, uint8_t* valid, uint32_t* combs,
+                         uint32_t* prefix, DevTables T, hipStream_t st) {
+  if (!n_keys) return;
+  VRF_DISPATCH_SUITE(suite, {
+    hipLaunchKernelGGL(k_keyset_decode<S>, grid_for(n_keys), dim3(BLOCK), 0, st, n_keys, pks, xy, valid, T);
+    hipLaunchKernelGGL(k_keyset_comb<S>, dim3((unsigned)((n_keys * COMB_ROWS + 63) / 64)), dim3(64), 0, st, n_keys, xy,
+                       combs, prefix);
+  });
+}
+
 // ---- test primitive: Fq multiplication ----
 __global__ void __launch_bounds__(BLOCK) k_fq_mul(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* r) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;

@@ -13,6 +13,40 @@ __global__ void __launch_bounds__(BLOCK) k_verify_decode(VerifyArgs a) {
   verify_decode_multi<S>(a.k_lane, a.T, first, a.n, a.pk, a.h, a.gamma, a.ws.tabs, a.ws.pts, a.ws.flags);
 }
 
+// stage 1, keyed: only H and Gamma are decompressed; validity also requires a valid, existing key
+template <class S>
+__global__ void __launch_bounds__(BLOCK) k_verify_decode_keyed(VerifyArgs a) {
+  size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
+  if (first >= a.n) return;
+  verify_decode_multi<S, 2>(a.k_lane, a.T, first, a.n, nullptr, a.h, a.gamma, a.ws.tabs, a.ws.pts, a.ws.flags);
+#pragma unroll 1
+  for (int k = 0; k < a.k_lane; ++k) {
+    const size_t i = first + k;
+    if (i >= a.n) break;
+    const uint32_t key = a.key_index[i];
+    const bool key_ok = key < a.n_keys && a.key_valid[key] != 0;
+    if (!key_ok) a.ws.flags[i] = 0;
+  }
+}
+
+// stage 2, keyed U half: U = s*G - c*Y from two fixed-base combs (64 mixed additions, no doublings)
+template <class S>
+__global__ void __launch_bounds__(BLOCK) k_verify_comb_u(VerifyArgs a) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  uint32_t c[8], s[8];
+  load32(c, a.c, i); load32(s, a.s, i);
+  if (!fr_is_canonical<S>(c) || !fr_is_canonical<S>(s)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { c[j] = 0; s[j] = 0; }
+  }
+  const uint32_t key = a.key_index[i] < a.n_keys ? a.key_index[i] : 0;
+  PtE r = comb_mul<S>(a.T.g_comb, s);
+  r = comb_add<S>(r, a.key_combs + (size_t)key * COMB_WORDS, c, true);
+  uint32_t* out = a.ws.pts + i * PROVE_PTS_WORDS;
+  fe_store(out, r.X); fe_store(out + NL, r.Y); fe_store(out + 2 * NL, r.Z);
+}
+
 // stage 1 for affine inputs (x || y, 64 bytes per point): no square roots.  The compressed encodings
 // the challenge hash needs are written to the aux region.
 template <class S>
@@ -55,18 +89,21 @@ __global__ void __launch_bounds__(BLOCK) k_verify_finish(VerifyArgs a) {
   size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   if (first >= a.n) return;
   verify_finish_multi<S>(a.k_lane, first, a.n, a.ws.pts, PROVE_PTS_WORDS, a.pk, a.h, a.gamma,
-                         a.affine_in ? a.ws.aux : nullptr, AUX_WORDS, a.c, a.s, a.ad, a.ws.flags, a.status);
+                         a.affine_in ? a.ws.aux : nullptr, AUX_WORDS, a.c, a.s, a.ad, a.ws.flags, a.status,
+                         a.key_index, a.n_keys);
 }
 
 template <class S>
 static void launch_verify_t(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], st);
-  if (a.affine_in) hipLaunchKernelGGL(k_verify_decode_affine<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (a.key_index) hipLaunchKernelGGL(k_verify_decode_keyed<S>, grid_for((a.n + a.k_lane - 1) / a.k_lane), dim3(BLOCK), 0, st, a);
+  else if (a.affine_in) hipLaunchKernelGGL(k_verify_decode_affine<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
   else hipLaunchKernelGGL(k_verify_decode<S>, grid_for((a.n + a.k_lane - 1) / a.k_lane), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
   hipLaunchKernelGGL((k_verify_straus<S, 1>), grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL((k_verify_straus<S, 0>), grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (a.key_index) hipLaunchKernelGGL(k_verify_comb_u<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((k_verify_straus<S, 0>), grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[3], st);
   hipLaunchKernelGGL(k_verify_finish<S>, grid_for((a.n + a.k_lane - 1) / a.k_lane), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[4], st);

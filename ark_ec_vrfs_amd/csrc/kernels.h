@@ -47,6 +47,12 @@ struct VerifyArgs {
   int affine_in;
   BytesView ad;
   uint8_t* status;
+  // keyed verification (key_index != nullptr): pk is the key set's encodings [n_keys][32]; the U half uses the
+  // key's context-resident comb instead of per-proof tables
+  const uint32_t* key_index;    // [n] index of each proof's key
+  const uint32_t* key_combs;    // [n_keys][32][255][PTA_WORDS]
+  const uint8_t* key_valid;     // [n_keys] 1 = decodes to a point of the prime-order subgroup
+  size_t n_keys;
   Workspace ws;
   DevTables T;
 };
@@ -88,6 +94,10 @@ void launch_hash_to_curve(int suite, size_t n, BytesView msg, uint8_t* points, D
 void launch_output_hash(int suite, size_t n, const uint8_t* gamma, uint8_t* hash, hipStream_t st);
 void launch_secret_from_seed(int suite, size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk,
                              uint8_t* pk, DevTables T, hipStream_t st);
+// key sets: decode + validate the keys (xy: [n][18] Montgomery words), then build one comb per key.
+// prefix: [n_keys * 32][255][9] words of scratch for the build.
+void launch_keyset_build(int suite, size_t n_keys, const uint8_t* pks, uint32_t* xy, uint8_t* valid, uint32_t* combs,
+                         uint32_t* prefix, DevTables T, hipStream_t st);
 void launch_point_validate(int suite, size_t n, const uint8_t* pts, uint8_t* xy, uint8_t* status,
                            uint32_t* tabs, DevTables T, hipStream_t st);
 // MSM: ws must hold msm_workspace_bytes(n, groups) bytes; groups = msm_groups(n, n, #CUs)  (msm.cuh)

@@ -319,9 +319,9 @@ VRF_HD PtE comb_mul(const uint32_t* comb, const uint32_t k[8]) {
   return acc;
 }
 
-// acc + k*Base from a comb table (continues an accumulator)
+// acc +/- k*Base from a comb table (continues an accumulator)
 template <class C>
-VRF_HD PtE comb_add(PtE acc, const uint32_t* comb, const uint32_t k[8]) {
+VRF_HD PtE comb_add(PtE acc, const uint32_t* comb, const uint32_t k[8], bool neg = false) {
 #pragma unroll 1
   for (int w = 0; w < 32; ++w) {
     uint32_t word = k[0];
@@ -336,7 +336,7 @@ VRF_HD PtE comb_add(PtE acc, const uint32_t* comb, const uint32_t k[8]) {
     e.x = fe_select(z, id.x, e.x);
     e.y = fe_select(z, id.y, e.y);
     e.dt = fe_select(z, id.dt, e.dt);
-    acc = te_add_affine<C>(acc, e, false);
+    acc = te_add_affine<C>(acc, e, neg);
   }
   return acc;
 }
@@ -389,6 +389,45 @@ VRF_HD void comb_entry(uint32_t* out, const FeN& bx, const FeN& by, int w, int j
   a.y = fe_mul(p.Y, zi);
   a.dt = fe_mul(fe_mul(a.x, a.y), C::d());
   pta_store(out, a);
+}
+
+// ------------------------------------------------------------------------ key sets
+// Context-resident fixed-base comb of a PUBLIC KEY (keyed verification: many proofs per key).  One lane builds
+// row w of a key: base_w = 256^w * Y by 8w doublings, entries j * base_w, j = 1..255, by a chain of unified
+// additions; the 255 projective entries are made affine with ONE inversion (Montgomery's trick; prefix
+// products in `prefix`, 255 x 9 words owned by the lane).  ~1.5 M instructions per row instead of ~280 M for
+// 255 independent double-and-add multiplications.
+constexpr int COMB_ROWS = 32, COMB_COLS = 255;
+constexpr size_t COMB_WORDS = (size_t)COMB_ROWS * COMB_COLS * PTA_WORDS;      // per base: 881,280 bytes
+template <class C>
+VRF_HD void comb_build_row(uint32_t* row /*[255][27]*/, uint32_t* prefix /*[255][9]*/, const FeN& x, const FeN& y, int w) {
+  PtE base = te_from_affine(x, y);
+#pragma unroll 1
+  for (int i = 0; i < 8 * w; ++i) base = te_dbl<C>(base, i == 8 * w - 1);
+  const PtC bc = te_to_cached<C>(base);
+  PtE acc = base;
+  FeN run = fe_one();
+#pragma unroll 1
+  for (int j = 0; j < COMB_COLS; ++j) {
+    uint32_t* slot = row + (size_t)j * PTA_WORDS;
+    fe_store(slot, acc.X); fe_store(slot + NL, acc.Y); fe_store(slot + 2 * NL, acc.Z);
+    fe_store(prefix + (size_t)j * NL, run);
+    run = fe_mul(run, acc.Z);
+    acc = te_add_cached<C>(acc, bc, false);
+  }
+  FeN inv = fe_inv(run);
+#pragma unroll 1
+  for (int j = COMB_COLS - 1; j >= 0; --j) {
+    uint32_t* slot = row + (size_t)j * PTA_WORDS;
+    const FeP X = fe_load<1, 5>(slot), Y = fe_load<1, 5>(slot + NL), Z = fe_load<1, 5>(slot + 2 * NL);
+    const FeN zi = fe_mul(inv, fe_load<1, 2>(prefix + (size_t)j * NL));
+    inv = fe_mul(inv, Z);
+    PtA a;
+    a.x = fe_mul(X, zi);
+    a.y = fe_mul(Y, zi);
+    a.dt = fe_mul(fe_mul(a.x, a.y), C::d());
+    pta_store(slot, a);
+  }
 }
 
 // ------------------------------------------------------------------------ challenge
@@ -456,7 +495,9 @@ constexpr int DEC_SLOT = 4 * NL;            // per point: y | num | den | prefix
 
 // points: base pointers of the pk / H / Gamma arrays; items [first, first + K) ∩ [0, n).
 // tabs_base / scratch_base / flags: workspace arrays indexed by item.
-template <class S>
+// NP = 3: pk, H, Gamma (table slots 0, 1, 2); NP = 2 (keyed verification: the key's tables are context
+// resident): H, Gamma (pk is not read, slots 1, 2).
+template <class S, int NP = 3>
 VRF_HD void verify_decode_multi(int K, const DevTables& T, size_t first, size_t n, const uint8_t* pk,
                                 const uint8_t* hh, const uint8_t* gamma, uint32_t* tabs_base,
                                 uint32_t* scratch_base, uint8_t* flags) {
@@ -465,9 +506,9 @@ VRF_HD void verify_decode_multi(int K, const DevTables& T, size_t first, size_t 
   FeN run = fe_one();
   uint64_t bits = 0;                         // per point: bit 2j = sign flag, bit 2j+1 = ok
 #pragma unroll 1
-  for (int j = 0; j < 3 * K; ++j) {
-    const size_t item = first + j / 3;
-    const int p = j % 3;
+  for (int j = 0; j < NP * K; ++j) {
+    const size_t item = first + j / NP;
+    const int p = j % NP + (3 - NP);
     if (item < n) {
       const uint8_t* src = p == 0 ? pk : (p == 1 ? hh : gamma);
       uint32_t enc[8];
@@ -487,9 +528,9 @@ VRF_HD void verify_decode_multi(int K, const DevTables& T, size_t first, size_t 
   FeN inv = fe_inv(run);
   uint32_t valid_mask = 0xffffffffu;
 #pragma unroll 1
-  for (int j = 3 * K - 1; j >= 0; --j) {
-    const size_t item = first + j / 3;
-    const int p = j % 3;
+  for (int j = NP * K - 1; j >= 0; --j) {
+    const size_t item = first + j / NP;
+    const int p = j % NP + (3 - NP);
     if (item < n) {
       const uint32_t* slot = scr + j * DEC_SLOT;
       DecodeA a;
@@ -503,7 +544,7 @@ VRF_HD void verify_decode_multi(int K, const DevTables& T, size_t first, size_t 
       inv = fe_mul(inv, a.den);
       Fe<1, 4> x;
       bool ok = decode_phase_b<S>(x, a, di, T.sq);
-      if (!ok) valid_mask &= ~(1u << (j / 3));
+      if (!ok) valid_mask &= ~(1u << (j / NP));
       build_glv_tables<S>(tabs_base + item * (VERIFY_TABS * WIN_TABLE_WORDS) + p * 2 * WIN_TABLE_WORDS, x, a.y);
     }
   }
@@ -519,7 +560,7 @@ VRF_HD void verify_finish_multi(int K, size_t first, size_t n, uint32_t* pts_bas
                                 const uint8_t* pk, const uint8_t* hh, const uint8_t* gamma,
                                 const uint32_t* enc_aux, int aux_stride, const uint8_t* c_arr,
                                 const uint8_t* s_arr, const BytesViewLite& ad, const uint8_t* flags,
-                                uint8_t* status) {
+                                uint8_t* status, const uint32_t* key_index = nullptr, size_t n_keys = 0) {
   FeN run = fe_one();
 #pragma unroll 1
   for (int j = 0; j < 2 * K; ++j) {
@@ -557,7 +598,10 @@ VRF_HD void verify_finish_multi(int K, size_t first, size_t n, uint32_t* pts_bas
 #pragma unroll
           for (int k = 0; k < 8; ++k) { pts[0][k] = aux[k]; pts[1][k] = aux[8 + k]; pts[2][k] = aux[16 + k]; }
         } else {
-          const uint32_t* w0 = reinterpret_cast<const uint32_t*>(pk + item * 32);
+          // keyed verification: pk holds the key set's encodings, key_index picks the item's key
+          size_t pk_row = item;
+          if (key_index) pk_row = key_index[item] < n_keys ? key_index[item] : 0;
+          const uint32_t* w0 = reinterpret_cast<const uint32_t*>(pk + pk_row * 32);
           const uint32_t* w1 = reinterpret_cast<const uint32_t*>(hh + item * 32);
           const uint32_t* w2 = reinterpret_cast<const uint32_t*>(gamma + item * 32);
 #pragma unroll

@@ -211,6 +211,27 @@ def secondary(ctx, lib, dev, sk, msg, pk, hh, gamma, c, s):
     t = _time(lambda: ctx.ietf_verify_batch_affine_dev(xy[0], xy[1], xy[2], c, s, vst))
     assert int(vst.sum()) == 0
     res["ietf_verify_affine_2^%d" % (n.bit_length() - 1)] = {"verifies_per_s": n / t, "ms": t * 1e3, "bytes_per_item": 257}
+    # keyed verification: the same 2^n proofs re-made under 1024 keys whose combs stay resident in HBM (129 B/verify + 4 B index)
+    try:
+        nk = 1024
+        kseeds = torch.arange(nk, dtype=torch.int64, device=dev).view(torch.uint8).reshape(nk, 8)
+        ksk, kpk = mk(nk), mk(nk)
+        _lib.check(lib.vrfhip_secret_from_seed_batch_dev(ctx.handle, nk, kseeds.data_ptr(), 8, ksk.data_ptr(), kpk.data_ptr(), stream), "seed")
+        kidx = (torch.arange(n, device=dev) * 2654435761 % nk).to(torch.int32)
+        g2, c2, s2, h2 = mk(), mk(), mk(), mk()
+        ctx.ietf_prove_batch_dev(ksk[kidx.long()].contiguous(), msg, 32, g2, c2, s2, None, h2, vst)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ks, kst = ctx.keyset_create(kpk.cpu().numpy())
+        tb = time.perf_counter() - t0
+        t = _time(lambda: ctx.ietf_verify_batch_keyed_dev(ks, kidx, h2, g2, c2, s2, vst))
+        assert int(vst.sum()) == 0 and int(kst.sum()) == 0
+        res["ietf_verify_keyed_2^%d" % (n.bit_length() - 1)] = {"verifies_per_s": n / t, "ms": t * 1e3, "keys": nk,
+                                                                "keyset_build_ms": tb * 1e3, "keyset_bytes": ks.bytes(),
+                                                                "bytes_per_item": 133}
+        ks.close()
+    except Exception as e:
+        res["ietf_verify_keyed"] = {"error": repr(e)}
     # config 3: Pedersen prove + verify (Bandersnatch; 288 / 225 B)
     g, pc, r, ok, ss, sb = (mk() for _ in range(6))
     pst = torch.empty(n, dtype=torch.uint8, device=dev)

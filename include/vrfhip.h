@@ -62,6 +62,7 @@ typedef enum vrfhip_error {
 } vrfhip_error;
 
 typedef struct vrfhip_ctx vrfhip_ctx;
+typedef struct vrfhip_keyset vrfhip_keyset;
 
 /* Library / context ------------------------------------------------------------------- */
 
@@ -121,6 +122,31 @@ int32_t vrfhip_ietf_verify_batch_affine_dev(vrfhip_ctx* ctx, size_t n, const uin
                                             const uint8_t* d_c, const uint8_t* d_s, const uint8_t* d_ad,
                                             const uint32_t* d_ad_off, uint32_t ad_len,
                                             uint8_t* d_status, void* stream);
+
+/* Keyed verification: many proofs per public key (`Public`, src/lib.rs:15).  A key set keeps, for each of
+ * n_keys public keys, a validated point and its 8-bit fixed-base comb (881,280 bytes per key) resident in
+ * HBM: 100,000 keys take 88 GB of the 288 GB.  Verification against a key of the set needs no decompression
+ * of pk and computes U = s*G - c*Y with 64 mixed additions and no doublings.
+ * vrfhip_keyset_create: pks = n_keys x 32 B compressed points (host); status (nullable, host) receives
+ * 0 / 2 per key: a key must decode to a point of the prime-order subgroup (the checked decode of `codec`).
+ * Proofs that name an invalid or out-of-range key are reported InvalidData.  The key set belongs to `ctx`
+ * and must be destroyed before it. */
+int32_t vrfhip_keyset_create(vrfhip_ctx* ctx, size_t n_keys, const uint8_t* pks, uint8_t* status,
+                             vrfhip_keyset** out);
+void vrfhip_keyset_destroy(vrfhip_keyset* keys);
+size_t vrfhip_keyset_bytes(const vrfhip_keyset* keys);
+
+/* `ietf::Verifier::verify` for n items whose public keys belong to `keys`: key_index[i] selects the key of
+ * item i; everything else as vrfhip_ietf_verify_batch.  Same statuses as verifying against the key's bytes. */
+int32_t vrfhip_ietf_verify_batch_keyed(vrfhip_ctx* ctx, const vrfhip_keyset* keys, size_t n,
+                                       const uint32_t* key_index, const uint8_t* input, const uint8_t* output,
+                                       const uint8_t* c, const uint8_t* s, const uint8_t* ad,
+                                       const uint32_t* ad_off, uint32_t ad_len, uint8_t* status);
+int32_t vrfhip_ietf_verify_batch_keyed_dev(vrfhip_ctx* ctx, const vrfhip_keyset* keys, size_t n,
+                                           const uint32_t* d_key_index, const uint8_t* d_input,
+                                           const uint8_t* d_output, const uint8_t* d_c, const uint8_t* d_s,
+                                           const uint8_t* d_ad, const uint32_t* d_ad_off, uint32_t ad_len,
+                                           uint8_t* d_status, void* stream);
 
 /* `Input::new(msg)` + `Secret::output` + `ietf::Prover::prove` for n items (src/lib.rs:14-16).
  * sk: n x 32 B secret scalars.  Messages: blob `msg`; if msg_off is NULL item i is
