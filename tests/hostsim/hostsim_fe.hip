@@ -57,6 +57,18 @@ int hs_decode_checked(const uint8_t* enc) {
   ok = ok && subgroup_by_2descent<SuiteBS>(a.y, host_tables());
   return ok ? 0 : 2;
 }
+// key-set comb row w of the point (x, y): entry j-1 = j * 256^w * P as affine x || y (64 bytes each, 255 entries)
+void hs_comb_row(const uint8_t* xb, const uint8_t* yb, int w, uint8_t* out) {
+  std::vector<uint32_t> row(COMB_COLS * PTA_WORDS), prefix(COMB_COLS * NL);
+  comb_build_row<SuiteBS>(row.data(), prefix.data(), in(xb), in(yb), w);
+  for (int j = 0; j < COMB_COLS; ++j) {
+    PtA a = pta_load(row.data() + (size_t)j * PTA_WORDS);
+    ::out(out + 64 * j, a.x); ::out(out + 64 * j + 32, a.y);
+    // the cached product d*x*y must match too
+    FeN dt = fe_mul(fe_mul(a.x, a.y), SuiteBS::d());
+    if (!fe_eq(dt, a.dt)) memset(out + 64 * j, 0xee, 64);
+  }
+}
 int hs_decode(const uint8_t* enc, uint8_t* x, uint8_t* y) {
   uint32_t w[8]; memcpy(w, enc, 32);
   DecodeA a = decode_phase_a<SuiteBS>(w);

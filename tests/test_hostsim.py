@@ -296,3 +296,16 @@ def test_subgroup_by_2descent_equals_r_times_p(hs):
         if want == 2 and co.point_decode(enc, subgroup=False) is not None:
             n_decodable_outside += 1
     assert seen[0] > 150 and n_decodable_outside > 300        # members, and curve points outside the subgroup
+
+
+def test_keyset_comb_row_matches_oracle_multiples(hs):
+    """comb_build_row (keyed verification): row w of a key's comb holds j * 256^w * Y for j = 1..255, made affine
+    with one shared inversion; spot-checked against the oracle's scalar multiplication."""
+    Y = o.te_mul(S, 0x1234567, (S.gx, S.gy))
+    buf = ctypes.create_string_buffer(64 * 255)
+    for w in (0, 1, 7, 31):
+        hs.hs_comb_row(_b(Y[0]), _b(Y[1]), w, buf)
+        for j in (1, 2, 3, 100, 254, 255):
+            want = o.te_mul(S, (j << (8 * w)) % S.r, Y)
+            got = buf.raw[64 * (j - 1): 64 * j]
+            assert (int.from_bytes(got[:32], "little"), int.from_bytes(got[32:], "little")) == want, (w, j)
