@@ -75,7 +75,7 @@ VRF_HD void rlc_flush_cols(const RlcArgs& a, const uint64_t (&cols)[16]) {
 }
 
 template <class S>
-__global__ void __launch_bounds__(BLOCK) k_rlc_decode(RlcArgs a) {
+__global__ void __launch_bounds__(BLOCK, 2) k_rlc_decode(RlcArgs a) {
   const size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   const int K = a.k_lane;
   const size_t n = a.n;
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(BLOCK) k_rlc_decode(RlcArgs a) {
 // point: x || y, 32-byte little-endian canonical): no square roots.  One lane per proof.  InvalidData =
 // coordinate >= q or point off the curve.
 template <class S>
-__global__ void __launch_bounds__(BLOCK) k_rlc_prep_affine(RlcArgs a) {
+__global__ void __launch_bounds__(BLOCK, 2) k_rlc_prep_affine(RlcArgs a) {
   const size_t item = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t n = a.n;
   uint64_t cols[16];
@@ -247,7 +247,10 @@ static void launch_rlc_t(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, h
   (void)hipMemsetAsync(a.fixed_cols, 0, 16 * sizeof(uint64_t), st);
   if (ev) (void)hipEventRecord(ev[0], st);
   if (a.affine_in) hipLaunchKernelGGL(k_rlc_prep_affine<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  else hipLaunchKernelGGL(k_rlc_decode<S>, grid_for((a.n + a.k_lane - 1) / a.k_lane), dim3(BLOCK), 0, st, a);
+  else {
+    const dim3 gk = grid_for((a.n + a.k_lane - 1) / a.k_lane);
+    hipLaunchKernelGGL(k_rlc_decode<S>, gk, dim3(BLOCK), spread_lds_bytes(gk.x), st, a);
+  }
   hipLaunchKernelGGL(k_rlc_fixed<S>, dim3(1), dim3(64), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
   launch_msm_core(a.suite, a.L, nullptr, nullptr, nullptr, fail_flag, st, ev ? ev + 2 : nullptr);

@@ -123,4 +123,27 @@ VRF_HD void store32(uint8_t* base, size_t i, const uint32_t w[8]) {
 constexpr int BLOCK = 128;
 inline dim3 grid_for(size_t threads) { return dim3((unsigned)((threads + BLOCK - 1) / BLOCK)); }
 
+// Dynamic LDS bytes that make a SMALL grid spread over the whole chip.  The kernels that share inversions
+// across K proofs per lane launch n/K lanes: at 2^20 proofs that is 1024 workgroups for 256 CUs, and since
+// such a kernel needs ~140 VGPRs (three waves per SIMD fit) the dispatcher packs six workgroups per CU and
+// leaves a third of the CUs idle (measured: SQ_WAVE_CYCLES of k_verify_decode at 0.56 of the Straus
+// kernels', 75 % VALU utilisation).  Reserving 160 KiB / ceil(workgroups / CUs) of LDS per workgroup caps
+// the workgroups a CU accepts at the even share; big grids get 0 (no effect).
+inline size_t spread_lds_bytes(size_t workgroups) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+    else
+      cus = 256;
+  }
+  const size_t share = (workgroups + cus - 1) / cus;          // even number of workgroups per CU
+  if (share == 0 || share > 8) return 0;                      // large grid: occupancy is not the problem
+  size_t bytes = (size_t(160) * 1024) / share;
+  bytes -= bytes % 1024;
+  return bytes > 64 * 1024 ? 64 * 1024 : bytes;               // default dynamic-LDS limit without an attribute
+}
+
 }  // namespace vrf
