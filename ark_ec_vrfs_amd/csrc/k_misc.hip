@@ -29,7 +29,7 @@ void launch_init_tables(int suite, uint32_t* g_win, uint32_t* g_comb, uint32_t* 
 
 // ---- Input::new ----
 template <class S>
-__global__ void __launch_bounds__(BLOCK) k_hash_to_curve(size_t n, BytesView msg, uint8_t* points, DevTables T) {
+__global__ void __launch_bounds__(BLOCK, 2) k_hash_to_curve(size_t n, BytesView msg, uint8_t* points, DevTables T) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint8_t* m; uint32_t len;
@@ -63,7 +63,7 @@ void launch_output_hash(int suite, size_t n, const uint8_t* gamma, uint8_t* hash
 
 // ---- Secret::from_seed / Secret::public ----
 template <class S>
-__global__ void __launch_bounds__(BLOCK) k_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len,
+__global__ void __launch_bounds__(BLOCK, 2) k_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len,
                                                              uint8_t* sk_out, uint8_t* pk_out, DevTables T) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(BLOCK) k_keyset_decode(size_t n, const uint8_t
   valid[i] = ok ? 1 : 0;
 }
 template <class S>
-__global__ void __launch_bounds__(64) k_keyset_comb(size_t n_keys, const uint32_t* xy, uint32_t* combs, uint32_t* prefix) {
+__global__ void __launch_bounds__(64, 2) k_keyset_comb(size_t n_keys, const uint32_t* xy, uint32_t* combs, uint32_t* prefix) {
   size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;           // one lane per (key, row)
   if (t >= n_keys * COMB_ROWS) return;
   const size_t key = t / COMB_ROWS;

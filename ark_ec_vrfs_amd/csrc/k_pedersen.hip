@@ -6,7 +6,7 @@
 namespace vrf {
 
 template <class S>
-__global__ void __launch_bounds__(BLOCK) k_ped_verify_decode(PedersenVerifyArgs a) {
+__global__ void __launch_bounds__(BLOCK, 2) k_ped_verify_decode(PedersenVerifyArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
   uint32_t enc[5][8];

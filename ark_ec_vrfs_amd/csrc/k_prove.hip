@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(BLOCK, 2) k_prove_prepare(ProveArgs a) {
 // succeeded records the counter and takes the next item at once, so a wave performs about two attempts per
 // item and the only idle lanes are those of the last few iterations of the whole grid.
 template <class S>
-__global__ void __launch_bounds__(64) k_tai_find(size_t n, BytesView msg, uint8_t* ctr_out, SqrtTables T,
+__global__ void __launch_bounds__(64, 2) k_tai_find(size_t n, BytesView msg, uint8_t* ctr_out, SqrtTables T,
                                                  unsigned long long* queue) {
   constexpr size_t NONE = ~size_t(0);
   const int lane = threadIdx.x;
