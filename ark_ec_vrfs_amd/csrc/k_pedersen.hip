@@ -5,8 +5,8 @@
 
 namespace vrf {
 
-template <class S>
-__global__ void __launch_bounds__(BLOCK, 2) k_ped_verify_decode(PedersenVerifyArgs a) {
+template <class S, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_ped_verify_decode(PedersenVerifyArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
   uint32_t enc[5][8];
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(BLOCK) k_ped_verify_finish(PedersenVerifyArgs 
 template <class S>
 static void launch_ped_t(const PedersenVerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], st);
-  hipLaunchKernelGGL(k_ped_verify_decode<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  VRF_LAUNCH_MINW(k_ped_verify_decode, S, a.n, grid_for(a.n), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
   hipLaunchKernelGGL((k_ped_verify_straus<S, 0>), grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[2], st);

@@ -6,8 +6,8 @@
 namespace vrf {
 
 // stage 1: H = hash_to_curve(msg) (or decode a given H), enc(H), nonce, window table of H
-template <class S>
-__global__ void __launch_bounds__(BLOCK, 2) k_prove_prepare(ProveArgs a) {
+template <class S, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare(ProveArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
   uint32_t sk[8], hg[8], h_enc[8], k[8];
@@ -74,8 +74,8 @@ __global__ void __launch_bounds__(64, 2) k_tai_find(size_t n, BytesView msg, uin
 
 // stage 1 for the common case (Elligator suite, H from messages): PROVE_K proofs per lane share the two
 // inversions of hash-to-curve.  The Pedersen extras (blinding, second nonce) are added per item.
-template <class S>
-__global__ void __launch_bounds__(BLOCK, 2) k_prove_prepare_multi(ProveArgs a) {
+template <class S, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare_multi(ProveArgs a) {
   if constexpr (S::H2C_ELL2) {
     size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
     if (first >= a.n) return;
@@ -127,8 +127,8 @@ __global__ void __launch_bounds__(BLOCK) k_prove_mul(ProveArgs a) {
 
 // stage 3: PROVE_K proofs per lane share the inversion of their 4K projective Z; then per item the
 // challenge and s = k + c*sk (Pedersen: also sb = kb + c*b).
-template <class S>
-__global__ void __launch_bounds__(BLOCK, 2) k_prove_finish(ProveArgs a) {
+template <class S, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_prove_finish(ProveArgs a) {
   size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   if (first >= a.n) return;
   const int tstride = 2 * WIN_TABLE_WORDS;
@@ -177,10 +177,11 @@ __global__ void __launch_bounds__(BLOCK, 2) k_prove_finish(ProveArgs a) {
 
 template <class S>
 static void launch_prove_t(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
-  const dim3 gk = grid_for((a.n + a.k_lane - 1) / a.k_lane);      // K proofs per lane: a small grid
+  const size_t lanes_k_ = (a.n + a.k_lane - 1) / a.k_lane;      // K proofs per lane: a small grid
+  const dim3 gk = grid_for(lanes_k_);
   if (ev) (void)hipEventRecord(ev[0], st);
   if (S::H2C_ELL2 && !a.h_given) {
-    hipLaunchKernelGGL(k_prove_prepare_multi<S>, gk, dim3(BLOCK), spread_lds_bytes(gk.x), st, a);
+    VRF_LAUNCH_MINW(k_prove_prepare_multi, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
   } else {
     if (!S::H2C_ELL2 && !a.h_given) {
       (void)hipMemsetAsync(a.tai_queue, 0, sizeof(unsigned long long), st);
@@ -188,12 +189,12 @@ static void launch_prove_t(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
       hipLaunchKernelGGL(k_tai_find<S>, dim3((unsigned)waves), dim3(64), 0, st, a.n, a.msg, a.ws.flags, a.T.sq,
                          a.tai_queue);
     }
-    hipLaunchKernelGGL(k_prove_prepare<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+    VRF_LAUNCH_MINW(k_prove_prepare, S, a.n, grid_for(a.n), 0, st, a);
   }
   if (ev) (void)hipEventRecord(ev[1], st);
   hipLaunchKernelGGL(k_prove_mul<S>, grid_for(2 * a.n), dim3(BLOCK), 0, st, a);
   if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
-  hipLaunchKernelGGL(k_prove_finish<S>, gk, dim3(BLOCK), spread_lds_bytes(gk.x), st, a);
+  VRF_LAUNCH_MINW(k_prove_finish, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
   if (ev) (void)hipEventRecord(ev[4], st);
 }
 // This file is compiled once per suite (Makefile: -DVRF_PROVE_SUITE=1|2 -> k_prove_bs.o, k_prove_jj.o) so

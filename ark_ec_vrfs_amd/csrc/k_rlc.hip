@@ -74,8 +74,8 @@ VRF_HD void rlc_flush_cols(const RlcArgs& a, const uint64_t (&cols)[16]) {
   }
 }
 
-template <class S>
-__global__ void __launch_bounds__(BLOCK, 2) k_rlc_decode(RlcArgs a) {
+template <class S, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_rlc_decode(RlcArgs a) {
   const size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   const int K = a.k_lane;
   const size_t n = a.n;
@@ -149,8 +149,8 @@ __global__ void __launch_bounds__(BLOCK, 2) k_rlc_decode(RlcArgs a) {
 // The same stage for callers that hold the points in memory as arkworks `Affine { x, y }` (64 bytes per
 // point: x || y, 32-byte little-endian canonical): no square roots.  One lane per proof.  InvalidData =
 // coordinate >= q or point off the curve.
-template <class S>
-__global__ void __launch_bounds__(BLOCK, 2) k_rlc_prep_affine(RlcArgs a) {
+template <class S, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_rlc_prep_affine(RlcArgs a) {
   const size_t item = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   const size_t n = a.n;
   uint64_t cols[16];
@@ -246,10 +246,11 @@ static void launch_rlc_t(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, h
   (void)hipMemsetAsync(a.L.flags, 0, 256, st);
   (void)hipMemsetAsync(a.fixed_cols, 0, 16 * sizeof(uint64_t), st);
   if (ev) (void)hipEventRecord(ev[0], st);
-  if (a.affine_in) hipLaunchKernelGGL(k_rlc_prep_affine<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (a.affine_in) VRF_LAUNCH_MINW(k_rlc_prep_affine, S, a.n, grid_for(a.n), 0, st, a);
   else {
-    const dim3 gk = grid_for((a.n + a.k_lane - 1) / a.k_lane);
-    hipLaunchKernelGGL(k_rlc_decode<S>, gk, dim3(BLOCK), spread_lds_bytes(gk.x), st, a);
+    const size_t lanes_k_ = (a.n + a.k_lane - 1) / a.k_lane;
+    const dim3 gk = grid_for(lanes_k_);
+    VRF_LAUNCH_MINW(k_rlc_decode, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
   }
   hipLaunchKernelGGL(k_rlc_fixed<S>, dim3(1), dim3(64), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);

@@ -6,16 +6,16 @@ namespace vrf {
 
 // stage 1: one lane per proof.  Decompress pk, H, Gamma; build their GLV window-table pairs.
 // VERIFY_K proofs per lane share one inversion (3K decompression denominators).
-template <class S>
-__global__ void __launch_bounds__(BLOCK, 2) k_verify_decode(VerifyArgs a) {
+template <class S, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_verify_decode(VerifyArgs a) {
   size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   if (first >= a.n) return;
   verify_decode_multi<S>(a.k_lane, a.T, first, a.n, a.pk, a.h, a.gamma, a.ws.tabs, a.ws.pts, a.ws.flags);
 }
 
 // stage 1, keyed: only H and Gamma are decompressed; validity also requires a valid, existing key
-template <class S>
-__global__ void __launch_bounds__(BLOCK, 2) k_verify_decode_keyed(VerifyArgs a) {
+template <class S, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_verify_decode_keyed(VerifyArgs a) {
   size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   if (first >= a.n) return;
   verify_decode_multi<S, 2>(a.k_lane, a.T, first, a.n, nullptr, a.h, a.gamma, a.ws.tabs, a.ws.pts, a.ws.flags);
@@ -84,8 +84,8 @@ __global__ void __launch_bounds__(BLOCK) k_verify_straus(VerifyArgs a) {
 
 // stage 3: VERIFY_K proofs per lane share one inversion (2K Z coordinates).  Affine U, V; challenge
 // hash; compare.
-template <class S>
-__global__ void __launch_bounds__(BLOCK, 2) k_verify_finish(VerifyArgs a) {
+template <class S, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_verify_finish(VerifyArgs a) {
   size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   if (first >= a.n) return;
   verify_finish_multi<S>(a.k_lane, first, a.n, a.ws.pts, PROVE_PTS_WORDS, a.pk, a.h, a.gamma,
@@ -95,18 +95,19 @@ __global__ void __launch_bounds__(BLOCK, 2) k_verify_finish(VerifyArgs a) {
 
 template <class S>
 static void launch_verify_t(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
-  const dim3 gk = grid_for((a.n + a.k_lane - 1) / a.k_lane);      // K proofs per lane: a small grid
+  const size_t lanes_k_ = (a.n + a.k_lane - 1) / a.k_lane;      // K proofs per lane: a small grid
+  const dim3 gk = grid_for(lanes_k_);
   if (ev) (void)hipEventRecord(ev[0], st);
-  if (a.key_index) hipLaunchKernelGGL(k_verify_decode_keyed<S>, gk, dim3(BLOCK), spread_lds_bytes(gk.x), st, a);
+  if (a.key_index) VRF_LAUNCH_MINW(k_verify_decode_keyed, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
   else if (a.affine_in) hipLaunchKernelGGL(k_verify_decode_affine<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
-  else hipLaunchKernelGGL(k_verify_decode<S>, gk, dim3(BLOCK), spread_lds_bytes(gk.x), st, a);
+  else VRF_LAUNCH_MINW(k_verify_decode, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
   hipLaunchKernelGGL((k_verify_straus<S, 1>), grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[2], st);
   if (a.key_index) hipLaunchKernelGGL(k_verify_comb_u<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
   else hipLaunchKernelGGL((k_verify_straus<S, 0>), grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[3], st);
-  hipLaunchKernelGGL(k_verify_finish<S>, gk, dim3(BLOCK), spread_lds_bytes(gk.x), st, a);
+  VRF_LAUNCH_MINW(k_verify_finish, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
   if (ev) (void)hipEventRecord(ev[4], st);
 }
 void launch_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {

@@ -123,6 +123,17 @@ VRF_HD void store32(uint8_t* base, size_t i, const uint32_t w[8]) {
 constexpr int BLOCK = 128;
 inline dim3 grid_for(size_t threads) { return dim3((unsigned)((threads + BLOCK - 1) / BLOCK)); }
 
+// The kernels that run K proofs per lane (or one heavy item per lane) need 256 VGPRs plus 18..98 AGPRs when
+// compiled freely: one wave per SIMD and ~72 % VALU utilisation.  Capped at 256 registers (MINW = 2) they
+// spill a little and run two waves per SIMD, which pays once the grid has two waves per SIMD to offer; below
+// that (2^16-item batches) the uncapped build is faster.  VRF_LAUNCH_MINW picks the instantiation.
+inline bool two_waves_pay(size_t lanes) { return lanes >= size_t(131072); }
+#define VRF_LAUNCH_MINW(KERNEL, S_, lanes, grid, lds, st, args)                                   \
+  do {                                                                                            \
+    if (two_waves_pay(lanes)) hipLaunchKernelGGL((KERNEL<S_, 2>), grid, dim3(BLOCK), lds, st, args); \
+    else hipLaunchKernelGGL((KERNEL<S_, 1>), grid, dim3(BLOCK), lds, st, args);                   \
+  } while (0)
+
 // Dynamic LDS bytes that make a SMALL grid spread over the whole chip.  The kernels that share inversions
 // across K proofs per lane launch n/K lanes: at 2^20 proofs that is 1024 workgroups for 256 CUs, and since
 // such a kernel needs ~140 VGPRs (three waves per SIMD fit) the dispatcher packs six workgroups per CU and
