@@ -92,9 +92,17 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
   // 1. histogram of the group's digits
   counts[t] = 0; counts[t + MSM_BLOCK] = 0;
   __syncthreads();
-  for (uint32_t j = t; j < cnt_all; j += MSM_BLOCK) {
-    int d = dig[j];
-    if (d != 0) atomicAdd(&counts[(d < 0 ? -d : d) - 1], 1u);
+  // four independent digit loads per trip keep the memory pipe busy (a lane's trip is latency-bound)
+  for (uint32_t j0 = t; j0 < cnt_all; j0 += 4 * MSM_BLOCK) {
+    int d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t j = j0 + u * MSM_BLOCK;
+      d[u] = j < cnt_all ? dig[j] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (d[u] != 0) atomicAdd(&counts[(d[u] < 0 ? -d[u] : d[u]) - 1], 1u);
   }
   __syncthreads();
   // 2. exclusive scan over 1024 counts: lane t scans its pair, waves scan by shuffles
@@ -122,13 +130,23 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
   __syncthreads();
   // 3. scatter into bucket order, transposed so that entry i of lane l sits at list[i*512 + l]
   const uint32_t chunk = (m + MSM_BLOCK - 1) / MSM_BLOCK;
-  for (uint32_t j = t; j < cnt_all; j += MSM_BLOCK) {
-    int d = dig[j];
-    if (d != 0) {
-      uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
-      uint32_t pos = atomicAdd(&cursor[b], 1u);
-      uint32_t lane = pos / chunk, i = pos - lane * chunk;
-      list[(size_t)i * MSM_BLOCK + lane] = j | (b << MSM_IDX_BITS) | (d < 0 ? 0x80000000u : 0u);
+  for (uint32_t j0 = t; j0 < cnt_all; j0 += 4 * MSM_BLOCK) {
+    int dd[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t j = j0 + u * MSM_BLOCK;
+      dd[u] = j < cnt_all ? dig[j] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int d = dd[u];
+      const uint32_t j = j0 + u * MSM_BLOCK;
+      if (d != 0) {
+        uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1;
+        uint32_t pos = atomicAdd(&cursor[b], 1u);
+        uint32_t lane = pos / chunk, i = pos - lane * chunk;
+        list[(size_t)i * MSM_BLOCK + lane] = j | (b << MSM_IDX_BITS) | (d < 0 ? 0x80000000u : 0u);
+      }
     }
   }
   __threadfence_block();
