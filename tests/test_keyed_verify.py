@@ -118,3 +118,38 @@ def test_keyed_full_size_2_20(ctx):
         assert torch.equal(st, st2) and torch.equal(torch.nonzero(st).flatten(), torch.arange(0, n, 1024, device=dev))
     finally:
         ks.close()
+
+
+def test_keyed_jubjub(synth):
+    """The other suite: keys are validated by r*P = O (no 2-descent on a cofactor-8 curve), same statuses as the
+    plain verifier."""
+    from ark_ec_vrfs_amd import Context, JubJubSha512Tai
+    cj = Context(0, suite=JubJubSha512Tai)
+    co.set_suite(2)
+    try:
+        n, nk = 500, 9
+        sk, _ = synth(nk, start=40)
+        _, msg = synth(n, start=777)
+        key = (np.arange(n, dtype=np.uint32) * 5) % nk
+        got = cj.ietf_prove_batch(sk[key], msgs=msg, ad=b"jj")
+        pks = np.stack([got["pk"][np.nonzero(key == k)[0][0]] for k in range(nk)])
+        bad = pks.copy()
+        bad[4] = np.frombuffer((5).to_bytes(32, "little"), np.uint8)
+        ks, kst = cj.keyset_create(bad)
+        try:
+            want_key_ok = [co.point_decode(bad[k].tobytes(), subgroup=True) is not None for k in range(nk)]
+            assert [s == 0 for s in kst] == want_key_ok and not want_key_ok[4]
+            s2 = got["s"].copy(); s2[::50, 1] ^= 4
+            st = cj.ietf_verify_batch_keyed(ks, key, got["input"], got["output"], got["c"], s2, ad=b"jj")
+            plain = cj.ietf_verify_batch(bad[key], got["input"], got["output"], got["c"], s2, ad=b"jj")
+            want = co.ietf_verify_batch(bad[key], got["input"], got["output"], got["c"], s2, b"jj", threads=NCPU)
+            assert (plain == want).all()
+            # the plain verifier does not test subgroup membership of pk; the key set does (checked decode):
+            # proofs under the rejected key are InvalidData there, everything else agrees
+            for i in range(n):
+                assert st[i] == (2 if key[i] == 4 else want[i]), i
+        finally:
+            ks.close()
+    finally:
+        co.set_suite(1)
+        cj.close()
