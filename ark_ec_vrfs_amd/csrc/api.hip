@@ -226,7 +226,9 @@ int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out) 
   }
   const size_t sqrt_p_bytes = sizeof(vrfk_tables::SQRT_P);
   const size_t lut_bytes = sizeof(vrfk_tables::SQRT_LUT);
-  const size_t comb_bytes = (size_t)32 * 255 * PTA_WORDS * sizeof(uint32_t);
+  const size_t comb_bytes = GCOMB_WORDS * sizeof(uint32_t);            // 56.6 MB per generator (16-bit signed windows)
+  const size_t prefix_bytes = (size_t)2 * GC_ROWS * GC_SEGS * GC_SEG * NL * sizeof(uint32_t);
+  uint32_t* d_prefix = nullptr;
   HIP_TRY_C(hipMalloc(&ctx->d_sqrt_p, sqrt_p_bytes));
   HIP_TRY_C(hipMalloc(&ctx->d_sqrt_lut, lut_bytes));
   HIP_TRY_C(hipMalloc(&ctx->d_g_win, 2 * WIN_TABLE_WORDS * sizeof(uint32_t)));
@@ -237,9 +239,14 @@ int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out) 
                            ctx->stream));
   HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_lut, vrfk_tables::SQRT_LUT, lut_bytes, hipMemcpyHostToDevice,
                            ctx->stream));
-  launch_init_tables((int)suite, ctx->d_g_win, ctx->d_g_comb, ctx->d_b_comb, ctx->stream);
-  HIP_TRY_C(hipGetLastError());
-  HIP_TRY_C(hipStreamSynchronize(ctx->stream));
+  HIP_TRY_C(hipMalloc(&d_prefix, prefix_bytes));
+  launch_init_tables((int)suite, ctx->d_g_win, ctx->d_g_comb, ctx->d_b_comb, d_prefix, ctx->stream);
+  {
+    hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_prefix);
+    HIP_TRY_C(e1);
+    HIP_TRY_C(e2);
+  }
 #undef HIP_TRY_C
   ctx->T.sq.P = ctx->d_sqrt_p;
   ctx->T.sq.lut = ctx->d_sqrt_lut;

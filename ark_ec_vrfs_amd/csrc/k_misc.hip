@@ -8,23 +8,24 @@ template <class S>
 __global__ void k_init_gwin(uint32_t* g_win) {
   if (blockIdx.x == 0 && threadIdx.x == 0) build_glv_tables<S>(g_win, S::gx(), S::gy());
 }
+// one lane per (base, row, segment) of the two generator tables (gcomb_build_segment); prefix: GC_SEG x 9 words per lane
 template <class S>
-__global__ void __launch_bounds__(BLOCK) k_init_comb(uint32_t* comb, int which) {
-  int t = blockIdx.x * BLOCK + threadIdx.x;
-  if (t >= 32 * 255) return;
-  int w = t / 255, j = t % 255 + 1;
-  FeN bx = which ? S::bx() : S::gx();
-  FeN by = which ? S::by() : S::gy();
-  comb_entry<S>(comb + (size_t)t * PTA_WORDS, bx, by, w, j);
+__global__ void __launch_bounds__(64, 2) k_init_gcomb(uint32_t* g_comb, uint32_t* b_comb, uint32_t* prefix) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= 2 * GC_ROWS * GC_SEGS) return;
+  const int which = t / (GC_ROWS * GC_SEGS), r = t % (GC_ROWS * GC_SEGS);
+  const int w = r / GC_SEGS, seg = r % GC_SEGS;
+  const FeN bx = which ? S::bx() : S::gx();
+  const FeN by = which ? S::by() : S::gy();
+  gcomb_build_segment<S>(which ? b_comb : g_comb, prefix + (size_t)t * GC_SEG * NL, bx, by, w, seg);
 }
 template <class S>
-static void init_tables_t(uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, hipStream_t st) {
+static void init_tables_t(uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, uint32_t* prefix, hipStream_t st) {
   hipLaunchKernelGGL(k_init_gwin<S>, dim3(1), dim3(64), 0, st, g_win);
-  hipLaunchKernelGGL(k_init_comb<S>, grid_for(32 * 255), dim3(BLOCK), 0, st, g_comb, 0);
-  hipLaunchKernelGGL(k_init_comb<S>, grid_for(32 * 255), dim3(BLOCK), 0, st, b_comb, 1);
+  hipLaunchKernelGGL(k_init_gcomb<S>, dim3((2 * GC_ROWS * GC_SEGS + 63) / 64), dim3(64), 0, st, g_comb, b_comb, prefix);
 }
-void launch_init_tables(int suite, uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, hipStream_t st) {
-  VRF_DISPATCH_SUITE(suite, init_tables_t<S>(g_win, g_comb, b_comb, st));
+void launch_init_tables(int suite, uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, uint32_t* prefix, hipStream_t st) {
+  VRF_DISPATCH_SUITE(suite, init_tables_t<S>(g_win, g_comb, b_comb, prefix, st));
 }
 
 // ---- Input::new ----

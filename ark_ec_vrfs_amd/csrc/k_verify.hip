@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(BLOCK) k_verify_comb_u(VerifyArgs a) {
     for (int j = 0; j < 8; ++j) { c[j] = 0; s[j] = 0; }
   }
   const uint32_t key = a.key_index[i] < a.n_keys ? a.key_index[i] : 0;
-  PtE r = comb_mul<S>(a.T.g_comb, s);
+  PtE r = gcomb_mul<S>(a.T.g_comb, s);
   r = comb_add<S>(r, a.key_combs + (size_t)key * COMB_WORDS, c, true);
   uint32_t* out = a.ws.pts + i * PROVE_PTS_WORDS;
   fe_store(out, r.X); fe_store(out + NL, r.Y); fe_store(out + 2 * NL, r.Z);

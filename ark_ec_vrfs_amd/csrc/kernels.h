@@ -85,7 +85,8 @@ struct PedersenVerifyArgs {
 };
 
 // launchers (each defined next to its kernels)
-void launch_init_tables(int suite, uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, hipStream_t st);
+// generator tables: GCOMB_WORDS words each; prefix: 2 * GC_ROWS * GC_SEGS * GC_SEG * 9 words of build scratch
+void launch_init_tables(int suite, uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, uint32_t* prefix, hipStream_t st);
 // ev: optional 5 events recorded on `st` before stage 1 and after stages 1, 2a, 2b, 3 (profiling)
 void launch_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
 void launch_ietf_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);

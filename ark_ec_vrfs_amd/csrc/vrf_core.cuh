@@ -35,7 +35,7 @@ VRF_HD void bytes_lite_get(const BytesViewLite& v, size_t i, const uint8_t*& p, 
 struct DevTables {
   SqrtTables sq;
   const uint32_t* g_win;     // [2][8][PTC_WORDS]    j*G and j*psi(G), j = 1..8, cached form
-  const uint32_t* g_comb;    // [32][255][PTA_WORDS] j*256^w*G affine (fixed-base comb)
+  const uint32_t* g_comb;    // [GC_ROWS][GC_COLS][PTA_WORDS] j*2^(GCB*w)*G affine, signed windows (gcomb_*)
   const uint32_t* b_comb;    // same for the Pedersen blinding base
 };
 
@@ -296,7 +296,128 @@ VRF_HD PtE win_mul(const uint32_t* tab, const uint32_t rec[8], bool negate = fal
   return acc;
 }
 
-// k*Base from an 8-bit fixed-base comb table [32][255] of affine entries
+// ---- fixed-base tables of the suite's generators G and B: signed GCB-bit windows, no doublings ----
+// k = sum_w d_w 2^(GCB w), d_w in [-2^(GCB-1), 2^(GCB-1)); row w holds j * 2^(GCB w) * Base for j = 1..2^(GCB-1)
+// as affine-cached entries.  GCB = 16 on the device: 16 mixed additions per scalar from a 56.6 MB table per
+// base (HBM / MALL resident, next entry prefetched while the current addition runs) instead of 32 from an
+// L2-resident 8-bit comb.  The host simulation compiles the same code with GCB = 8 (-DVRF_GCOMB_BITS=8).
+#ifndef VRF_GCOMB_BITS
+#define VRF_GCOMB_BITS 16
+#endif
+constexpr int GCB = VRF_GCOMB_BITS;
+static_assert(GCB == 8 || GCB == 16, "window must divide 32");
+constexpr int GC_ROWS = 256 / GCB;
+constexpr int GC_COLS = 1 << (GCB - 1);
+constexpr size_t GCOMB_WORDS = (size_t)GC_ROWS * GC_COLS * PTA_WORDS;
+constexpr int GC_SEG = GC_COLS < 256 ? GC_COLS : 256;            // entries built by one lane (one inversion)
+constexpr int GC_SEGS = GC_COLS / GC_SEG;
+
+// signed digit of window w with the carry of the windows below; k < 2^253 so the top window cannot overflow
+VRF_HD int gcomb_digit(const uint32_t k[8], int w, uint32_t& carry) {
+  const int bit = w * GCB;
+  uint32_t word = k[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if ((bit >> 5) == i) word = k[i];
+  uint32_t chunk = ((word >> (bit & 31)) & ((1u << GCB) - 1)) + carry;
+  carry = chunk >= (1u << (GCB - 1)) ? 1u : 0u;
+  return (int)chunk - (int)(carry << GCB);
+}
+VRF_HD PtA gcomb_entry(const uint32_t* tab, int w, int d) {
+  const int mag = d < 0 ? -d : d;
+  PtA e = pta_load(tab + ((size_t)w * GC_COLS + (mag ? mag - 1 : 0)) * PTA_WORDS);
+  const PtA id = pta_identity();
+  const bool z = mag == 0;
+  e.x = fe_select(z, id.x, e.x);
+  e.y = fe_select(z, id.y, e.y);
+  e.dt = fe_select(z, id.dt, e.dt);
+  return e;
+}
+// acc +/- k*Base
+template <class C>
+VRF_HD PtE gcomb_add(PtE acc, const uint32_t* tab, const uint32_t k[8], bool neg = false) {
+  uint32_t carry = 0;
+  int d = gcomb_digit(k, 0, carry);
+  PtA e = gcomb_entry(tab, 0, d);
+#pragma unroll 1
+  for (int w = 0; w < GC_ROWS; ++w) {
+    const PtA cur = e;
+    const bool sgn = d < 0;
+    if (w + 1 < GC_ROWS) {                       // next entry in flight during this addition
+      d = gcomb_digit(k, w + 1, carry);
+      e = gcomb_entry(tab, w + 1, d);
+    }
+    acc = te_add_affine<C>(acc, cur, sgn != neg);
+  }
+  return acc;
+}
+template <class C>
+VRF_HD PtE gcomb_mul(const uint32_t* tab, const uint32_t k[8]) { return gcomb_add<C>(te_identity(), tab, k); }
+// k1*G + k2*B (one add call site)
+template <class C>
+VRF_HD PtE gcomb_mul2(const uint32_t* tab1, const uint32_t k1[8], const uint32_t* tab2, const uint32_t k2[8]) {
+  PtE acc = te_identity();
+#pragma unroll 1
+  for (int t = 0; t < 2; ++t) {
+    uint32_t k[8];
+    sel8(k, t != 0, k2, k1);
+    acc = gcomb_add<C>(acc, t ? tab2 : tab1, k);
+  }
+  return acc;
+}
+
+// count entries start, start + step, start + 2 step, ... made affine with ONE inversion (Montgomery's trick;
+// prefix: count x 9 words owned by the caller)
+template <class C>
+VRF_HD void comb_chain(uint32_t* row, uint32_t* prefix, PtE acc, const PtC& step, int count) {
+  FeN run = fe_one();
+#pragma unroll 1
+  for (int j = 0; j < count; ++j) {
+    uint32_t* slot = row + (size_t)j * PTA_WORDS;
+    fe_store(slot, acc.X); fe_store(slot + NL, acc.Y); fe_store(slot + 2 * NL, acc.Z);
+    fe_store(prefix + (size_t)j * NL, run);
+    run = fe_mul(run, acc.Z);
+    acc = te_add_cached<C>(acc, step, false);
+  }
+  FeN inv = fe_inv(run);
+#pragma unroll 1
+  for (int j = count - 1; j >= 0; --j) {
+    uint32_t* slot = row + (size_t)j * PTA_WORDS;
+    const FeP X = fe_load<1, 5>(slot), Y = fe_load<1, 5>(slot + NL), Z = fe_load<1, 5>(slot + 2 * NL);
+    const FeN zi = fe_mul(inv, fe_load<1, 2>(prefix + (size_t)j * NL));
+    inv = fe_mul(inv, Z);
+    PtA a;
+    a.x = fe_mul(X, zi);
+    a.y = fe_mul(Y, zi);
+    a.dt = fe_mul(fe_mul(a.x, a.y), C::d());
+    pta_store(slot, a);
+  }
+}
+// segment `seg` of row w of a generator table: entries j = seg*GC_SEG + 1 .. (seg+1)*GC_SEG
+template <class C>
+VRF_HD void gcomb_build_segment(uint32_t* tab, uint32_t* prefix, const FeN& x, const FeN& y, int w, int seg) {
+  PtE base = te_from_affine(x, y);
+#pragma unroll 1
+  for (int i = 0; i < GCB * w; ++i) base = te_dbl<C>(base, true);        // 2^(GCB w) * Base
+  const PtC step = te_to_cached<C>(base);
+  PtE big = base;
+#pragma unroll 1
+  for (int i = 1; i < GC_SEG; i <<= 1) big = te_dbl<C>(big, true);        // GC_SEG * base
+  const PtC bigc = te_to_cached<C>(big);
+  PtE start = te_identity();                                              // seg * big, double and add
+#pragma unroll 1
+  for (int b = 15; b >= 0; --b) {
+    start = te_dbl<C>(start, true);
+    PtE sum = te_add_cached<C>(start, bigc, false);
+    const bool bit = (seg >> b) & 1;
+    start.X = fe_select(bit, sum.X, start.X); start.Y = fe_select(bit, sum.Y, start.Y);
+    start.Z = fe_select(bit, sum.Z, start.Z); start.T = fe_select(bit, sum.T, start.T);
+  }
+  start = te_add_cached<C>(start, step, false);                           // (seg * GC_SEG + 1) * base
+  comb_chain<C>(tab + ((size_t)w * GC_COLS + (size_t)seg * GC_SEG) * PTA_WORDS, prefix, start, step, GC_SEG);
+}
+
+// k*Base from an 8-bit unsigned comb [32][255] of affine entries (key sets: 881 KB per public key)
 template <class C>
 VRF_HD PtE comb_mul(const uint32_t* comb, const uint32_t k[8]) {
   PtE acc = te_identity();
@@ -340,20 +461,6 @@ VRF_HD PtE comb_add(PtE acc, const uint32_t* comb, const uint32_t k[8], bool neg
   }
   return acc;
 }
-// k1*G + k2*B from the two fixed-base combs (one add call site)
-template <class C>
-VRF_HD PtE comb_mul2(const uint32_t* comb1, const uint32_t k1[8], const uint32_t* comb2,
-                     const uint32_t k2[8]) {
-  PtE acc = te_identity();
-#pragma unroll 1
-  for (int t = 0; t < 2; ++t) {
-    uint32_t k[8];
-    sel8(k, t != 0, k2, k1);
-    acc = comb_add<C>(acc, t ? comb2 : comb1, k);
-  }
-  return acc;
-}
-
 // ------------------------------------------------------------------------ table init helpers
 // k*P by branch-free double-and-add (one-time table construction only)
 template <class C>
@@ -376,21 +483,6 @@ VRF_HD PtE te_mul_slow(const PtE& base, const uint32_t k[8]) {
   }
   return acc;
 }
-// comb entry (w, j): (j * 256^w) * Base as an affine cached entry, j in 1..255
-template <class C>
-VRF_HD void comb_entry(uint32_t* out, const FeN& bx, const FeN& by, int w, int j) {
-  uint32_t k[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) k[i] = ((w >> 2) == i) ? ((uint32_t)j << ((w & 3) * 8)) : 0u;
-  PtE p = te_mul_slow<C>(te_from_affine(bx, by), k);
-  FeN zi = fe_inv(p.Z);
-  PtA a;
-  a.x = fe_mul(p.X, zi);
-  a.y = fe_mul(p.Y, zi);
-  a.dt = fe_mul(fe_mul(a.x, a.y), C::d());
-  pta_store(out, a);
-}
-
 // ------------------------------------------------------------------------ key sets
 // Context-resident fixed-base comb of a PUBLIC KEY (keyed verification: many proofs per key).  One lane builds
 // row w of a key: base_w = 256^w * Y by 8w doublings, entries j * base_w, j = 1..255, by a chain of unified
@@ -404,30 +496,7 @@ VRF_HD void comb_build_row(uint32_t* row /*[255][27]*/, uint32_t* prefix /*[255]
   PtE base = te_from_affine(x, y);
 #pragma unroll 1
   for (int i = 0; i < 8 * w; ++i) base = te_dbl<C>(base, i == 8 * w - 1);
-  const PtC bc = te_to_cached<C>(base);
-  PtE acc = base;
-  FeN run = fe_one();
-#pragma unroll 1
-  for (int j = 0; j < COMB_COLS; ++j) {
-    uint32_t* slot = row + (size_t)j * PTA_WORDS;
-    fe_store(slot, acc.X); fe_store(slot + NL, acc.Y); fe_store(slot + 2 * NL, acc.Z);
-    fe_store(prefix + (size_t)j * NL, run);
-    run = fe_mul(run, acc.Z);
-    acc = te_add_cached<C>(acc, bc, false);
-  }
-  FeN inv = fe_inv(run);
-#pragma unroll 1
-  for (int j = COMB_COLS - 1; j >= 0; --j) {
-    uint32_t* slot = row + (size_t)j * PTA_WORDS;
-    const FeP X = fe_load<1, 5>(slot), Y = fe_load<1, 5>(slot + NL), Z = fe_load<1, 5>(slot + 2 * NL);
-    const FeN zi = fe_mul(inv, fe_load<1, 2>(prefix + (size_t)j * NL));
-    inv = fe_mul(inv, Z);
-    PtA a;
-    a.x = fe_mul(X, zi);
-    a.y = fe_mul(Y, zi);
-    a.dt = fe_mul(fe_mul(a.x, a.y), C::d());
-    pta_store(slot, a);
-  }
+  comb_chain<C>(row, prefix, base, te_to_cached<C>(base), COMB_COLS);
 }
 
 // ------------------------------------------------------------------------ challenge
@@ -675,7 +744,7 @@ VRF_HD void verify_straus_item(uint32_t* out_uv, const DevTables& T, const uint3
     PtE r;
     if (HALF == 0) {
       r = win_mul<S>(tabs, recc, true);
-      r = comb_add<S>(r, T.g_comb, s);
+      r = gcomb_add<S>(r, T.g_comb, s);
     } else {
       r = straus2<S>(tabs + 2 * WIN_TABLE_WORDS, recs, tabs + 4 * WIN_TABLE_WORDS, recc, true);
     }
@@ -700,7 +769,7 @@ VRF_HD void verify_straus_item(uint32_t* out_uv, const DevTables& T, const uint3
     for (int i = 0; i < 4; ++i) { q.rec[2][i] = 0; q.rec[3][i] = 0; }
     q.neg[2] = false; q.neg[3] = false;
     r = straus4<S, 2>(q);
-    r = comb_add<S>(r, T.g_comb, s);
+    r = gcomb_add<S>(r, T.g_comb, s);
   } else {
     glv_decompose_bs(h[2], h[3], s);
 #pragma unroll
@@ -1145,9 +1214,9 @@ VRF_HD void prove_mul_item(uint32_t* out /*2*UV_WORDS*/, const DevTables& T, con
     uint32_t k2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) k2[i] = scalar2[i];
-    c = comb_mul2<S>(T.g_comb, scalar, T.b_comb, k2);
+    c = gcomb_mul2<S>(T.g_comb, scalar, T.b_comb, k2);
   } else {
-    c = comb_mul<S>(T.g_comb, scalar);
+    c = gcomb_mul<S>(T.g_comb, scalar);
   }
   fe_store(out + UV_WORDS, c.X); fe_store(out + UV_WORDS + NL, c.Y);
   fe_store(out + UV_WORDS + 2 * NL, c.Z);
@@ -1275,8 +1344,8 @@ VRF_HD void pedersen_verify_straus_item(uint32_t* out_uv, const DevTables& T, co
       r = straus2<S>(tabs, recs, tabs + 2 * WIN_TABLE_WORDS, recc, true);      // s*H - c*Gamma
     } else {
       r = win_mul<S>(tabs + 4 * WIN_TABLE_WORDS, recc, true);                   // -c*pk_com
-      r = comb_add<S>(r, T.g_comb, s);
-      r = comb_add<S>(r, T.b_comb, sb);
+      r = gcomb_add<S>(r, T.g_comb, s);
+      r = gcomb_add<S>(r, T.b_comb, sb);
     }
     fe_store(out_uv, r.X);
     fe_store(out_uv + NL, r.Y);
@@ -1309,8 +1378,8 @@ VRF_HD void pedersen_verify_straus_item(uint32_t* out_uv, const DevTables& T, co
     for (int i = 0; i < 4; ++i) { q.rec[2][i] = 0; q.rec[3][i] = 0; }
     q.neg[2] = false; q.neg[3] = false;
     r = straus4<S, 2>(q);
-    r = comb_add<S>(r, T.g_comb, s);
-    r = comb_add<S>(r, T.b_comb, sb);
+    r = gcomb_add<S>(r, T.g_comb, s);
+    r = gcomb_add<S>(r, T.b_comb, sb);
   }
   fe_store(out_uv, r.X);
   fe_store(out_uv + NL, r.Y);
@@ -1418,7 +1487,7 @@ VRF_HD void secret_from_seed_item(uint32_t sk[8], const uint8_t* seed, uint32_t 
 // [ref src/lib.rs:16 `Secret::public`]  pk = sk*G via the fixed-base comb, encoded.
 template <class S>
 VRF_HD void public_from_secret_item(uint32_t pk[8], const DevTables& T, const uint32_t sk[8]) {
-  PtE p = comb_mul<S>(T.g_comb, sk);
+  PtE p = gcomb_mul<S>(T.g_comb, sk);
   FeN x, y;
   te_to_affine(x, y, p);
   te_encode_affine(pk, x, y);

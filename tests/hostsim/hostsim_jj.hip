@@ -11,22 +11,13 @@ struct HostTablesJ {
   HostTablesJ() {
     g_win.resize(2 * WIN_TABLE_WORDS);
     build_glv_tables<SJ>(g_win.data(), SJ::gx(), SJ::gy());
-    g_comb.resize((size_t)32 * 255 * PTA_WORDS); b_comb.resize((size_t)32 * 255 * PTA_WORDS);
+    g_comb.resize(GCOMB_WORDS); b_comb.resize(GCOMB_WORDS);
+    std::vector<uint32_t> prefix((size_t)GC_SEG * NL);
     for (int which = 0; which < 2; ++which)
-    for (int w = 0; w < 32; ++w) {
-      uint32_t* comb = which ? b_comb.data() : g_comb.data();
-      uint32_t k[8] = {0}; k[w >> 2] = 1u << ((w & 3) * 8);
-      PtE base = te_mul_slow<SJ>(which ? te_from_affine(SJ::bx(), SJ::by()) : te_from_affine(SJ::gx(), SJ::gy()), k);
-      PtC bc = te_to_cached<SJ>(base);
-      PtE acc = base;
-      for (int j = 1; j <= 255; ++j) {
-        FeN zi = fe_inv(acc.Z);
-        PtA a; a.x = fe_mul(acc.X, zi); a.y = fe_mul(acc.Y, zi);
-        a.dt = fe_mul(fe_mul(a.x, a.y), SJ::d());
-        pta_store(comb + ((size_t)w * 255 + (j - 1)) * PTA_WORDS, a);
-        acc = te_add_cached<SJ>(acc, bc, false);
-      }
-    }
+    for (int w = 0; w < GC_ROWS; ++w)
+    for (int seg = 0; seg < GC_SEGS; ++seg)       // the device's own table builder (k_init_gcomb runs it per lane)
+      gcomb_build_segment<SJ>(which ? b_comb.data() : g_comb.data(), prefix.data(),
+                              which ? SJ::bx() : SJ::gx(), which ? SJ::by() : SJ::gy(), w, seg);
     t.sq.P = vrfk_tables::SQRT_P; t.sq.lut = vrfk_tables::SQRT_LUT;
     t.g_win = g_win.data(); t.g_comb = g_comb.data(); t.b_comb = b_comb.data();
   }

@@ -19,25 +19,13 @@ struct HostTables {
   HostTables() {
     g_win.resize(2 * WIN_TABLE_WORDS);
     build_glv_tables<SuiteBS>(g_win.data(), SuiteBS::gx(), SuiteBS::gy());
-    g_comb.resize((size_t)32 * 255 * PTA_WORDS);
-    b_comb.resize((size_t)32 * 255 * PTA_WORDS);
-    // comb by repeated addition instead of 8160 scalar multiplications (host is slow):
+    g_comb.resize(GCOMB_WORDS); b_comb.resize(GCOMB_WORDS);
+    std::vector<uint32_t> prefix((size_t)GC_SEG * NL);
     for (int which = 0; which < 2; ++which)
-    for (int w = 0; w < 32; ++w) {
-      uint32_t* comb = which ? b_comb.data() : g_comb.data();
-      uint32_t k[8] = {0}; k[w >> 2] = 1u << ((w & 3) * 8);
-      PtE base = te_mul_slow<SuiteBS>(which ? te_from_affine(SuiteBS::bx(), SuiteBS::by())
-                                            : te_from_affine(SuiteBS::gx(), SuiteBS::gy()), k);
-      PtC bc = te_to_cached<SuiteBS>(base);
-      PtE acc = base;
-      for (int j = 1; j <= 255; ++j) {
-        FeN zi = fe_inv(acc.Z);
-        PtA a; a.x = fe_mul(acc.X, zi); a.y = fe_mul(acc.Y, zi);
-        a.dt = fe_mul(fe_mul(a.x, a.y), SuiteBS::d());
-        pta_store(comb + ((size_t)w * 255 + (j - 1)) * PTA_WORDS, a);
-        acc = te_add_cached<SuiteBS>(acc, bc, false);
-      }
-    }
+    for (int w = 0; w < GC_ROWS; ++w)
+    for (int seg = 0; seg < GC_SEGS; ++seg)       // the device's own table builder (k_init_gcomb runs it per lane)
+      gcomb_build_segment<SuiteBS>(which ? b_comb.data() : g_comb.data(), prefix.data(),
+                              which ? SuiteBS::bx() : SuiteBS::gx(), which ? SuiteBS::by() : SuiteBS::gy(), w, seg);
     t.sq = host_tables(); t.g_win = g_win.data(); t.g_comb = g_comb.data(); t.b_comb = b_comb.data();
   }
 };
@@ -45,16 +33,19 @@ HostTables& HT() { static HostTables h; return h; }
 }
 extern "C" {
 void hs_init() { (void)HT(); }
-// single comb entry through the device init path (checks comb_entry against the additive build)
+// entry (w, j) of the generator table built by gcomb_build_segment against j * 2^(GCB w) * G by the ladder
 int hs_comb_entry_check(int w, int j) {
-  uint32_t e[PTA_WORDS];
-  comb_entry<SuiteBS>(e, SuiteBS::gx(), SuiteBS::gy(), w, j);
-  // compare canonical values
-  const uint32_t* ref = HT().g_comb.data() + ((size_t)w * 255 + (j - 1)) * PTA_WORDS;
-  for (int c = 0; c < 3; ++c)
-    if (!fe_eq(fe_load<1, 2>(e + c * NL), fe_load<1, 2>(ref + c * NL))) return 0;
-  return 1;
+  if (w >= GC_ROWS || j < 1 || j > GC_COLS) return -1;
+  uint32_t k[8] = {0};
+  const int bit = w * GCB;
+  k[bit >> 5] = (uint32_t)j << (bit & 31);
+  PtE p = te_mul_slow<SuiteBS>(te_from_affine(SuiteBS::gx(), SuiteBS::gy()), k);
+  FeN zi = fe_inv(p.Z);
+  FeN x = fe_mul(p.X, zi), y = fe_mul(p.Y, zi), dt = fe_mul(fe_mul(x, y), SuiteBS::d());
+  const uint32_t* ref = HT().g_comb.data() + ((size_t)w * GC_COLS + (j - 1)) * PTA_WORDS;
+  return fe_eq(x, fe_load<1, 2>(ref)) && fe_eq(y, fe_load<1, 2>(ref + NL)) && fe_eq(dt, fe_load<1, 2>(ref + 2 * NL));
 }
+int hs_gcomb_geometry(int* rows, int* cols) { *rows = GC_ROWS; *cols = GC_COLS; return GCB; }
 void hs_hash_to_curve(const uint8_t* msg, uint32_t len, uint8_t* out) {
   PtE h = hash_to_curve_ell2<SuiteBS>(msg, len, HT().t.sq);
   FeN x, y; te_to_affine(x, y, h);

@@ -20,20 +20,13 @@ struct HostTables {
   HostTables() {
     g_win.resize(2 * WIN_TABLE_WORDS);
     build_glv_tables<SuiteBS>(g_win.data(), SuiteBS::gx(), SuiteBS::gy());
-    g_comb.resize((size_t)32 * 255 * PTA_WORDS);
-    for (int w = 0; w < 32; ++w) {
-      uint32_t k[8] = {0}; k[w >> 2] = 1u << ((w & 3) * 8);
-      PtE base = te_mul_slow<SuiteBS>(te_from_affine(SuiteBS::gx(), SuiteBS::gy()), k);
-      PtC bc = te_to_cached<SuiteBS>(base);
-      PtE acc = base;
-      for (int j = 1; j <= 255; ++j) {
-        FeN zi = fe_inv(acc.Z);
-        PtA a; a.x = fe_mul(acc.X, zi); a.y = fe_mul(acc.Y, zi);
-        a.dt = fe_mul(fe_mul(a.x, a.y), SuiteBS::d());
-        pta_store(g_comb.data() + ((size_t)w * 255 + (j - 1)) * PTA_WORDS, a);
-        acc = te_add_cached<SuiteBS>(acc, bc, false);
-      }
-    }
+    g_comb.resize(GCOMB_WORDS);
+    std::vector<uint32_t> prefix((size_t)GC_SEG * NL);
+    for (int which = 0; which < 1; ++which)
+    for (int w = 0; w < GC_ROWS; ++w)
+    for (int seg = 0; seg < GC_SEGS; ++seg)       // the device's own table builder (k_init_gcomb runs it per lane)
+      gcomb_build_segment<SuiteBS>(g_comb.data(), prefix.data(),
+                              which ? SuiteBS::bx() : SuiteBS::gx(), which ? SuiteBS::by() : SuiteBS::gy(), w, seg);
     t.sq = host_tables(); t.g_win = g_win.data(); t.g_comb = g_comb.data(); t.b_comb = nullptr;
   }
 };

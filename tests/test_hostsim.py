@@ -129,8 +129,14 @@ def test_decode_and_verify_status_against_oracle(hs):
         assert hs.hs_ietf_verify(*bad, ad, len(ad)) == 2
 
 
-def test_comb_entries_match_additive_construction(hs):
-    for (w, j) in [(0, 1), (0, 255), (3, 17), (31, 1), (31, 7)]:
+def test_generator_table_entries_match_the_ladder(hs):
+    """The signed-window generator tables are built by the device's own segment builder (one inversion per
+    segment); entries must equal j * 2^(bits w) * G computed by the branch-free ladder.  The host simulation
+    uses 8-bit windows (the device 16-bit: same code, GC_* constants differ)."""
+    rows, cols = ctypes.c_int(), ctypes.c_int()
+    bits = hs.hs_gcomb_geometry(ctypes.byref(rows), ctypes.byref(cols))
+    assert (bits, rows.value, cols.value) == (8, 32, 128)
+    for (w, j) in [(0, 1), (0, 2), (0, 128), (3, 17), (31, 1), (31, 7), (17, 127)]:
         assert hs.hs_comb_entry_check(w, j) == 1
 
 
