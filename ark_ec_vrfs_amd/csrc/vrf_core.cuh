@@ -729,7 +729,7 @@ VRF_HD bool verify_decode_affine_item(uint32_t enc_out[3][8], const uint32_t (&x
   return valid;
 }
 
-// HALF 0: U = s*G - c*Y = comb(G, s) - (c1*Y + c2*psi Y)   (2-table GLV Straus + 8-bit fixed-base comb)
+// HALF 0: U = s*G - c*Y = comb(G, s) - (c1*Y + c2*psi Y)   (2-table GLV Straus + 16-bit signed fixed-base table)
 // HALF 1: V = s*H - c*Gamma                                 (4-table GLV Straus over tabs[2..5])
 // GLV: k = k1 + k2*lambda with 128-bit halves; the c terms are subtracted.  The two halves run as
 // separate launches so that every wave executes one shape.

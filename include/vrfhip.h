@@ -80,7 +80,8 @@ void vrfhip_ctx_destroy(vrfhip_ctx* ctx);
 
 /* Size the internal HBM workspace for exactly `max_items` items per launch group (optional).
  * Larger batches are processed in chunks of `max_items`.  Without this call the workspace
- * grows on demand up to 2^20 items (about 3.7 KiB of HBM per item). */
+ * grows on demand up to 2^20 items (about 7.3 KiB of HBM per item; a context also holds 113 MB of
+ * fixed-base tables of the two generators). */
 int32_t vrfhip_ctx_reserve(vrfhip_ctx* ctx, size_t max_items);
 
 /* Bytes of device workspace currently held by the context. */
@@ -126,7 +127,7 @@ int32_t vrfhip_ietf_verify_batch_affine_dev(vrfhip_ctx* ctx, size_t n, const uin
 /* Keyed verification: many proofs per public key (`Public`, src/lib.rs:15).  A key set keeps, for each of
  * n_keys public keys, a validated point and its 8-bit fixed-base comb (881,280 bytes per key) resident in
  * HBM: 100,000 keys take 88 GB of the 288 GB.  Verification against a key of the set needs no decompression
- * of pk and computes U = s*G - c*Y with 64 mixed additions and no doublings.
+ * of pk and computes U = s*G - c*Y with 48 mixed additions and no doublings.
  * vrfhip_keyset_create: pks = n_keys x 32 B compressed points (host); status (nullable, host) receives
  * 0 / 2 per key: a key must decode to a point of the prime-order subgroup (the checked decode of `codec`).
  * Proofs that name an invalid or out-of-range key are reported InvalidData.  The key set belongs to `ctx`
