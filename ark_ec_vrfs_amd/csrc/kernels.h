@@ -139,7 +139,7 @@ inline bool two_waves_pay(size_t lanes) { return lanes >= size_t(131072); }
 // across K proofs per lane launch n/K lanes: at 2^20 proofs that is 1024 workgroups for 256 CUs, and since
 // such a kernel needs ~140 VGPRs (three waves per SIMD fit) the dispatcher packs six workgroups per CU and
 // leaves a third of the CUs idle (measured: SQ_WAVE_CYCLES of k_verify_decode at 0.56 of the Straus
-// kernels', 75 % VALU utilisation).  Reserving 160 KiB / ceil(workgroups / CUs) of LDS per workgroup caps
+// kernels', 75 % VALU utilisation).  Reserving 152 KiB / ceil(workgroups / CUs) of LDS per workgroup caps
 // the workgroups a CU accepts at the even share; big grids get 0 (no effect).
 inline size_t spread_lds_bytes(size_t workgroups) {
   static int cus = 0;
@@ -153,7 +153,7 @@ inline size_t spread_lds_bytes(size_t workgroups) {
   }
   const size_t share = (workgroups + cus - 1) / cus;          // even number of workgroups per CU
   if (share == 0 || share > 8) return 0;                      // large grid: occupancy is not the problem
-  size_t bytes = (size_t(160) * 1024) / share;
+  size_t bytes = (size_t(152) * 1024) / share;                // `share` workgroups fit in the 160 KiB, share + 1 do not
   bytes -= bytes % 1024;
   return bytes > 64 * 1024 ? 64 * 1024 : bytes;               // default dynamic-LDS limit without an attribute
 }
