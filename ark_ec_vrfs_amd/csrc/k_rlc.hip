@@ -19,8 +19,8 @@
 //   k_rlc_fixed  : normalises the columns mod r and appends G and B with their digits.
 //   then k_msm_buckets / k_msm_final (k_msm.hip) and the verdict byte.
 // Weights: (z_i, z'_i) = the first two 16-byte little-endian halves of
-// SHA-512("vrfhip-rlc-v1" || seed[32] || u64_le(index of the proof in the caller's batch)); the seed
-// must be unpredictable to whoever produced the proofs.
+// SHA-512("vrfhip-rlc-v1" || seed[32] || u64_le(index of the proof in the caller's batch)) with the low
+// three bits forced to 001; the seed must be unpredictable to whoever produced the proofs.
 #include "kernels.h"
 #include "msm.cuh"
 

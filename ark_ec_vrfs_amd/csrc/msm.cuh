@@ -105,6 +105,10 @@ VRF_HD void rlc_weights(uint32_t z[8], uint32_t zp[8], const uint8_t* seed, uint
   sha512_le512(le, h);
 #pragma unroll
   for (int i = 0; i < 4; ++i) { z[i] = le[i]; zp[i] = le[4 + i]; z[4 + i] = 0; zp[4 + i] = 0; }
+  // weights = 1 (mod 8): a weight then fixes every point of order dividing the cofactor (4 or 8), so a lone
+  // small-order defect is never annihilated (defence in depth; the subgroup precondition remains)
+  z[0] = (z[0] & ~7u) | 1u;
+  zp[0] = (zp[0] & ~7u) | 1u;
 }
 
 // host side (k_msm.hip)

@@ -204,14 +204,15 @@ int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_
 /* `pedersen::Verifier::verify` for a whole batch with ONE multi-scalar multiplication (random linear
  * combination).  With c_i recomputed from the proof's own points, the batch is
  * accepted iff  sum_i z_i (s_i H_i - c_i Gamma_i - Ok_i) + z'_i (s_i G + sb_i B - c_i pk_com_i - R_i)
- * is the neutral element, (z_i, z'_i) = 2 x 128 bits of SHA-512("vrfhip-rlc-v1" || seed || u64_le(i)).
+ * is the neutral element, (z_i, z'_i) = 2 x 128 bits of SHA-512("vrfhip-rlc-v1" || seed || u64_le(i)), each forced to 1 (mod 8).
  * `seed` (32 bytes, host memory) must be unpredictable to the provers (fresh randomness per call);
  * a batch holding an invalid proof is then accepted with probability <= 2^-128.
  * The bound holds under the precondition of every verify entry point -- all five points of every proof lie in
  * the prime-order subgroup, as arkworks' checked deserialisation guarantees for the reference's typed values
  * (vrfhip_point_validate_batch for raw bytes).  It is NOT a courtesy here: a defect of small order (a proof
  * point shifted by a 2- or 4-torsion point) is annihilated by a weight divisible by its order, so unvalidated
- * points could pass the batch equation with probability up to 1/2 although the per-proof check rejects them.
+ * points could pass the batch equation although the per-proof check rejects them.  Weights are 1 (mod 8), so
+ * a single such proof is always caught; two colluding proofs whose small-order defects cancel are not.
  *
  * _dev form: enqueues the work and returns.  d_status[i] = 0 if proof i is part of the batch sum,
  * 2 (InvalidData) if it does not decode (it is then left out of the sum).  d_fail_flag[0] = 0 if every

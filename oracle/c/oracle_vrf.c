@@ -690,7 +690,7 @@ void oracle_pedersen_prove_batch(size_t n, const uint8_t* sk, const uint8_t* msg
 /* Batched Pedersen verification by random linear combination, the slow way:
  * for every proof the two defects D1 = s*H - c*Gamma - Ok and D2 = s*G + sb*B - c*pk_com - R are
  * computed by double-and-add, weighted by (z_i, z'_i) = the two little-endian 16-byte halves of
- * SHA-512("vrfhip-rlc-v1" || seed || u64_le(index0 + i)) and summed.  status[i] = 0 (in the sum) or 2
+ * SHA-512("vrfhip-rlc-v1" || seed || u64_le(index0 + i)), low three bits forced to 001, and summed.  status[i] = 0 (in the sum) or 2
  * (undecodable: left out).  Returns 0 if the sum is the neutral element, else 1. */
 int oracle_pedersen_rlc_check(size_t n, const uint8_t* h, const uint8_t* gamma, const uint8_t* proof160,
                               const uint8_t* ad, size_t ad_len, const uint8_t seed[32], uint64_t index0,
@@ -730,6 +730,7 @@ int oracle_pedersen_rlc_check(size_t n, const uint8_t* h, const uint8_t* gamma, 
       z[0] |= (uint64_t)dg[k] << (8 * k); z[1] |= (uint64_t)dg[8 + k] << (8 * k);
       zp[0] |= (uint64_t)dg[16 + k] << (8 * k); zp[1] |= (uint64_t)dg[24 + k] << (8 * k);
     }
+    z[0] = (z[0] & ~(uint64_t)7) | 1; zp[0] = (zp[0] & ~(uint64_t)7) | 1;   /* weights = 1 (mod 8) */
     pt t0, t1, d1, d2, n0;
     pt_mul(&t0, &H, s); pt_mul(&t1, &Gm, c); pt_neg(&n0, &t1); pt_add(&d1, &t0, &n0);
     pt_neg(&n0, &Ok); pt_add(&d1, &d1, &n0);

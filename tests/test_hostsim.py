@@ -248,7 +248,7 @@ def test_multi_proof_prepare_matches_oracle(hs):
 def test_msm_digit_recoding_and_rlc_weights(hs):
     """msm.cuh: signed radix-2^11 digits (folded at r/2) rebuild +-k mod r, stay in [-1024, 1024], leave the
     windows >= 12 empty for 128-bit scalars; the batched-verification weights are the two 16-byte halves of
-    SHA-512("vrfhip-rlc-v1" || seed || u64_le(i)); the MSM index map puts G and B after the three classes
+    SHA-512("vrfhip-rlc-v1" || seed || u64_le(i)) with the low three bits forced to 001; the MSM index map puts G and B after the three classes
     with full-size scalars."""
     import hashlib
     rnd = random.Random(11)
@@ -274,7 +274,8 @@ def test_msm_digit_recoding_and_rlc_weights(hs):
         z, zp = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
         hs.hs_rlc_weights(seed, ctypes.c_uint64(idx), z, zp)
         dg = hashlib.sha512(b"vrfhip-rlc-v1" + seed + idx.to_bytes(8, "little")).digest()
-        assert z.raw == dg[:16] + bytes(16) and zp.raw == dg[16:32] + bytes(16)
+        fix = lambda b: bytes([(b[0] & 0xf8) | 1]) + b[1:]
+        assert z.raw == fix(dg[:16]) + bytes(16) and zp.raw == fix(dg[16:32]) + bytes(16)
     hs.hs_rlc_index.restype = ctypes.c_uint64
     n = 1000
     idx = sorted(hs.hs_rlc_index(p, ctypes.c_uint64(n), ctypes.c_uint64(i)) for p in range(5) for i in range(n))

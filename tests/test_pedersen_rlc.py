@@ -252,3 +252,31 @@ def test_gpu_rlc_full_size_2_20(ctx):
     ctx.pedersen_verify_batch_rlc_dev(hh, g, pc, r, ok, s, sb, st, flag, os.urandom(32))
     torch.cuda.synchronize()
     assert int(flag[0]) == 0
+
+
+def _shift_by_order2(enc):
+    """enc(P + (0, -1)) = enc((-x, -y)): the same point plus the rational 2-torsion point (outside the subgroup)."""
+    x, y = o.point_decode(S, enc.tobytes())
+    return np.frombuffer(o.point_encode(S, ((-x) % S.q, (-y) % S.q)), np.uint8)
+
+
+def test_oracle_rlc_lone_small_order_defect_is_caught(synth):
+    """Weights are 1 (mod 8): a single proof whose Ok (or R) is shifted by a point of order 2 fails the batch
+    equation for every seed, although an even weight would have annihilated the defect."""
+    a = _proofs(synth, 8, 4321, b"t")
+    for field in ("ok", "r"):
+        b = {k: v.copy() for k, v in a.items()}
+        b[field][3] = _shift_by_order2(a[field][3])
+        assert co.pedersen_verify_batch(*_args(b), b"t", threads=1)[3] == 1
+        for sd in (SEED, b"\x07" * 32, os.urandom(32), os.urandom(32)):
+            assert co.pedersen_rlc_check(*_args(b), seed=sd, ad=b"t")[1] == 1
+
+
+@pytest.mark.gpu
+def test_gpu_rlc_lone_small_order_defect_is_caught(ctx, synth):
+    a = _proofs(synth, 200, 4321, b"t")
+    b = {k: v.copy() for k, v in a.items()}
+    b["ok"][77] = _shift_by_order2(a["ok"][77])
+    for _ in range(4):
+        st, ok = ctx.pedersen_verify_batch_rlc(*_args(b), ad=b"t")          # fresh random seeds
+        assert not ok and st[77] == 1 and st.sum() == 1
