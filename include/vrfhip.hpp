@@ -18,7 +18,8 @@
 //   pedersen::Verifier::verify(input, output, ad, &p)      pedersen::verify(ctx, input, output, ad, p) -> Result
 //   Error::{VerificationFailure, InvalidData}              enum class Error; Result = std::optional<Error> (nullopt = Ok(()))
 // Batch forms (what the GPU is for) take std::vector of the same types: ietf::verify_batch, ietf::prove_batch,
-// pedersen::verify_batch (single-MSM random-linear-combination path with automatic per-proof fallback).
+// pedersen::verify_batch (single-MSM random-linear-combination path with automatic per-proof fallback),
+// KeySet + ietf::verify_batch_keyed (public keys with HBM-resident fixed-base tables).
 #ifndef VRFHIP_HPP
 #define VRFHIP_HPP
 
@@ -83,6 +84,30 @@ class Context {
 };
 
 template <class S> struct Public { Bytes32 encoded; };     // `Public`: compressed point (ArkworksCodec)
+
+// A set of `Public` keys whose validated points and fixed-base tables stay resident in HBM (881 KB per key):
+// the verifier of a validator set builds it once and names keys by index afterwards (ietf::verify_batch_keyed).
+template <class S>
+class KeySet {
+ public:
+  KeySet(const Context<S>& ctx, const std::vector<Public<S>>& keys) : valid_(keys.size()) {
+    Bytes flat(keys.size() * 32), st(keys.size());
+    for (size_t i = 0; i < keys.size(); ++i) std::memcpy(flat.data() + 32 * i, keys[i].encoded.data(), 32);
+    check(vrfhip_keyset_create(ctx.handle(), keys.size(), flat.data(), st.data(), &h_), "vrfhip_keyset_create");
+    for (size_t i = 0; i < keys.size(); ++i) valid_[i] = st[i] == VRFHIP_ST_OK;
+  }
+  ~KeySet() { vrfhip_keyset_destroy(h_); }
+  KeySet(const KeySet&) = delete;
+  KeySet& operator=(const KeySet&) = delete;
+  const vrfhip_keyset* handle() const { return h_; }
+  size_t size() const { return valid_.size(); }
+  bool valid(size_t i) const { return valid_[i]; }          // key i is a point of the prime-order subgroup
+  size_t bytes() const { return vrfhip_keyset_bytes(h_); }
+
+ private:
+  vrfhip_keyset* h_ = nullptr;
+  std::vector<bool> valid_;
+};
 template <class S> struct Output;
 
 template <class S>
@@ -176,6 +201,24 @@ std::vector<Result> verify_batch(const Context<S>& ctx, const std::vector<Item<S
   Bytes st(n);
   check(vrfhip_ietf_verify_batch(ctx.handle(), n, pk.data(), h.data(), g.data(), c.data(), s.data(), detail::ad_ptr(ad),
                                  nullptr, (uint32_t)ad.size(), st.data()), "vrfhip_ietf_verify_batch");
+  std::vector<Result> r(n);
+  for (size_t i = 0; i < n; ++i) r[i] = result_of(st[i]);
+  return r;
+}
+// n x verify against keys of a KeySet: key_index[i] names the key of items[i] (items[i].pub is not read)
+template <class S>
+std::vector<Result> verify_batch_keyed(const Context<S>& ctx, const KeySet<S>& keys, const std::vector<uint32_t>& key_index,
+                                       const std::vector<Item<S>>& items, const Bytes& ad) {
+  const size_t n = items.size();
+  if (key_index.size() != n) throw std::invalid_argument("verify_batch_keyed: ragged batch");
+  Bytes h = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.input.encoded; });
+  Bytes g = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.output.encoded; });
+  Bytes c = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.c; });
+  Bytes s = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.s; });
+  Bytes st(n);
+  check(vrfhip_ietf_verify_batch_keyed(ctx.handle(), keys.handle(), n, key_index.data(), h.data(), g.data(), c.data(),
+                                       s.data(), detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), st.data()),
+        "vrfhip_ietf_verify_batch_keyed");
   std::vector<Result> r(n);
   for (size_t i = 0; i < n; ++i) r[i] = result_of(st[i]);
   return r;

@@ -90,6 +90,29 @@ int main(int argc, char** argv) {
     else if (i == 1999) CHECK(res[i] == Error::InvalidData);
     else CHECK(!res[i].has_value());
   }
+  // keyed verification: 16 validators, every proof names its key by index; same verdicts as the plain call
+  {
+    const size_t nk = 16, m = 640;
+    std::vector<Secret<S>> vals(sks.begin(), sks.begin() + nk);
+    std::vector<Public<S>> pubs;
+    for (const auto& v : vals) pubs.push_back(v.public_key());
+    pubs[5].encoded.fill(0); pubs[5].encoded[0] = 3;                       // y = 3: not a curve point
+    KeySet<S> keys(ctx, pubs);
+    CHECK(keys.size() == nk && !keys.valid(5) && keys.valid(4) && keys.bytes() >= nk * 881280);
+    std::vector<Secret<S>> who;
+    std::vector<Bytes> what;
+    std::vector<uint32_t> idx;
+    for (size_t i = 0; i < m; ++i) { idx.push_back((uint32_t)((i * 7) % nk)); who.push_back(vals[idx[i]]); what.push_back(msgs[i]); }
+    auto kitems = ietf::prove_batch(ctx, who, what, unhex(ad));
+    kitems[100].proof.s[2] ^= 1;
+    idx[200] = 99;                                                         // no such key
+    const auto kres = ietf::verify_batch_keyed(ctx, keys, idx, kitems, unhex(ad));
+    for (size_t i = 0; i < m; ++i) {
+      if (i == 200 || idx[i] == 5) CHECK(kres[i] == Error::InvalidData);
+      else if (i == 100) CHECK(kres[i] == Error::VerificationFailure);
+      else CHECK(!kres[i].has_value());
+    }
+  }
   // batched Pedersen verification: fast path on a valid batch, per-proof verdicts on a tampered one
   std::vector<pedersen::Item<S>> pitems;
   for (size_t i = 0; i < 300; ++i) {
