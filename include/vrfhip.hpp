@@ -17,6 +17,8 @@
 //   pedersen::Prover::prove(..) -> (Proof, blinding)       pedersen::prove(..) -> std::pair<Proof, Scalar>
 //   pedersen::Verifier::verify(input, output, ad, &p)      pedersen::verify(ctx, input, output, ad, p) -> Result
 //   Error::{VerificationFailure, InvalidData}              enum class Error; Result = std::optional<Error> (nullopt = Ok(()))
+// Several GPUs from one process: ietf::verify_batch_sharded over one Context per device (contiguous slices, one
+// host thread per context, no exchange) -- the single-process form of `bench.py --gpus N`.
 // Batch forms (what the GPU is for) take std::vector of the same types: ietf::verify_batch, ietf::prove_batch,
 // pedersen::verify_batch (single-MSM random-linear-combination path with automatic per-proof fallback),
 // KeySet + ietf::verify_batch_keyed (public keys with HBM-resident fixed-base tables).
@@ -30,6 +32,7 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -203,6 +206,29 @@ std::vector<Result> verify_batch(const Context<S>& ctx, const std::vector<Item<S
                                  nullptr, (uint32_t)ad.size(), st.data()), "vrfhip_ietf_verify_batch");
   std::vector<Result> r(n);
   for (size_t i = 0; i < n; ++i) r[i] = result_of(st[i]);
+  return r;
+}
+// n x verify over several contexts (one per GPU): context g verifies items [g*n/G, (g+1)*n/G) on its own host
+// thread; items are independent, so the only merge is the concatenation of the results.
+template <class S>
+std::vector<Result> verify_batch_sharded(const std::vector<const Context<S>*>& ctxs, const std::vector<Item<S>>& items,
+                                         const Bytes& ad) {
+  const size_t n = items.size(), G = ctxs.size();
+  if (G == 0) throw std::invalid_argument("verify_batch_sharded: no context");
+  std::vector<Result> r(n);
+  std::vector<std::exception_ptr> err(G);
+  std::vector<std::thread> th;
+  for (size_t g = 0; g < G; ++g)
+    th.emplace_back([&, g] {
+      try {
+        const size_t lo = n * g / G, hi = n * (g + 1) / G;
+        std::vector<Item<S>> part(items.begin() + lo, items.begin() + hi);
+        std::vector<Result> pr = verify_batch(*ctxs[g], part, ad);
+        for (size_t i = lo; i < hi; ++i) r[i] = pr[i - lo];
+      } catch (...) { err[g] = std::current_exception(); }
+    });
+  for (auto& t : th) t.join();
+  for (auto& e : err) if (e) std::rethrow_exception(e);
   return r;
 }
 // n x verify against keys of a KeySet: key_index[i] names the key of items[i] (items[i].pub is not read)

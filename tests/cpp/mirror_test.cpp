@@ -90,6 +90,17 @@ int main(int argc, char** argv) {
     else if (i == 1999) CHECK(res[i] == Error::InvalidData);
     else CHECK(!res[i].has_value());
   }
+  // several contexts from one process (one per GPU; here three on the same device): slices tile the batch
+  {
+    Context<S> c1(0), c2(0);
+    const std::vector<const Context<S>*> set = {&ctx, &c1, &c2};
+    const auto sres = ietf::verify_batch_sharded(set, items, unhex(ad));
+    CHECK(sres.size() == n);
+    for (size_t i = 0; i < n; ++i) CHECK(sres[i] == res[i]);
+    const std::vector<ietf::Item<S>> few(items.begin(), items.begin() + 2);          // fewer items than contexts
+    const auto fres = ietf::verify_batch_sharded(set, few, unhex(ad));
+    CHECK(fres.size() == 2 && !fres[0].has_value() && !fres[1].has_value());
+  }
   // keyed verification: 16 validators, every proof names its key by index; same verdicts as the plain call
   {
     const size_t nk = 16, m = 640;
