@@ -59,6 +59,7 @@ struct vrfhip_ctx {
   void* d_msm_ws = nullptr;
   size_t msm_ws_bytes = 0;
   unsigned long long* d_queue = nullptr;   // work-queue counter of k_tai_find
+  uint32_t* d_pair_prep = nullptr;         // Miller-loop lines of shared G2 points (pairing check, SRS case)
   int cus = 256;
   // optional per-stage timing (hipEvents on the launch stream), see vrfhip_ctx_profile
   bool prof = false;
@@ -235,6 +236,8 @@ int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out) 
   HIP_TRY_C(hipMalloc(&ctx->d_g_comb, comb_bytes));
   HIP_TRY_C(hipMalloc(&ctx->d_b_comb, comb_bytes));
   HIP_TRY_C(hipMalloc(&ctx->d_queue, 256));
+  HIP_TRY_C(hipMalloc(&ctx->d_pair_prep, pairing_prep_bytes()));
+  HIP_TRY_C(hipMemset(ctx->d_pair_prep, 0, pairing_prep_bytes()));
   HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_p, vrfk_tables::SQRT_P, sqrt_p_bytes, hipMemcpyHostToDevice,
                            ctx->stream));
   HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_lut, vrfk_tables::SQRT_LUT, lut_bytes, hipMemcpyHostToDevice,
@@ -272,6 +275,7 @@ void vrfhip_ctx_destroy(vrfhip_ctx* ctx) {
     if (ctx->d_g_comb) (void)hipFree(ctx->d_g_comb);
     if (ctx->d_b_comb) (void)hipFree(ctx->d_b_comb);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx->d_pair_prep) (void)hipFree(ctx->d_pair_prep);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   }
   delete ctx;
@@ -998,7 +1002,8 @@ int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
   if (!d_g1 || !d_g2 || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  launch_pairing_check2(n, d_g1, d_g2, g2_shared ? 0 : 384, d_status, static_cast<hipStream_t>(stream));
+  launch_pairing_check2(n, d_g1, d_g2, g2_shared ? 0 : 384, d_status, static_cast<hipStream_t>(stream),
+                        g2_shared ? ctx->d_pair_prep : nullptr);
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
 }

@@ -733,4 +733,43 @@ VRF_HD_NOINLINE uint32_t pairing_check2_item(const uint32_t* g1, const uint32_t*
   return one ? PST_OK : PST_FAIL;
 }
 
+// ---- shared G2 points (the SRS case of a KZG check: every item pairs against the same Q0, Q1) ----
+// The G2 walk of the Miller loop does not depend on the G1 points: its 68 lines per pair are computed ONCE
+// (pairing_prepare_g2_pair, one lane per pair) and every item only scales them by its own (x_P, y_P).
+constexpr int G2_LINES = 63 + 5;                       // doublings for bits 62..0, additions at the 5 set bits
+constexpr int G2_LINE_WORDS = 3 * 2 * NLB;             // c0, c1, c4 as Fp2 limbs
+constexpr int G2_PREP_WORDS = 2 * G2_LINES * G2_LINE_WORDS + 4;   // two pairs + flags (ok0, inf0, ok1, inf1)
+
+VRF_HD void fp2_store_words(uint32_t* dst, const Fp2& x) {
+  for (int i = 0; i < NLB; ++i) { dst[i] = (uint32_t)x.a.v[i]; dst[NLB + i] = (uint32_t)x.b.v[i]; }
+}
+VRF_HD Fp2 fp2_load_words(const uint32_t* src) {
+  Fp2 x;
+  for (int i = 0; i < NLB; ++i) { x.a.v[i] = (int32_t)src[i]; x.b.v[i] = (int32_t)src[NLB + i]; }
+  return x;
+}
+// lines of pair `pi` (g2: 2 x 48 words) in Miller-loop order, then its flags
+VRF_HD_NOINLINE void pairing_prepare_g2_pair(const uint32_t* g2, uint32_t* prep, int pi) {
+  G2Aff Q;
+  bool inf;
+  const bool ok = g2_load(Q, inf, g2 + 48 * pi);
+  G2Proj T;
+  T.X = Q.x; T.Y = Q.y; T.Z = fp2_one();
+  uint32_t* dst = prep + (size_t)pi * G2_LINES * G2_LINE_WORDS;
+  for (int bit = 62; bit >= 0; --bit) {
+    Fp2 c0, c1, c4;
+    g2_double_step(&T, &c0, &c1, &c4);
+    fp2_store_words(dst, c0); fp2_store_words(dst + 2 * NLB, c1); fp2_store_words(dst + 4 * NLB, c4);
+    dst += G2_LINE_WORDS;
+    if ((X_ABS >> bit) & 1) {
+      g2_add_step(&T, &Q, &c0, &c1, &c4);
+      fp2_store_words(dst, c0); fp2_store_words(dst + 2 * NLB, c1); fp2_store_words(dst + 4 * NLB, c4);
+      dst += G2_LINE_WORDS;
+    }
+  }
+  uint32_t* flags = prep + (size_t)2 * G2_LINES * G2_LINE_WORDS;
+  flags[2 * pi] = ok ? 1u : 0u;
+  flags[2 * pi + 1] = inf ? 1u : 0u;
+}
+
 }  // namespace bls

@@ -411,4 +411,49 @@ __device__ __attribute__((noinline)) uint32_t pairing_check2_quad(const uint32_t
   return one ? PST_OK : PST_FAIL;
 }
 
+// One item per quad against prepared G2 lines (pairing_prepare_g2_pair).  g1: 2 x 24 words.  An iteration costs
+// the squaring, the two sparse products and one Fp2-by-Fp product per lane (lane 2i scales c1 of pair i by
+// x_P, lane 2i+1 scales c4 by y_P) instead of also the five to seven rounds of a G2 step.
+__device__ __attribute__((noinline)) uint32_t pairing_check2_quad_prepared(const uint32_t* g1, const uint32_t* prep, int q) {
+  const int pi = q >> 1;
+  G1Aff P;
+  bool i1;
+  const bool ok1 = g1_load(P, i1, g1 + 24 * pi);
+  const uint32_t* flags = prep + (size_t)2 * G2_LINES * G2_LINE_WORDS;
+  const bool ok = ok1 && flags[2 * pi] != 0;
+  const int my_skip = (i1 || flags[2 * pi + 1] != 0) ? 1 : 0, my_ok = ok ? 1 : 0;
+  const int skip0 = qperm_i32<QP_BC0>(my_skip), skip1 = qperm_i32<QP_BC2>(my_skip);
+  const bool all_ok = qperm_i32<QP_BC0>(my_ok) != 0 && qperm_i32<QP_BC2>(my_ok) != 0;
+  const FpS scale = (q & 1) ? P.y : P.x;
+  const uint32_t* my_line = prep + (size_t)pi * G2_LINES * G2_LINE_WORDS + ((q & 1) ? 4 * NLB : 2 * NLB);
+  const uint32_t* line0 = prep;
+  Q12 f = q12_one(q);
+#pragma unroll 1
+  for (int bit = 62; bit >= 0; --bit) {
+    f = fp12_sqr_q(f, q);
+    const int nsteps = ((X_ABS >> bit) & 1) ? 2 : 1;
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+      const Fp2 scaled = fp2_fit(fp2_mul_fp(fp2_load_words(my_line), scale));
+#pragma unroll 1
+      for (int i = 0; i < 2; ++i) {
+        const Fp2 l0 = fp2_load_words(line0 + (size_t)i * G2_LINES * G2_LINE_WORDS);
+        const Fp2 l1 = fp2_sel(i == 0, qperm<QP_BC0>(scaled), qperm<QP_BC2>(scaled));
+        const Fp2 l4 = fp2_sel(i == 0, qperm<QP_BC1>(scaled), qperm<0xff>(scaled));
+        const bool skip = (i == 0 ? skip0 : skip1) != 0;
+        if (!skip) f = fp12_mul_by_014_q(f, l0, l1, l4, q);
+      }
+      my_line += G2_LINE_WORDS;
+      line0 += G2_LINE_WORDS;
+    }
+  }
+  f = fp12_conj_q(f);
+  const Q12 e = final_exponentiation_q(f, q);
+  Fp12 full;
+  q12_gather(&full, e);
+  const bool one = fp12_is_one(&full);
+  if (!all_ok) return PST_INVALID;
+  return one ? PST_OK : PST_FAIL;
+}
+
 }  // namespace bls

@@ -24,15 +24,44 @@ __global__ void __launch_bounds__(64) k_pairing_check2(size_t n, const uint8_t* 
   status[i] = (uint8_t)bls::pairing_check2_item(w1, w2);
 }
 
+// shared G2 points: the 2 x 68 Miller-loop lines, one lane per pair (the one-lane tower: ~3 ms of latency, so the
+// buffer also keeps the 96 words of the points its lines belong to and a valid word -- a verifier's SRS does
+// not change between calls, and a call with the same points finds the lines in place)
+__global__ void __launch_bounds__(64) k_pairing_prepare_g2(const uint8_t* g2, uint32_t* prep) {
+  if (blockIdx.x != 0) return;
+  const uint32_t* p2 = reinterpret_cast<const uint32_t*>(g2);
+  uint32_t* key = prep + bls::G2_PREP_WORDS;
+  const int t = (int)threadIdx.x;
+  const bool same = key[96] == 1u && key[t] == p2[t] && (t >= 32 || key[64 + t] == p2[64 + t]);
+  if (__all(same ? 1 : 0)) return;
+  if (t < 2) {
+    uint32_t w2[96];
+    for (int k = 0; k < 96; ++k) w2[k] = p2[k];
+    bls::pairing_prepare_g2_pair(w2, prep, t);
+  }
+  __threadfence();
+  key[t] = p2[t];
+  if (t < 32) key[64 + t] = p2[64 + t];
+  if (t == 0) key[96] = 1u;
+}
+
+size_t pairing_prep_bytes() { return (size_t)(bls::G2_PREP_WORDS + 96 + 1) * sizeof(uint32_t); }
+
 void launch_pairing_check2_quad(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status,
                                 hipStream_t st);
+void launch_pairing_check2_quad_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st);
 
 void launch_pairing_check2(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status,
-                           hipStream_t st) {
+                           hipStream_t st, uint32_t* prep) {
   if (!n) return;
   const char* mode = getenv("VRFHIP_PAIRING");
   if (mode && !strcmp(mode, "lane")) {
     hipLaunchKernelGGL(k_pairing_check2, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, g1, g2, g2_stride, status);
+    return;
+  }
+  if (g2_stride == 0 && prep && !(mode && !strcmp(mode, "noprep"))) {
+    hipLaunchKernelGGL(k_pairing_prepare_g2, dim3(1), dim3(64), 0, st, g2, prep);
+    launch_pairing_check2_quad_prepared(n, g1, prep, status, st);
     return;
   }
   launch_pairing_check2_quad(n, g1, g2, g2_stride, status, st);

@@ -72,6 +72,23 @@ __global__ void __launch_bounds__(PAIR_BLOCK) k_pairing_quad_selftest(size_t n, 
   if (q == 0) status[item] = (uint8_t)bad;
 }
 
+__global__ void __launch_bounds__(PAIR_BLOCK) k_pairing_check2_quad_prepared(size_t n, const uint8_t* g1, const uint32_t* prep,
+                                                                              uint8_t* status) {
+  const size_t lane = (size_t)blockIdx.x * PAIR_BLOCK + threadIdx.x;
+  const size_t item = lane >> 2;
+  const int q = (int)(lane & 3);
+  if (item >= n) return;
+  const uint32_t st = bls::pairing_check2_quad_prepared(reinterpret_cast<const uint32_t*>(g1 + item * 192), prep, q);
+  if (q == 0) status[item] = (uint8_t)st;
+}
+
+void launch_pairing_check2_quad_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st) {
+  if (!n) return;
+  const size_t lanes = 4 * n;
+  hipLaunchKernelGGL(k_pairing_check2_quad_prepared, dim3((unsigned)((lanes + PAIR_BLOCK - 1) / PAIR_BLOCK)), dim3(PAIR_BLOCK),
+                     0, st, n, g1, prep, status);
+}
+
 void launch_pairing_check2_quad(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status,
                                 hipStream_t st) {
   if (!n) return;

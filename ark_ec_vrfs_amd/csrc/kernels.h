@@ -104,8 +104,11 @@ void launch_point_validate(int suite, size_t n, const uint8_t* pts, uint8_t* xy,
 // MSM: ws must hold msm_workspace_bytes(n, groups) bytes; groups = msm_groups(n, n, #CUs)  (msm.cuh)
 void launch_msm(int suite, size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t* out_enc,
                 uint8_t* out_xy, uint8_t* status, void* ws, int groups, hipStream_t st);
+// g2_stride == 0: every item uses the same two G2 points; prep (pairing_prep_bytes() of device memory, nullable)
+// then receives their Miller-loop lines, computed once
+size_t pairing_prep_bytes();
 void launch_pairing_check2(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status,
-                           hipStream_t st);
+                           hipStream_t st, uint32_t* prep = nullptr);
 void launch_pairing_quad_selftest(size_t n, const uint8_t* in, uint8_t* status, hipStream_t st);
 void launch_fq_mul(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* r, hipStream_t st);
 

@@ -288,6 +288,17 @@ def secondary(ctx, lib, dev, sk, msg, pk, hh, gamma, c, s):
         t = _time(lambda: ctx.pairing_check_batch_dev(d1, d2, pstat))
         assert int(pstat.sum()) == 0
         res["pairing_check_2^14"] = {"checks_per_s": k / t, "ms": t * 1e3, "bytes_per_item": 577}
+        # the same size against one shared G2 pair (a KZG verifier's SRS): lines prepared once per context
+        from test_bls_pairing import enc_g1, enc_g2, b as bo
+        cc = 0x1234567FEDCBA987
+        sh = np.frombuffer(enc_g2(bo.g2_mul(7, bo.G2)) + enc_g2(bo.g2_mul(7 * cc % bo.R, bo.G2)), np.uint8).copy()
+        rows = [enc_g1(bo.g1_mul(a * cc % bo.R, bo.G1)) + enc_g1(bo.g1_neg(bo.g1_mul(a, bo.G1))) for a in range(1, 9)]
+        s1 = np.frombuffer(b"".join(rows), np.uint8).reshape(-1, 192)
+        d1 = torch.from_numpy(np.tile(s1, (k // 8, 1)).copy()).to(dev)
+        dsh = torch.from_numpy(sh).to(dev)
+        t = _time(lambda: ctx.pairing_check_batch_dev(d1, dsh, pstat, g2_shared=True))
+        assert int(pstat.sum()) == 0
+        res["pairing_check_shared_g2_2^14"] = {"checks_per_s": k / t, "ms": t * 1e3, "bytes_per_item": 193}
     except Exception as e:                                      # the headline number must not depend on this leg
         res["pairing_check_2^14"] = {"error": repr(e)}
     return res

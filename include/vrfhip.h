@@ -272,7 +272,9 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
  * BLS12-381, per item: the KZG equation that ends `ring::Verifier::verify` (src/lib.rs:14).
  * g1: n x 2 x 96 B, each point x || y as 48-byte little-endian canonical integers;
  * g2: n x 2 x 192 B, each point x.c0 || x.c1 || y.c0 || y.c1 (48-byte LE each); if g2_shared
- * is non-zero, g2 holds a single pair of points (384 B) used by every item (the SRS case).
+ * is non-zero, g2 holds a single pair of points (384 B) used by every item (the SRS case):
+ * their Miller-loop lines are computed once (arkworks' `G2Prepared`) and stay in the context, so
+ * later calls with the same pair reuse them.
  * An all-zero encoding is the point at infinity.  status[i]: 0 = product is one,
  * 1 = VerificationFailure, 2 = InvalidData (coordinate >= p or point off its curve).
  * Subgroup membership of the inputs is the caller's precondition, as for arkworks' prepared

@@ -155,6 +155,51 @@ def test_gpu_pairing_check_matches_oracle(ctx):
 
 
 @pytest.mark.gpu
+def test_gpu_pairing_shared_g2_prepared_lines(ctx):
+    """Shared G2 points (g2_shared=True) go through lines prepared once; the verdicts must equal the per-item
+    path fed the same G2 points in every row, on valid, wrong, off-curve and infinity items, and with shared
+    G2 points that are invalid or at infinity."""
+    c = 0x1234567FEDCBA987
+    Q0, Q1 = b.g2_mul(7, b.G2), b.g2_mul(7 * c % b.R, b.G2)
+    rows, want = [], []
+    for a in range(1, 41):
+        good = a % 5 != 0
+        p0 = b.g1_mul(a * c % b.R, b.G1)
+        p1 = b.g1_neg(b.g1_mul(a if good else a + 1, b.G1))
+        rows.append(enc_g1(p0) + enc_g1(p1)); want.append(0 if good else 1)
+    g1 = np.frombuffer(b"".join(rows), np.uint8).reshape(-1, 192).copy()
+    g1[7, 3] ^= 1; want[7] = 2                                  # off the curve
+    g1[11] = 0; want[11] = 0                                    # both at infinity
+    g1[13, 96:] = 0; want[13] = 1                               # second point at infinity: e(P0, Q0) != 1
+    sh = np.frombuffer(enc_g2(Q0) + enc_g2(Q1), np.uint8).copy()
+    per_item = np.tile(sh, (g1.shape[0], 1))
+    got_shared = ctx.pairing_check_batch(g1, sh, g2_shared=True)
+    got_items = ctx.pairing_check_batch(g1, per_item)
+    assert list(got_items) == want
+    assert list(got_shared) == want
+    # a batch that does not fill its last wave / workgroup
+    assert list(ctx.pairing_check_batch(g1[:3], sh, g2_shared=True)) == want[:3]
+    # shared points: Q1 at infinity (only e(P0, Q0) counts), Q0 off its curve (every item invalid)
+    sh_inf = sh.copy(); sh_inf[192:] = 0
+    a = ctx.pairing_check_batch(g1, sh_inf, g2_shared=True)
+    bb = ctx.pairing_check_batch(g1, np.tile(sh_inf, (g1.shape[0], 1)))
+    assert list(a) == list(bb) and a[11] == 0 and a[0] == 1 and a[7] == 2
+    sh_bad = sh.copy(); sh_bad[5] ^= 1
+    a = ctx.pairing_check_batch(g1, sh_bad, g2_shared=True)
+    assert (a == 2).all()
+    # the context keeps the lines of the last shared pair: a changed pair replaces them, an unchanged one reuses them
+    for _ in range(2):
+        assert list(ctx.pairing_check_batch(g1, sh, g2_shared=True)) == want
+    # the verdicts also agree with the path that does not prepare lines
+    import os
+    os.environ["VRFHIP_PAIRING"] = "noprep"
+    try:
+        assert list(ctx.pairing_check_batch(g1, sh, g2_shared=True)) == want
+    finally:
+        del os.environ["VRFHIP_PAIRING"]
+
+
+@pytest.mark.gpu
 def test_gpu_pairing_batch_2_14_tiled(ctx):
     """BASELINE.json config 5 size: 2^14 checks (64 distinct oracle-made items tiled), every 97th corrupted."""
     import torch
