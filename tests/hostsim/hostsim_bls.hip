@@ -1,6 +1,7 @@
 // tests/hostsim -- TEST TOOLING ONLY: host build of the BLS12-381 pairing headers.
 #include "../../ark_ec_vrfs_amd/csrc/bls12.cuh"
 #include <cstring>
+#include <vector>
 using namespace bls;
 static FpS inw(const uint8_t* b) { uint32_t w[12]; memcpy(w, b, 48); FpS r; fp_from_words(r, w); return r; }
 template <class A> static void outw(uint8_t* b, const A& a) { uint32_t w[12]; fp_to_words(w, a); memcpy(b, w, 48); }
@@ -48,6 +49,44 @@ int hb_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* ml, uint8_t* fe) {
   final_exponentiation(&e, &f);
   out12(fe, &e);
   return ok;
+}
+// the shared-G2 route: lines from pairing_prepare_g2_pair, scaled per item the way the quad kernel does
+// (c1 * x_P, c4 * y_P), absorbed in Miller-loop order
+uint32_t hb_pairing_check2_prepared(const uint8_t* g1x2, const uint8_t* g2x2) {
+  uint32_t w1[48], w2[96]; memcpy(w1, g1x2, 192); memcpy(w2, g2x2, 384);
+  std::vector<uint32_t> prep(G2_PREP_WORDS);
+  pairing_prepare_g2_pair(w2, prep.data(), 0);
+  pairing_prepare_g2_pair(w2, prep.data(), 1);
+  const uint32_t* flags = prep.data() + (size_t)2 * G2_LINES * G2_LINE_WORDS;
+  G1Aff P[2];
+  bool skip[2], ok = true;
+  for (int i = 0; i < 2; ++i) {
+    bool i1;
+    ok = g1_load(P[i], i1, w1 + 24 * i) && ok;
+    ok = ok && flags[2 * i] != 0;
+    skip[i] = i1 || flags[2 * i + 1] != 0;
+  }
+  Fp12 f, t;
+  fp12_one(&f);
+  int k = 0;
+  for (int bit = 62; bit >= 0; --bit) {
+    fp12_sqr(&t, &f); f = t;
+    const int nsteps = ((X_ABS >> bit) & 1) ? 2 : 1;
+    for (int step = 0; step < nsteps; ++step, ++k)
+      for (int i = 0; i < 2; ++i) {
+        const uint32_t* L = prep.data() + ((size_t)i * G2_LINES + k) * G2_LINE_WORDS;
+        Fp2 c0 = fp2_load_words(L);
+        Fp2 c1 = fp2_fit(fp2_mul_fp(fp2_load_words(L + 2 * NLB), P[i].x));
+        Fp2 c4 = fp2_fit(fp2_mul_fp(fp2_load_words(L + 4 * NLB), P[i].y));
+        if (!skip[i]) fp12_mul_by_014(&f, &c0, &c1, &c4);
+      }
+  }
+  if (k != G2_LINES) return 99;
+  fp12_conj(&t, &f); f = t;
+  Fp12 e;
+  final_exponentiation(&e, &f);
+  if (!ok) return PST_INVALID;
+  return fp12_is_one(&e) ? PST_OK : PST_FAIL;
 }
 uint32_t hb_pairing_check2(const uint8_t* g1x2, const uint8_t* g2x2) {
   uint32_t w1[48], w2[96]; memcpy(w1, g1x2, 192); memcpy(w2, g2x2, 384);

@@ -126,6 +126,27 @@ def test_hostsim_pairing_values_and_checks(hb):
     assert hb.hb_pairing_check2(bytes(192), enc_g2(b.G2) + enc_g2(b.G2)) == 0          # infinity pairs with anything
 
 
+def test_hostsim_pairing_prepared_lines(hb):
+    """The shared-G2 route (lines of pairing_prepare_g2_pair, scaled per item) gives the verdicts of the plain
+    check: valid, wrong, invalid G1 / G2, points at infinity on either side."""
+    hb.hb_pairing_check2_prepared.restype = ctypes.c_uint32
+    cases = []
+    for (p0, q0), (p1, q1) in kzg_like_items(2, seed=6):
+        g2 = enc_g2(q0) + enc_g2(q1)
+        cases += [(enc_g1(p0) + enc_g1(p1), g2), (enc_g1(p0) + enc_g1(b.g1_add(p1, b.G1)), g2),
+                  (enc_g1(p0) + bytes(96), g2), (bytes(192), g2), (enc_g1(p0) + enc_g1(p1), enc_g2(q0) + bytes(192)),
+                  (enc_g1(p0) + enc_g1(p1), bytes(384))]
+        bad1 = bytearray(enc_g1(p0) + enc_g1(p1)); bad1[100] ^= 1
+        bad2 = bytearray(g2); bad2[200] ^= 1
+        cases += [(bytes(bad1), g2), (enc_g1(p0) + enc_g1(p1), bytes(bad2))]
+    seen = set()
+    for g1, g2 in cases:
+        want = hb.hb_pairing_check2(g1, g2)
+        assert hb.hb_pairing_check2_prepared(g1, g2) == want
+        seen.add(want)
+    assert seen == {0, 1, 2}
+
+
 @pytest.mark.gpu
 def test_gpu_pairing_check_matches_oracle(ctx):
     items = kzg_like_items(6, seed=9)
