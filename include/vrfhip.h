@@ -19,6 +19,8 @@
  *    output guarantee).  Per-item outcomes go to a status byte array mirroring `Error`
  *    (src/lib.rs:15): 0 = Ok, 1 = VerificationFailure, 2 = InvalidData.
  *  - Thread safety: a context may be shared; calls on one context serialise internally.
+ *    A context owns ONE workspace: `*_dev` calls on the same context must all be enqueued on the
+ *    same stream (or be ordered by the caller's events); for concurrent streams use one context each.
  *  - Precondition (as for the reference's `AffinePoint` values, which arkworks validates on
  *    deserialisation): input points lie in the prime-order subgroup.  Undecodable encodings
  *    and non-canonical scalars are reported as InvalidData; subgroup membership is checked by
