@@ -42,6 +42,24 @@ __global__ void __launch_bounds__(BLOCK) k_ped_verify_straus(PedersenVerifyArgs 
                                              a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), c, s, sb);
 }
 
+// small batches: both halves in one launch (blockIdx.y picks the half), see k_verify_straus_both
+template <class S>
+__global__ void __launch_bounds__(BLOCK) k_ped_verify_straus_both(PedersenVerifyArgs a) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  uint32_t c[8], s[8], sb[8];
+  load32(s, a.s, i); load32(sb, a.sb, i);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c[j] = a.ws.aux[i * AUX_WORDS + j];
+  if (!fr_is_canonical<S>(s) || !fr_is_canonical<S>(sb)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0; sb[j] = 0; }
+  }
+  const uint32_t* tabs = a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS);
+  if (blockIdx.y == 0) pedersen_verify_straus_item<S, 1>(a.ws.pts + i * PROVE_PTS_WORDS + UV_WORDS, a.T, tabs, c, s, sb);
+  else pedersen_verify_straus_item<S, 0>(a.ws.pts + i * PROVE_PTS_WORDS, a.T, tabs, c, s, sb);
+}
+
 template <class S>
 __global__ void __launch_bounds__(BLOCK) k_ped_verify_finish(PedersenVerifyArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -57,6 +75,13 @@ static void launch_ped_t(const PedersenVerifyArgs& a, hipStream_t st, hipEvent_t
   if (ev) (void)hipEventRecord(ev[0], st);
   VRF_LAUNCH_MINW(k_ped_verify_decode, S, a.n, grid_for(a.n), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
+  if (!ev && a.n <= STRAUS_FUSE_MAX_ITEMS) {
+    dim3 g2 = grid_for(a.n);
+    g2.y = 2;
+    hipLaunchKernelGGL(k_ped_verify_straus_both<S>, g2, dim3(BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_ped_verify_finish<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+    return;
+  }
   hipLaunchKernelGGL((k_ped_verify_straus<S, 0>), grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[2], st);
   hipLaunchKernelGGL((k_ped_verify_straus<S, 1>), grid_for(a.n), dim3(BLOCK), 0, st, a);

@@ -82,6 +82,23 @@ __global__ void __launch_bounds__(BLOCK) k_verify_straus(VerifyArgs a) {
                                     a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), c, s);
 }
 
+// stage 2 for small batches: both halves in one launch (blockIdx.y = 0: V, 1: U).  Below two waves per SIMD a
+// launch lasts as long as one lane's chain of 128 doublings, so the halves overlap instead of queueing.
+template <class S>
+__global__ void __launch_bounds__(BLOCK) k_verify_straus_both(VerifyArgs a) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  uint32_t c[8], s[8];
+  load32(c, a.c, i); load32(s, a.s, i);
+  if (!fr_is_canonical<S>(c) || !fr_is_canonical<S>(s)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { c[j] = 0; s[j] = 0; }
+  }
+  const uint32_t* tabs = a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS);
+  if (blockIdx.y == 0) verify_straus_item<S, 1>(a.ws.pts + i * PROVE_PTS_WORDS + UV_WORDS, a.T, tabs, c, s);
+  else verify_straus_item<S, 0>(a.ws.pts + i * PROVE_PTS_WORDS, a.T, tabs, c, s);
+}
+
 // stage 3: VERIFY_K proofs per lane share one inversion (2K Z coordinates).  Affine U, V; challenge
 // hash; compare.
 template <class S, int MINW>
@@ -101,6 +118,13 @@ static void launch_verify_t(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev)
   if (a.key_index) VRF_LAUNCH_MINW(k_verify_decode_keyed, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
   else if (a.affine_in) hipLaunchKernelGGL(k_verify_decode_affine<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
   else VRF_LAUNCH_MINW(k_verify_decode, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
+  if (!ev && !a.key_index && a.n <= STRAUS_FUSE_MAX_ITEMS) {
+    dim3 g2 = grid_for(a.n);
+    g2.y = 2;
+    hipLaunchKernelGGL(k_verify_straus_both<S>, g2, dim3(BLOCK), 0, st, a);
+    VRF_LAUNCH_MINW(k_verify_finish, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
+    return;
+  }
   if (ev) (void)hipEventRecord(ev[1], st);
   hipLaunchKernelGGL((k_verify_straus<S, 1>), grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[2], st);

@@ -125,6 +125,10 @@ VRF_HD void store32(uint8_t* base, size_t i, const uint32_t w[8]) {
 }
 
 constexpr int BLOCK = 128;
+// Verification batches up to this size run their two Straus halves (U and V) in one launch: below two waves
+// per SIMD a launch lasts as long as one lane's 128-doubling chain, so the halves overlap instead of queueing
+// (measured: 2^14 2.73 -> 1.98 ms, 2^16 4.35 -> 3.25 ms, neutral at 2^17, slightly worse beyond).
+constexpr size_t STRAUS_FUSE_MAX_ITEMS = (size_t)1 << 17;
 inline dim3 grid_for(size_t threads) { return dim3((unsigned)((threads + BLOCK - 1) / BLOCK)); }
 
 // The kernels that run K proofs per lane (or one heavy item per lane) need 256 VGPRs plus 18..98 AGPRs when
