@@ -495,3 +495,31 @@ def test_affine_input_verify_matches_compressed(ctx, synth):
     big = xy["output"].copy(); big[4, :32] = np.frombuffer(int(Q).to_bytes(32, "little"), np.uint8)   # x >= q
     got = ctx.ietf_verify_batch_affine(off, xy["input"], big, pr["c"], pr["s"], ad=b"aff")
     assert got[3] == 2 and got[4] == 2 and (np.delete(got, [3, 4]) == 0).all()
+
+
+def test_fused_and_separate_straus_launches_agree(ctx, synth):
+    """Batches up to 2^17 run the U and V halves in one launch; a profiled context keeps the separate launches
+    (the only path of larger batches).  Same statuses on a mixed batch, IETF and Pedersen."""
+    n = 3000
+    sk, msg = synth(n, start=123000)
+    p = ctx.ietf_prove_batch(sk, msgs=msg, ad=b"f")
+    s = p["s"].copy(); s[::7, 0] ^= 1
+    s[5] = np.frombuffer(int(R).to_bytes(32, "little"), np.uint8)
+    out = p["output"].copy(); out[11] = out[12]
+    fused = ctx.ietf_verify_batch(p["pk"], p["input"], out, p["c"], s, ad=b"f")
+    ctx.profile(True)
+    try:
+        separate = ctx.ietf_verify_batch(p["pk"], p["input"], out, p["c"], s, ad=b"f")
+    finally:
+        ctx.profile(False); ctx.profile_read()
+    assert (fused == separate).all()
+    assert fused[5] == 2 and fused[11] == 1 and fused[7] == 1 and fused[1] == 0 and int((fused == 0).sum()) > n // 2
+    q = ctx.pedersen_prove_batch(sk, msgs=msg, ad=b"f")
+    sb = q["sb"].copy(); sb[::5, 3] ^= 4
+    fused = ctx.pedersen_verify_batch(q["input"], q["output"], q["pk_com"], q["r"], q["ok"], q["s"], sb, ad=b"f")
+    ctx.profile(True)
+    try:
+        separate = ctx.pedersen_verify_batch(q["input"], q["output"], q["pk_com"], q["r"], q["ok"], q["s"], sb, ad=b"f")
+    finally:
+        ctx.profile(False); ctx.profile_read()
+    assert (fused == separate).all() and fused[5] == 1 and fused[1] == 0
