@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: batch 2^20 Bandersnatch IETF-ECVRF verification on MI355X.
+"""bench.py -- the BASELINE.json benchmark of libvrfhip on MI355X.
 
-A "step" is one pass of the verify hot path (vrfhip_ietf_verify_batch_dev: decode -> Straus ->
-finish) over one batch of 2^20 synthetic proofs per GPU that already sit in HBM (SURVEY.md
-section 8d: seed_i = u64_le(i), sk_i = from_seed, msg_i = SHA512("vrfhip-msg" || u64_le(i))[..32],
-ad = "").  The proofs themselves are produced by the GPU prove path before the timed region.
-N > 1: one process per GPU (torch.distributed / RCCL); every rank verifies its own 2^20 items
-(weak scaling), the only collective is the gather of the status bytes.
+Headline (`metric`, `value`): batch 2^20 Bandersnatch IETF-ECVRF verification from the wire format
+(BASELINE.json configs[2]).  A "step" is one pass of the verify hot path (vrfhip_ietf_verify_batch_dev: checked
+decode -> Straus -> finish) over one batch of 2^20 synthetic proofs per GPU that already sit in HBM (SURVEY.md
+section 8d: seed_i = u64_le(i), sk_i = from_seed, msg_i = SHA512("vrfhip-msg" || u64_le(i))[..32], ad = "").
+The proofs themselves are produced by the GPU prove path before the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the longest kernel (k_verify_straus<1>) against
-HBM as the contract asks -- the path is VALU-integer bound, so `valu` gives the meaningful
-ceiling: executed vector instructions per second against the measured v_mad_u64_u32 issue peak.
-`cpu_baseline` times the plain-C oracle (oracle/c, kind "port") on this box's host cores.
+`python bench.py --gpus N` starts its own ranks when it is not already running under torch.distributed.run (the
+parent touches no GPU: it only spawns `python -m torch.distributed.run ... bench.py` and relays its output).
+N > 1: one process per GPU over RCCL; every rank works on its own 2^20 items (weak scaling); the only
+collective is the gather of the result bytes.
+
+The JSON line also carries, under "configs", the other BASELINE.json configurations measured in the same run
+(IETF prove 2^16; Pedersen prove + verify on JubJub 2^20, per proof and batched; pairing checks 2^14, per item
+and against a shared G2 pair), each with its own `roofline` (dominant kernel, HIP events on the launch stream)
+and, at N = 1, a `cpu_baseline` leg (the plain-C / Python oracle under oracle/, kind "port", bounded sample).
+
+`roofline` prices the longest kernel against HBM as the contract asks; the path is VALU-integer bound, so
+`valu` gives the ceiling that matters: executed vector instructions per second (rocprofv3 --pmc, profiles/)
+against 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz.
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,9 +36,37 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LOG2_BATCH = 20
-BYTES_PER_VERIFY = 161            # pk 32 + H 32 + Gamma 32 + c 32 + s 32 in, 1 status byte out
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s
-VALU_INT_PEAK = 256 * 4 * 16 * 2.4e9   # lanes/s: 256 CU x 4 SIMD x 16 int lanes/clk x 2.4 GHz (microbench: profiles/r01_instr_rate_microbench.jsonl)
+VALU_INT_PEAK = 256 * 4 * 16 * 2.4e9   # lanes/s (microbench: profiles/r01_instr_rate_microbench.jsonl)
+# algorithmic bytes per unit
+B_VERIFY, B_PROVE, B_PED_PROVE, B_PED_VERIFY, B_PAIRING, B_PAIRING_SHARED = 161, 160, 288, 225, 577, 193
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2-batch", type=int, default=LOG2_BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="headline only (skip the other BASELINE.json configs)")
+    ap.add_argument("--config-steps", type=int, default=5, help="timed steps per secondary config")
+    ap.add_argument("--prevalidated", action="store_true",
+                    help="headline without the subgroup check (inputs declared validated by the caller)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU time budget per cpu_baseline leg")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 outside torch.distributed.run: spawn the ranks.  Nothing here touches a GPU (no torch import)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def synth_msgs(lo, n):
@@ -39,46 +77,363 @@ def synth_msgs(lo, n):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2-batch", type=int, default=LOG2_BATCH)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--secondary", action="store_true",
-                    help="also time the other BASELINE.json configs (prove 2^16, Pedersen 2^20, MSM 2^20, "
-                         "pairing 2^14, affine-input verify) and attach them under \"secondary\"")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    args = ap.parse_args()
+class Dist:
+    """Rank bookkeeping + the two collectives the bench needs (result gather, max of elapsed)."""
 
-    import torch
-    import torch.distributed as dist
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        # rehearsal hook: VRFHIP_BENCH_BACKEND=gloo lets several ranks share the GPUs that exist
+        # (rank -> device modulo device_count, result gather through host memory)
+        self.backend = os.environ.get("VRFHIP_BENCH_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        if ndev == 0:
+            raise SystemExit("no GPU visible: libvrfhip has no CPU path")
+        if self.backend == "nccl" and self.world > ndev:
+            raise SystemExit(f"--gpus {self.world} but only {ndev} device(s) visible (VRFHIP_BENCH_BACKEND=gloo shares them)")
+        self.local = local % ndev
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device("cuda", self.local)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def gather(self, t, n_per_rank):
+        if self.world == 1:
+            return t
+        from ark_ec_vrfs_amd.sharding import gather_results
+        if self.backend == "nccl":
+            return gather_results(t, self.world * n_per_rank, self.rank, self.world)   # RCCL: result gather only
+        return gather_results(t.cpu(), self.world * n_per_rank, self.rank, self.world).to(self.dev)
+
+    def max_elapsed(self, elapsed):
+        if self.world == 1:
+            return elapsed
+        t = self.torch.tensor([elapsed], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed(D, fn, steps, warmup, gather_t=None, n_per_rank=0):
+    """warmup untimed calls, then exactly `steps` calls between barrier + synchronize; max over ranks."""
+    out = None
+    for _ in range(warmup):
+        fn()
+        if gather_t is not None:
+            D.gather(gather_t, n_per_rank)
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+        if gather_t is not None:
+            out = D.gather(gather_t, n_per_rank)
+    D.barrier()
+    return D.max_elapsed(time.perf_counter() - t0), out
+
+
+def pmc_for(name, log2_batch):
+    """HBM traffic and executed vector instructions per launch of a config's dominant kernel, measured with
+    rocprofv3 --pmc on the same command line (profiles/pmc_kernels.json; tools/summarize_profiles.py)."""
+    path = os.path.join(ROOT, "profiles", "pmc_kernels.json")
+    if os.path.exists(path):
+        e = json.load(open(path)).get(name)
+        if e and e.get("log2_batch") == log2_batch:
+            return e
+    if name == "ietf_verify":
+        legacy = os.path.join(ROOT, "profiles", "pmc_k_verify_straus.json")
+        if os.path.exists(legacy):
+            e = json.load(open(legacy))
+            if e.get("log2_batch") == log2_batch:
+                return e
+    return None
+
+
+def roofline(kernel, bytes_per_unit, units, kernel_ms, launches, pmc):
+    sec = kernel_ms / 1e3
+    achieved = bytes_per_unit * units / sec / 1e9 if sec > 0 else 0.0
+    r = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_launch") if pmc else None,
+         "avg_launch_ms": kernel_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": bytes_per_unit * units}
+    v = None
+    if pmc and pmc.get("valu_lane_instructions_per_launch") and sec > 0:
+        lanes = pmc["valu_lane_instructions_per_launch"]
+        v = {"bound": "valu_int", "achieved": lanes / sec, "peak": VALU_INT_PEAK, "unit": "lane-instr/s",
+             "frac": lanes / sec / VALU_INT_PEAK, "source": pmc.get("source")}
+    return r, v
+
+
+def stage_avg(ctx):
+    ms, groups = ctx.profile_read()
+    g = max(groups, 1)
+    return [m / g for m in ms], groups
+
+
+# ------------------------------------------------------------------------------------------- cpu legs
+def cpu_cores():
+    # a one-GPU box's CPU share is 16 cores (more threads than that only oversubscribe the cgroup)
+    return min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+
+
+def cpu_leg(fn, probe, budget_s, cap, unit, what):
+    """fn(m) runs the oracle on the first m items.  Probe, then one bounded run of about budget_s seconds."""
+    cores = cpu_cores()
+    t0 = time.perf_counter()
+    fn(probe)
+    rate = probe / (time.perf_counter() - t0)
+    m = int(min(cap, max(probe, rate * budget_s)))
+    t0 = time.perf_counter()
+    fn(m)
+    dt = time.perf_counter() - t0
+    return {"value": m / dt, "unit": unit, "cores": cores, "kind": "port",
+            "sample": "first %d items of the same batch, %.1f s wall on %d threads; %s" % (m, dt, cores, what),
+            "note": "CPU restatement in C (oracle/c/oracle_vrf.c), not arkworks: no Rust toolchain on this box"}
+
+
+# ------------------------------------------------------------------------------------------- configs
+def cfg_ietf_prove(D, args, ctx, sk, msg, want_cpu):
+    """BASELINE.json configs[1]: batch 2^16 IETF prove, Bandersnatch (Elligator 2 + fixed-base + GLV)."""
+    torch = D.torch
+    m = min(sk.shape[0], 1 << 16)
+    mk = lambda: torch.empty((m, 32), dtype=torch.uint8, device=D.dev)
+    g, c, s, pk, hh = mk(), mk(), mk(), mk(), mk()
+    st = torch.empty(m, dtype=torch.uint8, device=D.dev)
+    fn = lambda: ctx.ietf_prove_batch_dev(sk[:m], msg[:m], 32, g, c, s, pk, hh, st)
+    fn(); torch.cuda.synchronize()
+    ctx.profile(True)
+    el, _ = timed(D, fn, args.config_steps, 1)
+    ctx.profile(False)
+    ms, groups = stage_avg(ctx)
+    assert int(st.sum()) == 0
+    r, v = roofline("k_prove_mul (sk*H, sk*G, k*H, k*G: 2 lanes per proof)", B_PROVE, m, ms[1], groups,
+                    pmc_for("ietf_prove", 16))
+    out = {"workload": "IETF ECVRF prove (Input::new + Secret::output + prove), Bandersnatch_SHA-512_ELL2, batch 2^16 per GPU "
+                       "(BASELINE.json configs[1])",
+           "value": D.world * m * args.config_steps / el, "unit": "proofs/s", "ms_per_step": el / args.config_steps * 1e3,
+           "bytes_per_unit": B_PROVE, "roofline": r, "valu": v,
+           "stage_ms_per_step": {"prepare": ms[0], "mul": ms[1], "finish": ms[3]}}
+    if want_cpu:
+        from oracle import c_oracle as co
+        skh, msgh = sk[:m].cpu().numpy(), msg[:m].cpu().numpy()
+        gh, ch, sh = g.cpu().numpy(), c.cpu().numpy(), s.cpu().numpy()
+
+        def leg(k):
+            ref = co.ietf_prove_batch(skh[:k], msgs=msgh[:k], ad=b"", threads=cpu_cores())
+            assert (ref["output"] == gh[:k]).all() and (ref["c"] == ch[:k]).all() and (ref["s"] == sh[:k]).all(), \
+                "GPU proofs differ from the CPU oracle on the sample"
+        out["cpu_baseline"] = cpu_leg(leg, 32 * cpu_cores(), args.cpu_seconds, m, "proofs/s", "proof bytes equal the GPU's")
+    return out
+
+
+def cfg_pedersen_jubjub(D, args, msg, lo, want_cpu):
+    """BASELINE.json configs[3]: Pedersen VRF batch 2^20 prove + verify on JubJub (sharded: every rank its own batch)."""
+    torch = D.torch
+    from ark_ec_vrfs_amd import Context, JubJubSha512Tai, _lib
+    lib = _lib.load()
+    n = msg.shape[0]
+    cj = Context(D.local, suite=JubJubSha512Tai)
+    stream = torch.cuda.current_stream().cuda_stream
+    mk = lambda: torch.empty((n, 32), dtype=torch.uint8, device=D.dev)
+    seeds = (torch.arange(n, dtype=torch.int64, device=D.dev) + lo).view(torch.uint8).reshape(n, 8)
+    skj = mk()
+    _lib.check(lib.vrfhip_secret_from_seed_batch_dev(cj.handle, n, seeds.data_ptr(), 8, skj.data_ptr(), None, stream), "seed")
+    g, pc, r, ok, ss, sb, hj = (mk() for _ in range(7))
+    pst = torch.empty(n, dtype=torch.uint8, device=D.dev)
+    flag = torch.empty(1, dtype=torch.uint8, device=D.dev)
+    seed = os.urandom(32)
+    res = {}
+    lg = n.bit_length() - 1
+    # prove
+    fn = lambda: cj.pedersen_prove_batch_dev(skj, msg, 32, g, pc, r, ok, ss, sb, None, hj, pst)
+    fn(); torch.cuda.synchronize()
+    cj.profile(True)
+    el, _ = timed(D, fn, args.config_steps, 1)
+    cj.profile(False)
+    ms, groups = stage_avg(cj)
+    assert int(pst.sum()) == 0
+    rf, v = roofline("k_prove_mul (253-bit Straus: JubJub has no endomorphism)", B_PED_PROVE, n, ms[1], groups,
+                     pmc_for("pedersen_prove_jubjub", lg))
+    res["pedersen_prove_jubjub"] = {
+        "workload": "Pedersen VRF prove, JubJub_SHA-512_TAI, batch 2^%d per GPU (BASELINE.json configs[3], prove half)" % lg,
+        "value": D.world * n * args.config_steps / el, "unit": "proofs/s", "ms_per_step": el / args.config_steps * 1e3,
+        "bytes_per_unit": B_PED_PROVE, "roofline": rf, "valu": v,
+        "stage_ms_per_step": {"tai_find+prepare": ms[0], "mul": ms[1], "finish": ms[3]}}
+    # per-proof verify
+    fn = lambda: cj.pedersen_verify_batch_dev(hj, g, pc, r, ok, ss, sb, pst)
+    fn(); torch.cuda.synchronize()
+    cj.profile(True)
+    el, _ = timed(D, fn, args.config_steps, 1, gather_t=pst, n_per_rank=n)
+    cj.profile(False)
+    ms, groups = stage_avg(cj)
+    assert int(pst.sum()) == 0
+    rf, v = roofline("k_ped_verify_straus<0> (s*H - c*Gamma)", B_PED_VERIFY, n, ms[1], groups,
+                     pmc_for("pedersen_verify_jubjub", lg))
+    res["pedersen_verify_jubjub"] = {
+        "workload": "Pedersen VRF verify per proof, JubJub_SHA-512_TAI, batch 2^%d per GPU (BASELINE.json configs[3], verify half)" % lg,
+        "value": D.world * n * args.config_steps / el, "unit": "verifies/s", "ms_per_step": el / args.config_steps * 1e3,
+        "bytes_per_unit": B_PED_VERIFY, "roofline": rf, "valu": v,
+        "stage_ms_per_step": {"decode": ms[0], "straus_a": ms[1], "straus_b": ms[2], "finish": ms[3]}}
+    # batched verify: one MSM over 5n + 2 points (random linear combination)
+    fn = lambda: cj.pedersen_verify_batch_rlc_dev(hj, g, pc, r, ok, ss, sb, pst, flag, seed)
+    fn(); torch.cuda.synchronize()
+    cj.profile(True)
+    el, _ = timed(D, fn, args.config_steps, 1, gather_t=pst, n_per_rank=n)
+    cj.profile(False)
+    ms, groups = stage_avg(cj)
+    assert int(flag[0]) == 0 and int(pst.sum()) == 0
+    rf, v = roofline("k_rlc_decode (five decompressions per proof, digits and points into the MSM layout)", B_PED_VERIFY, n,
+                     ms[0], groups, pmc_for("pedersen_rlc_jubjub", lg))
+    res["pedersen_verify_batched_jubjub"] = {
+        "workload": "Pedersen VRF verify, whole batch by one Pippenger MSM (random linear combination), JubJub, 2^%d per GPU" % lg,
+        "value": D.world * n * args.config_steps / el, "unit": "verifies/s", "ms_per_step": el / args.config_steps * 1e3,
+        "bytes_per_unit": B_PED_VERIFY, "roofline": rf, "valu": v,
+        "stage_ms_per_step": {"decode": ms[0], "msm_buckets": ms[1], "msm_final": ms[2] + ms[3]}}
+    if want_cpu:
+        from oracle import c_oracle as co
+        host = lambda t: t.cpu().numpy()
+        skh, msgh = host(skj[:1 << 16]), host(msg[:1 << 16])
+        ref_names = (("output", g), ("pk_com", pc), ("r", r), ("ok", ok), ("s", ss), ("sb", sb))
+        refs = {k: host(t[:1 << 16]) for k, t in ref_names}
+        hjh = host(hj[:1 << 16])
+        co.set_suite(2)
+        try:
+            def leg_p(k):
+                ref = co.pedersen_prove_batch(skh[:k], msgs=msgh[:k], ad=b"", threads=cpu_cores())
+                for name in refs:
+                    assert (ref[name] == refs[name][:k]).all(), "GPU Pedersen proofs differ from the CPU oracle: " + name
+            res["pedersen_prove_jubjub"]["cpu_baseline"] = cpu_leg(leg_p, 16 * cpu_cores(), args.cpu_seconds, 1 << 16,
+                                                                   "proofs/s", "proof bytes equal the GPU's")
+
+            def leg_v(k):
+                st = co.pedersen_verify_batch(hjh[:k], refs["output"][:k], refs["pk_com"][:k], refs["r"][:k], refs["ok"][:k],
+                                              refs["s"][:k], refs["sb"][:k], b"", threads=cpu_cores())
+                assert not st.any(), "CPU oracle rejects GPU-made proofs"
+            leg = cpu_leg(leg_v, 16 * cpu_cores(), args.cpu_seconds, 1 << 16, "verifies/s", "statuses equal the GPU's")
+            res["pedersen_verify_jubjub"]["cpu_baseline"] = leg
+            res["pedersen_verify_batched_jubjub"]["cpu_baseline"] = dict(leg, sample=leg["sample"] + " (per-proof verifier)")
+        finally:
+            co.set_suite(1)
+    cj.close()
+    return res
+
+
+def cfg_pairing(D, args, ctx, want_cpu):
+    """BASELINE.json configs[4]: 2^14 pairing checks e(P0,Q0) e(P1,Q1) == 1 (Miller loop + final exponentiation)."""
+    torch = D.torch
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "pairing_items.json")))
+    hx = lambda h: np.frombuffer(bytes.fromhex(h), np.uint8)
+    k = 1 << 14
+    g1 = np.stack([hx(it["g1"]) for it in fx["per_item"]])
+    g2 = np.stack([hx(it["g2"]) for it in fx["per_item"]])
+    reps = k // g1.shape[0]
+    d1 = torch.from_numpy(np.tile(g1, (reps, 1)).copy()).to(D.dev)
+    d2 = torch.from_numpy(np.tile(g2, (reps, 1)).copy()).to(D.dev)
+    pstat = torch.empty(k, dtype=torch.uint8, device=D.dev)
+    res = {}
+
+    def run(name, fn, bytes_per, kernel, workload, pmc_name):
+        fn(); torch.cuda.synchronize()
+        evs = []
+
+        def evfn():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record()       # the kernel is launched on torch's current stream (api.py)
+            evs.append((a, b))
+        el, _ = timed(D, evfn, args.config_steps, 1, gather_t=pstat, n_per_rank=k)
+        assert int(pstat.sum()) == 0
+        kms = sum(a.elapsed_time(b) for a, b in evs[-args.config_steps:]) / args.config_steps
+        rf, v = roofline(kernel, bytes_per, k, kms, args.config_steps, pmc_for(pmc_name, 14))
+        res[name] = {"workload": workload, "value": D.world * k * args.config_steps / el, "unit": "checks/s",
+                     "ms_per_step": el / args.config_steps * 1e3, "bytes_per_unit": bytes_per, "roofline": rf, "valu": v}
+
+    run("pairing_check", lambda: ctx.pairing_check_batch_dev(d1, d2, pstat), B_PAIRING,
+        "k_pairing_check2_quad (one item per DPP quad: 2-pair Miller loop + final exponentiation)",
+        "BLS12-381 pairing check, 2 (G1, G2) pairs per item, batch 2^14 per GPU (BASELINE.json configs[4]); "
+        "8 fixture items tiled (the kernel has no data-dependent shortcuts)", "pairing_check")
+    s1 = np.stack([hx(h) for h in fx["shared"]])
+    ds1 = torch.from_numpy(np.tile(s1, (k // s1.shape[0], 1)).copy()).to(D.dev)
+    dsh = torch.from_numpy(hx(fx["shared_g2"]).copy()).to(D.dev)
+    run("pairing_check_shared_g2", lambda: ctx.pairing_check_batch_dev(ds1, dsh, pstat, g2_shared=True), B_PAIRING_SHARED,
+        "k_pairing_check2_quad_prepared (lines of the shared G2 pair prepared once per context)",
+        "the same check against ONE shared G2 pair (a KZG verifier's SRS), batch 2^14 per GPU", "pairing_check_shared")
+    if want_cpu:
+        from oracle import bls_oracle as bo
+
+        def dec1(raw):
+            v = [int.from_bytes(bytes(raw[48 * i:48 * i + 48]), "little") for i in range(4)]
+            return (v[0], v[1]), (v[2], v[3])
+
+        def dec2(raw):
+            v = [int.from_bytes(bytes(raw[48 * i:48 * i + 48]), "little") for i in range(8)]
+            return (bo.Fp2(v[0], v[1]), bo.Fp2(v[2], v[3])), (bo.Fp2(v[4], v[5]), bo.Fp2(v[6], v[7]))
+        items = []
+        for a, b in zip(g1, g2):
+            (p0, p1), (q0, q1) = dec1(a), dec2(b)
+            items.append([(p0, q0), (p1, q1)])
+        t0 = time.perf_counter()
+        cnt = 0
+        while time.perf_counter() - t0 < args.cpu_seconds:
+            assert bo.pairing_check(items[cnt % len(items)])
+            cnt += 1
+        dt = time.perf_counter() - t0
+        leg = {"value": cnt / dt, "unit": "checks/s", "cores": 1, "kind": "port",
+               "sample": "%d checks of the fixture items, %.1f s on 1 thread; verdicts equal the GPU's" % (cnt, dt),
+               "note": "pure-Python big-int restatement (oracle/bls_oracle.py), not arkworks: orders of magnitude slower than "
+                       "a native CPU pairing (arkworks / blst: roughly 1e3 checks/s/core)"}
+        res["pairing_check"]["cpu_baseline"] = leg
+        res["pairing_check_shared_g2"]["cpu_baseline"] = leg
+    return res
+
+
+def headline_cpu_baseline(args, pk, hh, gamma, c, s, status):
+    """The plain-C oracle (a port, not arkworks) on this box's host cores, bounded sample of the same batch."""
+    from oracle import c_oracle as co
+    cap = 1 << 18
+    host = lambda t: t[:cap].cpu().numpy()
+    pkh, hhh, gh, ch, sh, sth = host(pk), host(hh), host(gamma), host(c), host(s), host(status)
+
+    def leg(k):
+        st = co.ietf_verify_batch(pkh[:k], hhh[:k], gh[:k], ch[:k], sh[:k], b"", threads=cpu_cores())
+        assert (st == sth[:k]).all(), "GPU statuses differ from the CPU oracle on the sample"
+    out = cpu_leg(leg, 64 * cpu_cores(), args.cpu_seconds, cap, "verifies/s", "statuses equal the GPU's")
+    m1 = 256
+    t0 = time.perf_counter()
+    co.ietf_verify_batch(pkh[:m1], hhh[:m1], gh[:m1], ch[:m1], sh[:m1], b"", threads=1)
+    out["single_core"] = m1 / (time.perf_counter() - t0)
+    out["note"] += "; the oracle's verify does not include the subgroup check of the three decoded points"
+    return out
+
+
+def run_rank(args):
+    D = Dist(args)
+    torch = D.torch
     from ark_ec_vrfs_amd import Context, _lib
-    from ark_ec_vrfs_amd.sharding import gather_results
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    # rehearsal hook: VRFHIP_BENCH_BACKEND=gloo lets several ranks share the GPUs that exist
-    # (rank -> device modulo device_count, status gather through host memory)
-    backend = os.environ.get("VRFHIP_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
+    rank, world, dev = D.rank, D.world, D.dev
     n = 1 << args.log2_batch
     lo = rank * n                                  # weak scaling: rank g owns items [g*n, (g+1)*n)
-    ctx = Context(local)
+    ctx = Context(D.local)
+    can_check = hasattr(ctx, "set_prevalidated")    # the fused subgroup check (vrfhip_ctx_set_flags)
+    if args.prevalidated and can_check:
+        ctx.set_prevalidated(True)
     lib = _lib.load()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -90,243 +445,77 @@ def main():
     mk = lambda: torch.empty((n, 32), dtype=torch.uint8, device=dev)
     gamma, c, s, pk, hh = mk(), mk(), mk(), mk(), mk()
     pst = torch.empty(n, dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ctx.ietf_prove_batch_dev(sk, msg, 32, gamma, c, s, pk, hh, pst)
-    torch.cuda.synchronize()
-    prove_s = time.perf_counter() - t0             # includes first-touch of the workspace
-    t0 = time.perf_counter()
-    ctx.ietf_prove_batch_dev(sk, msg, 32, gamma, c, s, pk, hh, pst)
-    torch.cuda.synchronize()
-    prove_s = min(prove_s, time.perf_counter() - t0)
+    prove_s = 1e30
+    for _ in range(2):                              # the first call includes first-touch of the workspace
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.ietf_prove_batch_dev(sk, msg, 32, gamma, c, s, pk, hh, pst)
+        torch.cuda.synchronize()
+        prove_s = min(prove_s, time.perf_counter() - t0)
     assert int(pst.sum()) == 0
     status = torch.full((n,), 255, dtype=torch.uint8, device=dev)
 
-    def step():
-        ctx.ietf_verify_batch_dev(pk, hh, gamma, c, s, status)
-        if world > 1:
-            if backend == "nccl":
-                return gather_results(status, world * n, rank, world)   # RCCL: result gather only
-            return gather_results(status.cpu(), world * n, rank, world).to(dev)
-        return status
-
+    step = lambda: ctx.ietf_verify_batch_dev(pk, hh, gamma, c, s, status)
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+        D.gather(status, n)
     ctx.profile(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        full = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, full = timed(D, step, args.steps, 0, gather_t=status, n_per_rank=n)
     ctx.profile(False)
-    stage_ms, groups = ctx.profile_read()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    stage_ms, groups = stage_avg(ctx)
     n_bad = int((full != 0).sum())
     assert n_bad == 0, f"{n_bad} synthetic proofs failed to verify"
 
+    want_cpu = (not args.no_cpu_baseline) and world == 1
+    configs = {}
+    if not args.no_configs:
+        legs = (("ietf_prove", lambda: {"ietf_prove": cfg_ietf_prove(D, args, ctx, sk, msg, want_cpu and rank == 0)}),
+                ("pedersen_jubjub", lambda: cfg_pedersen_jubjub(D, args, msg, lo, want_cpu and rank == 0)),
+                ("pairing", lambda: cfg_pairing(D, args, ctx, want_cpu and rank == 0)))
+        for name, leg in legs:
+            if world > 1:
+                configs.update(leg())               # every rank takes part in the barriers: no swallowing of errors
+                continue
+            try:
+                configs.update(leg())
+            except Exception as e:                  # the headline number must not depend on a secondary leg
+                configs[name] = {"error": repr(e)}
+
     if rank == 0:
-        total_items = world * n * args.steps
-        value = total_items / elapsed
-        straus_s = stage_ms[1] / max(groups, 1) / 1e3          # average launch duration of k_verify_straus<1>
-        achieved_gbs = BYTES_PER_VERIFY * n / straus_s / 1e9
-        # measured constants of the same command line (rocprofv3 --pmc passes, see profiles/)
-        traffic = None
-        valu = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_k_verify_straus.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            if pmc.get("log2_batch") == args.log2_batch:
-                traffic = pmc.get("hbm_bytes_per_launch")
-                lanes = pmc.get("valu_lane_instructions_per_launch")
-                if lanes:
-                    valu = {"bound": "valu_int", "achieved": lanes / straus_s, "peak": VALU_INT_PEAK,
-                            "unit": "lane-instr/s", "frac": lanes / straus_s / VALU_INT_PEAK,
-                            "source": pmc.get("source")}
+        value = world * n * args.steps / elapsed
+        checked = can_check and not args.prevalidated
+        r, v = roofline("k_verify_straus<1> (V = s*H - c*Gamma, the longest kernel)", B_VERIFY, n, stage_ms[1], groups,
+                        pmc_for("ietf_verify", args.log2_batch))
         out = {
             "metric": "Bandersnatch IETF-ECVRF verifies/sec, 2^%d batch per GPU" % args.log2_batch,
             "value": value, "unit": "verifies/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "IETF ECVRF verify, Bandersnatch_SHA-512_ELL2, batch 2^%d per GPU, compressed "
-                                   "points (161 B/verify), ad=\"\" (BASELINE.json configs[2])" % args.log2_batch,
-                       "global_batch": world * n, "parallelism": "items sharded x%d, result gather only" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_verify_straus<1> (V = s*H - c*Gamma, the longest kernel)", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": straus_s * 1e3, "launches_timed": groups},
-            "valu": valu,
-            "stage_ms_per_step": {"decode": stage_ms[0] / max(groups, 1), "straus_v": stage_ms[1] / max(groups, 1),
-                                  "straus_u": stage_ms[2] / max(groups, 1), "finish": stage_ms[3] / max(groups, 1)},
+            "config": {"workload": "IETF ECVRF verify, Bandersnatch_SHA-512_ELL2, batch 2^%d per GPU, compressed points "
+                                   "(161 B/verify), %s, ad=\"\" (BASELINE.json configs[2])"
+                                   % (args.log2_batch, "checked decode: on curve + prime-order subgroup, as arkworks' "
+                                      "deserialisation" if checked else "inputs declared pre-validated (no subgroup check)"),
+                       "global_batch": world * n, "parallelism": "items sharded x%d, result gather only" % world,
+                       "subgroup_check": checked},
+            "roofline": r, "valu": v,
+            "stage_ms_per_step": {"decode": stage_ms[0], "straus_v": stage_ms[1], "straus_u": stage_ms[2],
+                                  "finish": stage_ms[3]},
             "proofs_per_sec": n / prove_s,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, pk, hh, gamma, c, s, status)
-        if args.secondary and world == 1:
-            out["secondary"] = secondary(ctx, lib, dev, sk, msg, pk, hh, gamma, c, s)
+        if want_cpu:
+            out["cpu_baseline"] = headline_cpu_baseline(args, pk, hh, gamma, c, s, status)
+        if configs:
+            out["configs"] = configs
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.close()
     ctx.close()
 
 
-def _time(fn, reps=3):
-    import torch
-    best = 1e30
-    for _ in range(reps):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        fn()
-        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-    return best
-
-
-def secondary(ctx, lib, dev, sk, msg, pk, hh, gamma, c, s):
-    """Other configs of BASELINE.json, same synthetic items, device-resident; best of 3."""
-    import torch
-    from ark_ec_vrfs_amd import _lib
-    n = sk.shape[0]
-    res = {}
-    stream = torch.cuda.current_stream().cuda_stream
-    mk = lambda m=n, w=32: torch.empty((m, w), dtype=torch.uint8, device=dev)
-    # config 1: IETF prove at 2^16 (160 B/proof)
-    m = min(n, 1 << 16)
-    o1, o2, o3, o4, o5 = mk(m), mk(m), mk(m), mk(m), mk(m)
-    st = torch.empty(m, dtype=torch.uint8, device=dev)
-    t = _time(lambda: ctx.ietf_prove_batch_dev(sk[:m], msg[:m], 32, o1, o2, o3, o4, o5, st))
-    res["ietf_prove_2^16"] = {"proofs_per_s": m / t, "ms": t * 1e3, "bytes_per_item": 160}
-    # affine-input verify (257 B/verify)
-    xy = [mk(n, 64) for _ in range(3)]
-    vst = torch.empty(n, dtype=torch.uint8, device=dev)
-    for src, dst in zip((pk, hh, gamma), xy):
-        _lib.check(lib.vrfhip_point_validate_batch_dev(ctx.handle, n, src.data_ptr(), dst.data_ptr(), vst.data_ptr(), stream), "validate")
-    t = _time(lambda: ctx.ietf_verify_batch_affine_dev(xy[0], xy[1], xy[2], c, s, vst))
-    assert int(vst.sum()) == 0
-    res["ietf_verify_affine_2^%d" % (n.bit_length() - 1)] = {"verifies_per_s": n / t, "ms": t * 1e3, "bytes_per_item": 257}
-    # keyed verification: the same 2^n proofs re-made under 1024 keys whose combs stay resident in HBM (129 B/verify + 4 B index)
-    try:
-        nk = 1024
-        kseeds = torch.arange(nk, dtype=torch.int64, device=dev).view(torch.uint8).reshape(nk, 8)
-        ksk, kpk = mk(nk), mk(nk)
-        _lib.check(lib.vrfhip_secret_from_seed_batch_dev(ctx.handle, nk, kseeds.data_ptr(), 8, ksk.data_ptr(), kpk.data_ptr(), stream), "seed")
-        kidx = (torch.arange(n, device=dev) * 2654435761 % nk).to(torch.int32)
-        g2, c2, s2, h2 = mk(), mk(), mk(), mk()
-        ctx.ietf_prove_batch_dev(ksk[kidx.long()].contiguous(), msg, 32, g2, c2, s2, None, h2, vst)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ks, kst = ctx.keyset_create(kpk.cpu().numpy())
-        tb = time.perf_counter() - t0
-        t = _time(lambda: ctx.ietf_verify_batch_keyed_dev(ks, kidx, h2, g2, c2, s2, vst))
-        assert int(vst.sum()) == 0 and int(kst.sum()) == 0
-        res["ietf_verify_keyed_2^%d" % (n.bit_length() - 1)] = {"verifies_per_s": n / t, "ms": t * 1e3, "keys": nk,
-                                                                "keyset_build_ms": tb * 1e3, "keyset_bytes": ks.bytes(),
-                                                                "bytes_per_item": 133}
-        ks.close()
-    except Exception as e:
-        res["ietf_verify_keyed"] = {"error": repr(e)}
-    # config 3: Pedersen prove + verify (Bandersnatch; 288 / 225 B)
-    g, pc, r, ok, ss, sb = (mk() for _ in range(6))
-    pst = torch.empty(n, dtype=torch.uint8, device=dev)
-    tp = _time(lambda: ctx.pedersen_prove_batch_dev(sk, msg, 32, g, pc, r, ok, ss, sb, None, None, pst))
-    tv = _time(lambda: ctx.pedersen_verify_batch_dev(hh, g, pc, r, ok, ss, sb, pst))
-    assert int(pst.sum()) == 0
-    # batched verification: one MSM over 5n + 2 points (random linear combination), compressed and affine inputs
-    flag = torch.empty(1, dtype=torch.uint8, device=dev)
-    seed = os.urandom(32)
-    tb = _time(lambda: ctx.pedersen_verify_batch_rlc_dev(hh, g, pc, r, ok, ss, sb, pst, flag, seed))
-    assert int(flag[0]) == 0 and int(pst.sum()) == 0
-    pxy = [mk(n, 64) for _ in range(5)]
-    for src, dst in zip((hh, g, pc, r, ok), pxy):
-        _lib.check(lib.vrfhip_point_validate_batch_dev(ctx.handle, n, src.data_ptr(), dst.data_ptr(), vst.data_ptr(), stream), "validate")
-    ta = _time(lambda: ctx.pedersen_verify_batch_rlc_dev(*pxy, ss, sb, pst, flag, seed, affine=True))
-    assert int(flag[0]) == 0 and int(pst.sum()) == 0
-    res["pedersen_2^%d" % (n.bit_length() - 1)] = {"proofs_per_s": n / tp, "verifies_per_s": n / tv,
-                                                   "batched_verifies_per_s": n / tb, "batched_affine_verifies_per_s": n / ta,
-                                                   "bytes_per_proof": 288, "bytes_per_verify": 225,
-                                                   "bytes_per_verify_affine": 385}
-    # config 3 as BASELINE.json words it: Pedersen on JubJub (suite parity unpinned, see DESIGN.md)
-    try:
-        from ark_ec_vrfs_amd import Context, JubJubSha512Tai
-        cj = Context(dev.index or 0, suite=JubJubSha512Tai)
-        skj = torch.empty((n, 32), dtype=torch.uint8, device=dev)
-        seeds = torch.arange(n, dtype=torch.int64, device=dev).view(torch.uint8).reshape(n, 8)
-        _lib.check(lib.vrfhip_secret_from_seed_batch_dev(cj.handle, n, seeds.data_ptr(), 8, skj.data_ptr(), None, stream), "seed")
-        hj = mk()
-        tp = _time(lambda: cj.pedersen_prove_batch_dev(skj, msg, 32, g, pc, r, ok, ss, sb, None, hj, pst))
-        tv = _time(lambda: cj.pedersen_verify_batch_dev(hj, g, pc, r, ok, ss, sb, pst))
-        assert int(pst.sum()) == 0
-        tb = _time(lambda: cj.pedersen_verify_batch_rlc_dev(hj, g, pc, r, ok, ss, sb, pst, flag, seed))
-        assert int(flag[0]) == 0 and int(pst.sum()) == 0
-        res["pedersen_jubjub_2^%d" % (n.bit_length() - 1)] = {"proofs_per_s": n / tp, "verifies_per_s": n / tv,
-                                                              "batched_verifies_per_s": n / tb,
-                                                              "bytes_per_proof": 288, "bytes_per_verify": 225}
-        cj.close()
-    except Exception as e:
-        res["pedersen_jubjub"] = {"error": repr(e)}
-    # MSM over the public keys with the secrets as scalars (96 B/term)
-    out = torch.empty(32, dtype=torch.uint8, device=dev); mst = torch.empty(1, dtype=torch.uint8, device=dev)
-    t = _time(lambda: ctx.msm_dev(xy[0], sk, out, None, mst))
-    assert int(mst[0]) == 0
-    res["msm_2^%d" % (n.bit_length() - 1)] = {"points_per_s": n / t, "ms": t * 1e3, "bytes_per_item": 96}
-    # config 4: pairing checks at 2^14 (577 B/check); 8 oracle-made items tiled
-    try:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from test_bls_pairing import kzg_like_items, pack
-        g1, g2 = pack(kzg_like_items(8, seed=21))
-        k = 1 << 14
-        d1 = torch.from_numpy(np.tile(g1, (k // 8, 1)).copy()).to(dev)
-        d2 = torch.from_numpy(np.tile(g2, (k // 8, 1)).copy()).to(dev)
-        pstat = torch.empty(k, dtype=torch.uint8, device=dev)
-        t = _time(lambda: ctx.pairing_check_batch_dev(d1, d2, pstat))
-        assert int(pstat.sum()) == 0
-        res["pairing_check_2^14"] = {"checks_per_s": k / t, "ms": t * 1e3, "bytes_per_item": 577}
-        # the same size against one shared G2 pair (a KZG verifier's SRS): lines prepared once per context
-        from test_bls_pairing import enc_g1, enc_g2, b as bo
-        cc = 0x1234567FEDCBA987
-        sh = np.frombuffer(enc_g2(bo.g2_mul(7, bo.G2)) + enc_g2(bo.g2_mul(7 * cc % bo.R, bo.G2)), np.uint8).copy()
-        rows = [enc_g1(bo.g1_mul(a * cc % bo.R, bo.G1)) + enc_g1(bo.g1_neg(bo.g1_mul(a, bo.G1))) for a in range(1, 9)]
-        s1 = np.frombuffer(b"".join(rows), np.uint8).reshape(-1, 192)
-        d1 = torch.from_numpy(np.tile(s1, (k // 8, 1)).copy()).to(dev)
-        dsh = torch.from_numpy(sh).to(dev)
-        t = _time(lambda: ctx.pairing_check_batch_dev(d1, dsh, pstat, g2_shared=True))
-        assert int(pstat.sum()) == 0
-        res["pairing_check_shared_g2_2^14"] = {"checks_per_s": k / t, "ms": t * 1e3, "bytes_per_item": 193}
-    except Exception as e:                                      # the headline number must not depend on this leg
-        res["pairing_check_2^14"] = {"error": repr(e)}
-    return res
-
-
-def cpu_baseline(args, pk, hh, gamma, c, s, status):
-    """The plain-C oracle (a port, not arkworks) on this box's host cores, bounded sample of the same batch."""
-    from oracle import c_oracle as co
-    # a one-GPU box's CPU share is 16 cores (more threads than that only oversubscribe the cgroup)
-    cores = min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0)))
-    host = lambda t, m: t[:m].cpu().numpy()
-    probe = 64 * cores
-    t0 = time.perf_counter()
-    st = co.ietf_verify_batch(host(pk, probe), host(hh, probe), host(gamma, probe), host(c, probe), host(s, probe), b"", threads=cores)
-    rate = probe / (time.perf_counter() - t0)
-    m = int(min(1 << 18, max(probe, rate * args.cpu_seconds)))
-    t0 = time.perf_counter()
-    st = co.ietf_verify_batch(host(pk, m), host(hh, m), host(gamma, m), host(c, m), host(s, m), b"", threads=cores)
-    dt = time.perf_counter() - t0
-    assert (st == status[:m].cpu().numpy()).all(), "GPU statuses differ from the CPU oracle on the sample"
-    t0 = time.perf_counter()
-    m1 = max(64, int(m / cores / 8))
-    co.ietf_verify_batch(host(pk, m1), host(hh, m1), host(gamma, m1), host(c, m1), host(s, m1), b"", threads=1)
-    dt1 = time.perf_counter() - t0
-    return {"value": m / dt, "unit": "verifies/s", "cores": cores, "kind": "port",
-            "sample": "first %d items of the same 2^%d batch, %.1f s wall on %d threads; statuses equal the GPU's" % (m, args.log2_batch, dt, cores),
-            "single_core": m1 / dt1,
-            "note": "CPU restatement in C (oracle/c/oracle_vrf.c), not arkworks: no Rust toolchain on this box"}
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":
