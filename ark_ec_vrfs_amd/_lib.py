@@ -16,7 +16,9 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvrfhip.so")
 # Every symbol include/vrfhip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "vrfhip_abi_version", "vrfhip_last_error", "vrfhip_ctx_create", "vrfhip_ctx_destroy",
+    "vrfhip_suite_desc_default", "vrfhip_ctx_create_desc", "vrfhip_ctx_get_desc",
     "vrfhip_ctx_reserve", "vrfhip_ctx_workspace_bytes", "vrfhip_ctx_profile", "vrfhip_ctx_profile_read",
+    "vrfhip_ctx_set_flags", "vrfhip_ctx_get_flags",
     "vrfhip_ietf_verify_batch", "vrfhip_ietf_verify_batch_dev",
     "vrfhip_ietf_verify_batch_affine", "vrfhip_ietf_verify_batch_affine_dev",
     "vrfhip_keyset_create", "vrfhip_keyset_destroy", "vrfhip_keyset_bytes",
@@ -32,12 +34,19 @@ SYMBOLS = [
     "vrfhip_output_hash_batch", "vrfhip_output_hash_batch_dev",
     "vrfhip_secret_from_seed_batch", "vrfhip_secret_from_seed_batch_dev",
     "vrfhip_point_validate_batch", "vrfhip_point_validate_batch_dev",
-    "vrfhip_fq_mul_batch", "vrfhip_test_pairing_quad_ops",
+    "vrfhip_fq_mul_batch", "vrfhip_test_pairing_quad_ops", "vrfhip_debug_proofs_per_lane",
 ]
 
 
 class VrfHipError(RuntimeError):
     pass
+
+
+class SuiteDescStruct(ctypes.Structure):
+    """`vrfhip_suite_desc` (include/vrfhip.h)."""
+    _fields_ = [("struct_size", c_uint32), ("curve", c_int32), ("suite_id_len", c_uint32),
+                ("suite_id", c_uint8 * 64), ("h2c_dst_len", c_uint32), ("h2c_dst", c_uint8 * 128),
+                ("generator", c_uint8 * 64), ("blinding_base", c_uint8 * 64), ("challenge_len", c_uint32)]
 
 
 _lib = None
@@ -64,6 +73,9 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_last_error.restype = c_char_p
     lib.vrfhip_ctx_create.argtypes = [c_int32, c_int32, POINTER(c_void_p)]
     lib.vrfhip_ctx_create.restype = c_int32
+    lib.vrfhip_suite_desc_default.argtypes = [c_int32, POINTER(SuiteDescStruct)]
+    lib.vrfhip_ctx_create_desc.argtypes = [POINTER(SuiteDescStruct), c_int32, POINTER(c_void_p)]
+    lib.vrfhip_ctx_get_desc.argtypes = [c_void_p, POINTER(SuiteDescStruct)]
     lib.vrfhip_ctx_destroy.argtypes = [c_void_p]
     lib.vrfhip_ctx_destroy.restype = None
     lib.vrfhip_ctx_reserve.argtypes = [c_void_p, c_size_t]
@@ -72,6 +84,9 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_ctx_workspace_bytes.restype = c_size_t
     lib.vrfhip_ctx_profile.argtypes = [c_void_p, c_int32]
     lib.vrfhip_ctx_profile_read.argtypes = [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_uint64)]
+    lib.vrfhip_ctx_set_flags.argtypes = [c_void_p, c_uint32]
+    lib.vrfhip_ctx_get_flags.argtypes = [c_void_p]
+    lib.vrfhip_ctx_get_flags.restype = c_uint32
     P = c_void_p  # raw addresses (host buffers or device pointers)
     lib.vrfhip_ietf_verify_batch.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P]
     lib.vrfhip_ietf_verify_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P, c_void_p]
@@ -116,10 +131,11 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_point_validate_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, c_void_p]
     lib.vrfhip_fq_mul_batch.argtypes = [c_void_p, c_size_t, P, P, P]
     lib.vrfhip_test_pairing_quad_ops.argtypes = [c_void_p, c_size_t, P, P]
+    lib.vrfhip_debug_proofs_per_lane.argtypes = [c_size_t]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("vrfhip_last_error", "vrfhip_ctx_destroy", "vrfhip_ctx_workspace_bytes",
-                        "vrfhip_keyset_destroy", "vrfhip_keyset_bytes"):
+                        "vrfhip_keyset_destroy", "vrfhip_keyset_bytes", "vrfhip_ctx_get_flags"):
             fn.restype = c_int32
     _lib = lib
     return lib

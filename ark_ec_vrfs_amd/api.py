@@ -59,6 +59,48 @@ class JubJubSha512Tai(Suite):
     SUITE_ENUM = 2
 
 
+CURVE_BANDERSNATCH, CURVE_JUBJUB = 1, 2
+
+
+@dataclass
+class SuiteDesc:
+    """`vrfhip_suite_desc`: what a `Suite` / `PedersenSuite` impl states as data (src/lib.rs:16): SUITE_ID, the
+    hash-to-curve DST, the generator and the Pedersen blinding base (x || y, 32-byte little-endian each)."""
+    curve: int
+    suite_id: bytes
+    h2c_dst: bytes
+    generator: bytes
+    blinding_base: bytes
+    challenge_len: int = 32
+
+    @staticmethod
+    def default(suite: type) -> "SuiteDesc":
+        """The built-in descriptor of a suite class (what Context(suite=...) uses)."""
+        d = _lib.SuiteDescStruct()
+        _lib.check(_lib.load().vrfhip_suite_desc_default(suite.SUITE_ENUM, ctypes.byref(d)), "vrfhip_suite_desc_default")
+        return SuiteDesc._from_struct(d)
+
+    @staticmethod
+    def _from_struct(d) -> "SuiteDesc":
+        return SuiteDesc(int(d.curve), bytes(d.suite_id[:d.suite_id_len]), bytes(d.h2c_dst[:d.h2c_dst_len]),
+                         bytes(d.generator), bytes(d.blinding_base), int(d.challenge_len))
+
+    def _to_struct(self):
+        if len(self.suite_id) > 64 or len(self.h2c_dst) > 128 or len(self.generator) != 64 or len(self.blinding_base) != 64:
+            raise ValueError("descriptor field out of range")
+        d = _lib.SuiteDescStruct()
+        d.struct_size = ctypes.sizeof(_lib.SuiteDescStruct)
+        d.curve = self.curve
+        d.suite_id_len = len(self.suite_id)
+        ctypes.memmove(d.suite_id, bytes(self.suite_id), len(self.suite_id))
+        d.h2c_dst_len = len(self.h2c_dst)
+        ctypes.memmove(d.h2c_dst, bytes(self.h2c_dst), len(self.h2c_dst))
+        ctypes.memmove(d.generator, bytes(self.generator), 64)
+        ctypes.memmove(d.blinding_base, bytes(self.blinding_base), 64)
+        d.challenge_len = self.challenge_len
+        return d
+
+
 def _np_u8(b, n_bytes: Optional[int] = None) -> np.ndarray:
     a = np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else b
     a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
@@ -81,13 +123,24 @@ def _pack_var(items: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
 class Context:
     """One GPU + one suite: owns the device tables and HBM workspace (vrfhip_ctx)."""
 
-    def __init__(self, device: int = 0, suite: type = BandersnatchSha512Ell2):
+    def __init__(self, device: int = 0, suite: type = BandersnatchSha512Ell2, desc: Optional[SuiteDesc] = None):
+        """suite: a built-in suite class; desc: a suite descriptor (overrides `suite`), e.g. the upstream JubJub
+        constants filled in by the caller."""
         self._lib = _lib.load()
         self.suite = suite
         h = ctypes.c_void_p()
-        _lib.check(self._lib.vrfhip_ctx_create(suite.SUITE_ENUM, device, ctypes.byref(h)), "vrfhip_ctx_create")
+        if desc is not None:
+            d = desc._to_struct()
+            _lib.check(self._lib.vrfhip_ctx_create_desc(ctypes.byref(d), device, ctypes.byref(h)), "vrfhip_ctx_create_desc")
+        else:
+            _lib.check(self._lib.vrfhip_ctx_create(suite.SUITE_ENUM, device, ctypes.byref(h)), "vrfhip_ctx_create")
         self._h = h
         self.device = device
+
+    def desc(self) -> SuiteDesc:
+        d = _lib.SuiteDescStruct()
+        _lib.check(self._lib.vrfhip_ctx_get_desc(self._h, ctypes.byref(d)), "vrfhip_ctx_get_desc")
+        return SuiteDesc._from_struct(d)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -106,6 +159,20 @@ class Context:
 
     def reserve(self, max_items: int) -> None:
         _lib.check(self._lib.vrfhip_ctx_reserve(self._h, max_items), "vrfhip_ctx_reserve")
+
+    # VRFHIP_FLAG_PREVALIDATED_* (include/vrfhip.h)
+    PREVALIDATED_PUBLIC, PREVALIDATED_INPUT, PREVALIDATED_OUTPUT, PREVALIDATED_PROOF, PREVALIDATED_ALL = 1, 2, 4, 8, 15
+
+    def set_flags(self, flags: int) -> None:
+        """Point classes whose prime-order-subgroup membership the caller vouches for (their test is skipped)."""
+        _lib.check(self._lib.vrfhip_ctx_set_flags(self._h, int(flags)), "vrfhip_ctx_set_flags")
+
+    def get_flags(self) -> int:
+        return int(self._lib.vrfhip_ctx_get_flags(self._h))
+
+    def set_prevalidated(self, on: bool = True) -> None:
+        """All points declared validated by the caller (on) / everything checked as arkworks' deserialisation does (off)."""
+        self.set_flags(self.PREVALIDATED_ALL if on else 0)
 
     def profile(self, enable: bool) -> None:
         """Record hipEvents around the three kernels of every prove/verify launch group."""

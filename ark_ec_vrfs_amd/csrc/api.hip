@@ -39,7 +39,9 @@ constexpr size_t DEFAULT_CHUNK = size_t(1) << 20;
 
 struct vrfhip_ctx {
   int device = 0;
-  vrfhip_suite suite = VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2;
+  vrfhip_suite suite = VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2;   // selects the compiled arithmetic (= desc.curve)
+  vrfhip_suite_desc desc{};
+  SuiteStr* d_str = nullptr;
   hipStream_t stream = nullptr;      // used by the host-pointer entry points
   std::recursive_mutex mu;
   // shared tables
@@ -61,6 +63,8 @@ struct vrfhip_ctx {
   unsigned long long* d_queue = nullptr;   // work-queue counter of k_tai_find
   uint32_t* d_pair_prep = nullptr;         // Miller-loop lines of shared G2 points (pairing check, SRS case)
   int cus = 256;
+  uint32_t flags = 0;                      // VRFHIP_FLAG_PREVALIDATED_* (vrfhip_ctx_set_flags)
+  uint32_t check_mask() const { return ~flags & (uint32_t)VRFHIP_FLAG_PREVALIDATED_ALL; }
   // optional per-stage timing (hipEvents on the launch stream), see vrfhip_ctx_profile
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;   // 5 per launch group
@@ -191,15 +195,65 @@ size_t blob_bytes(size_t n, const uint32_t* off, uint32_t len, bool shared) {
 
 extern "C" {
 
-int32_t vrfhip_abi_version(void) { return 100; }
+int32_t vrfhip_abi_version(void) { return 110; }
 
 const char* vrfhip_last_error(void) { return g_last_error.c_str(); }
+
+int32_t vrfhip_suite_desc_default(vrfhip_suite suite, vrfhip_suite_desc* out) {
+  if (!out) return fail(VRFHIP_ERR_BAD_ARG, "out is NULL");
+  std::memset(out, 0, sizeof *out);
+  out->struct_size = (uint32_t)sizeof *out;
+  out->challenge_len = 32;
+  auto put = [](uint8_t* dst, uint32_t& len, const char* s) {
+    len = (uint32_t)std::strlen(s);
+    std::memcpy(dst, s, len);
+  };
+  if (suite == VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2) {
+    out->curve = VRFHIP_CURVE_BANDERSNATCH;
+    put(out->suite_id, out->suite_id_len, "Bandersnatch_SHA-512_ELL2");
+    put(out->h2c_dst, out->h2c_dst_len, "ECVRF_Bandersnatch_XMD:SHA-512_ELL2_RO_Bandersnatch_SHA-512_ELL2");
+    std::memcpy(out->generator, vrfk_tables::BS_G_XY, 64);
+    std::memcpy(out->blinding_base, vrfk_tables::BS_B_XY, 64);
+  } else if (suite == VRFHIP_SUITE_JUBJUB_SHA512_TAI) {
+    out->curve = VRFHIP_CURVE_JUBJUB;
+    put(out->suite_id, out->suite_id_len, "JubJub_SHA-512_TAI");
+    std::memcpy(out->generator, vrfk_tables::JJ_G_XY, 64);
+    std::memcpy(out->blinding_base, vrfk_tables::JJ_B_XY, 64);
+  } else {
+    return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported suite");
+  }
+  return VRFHIP_SUCCESS;
+}
 
 int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out) {
   if (!out) return fail(VRFHIP_ERR_BAD_ARG, "out is NULL");
   *out = nullptr;
-  if (suite != VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2 && suite != VRFHIP_SUITE_JUBJUB_SHA512_TAI)
-    return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported suite");
+  vrfhip_suite_desc d;
+  int32_t rc = vrfhip_suite_desc_default(suite, &d);
+  if (rc) return rc;
+  return vrfhip_ctx_create_desc(&d, device, out);
+}
+
+int32_t vrfhip_ctx_get_desc(const vrfhip_ctx* ctx, vrfhip_suite_desc* out) {
+  if (!ctx || !out) return fail(VRFHIP_ERR_BAD_ARG, "NULL argument");
+  *out = ctx->desc;
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vrfhip_ctx** out) {
+  if (!out) return fail(VRFHIP_ERR_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  if (!desc) return fail(VRFHIP_ERR_BAD_ARG, "desc is NULL");
+  if (desc->struct_size != sizeof(vrfhip_suite_desc)) return fail(VRFHIP_ERR_BAD_ARG, "desc.struct_size mismatch");
+  if (desc->curve != VRFHIP_CURVE_BANDERSNATCH && desc->curve != VRFHIP_CURVE_JUBJUB)
+    return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported curve");
+  if (desc->challenge_len != 32) return fail(VRFHIP_ERR_UNSUPPORTED, "challenge_len must be 32");
+  if (desc->suite_id_len == 0 || desc->suite_id_len > sizeof desc->suite_id)
+    return fail(VRFHIP_ERR_BAD_ARG, "suite_id_len out of range");
+  const bool ell2 = desc->curve == VRFHIP_CURVE_BANDERSNATCH;
+  if (ell2 && (desc->h2c_dst_len == 0 || desc->h2c_dst_len > sizeof desc->h2c_dst))
+    return fail(VRFHIP_ERR_BAD_ARG, "h2c_dst_len out of range");
+  const vrfhip_suite suite = ell2 ? VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2 : VRFHIP_SUITE_JUBJUB_SHA512_TAI;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     return fail(VRFHIP_ERR_NO_DEVICE, "no HIP device visible: libvrfhip has no CPU path");
@@ -209,6 +263,7 @@ int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out) 
   vrfhip_ctx* ctx = new vrfhip_ctx();
   ctx->device = device;
   ctx->suite = suite;
+  ctx->desc = *desc;
   auto cleanup = [&](int32_t rc) {
     vrfhip_ctx_destroy(ctx);
     return rc;
@@ -230,8 +285,10 @@ int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out) 
   const size_t comb_bytes = GCOMB_WORDS * sizeof(uint32_t);            // 56.6 MB per generator (16-bit signed windows)
   const size_t prefix_bytes = (size_t)2 * GC_ROWS * GC_SEGS * GC_SEG * NL * sizeof(uint32_t);
   uint32_t* d_prefix = nullptr;
+  uint8_t* d_init = nullptr;          // 128 B points | 36 words Montgomery | 2 B flags
   HIP_TRY_C(hipMalloc(&ctx->d_sqrt_p, sqrt_p_bytes));
   HIP_TRY_C(hipMalloc(&ctx->d_sqrt_lut, lut_bytes));
+  HIP_TRY_C(hipMalloc(&ctx->d_str, sizeof(SuiteStr)));
   HIP_TRY_C(hipMalloc(&ctx->d_g_win, 2 * WIN_TABLE_WORDS * sizeof(uint32_t)));
   HIP_TRY_C(hipMalloc(&ctx->d_g_comb, comb_bytes));
   HIP_TRY_C(hipMalloc(&ctx->d_b_comb, comb_bytes));
@@ -242,17 +299,43 @@ int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out) 
                            ctx->stream));
   HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_lut, vrfk_tables::SQRT_LUT, lut_bytes, hipMemcpyHostToDevice,
                            ctx->stream));
-  HIP_TRY_C(hipMalloc(&d_prefix, prefix_bytes));
-  launch_init_tables((int)suite, ctx->d_g_win, ctx->d_g_comb, ctx->d_b_comb, d_prefix, ctx->stream);
-  {
-    hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_prefix);
-    HIP_TRY_C(e1);
-    HIP_TRY_C(e2);
+  SuiteStr hs{};
+  hs.suite_id_len = desc->suite_id_len;
+  std::memcpy(hs.suite_id, desc->suite_id, desc->suite_id_len);
+  if (ell2) {
+    hs.dst_len = desc->h2c_dst_len;
+    std::memcpy(hs.dst, desc->h2c_dst, desc->h2c_dst_len);
   }
-#undef HIP_TRY_C
+  uint8_t gb[128];
+  std::memcpy(gb, desc->generator, 64);
+  std::memcpy(gb + 64, desc->blinding_base, 64);
+  HIP_TRY_C(hipMalloc(&d_init, 512));
+  HIP_TRY_C(hipMalloc(&d_prefix, prefix_bytes));
+  auto free_tmp = [&]() { (void)hipFree(d_prefix); (void)hipFree(d_init); };
   ctx->T.sq.P = ctx->d_sqrt_p;
   ctx->T.sq.lut = ctx->d_sqrt_lut;
+  ctx->T.sq.str = ctx->d_str;
+  {
+    hipError_t e0 = hipMemcpy(ctx->d_str, &hs, sizeof hs, hipMemcpyHostToDevice);
+    hipError_t e1 = e0 == hipSuccess ? hipMemcpy(d_init, gb, sizeof gb, hipMemcpyHostToDevice) : e0;
+    if (e1 != hipSuccess) { free_tmp(); HIP_TRY_C(e1); }
+  }
+  uint32_t* d_mont = reinterpret_cast<uint32_t*>(d_init + 128);
+  uint8_t* d_flags = d_init + 128 + 4 * NL * sizeof(uint32_t);
+  launch_init_tables((int)suite, ctx->d_g_win, ctx->d_g_comb, ctx->d_b_comb, d_prefix, d_init, d_mont, d_flags, ctx->T.sq,
+                     ctx->stream);
+  uint8_t base_ok[2] = {0, 0};
+  {
+    hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
+    hipError_t e3 = hipMemcpy(base_ok, d_flags, 2, hipMemcpyDeviceToHost);
+    free_tmp();
+    HIP_TRY_C(e1);
+    HIP_TRY_C(e2);
+    HIP_TRY_C(e3);
+  }
+#undef HIP_TRY_C
+  if (!base_ok[0]) return cleanup(fail(VRFHIP_ERR_BAD_ARG, "desc.generator is not a non-identity point of the prime-order subgroup"));
+  if (!base_ok[1]) return cleanup(fail(VRFHIP_ERR_BAD_ARG, "desc.blinding_base is not a non-identity point of the prime-order subgroup"));
   ctx->T.g_win = ctx->d_g_win;
   ctx->T.g_comb = ctx->d_g_comb;
   ctx->T.b_comb = ctx->d_b_comb;
@@ -271,6 +354,7 @@ void vrfhip_ctx_destroy(vrfhip_ctx* ctx) {
     if (ctx->d_msm_ws) (void)hipFree(ctx->d_msm_ws);
     if (ctx->d_sqrt_p) (void)hipFree(ctx->d_sqrt_p);
     if (ctx->d_sqrt_lut) (void)hipFree(ctx->d_sqrt_lut);
+    if (ctx->d_str) (void)hipFree(ctx->d_str);
     if (ctx->d_g_win) (void)hipFree(ctx->d_g_win);
     if (ctx->d_g_comb) (void)hipFree(ctx->d_g_comb);
     if (ctx->d_b_comb) (void)hipFree(ctx->d_b_comb);
@@ -292,6 +376,17 @@ int32_t vrfhip_ctx_reserve(vrfhip_ctx* ctx, size_t max_items) {
 }
 
 size_t vrfhip_ctx_workspace_bytes(const vrfhip_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
+
+int32_t vrfhip_ctx_set_flags(vrfhip_ctx* ctx, uint32_t flags) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (flags & ~(uint32_t)VRFHIP_FLAG_PREVALIDATED_ALL) return fail(VRFHIP_ERR_BAD_ARG, "unknown flag bits");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  ctx->flags = flags;
+  return VRFHIP_SUCCESS;
+}
+uint32_t vrfhip_ctx_get_flags(const vrfhip_ctx* ctx) { return ctx ? ctx->flags : 0; }
+
+int32_t vrfhip_debug_proofs_per_lane(size_t n) { return lanes_k(n, VERIFY_K); }
 
 int32_t vrfhip_ctx_profile(vrfhip_ctx* ctx, int32_t enable) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
@@ -348,6 +443,7 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
     a.n = m;
     a.pk = ks ? d_pk : d_pk + base * pw; a.h = d_input + base * pw; a.gamma = d_output + base * pw;
     a.affine_in = affine ? 1 : 0;
+    a.check_mask = ctx->check_mask();
     a.key_index = ks ? d_key_index + base : nullptr;
     a.key_combs = ks ? ks->d_combs : nullptr;
     a.key_valid = ks ? ks->d_valid : nullptr;
@@ -588,6 +684,7 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
     a.h_out = at(o.input, base, 32);
     a.status = at(o.status, base, 1);
     a.pedersen = pedersen ? 1 : 0;
+    a.check_mask = ctx->check_mask();
     a.r_out = at(o.r, base, 32); a.ok_out = at(o.ok, base, 32); a.sb_out = at(o.sb, base, 32);
     a.blinding_out = at(o.blinding, base, 32);
     a.ws = ctx->ws;
@@ -735,6 +832,7 @@ int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_
     a.h = d_input + base * 32; a.gamma = d_output + base * 32; a.pk_com = d_pk_com + base * 32;
     a.r = d_r + base * 32; a.ok = d_ok + base * 32; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
     a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
+    a.check_mask = ctx->check_mask();
     a.status = d_status + base;
     a.ws = ctx->ws;
     a.T = ctx->T;
@@ -818,6 +916,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
     a.h = d_input + base * pw; a.gamma = d_output + base * pw; a.pk_com = d_pk_com + base * pw;
     a.r = d_r + base * pw; a.ok = d_ok + base * pw; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
     a.affine_in = affine ? 1 : 0;
+    a.check_mask = ctx->check_mask();
     a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
     a.status = d_status + base;
     a.scratch = ctx->ws.tabs;
@@ -1101,7 +1200,7 @@ int32_t vrfhip_output_hash_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d
   if (!d_output || !d_hash) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  launch_output_hash((int)ctx->suite, n, d_output, d_hash, static_cast<hipStream_t>(stream));
+  launch_output_hash((int)ctx->suite, n, d_output, d_hash, ctx->T, static_cast<hipStream_t>(stream));
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
 }

@@ -366,9 +366,13 @@ VRF_HD FeN fe_inv(const Fe<L, V>& a) {   // a^(q-2); 0 -> 0
 // Table-driven Tonelli-Shanks for 2-adicity 32.  tbl = SQRT_P (4 x 256 x 9 words, h^(j 2^(8k))),
 // lut = SQRT_LUT.  Returns is_square(w) and sets `root` to sqrt(w) if w is a square, else to
 // sqrt(Z*w) (Z = 5, the suite's Elligator non-residue).  Constant shape: 220 + 24 squarings.
+struct SuiteStr;         // vrf_core.cuh: byte strings of the suite descriptor
 struct SqrtTables {
   const uint32_t* P;     // [4][256][9]
   const uint8_t* lut;    // [1 << SQRT_LUT_BITS]
+  // The suite's byte strings travel with these tables because the same helpers (hash-to-curve, point decoding)
+  // receive them: `Suite::SUITE_ID` and the hash-to-curve DST of the context's descriptor (device memory).
+  const SuiteStr* str;
 };
 
 VRF_HD uint32_t sqrt_lut_index(const SqrtTables& T, const FeN& y) {
@@ -408,6 +412,101 @@ VRF_HD bool fe_sqrt_or_zsqrt(FeN& root, const Fe<L, V>& w_in, const SqrtTables& 
   FeN rz = fe_mul(r, fe_const(vrfk::SQRT_CZ_M));
   root = fe_select(odd, rz, r);
   return !odd;    // w == 0: b = 0, lut garbage, but x0 = 0 => root = 0; caller treats 0 as square
+}
+
+
+// ------------------------------------------------------------------ quadratic character (Jacobi symbol)
+// Is w a non-zero square?  The Euler criterion costs an exponentiation (~255 squarings, ~58 k instruction
+// slots).  Here: the Jacobi symbol (g / q) by "positive divsteps" (Bernstein-Yang safegcd with the sum in
+// place of the difference, so f and g stay non-negative and quadratic reciprocity applies as is):
+//     g odd and eta < 0 : swap (f, g), eta = -eta       sign flips iff f = g = 3 (mod 4)
+//     g odd             : g += f                        (g / f) depends on g mod f only
+//     then              : g /= 2, eta -= 1              sign flips iff f = 3, 5 (mod 8)
+// The pair converges to f = g = gcd; the symbol is known once f = 1.  Every decision reads the low bits of f
+// and g and the counter eta only, so JAC_K = 29 steps run on the low 32-bit words (one VGPR each) and yield a
+// 2x2 matrix of non-negative 30-bit entries; applying it to the 9-limb numbers divides by 2^29 exactly, i.e.
+// drops one 29-bit limb.  The step is branch-free and every lane of a wave runs the same shape; 24..30 rounds
+// for 255-bit inputs (measured on 3e4 random values; a wave pays the maximum of its lanes, ~29).  ~1000 cheap
+// 32-bit VOP2 instructions + 36 multiply-adds per round: about a third of the exponentiation.
+// chi(R) = chi(2)^261 = 1 because q = 1 (mod 8): the symbol of the Montgomery image is the symbol of the value.
+constexpr int JAC_K = 29;
+constexpr int JAC_MAX_ROUNDS = 40;      // rounds needed: <= 30 in 3e4 samples, tail decays ~50x per round
+
+// wave-level "any lane" on the device, identity on the host build
+VRF_HD bool vrf_any(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __any((int)x) != 0;
+#else
+  return x;
+#endif
+}
+
+// x: exact 29-bit limbs of an integer in [0, 2^256).  Returns +1 / -1, 0 if x = 0 (mod q), 2 if the rounds ran out.
+VRF_HD int jacobi_limbs(const uint32_t x[NL]) {
+  uint32_t f[NL], g[NL];
+  uint32_t nz = 0, dq = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { f[i] = vrfk::Q29[i]; g[i] = x[i]; nz |= x[i]; dq |= x[i] ^ vrfk::Q29[i]; }
+  const bool zero = nz == 0 || dq == 0;          // canonical inputs are < 2q: the multiples of q are 0 and q
+  int32_t eta = -1;
+  uint32_t jac = 0;                               // bit 1 carries the sign
+  bool done = zero;
+#pragma unroll 1
+  for (int round = 0; round < JAC_MAX_ROUNDS; ++round) {
+    if (!vrf_any(!done)) break;
+    uint32_t f0 = f[0] | (f[1] << LW), g0 = g[0] | (g[1] << LW);
+    uint32_t u = 1, v = 0, q = 0, r = 1, jl = jac;
+    int32_t e = eta;
+#pragma unroll
+    for (int i = 0; i < JAC_K; ++i) {
+      const uint32_t m = 0u - (g0 & 1u);                       // g odd
+      const uint32_t sw = m & (uint32_t)(e >> 31);             // ... and eta < 0: swap
+      jl ^= f0 & g0 & sw;
+      uint32_t t = (f0 ^ g0) & sw; f0 ^= t; g0 ^= t;
+      t = (u ^ q) & sw; u ^= t; q ^= t;
+      t = (v ^ r) & sw; v ^= t; r ^= t;
+      e = (e ^ (int32_t)sw) - (int32_t)sw;
+      g0 += f0 & m; q += u & m; r += v & m;
+      g0 >>= 1; u <<= 1; v <<= 1; e -= 1;
+      jl ^= f0 ^ (f0 >> 1);
+    }
+    // (f, g) <- (u f + v g, q f + r g) / 2^29: the low limb of both sums is zero by construction
+    uint32_t nf[NL], ng[NL];
+    uint64_t af = mad(u, f[0], (uint64_t)v * g[0]) >> LW, ag = mad(q, f[0], (uint64_t)r * g[0]) >> LW;
+#pragma unroll
+    for (int i = 1; i < NL; ++i) {
+      af = mad(u, f[i], mad(v, g[i], af));
+      ag = mad(q, f[i], mad(r, g[i], ag));
+      nf[i - 1] = (uint32_t)af & LMASK; af >>= LW;
+      ng[i - 1] = (uint32_t)ag & LMASK; ag >>= LW;
+    }
+    nf[NL - 1] = (uint32_t)af; ng[NL - 1] = (uint32_t)ag;
+    uint32_t rest = 0;
+#pragma unroll
+    for (int i = 1; i < NL; ++i) rest |= nf[i];
+    const bool now_one = nf[0] == 1u && rest == 0;
+    // lanes that had finished keep their state (f = 1 is not absorbing under further steps)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { f[i] = done ? f[i] : nf[i]; g[i] = done ? g[i] : ng[i]; }
+    eta = done ? eta : e;
+    jac = done ? jac : jl;
+    done = done || now_one;
+  }
+  if (zero) return 0;
+  if (!done) return 2;
+  return (jac & 2u) ? -1 : 1;
+}
+
+// w is a non-zero square.  The fall-back (rounds exhausted; not observed) is the exponentiation.
+template <int L, int V>
+VRF_HD bool fe_is_nonzero_square(const Fe<L, V>& w, const SqrtTables& T) {
+  const FeN c = fe_canon(w);
+  const int j = jacobi_limbs(c.v);
+  if (j == 2) {
+    FeN root;
+    return fe_sqrt_or_zsqrt(root, c, T) && !fe_is_zero(c);
+  }
+  return j == 1;
 }
 
 }  // namespace vrf

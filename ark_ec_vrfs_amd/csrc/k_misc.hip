@@ -4,28 +4,56 @@
 namespace vrf {
 
 // ---- one-time table construction (context creation) ----
+// gb_xy: the descriptor's generator and Pedersen blinding base, x || y as 32-byte little-endian canonical
+// integers (2 x 64 bytes).  k_init_bases validates them (coordinates < q, on the curve, prime-order subgroup,
+// not the identity: flags[which] = 1) and leaves their Montgomery coordinates in mont[which][2][9].
 template <class S>
-__global__ void k_init_gwin(uint32_t* g_win) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) build_glv_tables<S>(g_win, S::gx(), S::gy());
+__global__ void k_init_bases(const uint8_t* gb_xy, uint32_t* mont, uint8_t* flags, SqrtTables T) {
+  const int which = threadIdx.x;
+  if (blockIdx.x != 0 || which >= 2) return;
+  uint32_t xw[8], yw[8];
+  load32(xw, gb_xy, 2 * which); load32(yw, gb_xy, 2 * which + 1);
+  bool ok = !u256_ge(xw, vrfk::Q32) && !u256_ge(yw, vrfk::Q32);
+  const FeN x = fe_from_u256(xw), y = fe_from_u256(yw);
+  // a x^2 + y^2 = 1 + d x^2 y^2   <=>   y^2 - ANEG x^2 - 1 = d (x y)^2
+  const FeN x2 = fe_sqr(x), y2 = fe_sqr(y), xyv = fe_mul(x, y);
+  auto lhs = fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(S::mul_aneg(x2), fe_one())))));
+  ok = ok && fe_eq(lhs, fe_mul(fe_sqr(xyv), S::d())) && !fe_is_zero(x);
+  uint32_t r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = S::r32(j);
+  const PtE rp = te_mul_slow<S>(te_from_affine(x, y), r);          // one-time: r * P = O by the plain ladder
+  ok = ok && fe_is_zero(rp.X) && fe_eq(rp.Y, rp.Z);
+  fe_store(mont + which * 2 * NL, x);
+  fe_store(mont + which * 2 * NL + NL, y);
+  flags[which] = ok ? 1 : 0;
+}
+template <class S>
+__global__ void k_init_gwin(uint32_t* g_win, const uint32_t* mont) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) build_glv_tables<S>(g_win, fe_load<1, 2>(mont), fe_load<1, 2>(mont + NL));
 }
 // one lane per (base, row, segment) of the two generator tables (gcomb_build_segment); prefix: GC_SEG x 9 words per lane
 template <class S>
-__global__ void __launch_bounds__(64, 2) k_init_gcomb(uint32_t* g_comb, uint32_t* b_comb, uint32_t* prefix) {
+__global__ void __launch_bounds__(64, 2) k_init_gcomb(uint32_t* g_comb, uint32_t* b_comb, uint32_t* prefix,
+                                                      const uint32_t* mont) {
   const int t = blockIdx.x * 64 + threadIdx.x;
   if (t >= 2 * GC_ROWS * GC_SEGS) return;
   const int which = t / (GC_ROWS * GC_SEGS), r = t % (GC_ROWS * GC_SEGS);
   const int w = r / GC_SEGS, seg = r % GC_SEGS;
-  const FeN bx = which ? S::bx() : S::gx();
-  const FeN by = which ? S::by() : S::gy();
+  const FeN bx = fe_load<1, 2>(mont + which * 2 * NL), by = fe_load<1, 2>(mont + which * 2 * NL + NL);
   gcomb_build_segment<S>(which ? b_comb : g_comb, prefix + (size_t)t * GC_SEG * NL, bx, by, w, seg);
 }
 template <class S>
-static void init_tables_t(uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, uint32_t* prefix, hipStream_t st) {
-  hipLaunchKernelGGL(k_init_gwin<S>, dim3(1), dim3(64), 0, st, g_win);
-  hipLaunchKernelGGL(k_init_gcomb<S>, dim3((2 * GC_ROWS * GC_SEGS + 63) / 64), dim3(64), 0, st, g_comb, b_comb, prefix);
+static void init_tables_t(uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, uint32_t* prefix, const uint8_t* gb_xy,
+                          uint32_t* mont, uint8_t* flags, SqrtTables T, hipStream_t st) {
+  hipLaunchKernelGGL(k_init_bases<S>, dim3(1), dim3(64), 0, st, gb_xy, mont, flags, T);
+  hipLaunchKernelGGL(k_init_gwin<S>, dim3(1), dim3(64), 0, st, g_win, (const uint32_t*)mont);
+  hipLaunchKernelGGL(k_init_gcomb<S>, dim3((2 * GC_ROWS * GC_SEGS + 63) / 64), dim3(64), 0, st, g_comb, b_comb, prefix,
+                     (const uint32_t*)mont);
 }
-void launch_init_tables(int suite, uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, uint32_t* prefix, hipStream_t st) {
-  VRF_DISPATCH_SUITE(suite, init_tables_t<S>(g_win, g_comb, b_comb, prefix, st));
+void launch_init_tables(int suite, uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, uint32_t* prefix,
+                        const uint8_t* gb_xy, uint32_t* mont, uint8_t* flags, SqrtTables T, hipStream_t st) {
+  VRF_DISPATCH_SUITE(suite, init_tables_t<S>(g_win, g_comb, b_comb, prefix, gb_xy, mont, flags, T, st));
 }
 
 // ---- Input::new ----
@@ -48,18 +76,18 @@ void launch_hash_to_curve(int suite, size_t n, BytesView msg, uint8_t* points, D
 
 // ---- Output::hash ----
 template <class S>
-__global__ void __launch_bounds__(BLOCK) k_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash) {
+__global__ void __launch_bounds__(BLOCK) k_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash, const SuiteStr* ss) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t g[8], o[16];
   load32(g, gamma, i);
-  output_hash_item<S>(o, g);
+  output_hash_item<S>(o, g, *ss);
   uint32_t* p = reinterpret_cast<uint32_t*>(hash + i * 64);
 #pragma unroll
   for (int j = 0; j < 16; ++j) p[j] = o[j];
 }
-void launch_output_hash(int suite, size_t n, const uint8_t* gamma, uint8_t* hash, hipStream_t st) {
-  if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_output_hash<S>, grid_for(n), dim3(BLOCK), 0, st, n, gamma, hash));
+void launch_output_hash(int suite, size_t n, const uint8_t* gamma, uint8_t* hash, DevTables T, hipStream_t st) {
+  if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_output_hash<S>, grid_for(n), dim3(BLOCK), 0, st, n, gamma, hash, T.sq.str));
 }
 
 // ---- Secret::from_seed / Secret::public ----

@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_ped_verify_decode(PedersenVerif
   uint32_t c[8];
   bool ok = pedersen_verify_decode_item<S>(c, a.T, enc, ad, ad_len,
                                                  a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS),
-                                                 a.ws.pts + i * PROVE_PTS_WORDS);
+                                                 a.ws.pts + i * PROVE_PTS_WORDS, a.check_mask);
   uint32_t* aux = a.ws.aux + i * AUX_WORDS;
 #pragma unroll
   for (int j = 0; j < 8; ++j) aux[j] = c[j];

@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare(ProveArgs a) {
   // try-and-increment suites: k_tai_find left the first decodable counter in the item's flag byte
   const uint32_t tai_start = (!S::H2C_ELL2 && !a.h_given) ? a.ws.flags[i] : 0u;
   bool ok = prove_prepare_item<S>(h_enc, k, a.ws.tabs + i * (2 * WIN_TABLE_WORDS), a.T, sk, msg,
-                                        msg_len, a.h_given ? hg : nullptr, tai_start);
+                                        msg_len, a.h_given ? hg : nullptr, tai_start, a.check_mask);
   uint32_t* aux = a.ws.aux + i * AUX_WORDS;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { aux[j] = h_enc[j]; aux[8 + j] = k[j]; }
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare(ProveArgs a) {
     const uint8_t* ad; uint32_t ad_len;
     bytes_get(a.ad, i, ad, ad_len);
     uint32_t b[8], kb[8];
-    pedersen_blinding<S>(b, sk, h_enc, ad, ad_len);
+    pedersen_blinding<S>(b, sk, h_enc, ad, ad_len, *a.T.sq.str);
     nonce_rfc8032<S>(kb, b, h_enc);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { aux[16 + j] = b[j]; aux[24 + j] = kb[j]; }
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare_multi(ProveArgs a
         for (int t = 0; t < 8; ++t) h_enc[t] = aux[t];
         const uint8_t* ad; uint32_t ad_len;
         bytes_get(a.ad, i, ad, ad_len);
-        pedersen_blinding<S>(b, sk, h_enc, ad, ad_len);
+        pedersen_blinding<S>(b, sk, h_enc, ad, ad_len, *a.T.sq.str);
         nonce_rfc8032<S>(kb, b, h_enc);
 #pragma unroll
         for (int t = 0; t < 8; ++t) { aux[16 + t] = b[t]; aux[24 + t] = kb[t]; }
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_finish(ProveArgs a) {
     }
     const uint8_t* ad; uint32_t ad_len;
     bytes_get(a.ad, i, ad, ad_len);
-    prove_respond_item<S>(c, s, enc, h_enc, sk, k, ad, ad_len);
+    prove_respond_item<S>(c, s, enc, h_enc, sk, k, ad, ad_len, *a.T.sq.str);
     bool ok = a.ws.flags[i] != 0;
     if (a.pedersen) {
       uint32_t b[8], kb[8], cb[8], sb[8];

@@ -10,7 +10,7 @@ template <class S, int MINW>
 __global__ void __launch_bounds__(BLOCK, MINW) k_verify_decode(VerifyArgs a) {
   size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   if (first >= a.n) return;
-  verify_decode_multi<S>(a.k_lane, a.T, first, a.n, a.pk, a.h, a.gamma, a.ws.tabs, a.ws.pts, a.ws.flags);
+  verify_decode_multi<S>(a.k_lane, a.T, first, a.n, a.pk, a.h, a.gamma, a.ws.tabs, a.ws.pts, a.ws.flags, a.check_mask);
 }
 
 // stage 1, keyed: only H and Gamma are decompressed; validity also requires a valid, existing key
@@ -18,7 +18,8 @@ template <class S, int MINW>
 __global__ void __launch_bounds__(BLOCK, MINW) k_verify_decode_keyed(VerifyArgs a) {
   size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   if (first >= a.n) return;
-  verify_decode_multi<S, 2>(a.k_lane, a.T, first, a.n, nullptr, a.h, a.gamma, a.ws.tabs, a.ws.pts, a.ws.flags);
+  verify_decode_multi<S, 2>(a.k_lane, a.T, first, a.n, nullptr, a.h, a.gamma, a.ws.tabs, a.ws.pts, a.ws.flags,
+                            a.check_mask);
 #pragma unroll 1
   for (int k = 0; k < a.k_lane; ++k) {
     const size_t i = first + k;
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(BLOCK) k_verify_decode_affine(VerifyArgs a) {
   const uint32_t* p2 = reinterpret_cast<const uint32_t*>(a.gamma + i * 64);
 #pragma unroll
   for (int j = 0; j < 16; ++j) { xy[0][j] = p0[j]; xy[1][j] = p1[j]; xy[2][j] = p2[j]; }
-  bool ok = verify_decode_affine_item<S>(enc, xy, a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS));
+  bool ok = verify_decode_affine_item<S>(enc, xy, a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), a.T.sq, a.check_mask);
   uint32_t* aux = a.ws.aux + i * AUX_WORDS;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { aux[j] = enc[0][j]; aux[8 + j] = enc[1][j]; aux[16 + j] = enc[2][j]; }
@@ -107,7 +108,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_verify_finish(VerifyArgs a) {
   if (first >= a.n) return;
   verify_finish_multi<S>(a.k_lane, first, a.n, a.ws.pts, PROVE_PTS_WORDS, a.pk, a.h, a.gamma,
                          a.affine_in ? a.ws.aux : nullptr, AUX_WORDS, a.c, a.s, a.ad, a.ws.flags, a.status,
-                         a.key_index, a.n_keys);
+                         *a.T.sq.str, a.key_index, a.n_keys);
 }
 
 template <class S>

@@ -45,6 +45,7 @@ struct VerifyArgs {
   size_t n;
   const uint8_t *pk, *h, *gamma, *c, *s;   // affine_in != 0: pk, h, gamma are 64-byte x || y
   int affine_in;
+  uint32_t check_mask;                     // CHK_* bits: which decoded points get the subgroup test
   BytesView ad;
   uint8_t* status;
   // keyed verification (key_index != nullptr): pk is the key set's encodings [n_keys][32]; the U half uses the
@@ -68,6 +69,7 @@ struct ProveArgs {
   uint8_t *gamma, *c, *s, *pk_out, *h_out, *status;
   // Pedersen (pedersen != 0): c is unused; pk_out receives pk_com; extra outputs below
   int pedersen;
+  uint32_t check_mask;        // CHK_INPUT: subgroup test of a given H
   uint8_t *r_out, *ok_out, *sb_out, *blinding_out;
   unsigned long long* tai_queue;   // 8-byte device counter for k_tai_find (try-and-increment suites)
   Workspace ws;
@@ -78,6 +80,7 @@ struct PedersenVerifyArgs {
   int suite;
   size_t n;
   const uint8_t *h, *gamma, *pk_com, *r, *ok, *s, *sb;
+  uint32_t check_mask;        // CHK_INPUT | CHK_OUTPUT | CHK_PROOF
   BytesView ad;
   uint8_t* status;
   Workspace ws;
@@ -85,14 +88,17 @@ struct PedersenVerifyArgs {
 };
 
 // launchers (each defined next to its kernels)
-// generator tables: GCOMB_WORDS words each; prefix: 2 * GC_ROWS * GC_SEGS * GC_SEG * 9 words of build scratch
-void launch_init_tables(int suite, uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, uint32_t* prefix, hipStream_t st);
+// generator tables: GCOMB_WORDS words each; prefix: 2 * GC_ROWS * GC_SEGS * GC_SEG * 9 words of build scratch.
+// gb_xy (device, 128 B): the descriptor's generator and blinding base, x || y little-endian; mont (device, 36 words)
+// receives their Montgomery coordinates, flags (device, 2 B) 1 = valid point of the prime-order subgroup.
+void launch_init_tables(int suite, uint32_t* g_win, uint32_t* g_comb, uint32_t* b_comb, uint32_t* prefix,
+                        const uint8_t* gb_xy, uint32_t* mont, uint8_t* flags, SqrtTables T, hipStream_t st);
 // ev: optional 5 events recorded on `st` before stage 1 and after stages 1, 2a, 2b, 3 (profiling)
 void launch_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
 void launch_ietf_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
 void launch_pedersen_verify(const PedersenVerifyArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
 void launch_hash_to_curve(int suite, size_t n, BytesView msg, uint8_t* points, DevTables T, hipStream_t st);
-void launch_output_hash(int suite, size_t n, const uint8_t* gamma, uint8_t* hash, hipStream_t st);
+void launch_output_hash(int suite, size_t n, const uint8_t* gamma, uint8_t* hash, DevTables T, hipStream_t st);
 void launch_secret_from_seed(int suite, size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk,
                              uint8_t* pk, DevTables T, hipStream_t st);
 // key sets: decode + validate the keys (xy: [n][18] Montgomery words), then build one comb per key.

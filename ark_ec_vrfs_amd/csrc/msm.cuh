@@ -130,6 +130,7 @@ struct RlcArgs {
   uint64_t index0;            // index of the first proof in the caller's batch (weights depend on it)
   const uint8_t *h, *gamma, *pk_com, *r, *ok, *s, *sb;   // affine_in: the five point arrays are 64-byte x || y
   int affine_in;
+  uint32_t check_mask;        // CHK_INPUT | CHK_OUTPUT | CHK_PROOF: subgroup test of the decoded points
   BytesViewLite ad;
   uint8_t* status;            // [n] 0 = part of the batch sum, 2 = InvalidData (left out of it)
   uint32_t* scratch;          // per-proof scratch, scratch_stride words each (>= 5 * 37)

@@ -131,6 +131,26 @@ VRF_HD void sha512_put_le32x8(Sha512& s, const uint32_t w[8]) {
     sha512_put(s, ((uint64_t)bswap32(w[2 * j]) << 32) | bswap32(w[2 * j + 1]), 8);
 }
 
+// N 64-bit big-endian words held in registers, appended at a position known only at run time (after a
+// descriptor-supplied suite string): ONE put site in a rolled loop, the word picked by a select chain, so the
+// block-boundary compression is instantiated once instead of once per word.
+template <int N>
+VRF_HD void sha512_put_words(Sha512& s, const uint64_t (&w)[N]) {
+#pragma unroll 1
+  for (int i = 0; i < N; ++i) {
+    uint64_t v = w[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j)
+      if (i == j) v = w[j];
+    sha512_put(s, v, 8);
+  }
+}
+// 32 bytes given as 8 little-endian u32 words -> the 4 big-endian message words
+VRF_HD void sha512_words_le32x8(uint64_t out[4], const uint32_t w[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[j] = ((uint64_t)bswap32(w[2 * j]) << 32) | bswap32(w[2 * j + 1]);
+}
+
 // raw bytes from memory (host or device pointer valid in the calling context)
 VRF_HD void sha512_put_bytes(Sha512& s, const uint8_t* p, uint32_t n) {
   uint32_t i = 0;

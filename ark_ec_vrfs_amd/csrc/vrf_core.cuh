@@ -42,43 +42,33 @@ struct DevTables {
 constexpr int WIN_ENTRIES = 8;                       // signed radix-16: |digit| in 1..8
 constexpr int WIN_TABLE_WORDS = WIN_ENTRIES * PTC_WORDS;   // 288 words = 1152 B per base
 
-// ------------------------------------------------------------------------ suite byte strings
+// ------------------------------------------------------------------------ suites
+// [ref src/lib.rs:16 `Suite`, :14 `suites`]  What is compiled in is the ARITHMETIC of a suite: the curve (a, d,
+// cofactor, r), whether it has the GLV endomorphism, how subgroup membership is decided and which hash-to-curve
+// construction runs.  Everything a `Suite` impl states as data -- SUITE_ID, the hash-to-curve DST, the generator
+// and the Pedersen blinding base -- comes from the context's descriptor (vrfhip_suite_desc): the byte strings
+// below, and the fixed-base tables built from the descriptor's points at context creation.
+struct SuiteStr {
+  uint32_t suite_id_len;       // <= 64
+  uint32_t dst_len;            // <= 128 (Elligator suites; unused by try-and-increment)
+  uint8_t suite_id[64];        // `Suite::SUITE_ID`
+  uint8_t dst[128];            // RFC 9380 DST: upstream "ECVRF_" || h2c suite id || SUITE_ID
+};
+
 struct SuiteBS : CurveBS {
   static constexpr bool HAS_GLV = true;        // Bandersnatch endomorphism (te_psi, glv_decompose_bs)
   static constexpr bool SUBGROUP_2DESCENT = true;   // E(Fq) = Z2 x Z2 x Zr: the prime-order subgroup is 2E
   static constexpr bool H2C_ELL2 = true;       // Input::new = Elligator 2 (else try-and-increment)
-  static constexpr int SUITE_ID_LEN = 25;
-  static VRF_HD uint8_t suite_id(int i) {
-    constexpr char s[] = "Bandersnatch_SHA-512_ELL2";
-    return (uint8_t)s[i];
-  }
-  static constexpr int DST_LEN = 64;
-  static VRF_HD uint8_t dst(int i) {
-    constexpr char s[] = "ECVRF_Bandersnatch_XMD:SHA-512_ELL2_RO_Bandersnatch_SHA-512_ELL2";
-    return (uint8_t)s[i];
-  }
 };
 
-// JubJub_SHA-512_TAI (suite string, TAI details and blinding base are [RECALL]-level,
-// parity unpinned): a = -1, cofactor 8, try-and-increment hash-to-curve, no GLV.
+// JubJub: a = -1, cofactor 8, try-and-increment hash-to-curve, no GLV.
 struct SuiteJJ : CurveJJ {
   static constexpr bool HAS_GLV = false;
   static constexpr bool SUBGROUP_2DESCENT = false;  // cofactor 8 with a point of order 4: check r*P = O
   static constexpr bool H2C_ELL2 = false;
-  static constexpr int SUITE_ID_LEN = 18;
-  static VRF_HD uint8_t suite_id(int i) {
-    constexpr char s[] = "JubJub_SHA-512_TAI";
-    return (uint8_t)s[i];
-  }
-  static constexpr int DST_LEN = 1;
-  static VRF_HD uint8_t dst(int) { return 0; }
 };
 
-template <class S>
-VRF_HD void put_suite_id(Sha512& h) {
-#pragma unroll
-  for (int i = 0; i < S::SUITE_ID_LEN; ++i) sha512_put_byte(h, S::suite_id(i));
-}
+VRF_HD void put_suite_id(Sha512& h, const SuiteStr& ss) { sha512_put_bytes(h, ss.suite_id, ss.suite_id_len); }
 
 // ------------------------------------------------------------------------ batch inversion
 template <int N, int L, int V>
@@ -147,7 +137,7 @@ VRF_HD bool decode_phase_b(Fe<1, 4>& x_out, const DecodeA& a, const FeN& den_inv
 // B v^2 = u (u - e2)(u - e3), u = (1 + y)/(1 - y), a point lies in 2E iff B u, B (u - e2), B (u - e3) are
 // squares.  Their product is a square, so two tests decide; cleared of the denominator 1 - y:
 //     B (1 - y^2)   and   B (1 - y) ((1 + e2) y + (1 - e2))   are non-zero squares   (or y = 1: identity).
-// Two fixed exponentiations (~0.12 M instructions) instead of r*P = O (~0.6 M).  [codec: arkworks'
+// Two Jacobi symbols (fe.cuh: ~0.04 M instruction slots) instead of r*P = O (~0.6 M).  [codec: arkworks'
 // checked deserialisation, `codec` src/lib.rs:14]; tests compare with r*P = O on every coset.
 template <class S>
 VRF_HD bool subgroup_by_2descent(const FeN& y, const SqrtTables& T) {
@@ -157,11 +147,14 @@ VRF_HD bool subgroup_by_2descent(const FeN& y, const SqrtTables& T) {
   const FeN t1 = fe_mul(fe_mul(omy, fe_add(one, y)), fe_const(vrfk::BS_DESC_B_M));    // B (1 - y^2)
   const auto lin = fe_norm(fe_add(fe_mul(y, fe_const(vrfk::BS_DESC_1PE2_M)), fe_const(vrfk::BS_DESC_1ME2_M)));
   const FeN t2 = fe_mul(fe_mul(omy, lin), fe_const(vrfk::BS_DESC_B_M));
-  FeN r;
-  const bool s1 = fe_sqrt_or_zsqrt(r, t1, T) && !fe_is_zero(t1);
-  const bool s2 = fe_sqrt_or_zsqrt(r, t2, T) && !fe_is_zero(t2);
+  const bool s1 = fe_is_nonzero_square(t1, T);
+  const bool s2 = fe_is_nonzero_square(t2, T);
   return is_identity || (s1 && s2);
 }
+
+// check_mask bits (= the complement of include/vrfhip.h VRFHIP_FLAG_PREVALIDATED_*): which point classes get
+// the prime-order-subgroup test when they are decoded
+enum : uint32_t { CHK_PUBLIC = 1, CHK_INPUT = 2, CHK_OUTPUT = 4, CHK_PROOF = 8 };
 
 // ------------------------------------------------------------------------ window tables
 // multiples 1..8 of an affine point, cached form, written to `tab` (WIN_TABLE_WORDS words).
@@ -294,6 +287,23 @@ VRF_HD PtE win_mul(const uint32_t* tab, const uint32_t rec[8], bool negate = fal
     acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != negate, w == 0);
   }
   return acc;
+}
+
+// Prime-order subgroup membership of a decoded point [ref src/lib.rs:14 `codec`: arkworks' checked
+// deserialisation].  Bandersnatch: 2-descent on y (two Jacobi symbols).  JubJub (cyclic 2-part Z8): r*P = O from
+// the point's window table `tab` (multiples 1..8, cached form) -- the test arkworks itself runs.
+template <class S>
+VRF_HD bool in_prime_subgroup(const FeN& y, const uint32_t* tab, const SqrtTables& T) {
+  if constexpr (S::SUBGROUP_2DESCENT) {
+    return subgroup_by_2descent<S>(y, T);
+  } else {
+    uint32_t r[8], rec[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = S::r32(j);
+    scalar_recode_signed4(rec, r);
+    PtE rp = win_mul<S>(tab, rec);
+    return fe_is_zero(rp.X) && fe_eq(rp.Y, rp.Z);
+  }
 }
 
 // ---- fixed-base tables of the suite's generators G and B: signed GCB-bit windows, no doublings ----
@@ -504,13 +514,15 @@ VRF_HD void comb_build_row(uint32_t* row /*[255][27]*/, uint32_t* prefix /*[255]
 // c = int_be(SHA512(suite_id || 0x02 || enc(P1..P5) || ad || 0x00)[0..32]) mod r
 template <class S>
 VRF_HD void challenge5(uint32_t c_out[8], const uint32_t (&pts)[5][8], const uint8_t* ad,
-                       uint32_t ad_len) {
+                       uint32_t ad_len, const SuiteStr& ss) {
   Sha512 h;
   sha512_init(h);
-  put_suite_id<S>(h);
+  put_suite_id(h, ss);
   sha512_put_byte(h, 0x02);
+  uint64_t w[20];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) sha512_put_le32x8(h, pts[i]);
+  for (int i = 0; i < 5; ++i) sha512_words_le32x8(w + 4 * i, pts[i]);
+  sha512_put_words(h, w);
   sha512_put_bytes(h, ad, ad_len);
   sha512_put_byte(h, 0x00);
   sha512_final(h);
@@ -535,7 +547,7 @@ constexpr int VERIFY_TABS = 6;   // Y, psi Y, H, psi H, Gamma, psi Gamma
 // tabs: 6 * WIN_TABLE_WORDS words (GLV table pairs of Y, H, Gamma).  Returns validity.
 template <class S>
 VRF_HD bool verify_decode_item(const DevTables& T, const uint32_t pk[8], const uint32_t hh[8],
-                               const uint32_t gamma[8], uint32_t* tabs) {
+                               const uint32_t gamma[8], uint32_t* tabs, uint32_t check_mask = 0) {
   DecodeA a0 = decode_phase_a<S>(pk), a1 = decode_phase_a<S>(hh), a2 = decode_phase_a<S>(gamma);
   FeN dens[3] = {a0.den, a1.den, a2.den}, dinv[3];
   fe_batch_inv(dinv, dens);
@@ -552,6 +564,7 @@ VRF_HD bool verify_decode_item(const DevTables& T, const uint32_t pk[8], const u
     Fe<1, 4> x;
     valid = decode_phase_b<S>(x, a, di, T.sq) && valid;
     build_glv_tables<S>(tabs + p * 2 * WIN_TABLE_WORDS, x, a.y);
+    if ((check_mask >> p) & 1u) valid = in_prime_subgroup<S>(a.y, tabs + p * 2 * WIN_TABLE_WORDS, T.sq) && valid;
   }
   return valid;
 }
@@ -569,7 +582,7 @@ constexpr int DEC_SLOT = 4 * NL;            // per point: y | num | den | prefix
 template <class S, int NP = 3>
 VRF_HD void verify_decode_multi(int K, const DevTables& T, size_t first, size_t n, const uint8_t* pk,
                                 const uint8_t* hh, const uint8_t* gamma, uint32_t* tabs_base,
-                                uint32_t* scratch_base, uint8_t* flags) {
+                                uint32_t* scratch_base, uint8_t* flags, uint32_t check_mask = 0) {
   // scratch: K * 108 words owned by this lane = 3K point slots of 36 words
   uint32_t* scr = scratch_base + first * (3 * DEC_SLOT);
   FeN run = fe_one();
@@ -613,8 +626,10 @@ VRF_HD void verify_decode_multi(int K, const DevTables& T, size_t first, size_t 
       inv = fe_mul(inv, a.den);
       Fe<1, 4> x;
       bool ok = decode_phase_b<S>(x, a, di, T.sq);
+      uint32_t* tab = tabs_base + item * (VERIFY_TABS * WIN_TABLE_WORDS) + p * 2 * WIN_TABLE_WORDS;
+      build_glv_tables<S>(tab, x, a.y);
+      if ((check_mask >> p) & 1u) ok = in_prime_subgroup<S>(a.y, tab, T.sq) && ok;    // bit p: pk, H, Gamma
       if (!ok) valid_mask &= ~(1u << (j / NP));
-      build_glv_tables<S>(tabs_base + item * (VERIFY_TABS * WIN_TABLE_WORDS) + p * 2 * WIN_TABLE_WORDS, x, a.y);
     }
   }
 #pragma unroll 1
@@ -629,7 +644,8 @@ VRF_HD void verify_finish_multi(int K, size_t first, size_t n, uint32_t* pts_bas
                                 const uint8_t* pk, const uint8_t* hh, const uint8_t* gamma,
                                 const uint32_t* enc_aux, int aux_stride, const uint8_t* c_arr,
                                 const uint8_t* s_arr, const BytesViewLite& ad, const uint8_t* flags,
-                                uint8_t* status, const uint32_t* key_index = nullptr, size_t n_keys = 0) {
+                                uint8_t* status, const SuiteStr& ss, const uint32_t* key_index = nullptr,
+                                size_t n_keys = 0) {
   FeN run = fe_one();
 #pragma unroll 1
   for (int j = 0; j < 2 * K; ++j) {
@@ -683,7 +699,7 @@ VRF_HD void verify_finish_multi(int K, size_t first, size_t n, uint32_t* pts_bas
         const uint8_t* adp; uint32_t adl;
         bytes_lite_get(ad, item, adp, adl);
         uint32_t c2[8];
-        challenge5<S>(c2, pts, adp, adl);
+        challenge5<S>(c2, pts, adp, adl, ss);
         uint32_t diff = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) diff |= c2[k] ^ c[k];
@@ -698,7 +714,8 @@ VRF_HD void verify_finish_multi(int K, size_t first, size_t n, uint32_t* pts_bas
 // 32-byte little-endian canonical integers, no square roots.  Validity = coordinates < q and the
 // point is on the curve.
 template <class S>
-VRF_HD bool verify_decode_affine_item(uint32_t enc_out[3][8], const uint32_t (&xy)[3][16], uint32_t* tabs) {
+VRF_HD bool verify_decode_affine_item(uint32_t enc_out[3][8], const uint32_t (&xy)[3][16], uint32_t* tabs,
+                                      const SqrtTables& T, uint32_t check_mask = 0) {
   bool valid = true;
 #pragma unroll 1
   for (int p = 0; p < 3; ++p) {
@@ -715,6 +732,7 @@ VRF_HD bool verify_decode_affine_item(uint32_t enc_out[3][8], const uint32_t (&x
     auto lhs = fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(S::mul_aneg(x2), fe_one())))));
     valid = fe_eq(lhs, fe_mul(fe_mul(fe_sqr(xyv), S::d()), fe_one())) && valid;
     build_glv_tables<S>(tabs + p * 2 * WIN_TABLE_WORDS, x, y);
+    if ((check_mask >> p) & 1u) valid = in_prime_subgroup<S>(y, tabs + p * 2 * WIN_TABLE_WORDS, T) && valid;
     uint32_t e[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[j] = yw[j];
@@ -791,7 +809,7 @@ template <class S>
 VRF_HD uint32_t verify_finish_item(const uint32_t* uv, const uint32_t pk[8], const uint32_t hh[8],
                                    const uint32_t gamma[8], const uint32_t c[8],
                                    const uint32_t s[8], bool valid, const uint8_t* ad,
-                                   uint32_t ad_len) {
+                                   uint32_t ad_len, const SuiteStr& ss) {
   valid = valid && fr_is_canonical<S>(c) && fr_is_canonical<S>(s);
   FeP zin[2] = {fe_load<1, 5>(uv + 2 * NL), fe_load<1, 5>(uv + UV_WORDS + 2 * NL)};
   FeN zi[2];
@@ -803,7 +821,7 @@ VRF_HD uint32_t verify_finish_item(const uint32_t* uv, const uint32_t pk[8], con
   te_encode_affine(pts[4], fe_mul(fe_load<1, 5>(uv + UV_WORDS), zi[1]),
                    fe_mul(fe_load<1, 5>(uv + UV_WORDS + NL), zi[1]));
   uint32_t c2[8];
-  challenge5<S>(c2, pts, ad, ad_len);
+  challenge5<S>(c2, pts, ad, ad_len, ss);
   uint32_t diff = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) diff |= c2[i] ^ c[i];
@@ -815,15 +833,13 @@ VRF_HD uint32_t verify_finish_item(const uint32_t* uv, const uint32_t pk[8], con
 // [ref src/lib.rs:15-16 `Input::new` -> utils::hash_to_curve_ell2_rfc_9380]  SURVEY.md A.3
 // expand_message_xmd(SHA-512) with arkworks' 48-byte Z_pad, two field elements, Elligator 2
 // on the Montgomery model, map to twisted Edwards, add, clear cofactor.
-template <class S>
-VRF_HD void put_dst_prime(Sha512& h) {
-#pragma unroll
-  for (int i = 0; i < S::DST_LEN; ++i) sha512_put_byte(h, S::dst(i));
-  sha512_put_byte(h, (uint8_t)S::DST_LEN);
+VRF_HD void put_dst_prime(Sha512& h, const SuiteStr& ss) {
+  sha512_put_bytes(h, ss.dst, ss.dst_len);
+  sha512_put_byte(h, (uint8_t)ss.dst_len);
 }
 
 template <class S>
-VRF_HD void hash_to_field2(Fe<1, 4>& u0, Fe<1, 4>& u1, const uint8_t* msg, uint32_t msg_len) {
+VRF_HD void hash_to_field2(Fe<1, 4>& u0, Fe<1, 4>& u1, const uint8_t* msg, uint32_t msg_len, const SuiteStr& ss) {
   Sha512 b0;
   sha512_init(b0);
 #pragma unroll
@@ -832,7 +848,7 @@ VRF_HD void hash_to_field2(Fe<1, 4>& u0, Fe<1, 4>& u1, const uint8_t* msg, uint3
   sha512_put_byte(b0, 0x00);
   sha512_put_byte(b0, 0x60);                             // len_in_bytes = 96
   sha512_put_byte(b0, 0x00);
-  put_dst_prime<S>(b0);
+  put_dst_prime(b0, ss);
   sha512_final(b0);
   uint64_t h0[8], h1[8];
 #pragma unroll
@@ -848,7 +864,7 @@ VRF_HD void hash_to_field2(Fe<1, 4>& u0, Fe<1, 4>& u1, const uint8_t* msg, uint3
 #pragma unroll
     for (int i = 0; i < 8; ++i) sha512_put(b, h0[i] ^ h1[i], 8);
     sha512_put_byte(b, (uint8_t)(t + 1));
-    put_dst_prime<S>(b);
+    put_dst_prime(b, ss);
     sha512_final(b);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -919,7 +935,7 @@ VRF_HD PtE ell2_map(const Fe<1, 4>& u, const FeN& Dinv, const SqrtTables& T) {
 template <class S>
 VRF_HD PtE hash_to_curve_ell2(const uint8_t* msg, uint32_t msg_len, const SqrtTables& T) {
   Fe<1, 4> u[2];
-  hash_to_field2<S>(u[0], u[1], msg, msg_len);
+  hash_to_field2<S>(u[0], u[1], msg, msg_len, *T.str);
   FeN D[2], Di[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -949,10 +965,10 @@ VRF_HD PtE hash_to_curve_ell2(const uint8_t* msg, uint32_t msg_len, const SqrtTa
 // cofactor; first non-identity result wins.  Lanes iterate until they succeed (about two trips).
 // candidate encoding of attempt `ctr`: the first 32 bytes of SHA512(suite_id || 0x01 || data || ctr || 0x00)
 template <class S>
-VRF_HD void tai_candidate(uint32_t enc[8], const uint8_t* msg, uint32_t msg_len, uint32_t ctr) {
+VRF_HD void tai_candidate(uint32_t enc[8], const uint8_t* msg, uint32_t msg_len, uint32_t ctr, const SuiteStr& ss) {
   Sha512 h;
   sha512_init(h);
-  put_suite_id<S>(h);
+  put_suite_id(h, ss);
   sha512_put_byte(h, 0x01);
   sha512_put_bytes(h, msg, msg_len);
   sha512_put_byte(h, (uint8_t)ctr);
@@ -967,7 +983,7 @@ VRF_HD void tai_candidate(uint32_t enc[8], const uint8_t* msg, uint32_t msg_len,
 template <class S>
 VRF_HD bool tai_attempt_decodes(const uint8_t* msg, uint32_t msg_len, uint32_t ctr, const SqrtTables& T) {
   uint32_t enc[8];
-  tai_candidate<S>(enc, msg, msg_len, ctr);
+  tai_candidate<S>(enc, msg, msg_len, ctr, *T.str);
   DecodeA a = decode_phase_a<S>(enc);
   FeN root;
   bool sq = fe_sqrt_or_zsqrt(root, fe_mul(a.num, a.den), T);
@@ -983,7 +999,7 @@ VRF_HD PtE hash_to_curve_tai(const uint8_t* msg, uint32_t msg_len, const SqrtTab
 #pragma unroll 1
   for (uint32_t ctr = start; ctr < 256 && !done; ++ctr) {
     uint32_t enc[8];
-    tai_candidate<S>(enc, msg, msg_len, ctr);
+    tai_candidate<S>(enc, msg, msg_len, ctr, *T.str);
     DecodeA a = decode_phase_a<S>(enc);
     FeN di = fe_inv(a.den);
     Fe<1, 4> x;
@@ -1057,13 +1073,15 @@ constexpr int PROVE_PTS_WORDS = 4 * UV_WORDS;   // [half][win|comb][X,Y,Z]
 // b = int_be(SHA512(suite_id || 0xCC || sk_le32 || enc(H) || ad || 0x00)) mod r  (all 64 bytes)
 template <class S>
 VRF_HD void pedersen_blinding(uint32_t b[8], const uint32_t sk[8], const uint32_t h_enc[8],
-                              const uint8_t* ad, uint32_t ad_len) {
+                              const uint8_t* ad, uint32_t ad_len, const SuiteStr& ss) {
   Sha512 h;
   sha512_init(h);
-  put_suite_id<S>(h);
+  put_suite_id(h, ss);
   sha512_put_byte(h, 0xCC);
-  sha512_put_le32x8(h, sk);
-  sha512_put_le32x8(h, h_enc);
+  uint64_t w[8];
+  sha512_words_le32x8(w, sk);
+  sha512_words_le32x8(w + 4, h_enc);
+  sha512_put_words(h, w);
   sha512_put_bytes(h, ad, ad_len);
   sha512_put_byte(h, 0x00);
   sha512_final(h);
@@ -1075,7 +1093,7 @@ VRF_HD void pedersen_blinding(uint32_t b[8], const uint32_t sk[8], const uint32_
 template <class S>
 VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, const DevTables& T,
                                const uint32_t sk[8], const uint8_t* msg, uint32_t msg_len,
-                               const uint32_t* h_given, uint32_t tai_start = 0) {
+                               const uint32_t* h_given, uint32_t tai_start = 0, uint32_t check_mask = 0) {
   FeN x, y;
   bool valid = fr_is_canonical<S>(sk);
   if (h_given) {
@@ -1092,6 +1110,7 @@ VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, 
   te_encode_affine(h_enc, x, y);
   nonce_rfc8032<S>(k, sk, h_enc);
   build_glv_tables<S>(tab, x, y);          // {H, psi H}: 2 * WIN_TABLE_WORDS
+  if (h_given && (check_mask & CHK_INPUT)) valid = in_prime_subgroup<S>(y, tab, T.sq) && valid;   // a given H is wire data
   return valid;
 }
 
@@ -1113,7 +1132,7 @@ VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t 
       const uint8_t* m; uint32_t len;
       bytes_lite_get(msgs, item, m, len);
       Fe<1, 4> u0, u1;
-      hash_to_field2<S>(u0, u1, m, len);
+      hash_to_field2<S>(u0, u1, m, len, *T.sq.str);
       uint32_t* slot = pts_base + item * PROVE_PTS_WORDS;
 #pragma unroll 1
       for (int t = 0; t < 2; ++t) {
@@ -1229,7 +1248,7 @@ VRF_HD void prove_finish_item(uint32_t gamma_out[8], uint32_t c_out[8], uint32_t
                               uint32_t pk_out[8], uint32_t r_out[8], uint32_t ok_out[8],
                               const uint32_t* pts_in, const uint32_t h_enc[8],
                               const uint32_t sk[8], const uint32_t k[8], const uint8_t* ad,
-                              uint32_t ad_len) {
+                              uint32_t ad_len, const SuiteStr& ss) {
   FeP zin[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) zin[i] = fe_load<1, 5>(pts_in + i * UV_WORDS + 2 * NL);
@@ -1260,7 +1279,7 @@ VRF_HD void prove_finish_item(uint32_t gamma_out[8], uint32_t c_out[8], uint32_t
     pts[4][j] = enc[2][j];      // k*H
   }
   uint32_t c[8], cs[8], s[8];
-  challenge5<S>(c, pts, ad, ad_len);
+  challenge5<S>(c, pts, ad, ad_len, ss);
   fr_mul<S>(cs, c, sk);
   fr_add<S>(s, cs, k);
 #pragma unroll
@@ -1289,7 +1308,7 @@ VRF_HD FeN fe_sel5(int p, const FeN (&a)[5]) {
 template <class S>
 VRF_HD bool pedersen_verify_decode_item(uint32_t c_out[8], const DevTables& T,
                                         const uint32_t (&enc)[5][8], const uint8_t* ad,
-                                        uint32_t ad_len, uint32_t* tabs, uint32_t* pts) {
+                                        uint32_t ad_len, uint32_t* tabs, uint32_t* pts, uint32_t check_mask = 0) {
   FeN ys[5], dens[5], dinv[5];
   Fe<1, 6> nums[5];
   bool flags[5], oks[5];
@@ -1312,12 +1331,23 @@ VRF_HD bool pedersen_verify_decode_item(uint32_t c_out[8], const DevTables& T,
     FeN di = fe_sel5(p, dinv);
     Fe<1, 4> x;
     valid = decode_phase_b<S>(x, a, di, T.sq) && valid;
+    // check_mask: H is an input, Gamma an output, pk_com / R / Ok proof points
+    const bool chk = (check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF)) != 0;
     if (p < 3) {
-      build_glv_tables<S>(tabs + p * 2 * WIN_TABLE_WORDS, x, a.y);
+      uint32_t* tab = tabs + p * 2 * WIN_TABLE_WORDS;
+      build_glv_tables<S>(tab, x, a.y);
+      if (chk) valid = in_prime_subgroup<S>(a.y, tab, T.sq) && valid;
     } else {
       uint32_t* dst = pts + (p == 3 ? PED_R_OFF : PED_OK_OFF);
       fe_store(dst, x);
       fe_store(dst + NL, a.y);
+      if (chk) {
+        // R and Ok have no Straus table; suites without the 2-descent borrow the odd table slots (unused
+        // without an endomorphism) for the r*P = O test
+        uint32_t* tab = tabs + (p == 3 ? 1 : 3) * WIN_TABLE_WORDS;
+        if constexpr (!S::SUBGROUP_2DESCENT) build_win_table_from<S>(tab, te_from_affine(x, a.y));
+        valid = in_prime_subgroup<S>(a.y, tab, T.sq) && valid;
+      }
     }
   }
   uint32_t cp[5][8];
@@ -1325,7 +1355,7 @@ VRF_HD bool pedersen_verify_decode_item(uint32_t c_out[8], const DevTables& T,
   for (int j = 0; j < 8; ++j) {
     cp[0][j] = enc[2][j]; cp[1][j] = enc[0][j]; cp[2][j] = enc[1][j]; cp[3][j] = enc[3][j]; cp[4][j] = enc[4][j];
   }
-  challenge5<S>(c_out, cp, ad, ad_len);
+  challenge5<S>(c_out, cp, ad, ad_len, *T.sq.str);
   return valid;
 }
 
@@ -1441,7 +1471,8 @@ VRF_HD void prove_encode_multi(int K, size_t first, size_t n, const uint32_t* pt
 // challenge + response from already encoded points: enc = [sk*H, pk(_com), k*H, R]
 template <class S>
 VRF_HD void prove_respond_item(uint32_t c_out[8], uint32_t s_out[8], const uint32_t* enc, const uint32_t h_enc[8],
-                               const uint32_t sk[8], const uint32_t k[8], const uint8_t* ad, uint32_t ad_len) {
+                               const uint32_t sk[8], const uint32_t k[8], const uint8_t* ad, uint32_t ad_len,
+                               const SuiteStr& ss) {
   uint32_t pts[5][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -1452,7 +1483,7 @@ VRF_HD void prove_respond_item(uint32_t c_out[8], uint32_t s_out[8], const uint3
     pts[4][j] = enc[16 + j];      // k*H
   }
   uint32_t cs[8];
-  challenge5<S>(c_out, pts, ad, ad_len);
+  challenge5<S>(c_out, pts, ad, ad_len, ss);
   fr_mul<S>(cs, c_out, sk);
   fr_add<S>(s_out, cs, k);
 }
@@ -1460,12 +1491,14 @@ VRF_HD void prove_respond_item(uint32_t c_out[8], uint32_t s_out[8], const uint3
 // [ref src/lib.rs:15 `Output::hash` / utils::point_to_hash_rfc_9381]  SURVEY.md A.4:
 // beta = SHA512(suite_id || 0x03 || enc(Gamma) || 0x00)   (no cofactor multiplication)
 template <class S>
-VRF_HD void output_hash_item(uint32_t out16[16], const uint32_t gamma[8]) {
+VRF_HD void output_hash_item(uint32_t out16[16], const uint32_t gamma[8], const SuiteStr& ss) {
   Sha512 h;
   sha512_init(h);
-  put_suite_id<S>(h);
+  put_suite_id(h, ss);
   sha512_put_byte(h, 0x03);
-  sha512_put_le32x8(h, gamma);
+  uint64_t w[4];
+  sha512_words_le32x8(w, gamma);
+  sha512_put_words(h, w);
   sha512_put_byte(h, 0x00);
   sha512_final(h);
 #pragma unroll

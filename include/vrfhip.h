@@ -21,10 +21,12 @@
  *  - Thread safety: a context may be shared; calls on one context serialise internally.
  *    A context owns ONE workspace: `*_dev` calls on the same context must all be enqueued on the
  *    same stream (or be ordered by the caller's events); for concurrent streams use one context each.
- *  - Precondition (as for the reference's `AffinePoint` values, which arkworks validates on
- *    deserialisation): input points lie in the prime-order subgroup.  Undecodable encodings
- *    and non-canonical scalars are reported as InvalidData; subgroup membership is checked by
- *    vrfhip_point_validate_batch (`codec`), not inside verify.
+ *  - Points are wire data: every verify entry point (and prove with a given input point) decodes them with
+ *    the semantics of arkworks' checked deserialisation, which is what `codec::point_decode` applies before a
+ *    `Public` / `Input` / `Output` / proof value exists (src/lib.rs:14): on the curve AND in the prime-order
+ *    subgroup.  A point that fails either test, and a non-canonical scalar, give InvalidData.  A caller that
+ *    holds already validated points (typed arkworks values, an `Input` it hashed itself) can switch the
+ *    subgroup test off per point class with vrfhip_ctx_set_flags.
  */
 #ifndef VRFHIP_H
 #define VRFHIP_H
@@ -43,10 +45,36 @@ extern "C" {
 typedef enum vrfhip_suite {
   VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2 = 1, /* `suites::bandersnatch` (src/lib.rs:14) */
   /* `suites::jubjub`: a = -1, cofactor 8, try-and-increment hash-to-curve.  Suite string, TAI
-   * details and the Pedersen blinding base are recollections: parity unpinned;
-   * the blinding base is the TAI hash of "vrfhip-jubjub-blinding-base". */
+   * details and the Pedersen blinding base are recollections: parity unpinned.  The built-in
+   * descriptor uses the suite string "JubJub_SHA-512_TAI" and, as blinding base, the TAI hash of
+   * "vrfhip-jubjub-blinding-base" -- a caller that knows the upstream constants supplies them through
+   * vrfhip_ctx_create_desc. */
   VRFHIP_SUITE_JUBJUB_SHA512_TAI = 2
 } vrfhip_suite;
+
+/* Suite descriptor: what a `Suite` / `PedersenSuite` impl states as DATA (src/lib.rs:16 `Suite`, :14 `suites`):
+ * `Suite::SUITE_ID`, the hash-to-curve domain separation tag, `Suite::generator()` and
+ * `PedersenSuite::BLINDING_BASE`.  The arithmetic (field, curve coefficients, cofactor, subgroup order, hash-to-curve
+ * construction, endomorphism) is compiled per `curve`.  Lets a caller run a suite whose constants this library does not
+ * carry -- in particular the upstream JubJub suite string and blinding base, which could not be authenticated here
+ *  -- and makes the built-in suites nothing more than two pre-filled descriptors. */
+typedef enum vrfhip_curve {
+  VRFHIP_CURVE_BANDERSNATCH = 1, /* ark-ed-on-bls12-381-bandersnatch: a = -5, cofactor 4; Elligator 2 (RFC 9380) */
+  VRFHIP_CURVE_JUBJUB = 2        /* ark-ed-on-bls12-381 (JubJub): a = -1, cofactor 8; try-and-increment (RFC 9381) */
+} vrfhip_curve;
+
+typedef struct vrfhip_suite_desc {
+  uint32_t struct_size;      /* sizeof(vrfhip_suite_desc) of the caller's header */
+  int32_t curve;             /* vrfhip_curve; it also fixes the hash-to-curve construction (see the enum) */
+  uint32_t suite_id_len;     /* 1..64 */
+  uint8_t suite_id[64];      /* `Suite::SUITE_ID` */
+  uint32_t h2c_dst_len;      /* Bandersnatch: 1..128, the RFC 9380 DST (upstream: "ECVRF_" || h2c suite id || SUITE_ID);
+                                JubJub: ignored */
+  uint8_t h2c_dst[128];
+  uint8_t generator[64];     /* `Suite::generator()`: x || y, 32-byte little-endian canonical integers */
+  uint8_t blinding_base[64]; /* `PedersenSuite::BLINDING_BASE`, same form */
+  uint32_t challenge_len;    /* `Suite::CHALLENGE_LEN`; 32 is the only supported value */
+} vrfhip_suite_desc;
 
 typedef enum vrfhip_status {
   VRFHIP_ST_OK = 0,
@@ -79,6 +107,28 @@ const char* vrfhip_last_error(void);
  * Replaces the compile-time `Suite` selection (src/lib.rs:16). */
 int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out);
 void vrfhip_ctx_destroy(vrfhip_ctx* ctx);
+
+/* The built-in descriptor of `suite` (what vrfhip_ctx_create uses); a caller edits the fields it wants to replace. */
+int32_t vrfhip_suite_desc_default(vrfhip_suite suite, vrfhip_suite_desc* out);
+/* Create a context from a descriptor.  VRFHIP_ERR_BAD_ARG if a length is out of range or the generator / blinding
+ * base is not a non-identity point of the curve's prime-order subgroup (checked on the device);
+ * VRFHIP_ERR_UNSUPPORTED for an unknown curve or challenge length. */
+int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vrfhip_ctx** out);
+/* The descriptor a context was created from. */
+int32_t vrfhip_ctx_get_desc(const vrfhip_ctx* ctx, vrfhip_suite_desc* out);
+
+/* Which point classes the caller vouches for (prime-order subgroup membership already established, e.g. typed
+ * arkworks values or an input point the caller hashed itself): their subgroup test is skipped; the on-curve
+ * test always runs.  Default 0: everything is checked, as arkworks' deserialisation does.  Skipping the test on
+ * attacker-supplied bytes breaks VRF uniqueness (an output shifted by a 2-torsion point verifies with an even
+ * challenge) and voids the bound of the batched Pedersen verifier. */
+#define VRFHIP_FLAG_PREVALIDATED_PUBLIC 1u /* `Public` (pk of the IETF verifier) */
+#define VRFHIP_FLAG_PREVALIDATED_INPUT 2u  /* `Input` (H) */
+#define VRFHIP_FLAG_PREVALIDATED_OUTPUT 4u /* `Output` (Gamma) */
+#define VRFHIP_FLAG_PREVALIDATED_PROOF 8u  /* `pedersen::Proof` points pk_com, R, Ok */
+#define VRFHIP_FLAG_PREVALIDATED_ALL 15u
+int32_t vrfhip_ctx_set_flags(vrfhip_ctx* ctx, uint32_t flags);
+uint32_t vrfhip_ctx_get_flags(const vrfhip_ctx* ctx);
 
 /* Size the internal HBM workspace for exactly `max_items` items per launch group (optional).
  * Larger batches are processed in chunks of `max_items`.  Without this call the workspace
@@ -209,12 +259,11 @@ int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_
  * is the neutral element, (z_i, z'_i) = 2 x 128 bits of SHA-512("vrfhip-rlc-v1" || seed || u64_le(i)), each forced to 1 (mod 8).
  * `seed` (32 bytes, host memory) must be unpredictable to the provers (fresh randomness per call);
  * a batch holding an invalid proof is then accepted with probability <= 2^-128.
- * The bound holds under the precondition of every verify entry point -- all five points of every proof lie in
- * the prime-order subgroup, as arkworks' checked deserialisation guarantees for the reference's typed values
- * (vrfhip_point_validate_batch for raw bytes).  It is NOT a courtesy here: a defect of small order (a proof
- * point shifted by a 2- or 4-torsion point) is annihilated by a weight divisible by its order, so unvalidated
- * points could pass the batch equation although the per-proof check rejects them.  Weights are 1 (mod 8), so
- * a single such proof is always caught; two colluding proofs whose small-order defects cancel are not.
+ * The bound needs all five points of every proof in the prime-order subgroup, which the decode stage checks
+ * (InvalidData otherwise) unless the caller vouched for them with vrfhip_ctx_set_flags.  With PREVALIDATED
+ * flags set on unvalidated bytes the bound is void: a defect of small order (a proof point shifted by a 2- or
+ * 4-torsion point) is annihilated by a weight divisible by its order.  Weights are 1 (mod 8), so a single such
+ * proof is still caught; two colluding proofs whose small-order defects cancel are not.
  *
  * _dev form: enqueues the work and returns.  d_status[i] = 0 if proof i is part of the batch sum,
  * 2 (InvalidData) if it does not decode (it is then left out of the sum).  d_fail_flag[0] = 0 if every
@@ -279,7 +328,7 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
  * later calls with the same pair reuse them.
  * An all-zero encoding is the point at infinity.  status[i]: 0 = product is one,
  * 1 = VerificationFailure, 2 = InvalidData (coordinate >= p or point off its curve).
- * Subgroup membership of the inputs is the caller's precondition, as for arkworks' prepared
+ * Subgroup membership of the G1 / G2 inputs is the caller's precondition, as for arkworks' prepared
  * points. */
 int32_t vrfhip_pairing_check_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2,
                                    int32_t g2_shared, uint8_t* status);
@@ -323,6 +372,10 @@ int32_t vrfhip_point_validate_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t
  * 48 bytes, little-endian (reduced mod p by the loader).  status[i] = bit mask of differing operations
  * (1 mul, 2 sqr, 4 cyclotomic sqr, 8 mul_by_014, 16 frobenius, 32 conj / gather-scatter); 0 = all equal. */
 int32_t vrfhip_test_pairing_quad_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp12_pairs, uint8_t* status);
+
+/* Test-only: how many proofs one lane of the inversion-sharing stages (decode, finish, prepare) handles for a
+ * launch group of n items (1, 2, 4 or 8): lets the parity tests assert that every kernel variant was exercised. */
+int32_t vrfhip_debug_proofs_per_lane(size_t n);
 
 /* Test-only primitive: r[i] = a[i] * b[i] mod q on n x 32 B little-endian field elements
  * (exercises ark_ff::Fp mul through the 29-bit Montgomery pipeline). */

@@ -35,9 +35,11 @@ typedef struct {
   field fr;                      /* scalar field */
   fp d, a, gx, gy, bx, by;       /* curve a x^2 + y^2 = 1 + d x^2 y^2, generator, blinding base */
   const char* suite_id; size_t suite_id_len;
+  const char* h2c_dst; size_t h2c_dst_len;     /* RFC 9380 DST (Elligator suites) */
   int h2c_tai, cofactor_log2;
 } suite_t;
-static suite_t SUITE_BS, SUITE_JJ;
+static suite_t SUITE_BS, SUITE_JJ, SUITE_CUSTOM;
+static char CUSTOM_ID[64], CUSTOM_DST[128];
 static suite_t* S_ = &SUITE_BS;   /* current suite (tests select it with oracle_set_suite) */
 #define FR (S_->fr)
 #define BS_D_M (S_->d)
@@ -347,6 +349,7 @@ static void do_init(void) {
   q_from_int(&SUITE_BS.gx, P_BS_GX); q_from_int(&SUITE_BS.gy, P_BS_GY);
   q_from_int(&SUITE_BS.bx, P_BS_BX); q_from_int(&SUITE_BS.by, P_BS_BY);
   SUITE_BS.suite_id = "Bandersnatch_SHA-512_ELL2"; SUITE_BS.suite_id_len = 25; SUITE_BS.h2c_tai = 0; SUITE_BS.cofactor_log2 = 2;
+  SUITE_BS.h2c_dst = H2C_DST; SUITE_BS.h2c_dst_len = 64;
   field_init(&SUITE_JJ.fr, P_JJ_R_ORDER);
   q_from_int(&SUITE_JJ.d, P_JJ_D); q_neg(&SUITE_JJ.a, &fone);
   q_from_int(&SUITE_JJ.gx, P_JJ_GX); q_from_int(&SUITE_JJ.gy, P_JJ_GY);
@@ -414,15 +417,16 @@ static int hash_to_curve_tai(pt* out, const uint8_t* msg, size_t len) {
 }
 static void hash_to_curve(pt* out, const uint8_t* msg, size_t len) {
   if (S_->h2c_tai) { hash_to_curve_tai(out, msg, len); return; }
-  uint8_t dstp[65]; memcpy(dstp, H2C_DST, 64); dstp[64] = 64;
+  uint8_t dstp[129]; const size_t dl = S_->h2c_dst_len;
+  memcpy(dstp, S_->h2c_dst, dl); dstp[dl] = (uint8_t)dl;
   uint8_t zpad[48] = {0}, lib[3] = {0x00, 0x60, 0x00}, b0[64], b1[64], b2[64], x[64];
   sha512_ctx c;
   sha512_init(&c); sha512_update(&c, zpad, 48); sha512_update(&c, msg, len); sha512_update(&c, lib, 3);
-  sha512_update(&c, dstp, 65); sha512_final(&c, b0);
+  sha512_update(&c, dstp, dl + 1); sha512_final(&c, b0);
   uint8_t one = 1, two = 2;
-  sha512_init(&c); sha512_update(&c, b0, 64); sha512_update(&c, &one, 1); sha512_update(&c, dstp, 65); sha512_final(&c, b1);
+  sha512_init(&c); sha512_update(&c, b0, 64); sha512_update(&c, &one, 1); sha512_update(&c, dstp, dl + 1); sha512_final(&c, b1);
   for (int i = 0; i < 64; ++i) x[i] = b0[i] ^ b1[i];
-  sha512_init(&c); sha512_update(&c, x, 64); sha512_update(&c, &two, 1); sha512_update(&c, dstp, 65); sha512_final(&c, b2);
+  sha512_init(&c); sha512_update(&c, x, 64); sha512_update(&c, &two, 1); sha512_update(&c, dstp, dl + 1); sha512_final(&c, b2);
   uint8_t uni[96]; memcpy(uni, b1, 64); memcpy(uni + 64, b2, 32);
   fp u[2];
   for (int k = 0; k < 2; ++k) {              /* 48-byte big-endian integer mod q, Horner */
@@ -451,8 +455,42 @@ static void challenge(uint64_t c_out[4], const uint8_t pts[5][32], const uint8_t
   r_from_bytes_wide(c_out, h, 32, 1);
 }
 
+/* Checked deserialisation [ref src/lib.rs:14 `codec`: arkworks validates on-curve AND subgroup membership when
+ * `Public` / `Input` / `Output` / proof points are decoded].  g_check_mask selects which point classes get the
+ * r*P == O test (bits as include/vrfhip.h VRFHIP_FLAG_PREVALIDATED_*: 1 public key, 2 input, 4 output, 8 proof
+ * points); 0 = on-curve only (the caller vouches for the subgroup).  Default: everything checked, as upstream. */
+static int g_check_mask = 15;
+static void pt_mul(pt* r, const pt* p, const uint64_t k[4]);
+static int point_decode_chk(fp* x, fp* y, const uint8_t in[32], int bit) {
+  if (!point_decode(x, y, in)) return 0;
+  if (g_check_mask & bit) {
+    pt p, rp; pt_from_affine(&p, x, y); pt_mul(&rp, &p, FR.m);
+    if (!pt_is_identity(&rp)) return 0;
+  }
+  return 1;
+}
+
 /* ------------------------------------------------------------------ exported API */
 /* 1 = Bandersnatch_SHA-512_ELL2 (default), 2 = JubJub_SHA-512_TAI.  Process-global: tests only. */
+void oracle_set_check_mask(int mask) { g_check_mask = mask; }
+/* A suite from a descriptor (include/vrfhip.h vrfhip_suite_desc): curve 1 = Bandersnatch (Elligator 2), 2 = JubJub
+ * (try-and-increment); suite string, hash-to-curve DST, generator and blinding base (x || y, 32-byte little-endian)
+ * supplied by the caller.  Selects it as the current suite.  Returns -1 on a bad argument (the points are not
+ * validated here: the product does that). */
+int oracle_set_suite_desc(int curve, const uint8_t* suite_id, size_t id_len, const uint8_t* dst, size_t dst_len,
+                          const uint8_t g_xy[64], const uint8_t b_xy[64]) {
+  ensure_init();
+  if ((curve != 1 && curve != 2) || id_len == 0 || id_len > sizeof CUSTOM_ID || dst_len > sizeof CUSTOM_DST) return -1;
+  SUITE_CUSTOM = curve == 1 ? SUITE_BS : SUITE_JJ;
+  memcpy(CUSTOM_ID, suite_id, id_len); SUITE_CUSTOM.suite_id = CUSTOM_ID; SUITE_CUSTOM.suite_id_len = id_len;
+  if (dst_len) memcpy(CUSTOM_DST, dst, dst_len);
+  SUITE_CUSTOM.h2c_dst = CUSTOM_DST; SUITE_CUSTOM.h2c_dst_len = dst_len;
+  uint64_t t[4];
+  load_le(t, g_xy); q_from_int(&SUITE_CUSTOM.gx, t); load_le(t, g_xy + 32); q_from_int(&SUITE_CUSTOM.gy, t);
+  load_le(t, b_xy); q_from_int(&SUITE_CUSTOM.bx, t); load_le(t, b_xy + 32); q_from_int(&SUITE_CUSTOM.by, t);
+  S_ = &SUITE_CUSTOM;
+  return 0;
+}
 int oracle_set_suite(int id) {
   ensure_init();
   if (id == 1) S_ = &SUITE_BS; else if (id == 2) S_ = &SUITE_JJ; else return -1;
@@ -503,7 +541,7 @@ int oracle_ietf_prove(const uint8_t sk_le[32], const uint8_t* msg, size_t msg_le
   pt H, G, Gm, PK, KG, KH; fp x, y;
   uint8_t pts[5][32];
   if (h_given) {
-    if (!point_decode(&x, &y, h_given)) return 2;
+    if (!point_decode_chk(&x, &y, h_given, 2)) return 2;
     pt_from_affine(&H, &x, &y); memcpy(pts[1], h_given, 32);
   }
   else { hash_to_curve(&H, msg, msg_len); pt_to_affine(&x, &y, &H); point_encode(pts[1], &x, &y); pt_from_affine(&H, &x, &y); }
@@ -528,11 +566,11 @@ int oracle_ietf_verify(const uint8_t pk[32], const uint8_t h[32], const uint8_t 
   load_le(c, c_le); load_le(s, s_le);
   if (cmp4(c, FR.m) >= 0 || cmp4(s, FR.m) >= 0) return 2;
   fp x, y; pt Y, H, Gm, G, sG, cY, sH, cG, U, V, n;
-  if (!point_decode(&x, &y, pk)) return 2;
+  if (!point_decode_chk(&x, &y, pk, 1)) return 2;
   pt_from_affine(&Y, &x, &y);
-  if (!point_decode(&x, &y, h)) return 2;
+  if (!point_decode_chk(&x, &y, h, 2)) return 2;
   pt_from_affine(&H, &x, &y);
-  if (!point_decode(&x, &y, gamma)) return 2;
+  if (!point_decode_chk(&x, &y, gamma, 4)) return 2;
   pt_from_affine(&Gm, &x, &y);
   pt_from_affine(&G, &BS_GX_M, &BS_GY_M);
   pt_mul(&sG, &G, s); pt_mul(&cY, &Y, c); pt_neg(&n, &cY); pt_add(&U, &sG, &n);
@@ -562,7 +600,7 @@ int oracle_pedersen_prove(const uint8_t sk_le[32], const uint8_t* msg, size_t ms
   pt H, G, B, t0, t1, P; fp x, y;
   uint8_t pts[5][32];
   if (h_given) {
-    if (!point_decode(&x, &y, h_given)) return 2;
+    if (!point_decode_chk(&x, &y, h_given, 2)) return 2;
     memcpy(pts[1], h_given, 32);
   } else { hash_to_curve(&H, msg, msg_len); pt_to_affine(&x, &y, &H); point_encode(pts[1], &x, &y); }
   pt_from_affine(&H, &x, &y);
@@ -591,15 +629,15 @@ int oracle_pedersen_verify(const uint8_t h[32], const uint8_t gamma[32], const u
   load_le(s, proof160 + 96); load_le(sb, proof160 + 128);
   if (cmp4(s, FR.m) >= 0 || cmp4(sb, FR.m) >= 0) return 2;
   fp x, y; pt H, Gm, PC, R, Ok, G, B, l, r1, t0, t1;
-  if (!point_decode(&x, &y, h)) return 2;
+  if (!point_decode_chk(&x, &y, h, 2)) return 2;
   pt_from_affine(&H, &x, &y);
-  if (!point_decode(&x, &y, gamma)) return 2;
+  if (!point_decode_chk(&x, &y, gamma, 4)) return 2;
   pt_from_affine(&Gm, &x, &y);
-  if (!point_decode(&x, &y, proof160)) return 2;
+  if (!point_decode_chk(&x, &y, proof160, 8)) return 2;
   pt_from_affine(&PC, &x, &y);
-  if (!point_decode(&x, &y, proof160 + 32)) return 2;
+  if (!point_decode_chk(&x, &y, proof160 + 32, 8)) return 2;
   pt_from_affine(&R, &x, &y);
-  if (!point_decode(&x, &y, proof160 + 64)) return 2;
+  if (!point_decode_chk(&x, &y, proof160 + 64, 8)) return 2;
   pt_from_affine(&Ok, &x, &y);
   uint8_t pts[5][32];
   memcpy(pts[0], proof160, 32); memcpy(pts[1], h, 32); memcpy(pts[2], gamma, 32);
@@ -704,15 +742,15 @@ int oracle_pedersen_rlc_check(size_t n, const uint8_t* h, const uint8_t* gamma, 
     load_le(s, pr + 96); load_le(sb, pr + 128);
     fp x, y; pt H, Gm, PC, R, Ok;
     int ok = cmp4(s, FR.m) < 0 && cmp4(sb, FR.m) < 0;
-    ok = ok && point_decode(&x, &y, h + 32 * i);
+    ok = ok && point_decode_chk(&x, &y, h + 32 * i, 2);
     if (ok) pt_from_affine(&H, &x, &y);
-    ok = ok && point_decode(&x, &y, gamma + 32 * i);
+    ok = ok && point_decode_chk(&x, &y, gamma + 32 * i, 4);
     if (ok) pt_from_affine(&Gm, &x, &y);
-    ok = ok && point_decode(&x, &y, pr);
+    ok = ok && point_decode_chk(&x, &y, pr, 8);
     if (ok) pt_from_affine(&PC, &x, &y);
-    ok = ok && point_decode(&x, &y, pr + 32);
+    ok = ok && point_decode_chk(&x, &y, pr + 32, 8);
     if (ok) pt_from_affine(&R, &x, &y);
-    ok = ok && point_decode(&x, &y, pr + 64);
+    ok = ok && point_decode_chk(&x, &y, pr + 64, 8);
     if (ok) pt_from_affine(&Ok, &x, &y);
     status[i] = ok ? 0 : 2;
     if (!ok) continue;

@@ -45,6 +45,9 @@ def load() -> ctypes.CDLL:
         lib.oracle_point_decode.restype = c_int
         lib.oracle_fq_mul.argtypes = [P, P, P]
         lib.oracle_sha512.argtypes = [P, c_size_t, P]
+        lib.oracle_set_suite_desc.argtypes = [c_int, P, c_size_t, P, c_size_t, P, P]
+        lib.oracle_set_suite_desc.restype = c_int
+        lib.oracle_set_check_mask.argtypes = [c_int]
         _lib = lib
     return _lib
 
@@ -53,6 +56,23 @@ def set_suite(suite_id: int) -> None:
     """1 = Bandersnatch_SHA-512_ELL2 (default), 2 = JubJub_SHA-512_TAI (process-global selection)."""
     if load().oracle_set_suite(int(suite_id)) != 0:
         raise ValueError("unknown suite")
+
+
+def set_suite_desc(curve: int, suite_id: bytes, h2c_dst: bytes, g_xy: bytes, b_xy: bytes) -> None:
+    """Select a suite given as a descriptor (the fields of include/vrfhip.h vrfhip_suite_desc): curve 1 = Bandersnatch,
+    2 = JubJub; g_xy / b_xy = generator / blinding base as x || y, 32-byte little-endian.  set_suite(1) goes back."""
+    a = lambda b: np.frombuffer(bytes(b) + b"\0", np.uint8)
+    sid, dst, g, bb = a(suite_id), a(h2c_dst), a(g_xy), a(b_xy)
+    assert len(g_xy) == 64 and len(b_xy) == 64
+    if load().oracle_set_suite_desc(int(curve), sid.ctypes.data, len(suite_id), dst.ctypes.data, len(h2c_dst),
+                                    g.ctypes.data, bb.ctypes.data) != 0:
+        raise ValueError("bad suite descriptor")
+
+
+def set_check_mask(mask: int) -> None:
+    """Which point classes the verifiers subgroup-check on decode (arkworks' checked deserialisation): bit 1 public
+    key, 2 input, 4 output, 8 proof points; 15 (default) = all, as upstream; 0 = on-curve only.  Process-global."""
+    load().oracle_set_check_mask(int(mask))
 
 
 def _a(x):

@@ -7,12 +7,27 @@
 #include <vector>
 using namespace vrf;
 
+// suite strings of the host build (defaults: the built-in Bandersnatch descriptor); shared by the Bandersnatch units
+SuiteStr g_hs_str = [] {
+  SuiteStr s{};
+  const char id[] = "Bandersnatch_SHA-512_ELL2", dst[] = "ECVRF_Bandersnatch_XMD:SHA-512_ELL2_RO_Bandersnatch_SHA-512_ELL2";
+  s.suite_id_len = sizeof id - 1; memcpy(s.suite_id, id, sizeof id - 1);
+  s.dst_len = sizeof dst - 1; memcpy(s.dst, dst, sizeof dst - 1);
+  return s;
+}();
 static SqrtTables host_tables() {
-  SqrtTables t; t.P = vrfk_tables::SQRT_P; t.lut = vrfk_tables::SQRT_LUT; return t;
+  SqrtTables t; t.P = vrfk_tables::SQRT_P; t.lut = vrfk_tables::SQRT_LUT; t.str = &g_hs_str; return t;
 }
 static FeN in(const uint8_t* b) { uint32_t w[8]; memcpy(w, b, 32); return fe_from_u256(w); }
 template <int L, int V> static void out(uint8_t* b, const Fe<L, V>& a) { uint32_t w[8]; fe_to_u256(w, a); memcpy(b, w, 32); }
 extern "C" {
+// descriptor strings (vrfhip_suite_desc.suite_id / h2c_dst) for every Bandersnatch entry point of the host build
+void hs_set_suite_strings(const uint8_t* id, uint32_t id_len, const uint8_t* dst, uint32_t dst_len) {
+  SuiteStr s{};
+  s.suite_id_len = id_len; memcpy(s.suite_id, id, id_len);
+  s.dst_len = dst_len; memcpy(s.dst, dst, dst_len);
+  g_hs_str = s;
+}
 void hs_fe_mul(const uint8_t* a, const uint8_t* b, uint8_t* r) { out(r, fe_mul(in(a), in(b))); }
 void hs_fe_sqr(const uint8_t* a, uint8_t* r) { out(r, fe_sqr(in(a))); }
 void hs_fe_add(const uint8_t* a, const uint8_t* b, uint8_t* r) { out(r, fe_add(in(a), in(b))); }
@@ -34,16 +49,19 @@ void hs_fe_lazy(const uint8_t* a_, const uint8_t* b_, uint8_t* r) {
 int hs_fe_sqrt(const uint8_t* a, uint8_t* r) {
   FeN root; bool sq = fe_sqrt_or_zsqrt(root, in(a), host_tables()); out(r, root); return sq;
 }
+// quadratic character by positive divsteps (fe.cuh): +1 / -1 / 0, 2 = rounds exhausted
+int hs_fe_jacobi(const uint8_t* a) { FeN c = fe_canon(in(a)); return jacobi_limbs(c.v); }
+int hs_fe_is_nonzero_square(const uint8_t* a) { return fe_is_nonzero_square(in(a), host_tables()) ? 1 : 0; }
 int hs_fe_eq(const uint8_t* a, const uint8_t* b) { return fe_eq(in(a), fe_norm(fe_add(in(b), fe_zero()))); }
 void hs_h2f(const uint8_t* msg, uint32_t len, uint8_t* u0, uint8_t* u1) {
-  Fe<1,4> a, b; hash_to_field2<SuiteBS>(a, b, msg, len); out(u0, a); out(u1, b);
+  Fe<1,4> a, b; hash_to_field2<SuiteBS>(a, b, msg, len, g_hs_str); out(u0, a); out(u1, b);
 }
 void hs_sha512(const uint8_t* msg, uint32_t len, uint8_t* out) {
   Sha512 h; sha512_init(h); sha512_put_bytes(h, msg, len); sha512_final(h);
   for (int j = 0; j < 16; ++j) { uint32_t w = sha512_word_mem(h, j); memcpy(out + 4 * j, &w, 4); }
 }
 void hs_output_hash(const uint8_t* g, uint8_t* out) {
-  uint32_t gw[8], o[16]; memcpy(gw, g, 32); output_hash_item<SuiteBS>(o, gw); memcpy(out, o, 64);
+  uint32_t gw[8], o[16]; memcpy(gw, g, 32); output_hash_item<SuiteBS>(o, gw, g_hs_str); memcpy(out, o, 64);
 }
 void hs_secret_from_seed(const uint8_t* seed, uint32_t len, uint8_t* out) {
   uint32_t sk[8]; secret_from_seed_item<SuiteBS>(sk, seed, len); memcpy(out, sk, 32);

@@ -7,8 +7,9 @@
 #include <vector>
 using namespace vrf;
 
+extern SuiteStr g_hs_str;      // hostsim_fe.hip
 static SqrtTables host_tables() {
-  SqrtTables t; t.P = vrfk_tables::SQRT_P; t.lut = vrfk_tables::SQRT_LUT; return t;
+  SqrtTables t; t.P = vrfk_tables::SQRT_P; t.lut = vrfk_tables::SQRT_LUT; t.str = &g_hs_str; return t;
 }
 static FeN in(const uint8_t* b) { uint32_t w[8]; memcpy(w, b, 32); return fe_from_u256(w); }
 template <int L, int V> static void out(uint8_t* b, const Fe<L, V>& a) { uint32_t w[8]; fe_to_u256(w, a); memcpy(b, w, 32); }
@@ -16,30 +17,38 @@ namespace {
 struct HostTables {
   std::vector<uint32_t> g_win, g_comb, b_comb;
   DevTables t;
-  HostTables() {
-    g_win.resize(2 * WIN_TABLE_WORDS);
-    build_glv_tables<SuiteBS>(g_win.data(), SuiteBS::gx(), SuiteBS::gy());
-    g_comb.resize(GCOMB_WORDS); b_comb.resize(GCOMB_WORDS);
+  FeN gx, gy;
+  HostTables() { build(SuiteBS::gx(), SuiteBS::gy(), SuiteBS::bx(), SuiteBS::by()); }
+  // the tables a context builds from its descriptor's generator and blinding base (k_init_gwin / k_init_gcomb)
+  void build(const FeN& gx_, const FeN& gy_, const FeN& bx, const FeN& by) {
+    gx = gx_; gy = gy_;
+    g_win.assign(2 * WIN_TABLE_WORDS, 0);
+    build_glv_tables<SuiteBS>(g_win.data(), gx, gy);
+    g_comb.assign(GCOMB_WORDS, 0); b_comb.assign(GCOMB_WORDS, 0);
     std::vector<uint32_t> prefix((size_t)GC_SEG * NL);
     for (int which = 0; which < 2; ++which)
     for (int w = 0; w < GC_ROWS; ++w)
     for (int seg = 0; seg < GC_SEGS; ++seg)       // the device's own table builder (k_init_gcomb runs it per lane)
       gcomb_build_segment<SuiteBS>(which ? b_comb.data() : g_comb.data(), prefix.data(),
-                              which ? SuiteBS::bx() : SuiteBS::gx(), which ? SuiteBS::by() : SuiteBS::gy(), w, seg);
+                              which ? bx : gx, which ? by : gy, w, seg);
     t.sq = host_tables(); t.g_win = g_win.data(); t.g_comb = g_comb.data(); t.b_comb = b_comb.data();
   }
 };
 HostTables& HT() { static HostTables h; return h; }
 }
+static uint32_t g_check_mask_p = 0;    // CHK_* bits for the decode stages (0 = on-curve only)
 extern "C" {
+void hs_set_check_mask_prove(uint32_t m) { g_check_mask_p = m; }
 void hs_init() { (void)HT(); }
+// descriptor points (x || y, 32-byte little-endian each) -> rebuild the fixed-base tables
+void hs_set_bases(const uint8_t* g_xy, const uint8_t* b_xy) { HT().build(in(g_xy), in(g_xy + 32), in(b_xy), in(b_xy + 32)); }
 // entry (w, j) of the generator table built by gcomb_build_segment against j * 2^(GCB w) * G by the ladder
 int hs_comb_entry_check(int w, int j) {
   if (w >= GC_ROWS || j < 1 || j > GC_COLS) return -1;
   uint32_t k[8] = {0};
   const int bit = w * GCB;
   k[bit >> 5] = (uint32_t)j << (bit & 31);
-  PtE p = te_mul_slow<SuiteBS>(te_from_affine(SuiteBS::gx(), SuiteBS::gy()), k);
+  PtE p = te_mul_slow<SuiteBS>(te_from_affine(HT().gx, HT().gy), k);
   FeN zi = fe_inv(p.Z);
   FeN x = fe_mul(p.X, zi), y = fe_mul(p.Y, zi), dt = fe_mul(fe_mul(x, y), SuiteBS::d());
   const uint32_t* ref = HT().g_comb.data() + ((size_t)w * GC_COLS + (j - 1)) * PTA_WORDS;
@@ -57,12 +66,12 @@ static int prove_any(bool pedersen, const uint8_t* sk, const uint8_t* msg, uint3
   uint32_t hg[8]; if (h_given) memcpy(hg, h_given, 32);
   uint32_t k[8], kb[8];
   std::vector<uint32_t> tab(2 * WIN_TABLE_WORDS), pts(PROVE_PTS_WORDS);
-  bool valid = prove_prepare_item<SuiteBS>(h_enc, k, tab.data(), HT().t, skw, msg, len, h_given ? hg : nullptr);
-  if (pedersen) { pedersen_blinding<SuiteBS>(b, skw, h_enc, ad, ad_len); nonce_rfc8032<SuiteBS>(kb, b, h_enc); }
+  bool valid = prove_prepare_item<SuiteBS>(h_enc, k, tab.data(), HT().t, skw, msg, len, h_given ? hg : nullptr, 0, g_check_mask_p);
+  if (pedersen) { pedersen_blinding<SuiteBS>(b, skw, h_enc, ad, ad_len, g_hs_str); nonce_rfc8032<SuiteBS>(kb, b, h_enc); }
   prove_mul_item<SuiteBS>(pts.data(), HT().t, tab.data(), skw, pedersen ? b : nullptr);
   prove_mul_item<SuiteBS>(pts.data() + 2 * UV_WORDS, HT().t, tab.data(), k, pedersen ? kb : nullptr);
   // o: gamma, c, s, pk, r, ok
-  prove_finish_item<SuiteBS>(o[0], o[1], o[2], o[3], o[4], o[5], pts.data(), h_enc, skw, k, ad, ad_len);
+  prove_finish_item<SuiteBS>(o[0], o[1], o[2], o[3], o[4], o[5], pts.data(), h_enc, skw, k, ad, ad_len, g_hs_str);
   if (pedersen) { uint32_t cb[8]; fr_mul<SuiteBS>(cb, o[1], b); fr_add<SuiteBS>(sb, cb, kb); }
   return valid;
 }
@@ -91,7 +100,7 @@ uint32_t hs_pedersen_verify(const uint8_t* h, const uint8_t* g, const uint8_t* p
   memcpy(enc[0], h, 32); memcpy(enc[1], g, 32); memcpy(enc[2], proof160, 32); memcpy(enc[3], proof160 + 32, 32);
   memcpy(enc[4], proof160 + 64, 32); memcpy(s, proof160 + 96, 32); memcpy(sb, proof160 + 128, 32);
   std::vector<uint32_t> tabs(VERIFY_TABS * WIN_TABLE_WORDS), pts(PROVE_PTS_WORDS);
-  bool valid = pedersen_verify_decode_item<SuiteBS>(c, HT().t, enc, ad, ad_len, tabs.data(), pts.data());
+  bool valid = pedersen_verify_decode_item<SuiteBS>(c, HT().t, enc, ad, ad_len, tabs.data(), pts.data(), g_check_mask_p);
   uint32_t s2[8], sb2[8];
   bool canon = fr_is_canonical<SuiteBS>(s) && fr_is_canonical<SuiteBS>(sb);
   for (int j = 0; j < 8; ++j) { s2[j] = canon ? s[j] : 0; sb2[j] = canon ? sb[j] : 0; }
@@ -119,7 +128,7 @@ void hs_ietf_prove_multi(uint32_t n, const uint8_t* sk, const uint8_t* msgs, uin
     uint32_t skw[8], h_enc[8], k[8], c[8], s2[8];
     memcpy(skw, sk + 32 * i, 32); memcpy(h_enc, aux.data() + 32 * i, 32); memcpy(k, aux.data() + 32 * i + 8, 32);
     const uint32_t* enc = tabs.data() + i * 2 * WIN_TABLE_WORDS + PROVE_ENC_OFF;
-    prove_respond_item<SuiteBS>(c, s2, enc, h_enc, skw, k, ad, ad_len);
+    prove_respond_item<SuiteBS>(c, s2, enc, h_enc, skw, k, ad, ad_len, g_hs_str);
     memcpy(out + 160 * i, enc, 32); memcpy(out + 160 * i + 32, c, 32); memcpy(out + 160 * i + 64, s2, 32);
     memcpy(out + 160 * i + 96, enc + 8, 32); memcpy(out + 160 * i + 128, h_enc, 32);
   }

@@ -7,8 +7,9 @@
 #include <vector>
 using namespace vrf;
 
+extern SuiteStr g_hs_str;      // hostsim_fe.hip
 static SqrtTables host_tables() {
-  SqrtTables t; t.P = vrfk_tables::SQRT_P; t.lut = vrfk_tables::SQRT_LUT; return t;
+  SqrtTables t; t.P = vrfk_tables::SQRT_P; t.lut = vrfk_tables::SQRT_LUT; t.str = &g_hs_str; return t;
 }
 static FeN in(const uint8_t* b) { uint32_t w[8]; memcpy(w, b, 32); return fe_from_u256(w); }
 template <int L, int V> static void out(uint8_t* b, const Fe<L, V>& a) { uint32_t w[8]; fe_to_u256(w, a); memcpy(b, w, 32); }
@@ -17,31 +18,33 @@ namespace {
 struct HostTables {
   std::vector<uint32_t> g_win, g_comb;
   DevTables t;
-  HostTables() {
-    g_win.resize(2 * WIN_TABLE_WORDS);
-    build_glv_tables<SuiteBS>(g_win.data(), SuiteBS::gx(), SuiteBS::gy());
-    g_comb.resize(GCOMB_WORDS);
+  HostTables() { build(SuiteBS::gx(), SuiteBS::gy()); }
+  void build(const FeN& gx, const FeN& gy) {
+    g_win.assign(2 * WIN_TABLE_WORDS, 0);
+    build_glv_tables<SuiteBS>(g_win.data(), gx, gy);
+    g_comb.assign(GCOMB_WORDS, 0);
     std::vector<uint32_t> prefix((size_t)GC_SEG * NL);
-    for (int which = 0; which < 1; ++which)
     for (int w = 0; w < GC_ROWS; ++w)
     for (int seg = 0; seg < GC_SEGS; ++seg)       // the device's own table builder (k_init_gcomb runs it per lane)
-      gcomb_build_segment<SuiteBS>(g_comb.data(), prefix.data(),
-                              which ? SuiteBS::bx() : SuiteBS::gx(), which ? SuiteBS::by() : SuiteBS::gy(), w, seg);
+      gcomb_build_segment<SuiteBS>(g_comb.data(), prefix.data(), gx, gy, w, seg);
     t.sq = host_tables(); t.g_win = g_win.data(); t.g_comb = g_comb.data(); t.b_comb = nullptr;
   }
 };
 HostTables& HT() { static HostTables h; return h; }
 }
+static uint32_t g_check_mask = 0;      // CHK_* bits applied by the decode stages below (0 = on-curve only)
 extern "C" {
+void hs_set_check_mask(uint32_t m) { g_check_mask = m; }
+void hs_set_generator_verify(const uint8_t* g_xy) { HT().build(in(g_xy), in(g_xy + 32)); }
 uint32_t hs_ietf_verify(const uint8_t* pk, const uint8_t* h, const uint8_t* g, const uint8_t* c,
                         const uint8_t* s, const uint8_t* ad, uint32_t ad_len) {
   uint32_t w[5][8];
   memcpy(w[0], pk, 32); memcpy(w[1], h, 32); memcpy(w[2], g, 32); memcpy(w[3], c, 32); memcpy(w[4], s, 32);
   std::vector<uint32_t> tabs(VERIFY_TABS * WIN_TABLE_WORDS), uv(2 * UV_WORDS);
-  bool valid = verify_decode_item<SuiteBS>(HT().t, w[0], w[1], w[2], tabs.data());
+  bool valid = verify_decode_item<SuiteBS>(HT().t, w[0], w[1], w[2], tabs.data(), g_check_mask);
   verify_straus_item<SuiteBS, 0>(uv.data(), HT().t, tabs.data(), w[3], w[4]);
   verify_straus_item<SuiteBS, 1>(uv.data() + UV_WORDS, HT().t, tabs.data(), w[3], w[4]);
-  return verify_finish_item<SuiteBS>(uv.data(), w[0], w[1], w[2], w[3], w[4], valid, ad, ad_len);
+  return verify_finish_item<SuiteBS>(uv.data(), w[0], w[1], w[2], w[3], w[4], valid, ad, ad_len, g_hs_str);
 }
 // GLV pieces: k -> (k1, k2) as 2 x (16 B magnitude, 1 B sign) ; psi(P) encoded
 void hs_glv_decompose(const uint8_t* k, uint8_t* out34) {
@@ -64,10 +67,10 @@ uint32_t hs_ietf_verify_affine(const uint8_t* pk_xy, const uint8_t* h_xy, const 
   uint32_t xy[3][16], enc[3][8], cw[8], sw[8];
   memcpy(xy[0], pk_xy, 64); memcpy(xy[1], h_xy, 64); memcpy(xy[2], g_xy, 64); memcpy(cw, c, 32); memcpy(sw, s, 32);
   std::vector<uint32_t> tabs(VERIFY_TABS * WIN_TABLE_WORDS), uv(2 * UV_WORDS);
-  bool valid = verify_decode_affine_item<SuiteBS>(enc, xy, tabs.data());
+  bool valid = verify_decode_affine_item<SuiteBS>(enc, xy, tabs.data(), HT().t.sq, g_check_mask);
   verify_straus_item<SuiteBS, 0>(uv.data(), HT().t, tabs.data(), cw, sw);
   verify_straus_item<SuiteBS, 1>(uv.data() + UV_WORDS, HT().t, tabs.data(), cw, sw);
-  return verify_finish_item<SuiteBS>(uv.data(), enc[0], enc[1], enc[2], cw, sw, valid, ad, ad_len);
+  return verify_finish_item<SuiteBS>(uv.data(), enc[0], enc[1], enc[2], cw, sw, valid, ad, ad_len, g_hs_str);
 }
 // the K-proofs-per-lane pipeline exactly as the kernels run it (decode_multi -> straus -> finish_multi)
 void hs_ietf_verify_multi(uint32_t n, const uint8_t* pk, const uint8_t* h, const uint8_t* g, const uint8_t* c,
@@ -75,7 +78,7 @@ void hs_ietf_verify_multi(uint32_t n, const uint8_t* pk, const uint8_t* h, const
   std::vector<uint32_t> tabs((size_t)n * VERIFY_TABS * WIN_TABLE_WORDS), pts((size_t)n * PROVE_PTS_WORDS);
   std::vector<uint8_t> flags(n);
   for (size_t first = 0; first < n; first += VERIFY_K)
-    verify_decode_multi<SuiteBS>(VERIFY_K, HT().t, first, n, pk, h, g, tabs.data(), pts.data(), flags.data());
+    verify_decode_multi<SuiteBS>(VERIFY_K, HT().t, first, n, pk, h, g, tabs.data(), pts.data(), flags.data(), g_check_mask);
   for (size_t i = 0; i < n; ++i) {
     uint32_t cw[8], sw[8]; memcpy(cw, c + 32 * i, 32); memcpy(sw, s + 32 * i, 32);
     if (!fr_is_canonical<SuiteBS>(cw) || !fr_is_canonical<SuiteBS>(sw)) { memset(cw, 0, 32); memset(sw, 0, 32); }
@@ -85,7 +88,7 @@ void hs_ietf_verify_multi(uint32_t n, const uint8_t* pk, const uint8_t* h, const
   }
   BytesViewLite adv; adv.blob = ad; adv.off = nullptr; adv.len = ad_len; adv.stride = 0;
   for (size_t first = 0; first < n; first += VERIFY_K)
-    verify_finish_multi<SuiteBS>(VERIFY_K, first, n, pts.data(), PROVE_PTS_WORDS, pk, h, g, nullptr, 0, c, s, adv, flags.data(), status);
+    verify_finish_multi<SuiteBS>(VERIFY_K, first, n, pts.data(), PROVE_PTS_WORDS, pk, h, g, nullptr, 0, c, s, adv, flags.data(), status, g_hs_str);
 }
 }
 

@@ -1,0 +1,229 @@
+"""GPU (-m gpu): the subgroup test fused into every verify entry point ([ref src/lib.rs:14 `codec`]: arkworks'
+checked deserialisation precedes `verify`).  Statuses on points shifted by small-order points, on points of the
+other cosets, and on the forgery that motivates the check (an output shifted by a 2-torsion point with an even
+challenge) must EQUAL the C oracle's with its own r*P == O test switched on -- strict equality, no exclusions.
+CPU part: the oracle's check mask against the Python oracle's point_decode_checked."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import vrf_oracle as o
+
+S = o.BANDERSNATCH
+Q, R = S.q, S.r
+NCPU = min(16, os.cpu_count() or 1)
+T2 = (0, Q - 1)                                   # the affine point of order 2 of both curves
+
+
+def enc(Sx, P):
+    return np.frombuffer(o.point_encode(Sx, P), np.uint8)
+
+
+def other_coset_points(Sx, rnd, want):
+    """Decodable points outside the prime-order subgroup, found by sampling encodings (every coset shows up)."""
+    out = []
+    while len(out) < want:
+        b = bytes(rnd.getrandbits(8) for _ in range(32))
+        P = o.point_decode(Sx, b)
+        if P is not None and o.point_decode_checked(Sx, b) is None:
+            out.append(np.frombuffer(b, np.uint8))
+    return out
+
+
+def forge_output_shift(Sx, sk, H, ad, rnd):
+    """Gamma' = Gamma + T2 and a nonce ground until c is even => (c, s) passes a verifier that skips the
+    subgroup test although Gamma' != sk*H.  Returns (pk, H, Gamma', c, s) as encodings."""
+    G = (Sx.gx, Sx.gy)
+    pk = o.te_mul(Sx, sk, G)
+    gam = o.te_add(Sx, o.te_mul(Sx, sk, H), T2)
+    while True:
+        k = rnd.randrange(1, Sx.r)
+        U, V = o.te_mul(Sx, k, G), o.te_mul(Sx, k, H)
+        c = o.challenge_rfc9381(Sx, [pk, H, gam, U, V], ad)
+        if c % 2 == 0:
+            break
+    s = (k + c * sk) % Sx.r
+    le = lambda v: np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+    return enc(Sx, pk), enc(Sx, H), enc(Sx, gam), le(c), le(s)
+
+
+@pytest.fixture()
+def checked_oracle():
+    co.set_check_mask(15)           # the oracle's default; tests that lower it restore it here
+    yield co
+    co.set_check_mask(15)
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_oracle_check_mask_matches_python_checked_decode(checked_oracle):
+    rnd = random.Random(5)
+    sk = o.secret_from_seed(S, b"\x05")
+    H = o.data_to_point(S, b"checked")
+    pkb, hb, gb, cb, sb = forge_output_shift(S, sk, H, b"", rnd)
+    assert o.point_decode_checked(S, gb.tobytes()) is None and o.point_decode(S, gb.tobytes()) is not None
+    assert co.ietf_verify_batch(pkb, hb, gb, cb, sb, b"")[0] == 2          # checked: InvalidData
+    co.set_check_mask(0)
+    assert co.ietf_verify_batch(pkb, hb, gb, cb, sb, b"")[0] == 0          # unchecked: the forgery is ACCEPTED
+    co.set_check_mask(4)
+    assert co.ietf_verify_batch(pkb, hb, gb, cb, sb, b"")[0] == 2          # the output's bit alone catches it
+    co.set_check_mask(3)
+    assert co.ietf_verify_batch(pkb, hb, gb, cb, sb, b"")[0] == 0
+    for b in other_coset_points(S, rnd, 6):
+        assert co.point_decode(b.tobytes(), subgroup=True) is None and co.point_decode(b.tobytes()) is not None
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_flags_roundtrip_and_default_is_checked(ctx):
+    assert ctx.get_flags() == 0
+    ctx.set_flags(ctx.PREVALIDATED_INPUT | ctx.PREVALIDATED_PROOF)
+    assert ctx.get_flags() == 10
+    ctx.set_prevalidated(True)
+    assert ctx.get_flags() == 15
+    ctx.set_prevalidated(False)
+    assert ctx.get_flags() == 0
+    with pytest.raises(Exception):
+        ctx.set_flags(16)
+
+
+@pytest.mark.gpu
+def test_ietf_verify_statuses_on_non_subgroup_points_equal_checked_oracle(ctx, synth, checked_oracle):
+    rnd = random.Random(11)
+    n = 64
+    sk, msg = synth(n, start=4000)
+    ref = co.ietf_prove_batch(sk, msgs=msg, ad=b"chk", threads=NCPU)
+    a = {k: ref[k].copy() for k in ("pk", "input", "output", "c", "s")}
+    odd = other_coset_points(S, rnd, 12)
+    shift = lambda b: enc(S, o.te_add(S, o.point_decode(S, b.tobytes()), T2))
+    e32 = lambda v: np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+    a["pk"][1] = shift(ref["pk"][1]); a["input"][2] = shift(ref["input"][2]); a["output"][3] = shift(ref["output"][3])
+    a["pk"][4] = e32(1)                         # identity: in the subgroup, verification fails
+    a["pk"][5] = e32(Q - 1)                     # (0, -1): order 2
+    a["input"][6] = e32(Q - 1); a["output"][7] = e32(Q - 1); a["output"][8] = e32(1)
+    a["pk"][9] = e32(1 | (1 << 255))            # identity with the sign flag set (x = 0): accepted by the decoder
+    for j, b in enumerate(odd):                  # points of the cosets that have no affine torsion representative
+        a[("pk", "input", "output")[j % 3]][10 + j] = b
+    # the forgery: output shifted by T2, even challenge
+    for j in range(4):
+        sk_i = int.from_bytes(sk[30 + j].tobytes(), "little")
+        H = o.point_decode(S, ref["input"][30 + j].tobytes())
+        f = forge_output_shift(S, sk_i, H, b"chk", rnd)
+        for k, v in zip(("pk", "input", "output", "c", "s"), f):
+            a[k][30 + j] = v
+    want = co.ietf_verify_batch(a["pk"], a["input"], a["output"], a["c"], a["s"], b"chk", threads=NCPU)
+    got = ctx.ietf_verify_batch(a["pk"], a["input"], a["output"], a["c"], a["s"], ad=b"chk")
+    assert (got == want).all(), (got.tolist(), want.tolist())
+    assert list(want[1:4]) == [2, 2, 2] and want[4] == 1 and list(want[5:8]) == [2, 2, 2] and want[8] == 1
+    assert (want[10:22] == 2).all() and (want[30:34] == 2).all() and (want[34:] == 0).all()
+    # the affine-input entry point applies the same test
+    xy = {}
+    for k in ("pk", "input", "output"):
+        pts = [o.point_decode(S, a[k][i].tobytes()) for i in range(n)]
+        xy[k] = np.stack([np.frombuffer(int(P[0]).to_bytes(32, "little") + int(P[1]).to_bytes(32, "little"), np.uint8)
+                          for P in pts])
+    got_aff = ctx.ietf_verify_batch_affine(xy["pk"], xy["input"], xy["output"], a["c"], a["s"], ad=b"chk")
+    want_aff = want.copy(); want_aff[9] = want[4]         # the affine form has no sign flag: item 9 is the identity
+    assert (got_aff == want_aff).all()
+    # prove with a given input point outside the subgroup reports InvalidData
+    pr = ctx.ietf_prove_batch(sk[:8], inputs=a["input"][:8], ad=b"chk")
+    assert pr["status"][2] == 2 and pr["status"][6] == 2 and (np.delete(pr["status"], [2, 6]) == 0).all()
+
+
+@pytest.mark.gpu
+def test_prevalidated_flags_skip_the_test_on_valid_inputs(ctx, synth):
+    sk, msg = synth(512, start=7000)
+    ref = co.ietf_prove_batch(sk, msgs=msg, ad=b"", threads=NCPU)
+    bad_s = ref["s"].copy(); bad_s[::7, 3] ^= 4
+    want = co.ietf_verify_batch(ref["pk"], ref["input"], ref["output"], ref["c"], bad_s, b"", threads=NCPU)
+    try:
+        for flags in (0, 1, 2, 4, 8, 5, 15):
+            ctx.set_flags(flags)
+            got = ctx.ietf_verify_batch(ref["pk"], ref["input"], ref["output"], ref["c"], bad_s, ad=b"")
+            assert (got == want).all(), flags
+    finally:
+        ctx.set_flags(0)
+
+
+def _pedersen_case(Sx, cox, suite_ctx, rnd, tors_points):
+    n = 48
+    sk = np.stack([np.frombuffer(cox.secret_from_seed(o.synth_seed(9000 + i)), np.uint8) for i in range(n)])
+    msg = np.stack([np.frombuffer(o.synth_msg(9000 + i), np.uint8) for i in range(n)])
+    ref = cox.pedersen_prove_batch(sk, msgs=msg, ad=b"p", threads=NCPU)
+    names = ("input", "output", "pk_com", "r", "ok")
+    a = {k: ref[k].copy() for k in names + ("s", "sb")}
+    k = 1
+    for T in tors_points:                           # every point class shifted by every small-order point
+        for nm in names:
+            P = o.point_decode(Sx, ref[nm][k].tobytes())
+            a[nm][k] = enc(Sx, o.te_add(Sx, P, T))
+            k += 1
+    # two proofs whose small-order defects cancel in the batch equation (R shifted by T2 in both)
+    for i in (k, k + 1):
+        P = o.point_decode(Sx, ref["r"][i].tobytes())
+        a["r"][i] = enc(Sx, o.te_add(Sx, P, T2))
+    args = [a[x] for x in names + ("s", "sb")]
+    want = cox.pedersen_verify_batch(*args, b"p", threads=NCPU)
+    assert (want[1:k + 2] == 2).all() and want[0] == 0 and (want[k + 2:] == 0).all()
+    got = suite_ctx.pedersen_verify_batch(*args, ad=b"p")
+    assert (got == want).all(), (got.tolist(), want.tolist())
+    seed = bytes(range(32))
+    got_b, batch_ok = suite_ctx.pedersen_verify_batch_rlc(*args, ad=b"p", seed=seed)
+    assert (got_b == want).all()
+    st_o, fail_o = cox.pedersen_rlc_check(*args, seed, b"p")
+    assert (st_o == (want == 2) * 2).all() and fail_o == 0 and batch_ok     # the rest of the batch is valid
+
+
+@pytest.mark.gpu
+def test_pedersen_verify_and_batched_verify_on_shifted_points_bandersnatch(ctx, checked_oracle):
+    _pedersen_case(S, co, ctx, random.Random(3), [T2])
+
+
+@pytest.mark.gpu
+def test_pedersen_verify_and_batched_verify_on_shifted_points_jubjub(checked_oracle):
+    from ark_ec_vrfs_amd import Context, JubJubSha512Tai
+    J = o.jubjub_params()
+    rnd = random.Random(4)
+    # a generator of the 8-torsion: r * (a decodable point outside the subgroup), of order exactly 8
+    while True:
+        b = bytes(rnd.getrandbits(8) for _ in range(32))
+        P = o.point_decode(J, b)
+        if P is None:
+            continue
+        T8 = o.te_mul(J, J.r, P)
+        if o.te_mul(J, 4, T8) != (0, 1):
+            break
+    tors = [o.te_mul(J, j, T8) for j in (1, 2, 4)]          # orders 8, 4, 2
+    assert tors[2] == (0, J.q - 1)
+    co.set_suite(2)
+    cj = Context(0, suite=JubJubSha512Tai)
+    try:
+        _pedersen_case(J, co, cj, rnd, tors)
+    finally:
+        co.set_suite(1)
+        cj.close()
+
+
+@pytest.mark.gpu
+def test_keyed_verify_checks_input_and_output(ctx, synth, checked_oracle):
+    n, nk = 96, 4
+    rnd = random.Random(8)
+    ksk = np.stack([np.frombuffer(co.secret_from_seed(bytes([k, 99])), np.uint8) for k in range(nk)])
+    kpk = np.stack([np.frombuffer(co.public_from_secret(ksk[k].tobytes()), np.uint8) for k in range(nk)])
+    idx = np.array([i % nk for i in range(n)], np.uint32)
+    _, msg = synth(n, start=12000)
+    ref = co.ietf_prove_batch(ksk[idx], msgs=msg, ad=b"", threads=NCPU)
+    a = {k: ref[k].copy() for k in ("input", "output", "c", "s")}
+    a["input"][3] = enc(S, o.te_add(S, o.point_decode(S, ref["input"][3].tobytes()), T2))
+    a["output"][5] = enc(S, o.te_add(S, o.point_decode(S, ref["output"][5].tobytes()), T2))
+    odd = other_coset_points(S, rnd, 2)
+    a["input"][7], a["output"][9] = odd
+    want = co.ietf_verify_batch(kpk[idx], a["input"], a["output"], a["c"], a["s"], b"", threads=NCPU)
+    ks, kst = ctx.keyset_create(kpk)
+    try:
+        got = ctx.ietf_verify_batch_keyed(ks, idx, a["input"], a["output"], a["c"], a["s"])
+    finally:
+        ks.close()
+    assert (kst == 0).all() and (got == want).all() and list(want[[3, 5, 7, 9]]) == [2, 2, 2, 2] and want.sum() == 8

@@ -68,6 +68,21 @@ def test_inverse_and_table_driven_sqrt(hs):
             assert sq == 0 and r * r % Q == 5 * xm % Q            # sqrt(Z * w), Z = 5
 
 
+def test_jacobi_symbol_against_euler_criterion(hs):
+    """fe.cuh jacobi_limbs (positive divsteps on the Montgomery image) == w^((q-1)/2), never 'rounds exhausted'."""
+    rnd = random.Random(20)
+    vals = [rnd.getrandbits(256) for _ in range(3000)] + EDGE + [4, 9, 5, 7, Q - 4, Q - 5, 2 * Q, 2 * Q + 4]
+    vals += [pow(rnd.getrandbits(255), 2, Q) for _ in range(200)]           # squares
+    vals += [5 * pow(rnd.getrandbits(255), 2, Q) % Q for _ in range(200)]   # non-squares (5 is one)
+    vals += [1 << k for k in range(0, 256, 7)] + [Q - (1 << k) for k in range(0, 250, 11)]
+    for x in vals:
+        a = x % Q
+        want = 0 if a == 0 else (1 if pow(a, (Q - 1) // 2, Q) == 1 else -1)
+        got = hs.hs_fe_jacobi(_b(x))
+        assert got == want, (hex(x), got, want)
+        assert hs.hs_fe_is_nonzero_square(_b(x)) == (1 if want == 1 else 0)
+
+
 def test_sha512_all_padding_boundaries(hs):
     rnd = random.Random(3)
     for n in list(range(0, 20)) + [55, 111, 112, 113, 119, 120, 127, 128, 129, 239, 240, 241, 255, 256, 257, 300]:

@@ -267,9 +267,17 @@ def test_oracle_rlc_lone_small_order_defect_is_caught(synth):
     for field in ("ok", "r"):
         b = {k: v.copy() for k, v in a.items()}
         b[field][3] = _shift_by_order2(a[field][3])
-        assert co.pedersen_verify_batch(*_args(b), b"t", threads=1)[3] == 1
-        for sd in (SEED, b"\x07" * 32, os.urandom(32), os.urandom(32)):
-            assert co.pedersen_rlc_check(*_args(b), seed=sd, ad=b"t")[1] == 1
+        # checked decode (the oracle's default, as upstream): the shifted point is InvalidData and left out of the sum
+        assert co.pedersen_verify_batch(*_args(b), b"t", threads=1)[3] == 2
+        st, fail = co.pedersen_rlc_check(*_args(b), seed=SEED, ad=b"t")
+        assert st[3] == 2 and fail == 0
+        co.set_check_mask(0)                       # points vouched for by the caller: the odd weights catch it
+        try:
+            assert co.pedersen_verify_batch(*_args(b), b"t", threads=1)[3] == 1
+            for sd in (SEED, b"\x07" * 32, os.urandom(32), os.urandom(32)):
+                assert co.pedersen_rlc_check(*_args(b), seed=sd, ad=b"t")[1] == 1
+        finally:
+            co.set_check_mask(15)
 
 
 @pytest.mark.gpu
@@ -277,6 +285,14 @@ def test_gpu_rlc_lone_small_order_defect_is_caught(ctx, synth):
     a = _proofs(synth, 200, 4321, b"t")
     b = {k: v.copy() for k, v in a.items()}
     b["ok"][77] = _shift_by_order2(a["ok"][77])
-    for _ in range(4):
-        st, ok = ctx.pedersen_verify_batch_rlc(*_args(b), ad=b"t")          # fresh random seeds
-        assert not ok and st[77] == 1 and st.sum() == 1
+    # default (checked decode, as arkworks' deserialisation): the shifted point is InvalidData and left out
+    st, ok = ctx.pedersen_verify_batch_rlc(*_args(b), ad=b"t")
+    assert ok and st[77] == 2 and st.sum() == 2
+    # points declared pre-validated by the caller: the odd weights still catch the lone defect
+    ctx.set_prevalidated(True)
+    try:
+        for _ in range(4):
+            st, ok = ctx.pedersen_verify_batch_rlc(*_args(b), ad=b"t")          # fresh random seeds
+            assert not ok and st[77] == 1 and st.sum() == 1
+    finally:
+        ctx.set_prevalidated(False)
