@@ -35,6 +35,9 @@ SYMBOLS = [
     "vrfhip_secret_from_seed_batch", "vrfhip_secret_from_seed_batch_dev",
     "vrfhip_point_validate_batch", "vrfhip_point_validate_batch_dev",
     "vrfhip_fq_mul_batch", "vrfhip_test_pairing_quad_ops", "vrfhip_debug_proofs_per_lane",
+    "vrfhip_ietf_verify_batch_multi", "vrfhip_ietf_prove_batch_multi",
+    "vrfhip_pedersen_prove_batch_multi", "vrfhip_pedersen_verify_batch_multi",
+    "vrfhip_test_point_add", "vrfhip_test_scalar_mul", "vrfhip_test_sha512", "vrfhip_test_xmd",
 ]
 
 
@@ -132,6 +135,17 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_fq_mul_batch.argtypes = [c_void_p, c_size_t, P, P, P]
     lib.vrfhip_test_pairing_quad_ops.argtypes = [c_void_p, c_size_t, P, P]
     lib.vrfhip_debug_proofs_per_lane.argtypes = [c_size_t]
+    CP = POINTER(c_void_p)   # vrfhip_ctx* const*
+    lib.vrfhip_ietf_verify_batch_multi.argtypes = [CP, c_int32, c_size_t, P, P, P, P, P, P, P, c_uint32, P]
+    lib.vrfhip_ietf_prove_batch_multi.argtypes = [CP, c_int32, c_size_t, P, P, P, c_uint32, P, P, P, c_uint32,
+                                                  P, P, P, P, P, P]
+    lib.vrfhip_pedersen_prove_batch_multi.argtypes = [CP, c_int32, c_size_t, P, P, P, c_uint32, P, P, P, c_uint32,
+                                                      P, P, P, P, P, P, P, P, P]
+    lib.vrfhip_pedersen_verify_batch_multi.argtypes = [CP, c_int32, c_size_t, P, P, P, P, P, P, P, P, P, c_uint32, P, P]
+    lib.vrfhip_test_point_add.argtypes = [c_void_p, c_size_t, P, P, P, P]
+    lib.vrfhip_test_scalar_mul.argtypes = [c_void_p, c_size_t, P, P, P, P]
+    lib.vrfhip_test_sha512.argtypes = [c_void_p, c_size_t, P, P, c_uint32, P]
+    lib.vrfhip_test_xmd.argtypes = [c_void_p, c_size_t, P, P, c_uint32, P]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("vrfhip_last_error", "vrfhip_ctx_destroy", "vrfhip_ctx_workspace_bytes",

@@ -487,6 +487,33 @@ class Context:
                    "vrfhip_fq_mul_batch")
         return r
 
+    # ---- test primitives (vrfhip_test_*): the pieces under the batch calls ---------------
+    def test_point_add(self, a, b):
+        a, b = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (a, b))
+        n = a.shape[0]
+        out, st = np.empty((n, 32), np.uint8), np.empty(n, np.uint8)
+        _lib.check(self._lib.vrfhip_test_point_add(self._h, n, _ptr(a), _ptr(b), _ptr(out), _ptr(st)), "vrfhip_test_point_add")
+        return out, st
+
+    def test_scalar_mul(self, scalars, points):
+        k, p = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (scalars, points))
+        n = k.shape[0]
+        out, st = np.empty((n, 32), np.uint8), np.empty(n, np.uint8)
+        _lib.check(self._lib.vrfhip_test_scalar_mul(self._h, n, _ptr(k), _ptr(p), _ptr(out), _ptr(st)), "vrfhip_test_scalar_mul")
+        return out, st
+
+    def _test_hash(self, fn, name, msgs, width):
+        blob, off = _pack_var([bytes(m) for m in msgs])
+        out = np.empty((len(msgs), width), np.uint8)
+        _lib.check(fn(self._h, len(msgs), _ptr(blob), _ptr(off), 0, _ptr(out)), name)
+        return out
+
+    def test_sha512(self, msgs):
+        return self._test_hash(self._lib.vrfhip_test_sha512, "vrfhip_test_sha512", msgs, 64)
+
+    def test_xmd(self, msgs):
+        return self._test_hash(self._lib.vrfhip_test_xmd, "vrfhip_test_xmd", msgs, 96)
+
     # ---- device-pointer batch API (torch CUDA uint8 tensors, current stream) -----------
     def ietf_verify_batch_dev(self, pk, inp, out, c, s, status, ad=None, ad_off=None, ad_len=0, stream=None):
         import torch
@@ -507,6 +534,67 @@ class Context:
             self._h, n, sk.data_ptr(), dp(msg), dp(msg_off), msg_len, dp(inputs), dp(ad), dp(ad_off), ad_len,
             out.data_ptr(), c.data_ptr(), s.data_ptr(), dp(pk_out), dp(input_out), dp(status), st),
             "vrfhip_ietf_prove_batch_dev")
+
+
+def _ctx_array(ctxs):
+    arr = (ctypes.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
+    return arr, len(ctxs)
+
+
+def ietf_verify_batch_multi(ctxs, pk, inp, out, c, s, ad=b"") -> np.ndarray:
+    """vrfhip_ietf_verify_batch_multi: one call, one context per GPU, contiguous slices, one host thread each."""
+    pk, inp, out, c, s = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (pk, inp, out, c, s))
+    n = pk.shape[0]
+    blob, off, ad_len = Context._ad_args(ad, n)
+    st = np.empty(n, np.uint8)
+    arr, k = _ctx_array(ctxs)
+    _lib.check(_lib.load().vrfhip_ietf_verify_batch_multi(arr, k, n, _ptr(pk), _ptr(inp), _ptr(out), _ptr(c), _ptr(s),
+                                                          _ptr(blob), _ptr(off), ad_len, _ptr(st)),
+               "vrfhip_ietf_verify_batch_multi")
+    return st
+
+
+def ietf_prove_batch_multi(ctxs, sk, msgs, ad=b""):
+    sk = np.ascontiguousarray(sk, dtype=np.uint8).reshape(-1, 32)
+    n = sk.shape[0]
+    mblob, moff = _pack_var([bytes(m) for m in msgs])
+    blob, off, ad_len = Context._ad_args(ad, n)
+    res = {k: np.empty((n, 32), np.uint8) for k in ("output", "c", "s", "pk", "input")}
+    res["status"] = np.empty(n, np.uint8)
+    arr, k = _ctx_array(ctxs)
+    _lib.check(_lib.load().vrfhip_ietf_prove_batch_multi(
+        arr, k, n, _ptr(sk), _ptr(mblob), _ptr(moff), 0, None, _ptr(blob), _ptr(off), ad_len, _ptr(res["output"]),
+        _ptr(res["c"]), _ptr(res["s"]), _ptr(res["pk"]), _ptr(res["input"]), _ptr(res["status"])),
+        "vrfhip_ietf_prove_batch_multi")
+    return res
+
+
+def pedersen_prove_batch_multi(ctxs, sk, msgs, ad=b""):
+    sk = np.ascontiguousarray(sk, dtype=np.uint8).reshape(-1, 32)
+    n = sk.shape[0]
+    mblob, moff = _pack_var([bytes(m) for m in msgs])
+    blob, off, ad_len = Context._ad_args(ad, n)
+    names = ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input")
+    res = {k: np.empty((n, 32), np.uint8) for k in names}
+    res["status"] = np.empty(n, np.uint8)
+    arr, k = _ctx_array(ctxs)
+    _lib.check(_lib.load().vrfhip_pedersen_prove_batch_multi(
+        arr, k, n, _ptr(sk), _ptr(mblob), _ptr(moff), 0, None, _ptr(blob), _ptr(off), ad_len,
+        *[_ptr(res[x]) for x in names], _ptr(res["status"])), "vrfhip_pedersen_prove_batch_multi")
+    return res
+
+
+def pedersen_verify_batch_multi(ctxs, inp, out, pk_com, r, ok, s, sb, ad=b"", rlc_seed: Optional[bytes] = None) -> np.ndarray:
+    arrs = [np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (inp, out, pk_com, r, ok, s, sb)]
+    n = arrs[0].shape[0]
+    blob, off, ad_len = Context._ad_args(ad, n)
+    st = np.empty(n, np.uint8)
+    seed = None if rlc_seed is None else _np_u8(rlc_seed, 32)
+    arr, k = _ctx_array(ctxs)
+    _lib.check(_lib.load().vrfhip_pedersen_verify_batch_multi(arr, k, n, *[_ptr(x) for x in arrs], _ptr(blob), _ptr(off),
+                                                              ad_len, _ptr(seed), _ptr(st)),
+               "vrfhip_pedersen_verify_batch_multi")
+    return st
 
 
 class KeySet:

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -131,6 +132,7 @@ int32_t ensure_workspace(vrfhip_ctx* ctx, size_t items) {
 int32_t ensure_stage(vrfhip_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->stage_bytes) return VRFHIP_SUCCESS;
   if (ctx->d_stage) {
+    HIP_TRY(hipMemset(ctx->d_stage, 0, ctx->stage_bytes));     // may have held secret keys (prove entry points)
     HIP_TRY(hipFree(ctx->d_stage));
     ctx->d_stage = nullptr;
     ctx->stage_bytes = 0;
@@ -349,8 +351,11 @@ void vrfhip_ctx_destroy(vrfhip_ctx* ctx) {
     DeviceGuard guard(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
-    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
-    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);              // its secret part (nonces, blindings) is wiped after every prove
+    if (ctx->d_stage) {
+      (void)hipMemset(ctx->d_stage, 0, ctx->stage_bytes);      // staged secret keys: `Secret` zeroizes on drop
+      (void)hipFree(ctx->d_stage);
+    }
     if (ctx->d_msm_ws) (void)hipFree(ctx->d_msm_ws);
     if (ctx->d_sqrt_p) (void)hipFree(ctx->d_sqrt_p);
     if (ctx->d_sqrt_lut) (void)hipFree(ctx->d_sqrt_lut);
@@ -690,6 +695,9 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
     a.ws = ctx->ws;
     a.T = ctx->T;
     launch_ietf_prove(a, st, prof_events(ctx));
+    // the aux region held the nonces k, kb and the blinding factor b of these items: wipe it (the reference's
+    // `Secret` zeroizes on drop; nothing secret may outlive the call in device memory)
+    HIP_TRY(hipMemsetAsync(ctx->ws.aux, 0, m * AUX_WORDS * sizeof(uint32_t), st));
   }
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
@@ -751,6 +759,8 @@ int32_t prove_host_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t*
   } else {
     HIP_TRY(back(h.c, d.c, n * 32));
   }
+  HIP_TRY(hipMemsetAsync(d_sk, 0, n * 32, ctx->stream));               // staged secret keys
+  if (pedersen) HIP_TRY(hipMemsetAsync(d.blinding, 0, n * 32, ctx->stream));   // and blinding factors
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return VRFHIP_SUCCESS;
 }
@@ -1264,6 +1274,8 @@ int32_t vrfhip_secret_from_seed_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* 
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(sk_out, d_sk, n * 32, hipMemcpyDeviceToHost, ctx->stream));
   if (pk_out) HIP_TRY(hipMemcpyAsync(pk_out, d_pk, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemsetAsync(d_sk, 0, n * 32, ctx->stream));                // staged secrets and their seeds
+  if (seed_len) HIP_TRY(hipMemsetAsync(d_seed, 0, n * (size_t)seed_len, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return VRFHIP_SUCCESS;
 }
@@ -1333,6 +1345,199 @@ int32_t vrfhip_fq_mul_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const u
   HIP_TRY(hipMemcpyAsync(r, d_r, n * 32, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return VRFHIP_SUCCESS;
+}
+
+
+// ------------------------------------------------------------------------- test primitives
+int32_t vrfhip_test_point_add(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out,
+                              uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!a || !b || !out || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_stage(ctx, 3 * Stage::pad(n * 32) + Stage::pad(n));
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t *d_a = sg.take(n * 32), *d_b = sg.take(n * 32), *d_o = sg.take(n * 32), *d_st = sg.take(n);
+  HIP_TRY(hipMemcpyAsync(d_a, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_b, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  launch_test_point_add((int)ctx->suite, n, d_a, d_b, d_o, d_st, ctx->T, ctx->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, d_o, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_test_scalar_mul(vrfhip_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out,
+                               uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!scalars || !points || !out || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_workspace(ctx, n);
+  if (rc) return rc;
+  rc = ensure_stage(ctx, 3 * Stage::pad(n * 32) + Stage::pad(n));
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t *d_k = sg.take(n * 32), *d_p = sg.take(n * 32), *d_o = sg.take(n * 32), *d_st = sg.take(n);
+  HIP_TRY(hipMemcpyAsync(d_k, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_p, points, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  const size_t cap = ctx->ws_cap * (WS_TABS / 2);          // two window tables per item
+  for (size_t base = 0; base < n; base += cap) {
+    size_t m = std::min(cap, n - base);
+    launch_test_scalar_mul((int)ctx->suite, m, d_k + base * 32, d_p + base * 32, d_o + base * 32, d_st + base,
+                           ctx->ws.tabs, ctx->T, ctx->stream);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, d_o, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+}  // extern "C"
+
+namespace {
+int32_t test_hash_impl(vrfhip_ctx* ctx, size_t n, const uint8_t* msg, const uint32_t* msg_off, uint32_t msg_len,
+                       uint8_t* out, int which) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!out || (!msg && (msg_len || msg_off))) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  const size_t ob = which ? 96 : 64;
+  size_t msgb = blob_bytes(n, msg_off, msg_len, false);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_stage(ctx, Stage::pad(msgb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n * ob));
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t* d_msg = sg.take(msgb + 1);
+  uint32_t* d_off = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+  uint8_t* d_out = sg.take(n * ob);
+  if (msgb) HIP_TRY(hipMemcpyAsync(d_msg, msg, msgb, hipMemcpyHostToDevice, ctx->stream));
+  if (msg_off) HIP_TRY(hipMemcpyAsync(d_off, msg_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  launch_test_hash((int)ctx->suite, n, make_view(d_msg, msg_off ? d_off : nullptr, msg_len, false), d_out, which, ctx->T,
+                   ctx->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, d_out, n * ob, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
+// ---- one call, several devices: contiguous slices of the batch, one host thread per context ----
+// fn(ctx, lo, hi) handles items [lo, hi); the first failing slice decides the return value.
+template <class F>
+int32_t run_sharded(vrfhip_ctx* const* ctxs, int32_t n_ctx, size_t n, F fn) {
+  if (!ctxs || n_ctx <= 0) return fail(VRFHIP_ERR_BAD_ARG, "no contexts");
+  for (int32_t g = 0; g < n_ctx; ++g)
+    if (!ctxs[g]) return fail(VRFHIP_ERR_BAD_ARG, "NULL context");
+  std::vector<int32_t> rcs(n_ctx, VRFHIP_SUCCESS);
+  std::vector<std::string> errs(n_ctx);
+  std::vector<std::thread> th;
+  for (int32_t g = 0; g < n_ctx; ++g) {
+    const size_t lo = n * (size_t)g / (size_t)n_ctx, hi = n * (size_t)(g + 1) / (size_t)n_ctx;
+    if (lo == hi) continue;
+    th.emplace_back([&, g, lo, hi] {
+      rcs[g] = fn(ctxs[g], lo, hi);
+      if (rcs[g]) errs[g] = g_last_error;        // thread-local in the worker: carry it to the caller's thread
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int32_t g = 0; g < n_ctx; ++g)
+    if (rcs[g]) return fail(rcs[g], "device slice " + std::to_string(g) + ": " + errs[g]);
+  return VRFHIP_SUCCESS;
+}
+// a slice of a variable-length blob: offsets rebased to the slice's first byte
+struct BlobSlice {
+  const uint8_t* blob;
+  const uint32_t* off;         // nullptr: fixed layout
+  std::vector<uint32_t> local;
+  BlobSlice(const uint8_t* b, const uint32_t* o, uint32_t len, bool shared, size_t lo, size_t hi) {
+    if (o) {
+      local.resize(hi - lo + 1);
+      for (size_t i = lo; i <= hi; ++i) local[i - lo] = o[i] - o[lo];
+      blob = b + o[lo];
+      off = local.data();
+    } else {
+      blob = (b && !shared) ? b + lo * (size_t)len : b;
+      off = nullptr;
+    }
+  }
+};
+const uint8_t* at32(const uint8_t* p, size_t i) { return p ? p + i * 32 : nullptr; }
+uint8_t* at32(uint8_t* p, size_t i) { return p ? p + i * 32 : nullptr; }
+}  // namespace
+
+extern "C" {
+
+int32_t vrfhip_test_sha512(vrfhip_ctx* ctx, size_t n, const uint8_t* msg, const uint32_t* msg_off, uint32_t msg_len,
+                           uint8_t* out) {
+  return test_hash_impl(ctx, n, msg, msg_off, msg_len, out, 0);
+}
+int32_t vrfhip_test_xmd(vrfhip_ctx* ctx, size_t n, const uint8_t* msg, const uint32_t* msg_off, uint32_t msg_len,
+                        uint8_t* out) {
+  return test_hash_impl(ctx, n, msg, msg_off, msg_len, out, 1);
+}
+
+int32_t vrfhip_ietf_verify_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx, size_t n, const uint8_t* pk,
+                                       const uint8_t* input, const uint8_t* output, const uint8_t* c, const uint8_t* s,
+                                       const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len, uint8_t* status) {
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!pk || !input || !output || !c || !s || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  return run_sharded(ctxs, n_ctx, n, [&](vrfhip_ctx* ctx, size_t lo, size_t hi) {
+    BlobSlice a(ad, ad_off, ad_len, true, lo, hi);
+    return vrfhip_ietf_verify_batch(ctx, hi - lo, at32(pk, lo), at32(input, lo), at32(output, lo), at32(c, lo), at32(s, lo),
+                                    a.blob, a.off, ad_len, status + lo);
+  });
+}
+
+int32_t vrfhip_ietf_prove_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx, size_t n, const uint8_t* sk,
+                                      const uint8_t* msg, const uint32_t* msg_off, uint32_t msg_len, const uint8_t* input,
+                                      const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len, uint8_t* output,
+                                      uint8_t* c, uint8_t* s, uint8_t* pk_out, uint8_t* input_out, uint8_t* status) {
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!sk || !output || !c || !s) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  return run_sharded(ctxs, n_ctx, n, [&](vrfhip_ctx* ctx, size_t lo, size_t hi) {
+    BlobSlice m(msg, input ? nullptr : msg_off, msg_len, false, lo, hi), a(ad, ad_off, ad_len, true, lo, hi);
+    return vrfhip_ietf_prove_batch(ctx, hi - lo, at32(sk, lo), m.blob, m.off, msg_len, at32(input, lo), a.blob, a.off,
+                                   ad_len, at32(output, lo), at32(c, lo), at32(s, lo), at32(pk_out, lo),
+                                   at32(input_out, lo), status ? status + lo : nullptr);
+  });
+}
+
+int32_t vrfhip_pedersen_prove_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx, size_t n, const uint8_t* sk,
+                                          const uint8_t* msg, const uint32_t* msg_off, uint32_t msg_len,
+                                          const uint8_t* input, const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                          uint8_t* output, uint8_t* pk_com, uint8_t* r, uint8_t* ok, uint8_t* s,
+                                          uint8_t* sb, uint8_t* blinding_out, uint8_t* input_out, uint8_t* status) {
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!sk || !output || !pk_com || !r || !ok || !s || !sb) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  return run_sharded(ctxs, n_ctx, n, [&](vrfhip_ctx* ctx, size_t lo, size_t hi) {
+    BlobSlice m(msg, input ? nullptr : msg_off, msg_len, false, lo, hi), a(ad, ad_off, ad_len, true, lo, hi);
+    return vrfhip_pedersen_prove_batch(ctx, hi - lo, at32(sk, lo), m.blob, m.off, msg_len, at32(input, lo), a.blob, a.off,
+                                       ad_len, at32(output, lo), at32(pk_com, lo), at32(r, lo), at32(ok, lo), at32(s, lo),
+                                       at32(sb, lo), at32(blinding_out, lo), at32(input_out, lo),
+                                       status ? status + lo : nullptr);
+  });
+}
+
+int32_t vrfhip_pedersen_verify_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx, size_t n, const uint8_t* input,
+                                           const uint8_t* output, const uint8_t* pk_com, const uint8_t* r,
+                                           const uint8_t* ok, const uint8_t* s, const uint8_t* sb, const uint8_t* ad,
+                                           const uint32_t* ad_off, uint32_t ad_len, const uint8_t* rlc_seed,
+                                           uint8_t* status) {
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!input || !output || !pk_com || !r || !ok || !s || !sb || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  return run_sharded(ctxs, n_ctx, n, [&](vrfhip_ctx* ctx, size_t lo, size_t hi) {
+    BlobSlice a(ad, ad_off, ad_len, true, lo, hi);
+    if (rlc_seed)      // one multi-scalar multiplication per device slice; per-proof fallback inside the slice
+      return vrfhip_pedersen_verify_batch_rlc(ctx, hi - lo, at32(input, lo), at32(output, lo), at32(pk_com, lo), at32(r, lo),
+                                              at32(ok, lo), at32(s, lo), at32(sb, lo), a.blob, a.off, ad_len, rlc_seed,
+                                              status + lo, nullptr);
+    return vrfhip_pedersen_verify_batch(ctx, hi - lo, at32(input, lo), at32(output, lo), at32(pk_com, lo), at32(r, lo),
+                                        at32(ok, lo), at32(s, lo), at32(sb, lo), a.blob, a.off, ad_len, status + lo);
+  });
 }
 
 }  // extern "C"

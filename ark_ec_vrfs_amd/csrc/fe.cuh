@@ -415,6 +415,18 @@ VRF_HD bool fe_sqrt_or_zsqrt(FeN& root, const Fe<L, V>& w_in, const SqrtTables& 
 }
 
 
+// Low byte of the 2-adic discrete logarithm: w = (odd-order part) * g^e with g the generator of the
+// 2^32-torsion behind the square-root tables; returns e mod 256.  w (non-zero) is a 2^k-th power, k <= 8, iff
+// 2^k divides the result.  One fixed exponentiation (220 + 24 squarings), constant shape.
+template <int L, int V>
+VRF_HD uint32_t fe_dlog2_low8(const Fe<L, V>& w_in, const SqrtTables& T) {
+  FeN w = fe_mul(w_in, fe_one());
+  FeN v = fe_pow_prog(w, vrfk::POW_SQRT_PROG);        // w^((t-1)/2)
+  FeN b = fe_mul(fe_mul(w, v), v);                  // w^t, in the 2^32-torsion
+  for (int i = 0; i < 24; ++i) b = fe_sqr(b);       // g^(e 2^24): depends on e mod 2^8 only
+  return sqrt_lut_index(T, b);
+}
+
 // ------------------------------------------------------------------ quadratic character (Jacobi symbol)
 // Is w a non-zero square?  The Euler criterion costs an exponentiation (~255 squarings, ~58 k instruction
 // slots).  Here: the Jacobi symbol (g / q) by "positive divsteps" (Bernstein-Yang safegcd with the sum in

@@ -122,20 +122,7 @@ __global__ void __launch_bounds__(BLOCK) k_point_validate(size_t n, const uint8_
   FeN di = fe_inv(a.den);
   Fe<1, 4> x;
   bool ok = decode_phase_b<S>(x, a, di, T.sq);
-  if constexpr (S::SUBGROUP_2DESCENT) {
-    ok = ok && subgroup_by_2descent<S>(a.y, T.sq);
-  } else {
-    uint32_t* tab = tabs + i * WIN_TABLE_WORDS;
-    build_win_table<S>(tab, x, a.y);
-    uint32_t r[8], rec[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = S::r32(j);
-    scalar_recode_signed4(rec, r);
-    PtE rp = win_mul<S>(tab, rec);
-    // identity <=> X == 0 and Y == Z
-    bool is_id = fe_is_zero(rp.X) && fe_eq(rp.Y, rp.Z);
-    ok = ok && is_id;
-  }
+  ok = ok && in_prime_subgroup<S>(fe_mul(x, fe_one()), a.y, T.sq);
   status[i] = ok ? ST_OK : ST_INVALID_DATA;
   if (xy) {
     uint32_t xw[8], yw[8];
@@ -168,16 +155,7 @@ __global__ void __launch_bounds__(BLOCK) k_keyset_decode(size_t n, const uint8_t
   Fe<1, 4> x;
   bool ok = decode_phase_b<S>(x, a, di, T.sq);
   FeN xn = fe_mul(x, fe_one());
-  if constexpr (S::SUBGROUP_2DESCENT) {
-    ok = ok && subgroup_by_2descent<S>(a.y, T.sq);
-  } else {
-    // r * P = O by the branch-free ladder (one-time cost per key)
-    uint32_t r[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = S::r32(j);
-    PtE rp = te_mul_slow<S>(te_from_affine(xn, a.y), r);
-    ok = ok && fe_is_zero(rp.X) && fe_eq(rp.Y, rp.Z);
-  }
+  ok = ok && in_prime_subgroup<S>(xn, a.y, T.sq);
   // an invalid key gets the identity's tables: every proof that names it is reported InvalidData anyway
   FeN ky = fe_select(ok, a.y, fe_one());
   xn = fe_select(ok, xn, fe_zero());
@@ -202,6 +180,100 @@ void launch_keyset_build(int suite, size_t n_keys, const uint8_t* pks, uint32_t*
     hipLaunchKernelGGL(k_keyset_comb<S>, dim3((unsigned)((n_keys * COMB_ROWS + 63) / 64)), dim3(64), 0, st, n_keys, xy,
                        combs, prefix);
   });
+}
+
+// ---- test primitives: the group law, scalar multiplication, SHA-512 and XMD on their own ----
+// a + b of two decoded points (no subgroup test: the law itself is what is tested)
+template <class S>
+__global__ void __launch_bounds__(BLOCK) k_test_point_add(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out,
+                                                           uint8_t* status, DevTables T) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t ea[8], eb[8], e[8];
+  load32(ea, a, i); load32(eb, b, i);
+  DecodeA da = decode_phase_a<S>(ea), db = decode_phase_a<S>(eb);
+  FeN dens[2] = {da.den, db.den}, dinv[2];
+  fe_batch_inv(dinv, dens);
+  Fe<1, 4> xa, xb;
+  bool ok = decode_phase_b<S>(xa, da, dinv[0], T.sq);
+  ok = decode_phase_b<S>(xb, db, dinv[1], T.sq) && ok;
+  PtE r = te_add<S>(te_from_affine(xa, da.y), te_from_affine(xb, db.y));
+  FeN x, y;
+  te_to_affine(x, y, r);
+  te_encode_affine(e, x, y);
+  if (!ok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = 0;
+  }
+  store32(out, i, e);
+  status[i] = ok ? ST_OK : ST_INVALID_DATA;
+}
+// k * P by the variable-base path of the provers (GLV Straus on Bandersnatch, 253-bit windows on JubJub)
+template <class S>
+__global__ void __launch_bounds__(BLOCK) k_test_scalar_mul(size_t n, const uint8_t* k, const uint8_t* p, uint8_t* out,
+                                                            uint8_t* status, uint32_t* tabs, DevTables T) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t kw[8], ep[8], e[8];
+  load32(kw, k, i); load32(ep, p, i);
+  DecodeA d = decode_phase_a<S>(ep);
+  FeN di = fe_inv(d.den);
+  Fe<1, 4> x;
+  bool ok = decode_phase_b<S>(x, d, di, T.sq) && fr_is_canonical<S>(kw);
+  if (!fr_is_canonical<S>(kw)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kw[j] = 0;
+  }
+  uint32_t* tab = tabs + i * (2 * WIN_TABLE_WORDS);
+  build_glv_tables<S>(tab, x, d.y);
+  PtE r = var_base_mul<S>(tab, kw);
+  FeN rx, ry;
+  te_to_affine(rx, ry, r);
+  te_encode_affine(e, rx, ry);
+  if (!ok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = 0;
+  }
+  store32(out, i, e);
+  status[i] = ok ? ST_OK : ST_INVALID_DATA;
+}
+// which = 0: SHA-512 (64 B per item); which = 1: expand_message_xmd to 96 bytes with the context's DST
+template <class S>
+__global__ void __launch_bounds__(BLOCK) k_test_hash(size_t n, BytesView msg, uint8_t* out, int which, const SuiteStr* ss) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* m; uint32_t len;
+  bytes_get(msg, i, m, len);
+  if (which == 0) {
+    Sha512 h;
+    sha512_init(h);
+    sha512_put_bytes(h, m, len);
+    sha512_final(h);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + i * 64);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j] = sha512_word_mem(h, j);
+  } else {
+    uint64_t hb[2][8];
+    expand_message_xmd96<S>(hb, m, len, *ss);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + i * 96);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const uint64_t w = j < 8 ? hb[0][j] : hb[1][j - 8];
+      o[2 * j] = bswap32((uint32_t)(w >> 32));
+      o[2 * j + 1] = bswap32((uint32_t)w);
+    }
+  }
+}
+void launch_test_point_add(int suite, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint8_t* status,
+                           DevTables T, hipStream_t st) {
+  if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_test_point_add<S>, grid_for(n), dim3(BLOCK), 0, st, n, a, b, out, status, T));
+}
+void launch_test_scalar_mul(int suite, size_t n, const uint8_t* k, const uint8_t* p, uint8_t* out, uint8_t* status,
+                            uint32_t* tabs, DevTables T, hipStream_t st) {
+  if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_test_scalar_mul<S>, grid_for(n), dim3(BLOCK), 0, st, n, k, p, out, status, tabs, T));
+}
+void launch_test_hash(int suite, size_t n, BytesView msg, uint8_t* out, int which, DevTables T, hipStream_t st) {
+  if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_test_hash<S>, grid_for(n), dim3(BLOCK), 0, st, n, msg, out, which, T.sq.str));
 }
 
 // ---- test primitive: Fq multiplication ----

@@ -123,15 +123,11 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_rlc_decode(RlcArgs a) {
         inv = fe_mul(inv, d.den);
         Fe<1, 4> x;
         bool ok = decode_phase_b<S>(x, d, di, a.T.sq);
-        if (a.check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF)) {
-          // subgroup test; suites without the 2-descent build a window table behind the item's decode slots
-          uint32_t* tab = a.scratch + item * (size_t)a.scratch_stride + 5 * RLC_SLOT;
-          if constexpr (!S::SUBGROUP_2DESCENT) build_win_table_from<S>(tab, te_from_affine(x, d.y));
-          ok = in_prime_subgroup<S>(d.y, tab, a.T.sq) && ok;
-        }
-        if (!ok) valid_mask &= ~(1u << (j / 5));
         PtA pa;
         pa.x = fe_mul(x, fe_one());
+        if (a.check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF))
+          ok = in_prime_subgroup<S>(pa.x, d.y, a.T.sq) && ok;
+        if (!ok) valid_mask &= ~(1u << (j / 5));
         pa.y = d.y;
         pa.dt = fe_mul(fe_mul(pa.x, pa.y), S::d());
         pta_store(a.L.pts + rlc_index(p, n, item) * PTA_WORDS, pa);
@@ -182,11 +178,8 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_rlc_prep_affine(RlcArgs a) {
       FeN x2 = fe_sqr(pa.x), y2 = fe_sqr(pa.y);
       auto lhs = fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(S::mul_aneg(x2), fe_one())))));
       valid = fe_eq(lhs, fe_mul(pa.dt, xyv)) && valid;
-      if (a.check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF)) {
-        uint32_t* tab = a.scratch + item * (size_t)a.scratch_stride;
-        if constexpr (!S::SUBGROUP_2DESCENT) build_win_table_from<S>(tab, te_from_affine(pa.x, pa.y));
-        valid = in_prime_subgroup<S>(pa.y, tab, a.T.sq) && valid;
-      }
+      if (a.check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF))
+        valid = in_prime_subgroup<S>(pa.x, pa.y, a.T.sq) && valid;
       pta_store(a.L.pts + rlc_index(p, n, item) * PTA_WORDS, pa);
       // compressed encoding for the challenge: y, sign bit = (x > q - x); slot order pk_com, H, Gamma, R, Ok
       uint32_t e[8];

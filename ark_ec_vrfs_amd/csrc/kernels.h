@@ -117,6 +117,12 @@ void launch_pairing_check2(size_t n, const uint8_t* g1, const uint8_t* g2, size_
                            hipStream_t st, uint32_t* prep = nullptr);
 void launch_pairing_quad_selftest(size_t n, const uint8_t* in, uint8_t* status, hipStream_t st);
 void launch_fq_mul(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* r, hipStream_t st);
+// test primitives: group law, variable-base scalar multiplication (tabs: 2 * WIN_TABLE_WORDS words per item), hashes
+void launch_test_point_add(int suite, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint8_t* status,
+                           DevTables T, hipStream_t st);
+void launch_test_scalar_mul(int suite, size_t n, const uint8_t* k, const uint8_t* p, uint8_t* out, uint8_t* status,
+                            uint32_t* tabs, DevTables T, hipStream_t st);
+void launch_test_hash(int suite, size_t n, BytesView msg, uint8_t* out, int which, DevTables T, hipStream_t st);
 
 // 32-byte item <-> registers
 VRF_HD void load32(uint32_t w[8], const uint8_t* base, size_t i) {

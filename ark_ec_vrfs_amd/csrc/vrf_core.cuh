@@ -289,21 +289,46 @@ VRF_HD PtE win_mul(const uint32_t* tab, const uint32_t rec[8], bool negate = fal
   return acc;
 }
 
-// Prime-order subgroup membership of a decoded point [ref src/lib.rs:14 `codec`: arkworks' checked
-// deserialisation].  Bandersnatch: 2-descent on y (two Jacobi symbols).  JubJub (cyclic 2-part Z8): r*P = O from
-// the point's window table `tab` (multiples 1..8, cached form) -- the test arkworks itself runs.
+// Prime-order subgroup membership for a curve whose rational 2-power torsion is cyclic of order 8 (JubJub: one
+// rational point of order 2, cofactor 8): P lies in 8E iff the reduced Tate pairing with a generator T8 of the
+// 8-torsion is trivial, t_8(T8, P) = f_{8,T8}(P)^((q-1)/8) = 1.  f is three doubling steps of Miller's loop with
+// FIXED lines (T8, T4 = 2 T8, T2 = 4 T8 are constants: tools/gen_constants.py derives them and the formula below,
+// and checks it against r*P = O), evaluated without inversions modulo 8th powers:
+//   Yn = 1 + y, W = (1 - y) x, V2 = (1 + y) x, Xn = V2 + (A/3) W,
+//   V4 = Xn - c4 W, L4 = Yn - y4 W - lam4 V4, V8 = Xn - c8 W, L8 = Yn - y8 W - lam8 V8,
+//   f = L8^4 L4^2 V4^4 (B V2 W)^7,
+// and f is an 8th power iff 8 divides the 2-adic discrete logarithm of f (one fixed exponentiation, ~60 k
+// instruction slots; arkworks' own test, r*P = O, is a 252-bit scalar multiplication: ~330 k).  f = 0 only on
+// small-order points; the identity is accepted explicitly.
 template <class S>
-VRF_HD bool in_prime_subgroup(const FeN& y, const uint32_t* tab, const SqrtTables& T) {
-  if constexpr (S::SUBGROUP_2DESCENT) {
-    return subgroup_by_2descent<S>(y, T);
-  } else {
-    uint32_t r[8], rec[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = S::r32(j);
-    scalar_recode_signed4(rec, r);
-    PtE rp = win_mul<S>(tab, rec);
-    return fe_is_zero(rp.X) && fe_eq(rp.Y, rp.Z);
-  }
+VRF_HD bool subgroup_by_tate8(const FeN& x, const FeN& y, const SqrtTables& T) {
+  const FeN one = fe_one();
+  const bool is_identity = fe_is_zero(x) && fe_eq(y, one);
+  const FeN Yn = fe_mul(fe_add(one, y), one);                              // 1 + y (reduced)
+  const FeN W = fe_mul(fe_sub(one, y), x);                                 // (1 - y) x
+  const FeN V2 = fe_mul(Yn, x);                                            // (1 + y) x
+  const FeN Xn = fe_mul(fe_add(V2, fe_mul(W, fe_const(vrfk::JJ_TATE_A3_M))), one);
+  const FeN V4 = fe_mul(fe_sub(Xn, fe_mul(W, fe_const(vrfk::JJ_TATE_C4_M))), one);
+  const FeN V8 = fe_mul(fe_sub(Xn, fe_mul(W, fe_const(vrfk::JJ_TATE_C8_M))), one);
+  const FeN t4 = fe_mul(fe_add(fe_mul(W, fe_const(vrfk::JJ_TATE_Y4_M)), fe_mul(V4, fe_const(vrfk::JJ_TATE_LAM4_M))), one);
+  const FeN t8 = fe_mul(fe_add(fe_mul(W, fe_const(vrfk::JJ_TATE_Y8_M)), fe_mul(V8, fe_const(vrfk::JJ_TATE_LAM8_M))), one);
+  const FeN L4 = fe_mul(fe_sub(Yn, t4), one);
+  const FeN L8 = fe_mul(fe_sub(Yn, t8), one);
+  const FeN Z = fe_mul(fe_mul(V2, W), fe_const(vrfk::JJ_TATE_B_M));
+  const FeN Z2 = fe_sqr(Z), Z4 = fe_sqr(Z2);
+  const FeN Z7 = fe_mul(fe_mul(Z4, Z2), Z);
+  const FeN L8_4 = fe_sqr(fe_sqr(L8)), V4_4 = fe_sqr(fe_sqr(V4)), L4_2 = fe_sqr(L4);
+  const FeN f = fe_mul(fe_mul(L8_4, L4_2), fe_mul(V4_4, Z7));
+  const bool eighth_power = !fe_is_zero(f) && (fe_dlog2_low8(f, T) & 7u) == 0;
+  return is_identity || eighth_power;
+}
+
+// Prime-order subgroup membership of a decoded point (x, y) [ref src/lib.rs:14 `codec`: arkworks' checked
+// deserialisation].  Bandersnatch: 2-descent on y (two Jacobi symbols).  JubJub: Tate pairing with the 8-torsion.
+template <class S>
+VRF_HD bool in_prime_subgroup(const FeN& x, const FeN& y, const SqrtTables& T) {
+  if constexpr (S::SUBGROUP_2DESCENT) return subgroup_by_2descent<S>(y, T);
+  else return subgroup_by_tate8<S>(x, y, T);
 }
 
 // ---- fixed-base tables of the suite's generators G and B: signed GCB-bit windows, no doublings ----
@@ -564,7 +589,7 @@ VRF_HD bool verify_decode_item(const DevTables& T, const uint32_t pk[8], const u
     Fe<1, 4> x;
     valid = decode_phase_b<S>(x, a, di, T.sq) && valid;
     build_glv_tables<S>(tabs + p * 2 * WIN_TABLE_WORDS, x, a.y);
-    if ((check_mask >> p) & 1u) valid = in_prime_subgroup<S>(a.y, tabs + p * 2 * WIN_TABLE_WORDS, T.sq) && valid;
+    if ((check_mask >> p) & 1u) valid = in_prime_subgroup<S>(fe_mul(x, fe_one()), a.y, T.sq) && valid;
   }
   return valid;
 }
@@ -628,7 +653,7 @@ VRF_HD void verify_decode_multi(int K, const DevTables& T, size_t first, size_t 
       bool ok = decode_phase_b<S>(x, a, di, T.sq);
       uint32_t* tab = tabs_base + item * (VERIFY_TABS * WIN_TABLE_WORDS) + p * 2 * WIN_TABLE_WORDS;
       build_glv_tables<S>(tab, x, a.y);
-      if ((check_mask >> p) & 1u) ok = in_prime_subgroup<S>(a.y, tab, T.sq) && ok;    // bit p: pk, H, Gamma
+      if ((check_mask >> p) & 1u) ok = in_prime_subgroup<S>(fe_mul(x, fe_one()), a.y, T.sq) && ok;    // bit p: pk, H, Gamma
       if (!ok) valid_mask &= ~(1u << (j / NP));
     }
   }
@@ -732,7 +757,7 @@ VRF_HD bool verify_decode_affine_item(uint32_t enc_out[3][8], const uint32_t (&x
     auto lhs = fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(S::mul_aneg(x2), fe_one())))));
     valid = fe_eq(lhs, fe_mul(fe_mul(fe_sqr(xyv), S::d()), fe_one())) && valid;
     build_glv_tables<S>(tabs + p * 2 * WIN_TABLE_WORDS, x, y);
-    if ((check_mask >> p) & 1u) valid = in_prime_subgroup<S>(y, tabs + p * 2 * WIN_TABLE_WORDS, T) && valid;
+    if ((check_mask >> p) & 1u) valid = in_prime_subgroup<S>(x, y, T) && valid;
     uint32_t e[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[j] = yw[j];
@@ -838,8 +863,10 @@ VRF_HD void put_dst_prime(Sha512& h, const SuiteStr& ss) {
   sha512_put_byte(h, (uint8_t)ss.dst_len);
 }
 
+// expand_message_xmd(SHA-512) to 96 bytes with arkworks' 48-byte Z_pad: uniform = b1 || b2[0..32];
+// b1, b2 as the eight big-endian 64-bit words of each digest
 template <class S>
-VRF_HD void hash_to_field2(Fe<1, 4>& u0, Fe<1, 4>& u1, const uint8_t* msg, uint32_t msg_len, const SuiteStr& ss) {
+VRF_HD void expand_message_xmd96(uint64_t (&hb)[2][8], const uint8_t* msg, uint32_t msg_len, const SuiteStr& ss) {
   Sha512 b0;
   sha512_init(b0);
 #pragma unroll
@@ -854,7 +881,6 @@ VRF_HD void hash_to_field2(Fe<1, 4>& u0, Fe<1, 4>& u1, const uint8_t* msg, uint3
 #pragma unroll
   for (int i = 0; i < 8; ++i) h0[i] = b0.h[i];
   // b1 = H(b0 || 0x01 || DST'), b2 = H((b0 ^ b1) || 0x02 || DST'): one hashing site, two trips
-  uint64_t hb[2][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) h1[i] = 0;
 #pragma unroll 1
@@ -871,6 +897,12 @@ VRF_HD void hash_to_field2(Fe<1, 4>& u0, Fe<1, 4>& u1, const uint8_t* msg, uint3
       if (t == 0) { h1[i] = b.h[i]; hb[0][i] = b.h[i]; } else { hb[1][i] = b.h[i]; }
     }
   }
+}
+
+template <class S>
+VRF_HD void hash_to_field2(Fe<1, 4>& u0, Fe<1, 4>& u1, const uint8_t* msg, uint32_t msg_len, const SuiteStr& ss) {
+  uint64_t hb[2][8];
+  expand_message_xmd96<S>(hb, msg, msg_len, ss);
   // uniform = b1 (64 B) || b2[0..32];  u0 = BE(b1.h[0..6]);  u1 = BE(b1.h[6..8] || b2.h[0..4])
   uint32_t w0[16], w1[16];
 #pragma unroll
@@ -1110,7 +1142,7 @@ VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, 
   te_encode_affine(h_enc, x, y);
   nonce_rfc8032<S>(k, sk, h_enc);
   build_glv_tables<S>(tab, x, y);          // {H, psi H}: 2 * WIN_TABLE_WORDS
-  if (h_given && (check_mask & CHK_INPUT)) valid = in_prime_subgroup<S>(y, tab, T.sq) && valid;   // a given H is wire data
+  if (h_given && (check_mask & CHK_INPUT)) valid = in_prime_subgroup<S>(x, y, T.sq) && valid;   // a given H is wire data
   return valid;
 }
 
@@ -1201,6 +1233,32 @@ VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t 
       flags[item] = fr_is_canonical<S>(sk) ? 1 : 0;
     }
   }
+}
+
+// scalar * P from the GLV table pair {P, psi P} (or the single 253-bit table of a suite without endomorphism)
+template <class S>
+VRF_HD PtE var_base_mul(const uint32_t* tab, const uint32_t scalar[8]) {
+  PtE w;
+  if constexpr (S::HAS_GLV) {
+    Straus4 q;
+    GlvHalf h[2];
+    glv_decompose_bs(h[0], h[1], scalar);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      scalar_recode_signed4_128(q.rec[t], h[t].mag);
+      q.neg[t] = h[t].neg;
+    }
+    q.tab[0] = tab; q.tab[1] = tab + WIN_TABLE_WORDS; q.tab[2] = tab; q.tab[3] = tab;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { q.rec[2][i] = 0; q.rec[3][i] = 0; }
+    q.neg[2] = false; q.neg[3] = false;
+    w = straus4<S, 2>(q);
+  } else {
+    uint32_t rec[8];
+    scalar_recode_signed4(rec, scalar);
+    w = win_mul<S>(tab, rec);
+  }
+  return w;
 }
 
 template <class S>
@@ -1332,22 +1390,14 @@ VRF_HD bool pedersen_verify_decode_item(uint32_t c_out[8], const DevTables& T,
     Fe<1, 4> x;
     valid = decode_phase_b<S>(x, a, di, T.sq) && valid;
     // check_mask: H is an input, Gamma an output, pk_com / R / Ok proof points
-    const bool chk = (check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF)) != 0;
+    if (check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF))
+      valid = in_prime_subgroup<S>(fe_mul(x, fe_one()), a.y, T.sq) && valid;
     if (p < 3) {
-      uint32_t* tab = tabs + p * 2 * WIN_TABLE_WORDS;
-      build_glv_tables<S>(tab, x, a.y);
-      if (chk) valid = in_prime_subgroup<S>(a.y, tab, T.sq) && valid;
+      build_glv_tables<S>(tabs + p * 2 * WIN_TABLE_WORDS, x, a.y);
     } else {
       uint32_t* dst = pts + (p == 3 ? PED_R_OFF : PED_OK_OFF);
       fe_store(dst, x);
       fe_store(dst + NL, a.y);
-      if (chk) {
-        // R and Ok have no Straus table; suites without the 2-descent borrow the odd table slots (unused
-        // without an endomorphism) for the r*P = O test
-        uint32_t* tab = tabs + (p == 3 ? 1 : 3) * WIN_TABLE_WORDS;
-        if constexpr (!S::SUBGROUP_2DESCENT) build_win_table_from<S>(tab, te_from_affine(x, a.y));
-        valid = in_prime_subgroup<S>(a.y, tab, T.sq) && valid;
-      }
     }
   }
   uint32_t cp[5][8];

@@ -373,6 +373,50 @@ int32_t vrfhip_point_validate_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t
  * (1 mul, 2 sqr, 4 cyclotomic sqr, 8 mul_by_014, 16 frobenius, 32 conj / gather-scatter); 0 = all equal. */
 int32_t vrfhip_test_pairing_quad_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp12_pairs, uint8_t* status);
 
+/* One call, several devices ------------------------------------------------------------ */
+
+/* The batch entry points above over n_ctx contexts (one per GPU, same suite descriptor): items are independent
+ * (SURVEY.md section 8e), so context g gets the contiguous slice [g*n/n_ctx, (g+1)*n/n_ctx) and one host thread;
+ * no data crosses devices.  Host pointers, same semantics and statuses as the single-context call on the whole
+ * batch.  This is what a single-process Rust caller uses to spread `prove` / `verify` over the 8 GPUs of a node
+ * (multi-process callers shard the same way and gather results over RCCL: ark_ec_vrfs_amd/sharding.py).
+ * Returns the first failing slice's error.  rlc_seed (vrfhip_pedersen_verify_batch_multi): NULL = per-proof
+ * verification; non-NULL (32 bytes) = one multi-scalar multiplication per slice with the per-proof fallback. */
+int32_t vrfhip_ietf_verify_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx, size_t n, const uint8_t* pk,
+                                       const uint8_t* input, const uint8_t* output, const uint8_t* c, const uint8_t* s,
+                                       const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len, uint8_t* status);
+int32_t vrfhip_ietf_prove_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx, size_t n, const uint8_t* sk,
+                                      const uint8_t* msg, const uint32_t* msg_off, uint32_t msg_len, const uint8_t* input,
+                                      const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len, uint8_t* output,
+                                      uint8_t* c, uint8_t* s, uint8_t* pk_out, uint8_t* input_out, uint8_t* status);
+int32_t vrfhip_pedersen_prove_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx, size_t n, const uint8_t* sk,
+                                          const uint8_t* msg, const uint32_t* msg_off, uint32_t msg_len,
+                                          const uint8_t* input, const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                          uint8_t* output, uint8_t* pk_com, uint8_t* r, uint8_t* ok, uint8_t* s,
+                                          uint8_t* sb, uint8_t* blinding_out, uint8_t* input_out, uint8_t* status);
+int32_t vrfhip_pedersen_verify_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx, size_t n, const uint8_t* input,
+                                           const uint8_t* output, const uint8_t* pk_com, const uint8_t* r,
+                                           const uint8_t* ok, const uint8_t* s, const uint8_t* sb, const uint8_t* ad,
+                                           const uint32_t* ad_off, uint32_t ad_len, const uint8_t* rlc_seed,
+                                           uint8_t* status);
+
+/* Test-only primitives: the pieces under the batch calls, on their own, host pointers.
+ * point_add: out[i] = a[i] + b[i] (`AffinePoint` addition, ark_ec TE group law; src/lib.rs:15), compressed points,
+ *            status 2 if an operand does not decode (no subgroup test: the law is what is tested);
+ * scalar_mul: out[i] = scalars[i] * points[i] (`mul_bigint` through the provers' variable-base path);
+ * sha512:   out[i] = SHA-512(msg_i), 64 bytes (`Suite::Hasher`, src/lib.rs:16);
+ * xmd:      out[i] = expand_message_xmd(msg_i, DST of the context's descriptor, 96 bytes) with arkworks' 48-byte
+ *           Z_pad (`utils::hash_to_curve_ell2_rfc_9380`'s expander, src/lib.rs:14).  Messages as in
+ *           vrfhip_hash_to_curve_batch. */
+int32_t vrfhip_test_point_add(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out,
+                              uint8_t* status);
+int32_t vrfhip_test_scalar_mul(vrfhip_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out,
+                               uint8_t* status);
+int32_t vrfhip_test_sha512(vrfhip_ctx* ctx, size_t n, const uint8_t* msg, const uint32_t* msg_off, uint32_t msg_len,
+                           uint8_t* out);
+int32_t vrfhip_test_xmd(vrfhip_ctx* ctx, size_t n, const uint8_t* msg, const uint32_t* msg_off, uint32_t msg_len,
+                        uint8_t* out);
+
 /* Test-only: how many proofs one lane of the inversion-sharing stages (decode, finish, prepare) handles for a
  * launch group of n items (1, 2, 4 or 8): lets the parity tests assert that every kernel variant was exercised. */
 int32_t vrfhip_debug_proofs_per_lane(size_t n);

@@ -1,0 +1,308 @@
+//! `ark-ec-vrfs-hip` -- the `ark-ec-vrfs` API with an MI355X batch backend.
+//!
+//! The reference crate (`/root/reference/src/lib.rs:13-17`) is a re-export of `ark_vrf`; this crate re-exports the
+//! same list, so existing code keeps compiling, and adds [`GpuBatch`]: batches of `prove` / `verify` routed through
+//! libvrfhip's C ABI (`include/vrfhip.h`, raw bindings in [`ffi`]).  Single items keep using the arkworks CPU path
+//! (`BASELINE.json` configs[0]); a batch is where the GPU pays.
+//!
+//! **Status: source only.**  The build image has no Rust toolchain and the arithmetic crates are not vendored, so
+//! this file has never been compiled.  The `ark_vrf` items it names are the ones the reference re-exports; their exact
+//! signatures (`codec::point_encode`, `Secret::scalar`, `PedersenSuite::BLINDING_BASE`, ...) are recollections of
+//! upstream and may need touching up against the real crate.  What is machine-checked here is the FFI boundary:
+//! `src/ffi.rs` is generated from the C header and `tests/test_rust_shim.py` compares the two item by item.
+#![cfg_attr(not(feature = "std"), no_std)]
+extern crate alloc;
+
+use alloc::vec;
+use alloc::vec::Vec;
+use core::marker::PhantomData;
+
+// the reference's whole public surface (src/lib.rs:13-17), unchanged
+pub use ark_vrf::{
+    codec, ietf, pedersen, reexports, ring, ring_suite_types, suite_types, suites, utils, AffinePoint, BaseField,
+    CurveConfig, Error, HashOutput, Input, Output, Public, ScalarField, Secret, Suite,
+};
+
+pub mod ffi;
+
+use ark_vrf::pedersen::PedersenSuite;
+use ark_vrf::reexports::ark_serialize::CanonicalSerialize;
+
+/// Failure of the library itself (bad argument, HIP error, out of memory, no device): `vrfhip_error` + message.
+/// Per-item outcomes are `ark_vrf::Error` values, exactly as the CPU API reports them.
+#[derive(Debug, Clone)]
+pub struct GpuError {
+    pub code: i32,
+    pub message: alloc::string::String,
+}
+
+fn check(rc: i32) -> Result<(), GpuError> {
+    if rc == ffi::VRFHIP_SUCCESS {
+        return Ok(());
+    }
+    let msg = unsafe { core::ffi::CStr::from_ptr(ffi::vrfhip_last_error()) };
+    Err(GpuError { code: rc, message: msg.to_string_lossy().into_owned() })
+}
+
+fn status_to_result(st: u8) -> Result<(), Error> {
+    match st as i32 {
+        ffi::VRFHIP_ST_OK => Ok(()),
+        ffi::VRFHIP_ST_VERIFICATION_FAILURE => Err(Error::VerificationFailure),
+        _ => Err(Error::InvalidData),
+    }
+}
+
+/// A suite libvrfhip has arithmetic for.  Everything a `Suite` states as data travels in the descriptor, filled from
+/// the trait's own constants, so the GPU runs exactly the suite the CPU code runs (in particular the upstream JubJub
+/// suite string and blinding base, which libvrfhip's built-in JubJub descriptor does not claim to know).
+pub trait GpuSuite: Suite + PedersenSuite {
+    /// `ffi::VRFHIP_CURVE_*`: which compiled curve arithmetic (and hash-to-curve construction) applies.
+    const CURVE: i32;
+    /// RFC 9380 domain separation tag of `Suite::data_to_point` (Elligator suites); empty for try-and-increment.
+    fn h2c_dst() -> Vec<u8>;
+
+    fn descriptor() -> ffi::vrfhip_suite_desc {
+        let mut d = ffi::vrfhip_suite_desc {
+            struct_size: core::mem::size_of::<ffi::vrfhip_suite_desc>() as u32,
+            curve: Self::CURVE,
+            suite_id_len: Self::SUITE_ID.len() as u32,
+            suite_id: [0u8; 64],
+            h2c_dst_len: 0,
+            h2c_dst: [0u8; 128],
+            generator: [0u8; 64],
+            blinding_base: [0u8; 64],
+            challenge_len: Self::CHALLENGE_LEN as u32,
+        };
+        d.suite_id[..Self::SUITE_ID.len()].copy_from_slice(Self::SUITE_ID);
+        let dst = Self::h2c_dst();
+        d.h2c_dst_len = dst.len() as u32;
+        d.h2c_dst[..dst.len()].copy_from_slice(&dst);
+        affine_xy::<Self>(&Self::generator(), &mut d.generator);
+        affine_xy::<Self>(&Self::BLINDING_BASE, &mut d.blinding_base);
+        d
+    }
+}
+
+impl GpuSuite for suites::bandersnatch::BandersnatchSha512Ell2 {
+    const CURVE: i32 = ffi::VRFHIP_CURVE_BANDERSNATCH;
+    fn h2c_dst() -> Vec<u8> {
+        // "ECVRF_" || h2c suite id || SUITE_ID (authenticated by the golden vectors)
+        [b"ECVRF_".as_slice(), b"Bandersnatch_XMD:SHA-512_ELL2_RO_", Self::SUITE_ID].concat()
+    }
+}
+
+impl GpuSuite for suites::jubjub::JubJubSha512Tai {
+    const CURVE: i32 = ffi::VRFHIP_CURVE_JUBJUB;
+    fn h2c_dst() -> Vec<u8> {
+        Vec::new()
+    }
+}
+
+/// x || y, 32-byte little-endian canonical integers (arkworks' uncompressed field encoding, twice)
+fn affine_xy<S: Suite>(p: &AffinePoint<S>, out: &mut [u8; 64]) {
+    p.x.serialize_uncompressed(&mut out[..32]).expect("32-byte base field");
+    p.y.serialize_uncompressed(&mut out[32..]).expect("32-byte base field");
+}
+
+fn point32<S: Suite>(p: &AffinePoint<S>, out: &mut [u8]) {
+    let mut buf = Vec::with_capacity(32);
+    codec::point_encode::<S>(p, &mut buf);
+    out.copy_from_slice(&buf);
+}
+
+fn scalar32<S: Suite>(k: &ScalarField<S>, out: &mut [u8]) {
+    let mut buf = Vec::with_capacity(32);
+    codec::scalar_encode::<S>(k, &mut buf);
+    out.copy_from_slice(&buf);
+}
+
+/// One context (one GPU) per element; batches are cut into contiguous slices, one host thread per device
+/// (`vrfhip_*_batch_multi`).  `&self` only and internally synchronised, like the CPU API's pure functions.
+pub struct GpuBatch<S: GpuSuite> {
+    ctxs: Vec<*mut ffi::vrfhip_ctx>,
+    _suite: PhantomData<S>,
+}
+
+unsafe impl<S: GpuSuite> Send for GpuBatch<S> {}
+unsafe impl<S: GpuSuite> Sync for GpuBatch<S> {}
+
+impl<S: GpuSuite> GpuBatch<S> {
+    /// One context per listed device, all created from `S`'s own constants.
+    pub fn new(devices: &[i32]) -> Result<Self, GpuError> {
+        let desc = S::descriptor();
+        let mut this = GpuBatch { ctxs: Vec::new(), _suite: PhantomData };
+        for &dev in devices {
+            let mut ctx: *mut ffi::vrfhip_ctx = core::ptr::null_mut();
+            check(unsafe { ffi::vrfhip_ctx_create_desc(&desc, dev, &mut ctx) })?;
+            this.ctxs.push(ctx);
+        }
+        Ok(this)
+    }
+
+    /// The points handed to `verify` are typed arkworks values: their subgroup membership was established when they
+    /// were deserialised, so the library may skip its own test (`VRFHIP_FLAG_PREVALIDATED_*`).  Off by default.
+    pub fn trust_typed_points(&self, on: bool) -> Result<(), GpuError> {
+        let flags = if on { ffi::VRFHIP_FLAG_PREVALIDATED_ALL } else { 0 };
+        for &c in &self.ctxs {
+            check(unsafe { ffi::vrfhip_ctx_set_flags(c, flags) })?;
+        }
+        Ok(())
+    }
+
+    /// `Secret::output` + `ietf::Prover::prove` for every (secret, input) pair.
+    pub fn ietf_prove(
+        &self,
+        secrets: &[Secret<S>],
+        inputs: &[Input<S>],
+        ad: &[u8],
+    ) -> Result<Vec<(Output<S>, ietf::Proof<S>)>, GpuError> {
+        let n = secrets.len();
+        assert_eq!(n, inputs.len());
+        let (mut sk, mut h) = (vec![0u8; n * 32], vec![0u8; n * 32]);
+        for i in 0..n {
+            scalar32::<S>(&secrets[i].scalar, &mut sk[i * 32..(i + 1) * 32]);
+            point32::<S>(&inputs[i].0, &mut h[i * 32..(i + 1) * 32]);
+        }
+        let (mut gamma, mut c, mut s) = (vec![0u8; n * 32], vec![0u8; n * 32], vec![0u8; n * 32]);
+        let mut status = vec![0u8; n];
+        check(unsafe {
+            ffi::vrfhip_ietf_prove_batch_multi(
+                self.ctxs.as_ptr(), self.ctxs.len() as i32, n, sk.as_ptr(), core::ptr::null(), core::ptr::null(), 0,
+                h.as_ptr(), ad.as_ptr(), core::ptr::null(), ad.len() as u32, gamma.as_mut_ptr(), c.as_mut_ptr(),
+                s.as_mut_ptr(), core::ptr::null_mut(), core::ptr::null_mut(), status.as_mut_ptr(),
+            )
+        })?;
+        sk.iter_mut().for_each(|b| *b = 0); // the staged copy of the secrets
+        Ok((0..n)
+            .map(|i| {
+                let out = Output::<S>::from(codec::point_decode::<S>(&gamma[i * 32..(i + 1) * 32]).expect("GPU output"));
+                let proof = ietf::Proof::<S> {
+                    c: codec::scalar_decode::<S>(&c[i * 32..(i + 1) * 32]),
+                    s: codec::scalar_decode::<S>(&s[i * 32..(i + 1) * 32]),
+                };
+                (out, proof)
+            })
+            .collect())
+    }
+
+    /// `ietf::Verifier::verify(&public, input, output, ad, &proof)` for every item: `Ok(())`,
+    /// `Err(Error::VerificationFailure)` or `Err(Error::InvalidData)` per item, as the CPU verifier reports.
+    pub fn ietf_verify(
+        &self,
+        publics: &[Public<S>],
+        inputs: &[Input<S>],
+        outputs: &[Output<S>],
+        ad: &[u8],
+        proofs: &[ietf::Proof<S>],
+    ) -> Result<Vec<Result<(), Error>>, GpuError> {
+        let n = publics.len();
+        assert!(n == inputs.len() && n == outputs.len() && n == proofs.len());
+        let mut buf = vec![0u8; 5 * n * 32];
+        {
+            let (pk, rest) = buf.split_at_mut(n * 32);
+            let (h, rest) = rest.split_at_mut(n * 32);
+            let (g, rest) = rest.split_at_mut(n * 32);
+            let (c, s) = rest.split_at_mut(n * 32);
+            for i in 0..n {
+                let r = i * 32..(i + 1) * 32;
+                point32::<S>(&publics[i].0, &mut pk[r.clone()]);
+                point32::<S>(&inputs[i].0, &mut h[r.clone()]);
+                point32::<S>(&outputs[i].0, &mut g[r.clone()]);
+                scalar32::<S>(&proofs[i].c, &mut c[r.clone()]);
+                scalar32::<S>(&proofs[i].s, &mut s[r]);
+            }
+        }
+        let mut status = vec![0u8; n];
+        let p = buf.as_ptr();
+        check(unsafe {
+            ffi::vrfhip_ietf_verify_batch_multi(
+                self.ctxs.as_ptr(), self.ctxs.len() as i32, n, p, p.add(n * 32), p.add(2 * n * 32), p.add(3 * n * 32),
+                p.add(4 * n * 32), ad.as_ptr(), core::ptr::null(), ad.len() as u32, status.as_mut_ptr(),
+            )
+        })?;
+        Ok(status.into_iter().map(status_to_result).collect())
+    }
+
+    /// `pedersen::Prover::prove`: (output, proof, blinding factor) per item.
+    pub fn pedersen_prove(
+        &self,
+        secrets: &[Secret<S>],
+        inputs: &[Input<S>],
+        ad: &[u8],
+    ) -> Result<Vec<(Output<S>, pedersen::Proof<S>, ScalarField<S>)>, GpuError> {
+        let n = secrets.len();
+        assert_eq!(n, inputs.len());
+        let (mut sk, mut h) = (vec![0u8; n * 32], vec![0u8; n * 32]);
+        for i in 0..n {
+            scalar32::<S>(&secrets[i].scalar, &mut sk[i * 32..(i + 1) * 32]);
+            point32::<S>(&inputs[i].0, &mut h[i * 32..(i + 1) * 32]);
+        }
+        let mut o = vec![0u8; 7 * n * 32]; // gamma | pk_com | r | ok | s | sb | blinding
+        let mut status = vec![0u8; n];
+        let q = o.as_mut_ptr();
+        check(unsafe {
+            ffi::vrfhip_pedersen_prove_batch_multi(
+                self.ctxs.as_ptr(), self.ctxs.len() as i32, n, sk.as_ptr(), core::ptr::null(), core::ptr::null(), 0,
+                h.as_ptr(), ad.as_ptr(), core::ptr::null(), ad.len() as u32, q, q.add(n * 32), q.add(2 * n * 32),
+                q.add(3 * n * 32), q.add(4 * n * 32), q.add(5 * n * 32), q.add(6 * n * 32), core::ptr::null_mut(),
+                status.as_mut_ptr(),
+            )
+        })?;
+        sk.iter_mut().for_each(|b| *b = 0);
+        let pt = |k: usize, i: usize| codec::point_decode::<S>(&o[(k * n + i) * 32..(k * n + i + 1) * 32]).expect("GPU point");
+        let sc = |k: usize, i: usize| codec::scalar_decode::<S>(&o[(k * n + i) * 32..(k * n + i + 1) * 32]);
+        let res = (0..n)
+            .map(|i| {
+                let proof = pedersen::Proof::<S> { pk_com: pt(1, i), r: pt(2, i), ok: pt(3, i), s: sc(4, i), sb: sc(5, i) };
+                (Output::<S>::from(pt(0, i)), proof, sc(6, i))
+            })
+            .collect();
+        o.iter_mut().for_each(|b| *b = 0); // blinding factors
+        Ok(res)
+    }
+
+    /// `pedersen::Verifier::verify` per item.  `batched`: one multi-scalar multiplication per device slice (random
+    /// linear combination, fresh weights from `seed`), falling back to the per-proof kernels when the batch fails --
+    /// same statuses either way.
+    pub fn pedersen_verify(
+        &self,
+        inputs: &[Input<S>],
+        outputs: &[Output<S>],
+        ad: &[u8],
+        proofs: &[pedersen::Proof<S>],
+        batched_seed: Option<&[u8; 32]>,
+    ) -> Result<Vec<Result<(), Error>>, GpuError> {
+        let n = inputs.len();
+        assert!(n == outputs.len() && n == proofs.len());
+        let mut buf = vec![0u8; 7 * n * 32]; // h | gamma | pk_com | r | ok | s | sb
+        for i in 0..n {
+            let at = |k: usize| (k * n + i) * 32..(k * n + i + 1) * 32;
+            point32::<S>(&inputs[i].0, &mut buf[at(0)]);
+            point32::<S>(&outputs[i].0, &mut buf[at(1)]);
+            point32::<S>(&proofs[i].pk_com, &mut buf[at(2)]);
+            point32::<S>(&proofs[i].r, &mut buf[at(3)]);
+            point32::<S>(&proofs[i].ok, &mut buf[at(4)]);
+            scalar32::<S>(&proofs[i].s, &mut buf[at(5)]);
+            scalar32::<S>(&proofs[i].sb, &mut buf[at(6)]);
+        }
+        let mut status = vec![0u8; n];
+        let p = buf.as_ptr();
+        let seed = batched_seed.map_or(core::ptr::null(), |s| s.as_ptr());
+        check(unsafe {
+            ffi::vrfhip_pedersen_verify_batch_multi(
+                self.ctxs.as_ptr(), self.ctxs.len() as i32, n, p, p.add(n * 32), p.add(2 * n * 32), p.add(3 * n * 32),
+                p.add(4 * n * 32), p.add(5 * n * 32), p.add(6 * n * 32), ad.as_ptr(), core::ptr::null(),
+                ad.len() as u32, seed, status.as_mut_ptr(),
+            )
+        })?;
+        Ok(status.into_iter().map(status_to_result).collect())
+    }
+}
+
+impl<S: GpuSuite> Drop for GpuBatch<S> {
+    fn drop(&mut self) {
+        for &c in &self.ctxs {
+            unsafe { ffi::vrfhip_ctx_destroy(c) }; // wipes staged secrets before freeing (api.hip)
+        }
+    }
+}

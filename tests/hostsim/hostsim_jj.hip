@@ -35,6 +35,15 @@ static uint32_t g_check_mask_jj = 0;   // CHK_* bits for the decode stages (0 = 
 extern "C" {
 void hj_set_check_mask(uint32_t m) { g_check_mask_jj = m; }
 void hj_init() { (void)HJ(); }
+// decode + prime-order subgroup test (Tate pairing with the 8-torsion): 0 = in the subgroup, 2 = not decodable / not in it
+int hj_decode_checked(const uint8_t* enc) {
+  uint32_t w[8]; memcpy(w, enc, 32);
+  DecodeA a = decode_phase_a<SJ>(w);
+  FeN di = fe_inv(a.den);
+  Fe<1, 4> x; bool ok = decode_phase_b<SJ>(x, a, di, HJ().t.sq);
+  ok = ok && in_prime_subgroup<SJ>(fe_mul(x, fe_one()), a.y, HJ().t.sq);
+  return ok ? 0 : 2;
+}
 // a descriptor for the host build: suite string + generator and blinding base (x || y little-endian)
 void hj_configure(const uint8_t* id, uint32_t id_len, const uint8_t* g_xy, const uint8_t* b_xy) {
   SuiteStr s{};

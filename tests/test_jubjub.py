@@ -94,6 +94,34 @@ def test_hostsim_jubjub_equals_oracle(hj, J):
         assert hj.hj_pedersen_verify(o.point_encode(J, H), o.point_encode(J, gm), bytes(tam), ad, len(ad)) == 1
 
 
+def test_tate_pairing_subgroup_test_equals_r_times_p(hj, J):
+    """vrf_core.cuh subgroup_by_tate8 (device source, host build) == r*P = O on every coset of the 8-torsion, on
+    random decodable encodings, on the torsion points themselves and on the identity."""
+    rnd = random.Random(77)
+    while True:
+        P = o.point_decode(J, bytes(rnd.getrandbits(8) for _ in range(32)))
+        if P is not None:
+            T8 = o.te_mul(J, J.r, P)
+            if o.te_mul(J, 4, T8) != (0, 1):
+                break
+    tors = [o.te_mul(J, k, T8) for k in range(8)]
+    cases = [(t, k == 0) for k, t in enumerate(tors)]
+    for i in range(60):
+        Pg = o.te_mul(J, rnd.randrange(1, J.r), (J.gx, J.gy))
+        k = i % 8
+        cases.append((o.te_add(J, Pg, tors[k]), k == 0))
+    n_in = 0
+    for P, want in cases:
+        assert o.te_in_prime_subgroup(J, P) == want
+        assert (hj.hj_decode_checked(o.point_encode(J, P)) == 0) == want, P
+        n_in += want
+    for _ in range(120):
+        b = bytes(rnd.getrandbits(8) for _ in range(32))
+        want = o.point_decode_checked(J, b) is not None
+        assert (hj.hj_decode_checked(b) == 0) == want
+    assert n_in >= 8
+
+
 def test_tai_counter_hint_is_exact(hj, J):
     """k_tai_find's verdict (candidate decodes, judged without the inversion) picks the counter try-and-increment
     stops at: hashing from the hint equals hashing from 0 and the oracle, and no smaller counter decodes."""

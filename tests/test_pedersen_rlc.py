@@ -128,7 +128,12 @@ def test_gpu_rlc_verdict_and_statuses_match_the_oracles(ctx, synth):
     assert want_items[11] == 2 and want_items[300] == 2 and want_items.sum() == 4
     got, ok = ctx.pedersen_verify_batch_rlc(*_args(c), ad=ad, seed=SEED)
     assert (got == want_items).all() and ok
-    c["pk_com"][300] = np.frombuffer((2).to_bytes(32, "little"), np.uint8)      # y = 2 decodes: a wrong proof
+    c["pk_com"][300] = np.frombuffer((2).to_bytes(32, "little"), np.uint8)      # y = 2 decodes, outside the subgroup
+    want_items = co.pedersen_verify_batch(*_args(c), ad, threads=NCPU)
+    assert want_items[300] == 2
+    got, ok = ctx.pedersen_verify_batch_rlc(*_args(c), ad=ad, seed=SEED)
+    assert (got == want_items).all() and ok
+    c["pk_com"][300] = a["pk_com"][301]                                         # a valid point, the wrong one
     want_items = co.pedersen_verify_batch(*_args(c), ad, threads=NCPU)
     assert want_items[300] == 1
     got, ok = ctx.pedersen_verify_batch_rlc(*_args(c), ad=ad, seed=SEED)

@@ -1,0 +1,129 @@
+"""GPU (-m gpu): (1) the test primitives of SURVEY.md section 8b -- the twisted-Edwards group law, variable-base scalar
+multiplication, SHA-512 and expand_message_xmd on their own through the C ABI against Python big ints / hashlib / the
+stage vectors of the golden file; (2) the one-call multi-device entry points (vrfhip_*_batch_multi): several contexts
+on device 0 must give byte-for-byte the single-context results (contiguous slices, ragged messages, per-item ad,
+batches smaller than the context count)."""
+import hashlib
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import vrf_oracle as o
+
+pytestmark = pytest.mark.gpu
+S = o.BANDERSNATCH
+NCPU = min(16, os.cpu_count() or 1)
+enc = lambda Sx, P: np.frombuffer(o.point_encode(Sx, P), np.uint8)
+le = lambda v: np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+
+
+def _law_cases(Sx, rnd, n):
+    G = (Sx.gx, Sx.gy)
+    pts = [o.te_mul(Sx, rnd.randrange(1, Sx.r), G) for _ in range(n)]
+    a = pts + [pts[0], pts[1], (0, 1), pts[2], (0, 1)]
+    b = pts[1:] + pts[:1] + [pts[0], o.te_neg(Sx, pts[1]), pts[3], (0, 1), (0, 1)]      # doubling, inverse, identities
+    return a, b
+
+
+def test_point_add_and_scalar_mul_bandersnatch(ctx):
+    rnd = random.Random(41)
+    a, b = _law_cases(S, rnd, 24)
+    out, st = ctx.test_point_add(np.stack([enc(S, P) for P in a]), np.stack([enc(S, P) for P in b]))
+    assert (st == 0).all()
+    for i, (P, Qp) in enumerate(zip(a, b)):
+        assert out[i].tobytes() == o.point_encode(S, o.te_add(S, P, Qp)), i
+    # an undecodable operand
+    bad = np.stack([enc(S, a[0]), le(S.q)])
+    out, st = ctx.test_point_add(bad, np.stack([enc(S, a[1]), enc(S, a[1])]))
+    assert list(st) == [0, 2]
+    # k * P against the double-and-add oracle, edge scalars included
+    ks = [0, 1, 2, S.r - 1, S.r - 2, (1 << 128) - 1, 1 << 128, (1 << 252) + 12345] + [rnd.randrange(S.r) for _ in range(24)]
+    ks = [k % S.r for k in ks]
+    pts = [o.te_mul(S, rnd.randrange(1, S.r), (S.gx, S.gy)) for _ in ks]
+    out, st = ctx.test_scalar_mul(np.stack([le(k) for k in ks]), np.stack([enc(S, P) for P in pts]))
+    assert (st == 0).all()
+    for i, (k, P) in enumerate(zip(ks, pts)):
+        assert out[i].tobytes() == o.point_encode(S, o.te_mul(S, k, P)), i
+    # k * G == Secret::public for a thousand scalars (C oracle), and k >= r is InvalidData
+    n = 1000
+    sk = np.stack([np.frombuffer(co.secret_from_seed(bytes([i & 255, i >> 8, 3])), np.uint8) for i in range(n)])
+    G = np.tile(enc(S, (S.gx, S.gy)), (n, 1))
+    out, st = ctx.test_scalar_mul(sk, G)
+    for i in range(n):
+        assert out[i].tobytes() == co.public_from_secret(sk[i].tobytes()), i
+    out, st = ctx.test_scalar_mul(np.stack([le(S.r), le(5)]), G[:2])
+    assert list(st) == [2, 0]
+
+
+def test_point_add_and_scalar_mul_jubjub():
+    from ark_ec_vrfs_amd import Context, JubJubSha512Tai
+    J = o.jubjub_params()
+    rnd = random.Random(42)
+    cj = Context(0, suite=JubJubSha512Tai)
+    try:
+        a, b = _law_cases(J, rnd, 12)
+        out, st = cj.test_point_add(np.stack([enc(J, P) for P in a]), np.stack([enc(J, P) for P in b]))
+        assert (st == 0).all()
+        for i, (P, Qp) in enumerate(zip(a, b)):
+            assert out[i].tobytes() == o.point_encode(J, o.te_add(J, P, Qp)), i
+        ks = [0, 1, J.r - 1] + [rnd.randrange(J.r) for _ in range(13)]
+        pts = [o.te_mul(J, rnd.randrange(1, J.r), (J.gx, J.gy)) for _ in ks]
+        out, st = cj.test_scalar_mul(np.stack([le(k) for k in ks]), np.stack([enc(J, P) for P in pts]))
+        for i, (k, P) in enumerate(zip(ks, pts)):
+            assert out[i].tobytes() == o.point_encode(J, o.te_mul(J, k, P)), i
+    finally:
+        cj.close()
+
+
+def test_sha512_and_xmd_primitives(ctx, kat):
+    rnd = random.Random(43)
+    lens = list(range(0, 20)) + [47, 48, 55, 56, 63, 64, 110, 111, 112, 113, 127, 128, 129, 239, 240, 255, 256, 300, 1000]
+    msgs = [bytes(rnd.getrandbits(8) for _ in range(k)) for k in lens]
+    d = ctx.test_sha512(msgs)
+    for i, m in enumerate(msgs):
+        assert d[i].tobytes() == hashlib.sha512(m).digest(), lens[i]
+    x = ctx.test_xmd(msgs)
+    for i, m in enumerate(msgs):
+        assert x[i].tobytes() == o.xmd_sha512_96(m, S.h2c_dst), lens[i]
+    # stage vectors of the golden file
+    alphas = [bytes.fromhex(v["alpha"]) for v in kat["stages"]]
+    x = ctx.test_xmd(alphas)
+    for i, v in enumerate(kat["stages"]):
+        assert x[i].tobytes().hex() == v["xmd96"]
+
+
+def test_multi_context_calls_equal_single_context(ctx):
+    from ark_ec_vrfs_amd import (Context, ietf_prove_batch_multi, ietf_verify_batch_multi, pedersen_prove_batch_multi,
+                                 pedersen_verify_batch_multi)
+    rnd = random.Random(44)
+    extra = [Context(0), Context(0)]
+    ctxs = [ctx] + extra
+    try:
+        for n in (1, 2, 1000):
+            sk = np.stack([np.frombuffer(co.secret_from_seed(bytes([i & 255, i >> 8, 9])), np.uint8) for i in range(n)])
+            msgs = [bytes(rnd.getrandbits(8) for _ in range(rnd.choice([0, 1, 32, 33, 100]))) for _ in range(n)]
+            ads = [bytes(rnd.getrandbits(8) for _ in range(rnd.choice([0, 5, 70]))) for _ in range(n)]
+            one = ctx.ietf_prove_batch(sk, msgs=msgs, ad=ads)
+            many = ietf_prove_batch_multi(ctxs, sk, msgs, ad=ads)
+            for k in ("output", "c", "s", "pk", "input", "status"):
+                assert (one[k] == many[k]).all(), (n, k)
+            s_bad = one["s"].copy(); s_bad[::3, 2] ^= 1
+            st1 = ctx.ietf_verify_batch(one["pk"], one["input"], one["output"], one["c"], s_bad, ad=ads)
+            stm = ietf_verify_batch_multi(ctxs, one["pk"], one["input"], one["output"], one["c"], s_bad, ad=ads)
+            assert (st1 == stm).all() and st1[::3].all()
+            p1 = ctx.pedersen_prove_batch(sk, msgs=msgs, ad=b"shared")
+            pm = pedersen_prove_batch_multi(ctxs, sk, msgs, ad=b"shared")
+            for k in ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input"):
+                assert (p1[k] == pm[k]).all(), (n, k)
+            args = [p1[k] for k in ("input", "output", "pk_com", "r", "ok", "s", "sb")]
+            args[6] = args[6].copy(); args[6][::4, 0] ^= 8
+            v1 = ctx.pedersen_verify_batch(*args, ad=b"shared")
+            assert (pedersen_verify_batch_multi(ctxs, *args, ad=b"shared") == v1).all()
+            assert (pedersen_verify_batch_multi(ctxs, *args, ad=b"shared", rlc_seed=os.urandom(32)) == v1).all()
+            assert v1[::4].all()
+    finally:
+        for c in extra:
+            c.close()
