@@ -30,6 +30,7 @@ SYMBOLS = [
     "vrfhip_pedersen_verify_batch_rlc_affine", "vrfhip_pedersen_verify_batch_rlc_affine_dev",
     "vrfhip_msm", "vrfhip_msm_dev",
     "vrfhip_pairing_check_batch", "vrfhip_pairing_check_batch_dev",
+    "vrfhip_pairing_check_batch_rlc", "vrfhip_pairing_check_batch_rlc_dev", "vrfhip_g1_msm", "vrfhip_g1_msm_dev",
     "vrfhip_hash_to_curve_batch", "vrfhip_hash_to_curve_batch_dev",
     "vrfhip_output_hash_batch", "vrfhip_output_hash_batch_dev",
     "vrfhip_secret_from_seed_batch", "vrfhip_secret_from_seed_batch_dev",
@@ -124,6 +125,10 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_msm_dev.argtypes = [c_void_p, c_size_t, P, P, P, P, P, c_void_p]
     lib.vrfhip_pairing_check_batch.argtypes = [c_void_p, c_size_t, P, P, c_int32, P]
     lib.vrfhip_pairing_check_batch_dev.argtypes = [c_void_p, c_size_t, P, P, c_int32, P, c_void_p]
+    lib.vrfhip_pairing_check_batch_rlc.argtypes = [c_void_p, c_size_t, P, P, P, P, POINTER(c_int32)]
+    lib.vrfhip_pairing_check_batch_rlc_dev.argtypes = [c_void_p, c_size_t, P, P, P, P, P, c_void_p]
+    lib.vrfhip_g1_msm.argtypes = [c_void_p, c_size_t, P, P, P, P]
+    lib.vrfhip_g1_msm_dev.argtypes = [c_void_p, c_size_t, P, P, P, P, c_void_p]
     lib.vrfhip_hash_to_curve_batch.argtypes = [c_void_p, c_size_t, P, P, c_uint32, P]
     lib.vrfhip_hash_to_curve_batch_dev.argtypes = [c_void_p, c_size_t, P, P, c_uint32, P, c_void_p]
     lib.vrfhip_output_hash_batch.argtypes = [c_void_p, c_size_t, P, P]

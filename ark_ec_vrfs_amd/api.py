@@ -441,6 +441,42 @@ class Context:
                                                             int(g2_shared), status.data_ptr(), st),
                    "vrfhip_pairing_check_batch_dev")
 
+    def pairing_check_batch_rlc(self, g1, g2_shared, seed: Optional[bytes] = None):
+        """n checks against ONE shared G2 pair as a batch: two G1 MSMs + one pairing.  -> (status, batch_ok)"""
+        import os as _os
+        a = np.ascontiguousarray(g1, dtype=np.uint8).reshape(-1, 192)
+        b = np.ascontiguousarray(g2_shared, dtype=np.uint8).reshape(-1)
+        if b.size != 384:
+            raise ValueError("g2_shared must be 384 bytes")
+        n = a.shape[0]
+        sd = _np_u8(seed if seed is not None else _os.urandom(32), 32)
+        st = np.empty(n, dtype=np.uint8)
+        okf = ctypes.c_int32(1)
+        _lib.check(self._lib.vrfhip_pairing_check_batch_rlc(self._h, n, _ptr(a) if n else None, _ptr(b), _ptr(sd), _ptr(st),
+                                                            ctypes.byref(okf)), "vrfhip_pairing_check_batch_rlc")
+        return st, bool(okf.value)
+
+    def pairing_check_batch_rlc_dev(self, g1, g2_shared, status, verdict, seed: bytes, stream=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        sd = _np_u8(seed, 32)
+        _lib.check(self._lib.vrfhip_pairing_check_batch_rlc_dev(self._h, g1.shape[0], g1.data_ptr(), g2_shared.data_ptr(),
+                                                                _ptr(sd), status.data_ptr(), verdict.data_ptr(), st),
+                   "vrfhip_pairing_check_batch_rlc_dev")
+
+    def g1_msm(self, bases, scalars):
+        """`VariableBaseMSM::msm` on BLS12-381 G1: bases (n, 96), scalars (n, 32) -> 96-byte point; raises InvalidData."""
+        bs = np.ascontiguousarray(bases, dtype=np.uint8).reshape(-1, 96)
+        k = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        if bs.shape[0] != k.shape[0]:
+            raise ValueError("ragged batch")
+        out, st = np.empty(96, np.uint8), np.empty(1, np.uint8)
+        _lib.check(self._lib.vrfhip_g1_msm(self._h, bs.shape[0], _ptr(bs) if bs.size else None, _ptr(k) if k.size else None,
+                                           _ptr(out), _ptr(st)), "vrfhip_g1_msm")
+        if st[0] != ST_OK:
+            raise InvalidData()
+        return out.tobytes()
+
     def hash_to_curve_batch(self, msgs) -> np.ndarray:
         if isinstance(msgs, np.ndarray):
             m = np.ascontiguousarray(msgs, dtype=np.uint8)

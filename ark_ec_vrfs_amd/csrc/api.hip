@@ -14,6 +14,7 @@
 
 #include "kernels.h"
 #include "msm.cuh"
+#include "msm_g1.h"
 
 using namespace vrf;
 
@@ -1135,6 +1136,112 @@ int32_t vrfhip_pairing_check_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* g1,
   HIP_TRY(hipMemcpyAsync(d_g2, g2, g2b, hipMemcpyHostToDevice, ctx->stream));
   rc = vrfhip_pairing_check_batch_dev(ctx, n, d_g1, d_g2, g2_shared, d_st, ctx->stream);
   if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
+// ------------------------------------------------------------------------- G1 MSM, batched pairing check
+int32_t vrfhip_g1_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases, const uint8_t* d_scalars, uint8_t* d_out,
+                          uint8_t* d_status, void* stream) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (!d_out || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
+  if (n && (!d_bases || !d_scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if (n > (size_t(1) << 28)) return fail(VRFHIP_ERR_BAD_ARG, "batch too large");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int groups = g1_msm_groups(n ? n : 1, 1, G1_W_FULL, ctx->cus);
+  int32_t rc = ensure_msm_workspace(ctx, g1_msm_workspace_bytes(n ? n : 1, 1, G1_W_FULL, groups));
+  if (rc) return rc;
+  G1MsmLayout L = g1_msm_layout(n, 1, G1_W_FULL, groups, ctx->d_msm_ws);
+  launch_g1_msm(L, d_bases, d_scalars, d_status, st);
+  HIP_TRY(hipMemcpyAsync(d_out, L.sums, 96, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_g1_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases, const uint8_t* scalars, uint8_t* out,
+                      uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (!out || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
+  if (n && (!bases || !scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_stage(ctx, Stage::pad(n * 96 + 1) + Stage::pad(n * 32 + 1) + 2 * 256);
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t* d_b = sg.take(n * 96 + 1);
+  uint8_t* d_k = sg.take(n * 32 + 1);
+  uint8_t* d_o = sg.take(96);
+  uint8_t* d_st = sg.take(1);
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(d_b, bases, n * 96, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_k, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  }
+  rc = vrfhip_g1_msm_dev(ctx, n, d_b, d_k, d_o, d_st, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, d_o, 96, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(status, d_st, 1, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (status[0] != VRFHIP_ST_OK) std::memset(out, 0, 96);
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_pairing_check_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_g1, const uint8_t* d_g2_shared,
+                                           const uint8_t seed[32], uint8_t* d_status, uint8_t* d_verdict, void* stream) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (!d_verdict || !seed) return fail(VRFHIP_ERR_BAD_ARG, "NULL verdict or seed");
+  if (n && (!d_g1 || !d_g2_shared || !d_status)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if (n > (size_t(1) << 28)) return fail(VRFHIP_ERR_BAD_ARG, "batch too large");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemsetAsync(d_verdict, 0, 1, st));
+  if (n == 0) return VRFHIP_SUCCESS;
+  const int groups = g1_msm_groups(n, 2, G1_W_SHORT, ctx->cus);
+  int32_t rc = ensure_msm_workspace(ctx, g1_msm_workspace_bytes(n, 2, G1_W_SHORT, groups));
+  if (rc) return rc;
+  G1MsmLayout L = g1_msm_layout(n, 2, G1_W_SHORT, groups, ctx->d_msm_ws);
+  hipEvent_t* ev = prof_events(ctx);            // start | prep | buckets | final | pairing
+  if (ev) (void)hipEventRecord(ev[0], st);
+  launch_g1_rlc(L, d_g1, seed, 0, d_status, st, ev ? ev + 1 : nullptr);
+  // one pairing check for the whole batch: (sum z A, sum z B) against the shared pair (prepared lines)
+  launch_pairing_check2(1, L.sums, d_g2_shared, 0, d_verdict, st, ctx->d_pair_prep);
+  if (ev) (void)hipEventRecord(ev[4], st);
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_pairing_check_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2_shared,
+                                       const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (!seed) return fail(VRFHIP_ERR_BAD_ARG, "seed is NULL");
+  if (batch_ok) *batch_ok = 1;
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!g1 || !g2_shared || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_stage(ctx, Stage::pad(n * 192) + Stage::pad(384) + Stage::pad(n) + 256);
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t* d_g1 = sg.take(n * 192);
+  uint8_t* d_g2 = sg.take(384);
+  uint8_t* d_st = sg.take(n);
+  uint8_t* d_v = sg.take(1);
+  HIP_TRY(hipMemcpyAsync(d_g1, g1, n * 192, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_g2, g2_shared, 384, hipMemcpyHostToDevice, ctx->stream));
+  rc = vrfhip_pairing_check_batch_rlc_dev(ctx, n, d_g1, d_g2, seed, d_st, d_v, ctx->stream);
+  if (rc) return rc;
+  uint8_t verdict = 0;
+  HIP_TRY(hipMemcpyAsync(&verdict, d_v, 1, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (verdict != 0) {
+    // some item is false (or the shared pair is invalid): the per-item kernel names it
+    if (batch_ok) *batch_ok = 0;
+    launch_pairing_check2(n, d_g1, d_g2, 0, d_st, ctx->stream, ctx->d_pair_prep);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return VRFHIP_SUCCESS;

@@ -1,9 +1,33 @@
 // k_prove.hip -- IETF ECVRF batch proving kernels.
 // Replaces `Input::new`, `Secret::output` and `ietf::Prover::prove` (/root/reference src/lib.rs:14-16).
+//
+// Compiled once per (suite, stage) -- Makefile: -DVRF_PROVE_SUITE=1|2 -DVRF_PROVE_PART=1|2|3 -> k_prove_{bs,jj}_{1,2,3}.o --
+// so that the six sets of kernels build in parallel (this file was the long pole of the build).
 #include "kernels.h"
 #include <algorithm>
 
+#ifndef VRF_PROVE_SUITE
+#define VRF_PROVE_SUITE 1
+#endif
+#ifndef VRF_PROVE_PART
+#define VRF_PROVE_PART 1
+#endif
+
 namespace vrf {
+
+#if VRF_PROVE_SUITE == 2
+using ProveSuite = SuiteJJ;
+#define PROVE_STAGE(name) name##_jj
+#else
+using ProveSuite = SuiteBS;
+#define PROVE_STAGE(name) name##_bs
+#endif
+// the three stages of a suite, each defined by its own translation unit
+void PROVE_STAGE(launch_prove_stage1)(const ProveArgs& a, hipStream_t st);
+void PROVE_STAGE(launch_prove_stage2)(const ProveArgs& a, hipStream_t st);
+void PROVE_STAGE(launch_prove_stage3)(const ProveArgs& a, hipStream_t st);
+
+#if VRF_PROVE_PART == 1
 
 // stage 1: H = hash_to_curve(msg) (or decode a given H), enc(H), nonce, window table of H
 template <class S, int MINW>
@@ -16,7 +40,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare(ProveArgs a) {
   if (a.h_given) load32(hg, a.h_given, i); else bytes_get(a.msg, i, msg, msg_len);
   // try-and-increment suites: k_tai_find left the first decodable counter in the item's flag byte
   const uint32_t tai_start = (!S::H2C_ELL2 && !a.h_given) ? a.ws.flags[i] : 0u;
-  bool ok = prove_prepare_item<S>(h_enc, k, a.ws.tabs + i * (2 * WIN_TABLE_WORDS), a.T, sk, msg,
+  bool ok = prove_prepare_item<S>(h_enc, k, a.ws.tabs + i * PROVE_TAB_WORDS, a.T, sk, msg,
                                         msg_len, a.h_given ? hg : nullptr, tai_start, a.check_mask);
   uint32_t* aux = a.ws.aux + i * AUX_WORDS;
 #pragma unroll
@@ -101,6 +125,25 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare_multi(ProveArgs a
   }
 }
 
+void PROVE_STAGE(launch_prove_stage1)(const ProveArgs& a, hipStream_t st) {
+  using S = ProveSuite;
+  const size_t lanes_k_ = (a.n + a.k_lane - 1) / a.k_lane;      // K proofs per lane: a small grid
+  const dim3 gk = grid_for(lanes_k_);
+  if (S::H2C_ELL2 && !a.h_given) {
+    VRF_LAUNCH_MINW(k_prove_prepare_multi, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
+  } else {
+    if (!S::H2C_ELL2 && !a.h_given) {
+      (void)hipMemsetAsync(a.tai_queue, 0, sizeof(unsigned long long), st);
+      const size_t waves = std::min<size_t>((a.n + 63) / 64, 4096);        // persistent: 4 waves per SIMD
+      hipLaunchKernelGGL(k_tai_find<S>, dim3((unsigned)waves), dim3(64), 0, st, a.n, a.msg, a.ws.flags, a.T.sq,
+                         a.tai_queue);
+    }
+    VRF_LAUNCH_MINW(k_prove_prepare, S, a.n, grid_for(a.n), 0, st, a);
+  }
+}
+#endif  // part 1
+
+#if VRF_PROVE_PART == 2
 // stage 2: two lanes per proof: lane 0 -> (sk*H, sk*G), lane 1 -> (k*H, k*G)
 template <class S>
 __global__ void __launch_bounds__(BLOCK) k_prove_mul(ProveArgs a) {
@@ -121,17 +164,23 @@ __global__ void __launch_bounds__(BLOCK) k_prove_mul(ProveArgs a) {
     for (int j = 0; j < 8; ++j) sc[j] = 0;
   }
   prove_mul_item<S>(a.ws.pts + i * PROVE_PTS_WORDS + half * 2 * UV_WORDS, a.T,
-                          a.ws.tabs + i * (2 * WIN_TABLE_WORDS), sc,
+                          a.ws.tabs + i * PROVE_TAB_WORDS, sc,
                           a.pedersen ? a.ws.aux + i * AUX_WORDS + 16 + half * 8 : nullptr);
 }
 
+void PROVE_STAGE(launch_prove_stage2)(const ProveArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_prove_mul<ProveSuite>, grid_for(2 * a.n), dim3(BLOCK), 0, st, a);
+}
+#endif  // part 2
+
+#if VRF_PROVE_PART == 3
 // stage 3: PROVE_K proofs per lane share the inversion of their 4K projective Z; then per item the
 // challenge and s = k + c*sk (Pedersen: also sb = kb + c*b).
 template <class S, int MINW>
 __global__ void __launch_bounds__(BLOCK, MINW) k_prove_finish(ProveArgs a) {
   size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   if (first >= a.n) return;
-  const int tstride = 2 * WIN_TABLE_WORDS;
+  const int tstride = PROVE_TAB_WORDS;
   prove_encode_multi<S>(a.k_lane, first, a.n, a.ws.pts, a.ws.tabs, tstride);
 #pragma unroll 1
   for (int jj = 0; jj < a.k_lane; ++jj) {
@@ -175,38 +224,29 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_finish(ProveArgs a) {
   }
 }
 
-template <class S>
-static void launch_prove_t(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
-  const size_t lanes_k_ = (a.n + a.k_lane - 1) / a.k_lane;      // K proofs per lane: a small grid
+void PROVE_STAGE(launch_prove_stage3)(const ProveArgs& a, hipStream_t st) {
+  using S = ProveSuite;
+  const size_t lanes_k_ = (a.n + a.k_lane - 1) / a.k_lane;
   const dim3 gk = grid_for(lanes_k_);
-  if (ev) (void)hipEventRecord(ev[0], st);
-  if (S::H2C_ELL2 && !a.h_given) {
-    VRF_LAUNCH_MINW(k_prove_prepare_multi, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
-  } else {
-    if (!S::H2C_ELL2 && !a.h_given) {
-      (void)hipMemsetAsync(a.tai_queue, 0, sizeof(unsigned long long), st);
-      const size_t waves = std::min<size_t>((a.n + 63) / 64, 4096);        // persistent: 4 waves per SIMD
-      hipLaunchKernelGGL(k_tai_find<S>, dim3((unsigned)waves), dim3(64), 0, st, a.n, a.msg, a.ws.flags, a.T.sq,
-                         a.tai_queue);
-    }
-    VRF_LAUNCH_MINW(k_prove_prepare, S, a.n, grid_for(a.n), 0, st, a);
-  }
-  if (ev) (void)hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(k_prove_mul<S>, grid_for(2 * a.n), dim3(BLOCK), 0, st, a);
-  if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
   VRF_LAUNCH_MINW(k_prove_finish, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
-  if (ev) (void)hipEventRecord(ev[4], st);
 }
-// This file is compiled once per suite (Makefile: -DVRF_PROVE_SUITE=1|2 -> k_prove_bs.o, k_prove_jj.o) so
-// that the two sets of kernels build in parallel; the dispatcher lives in the Bandersnatch object.
-#if VRF_PROVE_SUITE == 2
-void launch_ietf_prove_jj(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) { launch_prove_t<SuiteJJ>(a, st, ev); }
-#else
-void launch_ietf_prove_jj(const ProveArgs& a, hipStream_t st, hipEvent_t* ev);
+#endif  // part 3
+
+// the dispatcher lives in one object (Bandersnatch, stage 2)
+#if VRF_PROVE_SUITE == 1 && VRF_PROVE_PART == 2
+void launch_prove_stage1_jj(const ProveArgs& a, hipStream_t st);
+void launch_prove_stage2_jj(const ProveArgs& a, hipStream_t st);
+void launch_prove_stage3_jj(const ProveArgs& a, hipStream_t st);
 void launch_ietf_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (a.n == 0) return;
-  if (a.suite == SUITE_JJ) launch_ietf_prove_jj(a, st, ev);
-  else launch_prove_t<SuiteBS>(a, st, ev);
+  const bool jj = a.suite == SUITE_JJ;
+  if (ev) (void)hipEventRecord(ev[0], st);
+  if (jj) launch_prove_stage1_jj(a, st); else launch_prove_stage1_bs(a, st);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  if (jj) launch_prove_stage2_jj(a, st); else launch_prove_stage2_bs(a, st);
+  if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
+  if (jj) launch_prove_stage3_jj(a, st); else launch_prove_stage3_bs(a, st);
+  if (ev) (void)hipEventRecord(ev[4], st);
 }
 #endif
 

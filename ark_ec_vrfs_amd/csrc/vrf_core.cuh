@@ -1100,6 +1100,65 @@ VRF_HD void te_to_affine(FeN& x, FeN& y, const PtE& p) {
 //   finish : shared inversion of the four Z, encodings, challenge, s.
 constexpr int PROVE_PTS_WORDS = 4 * UV_WORDS;   // [half][win|comb][X,Y,Z]
 
+// ---- prove: the two variable-base products of a proof, sk*H and k*H, share their base ----
+// Doubling the BASE once instead of the accumulators twice: with H' = 2^64 H (64 doublings in the prepare stage)
+// each 128-bit GLV half splits into two 64-bit quarters, so a product is 60 accumulator doublings + 64 additions
+// from the four tables {H, H', psi H, psi H'} instead of 124 + 64 from {H, psi H}.  Per proof: 184 doublings +
+// 142 additions instead of 248 + 128.  Without an endomorphism (JubJub) the tables are {H, 2^64 H, 2^128 H,
+// 2^192 H}: 312 doublings + 149 additions instead of 504 + 128.  Any digit split gives the same group element:
+// results stay bit-exact.
+constexpr int PROVE_TABS = 4;
+constexpr int PROVE_TAB_WORDS = PROVE_TABS * WIN_TABLE_WORDS;
+template <class S>
+VRF_HD void build_prove_tables(uint32_t* tab, const FeP& x, const FeP& y) {
+  PtE p = te_from_affine(x, y);
+  constexpr int NB = S::HAS_GLV ? 2 : 4;
+#pragma unroll 1
+  for (int j = 0; j < NB; ++j) {
+    if (j) {
+#pragma unroll 1
+      for (int i = 0; i < 64; ++i) p = te_dbl<S>(p, i == 63);
+    }
+    build_win_table_from<S>(tab + j * WIN_TABLE_WORDS, p);
+    if constexpr (S::HAS_GLV) build_win_table_from<S>(tab + (2 + j) * WIN_TABLE_WORDS, te_psi<S>(p));
+  }
+}
+// scalar * H from the four tables of build_prove_tables: stream t reads digits 16 t + w of a 64-digit signed
+// radix-16 string (GLV: k1's 32 digits then k2's 32 digits; else the 253-bit scalar) and adds from table t
+template <class S>
+VRF_HD PtE prove_var_mul(const uint32_t* tab, const uint32_t scalar[8]) {
+  uint32_t rec[8];
+  bool neg_lo = false, neg_hi = false;
+  if constexpr (S::HAS_GLV) {
+    GlvHalf h[2];
+    glv_decompose_bs(h[0], h[1], scalar);
+    uint32_t r0[4], r1[4];
+    scalar_recode_signed4_128(r0, h[0].mag);
+    scalar_recode_signed4_128(r1, h[1].mag);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rec[i] = r0[i]; rec[4 + i] = r1[i]; }
+    neg_lo = h[0].neg; neg_hi = h[1].neg;
+  } else {
+    scalar_recode_signed4(rec, scalar);
+  }
+  PtE acc = te_identity();
+#pragma unroll 1
+  for (int w = 15; w >= 0; --w) {
+    if (w != 15) {
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) acc = te_dbl<S>(acc, j == 3);
+    }
+#pragma unroll 1
+    for (int t = 0; t < PROVE_TABS; ++t) {
+      const int d = scalar_digit4(rec, 16 * t + w);
+      const bool neg = t < 2 ? neg_lo : neg_hi;
+      acc = te_add_cached<S>(acc, win_lookup(tab + t * WIN_TABLE_WORDS, d), (d < 0) != neg, t != PROVE_TABS - 1 || w == 0);
+    }
+  }
+  return acc;
+}
+
+
 // returns validity (always true for the hash-to-curve path; decode may fail)
 // [ref src/lib.rs:14 `pedersen::PedersenSuite::blinding`]  SURVEY.md A.5:
 // b = int_be(SHA512(suite_id || 0xCC || sk_le32 || enc(H) || ad || 0x00)) mod r  (all 64 bytes)
@@ -1141,7 +1200,7 @@ VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, 
   }
   te_encode_affine(h_enc, x, y);
   nonce_rfc8032<S>(k, sk, h_enc);
-  build_glv_tables<S>(tab, x, y);          // {H, psi H}: 2 * WIN_TABLE_WORDS
+  build_prove_tables<S>(tab, x, y);        // PROVE_TAB_WORDS words
   if (h_given && (check_mask & CHK_INPUT)) valid = in_prime_subgroup<S>(x, y, T.sq) && valid;   // a given H is wire data
   return valid;
 }
@@ -1226,7 +1285,7 @@ VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t 
       for (int i = 0; i < 8; ++i) sk[i] = w[i];
       te_encode_affine(h_enc, x, y);
       nonce_rfc8032<S>(k, sk, h_enc);
-      build_glv_tables<S>(tabs_base + item * (2 * WIN_TABLE_WORDS), x, y);
+      build_prove_tables<S>(tabs_base + item * PROVE_TAB_WORDS, x, y);
       uint32_t* aux = aux_base + item * aux_stride;
 #pragma unroll
       for (int i = 0; i < 8; ++i) { aux[i] = h_enc[i]; aux[8 + i] = k[i]; }
@@ -1264,27 +1323,7 @@ VRF_HD PtE var_base_mul(const uint32_t* tab, const uint32_t scalar[8]) {
 template <class S>
 VRF_HD void prove_mul_item(uint32_t* out /*2*UV_WORDS*/, const DevTables& T, const uint32_t* tab,
                            const uint32_t scalar[8], const uint32_t* scalar2) {
-  PtE w;
-  if constexpr (S::HAS_GLV) {
-    // scalar * H by GLV: k = k1 + k2*lambda over the table pair {H, psi H}
-    Straus4 q;
-    GlvHalf h[2];
-    glv_decompose_bs(h[0], h[1], scalar);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      scalar_recode_signed4_128(q.rec[t], h[t].mag);
-      q.neg[t] = h[t].neg;
-    }
-    q.tab[0] = tab; q.tab[1] = tab + WIN_TABLE_WORDS; q.tab[2] = tab; q.tab[3] = tab;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { q.rec[2][i] = 0; q.rec[3][i] = 0; }
-    q.neg[2] = false; q.neg[3] = false;
-    w = straus4<S, 2>(q);
-  } else {
-    uint32_t rec[8];
-    scalar_recode_signed4(rec, scalar);
-    w = win_mul<S>(tab, rec);
-  }
+  const PtE w = prove_var_mul<S>(tab, scalar);
   fe_store(out, w.X); fe_store(out + NL, w.Y); fe_store(out + 2 * NL, w.Z);
   PtE c;
   if (scalar2) {

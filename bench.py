@@ -375,6 +375,31 @@ def cfg_pairing(D, args, ctx, want_cpu):
     run("pairing_check_shared_g2", lambda: ctx.pairing_check_batch_dev(ds1, dsh, pstat, g2_shared=True), B_PAIRING_SHARED,
         "k_pairing_check2_quad_prepared (lines of the shared G2 pair prepared once per context)",
         "the same check against ONE shared G2 pair (a KZG verifier's SRS), batch 2^14 per GPU", "pairing_check_shared")
+    # the same shared-G2 checks as ONE batch: two G1 multi-scalar multiplications + one pairing (random linear
+    # combination).  At 2^14 the single pairing's latency (one quad) is the whole cost; the amortised rate shows at 2^18.
+    for lg in (14, 18):
+        m = 1 << lg
+        dm = torch.from_numpy(np.tile(s1, (m // s1.shape[0], 1)).copy()).to(D.dev)
+        mst = torch.empty(m, dtype=torch.uint8, device=D.dev)
+        verdict = torch.empty(1, dtype=torch.uint8, device=D.dev)
+        seed = os.urandom(32)
+        fn = lambda: ctx.pairing_check_batch_rlc_dev(dm, dsh, mst, verdict, seed)
+        fn(); torch.cuda.synchronize()
+        ctx.profile(True)
+        el, _ = timed(D, fn, args.config_steps, 1, gather_t=mst, n_per_rank=m)
+        ctx.profile(False)
+        ms, groups = stage_avg(ctx)
+        assert int(verdict[0]) == 0 and int(mst.sum()) == 0
+        heavy = max(range(4), key=lambda k: ms[k])
+        kname = ("k_g1_prep_rlc", "k_g1_buckets (Pippenger, 512 buckets per window in LDS)", "k_g1_final",
+                 "k_pairing_check2_quad_prepared (ONE check for the batch)")[heavy]
+        rf, v = roofline(kname, B_PAIRING_SHARED, m, ms[heavy], groups, pmc_for("pairing_check_batched", lg))
+        res["pairing_check_batched_shared_g2_2^%d" % lg] = {
+            "workload": "2^%d checks against one shared G2 pair verified as ONE batch: two BLS12-381 G1 MSMs + one pairing "
+                        "check (random linear combination, 128-bit weights)" % lg,
+            "value": D.world * m * args.config_steps / el, "unit": "checks/s", "ms_per_step": el / args.config_steps * 1e3,
+            "bytes_per_unit": B_PAIRING_SHARED, "roofline": rf, "valu": v,
+            "stage_ms_per_step": {"prep": ms[0], "msm_buckets": ms[1], "msm_final": ms[2], "pairing": ms[3]}}
     if want_cpu:
         from oracle import bls_oracle as bo
 
@@ -399,8 +424,8 @@ def cfg_pairing(D, args, ctx, want_cpu):
                "sample": "%d checks of the fixture items, %.1f s on 1 thread; verdicts equal the GPU's" % (cnt, dt),
                "note": "pure-Python big-int restatement (oracle/bls_oracle.py), not arkworks: orders of magnitude slower than "
                        "a native CPU pairing (arkworks / blst: roughly 1e3 checks/s/core)"}
-        res["pairing_check"]["cpu_baseline"] = leg
-        res["pairing_check_shared_g2"]["cpu_baseline"] = leg
+        for k in res:
+            res[k]["cpu_baseline"] = leg
     return res
 
 

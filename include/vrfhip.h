@@ -336,6 +336,31 @@ int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
                                        const uint8_t* d_g2, int32_t g2_shared, uint8_t* d_status,
                                        void* stream);
 
+/* The same n checks against ONE shared G2 pair (g2_shared: 384 B, a KZG verifier's SRS) as a batch: with secret
+ * 128-bit weights z_i = SHA-512("vrfhip-pairing-rlc-v1" || seed || u64_le(i))[0..16],
+ *     prod_i (e(A_i,Q0) e(B_i,Q1))^{z_i} = e(sum z_i A_i, Q0) e(sum z_i B_i, Q1):
+ * two G1 multi-scalar multiplications (Pippenger, buckets in LDS) and ONE pairing check for the whole batch -- the
+ * aggregation step in front of the pairing tail of `ring::Verifier::verify` (src/lib.rs:14).  g1: n x 192 B as above.
+ * `seed`: 32 bytes unpredictable to whoever made the items; a batch holding a false item passes with probability
+ * <= 2^-128 (the G1 points lie in the prime-order subgroup: the caller's precondition, as for arkworks' `G1Prepared`).
+ * _dev form: d_status[i] = 0 (part of the batch) or 2 (InvalidData: left out); d_verdict[0] = 0 if the batch equation
+ * holds, 1 if it does not (vrfhip_pairing_check_batch_dev names the item), 2 if the shared pair is invalid.
+ * Host form: the same per-item statuses as vrfhip_pairing_check_batch with g2_shared = 1 (a failing batch is
+ * re-checked per item); *batch_ok (nullable) reports whether the single pairing sufficed. */
+int32_t vrfhip_pairing_check_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2_shared,
+                                       const uint8_t seed[32], uint8_t* status, int32_t* batch_ok);
+int32_t vrfhip_pairing_check_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_g1, const uint8_t* d_g2_shared,
+                                           const uint8_t seed[32], uint8_t* d_status, uint8_t* d_verdict, void* stream);
+
+/* `VariableBaseMSM::msm` on BLS12-381 G1 (ark-bls12-381; the KZG commitment / aggregation primitive of the ring
+ * suite): out = sum_i scalars[i] * bases[i].  bases: n x 96 B (x || y, 48-byte little-endian; all-zero = infinity);
+ * scalars: n x 32 B little-endian, < r; out: 96 B in the same form; status: 1 byte, 0 = Ok, 2 = InvalidData (a
+ * coordinate >= p, a point off the curve or a scalar >= r; out is then zeroed by the host form).  n = 0: infinity. */
+int32_t vrfhip_g1_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases, const uint8_t* scalars, uint8_t* out,
+                      uint8_t* status);
+int32_t vrfhip_g1_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases, const uint8_t* d_scalars, uint8_t* d_out,
+                          uint8_t* d_status, void* stream);
+
 /* Building blocks --------------------------------------------------------------------- */
 
 /* `Input::new(data)` = Suite::data_to_point = hash_to_curve_ell2_rfc_9380 (src/lib.rs:14-16):

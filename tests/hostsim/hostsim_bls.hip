@@ -1,5 +1,6 @@
 // tests/hostsim -- TEST TOOLING ONLY: host build of the BLS12-381 pairing headers.
 #include "../../ark_ec_vrfs_amd/csrc/bls12.cuh"
+#include "../../ark_ec_vrfs_amd/csrc/g1.cuh"
 #include <cstring>
 #include <vector>
 using namespace bls;
@@ -91,5 +92,40 @@ uint32_t hb_pairing_check2_prepared(const uint8_t* g1x2, const uint8_t* g2x2) {
 uint32_t hb_pairing_check2(const uint8_t* g1x2, const uint8_t* g2x2) {
   uint32_t w1[48], w2[96]; memcpy(w1, g1x2, 192); memcpy(w2, g2x2, 384);
   return pairing_check2_item(w1, w2);
+}
+// ---- G1 group law (g1.cuh): points as x || y (96 B, all-zero = infinity) ----
+static G1P g1_in(const uint8_t* b) {
+  bool any = false; for (int i = 0; i < 96; ++i) any = any || b[i];
+  if (!any) return g1_identity();
+  G1P p; p.X = inw(b); p.Y = inw(b + 48); p.Z = fp_one(); return p;
+}
+static void g1_out(uint8_t* b, const G1P& p) {
+  if (g1_is_identity(p)) { memset(b, 0, 96); return; }
+  FpS x, y; g1_to_affine(x, y, p); outw(b, x); outw(b + 48, y);
+}
+// op 0: projective add (both operands rescaled by an odd factor so that Z != 1), 1: mixed add, 2: mixed add of -b, 3: doubling of a
+void hb_g1_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* r) {
+  G1P p = g1_in(a);
+  if (op == 0) {
+    G1P q = g1_in(b);
+    FpS k = inw(a + 48);                       // any non-zero scale
+    FpS one = fp_one();
+    if (fp_is_zero(k)) k = one;
+    p.X = fp_fit(fp_mul(p.X, k)); p.Y = fp_fit(fp_mul(p.Y, k)); p.Z = fp_fit(fp_mul(p.Z, k));
+    auto k2 = fp_fit(fp_add(k, one));
+    q.X = fp_fit(fp_mul(q.X, k2)); q.Y = fp_fit(fp_mul(q.Y, k2)); q.Z = fp_fit(fp_mul(q.Z, k2));
+    g1_out(r, g1_add(p, q));
+  } else if (op == 3) {
+    g1_out(r, g1_dbl(p));
+  } else {
+    g1_out(r, g1_madd(p, inw(b), inw(b + 48), op == 2));
+  }
+}
+// chains of the three laws: acc = sum_i (+/-) P_i by mixed additions into a running projective sum, then doubled k times
+void hb_g1_chain(uint32_t n, const uint8_t* pts, const uint8_t* signs, uint32_t dbl, uint8_t* r) {
+  G1P acc = g1_identity();
+  for (uint32_t i = 0; i < n; ++i) acc = g1_madd(acc, inw(pts + 96 * i), inw(pts + 96 * i + 48), signs[i] != 0);
+  for (uint32_t i = 0; i < dbl; ++i) acc = g1_dbl(acc);
+  g1_out(r, acc);
 }
 }

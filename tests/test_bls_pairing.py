@@ -66,6 +66,35 @@ def hb():
     return ctypes.CDLL(so)
 
 
+def test_g1_group_law_host_build(hb):
+    """g1.cuh (complete projective formulas, device source compiled for the host) against the oracle's affine law:
+    addition, mixed addition of +/- Q, doubling, and every exceptional case the complete formulas must absorb."""
+    rnd = random.Random(31)
+    G = b.G1
+    pts = [b.g1_mul(rnd.randrange(1, b.R), G) for _ in range(12)]
+    cases = [(pts[i], pts[(i + 1) % 12]) for i in range(12)]
+    cases += [(pts[0], pts[0]), (pts[1], b.g1_neg(pts[1])), (None, pts[2]), (pts[3], None), (None, None)]
+    out = ctypes.create_string_buffer(96)
+    for P1, P2 in cases:
+        hb.hb_g1_op(0, enc_g1(P1), enc_g1(P2), out)
+        assert out.raw == enc_g1(b.g1_add(P1, P2)), ("add", P1 is None, P2 is None)
+        if P2 is not None:
+            hb.hb_g1_op(1, enc_g1(P1), enc_g1(P2), out)
+            assert out.raw == enc_g1(b.g1_add(P1, P2)), "madd"
+            hb.hb_g1_op(2, enc_g1(P1), enc_g1(P2), out)
+            assert out.raw == enc_g1(b.g1_add(P1, b.g1_neg(P2))), "msub"
+        hb.hb_g1_op(3, enc_g1(P1), enc_g1(P1), out)
+        assert out.raw == enc_g1(b.g1_add(P1, P1)), "dbl"
+    # long chains keep the lazy limb bounds honest: 200 mixed additions (repeats included) then 64 doublings
+    seq = [pts[rnd.randrange(12)] for _ in range(200)]
+    signs = bytes(rnd.getrandbits(1) for _ in range(200))
+    hb.hb_g1_chain(200, b"".join(enc_g1(P) for P in seq), signs, 64, out)
+    acc = None
+    for P, sg in zip(seq, signs):
+        acc = b.g1_add(acc, b.g1_neg(P) if sg else P)
+    assert out.raw == enc_g1(b.g1_mul(1 << 64, acc) if acc is not None else None)
+
+
 def _call(f, *a, n=48):
     r = ctypes.create_string_buffer(n)
     f(*a, r)
@@ -260,3 +289,155 @@ def test_gpu_quad_tower_ops_match_one_lane_ops(ctx):
     st = np.full(n, 255, np.uint8)
     _lib.check(lib.vrfhip_test_pairing_quad_ops(ctx.handle, n, raw.ctypes.data, st.ctypes.data), "quad selftest")
     assert (st == 0).all(), {int(i): int(v) for i, v in enumerate(st) if v}
+
+
+# ------------------------------------------------------------------------------------------ G1 MSM, batched check
+def _g1_pool(k=48, seed=51):
+    rnd = random.Random(seed)
+    a = [rnd.randrange(1, b.R) for _ in range(k)]
+    return a, [b.g1_mul(x, b.G1) for x in a]
+
+
+@pytest.mark.gpu
+def test_gpu_g1_msm_matches_discrete_log_oracle(ctx):
+    """`VariableBaseMSM::msm` on G1 (k_msm_g1.hip) against sum_i k_i a_i * G computed from the discrete logs: random
+    scalars, equal points in one bucket (doubling through the complete law), P and -P, infinity, zero and extreme
+    scalars, sizes that cross the point-group boundaries, and invalid inputs."""
+    from ark_ec_vrfs_amd import InvalidData
+    rnd = random.Random(52)
+    a, pts = _g1_pool()
+    encs = [enc_g1(P_) for P_ in pts]
+    le32 = lambda v: int(v).to_bytes(32, "little")
+    assert ctx.g1_msm(np.zeros((0, 96), np.uint8), np.zeros((0, 32), np.uint8)) == bytes(96)      # empty sum: infinity
+    for n in (1, 2, 37, 1000, 8191, 8193, 20000):
+        idx = [rnd.randrange(len(pts)) for _ in range(n)]
+        ks = [rnd.randrange(b.R) for _ in range(n)]
+        if n >= 37:
+            ks[0], ks[1], ks[2] = 0, b.R - 1, 1
+            idx[3] = idx[4]; ks[3] = ks[4]                              # the same point twice in every window's bucket
+            ks[5] = ks[6]; idx[5] = idx[6]
+        bases = [encs[i] for i in idx]
+        acc = sum(k * a[i] for k, i in zip(ks, idx)) % b.R
+        if n >= 37:
+            bases[5] = enc_g1(b.g1_neg(pts[idx[5]]))                    # P and -P with one scalar: cancel
+            acc = (acc - 2 * ks[5] * a[idx[5]]) % b.R
+            bases[7] = bytes(96)                                        # the point at infinity
+            acc = (acc - ks[7] * a[idx[7]]) % b.R
+        got = ctx.g1_msm(np.frombuffer(b"".join(bases), np.uint8).reshape(-1, 96),
+                         np.frombuffer(b"".join(le32(k) for k in ks), np.uint8).reshape(-1, 32))
+        assert got == enc_g1(b.g1_mul(acc, b.G1) if acc else None), n
+    # every scalar equal (all points of a window in ONE bucket) and a sum that is the identity
+    n = 5000
+    idx = [i % len(pts) for i in range(n)]
+    k = rnd.randrange(1, b.R)
+    got = ctx.g1_msm(np.frombuffer(b"".join(encs[i] for i in idx), np.uint8).reshape(-1, 96),
+                     np.frombuffer(le32(k) * n, np.uint8).reshape(-1, 32))
+    assert got == enc_g1(b.g1_mul(k * sum(a[i] for i in idx) % b.R, b.G1))
+    two = np.frombuffer(encs[0] + enc_g1(b.g1_neg(pts[0])), np.uint8).reshape(2, 96)
+    assert ctx.g1_msm(two, np.frombuffer(le32(77) * 2, np.uint8).reshape(2, 32)) == bytes(96)
+    # invalid inputs
+    bad = np.frombuffer(encs[0] + encs[1], np.uint8).reshape(2, 96).copy()
+    kk = np.frombuffer(le32(3) + le32(4), np.uint8).reshape(2, 32).copy()
+    bad2 = bad.copy(); bad2[1, 7] ^= 1
+    with pytest.raises(InvalidData):
+        ctx.g1_msm(bad2, kk)                                            # off the curve
+    kk2 = kk.copy(); kk2[0] = np.frombuffer(le32(b.R), np.uint8)
+    with pytest.raises(InvalidData):
+        ctx.g1_msm(bad, kk2)                                            # scalar >= r
+    bad3 = bad.copy(); bad3[0, :48] = np.frombuffer(w(P), np.uint8)
+    with pytest.raises(InvalidData):
+        ctx.g1_msm(bad3, kk)                                            # coordinate >= p
+
+
+@pytest.mark.gpu
+def test_gpu_g1_msm_2_17_discrete_log(ctx):
+    rnd = np.random.default_rng(53)
+    a, pts = _g1_pool()
+    encs = np.stack([np.frombuffer(enc_g1(P_), np.uint8) for P_ in pts])
+    n = 1 << 17
+    idx = rnd.integers(0, len(pts), n)
+    ks = rnd.integers(0, 256, (n, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x3f                                                   # < 2^254 < r
+    acc = 0
+    for i in range(n):
+        acc += int.from_bytes(ks[i].tobytes(), "little") * a[idx[i]]
+    got = ctx.g1_msm(encs[idx], ks)
+    assert got == enc_g1(b.g1_mul(acc % b.R, b.G1))
+
+
+def _shared_fixture():
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pairing_items.json")))
+    hx = lambda h: np.frombuffer(bytes.fromhex(h), np.uint8)
+    return hx(fx["shared_g2"]), np.stack([hx(h) for h in fx["shared"]]), np.stack([hx(h) for h in fx["shared_bad"]])
+
+
+@pytest.mark.gpu
+def test_gpu_batched_pairing_check_statuses_equal_per_item_path(ctx):
+    """vrfhip_pairing_check_batch_rlc (two G1 MSMs + ONE pairing) against the per-item kernel and the oracle: all-valid
+    batches pass on the fast path; a false item makes the batch fail and is named by the fallback; InvalidData items
+    are left out; infinity points; sizes 1 .. 3000; the device form's verdict byte."""
+    import torch
+    sh, good, bad = _shared_fixture()
+    dec1 = lambda raw: [int.from_bytes(bytes(raw[48 * i:48 * i + 48]), "little") for i in range(4)]
+    dec2 = lambda raw: [int.from_bytes(bytes(raw[48 * i:48 * i + 48]), "little") for i in range(8)]
+    q = dec2(sh)
+    Q0, Q1 = (b.Fp2(q[0], q[1]), b.Fp2(q[2], q[3])), (b.Fp2(q[4], q[5]), b.Fp2(q[6], q[7]))
+    for row, want in ((good[0], True), (bad[0], False)):                 # the fixture means what it says (oracle)
+        v = dec1(row)
+        assert b.pairing_check([((v[0], v[1]), Q0), ((v[2], v[3]), Q1)]) == want
+    for n in (1, 2, 9, 300, 3000):
+        g1 = np.tile(good, (n // 8 + 1, 1))[:n].copy()
+        st, ok = ctx.pairing_check_batch_rlc(g1, sh)
+        assert ok and (st == 0).all(), n
+        assert (ctx.pairing_check_batch(g1, sh, g2_shared=True) == 0).all()
+    n = 1000
+    g1 = np.tile(good, (n // 8, 1)).copy()
+    g1[17] = bad[0]; g1[500] = bad[1]                                     # false items
+    g1[33, 5] ^= 1                                                        # off the curve: InvalidData
+    g1[44] = 0                                                            # both points at infinity: trivially true
+    g1[55, 96:] = 0                                                       # B at infinity: e(A, Q0) != 1
+    want = ctx.pairing_check_batch(g1, sh, g2_shared=True)
+    assert want[17] == 1 and want[500] == 1 and want[33] == 2 and want[44] == 0 and want[55] == 1 and want.sum() == 5
+    st, ok = ctx.pairing_check_batch_rlc(g1, sh)
+    assert not ok and (st == want).all()
+    g2 = g1.copy(); g2[17] = good[1]; g2[500] = good[2]; g2[55] = good[3]  # only the InvalidData item left
+    st, ok = ctx.pairing_check_batch_rlc(g2, sh)
+    assert ok and st[33] == 2 and st.sum() == 2
+    # device form: statuses {0, 2} and the verdict byte; a different seed gives the same verdicts
+    dev = torch.device("cuda:0")
+    d1, dsh = torch.from_numpy(g1).to(dev), torch.from_numpy(sh.copy()).to(dev)
+    dst = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+    dv = torch.full((1,), 9, dtype=torch.uint8, device=dev)
+    for seed in (bytes(32), os.urandom(32)):
+        ctx.pairing_check_batch_rlc_dev(d1, dsh, dst, dv, seed)
+        torch.cuda.synchronize()
+        assert int(dv[0]) == 1 and int(dst[33]) == 2 and int(dst.sum()) == 2
+        ctx.pairing_check_batch_rlc_dev(torch.from_numpy(g2).to(dev), dsh, dst, dv, seed)
+        torch.cuda.synchronize()
+        assert int(dv[0]) == 0
+    # an invalid shared pair: every item InvalidData, as on the per-item path
+    sh_bad = sh.copy(); sh_bad[5] ^= 1
+    st, ok = ctx.pairing_check_batch_rlc(g2, sh_bad)
+    assert not ok and (st == 2).all()
+
+
+@pytest.mark.gpu
+def test_gpu_batched_pairing_check_2_14_and_2_18(ctx):
+    import torch
+    sh, good, bad = _shared_fixture()
+    dev = torch.device("cuda:0")
+    dsh = torch.from_numpy(sh.copy()).to(dev)
+    for lg in (14, 18):
+        n = 1 << lg
+        g1 = np.tile(good, (n // 8, 1)).copy()
+        d1 = torch.from_numpy(g1).to(dev)
+        dst = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+        dv = torch.full((1,), 9, dtype=torch.uint8, device=dev)
+        ctx.pairing_check_batch_rlc_dev(d1, dsh, dst, dv, os.urandom(32))
+        torch.cuda.synchronize()
+        assert int(dv[0]) == 0 and int(dst.sum()) == 0
+        d1[n // 3] = torch.from_numpy(bad[0]).to(dev)                      # one false item anywhere fails the batch
+        ctx.pairing_check_batch_rlc_dev(d1, dsh, dst, dv, os.urandom(32))
+        torch.cuda.synchronize()
+        assert int(dv[0]) == 1 and int(dst.sum()) == 0
