@@ -521,4 +521,16 @@ VRF_HD bool fe_is_nonzero_square(const Fe<L, V>& w, const SqrtTables& T) {
   return j == 1;
 }
 
+// w is a square (zero included)
+template <int L, int V>
+VRF_HD bool fe_is_square_or_zero(const Fe<L, V>& w, const SqrtTables& T) {
+  const FeN c = fe_canon(w);
+  const int j = jacobi_limbs(c.v);
+  if (j == 2) {
+    FeN root;
+    return fe_sqrt_or_zsqrt(root, c, T) || fe_is_zero(c);
+  }
+  return j >= 0;
+}
+
 }  // namespace vrf

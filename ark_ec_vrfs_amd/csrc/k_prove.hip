@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare_multi(ProveArgs a
   if constexpr (S::H2C_ELL2) {
     size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
     if (first >= a.n) return;
-    prove_prepare_multi<S>(a.k_lane, a.T, first, a.n, a.sk, a.msg, a.ws.tabs, a.ws.pts, a.ws.aux, AUX_WORDS, a.ws.flags);
+    prove_prepare_multi<S>(a.k_lane, a.T, first, a.n, a.sk, a.msg, a.ws.tabs, a.ws.pts, a.ws.aux, AUX_WORDS, a.ws.flags,
+                           /*defer_tables=*/true);
     if (a.pedersen) {
 #pragma unroll 1
       for (int j = 0; j < a.k_lane; ++j) {
@@ -125,12 +126,21 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare_multi(ProveArgs a
   }
 }
 
+// stage 1b (after k_prove_prepare_multi): the window tables of H, one proof per lane
+template <class S>
+__global__ void __launch_bounds__(BLOCK) k_prove_tables(ProveArgs a) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  prove_tables_item<S>(a.ws.tabs + i * PROVE_TAB_WORDS, a.ws.pts + i * PROVE_PTS_WORDS);
+}
+
 void PROVE_STAGE(launch_prove_stage1)(const ProveArgs& a, hipStream_t st) {
   using S = ProveSuite;
   const size_t lanes_k_ = (a.n + a.k_lane - 1) / a.k_lane;      // K proofs per lane: a small grid
   const dim3 gk = grid_for(lanes_k_);
   if (S::H2C_ELL2 && !a.h_given) {
     VRF_LAUNCH_MINW(k_prove_prepare_multi, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
+    hipLaunchKernelGGL(k_prove_tables<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
   } else {
     if (!S::H2C_ELL2 && !a.h_given) {
       (void)hipMemsetAsync(a.tai_queue, 0, sizeof(unsigned long long), st);

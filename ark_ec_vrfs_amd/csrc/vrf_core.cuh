@@ -1010,17 +1010,14 @@ VRF_HD void tai_candidate(uint32_t enc[8], const uint8_t* msg, uint32_t msg_len,
   for (int j = 0; j < 8; ++j) enc[j] = sha512_word_mem(h, j);
 }
 // Does attempt `ctr` decode to a curve point?  (y < q, denominator non-zero, (y^2-1)(d y^2-a) a square: the
-// same verdict as decode_phase_b on (y^2-1)/(d y^2-a), without the inversion.)  k_tai_find uses it to hand
+// same verdict as decode_phase_b on (y^2-1)/(d y^2-a), without the inversion and without a square root.)  k_tai_find uses it to hand
 // hash_to_curve_tai a starting counter; a candidate of small order passes here and is rejected there.
 template <class S>
 VRF_HD bool tai_attempt_decodes(const uint8_t* msg, uint32_t msg_len, uint32_t ctr, const SqrtTables& T) {
   uint32_t enc[8];
   tai_candidate<S>(enc, msg, msg_len, ctr, *T.str);
   DecodeA a = decode_phase_a<S>(enc);
-  FeN root;
-  bool sq = fe_sqrt_or_zsqrt(root, fe_mul(a.num, a.den), T);
-  sq = sq || fe_is_zero(root);
-  return a.ok && sq;
+  return a.ok && fe_is_square_or_zero(fe_mul(a.num, a.den), T);       // Jacobi symbol: no exponentiation
 }
 
 // start: first counter to try (0, or the hint of k_tai_find: every smaller counter is known not to decode)
@@ -1213,7 +1210,7 @@ constexpr int PROVE_K = 8;
 template <class S>
 VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t n, const uint8_t* sk_arr,
                                 const BytesViewLite& msgs, uint32_t* tabs_base, uint32_t* pts_base,
-                                uint32_t* aux_base, int aux_stride, uint8_t* flags) {
+                                uint32_t* aux_base, int aux_stride, uint8_t* flags, bool defer_tables = false) {
   static_assert(S::H2C_ELL2, "multi-proof prepare is the Elligator path");
   FeN run = fe_one();
 #pragma unroll 1
@@ -1285,7 +1282,14 @@ VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t 
       for (int i = 0; i < 8; ++i) sk[i] = w[i];
       te_encode_affine(h_enc, x, y);
       nonce_rfc8032<S>(k, sk, h_enc);
-      build_prove_tables<S>(tabs_base + item * PROVE_TAB_WORDS, x, y);
+      if (defer_tables) {
+        // the kernels build the tables one proof per lane (prove_tables_item): 64 base doublings and four tables per
+        // proof are straight-line work that runs at twice the rate there than inside this K-proofs-per-lane stage
+        fe_store(slot + 6 * NL, x);
+        fe_store(slot + 7 * NL, y);
+      } else {
+        build_prove_tables<S>(tabs_base + item * PROVE_TAB_WORDS, x, y);
+      }
       uint32_t* aux = aux_base + item * aux_stride;
 #pragma unroll
       for (int i = 0; i < 8; ++i) { aux[i] = h_enc[i]; aux[8 + i] = k[i]; }
@@ -1318,6 +1322,12 @@ VRF_HD PtE var_base_mul(const uint32_t* tab, const uint32_t scalar[8]) {
     w = win_mul<S>(tab, rec);
   }
   return w;
+}
+
+// the deferred half of prove_prepare_multi: tables of H from the affine (x, y) it parked in the item's pts slot
+template <class S>
+VRF_HD void prove_tables_item(uint32_t* tab, const uint32_t* pts_slot) {
+  build_prove_tables<S>(tab, fe_load<1, 2>(pts_slot + 6 * NL), fe_load<1, 2>(pts_slot + 7 * NL));
 }
 
 template <class S>

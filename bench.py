@@ -66,6 +66,9 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    if os.environ.get("VRFHIP_BENCH_DRYRUN"):            # tests/test_bench_launch.py: show the launch, start nothing
+        print(json.dumps({"launch": cmd, "HSA_ENABLE_IPC_MODE_LEGACY": env["HSA_ENABLE_IPC_MODE_LEGACY"]}))
+        return 0
     return subprocess.run(cmd, env=env).returncode
 
 

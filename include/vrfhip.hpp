@@ -77,6 +77,17 @@ template <class S>
 class Context {
  public:
   explicit Context(int device = 0) { check(vrfhip_ctx_create(S::ID, device, &h_), "vrfhip_ctx_create"); }
+  // a suite given as data (`Suite::SUITE_ID`, generator, `PedersenSuite::BLINDING_BASE`, hash-to-curve DST)
+  Context(const vrfhip_suite_desc& desc, int device) { check(vrfhip_ctx_create_desc(&desc, device, &h_), "vrfhip_ctx_create_desc"); }
+  static vrfhip_suite_desc default_descriptor() {
+    vrfhip_suite_desc d;
+    check(vrfhip_suite_desc_default(S::ID, &d), "vrfhip_suite_desc_default");
+    return d;
+  }
+  // point classes whose subgroup membership the caller vouches for (typed, already validated values):
+  // VRFHIP_FLAG_PREVALIDATED_*; default 0 = arkworks' checked deserialisation inside every verify
+  void set_flags(uint32_t flags) { check(vrfhip_ctx_set_flags(h_, flags), "vrfhip_ctx_set_flags"); }
+  uint32_t flags() const { return vrfhip_ctx_get_flags(h_); }
   ~Context() { vrfhip_ctx_destroy(h_); }
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;

@@ -1,0 +1,50 @@
+"""CPU: bench.py's launch plumbing.  `python bench.py --gpus N` (N > 1, not under torch.distributed.run) must start
+its own ranks through `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`
+BEFORE anything touches a GPU (the parent imports neither torch nor the library), pass its own flags through, and
+under torch.distributed.run it must not launch again.  Also: the JSON line's contract keys on a recorded run."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gpus_n_self_launches_through_torch_distributed_run():
+    env = dict(os.environ, VRFHIP_BENCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "2"],
+                         env=env, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    cmd = d["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert d["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_parent_process_imports_no_gpu_runtime_before_spawning():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def self_launch")]
+    assert "import torch" not in head and "ark_ec_vrfs_amd" not in head     # module level: numpy / stdlib only
+    body = src[src.index("def self_launch"):src.index("def synth_msgs")]
+    assert "import torch" not in body and "Context(" not in body and "subprocess.run" in body
+    main = src[src.index("def main():"):]
+    assert main.index("self_launch(args)") < main.index("run_rank(args)")
+
+
+def test_recorded_bench_lines_carry_the_contract_keys():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02", "bench_n1*.json")))
+    assert files, "no recorded bench line under profiles/r02"
+    for f in files:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in d, (f, k)
+        assert d["config"]["workload"] and d["roofline"]["bound"] == "hbm" and d["vs_baseline"] is None
+        r = d["roofline"]
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9

@@ -1,0 +1,96 @@
+"""Condense tools/profile_round2.sh's rocprofv3 output (gpurun_out/r02prof/) into the tracked summaries:
+  profiles/r02/rocprofv3_kernel_stats_bench.csv       the --stats table of the bench command, as rocprofv3 wrote it
+  profiles/r02/rocprofv3_kernels_by_grid.json         per (kernel, grid size): launches, average duration from the kernel
+                                                      trace, counters per launch, corrected HBM bytes, VALU fraction
+  profiles/pmc_kernels.json                           what bench.py attaches to each config's roofline object
+Kernels are keyed by (name, grid) because the bench launches the same kernel at several batch sizes in one process.
+usage: python tools/summarize_profiles2.py gpurun_out/r02prof profiles/r02"""
+import collections, csv, glob, json, os, re, shutil, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+VALU_PEAK = 256 * 4 * 16 * 2.4e9
+
+
+def find(sub, suffix):
+    hits = glob.glob(os.path.join(src, sub, "**", "*" + suffix), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    return re.sub(r"^void ", "", name).split("(")[0]
+
+
+stats = find("stats", "kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(dst, "rocprofv3_kernel_stats_bench.csv"))
+table = collections.OrderedDict()
+trace = find("stats", "kernel_trace.csv")
+dur = collections.defaultdict(list)
+if trace:
+    for r in csv.DictReader(open(trace)):
+        name = short(r["Kernel_Name"])
+        if name.startswith("vrf::"):
+            grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])       # work-items, as Grid_Size in the counter files
+            dur[(name, grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+for key, v in dur.items():
+    table[key] = collections.OrderedDict(kernel=key[0], grid=key[1], launches=len(v), avg_duration_ns=sum(v) / len(v),
+                                         min_duration_ns=min(v))
+for sub in ("sq", "fetch", "write", "mix"):
+    path = find(sub, "counter_collection.csv")
+    if not path:
+        continue
+    acc = collections.defaultdict(list)
+    disp = {}
+    for r in csv.DictReader(open(path)):
+        name = short(r["Kernel_Name"])
+        if not name.startswith("vrf::"):
+            continue
+        key = (name, int(r["Grid_Size"]))
+        acc[(key, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        disp[key] = {k: r[k] for k in ("Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if k in r}
+    for (key, ctr), vals in acc.items():
+        e = table.setdefault(key, collections.OrderedDict(kernel=key[0], grid=key[1]))
+        e["dispatch"] = disp[key]
+        e[ctr] = sum(vals) / len(vals)
+for e in table.values():
+    if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+        # MI355X_MICROARCH.md, HBM section: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-B
+        # requests of 16 B/lane loads at 64 B -> x2 for these kernels (every global load here is a dwordx4)
+        e["hbm_bytes_per_launch"] = e["FETCH_SIZE"] * 2 * 1024 + e["WRITE_SIZE"] * 1024
+    if "SQ_INSTS_VALU" in e and "avg_duration_ns" in e:
+        e["valu_lane_instructions_per_launch"] = e["SQ_INSTS_VALU"] * 64
+        e["valu_frac_of_peak"] = e["SQ_INSTS_VALU"] * 64 / (e["avg_duration_ns"] * 1e-9) / VALU_PEAK
+rows = sorted(table.values(), key=lambda e: -e.get("avg_duration_ns", 0) * e.get("launches", 1))
+json.dump({"command": "rocprofv3 {--kernel-trace --stats | --pmc <one group per pass> --kernel-trace} -- python3 bench.py --steps 3 "
+                      "--warmup 1 --config-steps 2 --no-cpu-baseline",
+           "passes": ["SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE",
+                      "SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_SALU SQ_WAVE_CYCLES"],
+           "note": "averages per launch; valu_frac_of_peak = SQ_INSTS_VALU x 64 / duration / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz)",
+           "kernels": rows}, open(os.path.join(dst, "rocprofv3_kernels_by_grid.json"), "w"), indent=1)
+
+# config -> (kernel substring, grid) of its dominant kernel
+N20, N16, N14 = 1 << 20, 1 << 16, 1 << 14
+CONFIGS = [("ietf_verify", "k_verify_straus<vrf::SuiteBS, 1>", N20, 20), ("ietf_prove", "k_prove_mul<vrf::SuiteBS>", 2 * N16, 16),
+           ("pedersen_prove_jubjub", "k_prove_mul<vrf::SuiteJJ>", 2 * N20, 20),
+           ("pedersen_verify_jubjub", "k_ped_verify_straus<vrf::SuiteJJ, 0>", N20, 20),
+           ("pedersen_rlc_jubjub", "k_rlc_decode<vrf::SuiteJJ, 2>", None, 20),
+           ("pairing_check", "k_pairing_check2_quad(", 4 * N14, 14), ("pairing_check_shared", "k_pairing_check2_quad_prepared", 4 * N14, 14)]
+out = collections.OrderedDict()
+for cfg, pat, grid, lg in CONFIGS:
+    pat = pat.rstrip("(")
+    cand = [e for e in rows if (e["kernel"].endswith(pat) or pat in e["kernel"]) and (grid is None or abs(e["grid"] - grid) <= 256)
+            and not (pat.endswith("quad") and "prepared" in e["kernel"])]
+    if not cand:
+        continue
+    e = max(cand, key=lambda x: x.get("launches", 0))
+    out[cfg] = {"kernel": e["kernel"], "grid": e["grid"], "log2_batch": lg, "hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"),
+                "valu_lane_instructions_per_launch": e.get("valu_lane_instructions_per_launch"),
+                "avg_duration_ns_kernel_trace": e.get("avg_duration_ns"), "valu_frac_of_peak": e.get("valu_frac_of_peak"),
+                "source": "%s/rocprofv3_kernels_by_grid.json (tools/profile_round2.sh)" % dst}
+json.dump(out, open(os.path.join(os.path.dirname(dst.rstrip("/")), "pmc_kernels.json"), "w"), indent=1)
+for e in rows[:40]:
+    print("%-66s grid %-9d x%-3d %9.3f ms  valu %.3g  hbm %.3g B  frac %.2f" % (
+        e["kernel"][:66], e["grid"], e.get("launches", 0), e.get("avg_duration_ns", 0) / 1e6, e.get("SQ_INSTS_VALU", 0),
+        e.get("hbm_bytes_per_launch", 0), e.get("valu_frac_of_peak", 0)))
+print(json.dumps(out, indent=1)[:1500])
