@@ -43,7 +43,6 @@ struct vrfhip_ctx {
   int device = 0;
   vrfhip_suite suite = VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2;   // selects the compiled arithmetic (= desc.curve)
   vrfhip_suite_desc desc{};
-  SuiteStr* d_str = nullptr;
   hipStream_t stream = nullptr;      // used by the host-pointer entry points
   std::recursive_mutex mu;
   // shared tables
@@ -291,7 +290,6 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
   uint8_t* d_init = nullptr;          // 128 B points | 36 words Montgomery | 2 B flags
   HIP_TRY_C(hipMalloc(&ctx->d_sqrt_p, sqrt_p_bytes));
   HIP_TRY_C(hipMalloc(&ctx->d_sqrt_lut, lut_bytes));
-  HIP_TRY_C(hipMalloc(&ctx->d_str, sizeof(SuiteStr)));
   HIP_TRY_C(hipMalloc(&ctx->d_g_win, 2 * WIN_TABLE_WORDS * sizeof(uint32_t)));
   HIP_TRY_C(hipMalloc(&ctx->d_g_comb, comb_bytes));
   HIP_TRY_C(hipMalloc(&ctx->d_b_comb, comb_bytes));
@@ -302,12 +300,20 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
                            ctx->stream));
   HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_lut, vrfk_tables::SQRT_LUT, lut_bytes, hipMemcpyHostToDevice,
                            ctx->stream));
+  // the suite's byte strings, packed big-endian into the 64-bit words SHA-512 absorbs; they travel in the kernel
+  // arguments (SuiteStr, fe.cuh)
   SuiteStr hs{};
+  auto pack = [](uint64_t* w, const uint8_t* b, size_t n) {
+    for (size_t i = 0; i < n; ++i) w[i >> 3] |= (uint64_t)b[i] << (56 - 8 * (i & 7));
+  };
   hs.suite_id_len = desc->suite_id_len;
-  std::memcpy(hs.suite_id, desc->suite_id, desc->suite_id_len);
+  pack(hs.suite_id_w, desc->suite_id, desc->suite_id_len);
   if (ell2) {
-    hs.dst_len = desc->h2c_dst_len;
-    std::memcpy(hs.dst, desc->h2c_dst, desc->h2c_dst_len);
+    uint8_t dstp[129];
+    std::memcpy(dstp, desc->h2c_dst, desc->h2c_dst_len);
+    dstp[desc->h2c_dst_len] = (uint8_t)desc->h2c_dst_len;
+    hs.dst_prime_len = desc->h2c_dst_len + 1;
+    pack(hs.dst_prime_w, dstp, hs.dst_prime_len);
   }
   uint8_t gb[128];
   std::memcpy(gb, desc->generator, 64);
@@ -317,10 +323,9 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
   auto free_tmp = [&]() { (void)hipFree(d_prefix); (void)hipFree(d_init); };
   ctx->T.sq.P = ctx->d_sqrt_p;
   ctx->T.sq.lut = ctx->d_sqrt_lut;
-  ctx->T.sq.str = ctx->d_str;
+  ctx->T.sq.str = hs;
   {
-    hipError_t e0 = hipMemcpy(ctx->d_str, &hs, sizeof hs, hipMemcpyHostToDevice);
-    hipError_t e1 = e0 == hipSuccess ? hipMemcpy(d_init, gb, sizeof gb, hipMemcpyHostToDevice) : e0;
+    hipError_t e1 = hipMemcpy(d_init, gb, sizeof gb, hipMemcpyHostToDevice);
     if (e1 != hipSuccess) { free_tmp(); HIP_TRY_C(e1); }
   }
   uint32_t* d_mont = reinterpret_cast<uint32_t*>(d_init + 128);
@@ -360,7 +365,6 @@ void vrfhip_ctx_destroy(vrfhip_ctx* ctx) {
     if (ctx->d_msm_ws) (void)hipFree(ctx->d_msm_ws);
     if (ctx->d_sqrt_p) (void)hipFree(ctx->d_sqrt_p);
     if (ctx->d_sqrt_lut) (void)hipFree(ctx->d_sqrt_lut);
-    if (ctx->d_str) (void)hipFree(ctx->d_str);
     if (ctx->d_g_win) (void)hipFree(ctx->d_g_win);
     if (ctx->d_g_comb) (void)hipFree(ctx->d_g_comb);
     if (ctx->d_b_comb) (void)hipFree(ctx->d_b_comb);

@@ -366,13 +366,21 @@ VRF_HD FeN fe_inv(const Fe<L, V>& a) {   // a^(q-2); 0 -> 0
 // Table-driven Tonelli-Shanks for 2-adicity 32.  tbl = SQRT_P (4 x 256 x 9 words, h^(j 2^(8k))),
 // lut = SQRT_LUT.  Returns is_square(w) and sets `root` to sqrt(w) if w is a square, else to
 // sqrt(Z*w) (Z = 5, the suite's Elligator non-residue).  Constant shape: 220 + 24 squarings.
-struct SuiteStr;         // vrf_core.cuh: byte strings of the suite descriptor
+// Byte strings of the suite descriptor (include/vrfhip.h vrfhip_suite_desc), packed by the host into big-endian
+// 64-bit words -- the unit SHA-512 absorbs -- and carried BY VALUE inside the kernel arguments: uniform reads from
+// the kernarg segment are scalar loads, where a pointer into device memory cost every lane a vector load per byte.
+struct SuiteStr {
+  uint32_t suite_id_len;       // bytes, <= 64
+  uint32_t dst_prime_len;      // bytes of DST' = DST || byte(len(DST)), <= 129 (Elligator suites; 0 otherwise)
+  uint64_t suite_id_w[8];      // `Suite::SUITE_ID`, zero padded
+  uint64_t dst_prime_w[17];    // RFC 9380 DST' (upstream DST: "ECVRF_" || h2c suite id || SUITE_ID)
+};
 struct SqrtTables {
   const uint32_t* P;     // [4][256][9]
   const uint8_t* lut;    // [1 << SQRT_LUT_BITS]
   // The suite's byte strings travel with these tables because the same helpers (hash-to-curve, point decoding)
-  // receive them: `Suite::SUITE_ID` and the hash-to-curve DST of the context's descriptor (device memory).
-  const SuiteStr* str;
+  // receive them.
+  SuiteStr str;
 };
 
 VRF_HD uint32_t sqrt_lut_index(const SqrtTables& T, const FeN& y) {

@@ -76,12 +76,12 @@ void launch_hash_to_curve(int suite, size_t n, BytesView msg, uint8_t* points, D
 
 // ---- Output::hash ----
 template <class S>
-__global__ void __launch_bounds__(BLOCK) k_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash, const SuiteStr* ss) {
+__global__ void __launch_bounds__(BLOCK) k_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash, SuiteStr ss) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t g[8], o[16];
   load32(g, gamma, i);
-  output_hash_item<S>(o, g, *ss);
+  output_hash_item<S>(o, g, ss);
   uint32_t* p = reinterpret_cast<uint32_t*>(hash + i * 64);
 #pragma unroll
   for (int j = 0; j < 16; ++j) p[j] = o[j];
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(BLOCK) k_test_scalar_mul(size_t n, const uint8
 }
 // which = 0: SHA-512 (64 B per item); which = 1: expand_message_xmd to 96 bytes with the context's DST
 template <class S>
-__global__ void __launch_bounds__(BLOCK) k_test_hash(size_t n, BytesView msg, uint8_t* out, int which, const SuiteStr* ss) {
+__global__ void __launch_bounds__(BLOCK) k_test_hash(size_t n, BytesView msg, uint8_t* out, int which, SuiteStr ss) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint8_t* m; uint32_t len;
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(BLOCK) k_test_hash(size_t n, BytesView msg, ui
     for (int j = 0; j < 16; ++j) o[j] = sha512_word_mem(h, j);
   } else {
     uint64_t hb[2][8];
-    expand_message_xmd96<S>(hb, m, len, *ss);
+    expand_message_xmd96<S>(hb, m, len, ss);
     uint32_t* o = reinterpret_cast<uint32_t*>(out + i * 96);
 #pragma unroll
     for (int j = 0; j < 12; ++j) {

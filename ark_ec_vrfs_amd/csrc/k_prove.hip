@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare(ProveArgs a) {
     const uint8_t* ad; uint32_t ad_len;
     bytes_get(a.ad, i, ad, ad_len);
     uint32_t b[8], kb[8];
-    pedersen_blinding<S>(b, sk, h_enc, ad, ad_len, *a.T.sq.str);
+    pedersen_blinding<S>(b, sk, h_enc, ad, ad_len, a.T.sq.str);
     nonce_rfc8032<S>(kb, b, h_enc);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { aux[16 + j] = b[j]; aux[24 + j] = kb[j]; }
@@ -103,8 +103,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare_multi(ProveArgs a
   if constexpr (S::H2C_ELL2) {
     size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
     if (first >= a.n) return;
-    prove_prepare_multi<S>(a.k_lane, a.T, first, a.n, a.sk, a.msg, a.ws.tabs, a.ws.pts, a.ws.aux, AUX_WORDS, a.ws.flags,
-                           /*defer_tables=*/true);
+    prove_prepare_multi<S>(a.k_lane, a.T, first, a.n, a.sk, a.msg, a.ws.tabs, a.ws.pts, a.ws.aux, AUX_WORDS, a.ws.flags);
     if (a.pedersen) {
 #pragma unroll 1
       for (int j = 0; j < a.k_lane; ++j) {
@@ -117,7 +116,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare_multi(ProveArgs a
         for (int t = 0; t < 8; ++t) h_enc[t] = aux[t];
         const uint8_t* ad; uint32_t ad_len;
         bytes_get(a.ad, i, ad, ad_len);
-        pedersen_blinding<S>(b, sk, h_enc, ad, ad_len, *a.T.sq.str);
+        pedersen_blinding<S>(b, sk, h_enc, ad, ad_len, a.T.sq.str);
         nonce_rfc8032<S>(kb, b, h_enc);
 #pragma unroll
         for (int t = 0; t < 8; ++t) { aux[16 + t] = b[t]; aux[24 + t] = kb[t]; }
@@ -126,21 +125,12 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare_multi(ProveArgs a
   }
 }
 
-// stage 1b (after k_prove_prepare_multi): the window tables of H, one proof per lane
-template <class S>
-__global__ void __launch_bounds__(BLOCK) k_prove_tables(ProveArgs a) {
-  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= a.n) return;
-  prove_tables_item<S>(a.ws.tabs + i * PROVE_TAB_WORDS, a.ws.pts + i * PROVE_PTS_WORDS);
-}
-
 void PROVE_STAGE(launch_prove_stage1)(const ProveArgs& a, hipStream_t st) {
   using S = ProveSuite;
   const size_t lanes_k_ = (a.n + a.k_lane - 1) / a.k_lane;      // K proofs per lane: a small grid
   const dim3 gk = grid_for(lanes_k_);
   if (S::H2C_ELL2 && !a.h_given) {
     VRF_LAUNCH_MINW(k_prove_prepare_multi, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
-    hipLaunchKernelGGL(k_prove_tables<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
   } else {
     if (!S::H2C_ELL2 && !a.h_given) {
       (void)hipMemsetAsync(a.tai_queue, 0, sizeof(unsigned long long), st);
@@ -207,7 +197,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_finish(ProveArgs a) {
     }
     const uint8_t* ad; uint32_t ad_len;
     bytes_get(a.ad, i, ad, ad_len);
-    prove_respond_item<S>(c, s, enc, h_enc, sk, k, ad, ad_len, *a.T.sq.str);
+    prove_respond_item<S>(c, s, enc, h_enc, sk, k, ad, ad_len, a.T.sq.str);
     bool ok = a.ws.flags[i] != 0;
     if (a.pedersen) {
       uint32_t b[8], kb[8], cb[8], sb[8];

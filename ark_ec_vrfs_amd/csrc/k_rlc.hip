@@ -8,7 +8,7 @@
 //     D1 = s*H - c*Gamma - Ok = O      and      D2 = s*G + sb*B - c*pk_com - R = O.
 // c needs no curve arithmetic (every hashed point is part of the input), so for secret 128-bit weights
 // z_i, z'_i the single check  sum_i (z_i*D1_i + z'_i*D2_i) = O  accepts a batch containing an invalid
-// proof with probability <= 2^-128 (all points lie in the prime-order subgroup: the precondition of
+// proof with probability <= 2^-125 (128-bit weights with three fixed bits; all points lie in the prime-order subgroup: checked by
 // every verify entry point).  That sum is an MSM over 5n variable points plus the two fixed bases:
 //     sum_i [ (z s)_i H_i - (z c)_i Gamma_i - (z' c)_i pk_com_i - z'_i R_i - z_i Ok_i ]
 //       + (sum_i z'_i s_i) G + (sum_i z'_i sb_i) B.
@@ -43,7 +43,7 @@ VRF_HD void rlc_emit_item(const RlcArgs& a, size_t item, bool pts_valid, const u
   const uint8_t* adp; uint32_t adl;
   bytes_get(a.ad, item, adp, adl);
   uint32_t c[8], z[8], zp[8], t[8];
-  challenge5<S>(c, cp, adp, adl, *a.T.sq.str);
+  challenge5<S>(c, cp, adp, adl, a.T.sq.str);
   rlc_weights<S>(z, zp, a.seed, a.index0 + item);
   fr_mul<S>(t, z, s);
   msm_write_digits<S>(a.L.digits, N, rlc_index(0, n, item), t, false, !valid);     // + (z s) H

@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_verify_finish(VerifyArgs a) {
   if (first >= a.n) return;
   verify_finish_multi<S>(a.k_lane, first, a.n, a.ws.pts, PROVE_PTS_WORDS, a.pk, a.h, a.gamma,
                          a.affine_in ? a.ws.aux : nullptr, AUX_WORDS, a.c, a.s, a.ad, a.ws.flags, a.status,
-                         *a.T.sq.str, a.key_index, a.n_keys);
+                         a.T.sq.str, a.key_index, a.n_keys);
 }
 
 template <class S>

@@ -151,6 +151,14 @@ VRF_HD void sha512_words_le32x8(uint64_t out[4], const uint32_t w[8]) {
   for (int j = 0; j < 4; ++j) out[j] = ((uint64_t)bswap32(w[2 * j]) << 32) | bswap32(w[2 * j + 1]);
 }
 
+// n bytes packed big-endian into 64-bit words (zero padded): whole words, then the tail
+VRF_HD void sha512_put_packed(Sha512& s, const uint64_t* w, uint32_t n) {
+  uint32_t i = 0;
+#pragma unroll 1
+  for (; i + 8 <= n; i += 8) sha512_put(s, w[i >> 3], 8);
+  if (i < n) sha512_put(s, w[i >> 3], n - i);
+}
+
 // raw bytes from memory (host or device pointer valid in the calling context)
 VRF_HD void sha512_put_bytes(Sha512& s, const uint8_t* p, uint32_t n) {
   uint32_t i = 0;

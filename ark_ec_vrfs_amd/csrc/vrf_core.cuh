@@ -47,14 +47,7 @@ constexpr int WIN_TABLE_WORDS = WIN_ENTRIES * PTC_WORDS;   // 288 words = 1152 B
 // cofactor, r), whether it has the GLV endomorphism, how subgroup membership is decided and which hash-to-curve
 // construction runs.  Everything a `Suite` impl states as data -- SUITE_ID, the hash-to-curve DST, the generator
 // and the Pedersen blinding base -- comes from the context's descriptor (vrfhip_suite_desc): the byte strings
-// below, and the fixed-base tables built from the descriptor's points at context creation.
-struct SuiteStr {
-  uint32_t suite_id_len;       // <= 64
-  uint32_t dst_len;            // <= 128 (Elligator suites; unused by try-and-increment)
-  uint8_t suite_id[64];        // `Suite::SUITE_ID`
-  uint8_t dst[128];            // RFC 9380 DST: upstream "ECVRF_" || h2c suite id || SUITE_ID
-};
-
+// (SuiteStr, fe.cuh), and the fixed-base tables built from the descriptor's points at context creation.
 struct SuiteBS : CurveBS {
   static constexpr bool HAS_GLV = true;        // Bandersnatch endomorphism (te_psi, glv_decompose_bs)
   static constexpr bool SUBGROUP_2DESCENT = true;   // E(Fq) = Z2 x Z2 x Zr: the prime-order subgroup is 2E
@@ -68,7 +61,7 @@ struct SuiteJJ : CurveJJ {
   static constexpr bool H2C_ELL2 = false;
 };
 
-VRF_HD void put_suite_id(Sha512& h, const SuiteStr& ss) { sha512_put_bytes(h, ss.suite_id, ss.suite_id_len); }
+VRF_HD void put_suite_id(Sha512& h, const SuiteStr& ss) { sha512_put_packed(h, ss.suite_id_w, ss.suite_id_len); }
 
 // ------------------------------------------------------------------------ batch inversion
 template <int N, int L, int V>
@@ -858,10 +851,7 @@ VRF_HD uint32_t verify_finish_item(const uint32_t* uv, const uint32_t pk[8], con
 // [ref src/lib.rs:15-16 `Input::new` -> utils::hash_to_curve_ell2_rfc_9380]  SURVEY.md A.3
 // expand_message_xmd(SHA-512) with arkworks' 48-byte Z_pad, two field elements, Elligator 2
 // on the Montgomery model, map to twisted Edwards, add, clear cofactor.
-VRF_HD void put_dst_prime(Sha512& h, const SuiteStr& ss) {
-  sha512_put_bytes(h, ss.dst, ss.dst_len);
-  sha512_put_byte(h, (uint8_t)ss.dst_len);
-}
+VRF_HD void put_dst_prime(Sha512& h, const SuiteStr& ss) { sha512_put_packed(h, ss.dst_prime_w, ss.dst_prime_len); }
 
 // expand_message_xmd(SHA-512) to 96 bytes with arkworks' 48-byte Z_pad: uniform = b1 || b2[0..32];
 // b1, b2 as the eight big-endian 64-bit words of each digest
@@ -967,7 +957,7 @@ VRF_HD PtE ell2_map(const Fe<1, 4>& u, const FeN& Dinv, const SqrtTables& T) {
 template <class S>
 VRF_HD PtE hash_to_curve_ell2(const uint8_t* msg, uint32_t msg_len, const SqrtTables& T) {
   Fe<1, 4> u[2];
-  hash_to_field2<S>(u[0], u[1], msg, msg_len, *T.str);
+  hash_to_field2<S>(u[0], u[1], msg, msg_len, T.str);
   FeN D[2], Di[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -1015,7 +1005,7 @@ VRF_HD void tai_candidate(uint32_t enc[8], const uint8_t* msg, uint32_t msg_len,
 template <class S>
 VRF_HD bool tai_attempt_decodes(const uint8_t* msg, uint32_t msg_len, uint32_t ctr, const SqrtTables& T) {
   uint32_t enc[8];
-  tai_candidate<S>(enc, msg, msg_len, ctr, *T.str);
+  tai_candidate<S>(enc, msg, msg_len, ctr, T.str);
   DecodeA a = decode_phase_a<S>(enc);
   return a.ok && fe_is_square_or_zero(fe_mul(a.num, a.den), T);       // Jacobi symbol: no exponentiation
 }
@@ -1028,7 +1018,7 @@ VRF_HD PtE hash_to_curve_tai(const uint8_t* msg, uint32_t msg_len, const SqrtTab
 #pragma unroll 1
   for (uint32_t ctr = start; ctr < 256 && !done; ++ctr) {
     uint32_t enc[8];
-    tai_candidate<S>(enc, msg, msg_len, ctr, *T.str);
+    tai_candidate<S>(enc, msg, msg_len, ctr, T.str);
     DecodeA a = decode_phase_a<S>(enc);
     FeN di = fe_inv(a.den);
     Fe<1, 4> x;
@@ -1098,32 +1088,43 @@ VRF_HD void te_to_affine(FeN& x, FeN& y, const PtE& p) {
 constexpr int PROVE_PTS_WORDS = 4 * UV_WORDS;   // [half][win|comb][X,Y,Z]
 
 // ---- prove: the two variable-base products of a proof, sk*H and k*H, share their base ----
-// Doubling the BASE once instead of the accumulators twice: with H' = 2^64 H (64 doublings in the prepare stage)
-// each 128-bit GLV half splits into two 64-bit quarters, so a product is 60 accumulator doublings + 64 additions
-// from the four tables {H, H', psi H, psi H'} instead of 124 + 64 from {H, psi H}.  Per proof: 184 doublings +
-// 142 additions instead of 248 + 128.  Without an endomorphism (JubJub) the tables are {H, 2^64 H, 2^128 H,
-// 2^192 H}: 312 doublings + 149 additions instead of 504 + 128.  Any digit split gives the same group element:
-// results stay bit-exact.
-constexpr int PROVE_TABS = 4;
+// Without an endomorphism (JubJub) a 253-bit product costs 252 accumulator doublings.  Doubling the BASE instead --
+// tables {H, 2^64 H, 2^128 H, 2^192 H}, 192 base doublings once per proof -- leaves each product 60 accumulator
+// doublings + 64 additions (four streams of 16 signed radix-16 digits, one per table): 312 doublings + 149
+// additions per proof instead of 504 + 128 (k_prove_mul 34.5 -> 18.4 ms at 2^20).  Any digit split gives the same
+// group element: results stay bit-exact.
+// With GLV (Bandersnatch) the same trick -- {H, 2^64 H, psi H, psi 2^64 H}, 64-bit quarters -- was built and
+// measured, and withdrawn: it saves 128 accumulator doublings per proof in a kernel that runs at 93 % of the VALU
+// ceiling and pays 64 base doublings + two more tables in a stage that does not (its table stores are uncoalesced
+// 144-byte records: 0.76 of the ceiling at best): 34.5 ms per 2^20 proofs against 32.3 ms.  Bandersnatch keeps
+// the table pair {H, psi H} and two streams of 32 digits.
+template <class S> struct ProveLayout {
+  static constexpr int TABS = S::HAS_GLV ? 2 : 4;        // tables per proof
+  static constexpr int DIGITS = S::HAS_GLV ? 32 : 16;    // signed radix-16 digits per stream
+};
+constexpr int PROVE_TABS = 4;                            // workspace slots reserved per proof (largest layout)
 constexpr int PROVE_TAB_WORDS = PROVE_TABS * WIN_TABLE_WORDS;
 template <class S>
 VRF_HD void build_prove_tables(uint32_t* tab, const FeP& x, const FeP& y) {
-  PtE p = te_from_affine(x, y);
-  constexpr int NB = S::HAS_GLV ? 2 : 4;
+  if constexpr (S::HAS_GLV) {
+    build_glv_tables<S>(tab, x, y);                      // {H, psi H}
+  } else {
+    PtE p = te_from_affine(x, y);
 #pragma unroll 1
-  for (int j = 0; j < NB; ++j) {
-    if (j) {
+    for (int j = 0; j < ProveLayout<S>::TABS; ++j) {
+      if (j) {
 #pragma unroll 1
-      for (int i = 0; i < 64; ++i) p = te_dbl<S>(p, i == 63);
+        for (int i = 0; i < 64; ++i) p = te_dbl<S>(p, i == 63);
+      }
+      build_win_table_from<S>(tab + j * WIN_TABLE_WORDS, p);
     }
-    build_win_table_from<S>(tab + j * WIN_TABLE_WORDS, p);
-    if constexpr (S::HAS_GLV) build_win_table_from<S>(tab + (2 + j) * WIN_TABLE_WORDS, te_psi<S>(p));
   }
 }
-// scalar * H from the four tables of build_prove_tables: stream t reads digits 16 t + w of a 64-digit signed
-// radix-16 string (GLV: k1's 32 digits then k2's 32 digits; else the 253-bit scalar) and adds from table t
+// scalar * H from the tables of build_prove_tables: stream t reads digits DIGITS * t + w of a 64-digit signed radix-16
+// string (GLV: k1's 32 digits then k2's 32 digits; else the 253-bit scalar) and adds from table t
 template <class S>
 VRF_HD PtE prove_var_mul(const uint32_t* tab, const uint32_t scalar[8]) {
+  constexpr int NT = ProveLayout<S>::TABS, ND = ProveLayout<S>::DIGITS;
   uint32_t rec[8];
   bool neg_lo = false, neg_hi = false;
   if constexpr (S::HAS_GLV) {
@@ -1140,21 +1141,20 @@ VRF_HD PtE prove_var_mul(const uint32_t* tab, const uint32_t scalar[8]) {
   }
   PtE acc = te_identity();
 #pragma unroll 1
-  for (int w = 15; w >= 0; --w) {
-    if (w != 15) {
+  for (int w = ND - 1; w >= 0; --w) {
+    if (w != ND - 1) {
 #pragma unroll 1
       for (int j = 0; j < 4; ++j) acc = te_dbl<S>(acc, j == 3);
     }
 #pragma unroll 1
-    for (int t = 0; t < PROVE_TABS; ++t) {
-      const int d = scalar_digit4(rec, 16 * t + w);
-      const bool neg = t < 2 ? neg_lo : neg_hi;
-      acc = te_add_cached<S>(acc, win_lookup(tab + t * WIN_TABLE_WORDS, d), (d < 0) != neg, t != PROVE_TABS - 1 || w == 0);
+    for (int t = 0; t < NT; ++t) {
+      const int d = scalar_digit4(rec, ND * t + w);
+      const bool neg = 2 * t < NT ? neg_lo : neg_hi;
+      acc = te_add_cached<S>(acc, win_lookup(tab + t * WIN_TABLE_WORDS, d), (d < 0) != neg, t != NT - 1 || w == 0);
     }
   }
   return acc;
 }
-
 
 // returns validity (always true for the hash-to-curve path; decode may fail)
 // [ref src/lib.rs:14 `pedersen::PedersenSuite::blinding`]  SURVEY.md A.5:
@@ -1210,7 +1210,7 @@ constexpr int PROVE_K = 8;
 template <class S>
 VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t n, const uint8_t* sk_arr,
                                 const BytesViewLite& msgs, uint32_t* tabs_base, uint32_t* pts_base,
-                                uint32_t* aux_base, int aux_stride, uint8_t* flags, bool defer_tables = false) {
+                                uint32_t* aux_base, int aux_stride, uint8_t* flags) {
   static_assert(S::H2C_ELL2, "multi-proof prepare is the Elligator path");
   FeN run = fe_one();
 #pragma unroll 1
@@ -1220,7 +1220,7 @@ VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t 
       const uint8_t* m; uint32_t len;
       bytes_lite_get(msgs, item, m, len);
       Fe<1, 4> u0, u1;
-      hash_to_field2<S>(u0, u1, m, len, *T.sq.str);
+      hash_to_field2<S>(u0, u1, m, len, T.sq.str);
       uint32_t* slot = pts_base + item * PROVE_PTS_WORDS;
 #pragma unroll 1
       for (int t = 0; t < 2; ++t) {
@@ -1282,14 +1282,7 @@ VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t 
       for (int i = 0; i < 8; ++i) sk[i] = w[i];
       te_encode_affine(h_enc, x, y);
       nonce_rfc8032<S>(k, sk, h_enc);
-      if (defer_tables) {
-        // the kernels build the tables one proof per lane (prove_tables_item): 64 base doublings and four tables per
-        // proof are straight-line work that runs at twice the rate there than inside this K-proofs-per-lane stage
-        fe_store(slot + 6 * NL, x);
-        fe_store(slot + 7 * NL, y);
-      } else {
-        build_prove_tables<S>(tabs_base + item * PROVE_TAB_WORDS, x, y);
-      }
+      build_prove_tables<S>(tabs_base + item * PROVE_TAB_WORDS, x, y);
       uint32_t* aux = aux_base + item * aux_stride;
 #pragma unroll
       for (int i = 0; i < 8; ++i) { aux[i] = h_enc[i]; aux[8 + i] = k[i]; }
@@ -1322,12 +1315,6 @@ VRF_HD PtE var_base_mul(const uint32_t* tab, const uint32_t scalar[8]) {
     w = win_mul<S>(tab, rec);
   }
   return w;
-}
-
-// the deferred half of prove_prepare_multi: tables of H from the affine (x, y) it parked in the item's pts slot
-template <class S>
-VRF_HD void prove_tables_item(uint32_t* tab, const uint32_t* pts_slot) {
-  build_prove_tables<S>(tab, fe_load<1, 2>(pts_slot + 6 * NL), fe_load<1, 2>(pts_slot + 7 * NL));
 }
 
 template <class S>
@@ -1454,7 +1441,7 @@ VRF_HD bool pedersen_verify_decode_item(uint32_t c_out[8], const DevTables& T,
   for (int j = 0; j < 8; ++j) {
     cp[0][j] = enc[2][j]; cp[1][j] = enc[0][j]; cp[2][j] = enc[1][j]; cp[3][j] = enc[3][j]; cp[4][j] = enc[4][j];
   }
-  challenge5<S>(c_out, cp, ad, ad_len, *T.sq.str);
+  challenge5<S>(c_out, cp, ad, ad_len, T.sq.str);
   return valid;
 }
 

@@ -247,6 +247,46 @@ def cfg_ietf_prove(D, args, ctx, sk, msg, want_cpu):
     return out
 
 
+def cfg_ietf_keyed(D, args, ctx, msg, lo):
+    """The headline's workload for a verifier that knows its signers (`Public` keys of a validator set): 2^20 proofs
+    under 1024 keys whose validated points and fixed-base tables stay resident in HBM (vrfhip_keyset_create)."""
+    torch = D.torch
+    from ark_ec_vrfs_amd import _lib
+    lib = _lib.load()
+    n = msg.shape[0]
+    nk = 1024
+    stream = torch.cuda.current_stream().cuda_stream
+    mk = lambda m=n: torch.empty((m, 32), dtype=torch.uint8, device=D.dev)
+    kseeds = (torch.arange(nk, dtype=torch.int64, device=D.dev) + (1 << 40)).view(torch.uint8).reshape(nk, 8)
+    ksk, kpk = mk(nk), mk(nk)
+    _lib.check(lib.vrfhip_secret_from_seed_batch_dev(ctx.handle, nk, kseeds.data_ptr(), 8, ksk.data_ptr(), kpk.data_ptr(), stream), "seed")
+    kidx = ((torch.arange(n, device=D.dev) + lo) * 2654435761 % nk).to(torch.int32)
+    g2, c2, s2, h2 = mk(), mk(), mk(), mk()
+    vst = torch.empty(n, dtype=torch.uint8, device=D.dev)
+    ctx.ietf_prove_batch_dev(ksk[kidx.long()].contiguous(), msg, 32, g2, c2, s2, None, h2, vst)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ks, kst = ctx.keyset_create(kpk.cpu().numpy())
+    build_ms = (time.perf_counter() - t0) * 1e3
+    try:
+        fn = lambda: ctx.ietf_verify_batch_keyed_dev(ks, kidx, h2, g2, c2, s2, vst)
+        fn(); torch.cuda.synchronize()
+        ctx.profile(True)
+        el, _ = timed(D, fn, args.config_steps, 1, gather_t=vst, n_per_rank=n)
+        ctx.profile(False)
+        ms, groups = stage_avg(ctx)
+        assert int(vst.sum()) == 0 and int(kst.sum()) == 0
+        lg = n.bit_length() - 1
+        rf, v = roofline("k_verify_straus<1> (V = s*H - c*Gamma)", 133, n, ms[1], groups, pmc_for("ietf_verify", lg))
+        return {"workload": "IETF ECVRF verify against a resident key set (1024 validated keys, 881 KB comb each), batch 2^%d per "
+                            "GPU: 4-byte key index + H, Gamma, c, s per proof; H and Gamma checked-decoded" % lg,
+                "value": D.world * n * args.config_steps / el, "unit": "verifies/s", "ms_per_step": el / args.config_steps * 1e3,
+                "bytes_per_unit": 133, "roofline": rf, "valu": v, "keyset_build_ms": build_ms, "keyset_bytes": ks.bytes(),
+                "stage_ms_per_step": {"decode": ms[0], "straus_v": ms[1], "comb_u": ms[2], "finish": ms[3]}}
+    finally:
+        ks.close()
+
+
 def cfg_pedersen_jubjub(D, args, msg, lo, want_cpu):
     """BASELINE.json configs[3]: Pedersen VRF batch 2^20 prove + verify on JubJub (sharded: every rank its own batch)."""
     torch = D.torch
@@ -498,6 +538,7 @@ def run_rank(args):
     configs = {}
     if not args.no_configs:
         legs = (("ietf_prove", lambda: {"ietf_prove": cfg_ietf_prove(D, args, ctx, sk, msg, want_cpu and rank == 0)}),
+                ("ietf_verify_keyed", lambda: {"ietf_verify_keyed": cfg_ietf_keyed(D, args, ctx, msg, lo)}),
                 ("pedersen_jubjub", lambda: cfg_pedersen_jubjub(D, args, msg, lo, want_cpu and rank == 0)),
                 ("pairing", lambda: cfg_pairing(D, args, ctx, want_cpu and rank == 0)))
         for name, leg in legs:

@@ -258,7 +258,8 @@ int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_
  * accepted iff  sum_i z_i (s_i H_i - c_i Gamma_i - Ok_i) + z'_i (s_i G + sb_i B - c_i pk_com_i - R_i)
  * is the neutral element, (z_i, z'_i) = 2 x 128 bits of SHA-512("vrfhip-rlc-v1" || seed || u64_le(i)), each forced to 1 (mod 8).
  * `seed` (32 bytes, host memory) must be unpredictable to the provers (fresh randomness per call);
- * a batch holding an invalid proof is then accepted with probability <= 2^-128.
+ * a batch holding an invalid proof is then accepted with probability <= 2^-125 (the weights are 128-bit values with
+ * their low three bits fixed).
  * The bound needs all five points of every proof in the prime-order subgroup, which the decode stage checks
  * (InvalidData otherwise) unless the caller vouched for them with vrfhip_ctx_set_flags.  With PREVALIDATED
  * flags set on unvalidated bytes the bound is void: a defect of small order (a proof point shifted by a 2- or

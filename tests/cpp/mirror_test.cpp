@@ -139,6 +139,24 @@ int main(int argc, char** argv) {
   pres = pedersen::verify_batch(ctx, pitems, unhex(ped_ad), &fast);
   CHECK(!fast);
   for (size_t i = 0; i < pitems.size(); ++i) CHECK(i == 42 ? pres[i] == Error::VerificationFailure : !pres[i].has_value());
+  // a suite given as data: a context made from the default descriptor proves the same bytes; flags round trip
+  {
+    vrfhip_suite_desc d = Context<S>::default_descriptor();
+    CHECK(d.curve == VRFHIP_CURVE_BANDERSNATCH && d.suite_id_len == 25 && d.challenge_len == 32);
+    Context<S> from_desc(d, 0);
+    const auto a = ietf::prove_batch(ctx, {sks[0], sks[1]}, {msgs[0], msgs[1]}, unhex(ad));
+    const auto b = ietf::prove_batch(from_desc, {sks[0], sks[1]}, {msgs[0], msgs[1]}, unhex(ad));
+    CHECK(a[0].proof.c == b[0].proof.c && a[1].proof.s == b[1].proof.s && a[1].output.encoded == b[1].output.encoded);
+    d.suite_id[0] ^= 1;                                                    // another suite string: another challenge
+    Context<S> other(d, 0);
+    const auto c2 = ietf::prove_batch(other, {sks[0]}, {msgs[0]}, unhex(ad));
+    CHECK(!(c2[0].proof.c == a[0].proof.c) && c2[0].output.encoded == a[0].output.encoded);
+    CHECK(ctx.flags() == 0);
+    from_desc.set_flags(VRFHIP_FLAG_PREVALIDATED_INPUT | VRFHIP_FLAG_PREVALIDATED_PUBLIC);
+    CHECK(from_desc.flags() == 3);
+    const auto r = ietf::verify_batch(from_desc, b, unhex(ad));
+    CHECK(!r[0].has_value() && !r[1].has_value());
+  }
   std::printf("mirror_test ok: KAT, %zu IETF proofs, %zu Pedersen proofs\n", n, pitems.size());
   return 0;
 }

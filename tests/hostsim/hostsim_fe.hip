@@ -8,25 +8,29 @@
 using namespace vrf;
 
 // suite strings of the host build (defaults: the built-in Bandersnatch descriptor); shared by the Bandersnatch units
-SuiteStr g_hs_str = [] {
+static void hs_pack(uint64_t* w, const uint8_t* b, size_t n) {
+  for (size_t i = 0; i < n; ++i) w[i >> 3] |= (uint64_t)b[i] << (56 - 8 * (i & 7));
+}
+static SuiteStr hs_make_str(const uint8_t* id, uint32_t id_len, const uint8_t* dst, uint32_t dst_len) {
   SuiteStr s{};
-  const char id[] = "Bandersnatch_SHA-512_ELL2", dst[] = "ECVRF_Bandersnatch_XMD:SHA-512_ELL2_RO_Bandersnatch_SHA-512_ELL2";
-  s.suite_id_len = sizeof id - 1; memcpy(s.suite_id, id, sizeof id - 1);
-  s.dst_len = sizeof dst - 1; memcpy(s.dst, dst, sizeof dst - 1);
+  s.suite_id_len = id_len; hs_pack(s.suite_id_w, id, id_len);
+  if (dst_len) {
+    uint8_t dp[129]; memcpy(dp, dst, dst_len); dp[dst_len] = (uint8_t)dst_len;
+    s.dst_prime_len = dst_len + 1; hs_pack(s.dst_prime_w, dp, dst_len + 1);
+  }
   return s;
-}();
+}
+SuiteStr g_hs_str = hs_make_str((const uint8_t*)"Bandersnatch_SHA-512_ELL2", 25,
+                                (const uint8_t*)"ECVRF_Bandersnatch_XMD:SHA-512_ELL2_RO_Bandersnatch_SHA-512_ELL2", 64);
 static SqrtTables host_tables() {
-  SqrtTables t; t.P = vrfk_tables::SQRT_P; t.lut = vrfk_tables::SQRT_LUT; t.str = &g_hs_str; return t;
+  SqrtTables t; t.P = vrfk_tables::SQRT_P; t.lut = vrfk_tables::SQRT_LUT; t.str = g_hs_str; return t;
 }
 static FeN in(const uint8_t* b) { uint32_t w[8]; memcpy(w, b, 32); return fe_from_u256(w); }
 template <int L, int V> static void out(uint8_t* b, const Fe<L, V>& a) { uint32_t w[8]; fe_to_u256(w, a); memcpy(b, w, 32); }
 extern "C" {
 // descriptor strings (vrfhip_suite_desc.suite_id / h2c_dst) for every Bandersnatch entry point of the host build
 void hs_set_suite_strings(const uint8_t* id, uint32_t id_len, const uint8_t* dst, uint32_t dst_len) {
-  SuiteStr s{};
-  s.suite_id_len = id_len; memcpy(s.suite_id, id, id_len);
-  s.dst_len = dst_len; memcpy(s.dst, dst, dst_len);
-  g_hs_str = s;
+  g_hs_str = hs_make_str(id, id_len, dst, dst_len);
 }
 void hs_fe_mul(const uint8_t* a, const uint8_t* b, uint8_t* r) { out(r, fe_mul(in(a), in(b))); }
 void hs_fe_sqr(const uint8_t* a, uint8_t* r) { out(r, fe_sqr(in(a))); }

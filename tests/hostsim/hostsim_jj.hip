@@ -5,12 +5,13 @@
 using namespace vrf;
 typedef SuiteJJ SJ;
 namespace {
-SuiteStr g_hj_str = [] {
+static SuiteStr hj_make_str(const uint8_t* id, uint32_t id_len) {
   SuiteStr s{};
-  const char id[] = "JubJub_SHA-512_TAI";
-  s.suite_id_len = sizeof id - 1; memcpy(s.suite_id, id, sizeof id - 1);
+  s.suite_id_len = id_len;
+  for (uint32_t i = 0; i < id_len; ++i) s.suite_id_w[i >> 3] |= (uint64_t)id[i] << (56 - 8 * (i & 7));
   return s;
-}();
+}
+SuiteStr g_hj_str = hj_make_str((const uint8_t*)"JubJub_SHA-512_TAI", 18);
 struct HostTablesJ {
   std::vector<uint32_t> g_win, g_comb, b_comb;
   DevTables t;
@@ -25,11 +26,11 @@ struct HostTablesJ {
     for (int seg = 0; seg < GC_SEGS; ++seg)       // the device's own table builder (k_init_gcomb runs it per lane)
       gcomb_build_segment<SJ>(which ? b_comb.data() : g_comb.data(), prefix.data(),
                               which ? bx : gx, which ? by : gy, w, seg);
-    t.sq.P = vrfk_tables::SQRT_P; t.sq.lut = vrfk_tables::SQRT_LUT; t.sq.str = &g_hj_str;
+    t.sq.P = vrfk_tables::SQRT_P; t.sq.lut = vrfk_tables::SQRT_LUT; t.sq.str = g_hj_str;
     t.g_win = g_win.data(); t.g_comb = g_comb.data(); t.b_comb = b_comb.data();
   }
 };
-HostTablesJ& HJ() { static HostTablesJ h; return h; }
+HostTablesJ& HJ() { static HostTablesJ h; h.t.sq.str = g_hj_str; return h; }
 }
 static uint32_t g_check_mask_jj = 0;   // CHK_* bits for the decode stages (0 = on-curve only)
 extern "C" {
@@ -46,9 +47,7 @@ int hj_decode_checked(const uint8_t* enc) {
 }
 // a descriptor for the host build: suite string + generator and blinding base (x || y little-endian)
 void hj_configure(const uint8_t* id, uint32_t id_len, const uint8_t* g_xy, const uint8_t* b_xy) {
-  SuiteStr s{};
-  s.suite_id_len = id_len; memcpy(s.suite_id, id, id_len);
-  g_hj_str = s;
+  g_hj_str = hj_make_str(id, id_len);
   auto in = [](const uint8_t* b) { uint32_t w[8]; memcpy(w, b, 32); return fe_from_u256(w); };
   HJ().build(in(g_xy), in(g_xy + 32), in(b_xy), in(b_xy + 32));
 }

@@ -9,7 +9,7 @@ using namespace vrf;
 
 extern SuiteStr g_hs_str;      // hostsim_fe.hip
 static SqrtTables host_tables() {
-  SqrtTables t; t.P = vrfk_tables::SQRT_P; t.lut = vrfk_tables::SQRT_LUT; t.str = &g_hs_str; return t;
+  SqrtTables t; t.P = vrfk_tables::SQRT_P; t.lut = vrfk_tables::SQRT_LUT; t.str = g_hs_str; return t;
 }
 static FeN in(const uint8_t* b) { uint32_t w[8]; memcpy(w, b, 32); return fe_from_u256(w); }
 template <int L, int V> static void out(uint8_t* b, const Fe<L, V>& a) { uint32_t w[8]; fe_to_u256(w, a); memcpy(b, w, 32); }
@@ -34,7 +34,7 @@ struct HostTables {
     t.sq = host_tables(); t.g_win = g_win.data(); t.g_comb = g_comb.data(); t.b_comb = b_comb.data();
   }
 };
-HostTables& HT() { static HostTables h; return h; }
+HostTables& HT() { static HostTables h; h.t.sq.str = g_hs_str; return h; }      // strings may change between calls
 }
 static uint32_t g_check_mask_p = 0;    // CHK_* bits for the decode stages (0 = on-curve only)
 extern "C" {
