@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_prepare(ProveArgs a) {
   if (a.h_given) load32(hg, a.h_given, i); else bytes_get(a.msg, i, msg, msg_len);
   // try-and-increment suites: k_tai_find left the first decodable counter in the item's flag byte
   const uint32_t tai_start = (!S::H2C_ELL2 && !a.h_given) ? a.ws.flags[i] : 0u;
-  bool ok = prove_prepare_item<S>(h_enc, k, a.ws.tabs + i * PROVE_TAB_WORDS, a.T, sk, msg,
+  bool ok = prove_prepare_item<S>(h_enc, k, a.ws.tabs + i * ProveLayout<S>::TAB_WORDS, a.T, sk, msg,
                                         msg_len, a.h_given ? hg : nullptr, tai_start, a.check_mask);
   uint32_t* aux = a.ws.aux + i * AUX_WORDS;
 #pragma unroll
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(BLOCK) k_prove_mul(ProveArgs a) {
     for (int j = 0; j < 8; ++j) sc[j] = 0;
   }
   prove_mul_item<S>(a.ws.pts + i * PROVE_PTS_WORDS + half * 2 * UV_WORDS, a.T,
-                          a.ws.tabs + i * PROVE_TAB_WORDS, sc,
+                          a.ws.tabs + i * ProveLayout<S>::TAB_WORDS, sc,
                           a.pedersen ? a.ws.aux + i * AUX_WORDS + 16 + half * 8 : nullptr);
 }
 
@@ -180,7 +180,7 @@ template <class S, int MINW>
 __global__ void __launch_bounds__(BLOCK, MINW) k_prove_finish(ProveArgs a) {
   size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   if (first >= a.n) return;
-  const int tstride = PROVE_TAB_WORDS;
+  const int tstride = ProveLayout<S>::TAB_WORDS;
   prove_encode_multi<S>(a.k_lane, first, a.n, a.ws.pts, a.ws.tabs, tstride);
 #pragma unroll 1
   for (int jj = 0; jj < a.k_lane; ++jj) {

@@ -148,10 +148,28 @@ inline dim3 grid_for(size_t threads) { return dim3((unsigned)((threads + BLOCK -
 // spill a little and run two waves per SIMD, which pays once the grid has two waves per SIMD to offer; below
 // that (2^16-item batches) the uncapped build is faster.  VRF_LAUNCH_MINW picks the instantiation.
 inline bool two_waves_pay(size_t lanes) { return lanes >= size_t(131072); }
+// Static LDS of one kernel instantiation.  The compiler moves indexed per-thread arrays into LDS (8 KiB per
+// workgroup in k_prove_prepare_multi, 10 KiB in k_prove_mul) and that comes on top of the dynamic bytes
+// spread_lds_bytes() reserves: unaccounted, four 38 KiB workgroups no longer fit a CU and a 1024-workgroup grid
+// runs in two rounds (measured: prepare 7.8 -> 11.7 ms at 2^20).  The launch macro subtracts it.
+template <auto Kernel>
+inline size_t static_lds_of() {
+  static const size_t bytes = [] {
+    hipFuncAttributes fa{};
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(Kernel)) == hipSuccess ? (size_t)fa.sharedSizeBytes
+                                                                                          : (size_t)0;
+  }();
+  return bytes;
+}
+inline size_t dynamic_lds(size_t want, size_t static_bytes) { return want > static_bytes ? want - static_bytes : 0; }
 #define VRF_LAUNCH_MINW(KERNEL, S_, lanes, grid, lds, st, args)                                   \
   do {                                                                                            \
-    if (two_waves_pay(lanes)) hipLaunchKernelGGL((KERNEL<S_, 2>), grid, dim3(BLOCK), lds, st, args); \
-    else hipLaunchKernelGGL((KERNEL<S_, 1>), grid, dim3(BLOCK), lds, st, args);                   \
+    if (two_waves_pay(lanes))                                                                     \
+      hipLaunchKernelGGL((KERNEL<S_, 2>), grid, dim3(BLOCK),                                      \
+                         dynamic_lds(lds, static_lds_of<(KERNEL<S_, 2>)>()), st, args);           \
+    else                                                                                          \
+      hipLaunchKernelGGL((KERNEL<S_, 1>), grid, dim3(BLOCK),                                      \
+                         dynamic_lds(lds, static_lds_of<(KERNEL<S_, 1>)>()), st, args);           \
   } while (0)
 
 // Dynamic LDS bytes that make a SMALL grid spread over the whole chip.  The kernels that share inversions

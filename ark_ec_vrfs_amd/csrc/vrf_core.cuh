@@ -1101,9 +1101,8 @@ constexpr int PROVE_PTS_WORDS = 4 * UV_WORDS;   // [half][win|comb][X,Y,Z]
 template <class S> struct ProveLayout {
   static constexpr int TABS = S::HAS_GLV ? 2 : 4;        // tables per proof
   static constexpr int DIGITS = S::HAS_GLV ? 32 : 16;    // signed radix-16 digits per stream
+  static constexpr int TAB_WORDS = TABS * WIN_TABLE_WORDS;   // the proof's stride in the table region
 };
-constexpr int PROVE_TABS = 4;                            // workspace slots reserved per proof (largest layout)
-constexpr int PROVE_TAB_WORDS = PROVE_TABS * WIN_TABLE_WORDS;
 template <class S>
 VRF_HD void build_prove_tables(uint32_t* tab, const FeP& x, const FeP& y) {
   if constexpr (S::HAS_GLV) {
@@ -1123,22 +1122,14 @@ VRF_HD void build_prove_tables(uint32_t* tab, const FeP& x, const FeP& y) {
 // scalar * H from the tables of build_prove_tables: stream t reads digits DIGITS * t + w of a 64-digit signed radix-16
 // string (GLV: k1's 32 digits then k2's 32 digits; else the 253-bit scalar) and adds from table t
 template <class S>
+VRF_HD PtE var_base_mul(const uint32_t* tab, const uint32_t scalar[8]);
+template <class S>
 VRF_HD PtE prove_var_mul(const uint32_t* tab, const uint32_t scalar[8]) {
+  if constexpr (S::HAS_GLV) return var_base_mul<S>(tab, scalar);     // two-table GLV Straus over {H, psi H}
   constexpr int NT = ProveLayout<S>::TABS, ND = ProveLayout<S>::DIGITS;
   uint32_t rec[8];
-  bool neg_lo = false, neg_hi = false;
-  if constexpr (S::HAS_GLV) {
-    GlvHalf h[2];
-    glv_decompose_bs(h[0], h[1], scalar);
-    uint32_t r0[4], r1[4];
-    scalar_recode_signed4_128(r0, h[0].mag);
-    scalar_recode_signed4_128(r1, h[1].mag);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { rec[i] = r0[i]; rec[4 + i] = r1[i]; }
-    neg_lo = h[0].neg; neg_hi = h[1].neg;
-  } else {
-    scalar_recode_signed4(rec, scalar);
-  }
+  const bool neg_lo = false, neg_hi = false;
+  scalar_recode_signed4(rec, scalar);
   PtE acc = te_identity();
 #pragma unroll 1
   for (int w = ND - 1; w >= 0; --w) {
@@ -1197,7 +1188,7 @@ VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, 
   }
   te_encode_affine(h_enc, x, y);
   nonce_rfc8032<S>(k, sk, h_enc);
-  build_prove_tables<S>(tab, x, y);        // PROVE_TAB_WORDS words
+  build_prove_tables<S>(tab, x, y);        // ProveLayout<S>::TAB_WORDS words
   if (h_given && (check_mask & CHK_INPUT)) valid = in_prime_subgroup<S>(x, y, T.sq) && valid;   // a given H is wire data
   return valid;
 }
@@ -1282,7 +1273,7 @@ VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t 
       for (int i = 0; i < 8; ++i) sk[i] = w[i];
       te_encode_affine(h_enc, x, y);
       nonce_rfc8032<S>(k, sk, h_enc);
-      build_prove_tables<S>(tabs_base + item * PROVE_TAB_WORDS, x, y);
+      build_prove_tables<S>(tabs_base + item * ProveLayout<S>::TAB_WORDS, x, y);
       uint32_t* aux = aux_base + item * aux_stride;
 #pragma unroll
       for (int i = 0; i < 8; ++i) { aux[i] = h_enc[i]; aux[8 + i] = k[i]; }

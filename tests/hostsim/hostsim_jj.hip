@@ -74,7 +74,7 @@ void hj_hash_to_curve_from(const uint8_t* msg, uint32_t len, uint32_t start, uin
 int hj_prove(int pedersen, const uint8_t* sk, const uint8_t* msg, uint32_t len, const uint8_t* ad, uint32_t ad_len, uint8_t* out) {
   uint32_t skw[8]; memcpy(skw, sk, 32);
   uint32_t h_enc[8], k[8], kb[8], b[8], o[6][8], sb[8];
-  std::vector<uint32_t> tab(PROVE_TAB_WORDS), pts(PROVE_PTS_WORDS);
+  std::vector<uint32_t> tab(ProveLayout<SJ>::TAB_WORDS), pts(PROVE_PTS_WORDS);
   bool valid = prove_prepare_item<SJ>(h_enc, k, tab.data(), HJ().t, skw, msg, len, nullptr);
   if (pedersen) { pedersen_blinding<SJ>(b, skw, h_enc, ad, ad_len, g_hj_str); nonce_rfc8032<SJ>(kb, b, h_enc); }
   prove_mul_item<SJ>(pts.data(), HJ().t, tab.data(), skw, pedersen ? b : nullptr);

@@ -65,7 +65,7 @@ static int prove_any(bool pedersen, const uint8_t* sk, const uint8_t* msg, uint3
   uint32_t skw[8]; memcpy(skw, sk, 32);
   uint32_t hg[8]; if (h_given) memcpy(hg, h_given, 32);
   uint32_t k[8], kb[8];
-  std::vector<uint32_t> tab(PROVE_TAB_WORDS), pts(PROVE_PTS_WORDS);
+  std::vector<uint32_t> tab(ProveLayout<SuiteBS>::TAB_WORDS), pts(PROVE_PTS_WORDS);
   bool valid = prove_prepare_item<SuiteBS>(h_enc, k, tab.data(), HT().t, skw, msg, len, h_given ? hg : nullptr, 0, g_check_mask_p);
   if (pedersen) { pedersen_blinding<SuiteBS>(b, skw, h_enc, ad, ad_len, g_hs_str); nonce_rfc8032<SuiteBS>(kb, b, h_enc); }
   prove_mul_item<SuiteBS>(pts.data(), HT().t, tab.data(), skw, pedersen ? b : nullptr);
@@ -111,7 +111,7 @@ uint32_t hs_pedersen_verify(const uint8_t* h, const uint8_t* g, const uint8_t* p
 // batch prove through the K-per-lane prepare, exactly as the kernels run it; out: n x (gamma | c | s | pk | h)
 void hs_ietf_prove_multi(uint32_t n, const uint8_t* sk, const uint8_t* msgs, uint32_t msg_len, const uint8_t* ad,
                          uint32_t ad_len, uint8_t* out) {
-  std::vector<uint32_t> tabs((size_t)n * PROVE_TAB_WORDS), pts((size_t)n * PROVE_PTS_WORDS), aux((size_t)n * 32);
+  std::vector<uint32_t> tabs((size_t)n * ProveLayout<SuiteBS>::TAB_WORDS), pts((size_t)n * PROVE_PTS_WORDS), aux((size_t)n * 32);
   std::vector<uint8_t> flags(n);
   BytesViewLite mv; mv.blob = msgs; mv.off = nullptr; mv.len = msg_len; mv.stride = msg_len;
   for (size_t first = 0; first < n; first += PROVE_K)
@@ -119,15 +119,15 @@ void hs_ietf_prove_multi(uint32_t n, const uint8_t* sk, const uint8_t* msgs, uin
   for (size_t i = 0; i < n; ++i) {
     uint32_t skw[8], k[8];
     memcpy(skw, sk + 32 * i, 32); memcpy(k, aux.data() + 32 * i + 8, 32);
-    prove_mul_item<SuiteBS>(pts.data() + i * PROVE_PTS_WORDS, HT().t, tabs.data() + i * PROVE_TAB_WORDS, skw, nullptr);
-    prove_mul_item<SuiteBS>(pts.data() + i * PROVE_PTS_WORDS + 2 * UV_WORDS, HT().t, tabs.data() + i * PROVE_TAB_WORDS, k, nullptr);
+    prove_mul_item<SuiteBS>(pts.data() + i * PROVE_PTS_WORDS, HT().t, tabs.data() + i * ProveLayout<SuiteBS>::TAB_WORDS, skw, nullptr);
+    prove_mul_item<SuiteBS>(pts.data() + i * PROVE_PTS_WORDS + 2 * UV_WORDS, HT().t, tabs.data() + i * ProveLayout<SuiteBS>::TAB_WORDS, k, nullptr);
   }
   for (size_t first = 0; first < n; first += PROVE_K)
-    prove_encode_multi<SuiteBS>(PROVE_K, first, n, pts.data(), tabs.data(), PROVE_TAB_WORDS);
+    prove_encode_multi<SuiteBS>(PROVE_K, first, n, pts.data(), tabs.data(), ProveLayout<SuiteBS>::TAB_WORDS);
   for (size_t i = 0; i < n; ++i) {
     uint32_t skw[8], h_enc[8], k[8], c[8], s2[8];
     memcpy(skw, sk + 32 * i, 32); memcpy(h_enc, aux.data() + 32 * i, 32); memcpy(k, aux.data() + 32 * i + 8, 32);
-    const uint32_t* enc = tabs.data() + i * PROVE_TAB_WORDS + PROVE_ENC_OFF;
+    const uint32_t* enc = tabs.data() + i * ProveLayout<SuiteBS>::TAB_WORDS + PROVE_ENC_OFF;
     prove_respond_item<SuiteBS>(c, s2, enc, h_enc, skw, k, ad, ad_len, g_hs_str);
     memcpy(out + 160 * i, enc, 32); memcpy(out + 160 * i + 32, c, 32); memcpy(out + 160 * i + 64, s2, 32);
     memcpy(out + 160 * i + 96, enc + 8, 32); memcpy(out + 160 * i + 128, h_enc, 32);
