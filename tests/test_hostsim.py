@@ -18,8 +18,7 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
 @pytest.fixture(scope="module")
 def hs():
     so = os.path.join(HERE, "libhostsim.so")
-    if not os.path.exists(so):
-        subprocess.run(["make", "-C", HERE, "-j4", "libhostsim.so"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", HERE, "-j4", "libhostsim.so"], check=True, stdout=subprocess.DEVNULL)
     lib = ctypes.CDLL(so)
     lib.hs_init()
     return lib

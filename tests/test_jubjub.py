@@ -57,8 +57,7 @@ def test_oracles_agree_on_jubjub(J, c_jj):
 @pytest.fixture(scope="module")
 def hj():
     so = os.path.join(HERE, "libhostsim_jj.so")
-    if not os.path.exists(so):
-        subprocess.run(["make", "-C", HERE, "libhostsim_jj.so"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", HERE, "libhostsim_jj.so"], check=True, stdout=subprocess.DEVNULL)
     lib = ctypes.CDLL(so)
     lib.hj_init()
     return lib
