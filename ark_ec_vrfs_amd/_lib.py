@@ -38,7 +38,7 @@ SYMBOLS = [
     "vrfhip_fq_mul_batch", "vrfhip_test_pairing_quad_ops", "vrfhip_debug_proofs_per_lane",
     "vrfhip_ietf_verify_batch_multi", "vrfhip_ietf_prove_batch_multi",
     "vrfhip_pedersen_prove_batch_multi", "vrfhip_pedersen_verify_batch_multi",
-    "vrfhip_test_point_add", "vrfhip_test_scalar_mul", "vrfhip_test_sha512", "vrfhip_test_xmd",
+    "vrfhip_test_point_add", "vrfhip_test_scalar_mul", "vrfhip_test_sha512", "vrfhip_test_xmd", "vrfhip_test_batch_digest",
 ]
 
 
@@ -151,6 +151,7 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_test_scalar_mul.argtypes = [c_void_p, c_size_t, P, P, P, P]
     lib.vrfhip_test_sha512.argtypes = [c_void_p, c_size_t, P, P, c_uint32, P]
     lib.vrfhip_test_xmd.argtypes = [c_void_p, c_size_t, P, P, c_uint32, P]
+    lib.vrfhip_test_batch_digest.argtypes = [c_void_p, c_size_t, c_int32, P, P, P, P, c_uint32, ctypes.c_uint64, P]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("vrfhip_last_error", "vrfhip_ctx_destroy", "vrfhip_ctx_workspace_bytes",

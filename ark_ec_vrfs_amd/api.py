@@ -550,6 +550,26 @@ class Context:
     def test_xmd(self, msgs):
         return self._test_hash(self._lib.vrfhip_test_xmd, "vrfhip_test_xmd", msgs, 96)
 
+    def test_batch_digest(self, arrays, ad=None, index0: int = 0) -> bytes:
+        """The digest the batched (random-linear-combination) verifiers hash into their weights: arrays = list of
+        (n, w_j) uint8 arrays; ad = None, bytes (shared) or a list of n byte strings."""
+        import ctypes
+        arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in arrays]
+        n = arrs[0].shape[0]
+        ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        widths = np.array([a.size // n for a in arrs], np.uint32)
+        blob, off, ad_len = None, None, 0
+        if isinstance(ad, (bytes, bytearray)):
+            blob, ad_len = np.frombuffer(bytes(ad) + b"\0", np.uint8), len(ad)
+        elif ad is not None:
+            blob, off = _pack_var([bytes(a) for a in ad])
+        root = np.empty(32, np.uint8)
+        _lib.check(self._lib.vrfhip_test_batch_digest(self._h, n, len(arrs), ctypes.cast(ptrs, ctypes.c_void_p), _ptr(widths),
+                                                      _ptr(blob) if blob is not None else None,
+                                                      _ptr(off) if off is not None else None, ad_len, index0, _ptr(root)),
+                   "vrfhip_test_batch_digest")
+        return root.tobytes()
+
     # ---- device-pointer batch API (torch CUDA uint8 tensors, current stream) -----------
     def ietf_verify_batch_dev(self, pk, inp, out, c, s, status, ad=None, ad_off=None, ad_len=0, stream=None):
         import torch

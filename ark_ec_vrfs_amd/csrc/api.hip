@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "digest.cuh"
 #include "msm.cuh"
 #include "msm_g1.h"
 
@@ -915,11 +916,15 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
   if (n == 0) return VRFHIP_SUCCESS;
   int32_t rc = ensure_workspace(ctx, n);
   if (rc) return rc;
+  size_t msm_bytes;
   {
     size_t m = std::min(ctx->ws_cap, n), N = 5 * m + 2;
-    rc = ensure_msm_workspace(ctx, msm_workspace_bytes(N, msm_groups(N, 3 * m + 2, ctx->cus)));
+    msm_bytes = Stage::pad(msm_workspace_bytes(N, msm_groups(N, 3 * m + 2, ctx->cus)));
+    rc = ensure_msm_workspace(ctx, msm_bytes + Stage::pad(digest_ws_bytes(m)) + 256);   // MSM | digest tree | root
     if (rc) return rc;
   }
+  uint8_t* d_digest_ws = static_cast<uint8_t*>(ctx->d_msm_ws) + msm_bytes;
+  uint8_t* d_root = d_digest_ws + Stage::pad(digest_ws_bytes(std::min(ctx->ws_cap, n)));
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     size_t m = std::min(ctx->ws_cap, n - base), N = 5 * m + 2;
     RlcArgs a;
@@ -940,6 +945,14 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
     a.fixed_cols = reinterpret_cast<uint64_t*>(a.L.flags + 128);
     a.T = ctx->T;
     std::memcpy(a.seed, seed, 32);
+    // the weights of this launch group depend on every input byte of the group (digest.cuh)
+    DigestSrc ds{};
+    const uint8_t* arr[7] = {a.h, a.gamma, a.pk_com, a.r, a.ok, a.s, a.sb};
+    for (int j = 0; j < 7; ++j) { ds.p[j] = arr[j]; ds.w[j] = j < 5 ? (uint32_t)pw : 32u; }
+    ds.n_arr = 7;
+    ds.ad = a.ad;
+    launch_batch_digest(ds, m, base, d_digest_ws, d_root, st);
+    a.root = d_root;
     launch_pedersen_rlc(a, d_fail_flag, st, prof_events(ctx));
   }
   HIP_TRY(hipGetLastError());
@@ -1204,12 +1217,18 @@ int32_t vrfhip_pairing_check_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint
   HIP_TRY(hipMemsetAsync(d_verdict, 0, 1, st));
   if (n == 0) return VRFHIP_SUCCESS;
   const int groups = g1_msm_groups(n, 2, G1_W_SHORT, ctx->cus);
-  int32_t rc = ensure_msm_workspace(ctx, g1_msm_workspace_bytes(n, 2, G1_W_SHORT, groups));
+  const size_t msm_bytes = Stage::pad(g1_msm_workspace_bytes(n, 2, G1_W_SHORT, groups));
+  int32_t rc = ensure_msm_workspace(ctx, msm_bytes + Stage::pad(digest_ws_bytes(n)) + 256);   // MSM | digest tree | root
   if (rc) return rc;
   G1MsmLayout L = g1_msm_layout(n, 2, G1_W_SHORT, groups, ctx->d_msm_ws);
+  uint8_t* d_digest_ws = static_cast<uint8_t*>(ctx->d_msm_ws) + msm_bytes;
+  uint8_t* d_root = d_digest_ws + Stage::pad(digest_ws_bytes(n));
   hipEvent_t* ev = prof_events(ctx);            // start | prep | buckets | final | pairing
   if (ev) (void)hipEventRecord(ev[0], st);
-  launch_g1_rlc(L, d_g1, seed, 0, d_status, st, ev ? ev + 1 : nullptr);
+  DigestSrc ds{};
+  ds.p[0] = d_g1; ds.w[0] = 192; ds.n_arr = 1;
+  launch_batch_digest(ds, n, 0, d_digest_ws, d_root, st);   // the weights depend on every item of the batch
+  launch_g1_rlc(L, d_g1, seed, d_root, 0, d_status, st, ev ? ev + 1 : nullptr);
   // one pairing check for the whole batch: (sum z A, sum z B) against the shared pair (prepared lines)
   launch_pairing_check2(1, L.sums, d_g2_shared, 0, d_verdict, st, ctx->d_pair_prep);
   if (ev) (void)hipEventRecord(ev[4], st);
@@ -1589,6 +1608,46 @@ int32_t vrfhip_test_sha512(vrfhip_ctx* ctx, size_t n, const uint8_t* msg, const 
 int32_t vrfhip_test_xmd(vrfhip_ctx* ctx, size_t n, const uint8_t* msg, const uint32_t* msg_off, uint32_t msg_len,
                         uint8_t* out) {
   return test_hash_impl(ctx, n, msg, msg_off, msg_len, out, 1);
+}
+
+int32_t vrfhip_test_batch_digest(vrfhip_ctx* ctx, size_t n, int32_t n_arr, const uint8_t* const* arrays,
+                                 const uint32_t* widths, const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                 uint64_t index0, uint8_t root[32]) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (!root || !arrays || !widths || n == 0) return fail(VRFHIP_ERR_BAD_ARG, "NULL argument or empty batch");
+  if (n_arr < 1 || n_arr > DIGEST_MAX_ARRAYS) return fail(VRFHIP_ERR_BAD_ARG, "1..8 arrays");
+  if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  size_t need = Stage::pad(digest_ws_bytes(n)) + 512, adb = blob_bytes(n, ad_off, ad_len, true);
+  for (int32_t j = 0; j < n_arr; ++j) {
+    if (!arrays[j] || widths[j] == 0 || widths[j] % 4) return fail(VRFHIP_ERR_BAD_ARG, "array NULL or width not a multiple of 4");
+    need += Stage::pad(n * (size_t)widths[j]);
+  }
+  need += Stage::pad(adb + 1) + Stage::pad((n + 1) * 4);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_stage(ctx, need);
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  DigestSrc ds{};
+  ds.n_arr = n_arr;
+  for (int32_t j = 0; j < n_arr; ++j) {
+    uint8_t* d = sg.take(n * (size_t)widths[j]);
+    HIP_TRY(hipMemcpyAsync(d, arrays[j], n * (size_t)widths[j], hipMemcpyHostToDevice, ctx->stream));
+    ds.p[j] = d;
+    ds.w[j] = widths[j];
+  }
+  uint8_t* d_ad = sg.take(adb + 1);
+  uint32_t* d_off = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+  if (adb) HIP_TRY(hipMemcpyAsync(d_ad, ad, adb, hipMemcpyHostToDevice, ctx->stream));
+  if (ad_off) HIP_TRY(hipMemcpyAsync(d_off, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (ad) ds.ad = make_view(d_ad, ad_off ? d_off : nullptr, ad_len, true);
+  uint8_t* d_ws = sg.take(digest_ws_bytes(n));
+  uint8_t* d_root = sg.take(32);
+  launch_batch_digest(ds, n, index0, d_ws, d_root, ctx->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(root, d_root, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
 }
 
 int32_t vrfhip_ietf_verify_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx, size_t n, const uint8_t* pk,

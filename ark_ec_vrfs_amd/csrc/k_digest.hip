@@ -1,0 +1,45 @@
+// k_digest.hip -- batch digest kernels (digest.cuh): one leaf hash per item, then levels of 128-ary nodes.
+#include "digest.cuh"
+#include "kernels.h"
+
+namespace vrf {
+
+__global__ void __launch_bounds__(BLOCK) k_digest_leaves(DigestSrc src, size_t n, uint64_t index0, uint8_t* leaves) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  digest_leaf(leaves + i * 32, src, i, index0 + i);
+}
+
+__global__ void __launch_bounds__(64) k_digest_nodes(const uint8_t* children, size_t n_children, uint8_t* nodes) {
+  size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+  size_t first = t * DIGEST_FAN;
+  if (first >= n_children) return;
+  size_t count = n_children - first < (size_t)DIGEST_FAN ? n_children - first : (size_t)DIGEST_FAN;
+  digest_node(nodes + t * 32, children + first * 32, (uint32_t)count);
+}
+
+static size_t level_nodes(size_t n) { return (n + DIGEST_FAN - 1) / DIGEST_FAN; }
+
+size_t digest_ws_bytes(size_t n) {
+  size_t total = n, m = n;
+  do { m = level_nodes(m); total += m; } while (m > 1);
+  return total * 32 + 64;
+}
+
+void launch_batch_digest(const DigestSrc& src, size_t n, uint64_t index0, uint8_t* ws, uint8_t* root, hipStream_t st) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_digest_leaves, grid_for(n), dim3(BLOCK), 0, st, src, n, index0, ws);
+  const uint8_t* level = ws;
+  uint8_t* next = ws + n * 32;
+  size_t m = n;
+  do {
+    const size_t nodes = level_nodes(m);
+    uint8_t* out = nodes == 1 ? root : next;
+    hipLaunchKernelGGL(k_digest_nodes, dim3((unsigned)((nodes + 63) / 64)), dim3(64), 0, st, level, m, out);
+    level = next;
+    next += nodes * 32;
+    m = nodes;
+  } while (m > 1);
+}
+
+}  // namespace vrf

@@ -54,8 +54,8 @@ VRF_HD void g1_store_affine(uint32_t* dst, const G1Aff& P) {
 
 // ------------------------------------------------------------------------------- prep
 struct Seed32 { uint8_t b[32]; };
-__global__ void __launch_bounds__(128) k_g1_prep_rlc(G1MsmLayout L, const uint8_t* g1, Seed32 seed, uint64_t index0,
-                                                     uint8_t* status) {
+__global__ void __launch_bounds__(128) k_g1_prep_rlc(G1MsmLayout L, const uint8_t* g1, Seed32 seed,
+                                                     const uint8_t* root, uint64_t index0, uint8_t* status) {
   const size_t i = (size_t)blockIdx.x * 128 + threadIdx.x;
   if (i >= L.n) return;
   const uint32_t* w = reinterpret_cast<const uint32_t*>(g1 + i * 192);
@@ -71,13 +71,14 @@ __global__ void __launch_bounds__(128) k_g1_prep_rlc(G1MsmLayout L, const uint8_
     ok = g1_load(Q, qi, words) && ok;
     if (s == 0) { P[0] = Q; inf[0] = qi; } else { P[1] = Q; inf[1] = qi; }
   }
-  // z_i: 128 bits of SHA-512("vrfhip-pairing-rlc-v1" || seed || u64_le(index))
+  // z_i: 128 bits of SHA-512("vrfhip-pairing-rlc-v2" || seed || batch digest || u64_le(index))
   Sha512 h;
   sha512_init(h);
-  constexpr char tag[] = "vrfhip-pairing-rlc-v1";
+  constexpr char tag[] = "vrfhip-pairing-rlc-v2";
 #pragma unroll
   for (int j = 0; j < 21; ++j) sha512_put_byte(h, (uint8_t)tag[j]);
   sha512_put_bytes(h, seed.b, 32);
+  sha512_put_bytes(h, root, 32);
   const uint64_t idx = index0 + i;
 #pragma unroll
   for (int j = 0; j < 8; ++j) sha512_put_byte(h, (uint8_t)(idx >> (8 * j)));
@@ -331,13 +332,14 @@ static void launch_core(const G1MsmLayout& L, hipStream_t st, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[2], st);
 }
 
-void launch_g1_rlc(const G1MsmLayout& L, const uint8_t* g1, const uint8_t seed[32], uint64_t index0, uint8_t* status,
+void launch_g1_rlc(const G1MsmLayout& L, const uint8_t* g1, const uint8_t seed[32], const uint8_t* d_root, uint64_t index0,
+                   uint8_t* status,
                    hipStream_t st, hipEvent_t* ev) {
   if (L.n == 0) return;
   (void)hipMemsetAsync(L.flags, 0, 256, st);
   Seed32 sd;
   for (int i = 0; i < 32; ++i) sd.b[i] = seed[i];
-  hipLaunchKernelGGL(k_g1_prep_rlc, dim3((unsigned)((L.n + 127) / 128)), dim3(128), 0, st, L, g1, sd, index0, status);
+  hipLaunchKernelGGL(k_g1_prep_rlc, dim3((unsigned)((L.n + 127) / 128)), dim3(128), 0, st, L, g1, sd, d_root, index0, status);
   if (ev) (void)hipEventRecord(ev[0], st);
   launch_core(L, st, ev);
 }

@@ -19,7 +19,8 @@
 //   k_rlc_fixed  : normalises the columns mod r and appends G and B with their digits.
 //   then k_msm_buckets / k_msm_final (k_msm.hip) and the verdict byte.
 // Weights: (z_i, z'_i) = the first two 16-byte little-endian halves of
-// SHA-512("vrfhip-rlc-v1" || seed[32] || u64_le(index of the proof in the caller's batch)) with the low
+// SHA-512("vrfhip-rlc-v2" || seed[32] || digest of the launch group (digest.cuh) || u64_le(index of the proof in the
+// caller's batch)) with the low
 // three bits forced to 001; the seed must be unpredictable to whoever produced the proofs.
 #include "kernels.h"
 #include "msm.cuh"
@@ -44,7 +45,7 @@ VRF_HD void rlc_emit_item(const RlcArgs& a, size_t item, bool pts_valid, const u
   bytes_get(a.ad, item, adp, adl);
   uint32_t c[8], z[8], zp[8], t[8];
   challenge5<S>(c, cp, adp, adl, a.T.sq.str);
-  rlc_weights<S>(z, zp, a.seed, a.index0 + item);
+  rlc_weights<S>(z, zp, a.seed, a.root, a.index0 + item);
   fr_mul<S>(t, z, s);
   msm_write_digits<S>(a.L.digits, N, rlc_index(0, n, item), t, false, !valid);     // + (z s) H
   fr_mul<S>(t, z, c);

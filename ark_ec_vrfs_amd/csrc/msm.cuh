@@ -91,13 +91,14 @@ VRF_HD void msm_write_digits(int16_t* digits, size_t n, size_t i, const uint32_t
 VRF_HD size_t rlc_index(int p, size_t n, size_t i) { return (size_t)p * n + i + (p >= 3 ? 2 : 0); }
 
 template <class S>
-VRF_HD void rlc_weights(uint32_t z[8], uint32_t zp[8], const uint8_t* seed, uint64_t index) {
+VRF_HD void rlc_weights(uint32_t z[8], uint32_t zp[8], const uint8_t* seed, const uint8_t* root, uint64_t index) {
   Sha512 h;
   sha512_init(h);
-  constexpr char tag[] = "vrfhip-rlc-v1";
+  constexpr char tag[] = "vrfhip-rlc-v2";
 #pragma unroll
   for (int i = 0; i < 13; ++i) sha512_put_byte(h, (uint8_t)tag[i]);
   sha512_put_bytes(h, seed, 32);
+  sha512_put_bytes(h, root, 32);      // digest of the launch group's inputs (digest.cuh)
 #pragma unroll
   for (int i = 0; i < 8; ++i) sha512_put_byte(h, (uint8_t)(index >> (8 * i)));
   sha512_final(h);
@@ -139,6 +140,7 @@ struct RlcArgs {
   uint64_t* fixed_cols;       // [2][8] limb columns of sum z'_i s_i and sum z'_i sb_i
   DevTables T;
   uint8_t seed[32];
+  const uint8_t* root;        // [32] device memory: batch digest of this launch group (digest.cuh)
 };
 // enqueues decode + MSM; fail_flag[0] becomes 1 if the batch equation does not hold.
 // ev (nullable, 5 events): start | decode | buckets | final | final.

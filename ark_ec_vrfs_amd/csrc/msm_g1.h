@@ -35,10 +35,12 @@ size_t g1_msm_workspace_bytes(size_t n, int sets, int windows, int groups);
 G1MsmLayout g1_msm_layout(size_t n, int sets, int windows, int groups, void* ws);
 
 // Batched pairing check, G1 side: validates the 2n points (g1: n x 192 B), derives the 128-bit weights
-// z_i = SHA-512("vrfhip-pairing-rlc-v1" || seed || u64_le(index0 + i))[0..16], writes status[i] in {0, 2} and leaves
+// z_i = SHA-512("vrfhip-pairing-rlc-v2" || seed || d_root[32] || u64_le(index0 + i))[0..16] (d_root: the batch digest of
+// digest.cuh over the g1 items, device memory), writes status[i] in {0, 2} and leaves
 // (sum z_i A_i, sum z_i B_i) in L.sums -- exactly one g1 item for the pairing kernel.  L: sets = 2, windows = 13.
 // ev (nullable, 3 events): after prep, after buckets, after final.
-void launch_g1_rlc(const G1MsmLayout& L, const uint8_t* g1, const uint8_t seed[32], uint64_t index0, uint8_t* status,
+void launch_g1_rlc(const G1MsmLayout& L, const uint8_t* g1, const uint8_t seed[32], const uint8_t* d_root, uint64_t index0,
+                   uint8_t* status,
                    hipStream_t st, hipEvent_t* ev = nullptr);
 // `VariableBaseMSM::msm` on G1: bases n x 96 B, scalars n x 32 B little-endian (< r); result in L.sums[0..96],
 // status1[0] = 0 / 2 (a coordinate >= p, a point off the curve or a scalar >= r).  L: sets = 1, windows = 26.

@@ -256,10 +256,12 @@ int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_
 /* `pedersen::Verifier::verify` for a whole batch with ONE multi-scalar multiplication (random linear
  * combination).  With c_i recomputed from the proof's own points, the batch is
  * accepted iff  sum_i z_i (s_i H_i - c_i Gamma_i - Ok_i) + z'_i (s_i G + sb_i B - c_i pk_com_i - R_i)
- * is the neutral element, (z_i, z'_i) = 2 x 128 bits of SHA-512("vrfhip-rlc-v1" || seed || u64_le(i)), each forced to 1 (mod 8).
- * `seed` (32 bytes, host memory) must be unpredictable to the provers (fresh randomness per call);
- * a batch holding an invalid proof is then accepted with probability <= 2^-125 (the weights are 128-bit values with
- * their low three bits fixed).
+ * is the neutral element, (z_i, z'_i) = 2 x 128 bits of SHA-512("vrfhip-rlc-v2" || seed || D || u64_le(i)), each forced to
+ * 1 (mod 8).  D is a digest of every input byte of the launch group (points, scalars, ad: vrfhip_test_batch_digest states
+ * it), so the weights are fixed only once the batch is.  `seed` (32 bytes, host memory) should be fresh randomness per
+ * call: a batch holding an invalid proof is then accepted with probability <= 2^-125 (the weights are 128-bit values with
+ * their low three bits fixed).  A prover who knows or predicts the seed can no longer choose proofs after the weights: it
+ * has to search for batch contents whose own weights cancel its defect, 2^-125 per trial.
  * The bound needs all five points of every proof in the prime-order subgroup, which the decode stage checks
  * (InvalidData otherwise) unless the caller vouched for them with vrfhip_ctx_set_flags.  With PREVALIDATED
  * flags set on unvalidated bytes the bound is void: a defect of small order (a proof point shifted by a 2- or
@@ -338,7 +340,8 @@ int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
                                        void* stream);
 
 /* The same n checks against ONE shared G2 pair (g2_shared: 384 B, a KZG verifier's SRS) as a batch: with secret
- * 128-bit weights z_i = SHA-512("vrfhip-pairing-rlc-v1" || seed || u64_le(i))[0..16],
+ * 128-bit weights z_i = SHA-512("vrfhip-pairing-rlc-v2" || seed || D || u64_le(i))[0..16] (D: the batch digest of the g1
+ * items, vrfhip_test_batch_digest),
  *     prod_i (e(A_i,Q0) e(B_i,Q1))^{z_i} = e(sum z_i A_i, Q0) e(sum z_i B_i, Q1):
  * two G1 multi-scalar multiplications (Pippenger, buckets in LDS) and ONE pairing check for the whole batch -- the
  * aggregation step in front of the pairing tail of `ring::Verifier::verify` (src/lib.rs:14).  g1: n x 192 B as above.
@@ -442,6 +445,17 @@ int32_t vrfhip_test_sha512(vrfhip_ctx* ctx, size_t n, const uint8_t* msg, const 
                            uint8_t* out);
 int32_t vrfhip_test_xmd(vrfhip_ctx* ctx, size_t n, const uint8_t* msg, const uint32_t* msg_off, uint32_t msg_len,
                         uint8_t* out);
+
+/* Test-only: the batch digest that the random-linear-combination entry points hash into their weights, on its own.
+ *   leaf_i = SHA-512("vrfhip-leaf-v1" || u64_le(index0 + i) || arrays[0][i] || ... || arrays[n_arr-1][i] || ad_i || u32_le(|ad_i|))[0..32]
+ *   node   = SHA-512("vrfhip-node-v1" || u32_le(count) || child_0 || ... )[0..32] over runs of 16 consecutive children
+ *   root   = the single node of the last level (n <= 16: one level of nodes).
+ * arrays[j]: n x widths[j] bytes (host, widths a multiple of 4, 1 <= n_arr <= 8); ad as in the verify calls (NULL: empty).
+ * vrfhip_pedersen_verify_batch_rlc* digest (input, output, pk_com, r, ok, s, sb, ad) of every launch group with index0 = the
+ * group's first proof; vrfhip_pairing_check_batch_rlc* digest the g1 items.  n >= 1. */
+int32_t vrfhip_test_batch_digest(vrfhip_ctx* ctx, size_t n, int32_t n_arr, const uint8_t* const* arrays,
+                                 const uint32_t* widths, const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                 uint64_t index0, uint8_t root[32]);
 
 /* Test-only: how many proofs one lane of the inversion-sharing stages (decode, finish, prepare) handles for a
  * launch group of n items (1, 2, 4 or 8): lets the parity tests assert that every kernel variant was exercised. */

@@ -725,17 +725,63 @@ void oracle_pedersen_prove_batch(size_t n, const uint8_t* sk, const uint8_t* msg
   j.o0 = gamma; j.o1 = proof160; j.o2 = blinding_out; j.o4 = h_out; j.st = status;
   run_batch(j, n, threads);
 }
+/* Batch digest hashed into the weights of the random-linear-combination checks (ark_ec_vrfs_amd/csrc/digest.cuh states the
+ * definition): leaf_i = SHA-512("vrfhip-leaf-v1" || u64_le(index0 + i) || a_0[i] || ... || ad_i || u32_le(|ad_i|))[0..32];
+ * node = SHA-512("vrfhip-node-v1" || u32_le(count) || children)[0..32] over runs of 16; root = the last level's one node.
+ * arrs[j] + i * strides[j] is item i of array j (widths[j] bytes).  ad_off != NULL: per-item strings ad[ad_off[i]..ad_off[i+1]);
+ * else every item carries ad[0..ad_len).  n >= 1. */
+void oracle_batch_digest(size_t n, uint64_t index0, int n_arr, const uint8_t* const* arrs, const uint32_t* widths,
+                         const uint32_t* strides, const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                         uint8_t root[32]) {
+  uint8_t* level = (uint8_t*)malloc(n * 32);
+  for (size_t i = 0; i < n; ++i) {
+    sha512_ctx hc; uint8_t dg[64], idx[8], al[4];
+    uint64_t gi = index0 + i;
+    for (int k = 0; k < 8; ++k) idx[k] = (uint8_t)(gi >> (8 * k));
+    sha512_init(&hc); sha512_update(&hc, "vrfhip-leaf-v1", 14); sha512_update(&hc, idx, 8);
+    for (int j = 0; j < n_arr; ++j) sha512_update(&hc, arrs[j] + i * (size_t)strides[j], widths[j]);
+    const uint8_t* a = ad; uint32_t len = ad_len;
+    if (ad_off) { a = ad + ad_off[i]; len = ad_off[i + 1] - ad_off[i]; }
+    if (len) sha512_update(&hc, a, len);
+    for (int k = 0; k < 4; ++k) al[k] = (uint8_t)(len >> (8 * k));
+    sha512_update(&hc, al, 4); sha512_final(&hc, dg);
+    memcpy(level + 32 * i, dg, 32);
+  }
+  size_t m = n;
+  do {
+    size_t nodes = (m + 15) / 16;
+    for (size_t t = 0; t < nodes; ++t) {
+      uint32_t cnt = (uint32_t)(m - t * 16 < 16 ? m - t * 16 : 16);
+      sha512_ctx hc; uint8_t dg[64], cb[4];
+      for (int k = 0; k < 4; ++k) cb[k] = (uint8_t)(cnt >> (8 * k));
+      sha512_init(&hc); sha512_update(&hc, "vrfhip-node-v1", 14); sha512_update(&hc, cb, 4);
+      sha512_update(&hc, level + 32 * 16 * t, 32 * (size_t)cnt); sha512_final(&hc, dg);
+      memcpy(level + 32 * t, dg, 32);      /* node t overwrites children it has already consumed (t <= 16 t) */
+    }
+    m = nodes;
+  } while (m > 1);
+  memcpy(root, level, 32);
+  free(level);
+}
 /* Batched Pedersen verification by random linear combination, the slow way:
  * for every proof the two defects D1 = s*H - c*Gamma - Ok and D2 = s*G + sb*B - c*pk_com - R are
  * computed by double-and-add, weighted by (z_i, z'_i) = the two little-endian 16-byte halves of
- * SHA-512("vrfhip-rlc-v1" || seed || u64_le(index0 + i)), low three bits forced to 001, and summed.  status[i] = 0 (in the sum) or 2
- * (undecodable: left out).  Returns 0 if the sum is the neutral element, else 1. */
+ * SHA-512("vrfhip-rlc-v2" || seed || batch digest || u64_le(index0 + i)), low three bits forced to 001, and summed; the digest
+ * (oracle_batch_digest) covers H, Gamma, pk_com, R, Ok, s, sb and ad of the n proofs as ONE launch group.  status[i] = 0 (in
+ * the sum) or 2 (undecodable: left out).  Returns 0 if the sum is the neutral element, else 1. */
 int oracle_pedersen_rlc_check(size_t n, const uint8_t* h, const uint8_t* gamma, const uint8_t* proof160,
                               const uint8_t* ad, size_t ad_len, const uint8_t seed[32], uint64_t index0,
                               uint8_t* status) {
   ensure_init();
   pt acc; pt_identity(&acc);
   pt G, B; pt_from_affine(&G, &BS_GX_M, &BS_GY_M); pt_from_affine(&B, &BS_BX_M, &BS_BY_M);
+  uint8_t root[32];
+  memset(root, 0, 32);
+  if (n) {
+    const uint8_t* arrs[7] = {h, gamma, proof160, proof160 + 32, proof160 + 64, proof160 + 96, proof160 + 128};
+    const uint32_t widths[7] = {32, 32, 32, 32, 32, 32, 32}, strides[7] = {32, 32, 160, 160, 160, 160, 160};
+    oracle_batch_digest(n, index0, 7, arrs, widths, strides, ad, NULL, (uint32_t)ad_len, root);
+  }
   for (size_t i = 0; i < n; ++i) {
     const uint8_t* pr = proof160 + 160 * i;
     uint64_t s[4], sb[4], c[4];
@@ -761,8 +807,8 @@ int oracle_pedersen_rlc_check(size_t n, const uint8_t* h, const uint8_t* gamma, 
     sha512_ctx hc; uint8_t dg[64], idx[8];
     uint64_t gi = index0 + i;
     for (int k = 0; k < 8; ++k) idx[k] = (uint8_t)(gi >> (8 * k));
-    sha512_init(&hc); sha512_update(&hc, "vrfhip-rlc-v1", 13); sha512_update(&hc, seed, 32);
-    sha512_update(&hc, idx, 8); sha512_final(&hc, dg);
+    sha512_init(&hc); sha512_update(&hc, "vrfhip-rlc-v2", 13); sha512_update(&hc, seed, 32);
+    sha512_update(&hc, root, 32); sha512_update(&hc, idx, 8); sha512_final(&hc, dg);
     uint64_t z[4] = {0, 0, 0, 0}, zp[4] = {0, 0, 0, 0};
     for (int k = 0; k < 8; ++k) {
       z[0] |= (uint64_t)dg[k] << (8 * k); z[1] |= (uint64_t)dg[8 + k] << (8 * k);

@@ -159,6 +159,30 @@ def pedersen_rlc_check(h, gamma, pk_com, r, ok, s, sb, seed: bytes, ad: bytes = 
     return st, int(fail)
 
 
+def batch_digest(arrays, ad=None, index0: int = 0) -> bytes:
+    """Batch digest of the random-linear-combination verifiers (csrc/digest.cuh): arrays = list of (n, w_j) uint8
+    arrays; ad = None, bytes (shared by all items) or a list of n byte strings."""
+    arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in arrays]
+    n = arrs[0].shape[0]
+    ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    widths = np.array([a.size // n for a in arrs], np.uint32)
+    blob, off, ad_len = np.zeros(1, np.uint8), None, 0
+    if isinstance(ad, (bytes, bytearray)):
+        blob, ad_len = np.frombuffer(bytes(ad) + b"\0", np.uint8), len(ad)
+    elif ad is not None:
+        lens = [len(a) for a in ad]
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+        blob = np.frombuffer(b"".join(bytes(a) for a in ad) + b"\0", np.uint8)
+    root = np.empty(32, np.uint8)
+    lib = load()
+    P = c_void_p
+    lib.oracle_batch_digest.argtypes = [c_size_t, ctypes.c_uint64, ctypes.c_int, P, P, P, P, P, ctypes.c_uint32, P]
+    lib.oracle_batch_digest.restype = None
+    lib.oracle_batch_digest(n, index0, len(arrs), ctypes.cast(ptrs, ctypes.c_void_p), widths.ctypes.data, widths.ctypes.data,
+                            blob.ctypes.data, off.ctypes.data if off is not None else None, ad_len, root.ctypes.data)
+    return root.tobytes()
+
+
 def msm(bases_xy, scalars):
     """Naive sum_i k_i * P_i.  Returns (point32, xy64) or None on invalid input."""
     b = _a(bases_xy).reshape(-1, 64)

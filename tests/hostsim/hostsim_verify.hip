@@ -94,6 +94,7 @@ void hs_ietf_verify_multi(uint32_t n, const uint8_t* pk, const uint8_t* h, const
 
 // ---- MSM digit recoding and batched-verification weights (msm.cuh) ----
 #include "../../ark_ec_vrfs_amd/csrc/msm.cuh"
+#include "../../ark_ec_vrfs_amd/csrc/digest.cuh"
 extern "C" {
 void hs_msm_digits(int suite, const uint8_t* k, int negate, int zero, int16_t* out23) {
   uint32_t w[8]; memcpy(w, k, 32);
@@ -102,10 +103,32 @@ void hs_msm_digits(int suite, const uint8_t* k, int negate, int zero, int16_t* o
   else msm_write_digits<SuiteBS>(d, 1, 0, w, negate != 0, zero != 0);
   memcpy(out23, d, sizeof d);
 }
-void hs_rlc_weights(const uint8_t* seed, uint64_t index, uint8_t* z32, uint8_t* zp32) {
+void hs_rlc_weights(const uint8_t* seed, const uint8_t* root, uint64_t index, uint8_t* z32, uint8_t* zp32) {
   uint32_t z[8], zp[8];
-  rlc_weights<SuiteBS>(z, zp, seed, index);
+  rlc_weights<SuiteBS>(z, zp, seed, root, index);
   memcpy(z32, z, 32); memcpy(zp32, zp, 32);
+}
+// digest.cuh on the host: leaves then 128-ary node levels, exactly the kernels' loop (k_digest.hip)
+void hs_batch_digest(uint64_t n, uint64_t index0, int n_arr, const uint8_t* const* arrs, const uint32_t* widths,
+                     const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len, uint8_t* root) {
+  DigestSrc s{};
+  s.n_arr = n_arr;
+  for (int j = 0; j < n_arr; ++j) { s.p[j] = arrs[j]; s.w[j] = widths[j]; }
+  if (ad) { s.ad.blob = ad; s.ad.off = ad_off; s.ad.len = ad_len; s.ad.stride = 0; }
+  std::vector<uint8_t> level(n * 32), next;
+  for (uint64_t i = 0; i < n; ++i) digest_leaf(level.data() + 32 * i, s, i, index0 + i);
+  uint64_t m = n;
+  do {
+    uint64_t nodes = (m + DIGEST_FAN - 1) / DIGEST_FAN;
+    next.assign(nodes * 32, 0);
+    for (uint64_t t = 0; t < nodes; ++t) {
+      uint64_t cnt = m - t * DIGEST_FAN < (uint64_t)DIGEST_FAN ? m - t * DIGEST_FAN : (uint64_t)DIGEST_FAN;
+      digest_node(next.data() + 32 * t, level.data() + 32 * DIGEST_FAN * t, (uint32_t)cnt);
+    }
+    level.swap(next);
+    m = nodes;
+  } while (m > 1);
+  memcpy(root, level.data(), 32);
 }
 uint64_t hs_rlc_index(int p, uint64_t n, uint64_t i) { return rlc_index(p, n, i); }
 }

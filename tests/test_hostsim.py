@@ -262,7 +262,7 @@ def test_multi_proof_prepare_matches_oracle(hs):
 def test_msm_digit_recoding_and_rlc_weights(hs):
     """msm.cuh: signed radix-2^11 digits (folded at r/2) rebuild +-k mod r, stay in [-1024, 1024], leave the
     windows >= 12 empty for 128-bit scalars; the batched-verification weights are the two 16-byte halves of
-    SHA-512("vrfhip-rlc-v1" || seed || u64_le(i)) with the low three bits forced to 001; the MSM index map puts G and B after the three classes
+    SHA-512("vrfhip-rlc-v2" || seed || batch digest || u64_le(i)) with the low three bits forced to 001; the MSM index map puts G and B after the three classes
     with full-size scalars."""
     import hashlib
     rnd = random.Random(11)
@@ -283,17 +283,63 @@ def test_msm_digit_recoding_and_rlc_weights(hs):
         d = (ctypes.c_int16 * 23)()
         hs.hs_msm_digits(suite, _b(r - 5), 0, 1, d)
         assert not any(d)
-    seed = bytes(range(100, 132))
+    seed, root = bytes(range(100, 132)), bytes(range(7, 39))
     for idx in (0, 1, 255, 1 << 20, (1 << 63) + 12345):
         z, zp = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
-        hs.hs_rlc_weights(seed, ctypes.c_uint64(idx), z, zp)
-        dg = hashlib.sha512(b"vrfhip-rlc-v1" + seed + idx.to_bytes(8, "little")).digest()
+        hs.hs_rlc_weights(seed, root, ctypes.c_uint64(idx), z, zp)
+        dg = hashlib.sha512(b"vrfhip-rlc-v2" + seed + root + idx.to_bytes(8, "little")).digest()
         fix = lambda b: bytes([(b[0] & 0xf8) | 1]) + b[1:]
         assert z.raw == fix(dg[:16]) + bytes(16) and zp.raw == fix(dg[16:32]) + bytes(16)
     hs.hs_rlc_index.restype = ctypes.c_uint64
     n = 1000
     idx = sorted(hs.hs_rlc_index(p, ctypes.c_uint64(n), ctypes.c_uint64(i)) for p in range(5) for i in range(n))
     assert idx == list(range(3 * n)) + list(range(3 * n + 2, 5 * n + 2))          # 3n, 3n+1 are G and B
+
+
+def py_batch_digest(arrays, ads, index0=0):
+    """digest.cuh / vrfhip_test_batch_digest restated with hashlib (ads: one byte string per item)."""
+    import hashlib
+    n = len(arrays[0])
+    level = [hashlib.sha512(b"vrfhip-leaf-v1" + (index0 + i).to_bytes(8, "little") + b"".join(bytes(a[i]) for a in arrays)
+                            + ads[i] + len(ads[i]).to_bytes(4, "little")).digest()[:32] for i in range(n)]
+    while True:
+        level = [hashlib.sha512(b"vrfhip-node-v1" + len(level[t:t + 16]).to_bytes(4, "little")
+                                + b"".join(level[t:t + 16])).digest()[:32] for t in range(0, len(level), 16)]
+        if len(level) == 1:
+            return level[0]
+
+
+def test_batch_digest_header_and_oracle_equal_the_definition(hs):
+    """digest.cuh (host build) and oracle_batch_digest against the hashlib restatement: 1, 15, 16, 17, 257 and 16500 items
+    (one to four node levels), several arrays of different widths, shared / per-item / no ad."""
+    import numpy as np
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(5)
+    hs.hs_batch_digest.restype = None
+    for n, widths, mode in ((1, (32,), "none"), (15, (32, 64), "shared"), (16, (192,), "per"), (17, (32, 32, 32, 32, 32, 32, 32), "per"),
+                            (257, (36,), "per"), (16500, (32, 32), "shared")):
+        arrays = [rng.integers(0, 256, (n, w), dtype=np.uint8) for w in widths]
+        if mode == "per":
+            ads = [bytes(rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8)) for _ in range(n)]
+            ad_arg = ads
+        elif mode == "shared":
+            ads, ad_arg = [b"shared ad"] * n, b"shared ad"
+        else:
+            ads, ad_arg = [b""] * n, None
+        want = py_batch_digest(arrays, ads, index0=77)
+        assert co.batch_digest(arrays, ad_arg, index0=77) == want, (n, mode)
+        ptrs = (ctypes.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+        w = np.array(widths, np.uint32)
+        root = ctypes.create_string_buffer(32)
+        if mode == "per":
+            off = np.concatenate([[0], np.cumsum([len(a) for a in ads])]).astype(np.uint32)
+            blob = b"".join(ads) + b"\0"
+            hs.hs_batch_digest(ctypes.c_uint64(n), ctypes.c_uint64(77), len(arrays), ptrs, w.ctypes.data_as(ctypes.c_void_p), blob,
+                               off.ctypes.data_as(ctypes.c_void_p), 0, root)
+        else:
+            hs.hs_batch_digest(ctypes.c_uint64(n), ctypes.c_uint64(77), len(arrays), ptrs, w.ctypes.data_as(ctypes.c_void_p),
+                               ad_arg if ad_arg is not None else None, None, len(ads[0]), root)
+        assert root.raw == want, (n, mode)
 
 
 def test_subgroup_by_2descent_equals_r_times_p(hs):

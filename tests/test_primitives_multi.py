@@ -127,3 +127,35 @@ def test_multi_context_calls_equal_single_context(ctx):
     finally:
         for c in extra:
             c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_batch_digest_equals_the_oracle_and_the_definition(ctx):
+    """vrfhip_test_batch_digest (the digest hashed into the weights of the batched verifiers) against the C oracle and
+    the hashlib restatement: one to four node levels, seven arrays as the Pedersen entry point passes them,
+    shared / per-item / no ad, a non-zero first index."""
+    from oracle import c_oracle as co
+    from test_hostsim import py_batch_digest
+    rng = np.random.default_rng(9)
+    for n, widths, mode in ((1, (32,), "none"), (16, (192,), "none"), (17, (32,) * 7, "per"), (257, (36,), "per"),
+                            (4097, (64,) * 5 + (32, 32), "shared"), (40000, (32,) * 7, "per")):
+        arrays = [rng.integers(0, 256, (n, w), dtype=np.uint8) for w in widths]
+        if mode == "per":
+            ads = [bytes(rng.integers(0, 256, int(rng.integers(0, 24)), dtype=np.uint8)) for _ in range(n)]
+            ad_arg = ads
+        elif mode == "shared":
+            ads, ad_arg = [b"one ad for all"] * n, b"one ad for all"
+        else:
+            ads, ad_arg = [b""] * n, None
+        got = ctx.test_batch_digest(arrays, ad_arg, index0=5)
+        assert got == co.batch_digest(arrays, ad_arg, index0=5), (n, mode)
+        if n <= 4097:
+            assert got == py_batch_digest(arrays, ads, index0=5), (n, mode)
+    # every input byte matters
+    arrays = [rng.integers(0, 256, (300, 32), dtype=np.uint8) for _ in range(3)]
+    base = ctx.test_batch_digest(arrays, b"x")
+    for j, i in ((0, 0), (1, 150), (2, 299)):
+        mod = [a.copy() for a in arrays]
+        mod[j][i, 31] ^= 1
+        assert ctx.test_batch_digest(mod, b"x") != base
+    assert ctx.test_batch_digest(arrays, b"y") != base and ctx.test_batch_digest(arrays, b"x", index0=1) != base
