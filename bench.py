@@ -515,7 +515,8 @@ def headline_cpu_baseline(args, pk, hh, gamma, c, s, status):
     t0 = time.perf_counter()
     co.ietf_verify_batch(pkh[:m1], hhh[:m1], gh[:m1], ch[:m1], sh[:m1], b"", threads=1)
     out["single_core"] = m1 / (time.perf_counter() - t0)
-    out["note"] += "; the oracle's verify does not include the subgroup check of the three decoded points"
+    out["note"] += ("; like the GPU path it validates the three decoded points (r*P = O, arkworks' own subgroup test)"
+                    if not args.prevalidated else "; run with the oracle's default checked decode")
     return out
 
 
