@@ -113,6 +113,32 @@ class Dist:
             else:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
 
+    local_legs = False      # set while a secondary config runs at world > 1 (see timed)
+
+    def merge_leg_results(self, res):
+        """Every rank's {config: result} of one leg -> rank 0's view of the whole job: a config's rate is set by its
+        slowest rank (value = world x units / max elapsed = the minimum of the ranks' own figures); an error on any rank
+        is reported instead of a number.  One collective, reached by every rank whether its leg failed or not."""
+        if self.world == 1:
+            return res
+        slim = {k: ({"error": v["error"]} if "error" in v else {"value": v["value"], "ms_per_step": v["ms_per_step"]})
+                for k, v in res.items()}
+        allr = [None] * self.world
+        self.dist.all_gather_object(allr, slim)
+        out = dict(res)
+        for k in list(out):
+            errs = [r[k]["error"] for r in allr if k in r and "error" in r[k]] + ["missing on a rank" for r in allr if k not in r]
+            if errs:
+                out[k] = {"error": errs[0]}
+            elif "value" in out[k]:
+                out[k]["value"] = min(r[k]["value"] for r in allr)
+                out[k]["ms_per_step"] = max(r[k]["ms_per_step"] for r in allr)
+        for r in allr:
+            for k in r:
+                if k not in out:
+                    out[k] = {"error": r[k].get("error", "missing on rank 0")}
+        return out
+
     def barrier(self):
         self.torch.cuda.synchronize()
         if self.world > 1:
@@ -141,7 +167,19 @@ class Dist:
 
 
 def timed(D, fn, steps, warmup, gather_t=None, n_per_rank=0):
-    """warmup untimed calls, then exactly `steps` calls between barrier + synchronize; max over ranks."""
+    """warmup untimed calls, then exactly `steps` calls between barrier + synchronize; max over ranks.
+    Inside a secondary leg of a multi-rank run (D.local_legs) the bracket is this rank's own synchronize and nothing
+    is gathered: a leg that fails on one rank must not leave the others waiting at a barrier -- the ranks' results meet
+    once, after the leg (merge_leg_results)."""
+    if D.local_legs:
+        for _ in range(warmup):
+            fn()
+        D.torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        D.torch.cuda.synchronize()
+        return time.perf_counter() - t0, gather_t
     out = None
     for _ in range(warmup):
         fn()
@@ -581,14 +619,14 @@ def run_rank(args):
                 ("ietf_verify_keyed", lambda: {"ietf_verify_keyed": cfg_ietf_keyed(D, args, ctx, msg, lo)}),
                 ("pedersen_jubjub", lambda: cfg_pedersen_jubjub(D, args, msg, lo, want_cpu and rank == 0)),
                 ("pairing", lambda: cfg_pairing(D, args, ctx, want_cpu and rank == 0)))
+        D.local_legs = world > 1
         for name, leg in legs:
-            if world > 1:
-                configs.update(leg())               # every rank takes part in the barriers: no swallowing of errors
-                continue
             try:
-                configs.update(leg())
+                res = leg()
             except Exception as e:                  # the headline number must not depend on a secondary leg
-                configs[name] = {"error": repr(e)}
+                res = {name: {"error": repr(e)}}
+            configs.update(D.merge_leg_results(res))
+        D.local_legs = False
 
     if rank == 0:
         value = world * n * args.steps / elapsed
