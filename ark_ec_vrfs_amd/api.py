@@ -162,6 +162,11 @@ class Context:
 
     # VRFHIP_FLAG_PREVALIDATED_* (include/vrfhip.h)
     PREVALIDATED_PUBLIC, PREVALIDATED_INPUT, PREVALIDATED_OUTPUT, PREVALIDATED_PROOF, PREVALIDATED_ALL = 1, 2, 4, 8, 15
+    PROVE_POINTS_AFFINE = 16        # VRFHIP_FLAG_PROVE_POINTS_AFFINE: the provers write points as x || y (64 B)
+
+    def prove_point_bytes(self) -> int:
+        """Bytes per point in the provers' outputs (output, pk / pk_com, r, ok): 32 compressed, 64 with PROVE_POINTS_AFFINE."""
+        return 64 if self.get_flags() & self.PROVE_POINTS_AFFINE else 32
 
     def set_flags(self, flags: int) -> None:
         """Point classes whose prime-order-subgroup membership the caller vouches for (their test is skipped)."""
@@ -290,7 +295,8 @@ class Context:
             if msgs is None or len(msgs) != n:
                 raise ValueError("msgs must have n entries")
             msg_blob, msg_off = _pack_var([bytes(x) for x in msgs])
-        res = {k: np.empty((n, 32), dtype=np.uint8) for k in ("output", "c", "s", "pk", "input")}
+        pw = self.prove_point_bytes()
+        res = {k: np.empty((n, pw if k in ("output", "pk") else 32), dtype=np.uint8) for k in ("output", "c", "s", "pk", "input")}
         status = np.empty(n, dtype=np.uint8)
         blob, off, ad_len = self._ad_args(ad, n)
         _lib.check(self._lib.vrfhip_ietf_prove_batch(
@@ -322,7 +328,9 @@ class Context:
         sk = np.ascontiguousarray(sk, dtype=np.uint8).reshape(-1, 32)
         n = sk.shape[0]
         msg_blob, msg_off, msg_len, inp = self._msg_args(n, msgs, inputs)
-        res = {k: np.empty((n, 32), dtype=np.uint8) for k in ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input")}
+        pw = self.prove_point_bytes()
+        res = {k: np.empty((n, pw if k in ("output", "pk_com", "r", "ok") else 32), dtype=np.uint8)
+               for k in ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input")}
         status = np.empty(n, dtype=np.uint8)
         blob, off, ad_len = self._ad_args(ad, n)
         _lib.check(self._lib.vrfhip_pedersen_prove_batch(
@@ -615,7 +623,8 @@ def ietf_prove_batch_multi(ctxs, sk, msgs, ad=b""):
     n = sk.shape[0]
     mblob, moff = _pack_var([bytes(m) for m in msgs])
     blob, off, ad_len = Context._ad_args(ad, n)
-    res = {k: np.empty((n, 32), np.uint8) for k in ("output", "c", "s", "pk", "input")}
+    pw = ctxs[0].prove_point_bytes()
+    res = {k: np.empty((n, pw if k in ("output", "pk") else 32), np.uint8) for k in ("output", "c", "s", "pk", "input")}
     res["status"] = np.empty(n, np.uint8)
     arr, k = _ctx_array(ctxs)
     _lib.check(_lib.load().vrfhip_ietf_prove_batch_multi(
@@ -631,7 +640,8 @@ def pedersen_prove_batch_multi(ctxs, sk, msgs, ad=b""):
     mblob, moff = _pack_var([bytes(m) for m in msgs])
     blob, off, ad_len = Context._ad_args(ad, n)
     names = ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input")
-    res = {k: np.empty((n, 32), np.uint8) for k in names}
+    pw = ctxs[0].prove_point_bytes()
+    res = {k: np.empty((n, pw if k in ("output", "pk_com", "r", "ok") else 32), np.uint8) for k in names}
     res["status"] = np.empty(n, np.uint8)
     arr, k = _ctx_array(ctxs)
     _lib.check(_lib.load().vrfhip_pedersen_prove_batch_multi(

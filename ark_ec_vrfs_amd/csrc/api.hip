@@ -67,6 +67,7 @@ struct vrfhip_ctx {
   int cus = 256;
   uint32_t flags = 0;                      // VRFHIP_FLAG_PREVALIDATED_* (vrfhip_ctx_set_flags)
   uint32_t check_mask() const { return ~flags & (uint32_t)VRFHIP_FLAG_PREVALIDATED_ALL; }
+  size_t prove_point_bytes() const { return (flags & VRFHIP_FLAG_PROVE_POINTS_AFFINE) ? 64 : 32; }
   // optional per-stage timing (hipEvents on the launch stream), see vrfhip_ctx_profile
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;   // 5 per launch group
@@ -198,7 +199,7 @@ size_t blob_bytes(size_t n, const uint32_t* off, uint32_t len, bool shared) {
 
 extern "C" {
 
-int32_t vrfhip_abi_version(void) { return 110; }
+int32_t vrfhip_abi_version(void) { return 120; }
 
 const char* vrfhip_last_error(void) { return g_last_error.c_str(); }
 
@@ -390,7 +391,8 @@ size_t vrfhip_ctx_workspace_bytes(const vrfhip_ctx* ctx) { return ctx ? ctx->ws_
 
 int32_t vrfhip_ctx_set_flags(vrfhip_ctx* ctx, uint32_t flags) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (flags & ~(uint32_t)VRFHIP_FLAG_PREVALIDATED_ALL) return fail(VRFHIP_ERR_BAD_ARG, "unknown flag bits");
+  if (flags & ~(uint32_t)(VRFHIP_FLAG_PREVALIDATED_ALL | VRFHIP_FLAG_PROVE_POINTS_AFFINE))
+    return fail(VRFHIP_ERR_BAD_ARG, "unknown flag bits");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   ctx->flags = flags;
   return VRFHIP_SUCCESS;
@@ -690,13 +692,15 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
     a.h_given = d_input ? d_input + base * 32 : nullptr;
     a.tai_queue = ctx->d_queue;
     a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
-    a.gamma = at(o.output, base, 32); a.c = at(o.c, base, 32); a.s = at(o.s, base, 32);
-    a.pk_out = at(o.pk, base, 32);
+    const size_t ptw = ctx->prove_point_bytes();        // 32: compressed, 64: x || y (VRFHIP_FLAG_PROVE_POINTS_AFFINE)
+    a.out_affine = ptw == 64 ? 1 : 0;
+    a.gamma = at(o.output, base, ptw); a.c = at(o.c, base, 32); a.s = at(o.s, base, 32);
+    a.pk_out = at(o.pk, base, ptw);
     a.h_out = at(o.input, base, 32);
     a.status = at(o.status, base, 1);
     a.pedersen = pedersen ? 1 : 0;
     a.check_mask = ctx->check_mask();
-    a.r_out = at(o.r, base, 32); a.ok_out = at(o.ok, base, 32); a.sb_out = at(o.sb, base, 32);
+    a.r_out = at(o.r, base, ptw); a.ok_out = at(o.ok, base, ptw); a.sb_out = at(o.sb, base, 32);
     a.blinding_out = at(o.blinding, base, 32);
     a.ws = ctx->ws;
     a.T = ctx->T;
@@ -723,7 +727,8 @@ int32_t prove_host_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t*
   size_t msgb = input ? 0 : blob_bytes(n, msg_off, msg_len, false);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  size_t need = 11 * Stage::pad(n * 32) + Stage::pad(msgb + 1) + Stage::pad(adb + 1) +
+  const size_t ptw = ctx->prove_point_bytes();
+  size_t need = 7 * Stage::pad(n * 32) + 4 * Stage::pad(n * ptw) + Stage::pad(msgb + 1) + Stage::pad(adb + 1) +
                 2 * Stage::pad((n + 1) * 4) + Stage::pad(n);
   int32_t rc = ensure_stage(ctx, need);
   if (rc) return rc;
@@ -731,9 +736,9 @@ int32_t prove_host_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t*
   uint8_t* d_sk = sg.take(n * 32);
   uint8_t* d_in = sg.take(n * 32);
   ProveOut d{};
-  d.output = sg.take(n * 32); d.c = sg.take(n * 32); d.s = sg.take(n * 32);
-  d.pk = sg.take(n * 32); d.input = sg.take(n * 32);
-  d.r = sg.take(n * 32); d.ok = sg.take(n * 32); d.sb = sg.take(n * 32); d.blinding = sg.take(n * 32);
+  d.output = sg.take(n * ptw); d.c = sg.take(n * 32); d.s = sg.take(n * 32);
+  d.pk = sg.take(n * ptw); d.input = sg.take(n * 32);
+  d.r = sg.take(n * ptw); d.ok = sg.take(n * ptw); d.sb = sg.take(n * 32); d.blinding = sg.take(n * 32);
   uint8_t* d_msg = sg.take(msgb + 1);
   uint8_t* d_ad = sg.take(adb + 1);
   uint32_t* d_moff = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
@@ -752,14 +757,14 @@ int32_t prove_host_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t*
   auto back = [&](uint8_t* dst, const uint8_t* src, size_t bytes) -> hipError_t {
     return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
   };
-  HIP_TRY(back(h.output, d.output, n * 32));
+  HIP_TRY(back(h.output, d.output, n * ptw));
   HIP_TRY(back(h.s, d.s, n * 32));
-  HIP_TRY(back(h.pk, d.pk, n * 32));
+  HIP_TRY(back(h.pk, d.pk, n * ptw));
   HIP_TRY(back(h.input, d.input, n * 32));
   HIP_TRY(back(h.status, d.status, n));
   if (pedersen) {
-    HIP_TRY(back(h.r, d.r, n * 32));
-    HIP_TRY(back(h.ok, d.ok, n * 32));
+    HIP_TRY(back(h.r, d.r, n * ptw));
+    HIP_TRY(back(h.ok, d.ok, n * ptw));
     HIP_TRY(back(h.sb, d.sb, n * 32));
     HIP_TRY(back(h.blinding, d.blinding, n * 32));
   } else {
@@ -1597,6 +1602,15 @@ struct BlobSlice {
 };
 const uint8_t* at32(const uint8_t* p, size_t i) { return p ? p + i * 32 : nullptr; }
 uint8_t* at32(uint8_t* p, size_t i) { return p ? p + i * 32 : nullptr; }
+uint8_t* at_w(uint8_t* p, size_t i, size_t w) { return p ? p + i * w : nullptr; }
+// width of the provers' point outputs for a set of contexts: all must agree on VRFHIP_FLAG_PROVE_POINTS_AFFINE
+size_t prove_point_bytes_of(vrfhip_ctx* const* ctxs, int32_t n_ctx) {
+  if (!ctxs || n_ctx < 1 || !ctxs[0]) return 32;              // run_sharded reports the bad argument
+  const size_t w = ctxs[0]->prove_point_bytes();
+  for (int32_t g = 1; g < n_ctx; ++g)
+    if (!ctxs[g] || ctxs[g]->prove_point_bytes() != w) return 0;
+  return w;
+}
 }  // namespace
 
 extern "C" {
@@ -1668,10 +1682,12 @@ int32_t vrfhip_ietf_prove_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx, si
                                       uint8_t* c, uint8_t* s, uint8_t* pk_out, uint8_t* input_out, uint8_t* status) {
   if (n == 0) return VRFHIP_SUCCESS;
   if (!sk || !output || !c || !s) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  const size_t w = prove_point_bytes_of(ctxs, n_ctx);
+  if (!w) return fail(VRFHIP_ERR_BAD_ARG, "contexts disagree on VRFHIP_FLAG_PROVE_POINTS_AFFINE");
   return run_sharded(ctxs, n_ctx, n, [&](vrfhip_ctx* ctx, size_t lo, size_t hi) {
     BlobSlice m(msg, input ? nullptr : msg_off, msg_len, false, lo, hi), a(ad, ad_off, ad_len, true, lo, hi);
     return vrfhip_ietf_prove_batch(ctx, hi - lo, at32(sk, lo), m.blob, m.off, msg_len, at32(input, lo), a.blob, a.off,
-                                   ad_len, at32(output, lo), at32(c, lo), at32(s, lo), at32(pk_out, lo),
+                                   ad_len, at_w(output, lo, w), at32(c, lo), at32(s, lo), at_w(pk_out, lo, w),
                                    at32(input_out, lo), status ? status + lo : nullptr);
   });
 }
@@ -1683,10 +1699,12 @@ int32_t vrfhip_pedersen_prove_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx
                                           uint8_t* sb, uint8_t* blinding_out, uint8_t* input_out, uint8_t* status) {
   if (n == 0) return VRFHIP_SUCCESS;
   if (!sk || !output || !pk_com || !r || !ok || !s || !sb) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  const size_t w = prove_point_bytes_of(ctxs, n_ctx);
+  if (!w) return fail(VRFHIP_ERR_BAD_ARG, "contexts disagree on VRFHIP_FLAG_PROVE_POINTS_AFFINE");
   return run_sharded(ctxs, n_ctx, n, [&](vrfhip_ctx* ctx, size_t lo, size_t hi) {
     BlobSlice m(msg, input ? nullptr : msg_off, msg_len, false, lo, hi), a(ad, ad_off, ad_len, true, lo, hi);
     return vrfhip_pedersen_prove_batch(ctx, hi - lo, at32(sk, lo), m.blob, m.off, msg_len, at32(input, lo), a.blob, a.off,
-                                       ad_len, at32(output, lo), at32(pk_com, lo), at32(r, lo), at32(ok, lo), at32(s, lo),
+                                       ad_len, at_w(output, lo, w), at_w(pk_com, lo, w), at_w(r, lo, w), at_w(ok, lo, w), at32(s, lo),
                                        at32(sb, lo), at32(blinding_out, lo), at32(input_out, lo),
                                        status ? status + lo : nullptr);
   });

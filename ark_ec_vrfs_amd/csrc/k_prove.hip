@@ -176,6 +176,16 @@ void PROVE_STAGE(launch_prove_stage2)(const ProveArgs& a, hipStream_t st) {
 #if VRF_PROVE_PART == 3
 // stage 3: PROVE_K proofs per lane share the inversion of their 4K projective Z; then per item the
 // challenge and s = k + c*sk (Pedersen: also sb = kb + c*b).
+// 64-byte affine output of item i: x (canonical words from the encode stage) || y (the encoding without its sign bit)
+VRF_HD void store_xy(uint8_t* base, size_t i, const uint32_t* xw, const uint32_t enc[8], bool ok) {
+  uint32_t* p = reinterpret_cast<uint32_t*>(base + i * 64);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    p[k] = ok ? xw[k] : 0u;
+    p[8 + k] = ok ? (k == 7 ? enc[k] & 0x7fffffffu : enc[k]) : 0u;
+  }
+}
+
 template <class S, int MINW>
 __global__ void __launch_bounds__(BLOCK, MINW) k_prove_finish(ProveArgs a) {
   size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
@@ -209,16 +219,29 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_finish(ProveArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { sb[j] = 0; b[j] = 0; rr[j] = 0; okp[j] = 0; }
       }
-      store32(a.r_out, i, rr); store32(a.ok_out, i, okp); store32(a.sb_out, i, sb);
+      if (a.out_affine) {
+        store_xy(a.r_out, i, enc + 24 + PROVE_X_OFF, rr, ok);
+        store_xy(a.ok_out, i, enc + 16 + PROVE_X_OFF, okp, ok);
+      } else {
+        store32(a.r_out, i, rr); store32(a.ok_out, i, okp);
+      }
+      store32(a.sb_out, i, sb);
       if (a.blinding_out) store32(a.blinding_out, i, b);
     }
     if (!ok) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { g[j] = 0; c[j] = 0; s[j] = 0; pk[j] = 0; }
     }
-    store32(a.gamma, i, g); store32(a.s, i, s);
+    store32(a.s, i, s);
     if (a.c) store32(a.c, i, c);
-    if (a.pk_out) store32(a.pk_out, i, pk);
+    if (a.out_affine) {
+      // x || y instead of the compressed encoding: the caller builds typed points without a square root
+      store_xy(a.gamma, i, enc + PROVE_X_OFF, g, ok);
+      if (a.pk_out) store_xy(a.pk_out, i, enc + 8 + PROVE_X_OFF, pk, ok);
+    } else {
+      store32(a.gamma, i, g);
+      if (a.pk_out) store32(a.pk_out, i, pk);
+    }
     if (a.h_out) store32(a.h_out, i, h_enc);
     if (a.status) a.status[i] = ok ? ST_OK : ST_INVALID_DATA;
   }

@@ -70,6 +70,7 @@ struct ProveArgs {
   // Pedersen (pedersen != 0): c is unused; pk_out receives pk_com; extra outputs below
   int pedersen;
   uint32_t check_mask;        // CHK_INPUT: subgroup test of a given H
+  int out_affine;             // != 0: gamma, pk_out, r_out, ok_out are n x 64 B (x || y, canonical little-endian)
   uint8_t *r_out, *ok_out, *sb_out, *blinding_out;
   unsigned long long* tai_queue;   // 8-byte device counter for k_tai_find (try-and-increment suites)
   Workspace ws;

@@ -1515,6 +1515,7 @@ VRF_HD uint32_t pedersen_verify_finish_item(const uint32_t* pts, const uint32_t 
 // of every item (sk*H, sk*G(+bB), k*H, k*G(+kbB)) to enc_out[item][4][8].  Prefix products are parked in
 // the items' (now idle) table slots.
 constexpr int PROVE_ENC_OFF = 64;     // word offset of the 4 x 8-word encodings inside an item's table slot
+constexpr int PROVE_X_OFF = 32;       // the canonical x of encoding j sits PROVE_X_OFF words after it (affine outputs)
 template <class S>
 VRF_HD void prove_encode_multi(int K, size_t first, size_t n, const uint32_t* pts_base, uint32_t* tabs_base,
                                int tabs_stride) {
@@ -1536,11 +1537,13 @@ VRF_HD void prove_encode_multi(int K, size_t first, size_t n, const uint32_t* pt
       FeP Z = fe_load<1, 5>(pt + 2 * NL);
       FeN zi = fe_mul(inv, fe_load<1, 2>(tabs_base + item * tabs_stride + (j & 3) * NL));
       inv = fe_mul(inv, Z);
-      uint32_t e[8];
-      te_encode_affine(e, fe_mul(fe_load<1, 5>(pt), zi), fe_mul(fe_load<1, 5>(pt + NL), zi));
+      uint32_t e[8], xw[8];
+      fe_to_u256(xw, fe_mul(fe_load<1, 5>(pt), zi));
+      fe_to_u256(e, fe_mul(fe_load<1, 5>(pt + NL), zi));
+      if (u256_gt(xw, vrfk::QM1H32)) e[7] |= 0x80000000u;         // te_encode_affine, keeping the canonical x
       uint32_t* dst = tabs_base + item * tabs_stride + PROVE_ENC_OFF + (j & 3) * 8;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) dst[k] = e[k];
+      for (int k = 0; k < 8; ++k) { dst[k] = e[k]; dst[PROVE_X_OFF + k] = xw[k]; }
     }
   }
 }

@@ -127,6 +127,13 @@ int32_t vrfhip_ctx_get_desc(const vrfhip_ctx* ctx, vrfhip_suite_desc* out);
 #define VRFHIP_FLAG_PREVALIDATED_OUTPUT 4u /* `Output` (Gamma) */
 #define VRFHIP_FLAG_PREVALIDATED_PROOF 8u  /* `pedersen::Proof` points pk_com, R, Ok */
 #define VRFHIP_FLAG_PREVALIDATED_ALL 15u
+/* Output format of the provers (vrfhip_ietf_prove_batch*, vrfhip_pedersen_prove_batch*, their _dev and _multi forms): with
+ * this flag every POINT they write -- output (Gamma), pk_out / pk_com, r, ok -- is n x 64 B, x || y as 32-byte little-endian
+ * canonical integers, instead of the n x 32 B compressed encoding; the caller sizes those arrays accordingly.  A typed
+ * `Output` / `pedersen::Proof` is then built with `Affine::new_unchecked(x, y)`: no square root and no subgroup test on the
+ * CPU per point (decoding a compressed point costs the CPU more than the whole proof costs the GPU).  input_out (the
+ * encoding of H), scalars and statuses are unchanged; a failed item's points are all-zero. */
+#define VRFHIP_FLAG_PROVE_POINTS_AFFINE 16u
 int32_t vrfhip_ctx_set_flags(vrfhip_ctx* ctx, uint32_t flags);
 uint32_t vrfhip_ctx_get_flags(const vrfhip_ctx* ctx);
 

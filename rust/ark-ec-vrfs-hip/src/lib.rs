@@ -26,7 +26,7 @@ pub use ark_vrf::{
 pub mod ffi;
 
 use ark_vrf::pedersen::PedersenSuite;
-use ark_vrf::reexports::ark_serialize::CanonicalSerialize;
+use ark_vrf::reexports::ark_serialize::{CanonicalDeserialize, CanonicalSerialize};
 
 /// Failure of the library itself (bad argument, HIP error, out of memory, no device): `vrfhip_error` + message.
 /// Per-item outcomes are `ark_vrf::Error` values, exactly as the CPU API reports them.
@@ -110,6 +110,14 @@ fn point32<S: Suite>(p: &AffinePoint<S>, out: &mut [u8]) {
     out.copy_from_slice(&buf);
 }
 
+/// A point the GPU produced, from its x || y form (`VRFHIP_FLAG_PROVE_POINTS_AFFINE`): two field-element loads, no
+/// square root and no subgroup test -- the prover's outputs are multiples of points that were validated on the way in.
+fn point_from_xy<S: Suite>(xy: &[u8]) -> AffinePoint<S> {
+    let x = BaseField::<S>::deserialize_uncompressed_unchecked(&xy[..32]).expect("canonical x from the GPU");
+    let y = BaseField::<S>::deserialize_uncompressed_unchecked(&xy[32..64]).expect("canonical y from the GPU");
+    AffinePoint::<S>::new_unchecked(x, y)
+}
+
 fn scalar32<S: Suite>(k: &ScalarField<S>, out: &mut [u8]) {
     let mut buf = Vec::with_capacity(32);
     codec::scalar_encode::<S>(k, &mut buf);
@@ -135,6 +143,9 @@ impl<S: GpuSuite> GpuBatch<S> {
             let mut ctx: *mut ffi::vrfhip_ctx = core::ptr::null_mut();
             check(unsafe { ffi::vrfhip_ctx_create_desc(&desc, dev, &mut ctx) })?;
             this.ctxs.push(ctx);
+            // the provers hand back points as x || y: a typed `Output` / `Proof` then costs two field loads per point
+            // instead of a square root (`codec::point_decode`), which would dwarf the GPU's own time
+            check(unsafe { ffi::vrfhip_ctx_set_flags(ctx, ffi::VRFHIP_FLAG_PROVE_POINTS_AFFINE) })?;
         }
         Ok(this)
     }
@@ -142,7 +153,7 @@ impl<S: GpuSuite> GpuBatch<S> {
     /// The points handed to `verify` are typed arkworks values: their subgroup membership was established when they
     /// were deserialised, so the library may skip its own test (`VRFHIP_FLAG_PREVALIDATED_*`).  Off by default.
     pub fn trust_typed_points(&self, on: bool) -> Result<(), GpuError> {
-        let flags = if on { ffi::VRFHIP_FLAG_PREVALIDATED_ALL } else { 0 };
+        let flags = ffi::VRFHIP_FLAG_PROVE_POINTS_AFFINE | if on { ffi::VRFHIP_FLAG_PREVALIDATED_ALL } else { 0 };
         for &c in &self.ctxs {
             check(unsafe { ffi::vrfhip_ctx_set_flags(c, flags) })?;
         }
@@ -163,7 +174,7 @@ impl<S: GpuSuite> GpuBatch<S> {
             scalar32::<S>(&secrets[i].scalar, &mut sk[i * 32..(i + 1) * 32]);
             point32::<S>(&inputs[i].0, &mut h[i * 32..(i + 1) * 32]);
         }
-        let (mut gamma, mut c, mut s) = (vec![0u8; n * 32], vec![0u8; n * 32], vec![0u8; n * 32]);
+        let (mut gamma, mut c, mut s) = (vec![0u8; n * 64], vec![0u8; n * 32], vec![0u8; n * 32]); // gamma: x || y
         let mut status = vec![0u8; n];
         check(unsafe {
             ffi::vrfhip_ietf_prove_batch_multi(
@@ -175,7 +186,7 @@ impl<S: GpuSuite> GpuBatch<S> {
         sk.iter_mut().for_each(|b| *b = 0); // the staged copy of the secrets
         Ok((0..n)
             .map(|i| {
-                let out = Output::<S>::from(codec::point_decode::<S>(&gamma[i * 32..(i + 1) * 32]).expect("GPU output"));
+                let out = Output::<S>::from(point_from_xy::<S>(&gamma[i * 64..(i + 1) * 64]));
                 let proof = ietf::Proof::<S> {
                     c: codec::scalar_decode::<S>(&c[i * 32..(i + 1) * 32]),
                     s: codec::scalar_decode::<S>(&s[i * 32..(i + 1) * 32]),
@@ -237,24 +248,25 @@ impl<S: GpuSuite> GpuBatch<S> {
             scalar32::<S>(&secrets[i].scalar, &mut sk[i * 32..(i + 1) * 32]);
             point32::<S>(&inputs[i].0, &mut h[i * 32..(i + 1) * 32]);
         }
-        let mut o = vec![0u8; 7 * n * 32]; // gamma | pk_com | r | ok | s | sb | blinding
+        let mut p = vec![0u8; 4 * n * 64]; // gamma | pk_com | r | ok, x || y each
+        let mut o = vec![0u8; 3 * n * 32]; // s | sb | blinding
         let mut status = vec![0u8; n];
-        let q = o.as_mut_ptr();
+        let (q, w) = (p.as_mut_ptr(), o.as_mut_ptr());
         check(unsafe {
             ffi::vrfhip_pedersen_prove_batch_multi(
                 self.ctxs.as_ptr(), self.ctxs.len() as i32, n, sk.as_ptr(), core::ptr::null(), core::ptr::null(), 0,
-                h.as_ptr(), ad.as_ptr(), core::ptr::null(), ad.len() as u32, q, q.add(n * 32), q.add(2 * n * 32),
-                q.add(3 * n * 32), q.add(4 * n * 32), q.add(5 * n * 32), q.add(6 * n * 32), core::ptr::null_mut(),
+                h.as_ptr(), ad.as_ptr(), core::ptr::null(), ad.len() as u32, q, q.add(n * 64), q.add(2 * n * 64),
+                q.add(3 * n * 64), w, w.add(n * 32), w.add(2 * n * 32), core::ptr::null_mut(),
                 status.as_mut_ptr(),
             )
         })?;
         sk.iter_mut().for_each(|b| *b = 0);
-        let pt = |k: usize, i: usize| codec::point_decode::<S>(&o[(k * n + i) * 32..(k * n + i + 1) * 32]).expect("GPU point");
+        let pt = |k: usize, i: usize| point_from_xy::<S>(&p[(k * n + i) * 64..(k * n + i + 1) * 64]);
         let sc = |k: usize, i: usize| codec::scalar_decode::<S>(&o[(k * n + i) * 32..(k * n + i + 1) * 32]);
         let res = (0..n)
             .map(|i| {
-                let proof = pedersen::Proof::<S> { pk_com: pt(1, i), r: pt(2, i), ok: pt(3, i), s: sc(4, i), sb: sc(5, i) };
-                (Output::<S>::from(pt(0, i)), proof, sc(6, i))
+                let proof = pedersen::Proof::<S> { pk_com: pt(1, i), r: pt(2, i), ok: pt(3, i), s: sc(0, i), sb: sc(1, i) };
+                (Output::<S>::from(pt(0, i)), proof, sc(2, i))
             })
             .collect();
         o.iter_mut().for_each(|b| *b = 0); // blinding factors

@@ -85,8 +85,11 @@ def test_flags_roundtrip_and_default_is_checked(ctx):
     assert ctx.get_flags() == 15
     ctx.set_prevalidated(False)
     assert ctx.get_flags() == 0
+    ctx.set_flags(ctx.PROVE_POINTS_AFFINE)         # an output-format flag: no effect on what is checked
+    assert ctx.get_flags() == 16 and ctx.prove_point_bytes() == 64
+    ctx.set_flags(0)
     with pytest.raises(Exception):
-        ctx.set_flags(16)
+        ctx.set_flags(32)
 
 
 @pytest.mark.gpu

@@ -159,3 +159,80 @@ def test_gpu_batch_digest_equals_the_oracle_and_the_definition(ctx):
         mod[j][i, 31] ^= 1
         assert ctx.test_batch_digest(mod, b"x") != base
     assert ctx.test_batch_digest(arrays, b"y") != base and ctx.test_batch_digest(arrays, b"x", index0=1) != base
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("suite_name", ["bandersnatch", "jubjub"])
+def test_gpu_prove_points_affine_equal_the_decoded_compressed_outputs(suite_name):
+    """VRFHIP_FLAG_PROVE_POINTS_AFFINE: the provers write output / pk / pk_com / r / ok as x || y.  Those must be the
+    coordinates of exactly the points the default (compressed) mode returns -- decoded here by the C oracle -- for the
+    IETF and Pedersen provers, hashed and given inputs, 1 and several proofs per lane, one and three contexts, and a
+    failed item (sk >= r) must come back all-zero."""
+    from ark_ec_vrfs_amd import Context, JubJubSha512Tai, BandersnatchSha512Ell2
+    from ark_ec_vrfs_amd import api as A
+    jj = suite_name == "jubjub"
+    suite = JubJubSha512Tai if jj else BandersnatchSha512Ell2
+    if jj:
+        co.set_suite(2)
+    try:
+        ctxs = [Context(0, suite=suite) for _ in range(3)]
+        c0 = ctxs[0]
+        n = 300
+        sk = np.stack([np.frombuffer(co.secret_from_seed(o.synth_seed(4000 + i)), np.uint8) for i in range(n)])
+        sk[7] = 0xff                                      # >= r: InvalidData
+        msgs = [o.synth_msg(i)[: (i % 40)] for i in range(n)]
+
+        def xy_of(enc):
+            out = np.zeros((enc.shape[0], 64), np.uint8)
+            for i, e in enumerate(enc):
+                r = co.point_decode(bytes(e), subgroup=False)
+                if r is not None and bytes(e) != bytes(32):
+                    out[i] = np.frombuffer(r[0].to_bytes(32, "little") + r[1].to_bytes(32, "little"), np.uint8)
+            return out
+
+        ref_i = c0.ietf_prove_batch(sk, msgs=msgs, ad=b"xy")
+        ref_p = c0.pedersen_prove_batch(sk, msgs=msgs, ad=b"xy")
+        assert ref_i["status"][7] == 2 and (ref_i["status"] == 0).sum() == n - 1
+        for c in ctxs:
+            c.set_flags(c.PROVE_POINTS_AFFINE)
+        assert c0.prove_point_bytes() == 64
+        got_i = c0.ietf_prove_batch(sk, msgs=msgs, ad=b"xy")
+        got_p = c0.pedersen_prove_batch(sk, msgs=msgs, ad=b"xy")
+        for k in ("c", "s", "input", "status"):
+            assert (got_i[k] == ref_i[k]).all(), k
+        for k in ("s", "sb", "blinding", "input", "status"):
+            assert (got_p[k] == ref_p[k]).all(), k
+        for k in ("output", "pk"):
+            assert got_i[k].shape == (n, 64) and (got_i[k] == xy_of(ref_i[k])).all(), k
+        for k in ("output", "pk_com", "r", "ok"):
+            assert got_p[k].shape == (n, 64) and (got_p[k] == xy_of(ref_p[k])).all(), k
+        assert not got_i["output"][7].any() and not got_p["r"][7].any()
+        # given inputs (the Rust crate's path) and the multi-context calls
+        gi = c0.ietf_prove_batch(sk, inputs=ref_i["input"], ad=b"xy")
+        assert (gi["output"] == got_i["output"]).all() and (gi["s"] == ref_i["s"]).all()
+        mi = A.ietf_prove_batch_multi(ctxs, sk, msgs, ad=b"xy")
+        mp = A.pedersen_prove_batch_multi(ctxs, sk, msgs, ad=b"xy")
+        for k in ("output", "pk", "c", "s"):
+            assert (mi[k] == got_i[k]).all(), k
+        for k in ("output", "pk_com", "r", "ok", "s", "sb"):
+            assert (mp[k] == got_p[k]).all(), k
+        # several proofs per lane (K > 1 needs >= 2^18 items): x || y of a strided sample against the compressed run
+        big = 1 << 18
+        skb = np.tile(sk[:256], (big // 256, 1))
+        mb = np.frombuffer(np.random.default_rng(3).bytes(big * 16), np.uint8).reshape(big, 16)
+        c0.set_flags(0)
+        rb = c0.ietf_prove_batch(skb, msgs=mb, ad=b"")
+        c0.set_flags(c0.PROVE_POINTS_AFFINE)
+        gb = c0.ietf_prove_batch(skb, msgs=mb, ad=b"")
+        sel = np.arange(0, big, 1021)
+        assert (gb["output"][sel] == xy_of(rb["output"][sel])).all() and (gb["pk"][sel] == xy_of(rb["pk"][sel])).all()
+        assert (gb["c"] == rb["c"]).all() and (gb["s"] == rb["s"]).all()
+        # contexts that disagree on the flag are refused
+        ctxs[1].set_flags(0)
+        with pytest.raises(Exception):
+            A.ietf_prove_batch_multi(ctxs, sk, msgs, ad=b"xy")
+        for c in ctxs:
+            c.close()
+    finally:
+        if jj:
+            co.set_suite(1)
