@@ -13,6 +13,8 @@
  *  - `*_dev` entry points take DEVICE pointers (hipMalloc'ed / torch CUDA tensors) and a
  *    hipStream_t passed as void*; they enqueue work and return without synchronising.
  *    The plain entry points take HOST pointers, copy in, run, copy out and synchronise.
+ *    Device arrays of 32-, 64-, 96- and 192-byte items must be 4-byte aligned (the kernels read them as 32-bit
+ *    words; hipMalloc and tensor allocators give 256 bytes); message and `ad` blobs may have any alignment.
  *  - `ad` (additional data): one blob.  If `ad_off` is NULL every item uses the whole blob
  *    (`ad_len` bytes); otherwise item i uses blob[ad_off[i] .. ad_off[i+1]) (n+1 offsets).
  *  - Return value: 0 on success, negative vrfhip_error on API / runtime failure (no partial
