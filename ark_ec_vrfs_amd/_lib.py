@@ -56,6 +56,9 @@ class SuiteDescStruct(ctypes.Structure):
 _lib = None
 
 
+ABI_VERSION = 120      # vrfhip_abi_version() of the library this binding was written against
+
+
 def load() -> ctypes.CDLL:
     """Load libvrfhip.so (once).  torch is imported first when present so that the library
     binds to the HIP runtime already in the process (same SONAME libamdhip64.so.7) and device
@@ -74,6 +77,9 @@ def load() -> ctypes.CDLL:
     lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     u8p, u32p = POINTER(c_uint8), POINTER(c_uint32)
     lib.vrfhip_abi_version.restype = c_int32
+    if lib.vrfhip_abi_version() != ABI_VERSION:
+        raise VrfHipError(f"{LIB_PATH} has ABI version {lib.vrfhip_abi_version()}, this binding expects {ABI_VERSION}: rebuild "
+                          "(`make -C ark_ec_vrfs_amd/csrc`)")
     lib.vrfhip_last_error.restype = c_char_p
     lib.vrfhip_ctx_create.argtypes = [c_int32, c_int32, POINTER(c_void_p)]
     lib.vrfhip_ctx_create.restype = c_int32
