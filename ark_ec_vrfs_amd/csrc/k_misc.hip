@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(BLOCK) k_output_hash(size_t n, const uint8_t* 
   if (i >= n) return;
   uint32_t g[8], o[16];
   load32(g, gamma, i);
+  enc_canonical(g);                              // `Output::hash` encodes the typed point
   output_hash_item<S>(o, g, ss);
   uint32_t* p = reinterpret_cast<uint32_t*>(hash + i * 64);
 #pragma unroll

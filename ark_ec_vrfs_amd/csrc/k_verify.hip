@@ -4,6 +4,17 @@
 
 namespace vrf {
 
+// the proof's scalars for the Straus stages: c mod r (upstream decodes `Proof::c` with from_le_bytes_mod_order), s as is;
+// a non-canonical s is reported InvalidData by the finish stage: keep the digits in range here
+template <class S>
+VRF_HD void load_cs_reduced(uint32_t c[8], uint32_t s[8]) {
+  uint32_t cr[8];
+  fr_reduce256<S>(cr, c);
+  const bool s_ok = fr_is_canonical<S>(s);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { c[j] = s_ok ? cr[j] : 0u; s[j] = s_ok ? s[j] : 0u; }
+}
+
 // stage 1: one lane per proof.  Decompress pk, H, Gamma; build their GLV window-table pairs.
 // VERIFY_K proofs per lane share one inversion (3K decompression denominators).
 template <class S, int MINW>
@@ -37,10 +48,7 @@ __global__ void __launch_bounds__(BLOCK) k_verify_comb_u(VerifyArgs a) {
   if (i >= a.n) return;
   uint32_t c[8], s[8];
   load32(c, a.c, i); load32(s, a.s, i);
-  if (!fr_is_canonical<S>(c) || !fr_is_canonical<S>(s)) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { c[j] = 0; s[j] = 0; }
-  }
+  load_cs_reduced<S>(c, s);
   const uint32_t key = a.key_index[i] < a.n_keys ? a.key_index[i] : 0;
   PtE r = gcomb_mul<S>(a.T.g_comb, s);
   r = comb_add<S>(r, a.key_combs + (size_t)key * COMB_WORDS, c, true);
@@ -74,11 +82,7 @@ __global__ void __launch_bounds__(BLOCK) k_verify_straus(VerifyArgs a) {
   if (i >= a.n) return;
   uint32_t c[8], s[8];
   load32(c, a.c, i); load32(s, a.s, i);
-  // non-canonical scalars are reported InvalidData by stage 3; keep the comb digits in range here
-  if (!fr_is_canonical<S>(c) || !fr_is_canonical<S>(s)) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { c[j] = 0; s[j] = 0; }
-  }
+  load_cs_reduced<S>(c, s);
   verify_straus_item<S, HALF>(a.ws.pts + i * PROVE_PTS_WORDS + HALF * UV_WORDS, a.T,
                                     a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), c, s);
 }
@@ -91,10 +95,7 @@ __global__ void __launch_bounds__(BLOCK) k_verify_straus_both(VerifyArgs a) {
   if (i >= a.n) return;
   uint32_t c[8], s[8];
   load32(c, a.c, i); load32(s, a.s, i);
-  if (!fr_is_canonical<S>(c) || !fr_is_canonical<S>(s)) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { c[j] = 0; s[j] = 0; }
-  }
+  load_cs_reduced<S>(c, s);
   const uint32_t* tabs = a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS);
   if (blockIdx.y == 0) verify_straus_item<S, 1>(a.ws.pts + i * PROVE_PTS_WORDS + UV_WORDS, a.T, tabs, c, s);
   else verify_straus_item<S, 0>(a.ws.pts + i * PROVE_PTS_WORDS, a.T, tabs, c, s);

@@ -530,6 +530,17 @@ VRF_HD void comb_build_row(uint32_t* row /*[255][27]*/, uint32_t* prefix /*[255]
 // ------------------------------------------------------------------------ challenge
 // [ref src/lib.rs:14,16 `Suite::challenge` / utils::challenge_rfc_9381]  SURVEY.md A.4:
 // c = int_be(SHA512(suite_id || 0x02 || enc(P1..P5) || ad || 0x00)[0..32]) mod r
+// The transcript hashes take `point_encode` of the TYPED point.  arkworks decodes a compressed point with x = 0 (y = 1 or
+// y = q - 1) whatever its sign flag says and encodes it with the flag clear, so wire bytes are brought to that form
+// before they are hashed; every other accepted encoding is already canonical.  (parity on crafted inputs.)
+VRF_HD void enc_canonical(uint32_t w[8]) {
+  const uint32_t top = w[7] & 0x7fffffffu;
+  uint32_t d1 = (w[0] ^ 1u) | top, dm = (w[0] ^ (vrfk::Q32[0] - 1u)) | (top ^ vrfk::Q32[7]);
+#pragma unroll
+  for (int i = 1; i < 7; ++i) { d1 |= w[i]; dm |= w[i] ^ vrfk::Q32[i]; }
+  if (d1 == 0 || dm == 0) w[7] = top;
+}
+
 template <class S>
 VRF_HD void challenge5(uint32_t c_out[8], const uint32_t (&pts)[5][8], const uint8_t* ad,
                        uint32_t ad_len, const SuiteStr& ss) {
@@ -539,7 +550,13 @@ VRF_HD void challenge5(uint32_t c_out[8], const uint32_t (&pts)[5][8], const uin
   sha512_put_byte(h, 0x02);
   uint64_t w[20];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) sha512_words_le32x8(w + 4 * i, pts[i]);
+  for (int i = 0; i < 5; ++i) {
+    uint32_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = pts[i][j];
+    enc_canonical(e);
+    sha512_words_le32x8(w + 4 * i, e);
+  }
   sha512_put_words(h, w);
   sha512_put_bytes(h, ad, ad_len);
   sha512_put_byte(h, 0x00);
@@ -716,12 +733,13 @@ VRF_HD void verify_finish_multi(int K, size_t first, size_t n, uint32_t* pts_bas
         for (int k = 0; k < 8; ++k) { pts[3][k] = e[k]; pts[4][k] = encv[k]; c[k] = wc[k]; sc[k] = ws[k]; }
         const uint8_t* adp; uint32_t adl;
         bytes_lite_get(ad, item, adp, adl);
-        uint32_t c2[8];
+        uint32_t c2[8], cr[8];
         challenge5<S>(c2, pts, adp, adl, ss);
+        fr_reduce256<S>(cr, c);                  // `Proof::c` is decoded mod r upstream (scalar_decode), s strictly
         uint32_t diff = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) diff |= c2[k] ^ c[k];
-        bool valid = flags[item] != 0 && fr_is_canonical<S>(c) && fr_is_canonical<S>(sc);
+        for (int k = 0; k < 8; ++k) diff |= c2[k] ^ cr[k];
+        bool valid = flags[item] != 0 && fr_is_canonical<S>(sc);
         status[item] = (uint8_t)(!valid ? ST_INVALID_DATA : (diff == 0 ? ST_OK : ST_VERIFICATION_FAILURE));
       }
     }
@@ -828,7 +846,9 @@ VRF_HD uint32_t verify_finish_item(const uint32_t* uv, const uint32_t pk[8], con
                                    const uint32_t gamma[8], const uint32_t c[8],
                                    const uint32_t s[8], bool valid, const uint8_t* ad,
                                    uint32_t ad_len, const SuiteStr& ss) {
-  valid = valid && fr_is_canonical<S>(c) && fr_is_canonical<S>(s);
+  valid = valid && fr_is_canonical<S>(s);
+  uint32_t cr[8];
+  fr_reduce256<S>(cr, c);                        // `Proof::c` is decoded mod r upstream, s strictly
   FeP zin[2] = {fe_load<1, 5>(uv + 2 * NL), fe_load<1, 5>(uv + UV_WORDS + 2 * NL)};
   FeN zi[2];
   fe_batch_inv(zi, zin);
@@ -842,7 +862,7 @@ VRF_HD uint32_t verify_finish_item(const uint32_t* uv, const uint32_t pk[8], con
   challenge5<S>(c2, pts, ad, ad_len, ss);
   uint32_t diff = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) diff |= c2[i] ^ c[i];
+  for (int i = 0; i < 8; ++i) diff |= c2[i] ^ cr[i];
   if (!valid) return ST_INVALID_DATA;
   return diff == 0 ? ST_OK : ST_VERIFICATION_FAILURE;
 }

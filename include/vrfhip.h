@@ -26,7 +26,10 @@
  *  - Points are wire data: every verify entry point (and prove with a given input point) decodes them with
  *    the semantics of arkworks' checked deserialisation, which is what `codec::point_decode` applies before a
  *    `Public` / `Input` / `Output` / proof value exists (src/lib.rs:14): on the curve AND in the prime-order
- *    subgroup.  A point that fails either test, and a non-canonical scalar, give InvalidData.  A caller that
+ *    subgroup.  A point that fails either test, and a non-canonical scalar, give InvalidData -- with the two laxities of
+ *    upstream's own decoding: the challenge `c` of an IETF proof is taken mod r (`Proof::c` is decoded with
+ *    from_le_bytes_mod_order; `s`, `sb` and secrets are strict), and a compressed point with x = 0 is accepted whatever
+ *    its sign flag says and enters the transcript hashes in its canonical encoding (flag clear).  A caller that
  *    holds already validated points (typed arkworks values, an `Input` it hashed itself) can switch the
  *    subgroup test off per point class with vrfhip_ctx_set_flags.
  */

@@ -447,10 +447,19 @@ static void nonce(uint64_t k[4], const uint8_t sk_le[32], const uint8_t h_enc[32
   r_from_bytes_wide(k, h2, 64, 0);
 }
 /* [ref src/lib.rs:14,16 `Suite::challenge`] SURVEY.md A.4 */
+/* `point_encode` of the typed point a wire encoding decodes to: arkworks accepts x = 0 (y = 1 or y = q - 1) with the sign
+ * flag set and encodes it with the flag clear; every other accepted encoding is already canonical. */
+static void enc_canonical(uint8_t out[32], const uint8_t in[32]) {
+  memcpy(out, in, 32);
+  uint8_t t[32]; memcpy(t, in, 32); t[31] &= 0x7f;
+  uint64_t v[4], qm1[4]; load_le(v, t);
+  memcpy(qm1, FQ.m, sizeof qm1); qm1[0] -= 1;                 /* q is odd */
+  if ((v[0] == 1 && !v[1] && !v[2] && !v[3]) || cmp4(v, qm1) == 0) out[31] &= 0x7f;
+}
 static void challenge(uint64_t c_out[4], const uint8_t pts[5][32], const uint8_t* ad, size_t ad_len) {
   uint8_t h[64], two = 2, zero = 0; sha512_ctx c;
   sha512_init(&c); sha512_update(&c, SUITE_ID, SUITE_ID_LEN); sha512_update(&c, &two, 1);
-  for (int i = 0; i < 5; ++i) sha512_update(&c, pts[i], 32);
+  for (int i = 0; i < 5; ++i) { uint8_t e[32]; enc_canonical(e, pts[i]); sha512_update(&c, e, 32); }
   sha512_update(&c, ad, ad_len); sha512_update(&c, &zero, 1); sha512_final(&c, h);
   r_from_bytes_wide(c_out, h, 32, 1);
 }
@@ -518,7 +527,8 @@ int oracle_hash_to_curve(const uint8_t* msg, size_t len, uint8_t out[32]) {
 int oracle_output_hash(const uint8_t gamma[32], uint8_t out[64]) {
   ensure_init();
   uint8_t three = 3, zero = 0; sha512_ctx c;
-  sha512_init(&c); sha512_update(&c, SUITE_ID, SUITE_ID_LEN); sha512_update(&c, &three, 1); sha512_update(&c, gamma, 32);
+  uint8_t e[32]; enc_canonical(e, gamma);       /* `Output::hash` encodes the typed point */
+  sha512_init(&c); sha512_update(&c, SUITE_ID, SUITE_ID_LEN); sha512_update(&c, &three, 1); sha512_update(&c, e, 32);
   sha512_update(&c, &zero, 1); sha512_final(&c, out);
   return 0;
 }
@@ -563,8 +573,9 @@ int oracle_ietf_verify(const uint8_t pk[32], const uint8_t h[32], const uint8_t 
                        const uint8_t c_le[32], const uint8_t s_le[32], const uint8_t* ad, size_t ad_len) {
   ensure_init();
   uint64_t c[4], s[4], c2[4];
-  load_le(c, c_le); load_le(s, s_le);
-  if (cmp4(c, FR.m) >= 0 || cmp4(s, FR.m) >= 0) return 2;
+  r_from_bytes_wide(c, c_le, 32, 0);           /* `Proof::c`: scalar_decode = from_le_bytes_mod_order */
+  load_le(s, s_le);                            /* `Proof::s`: canonical deserialisation, strict */
+  if (cmp4(s, FR.m) >= 0) return 2;
   fp x, y; pt Y, H, Gm, G, sG, cY, sH, cG, U, V, n;
   if (!point_decode_chk(&x, &y, pk, 1)) return 2;
   pt_from_affine(&Y, &x, &y);

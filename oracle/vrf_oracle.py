@@ -212,6 +212,12 @@ def scalar_decode(b: bytes, r: int) -> Optional[int]:
     return v if v < r else None
 
 
+def challenge_decode(b: bytes, r: int) -> int:
+    """`ietf::Proof::c` as upstream decodes it: `codec::scalar_decode` = from_le_bytes_mod_order (never fails);
+    `s` goes through canonical deserialisation (scalar_decode above: None when >= r)."""
+    return int.from_bytes(b, "little") % r
+
+
 def point_encode(S: SuiteParams, P: Point) -> bytes:
     x, y = P
     out = bytearray(y.to_bytes(32, "little"))
@@ -389,7 +395,7 @@ def ietf_verify(S: SuiteParams, pk: Point, H: Point, gamma: Point, ad: bytes, c:
     G = (S.gx, S.gy)
     U = te_add(S, te_mul(S, s, G), te_neg(S, te_mul(S, c, pk)))
     V = te_add(S, te_mul(S, s, H), te_neg(S, te_mul(S, c, gamma)))
-    return challenge_rfc9381(S, [pk, H, gamma, U, V], ad) == c
+    return challenge_rfc9381(S, [pk, H, gamma, U, V], ad) == c % S.r      # `Proof::c` is a field element: mod r
 
 
 # --------------------------------------------------------------------------------------

@@ -83,11 +83,12 @@ int main(int argc, char** argv) {
   }
   items[7].proof.s[0] ^= 1;
   items[1234].output = items[1235].output;
-  for (auto& b : items[1999].proof.c) b = 0xff;
+  for (auto& b : items[1999].proof.c) b = 0xff;         // c >= r: decoded mod r, as `Proof::c` upstream -> a wrong challenge
+  for (auto& b : items[2000].proof.s) b = 0xff;         // s >= r: strict -> InvalidData
   const auto res = ietf::verify_batch(ctx, items, unhex(ad));
   for (size_t i = 0; i < n; ++i) {
-    if (i == 7 || i == 1234) CHECK(res[i] == Error::VerificationFailure);
-    else if (i == 1999) CHECK(res[i] == Error::InvalidData);
+    if (i == 7 || i == 1234 || i == 1999) CHECK(res[i] == Error::VerificationFailure);
+    else if (i == 2000) CHECK(res[i] == Error::InvalidData);
     else CHECK(!res[i].has_value());
   }
   // several contexts from one process (one per GPU; here three on the same device): slices tile the batch

@@ -112,6 +112,52 @@ def test_prove_and_verify_match_c_oracle_at_4096(ctx, synth, ad):
     assert (want[kinds == 0] == 0).all() and (want[(kinds >= 1) & (kinds <= 5)] != 0).all()
 
 
+def test_challenge_mod_r_and_noncanonical_identity_encoding(ctx, synth):
+    """Two corners where arkworks' decoding is laxer than a strict reading (ADVICE r1): `ietf::Proof::c` is decoded with
+    from_le_bytes_mod_order, so c + k r verifies like c (s is strict); a compressed point with x = 0 decodes whatever its
+    sign flag says and is hashed in its canonical form.  GPU == C oracle on both, on every verify entry point."""
+    sk, msg = synth(64, start=1300)
+    ref = co.ietf_prove_batch(sk, msgs=msg, ad=b"m", threads=4)
+    a = {k: ref[k].copy() for k in ("pk", "input", "output", "c", "s")}
+    enc = lambda v: np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
+    ival = lambda b: int.from_bytes(b.tobytes(), "little")
+    kmax = ((1 << 256) - 1) // R
+    for i in range(0, 32):
+        k = 1 + i % kmax
+        if ival(a["c"][i]) + k * R < (1 << 256):
+            a["c"][i] = enc(ival(a["c"][i]) + k * R)                 # still the same field element
+    a["s"][40] = enc(ival(a["s"][40]) + R)                           # s is strict: InvalidData
+    want = co.ietf_verify_batch(a["pk"], a["input"], a["output"], a["c"], a["s"], b"m", threads=4)
+    assert (want[:32] == 0).all() and want[40] == 2 and (np.delete(want, 40) == 0).all()
+    got = ctx.ietf_verify_batch(a["pk"], a["input"], a["output"], a["c"], a["s"], ad=b"m")
+    assert (got == want).all()
+    xy = np.zeros((3, 64, 64), np.uint8)
+    for j, k in enumerate(("pk", "input", "output")):
+        for i in range(64):
+            x, y = co.point_decode(a[k][i].tobytes())
+            xy[j, i] = np.frombuffer(x.to_bytes(32, "little") + y.to_bytes(32, "little"), np.uint8)
+    assert (ctx.ietf_verify_batch_affine(xy[0], xy[1], xy[2], a["c"], a["s"], ad=b"m") == want).all()
+    # identity public key, canonical and with the sign flag set: the same typed point, so the same challenge bytes.
+    # A proof for pk = O: sk = 0 is not a valid secret, but U = s G, V = s H - c Gamma can be met with Gamma = O too:
+    # take k, U = k G, V = k H, c = challenge(O, H, O, U, V), s = k.
+    Sg = S
+    H = o.data_to_point(Sg, b"identity corner")
+    kk = 123456789
+    U, V = o.te_mul(Sg, kk, (Sg.gx, Sg.gy)), o.te_mul(Sg, kk, H)
+    ident = (0, 1)
+    c = o.challenge_rfc9381(Sg, [ident, H, ident, U, V], b"")
+    row = lambda b: np.frombuffer(b, np.uint8).reshape(1, 32)
+    ide, flagged = (1).to_bytes(32, "little"), ((1 << 255) | 1).to_bytes(32, "little")
+    for pk_b, g_b in ((ide, ide), (flagged, ide), (ide, flagged), (flagged, flagged)):
+        args = (row(pk_b), row(o.point_encode(Sg, H)), row(g_b), row(o.scalar_encode(c)), row(o.scalar_encode(kk)))
+        w = co.ietf_verify_batch(*args, b"", threads=1)
+        g = ctx.ietf_verify_batch(*args, ad=b"")
+        assert w[0] == 0 and g[0] == 0, (pk_b[-1], g_b[-1])
+    # Output::hash of the flagged identity = hash of the canonical one
+    assert (ctx.output_hash_batch(row(flagged)) == ctx.output_hash_batch(row(ide))).all()
+    assert ctx.output_hash_batch(row(ide))[0].tobytes() == co.output_hash(ide)
+
+
 def test_invalid_encodings_and_scalars(ctx, synth):
     sk, msg = synth(16, start=900)
     ref = co.ietf_prove_batch(sk, msgs=msg, ad=b"", threads=4)
@@ -119,7 +165,7 @@ def test_invalid_encodings_and_scalars(ctx, synth):
     enc = lambda v: np.frombuffer(int(v).to_bytes(32, "little"), np.uint8)
     a["pk"][0] = enc(Q)                    # y >= q
     a["input"][1] = enc((1 << 256) - 1)    # y >= q with flag
-    a["c"][2] = enc(R)                     # scalar == r
+    a["c"][2] = enc(R)                     # c == r: `Proof::c` is decoded mod r upstream -> c = 0 -> VerificationFailure
     a["s"][3] = enc((1 << 256) - 1)        # scalar >= r
     # an encoding whose x^2 is a non-square
     y = 2
@@ -130,7 +176,7 @@ def test_invalid_encodings_and_scalars(ctx, synth):
     a["pk"][6] = enc(Q - 1)                # (0, -1), order 2: decodes
     want = co.ietf_verify_batch(a["pk"], a["input"], a["output"], a["c"], a["s"], b"", threads=4)
     got = ctx.ietf_verify_batch(a["pk"], a["input"], a["output"], a["c"], a["s"], ad=b"")
-    assert list(want[:5]) == [2, 2, 2, 2, 2] and (want[7:] == 0).all()
+    assert list(want[:5]) == [2, 2, 1, 2, 2] and (want[7:] == 0).all()
     assert (got[:5] == want[:5]).all() and (got[7:] == want[7:]).all()
     assert got[5] != 0 and got[6] != 0     # small-order pk: precondition violated, but never accepted
     # prove with a non-canonical secret reports InvalidData

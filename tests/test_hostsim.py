@@ -137,7 +137,9 @@ def test_decode_and_verify_status_against_oracle(hs):
                o.scalar_encode(c), o.scalar_encode(s)]
         assert hs.hs_ietf_verify(*enc, ad, len(ad)) == 0
         assert hs.hs_ietf_verify(*enc, ad + b"!", len(ad) + 1) == 1
-        bad = list(enc); bad[3] = S.r.to_bytes(32, "little")        # non-canonical scalar
+        bad = list(enc); bad[3] = (c + S.r).to_bytes(32, "little")  # `Proof::c` is decoded mod r: the same field element
+        assert hs.hs_ietf_verify(*bad, ad, len(ad)) == 0
+        bad = list(enc); bad[4] = (s + S.r).to_bytes(32, "little")  # s is strict
         assert hs.hs_ietf_verify(*bad, ad, len(ad)) == 2
         bad = list(enc); bad[0] = Q.to_bytes(32, "little")          # y >= q
         assert hs.hs_ietf_verify(*bad, ad, len(ad)) == 2
@@ -236,13 +238,14 @@ def test_multi_proof_lanes_match_oracle(hs):
     a["s"][3, 0] ^= 1
     a["pk"][9] = np.frombuffer(Q.to_bytes(32, "little"), np.uint8)            # y >= q in the middle of a lane group
     a["output"][10] = r["output"][11]
-    a["c"][17] = np.frombuffer(S.r.to_bytes(32, "little"), np.uint8)
+    a["c"][17] = np.frombuffer(S.r.to_bytes(32, "little"), np.uint8)         # c = r is the field element 0: wrong, not invalid
+    a["s"][18] = np.frombuffer(S.r.to_bytes(32, "little"), np.uint8)         # s is strict: InvalidData
     want = co.ietf_verify_batch(a["pk"], a["input"], a["output"], a["c"], a["s"], b"multi", threads=4)
     st = (ctypes.c_uint8 * n)()
     hs.hs_ietf_verify_multi(n, a["pk"].tobytes(), a["input"].tobytes(), a["output"].tobytes(), a["c"].tobytes(),
                             a["s"].tobytes(), b"multi", 5, st)
     assert list(st) == list(want)
-    assert list(want[[3, 9, 10, 17]]) == [1, 2, 1, 2] and want.sum() == 6
+    assert list(want[[3, 9, 10, 17, 18]]) == [1, 2, 1, 1, 2] and want.sum() == 7
 
 
 def test_multi_proof_prepare_matches_oracle(hs):
