@@ -83,6 +83,30 @@ def synth_msgs(lo, n):
     return out
 
 
+def slim_results(res):
+    """What a rank tells the others about a leg: per config its rate and step time, or its error."""
+    return {k: ({"error": v["error"]} if "error" in v else {"value": v["value"], "ms_per_step": v["ms_per_step"]})
+            for k, v in res.items()}
+
+
+def merge_rank_results(own, allr):
+    """own: this rank's full results of a leg; allr: slim_results of every rank.  A config's rate is set by its slowest
+    rank (each rank computed world x units / its own elapsed, so the job's figure is the minimum); an error or a missing
+    config on any rank is reported instead of a number."""
+    out = dict(own)
+    for k in list(out):
+        errs = [r[k]["error"] for r in allr if k in r and "error" in r[k]] + ["missing on a rank" for r in allr if k not in r]
+        if errs:
+            out[k] = {"error": errs[0]}
+        elif "value" in out[k]:
+            out[k] = dict(out[k], value=min(r[k]["value"] for r in allr), ms_per_step=max(r[k]["ms_per_step"] for r in allr))
+    for r in allr:
+        for k in r:
+            if k not in out:
+                out[k] = {"error": r[k].get("error", "missing on rank 0")}
+    return out
+
+
 class Dist:
     """Rank bookkeeping + the two collectives the bench needs (result gather, max of elapsed)."""
 
@@ -116,28 +140,13 @@ class Dist:
     local_legs = False      # set while a secondary config runs at world > 1 (see timed)
 
     def merge_leg_results(self, res):
-        """Every rank's {config: result} of one leg -> rank 0's view of the whole job: a config's rate is set by its
-        slowest rank (value = world x units / max elapsed = the minimum of the ranks' own figures); an error on any rank
-        is reported instead of a number.  One collective, reached by every rank whether its leg failed or not."""
+        """Every rank's {config: result} of one leg -> rank 0's view of the whole job (merge_rank_results).  One
+        collective, reached by every rank whether its leg failed or not."""
         if self.world == 1:
             return res
-        slim = {k: ({"error": v["error"]} if "error" in v else {"value": v["value"], "ms_per_step": v["ms_per_step"]})
-                for k, v in res.items()}
         allr = [None] * self.world
-        self.dist.all_gather_object(allr, slim)
-        out = dict(res)
-        for k in list(out):
-            errs = [r[k]["error"] for r in allr if k in r and "error" in r[k]] + ["missing on a rank" for r in allr if k not in r]
-            if errs:
-                out[k] = {"error": errs[0]}
-            elif "value" in out[k]:
-                out[k]["value"] = min(r[k]["value"] for r in allr)
-                out[k]["ms_per_step"] = max(r[k]["ms_per_step"] for r in allr)
-        for r in allr:
-            for k in r:
-                if k not in out:
-                    out[k] = {"error": r[k].get("error", "missing on rank 0")}
-        return out
+        self.dist.all_gather_object(allr, slim_results(res))
+        return merge_rank_results(res, allr)
 
     def barrier(self):
         self.torch.cuda.synchronize()

@@ -48,3 +48,18 @@ def test_recorded_bench_lines_carry_the_contract_keys():
         assert d["config"]["workload"] and d["roofline"]["bound"] == "hbm" and d["vs_baseline"] is None
         r = d["roofline"]
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+
+
+def test_secondary_leg_results_merge_across_ranks():
+    """bench.merge_rank_results: the slowest rank sets a config's rate; an error or a missing config on ANY rank replaces
+    the number (the headline line must still be printed)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    r0 = {"a": {"value": 10.0, "ms_per_step": 1.0, "unit": "x/s"}, "b": {"value": 5.0, "ms_per_step": 2.0}, "c": {"value": 1.0, "ms_per_step": 1.0}}
+    r1 = {"a": {"value": 8.0, "ms_per_step": 1.25}, "b": {"error": "boom"}, "d": {"error": "leg failed early"}}
+    m = b.merge_rank_results(r0, [b.slim_results(r0), b.slim_results(r1)])
+    assert m["a"] == {"value": 8.0, "ms_per_step": 1.25, "unit": "x/s"}
+    assert m["b"] == {"error": "boom"} and "error" in m["c"] and m["d"] == {"error": "leg failed early"}
+    assert b.merge_rank_results(r0, [b.slim_results(r0)] * 3)["b"]["value"] == 5.0
