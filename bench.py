@@ -212,12 +212,6 @@ def pmc_for(name, log2_batch):
         e = json.load(open(path)).get(name)
         if e and e.get("log2_batch") == log2_batch:
             return e
-    if name == "ietf_verify":
-        legacy = os.path.join(ROOT, "profiles", "pmc_k_verify_straus.json")
-        if os.path.exists(legacy):
-            e = json.load(open(legacy))
-            if e.get("log2_batch") == log2_batch:
-                return e
     return None
 
 
