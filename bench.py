@@ -206,7 +206,7 @@ def timed(D, fn, steps, warmup, gather_t=None, n_per_rank=0):
 
 def pmc_for(name, log2_batch):
     """HBM traffic and executed vector instructions per launch of a config's dominant kernel, measured with
-    rocprofv3 --pmc on the same command line (profiles/pmc_kernels.json; tools/summarize_profiles.py)."""
+    rocprofv3 --pmc on the same command line (profiles/pmc_kernels.json; tools/summarize_profiles2.py)."""
     path = os.path.join(ROOT, "profiles", "pmc_kernels.json")
     if os.path.exists(path):
         e = json.load(open(path)).get(name)
