@@ -17,6 +17,10 @@
 #include "msm.cuh"
 #include "msm_g1.h"
 
+namespace vrf {
+// k_pairing_row.hip: the selftest operands through the row-distributed tower (bls12_row.cuh); ORs 64 / 128 into status[i]
+void launch_pairing_row_selftest(size_t n, const uint8_t* in, uint8_t* status, hipStream_t st);
+}  // namespace vrf
 using namespace vrf;
 
 namespace {
@@ -1289,6 +1293,7 @@ int32_t vrfhip_test_pairing_quad_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* f
   uint8_t* d_st = sg.take(n);
   HIP_TRY(hipMemcpyAsync(d_in, fp12_pairs, n * 1152, hipMemcpyHostToDevice, ctx->stream));
   launch_pairing_quad_selftest(n, d_in, d_st, ctx->stream);
+  launch_pairing_row_selftest(n, d_in, d_st, ctx->stream);        // bits 64 / 128: the row-distributed tower
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -50,6 +50,10 @@ size_t pairing_prep_bytes() { return (size_t)(bls::G2_PREP_WORDS + 96 + 1) * siz
 void launch_pairing_check2_quad(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status,
                                 hipStream_t st);
 void launch_pairing_check2_quad_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st);
+void launch_pairing_check2_row_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st);
+// Up to this many checks against a prepared pair run one item per 16-lane ROW (three quads share the tower: half the
+// latency, 4/3 the lanes and some exchange traffic); beyond it throughput matters and a quad per item is better.
+constexpr size_t PAIRING_ROW_MAX_ITEMS = 1024;
 
 void launch_pairing_check2(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status,
                            hipStream_t st, uint32_t* prep) {
@@ -61,7 +65,8 @@ void launch_pairing_check2(size_t n, const uint8_t* g1, const uint8_t* g2, size_
   }
   if (g2_stride == 0 && prep && !(mode && !strcmp(mode, "noprep"))) {
     hipLaunchKernelGGL(k_pairing_prepare_g2, dim3(1), dim3(64), 0, st, g2, prep);
-    launch_pairing_check2_quad_prepared(n, g1, prep, status, st);
+    if (n <= PAIRING_ROW_MAX_ITEMS && !(mode && !strcmp(mode, "quad"))) launch_pairing_check2_row_prepared(n, g1, prep, status, st);
+    else launch_pairing_check2_quad_prepared(n, g1, prep, status, st);
     return;
   }
   launch_pairing_check2_quad(n, g1, g2, g2_stride, status, st);

@@ -239,13 +239,21 @@ def test_gpu_pairing_shared_g2_prepared_lines(ctx):
     # the context keeps the lines of the last shared pair: a changed pair replaces them, an unchanged one reuses them
     for _ in range(2):
         assert list(ctx.pairing_check_batch(g1, sh, g2_shared=True)) == want
-    # the verdicts also agree with the path that does not prepare lines
+    # the verdicts also agree with the path that does not prepare lines, and -- small batches run one item per
+    # 16-lane row (bls12_row.cuh), large ones one item per quad -- with the quad kernel forced on this small batch
+    # and with the row / quad switch crossed by a tiled batch
     import os
-    os.environ["VRFHIP_PAIRING"] = "noprep"
-    try:
-        assert list(ctx.pairing_check_batch(g1, sh, g2_shared=True)) == want
-    finally:
-        del os.environ["VRFHIP_PAIRING"]
+    for mode in ("noprep", "quad"):
+        os.environ["VRFHIP_PAIRING"] = mode
+        try:
+            assert list(ctx.pairing_check_batch(g1, sh, g2_shared=True)) == want, mode
+            a = ctx.pairing_check_batch(g1, sh_inf, g2_shared=True)
+            assert list(a) == list(bb), mode
+        finally:
+            del os.environ["VRFHIP_PAIRING"]
+    for reps in (25, 27):                                       # 1000 items: rows; 1080 items: quads
+        big = np.tile(g1, (reps, 1))
+        assert list(ctx.pairing_check_batch(big, sh, g2_shared=True)) == want * reps
 
 
 @pytest.mark.gpu
