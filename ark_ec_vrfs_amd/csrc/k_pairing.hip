@@ -53,7 +53,7 @@ void launch_pairing_check2_quad_prepared(size_t n, const uint8_t* g1, const uint
 void launch_pairing_check2_row_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st);
 // Up to this many checks against a prepared pair run one item per 16-lane ROW (three quads share the tower: half the
 // latency, 4/3 the lanes and some exchange traffic); beyond it throughput matters and a quad per item is better.
-constexpr size_t PAIRING_ROW_MAX_ITEMS = 1024;
+constexpr size_t PAIRING_ROW_MAX_ITEMS = 4096;   // measured: rows 5.8-6.1 ms up to 2^12 items, 12 ms at 2^13; quads 9.5 ms throughout
 
 void launch_pairing_check2(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status,
                            hipStream_t st, uint32_t* prep) {
@@ -65,7 +65,8 @@ void launch_pairing_check2(size_t n, const uint8_t* g1, const uint8_t* g2, size_
   }
   if (g2_stride == 0 && prep && !(mode && !strcmp(mode, "noprep"))) {
     hipLaunchKernelGGL(k_pairing_prepare_g2, dim3(1), dim3(64), 0, st, g2, prep);
-    if (n <= PAIRING_ROW_MAX_ITEMS && !(mode && !strcmp(mode, "quad"))) launch_pairing_check2_row_prepared(n, g1, prep, status, st);
+    const bool force_row = mode && !strcmp(mode, "row");
+    if ((n <= PAIRING_ROW_MAX_ITEMS && !(mode && !strcmp(mode, "quad"))) || force_row) launch_pairing_check2_row_prepared(n, g1, prep, status, st);
     else launch_pairing_check2_quad_prepared(n, g1, prep, status, st);
     return;
   }

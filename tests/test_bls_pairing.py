@@ -251,7 +251,7 @@ def test_gpu_pairing_shared_g2_prepared_lines(ctx):
             assert list(a) == list(bb), mode
         finally:
             del os.environ["VRFHIP_PAIRING"]
-    for reps in (25, 27):                                       # 1000 items: rows; 1080 items: quads
+    for reps in (102, 103):                                     # 4080 items: rows; 4120 items: quads
         big = np.tile(g1, (reps, 1))
         assert list(ctx.pairing_check_batch(big, sh, g2_shared=True)) == want * reps
 
