@@ -14,11 +14,13 @@
 //                  is cut into 512 equal chunks, every lane folds its chunk with complete mixed additions and
 //                  flushes a run when the bucket changes (first run parked as a "head" and merged afterwards), then
 //                  sum_j j B_j by a suffix scan and a tree over the 512 lanes, staged through LDS.
-//   k_g1_final   : per set, one lane per window: sum of the groups, 10 w doublings, tree-sum, affine, wire format.
+//   k_g1_final   : per set, one QUAD per window: sum of the groups, 10 w doublings (two rounds of one product per lane
+//                  each), tree-sum, affine, wire format.
 // Same schedule as k_msm.hip (twisted Edwards); the group law is g1.cuh's complete projective one.
 #include "msm_g1.h"
 
 #include "g1.cuh"
+#include "bls12_quad.cuh"     // qperm: DPP moves inside a quad (k_g1_final)
 #include "sha512.cuh"
 
 namespace vrf {
@@ -246,19 +248,50 @@ __global__ void __launch_bounds__(G1_BLOCK) k_g1_buckets(G1MsmLayout L) {
 }
 
 // ------------------------------------------------------------------------------- final
-__global__ void __launch_bounds__(64) k_g1_final(G1MsmLayout L) {
+// One doubling on the four lanes of a DPP quad (the point replicated in all four): two rounds of ONE field product per
+// lane -- Y^2 | YZ | Z^2 | XY, then (b3 Z^2)(8 Y^2) | (YZ)(8 Y^2) | t (Y^2 + b3 Z^2) | t (XY) with t = Y^2 - 3 b3 Z^2 -- instead
+// of nine products in a row: the kernel is one latency chain of 10 (W - 1) doublings.  Same formulas as g1_dbl.
+__device__ __forceinline__ G1P g1_dbl_quad(const G1P& p, int q) {
+  const FpS a1 = fp_select(q == 3, p.X, fp_select(q == 2, p.Z, p.Y));
+  const FpS b1 = fp_select(q == 1 || q == 2, p.Z, p.Y);
+  const FpS m1 = fp_fit(fp_mul(a1, b1));
+  const FpS t0 = qperm<QP_BC0>(m1), t1 = qperm<QP_BC1>(m1), zz = qperm<QP_BC2>(m1), xy = qperm<0xff>(m1);
+  const FpS z8 = fp_fit(fp_dbl(fp_dbl(fp_dbl(t0))));                            // 8 Y^2
+  const auto t2 = fp_reduce(fp_mul12(zz));                                      // b3 Z^2
+  const FpS t2s = fp_fit(t2);
+  const FpS y3 = fp_fit(fp_add(t0, t2));
+  const FpS t0m = fp_fit(fp_sub(t0, fp_norm(fp_add(fp_dbl(t2), t2))));          // Y^2 - 3 b3 Z^2
+  const FpS a2 = fp_select(q == 0, t2s, fp_select(q == 1, t1, t0m));
+  const FpS b2 = fp_select(q < 2, z8, fp_select(q == 2, y3, xy));
+  const FpS m2 = fp_fit(fp_mul(a2, b2));
+  const FpS x3 = qperm<QP_BC0>(m2), z3 = qperm<QP_BC1>(m2), ty = qperm<QP_BC2>(m2), tx = qperm<0xff>(m2);
+  G1P r;
+  r.X = fp_fit(fp_dbl(tx));
+  r.Y = fp_fit(fp_add(x3, ty));
+  r.Z = z3;
+  return r;
+}
+
+constexpr int G1_FINAL_BLOCK = 128;      // four lanes per window, up to 32 windows
+__global__ void __launch_bounds__(G1_FINAL_BLOCK) k_g1_final(G1MsmLayout L) {
   __shared__ uint32_t stage[32 * G1_PT_WORDS];
   const int t = threadIdx.x, set = blockIdx.x;
+  const int w = t >> 2, q = t & 3;                  // window, lane inside the window's quad
   G1P acc = g1_identity();
-  if (t < L.windows) {
-    for (int g = 0; g < L.groups; ++g)
-      acc = g1_add(acc, g1p_load(L.part + (((size_t)set * L.windows + t) * L.groups + g) * G1_PT_WORDS));
+  if (w < L.windows) {
+    for (int g = 0; g < L.groups; ++g)               // every lane of the quad forms the same sum: the quad stays replicated
+      acc = g1_add(acc, g1p_load(L.part + (((size_t)set * L.windows + w) * L.groups + g) * G1_PT_WORDS));
   }
-  // 2^(10 t) * R_t: lanes run in lockstep; the critical path is the top window's 10 (W - 1) doublings
-  const int nd = t < L.windows ? G1_C * t : 0;
+  // 2^(10 w) * R_w: the critical path is the top window's 10 (W - 1) doublings, each spread over its quad
+  const int nd = w < L.windows ? G1_C * w : 0;
 #pragma unroll 1
   for (int j = 0; j < G1_C * (L.windows - 1); ++j)
-    if (j < nd) acc = g1_dbl(acc);
+    if (j < nd) acc = g1_dbl_quad(acc, q);
+  // window w's result (lane 0 of its quad) -> thread w, which runs the tree below
+  __syncthreads();
+  if (q == 0 && w < 32) g1p_store(stage + w * G1_PT_WORDS, acc);
+  __syncthreads();
+  acc = t < 32 ? g1p_load(stage + t * G1_PT_WORDS) : g1_identity();
   // tree-sum of the window results (<= 32 windows) through LDS
 #pragma unroll 1
   for (int s = 16; s >= 1; s >>= 1) {
@@ -328,7 +361,7 @@ static void launch_core(const G1MsmLayout& L, hipStream_t st, hipEvent_t* ev) {
   }
   hipLaunchKernelGGL(k_g1_buckets, dim3((unsigned)(L.sets * L.windows * L.groups)), dim3(G1_BLOCK), lds_bytes, st, L);
   if (ev) (void)hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(k_g1_final, dim3((unsigned)L.sets), dim3(64), 0, st, L);
+  hipLaunchKernelGGL(k_g1_final, dim3((unsigned)L.sets), dim3(G1_FINAL_BLOCK), 0, st, L);
   if (ev) (void)hipEventRecord(ev[2], st);
 }
 
