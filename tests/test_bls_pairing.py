@@ -120,9 +120,14 @@ def test_hostsim_field_and_tower(hb):
         assert int.from_bytes(_call(hb.hb_fp_sqr, w(x)), "little") == x * x % P
         t, ww = ((x - y) * (x + y) - 3 * x * y) % P, (y - 2 * x) % P
         assert int.from_bytes(_call(hb.hb_fp_lazy, w(x), w(y)), "little") == t * ww % P      # signed lazy limbs
-    for _ in range(30):
-        x = rnd.randrange(1, P)
-        assert int.from_bytes(_call(hb.hb_fp_inv, w(x)), "little") == pow(x, P - 2, P)
+    # inversion by positive divsteps with cofactors (bls12.cuh fp_inv): random values, edge values, powers of two, small
+    # values, values near p, and 0 -> 0 as the power a^(p-2) gives
+    inv_cases = [0, 1, 2, 3, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, (1 << 380), (1 << 381) - 1 - (1 << 200)] + \
+        [1 << k for k in range(0, 381, 19)] + [P - (1 << k) for k in range(0, 380, 37)] + [rnd.randrange(1, P) for _ in range(1500)] + \
+        [rnd.randrange(1, 1 << 64) for _ in range(40)]
+    for x in inv_cases:
+        x %= P
+        assert int.from_bytes(_call(hb.hb_fp_inv, w(x)), "little") == pow(x, P - 2, P), hex(x)
     rf2 = lambda: b.Fp2(rnd.randrange(P), rnd.randrange(P))
     rf12 = lambda: b.Fp12(b.Fp6(rf2(), rf2(), rf2()), b.Fp6(rf2(), rf2(), rf2()))
     for _ in range(10):
