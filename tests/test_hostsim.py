@@ -54,6 +54,10 @@ def test_field_ops_against_python_ints(hs):
 
 def test_inverse_and_table_driven_sqrt(hs):
     rnd = random.Random(2)
+    # fe_inv: positive divsteps with cofactors (fe.cuh); 0 -> 0, powers of two, values near q, small values, random
+    for x in [0, 1, 2, 3, Q - 1, Q - 2, (Q - 1) // 2, (Q + 1) // 2, Q + 5] + [1 << k for k in range(0, 256, 11)] + \
+            [Q - (1 << k) for k in range(0, 250, 23)] + [rnd.getrandbits(256) for _ in range(2500)] + [rnd.getrandbits(40) for _ in range(50)]:
+        assert _call(hs.hs_fe_inv, x)[0] == pow(x % Q, Q - 2, Q), hex(x)
     for it in range(200):
         x = rnd.choice(EDGE) if it % 7 == 0 else rnd.getrandbits(256)
         assert _call(hs.hs_fe_inv, x)[0] == pow(x % Q, Q - 2, Q)
