@@ -256,9 +256,16 @@ def test_gpu_pairing_shared_g2_prepared_lines(ctx):
             assert list(a) == list(bb), mode
         finally:
             del os.environ["VRFHIP_PAIRING"]
-    for reps in (102, 103):                                     # 4080 items: rows; 4120 items: quads
+    for reps in (25, 26, 102, 103):        # 1000 items: one per wave (three rows); 1040, 4080: one per row; 4120: one per quad
         big = np.tile(g1, (reps, 1))
         assert list(ctx.pairing_check_batch(big, sh, g2_shared=True)) == want * reps
+    for rowmode in ("tri", "row"):                              # both row layouts forced on the small batch
+        os.environ["VRFHIP_PAIRING_ROW"] = rowmode
+        try:
+            assert list(ctx.pairing_check_batch(g1, sh, g2_shared=True)) == want, rowmode
+            assert list(ctx.pairing_check_batch(g1, sh_inf, g2_shared=True)) == list(bb), rowmode
+        finally:
+            del os.environ["VRFHIP_PAIRING_ROW"]
 
 
 @pytest.mark.gpu
