@@ -322,7 +322,7 @@ static size_t pad256(size_t x) { return (x + 255) & ~size_t(255); }
 int g1_msm_groups(size_t n, int sets, int windows, int cus) {
   int g = cus / (sets * windows);                 // about one round of the chip
   if (g < 1) g = 1;
-  const size_t max_g = (n + 8191) / 8192;        // at least 16 points per lane and group
+  const size_t max_g = (n + 2047) / 2048;        // at least 4 points per lane and group
   if ((size_t)g > max_g) g = (int)max_g;
   if (g < 1) g = 1;
   const size_t min_g = (n + G1_MAX_PER_GROUP - 1) / G1_MAX_PER_GROUP;
