@@ -163,6 +163,7 @@ class Context:
     # VRFHIP_FLAG_PREVALIDATED_* (include/vrfhip.h)
     PREVALIDATED_PUBLIC, PREVALIDATED_INPUT, PREVALIDATED_OUTPUT, PREVALIDATED_PROOF, PREVALIDATED_ALL = 1, 2, 4, 8, 15
     PROVE_POINTS_AFFINE = 16        # VRFHIP_FLAG_PROVE_POINTS_AFFINE: the provers write points as x || y (64 B)
+    COORDS_MONT256 = 32             # VRFHIP_FLAG_COORDS_MONT256: x || y pairs are arkworks' in-memory Montgomery limbs
 
     def prove_point_bytes(self) -> int:
         """Bytes per point in the provers' outputs (output, pk / pk_com, r, ok): 32 compressed, 64 with PROVE_POINTS_AFFINE."""

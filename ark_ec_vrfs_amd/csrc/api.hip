@@ -20,6 +20,11 @@
 namespace vrf {
 // k_pairing_row.hip: the selftest operands through the row-distributed tower (bls12_row.cuh); ORs 64 / 128 into status[i]
 void launch_pairing_row_selftest(size_t n, const uint8_t* in, uint8_t* status, hipStream_t st);
+// VRFHIP_FLAG_COORDS_MONT256: k_msm.hip takes the bases in Montgomery-256 form; k_misc.hip converts x || y outputs in place
+void launch_msm_coords(int suite, size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t* out_enc, uint8_t* out_xy,
+                       uint8_t* status, void* ws, int groups, int mont256, hipStream_t st);
+void launch_xy_to_mont256(size_t n, uint8_t* xy, hipStream_t st);
+void launch_xy_from_mont256(size_t n, uint8_t* xy, hipStream_t st);
 }  // namespace vrf
 using namespace vrf;
 
@@ -72,6 +77,7 @@ struct vrfhip_ctx {
   uint32_t flags = 0;                      // VRFHIP_FLAG_PREVALIDATED_* (vrfhip_ctx_set_flags)
   uint32_t check_mask() const { return ~flags & (uint32_t)VRFHIP_FLAG_PREVALIDATED_ALL; }
   size_t prove_point_bytes() const { return (flags & VRFHIP_FLAG_PROVE_POINTS_AFFINE) ? 64 : 32; }
+  bool coords_mont256() const { return (flags & VRFHIP_FLAG_COORDS_MONT256) != 0; }
   // optional per-stage timing (hipEvents on the launch stream), see vrfhip_ctx_profile
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;   // 5 per launch group
@@ -395,7 +401,7 @@ size_t vrfhip_ctx_workspace_bytes(const vrfhip_ctx* ctx) { return ctx ? ctx->ws_
 
 int32_t vrfhip_ctx_set_flags(vrfhip_ctx* ctx, uint32_t flags) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (flags & ~(uint32_t)(VRFHIP_FLAG_PREVALIDATED_ALL | VRFHIP_FLAG_PROVE_POINTS_AFFINE))
+  if (flags & ~(uint32_t)(VRFHIP_FLAG_PREVALIDATED_ALL | VRFHIP_FLAG_PROVE_POINTS_AFFINE | VRFHIP_FLAG_COORDS_MONT256))
     return fail(VRFHIP_ERR_BAD_ARG, "unknown flag bits");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   ctx->flags = flags;
@@ -459,7 +465,7 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
     a.k_lane = lanes_k(m, VERIFY_K);
     a.n = m;
     a.pk = ks ? d_pk : d_pk + base * pw; a.h = d_input + base * pw; a.gamma = d_output + base * pw;
-    a.affine_in = affine ? 1 : 0;
+    a.affine_in = affine ? (ctx->coords_mont256() ? 2 : 1) : 0;
     a.check_mask = ctx->check_mask();
     a.key_index = ks ? d_key_index + base : nullptr;
     a.key_combs = ks ? ks->d_combs : nullptr;
@@ -709,6 +715,11 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
     a.ws = ctx->ws;
     a.T = ctx->T;
     launch_ietf_prove(a, st, prof_events(ctx));
+    if (a.out_affine && ctx->coords_mont256()) {       // x || y outputs in arkworks' in-memory form
+      launch_xy_to_mont256(m, a.gamma, st);
+      launch_xy_to_mont256(m, a.pk_out, st);
+      if (pedersen) { launch_xy_to_mont256(m, a.r_out, st); launch_xy_to_mont256(m, a.ok_out, st); }
+    }
     // the aux region held the nonces k, kb and the blinding factor b of these items: wipe it (the reference's
     // `Secret` zeroizes on drop; nothing secret may outlive the call in device memory)
     HIP_TRY(hipMemsetAsync(ctx->ws.aux, 0, m * AUX_WORDS * sizeof(uint32_t), st));
@@ -944,7 +955,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
     const size_t pw = affine ? 64 : 32;
     a.h = d_input + base * pw; a.gamma = d_output + base * pw; a.pk_com = d_pk_com + base * pw;
     a.r = d_r + base * pw; a.ok = d_ok + base * pw; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
-    a.affine_in = affine ? 1 : 0;
+    a.affine_in = affine ? (ctx->coords_mont256() ? 2 : 1) : 0;
     a.check_mask = ctx->check_mask();
     a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
     a.status = d_status + base;
@@ -1017,6 +1028,7 @@ int32_t rlc_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* inp
     if (affine) {
       for (int i = 0; i < 5; ++i) {
         uint8_t* enc = sg.take(n * 32);
+        if (ctx->coords_mont256()) launch_xy_from_mont256(n, d[i], ctx->stream);      // the staged copy, in place
         launch_affine_compress(n, d[i], enc, ctx->stream);
         d[i] = enc;
       }
@@ -1089,6 +1101,7 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
     uint8_t enc[32] = {1};
     HIP_TRY(hipMemcpyAsync(d_out_point, enc, 32, hipMemcpyHostToDevice, st));
     if (d_out_xy) HIP_TRY(hipMemcpyAsync(d_out_xy, id, 64, hipMemcpyHostToDevice, st));
+    if (d_out_xy && ctx->coords_mont256()) launch_xy_to_mont256(1, d_out_xy, st);
     HIP_TRY(hipMemsetAsync(d_status, 0, 1, st));
     HIP_TRY(hipStreamSynchronize(st));     // the sources above are stack buffers
     return VRFHIP_SUCCESS;
@@ -1096,7 +1109,9 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
   int groups = msm_groups(n, n, ctx->cus);
   int32_t rc = ensure_msm_workspace(ctx, msm_workspace_bytes(n, groups));
   if (rc) return rc;
-  launch_msm((int)ctx->suite, n, d_bases_xy, d_scalars, d_out_point, d_out_xy, d_status, ctx->d_msm_ws, groups, st);
+  launch_msm_coords((int)ctx->suite, n, d_bases_xy, d_scalars, d_out_point, d_out_xy, d_status, ctx->d_msm_ws, groups,
+                    ctx->coords_mont256() ? 1 : 0, st);
+  if (d_out_xy && ctx->coords_mont256()) launch_xy_to_mont256(1, d_out_xy, st);
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
 }
@@ -1435,6 +1450,7 @@ int32_t vrfhip_point_validate_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t
     size_t m = std::min(cap, n - base);
     launch_point_validate((int)ctx->suite, m, d_points + base * 32, d_xy_out ? d_xy_out + base * 64 : nullptr,
                           d_status + base, ctx->ws.tabs, ctx->T, static_cast<hipStream_t>(stream));
+    if (d_xy_out && ctx->coords_mont256()) launch_xy_to_mont256(m, d_xy_out + base * 64, static_cast<hipStream_t>(stream));
   }
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;

@@ -322,6 +322,43 @@ VRF_HD void fe_to_u256(uint32_t w[8], const Fe<L, V>& a) {
   limbs_to_u256(w, c);
 }
 
+// Coordinates at the ABI come as canonical integers or -- VRFHIP_FLAG_COORDS_MONT256 -- as arkworks' in-memory field
+// elements: the Montgomery image x 2^256 mod q, four little-endian u64.  Both are integers < q on the wire.
+//   in : words -> Fe (x 2^261) and the canonical words of x (the sign of x, the encoding of y need them)
+//   out: Fe -> words
+VRF_HD FeN fe_from_abi(uint32_t canon[8], const uint32_t w[8], bool mont256) {
+  Fe<1, 3> t;
+  u256_to_limbs(t.v, w);
+  FeN k;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) k.v[i] = mont256 ? vrfk::TWO266_29[i] : vrfk::R2_29[i];
+  const FeN r = fe_mul(t, k);          // canonical: x R^2 / R; Montgomery-256: (x 2^256) 2^266 / 2^261
+  if (mont256) {
+    fe_to_u256(canon, r);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) canon[i] = w[i];
+  }
+  return r;
+}
+template <int L, int V>
+VRF_HD void fe_to_mont256(uint32_t w[8], const Fe<L, V>& a) {
+  static_assert(L <= 6, "");
+  FeN t = fe_mul(a, fe_const(vrfk::TWO256_29));      // (x 2^261) 2^256 / 2^261 = x 2^256, value < q + tiny
+  uint32_t c[NL];
+  fe_reduce_once(c, t);
+  limbs_to_u256(w, c);
+}
+// canonical words of x -> the words of its Montgomery-256 image (outputs that were produced canonically)
+VRF_HD void u256_canon_to_mont256(uint32_t w[8]) {
+  Fe<1, 3> t;
+  u256_to_limbs(t.v, w);
+  FeN k;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) k.v[i] = vrfk::R2_29[i];
+  fe_to_mont256(w, fe_mul(t, k));
+}
+
 // 512-bit integer (16 x u32 LE) mod q -> Montgomery (hash_to_field, 48-byte inputs fit)
 VRF_HD Fe<1, 4> fe_from_u512(const uint32_t w[16]) {
   Fe<1, 3> lo, hi;

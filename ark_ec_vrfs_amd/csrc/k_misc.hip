@@ -290,4 +290,38 @@ void launch_fq_mul(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* r, hip
   if (n) hipLaunchKernelGGL(k_fq_mul, grid_for(n), dim3(BLOCK), 0, st, n, a, b, r);
 }
 
+// ---- x || y outputs in arkworks' in-memory form (VRFHIP_FLAG_COORDS_MONT256): canonical words -> x 2^256 mod q, in place.
+// An all-zero pair (a failed item, the neutral MSM result of an invalid input) stays all-zero.
+__global__ void __launch_bounds__(BLOCK) k_xy_to_mont256(size_t n, uint8_t* xy) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t* p = reinterpret_cast<uint32_t*>(xy + i * 64);
+  uint32_t xw[8], yw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { xw[j] = p[j]; yw[j] = p[8 + j]; }
+  u256_canon_to_mont256(xw);
+  u256_canon_to_mont256(yw);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { p[j] = xw[j]; p[8 + j] = yw[j]; }
+}
+void launch_xy_to_mont256(size_t n, uint8_t* xy, hipStream_t st) {
+  if (n && xy) hipLaunchKernelGGL(k_xy_to_mont256, grid_for(n), dim3(BLOCK), 0, st, n, xy);
+}
+// the other direction, in place (words >= q come out reduced: the callers have rejected those items already)
+__global__ void __launch_bounds__(BLOCK) k_xy_from_mont256(size_t n, uint8_t* xy) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t* p = reinterpret_cast<uint32_t*>(xy + i * 64);
+  uint32_t xw[8], yw[8], cx[8], cy[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { xw[j] = p[j]; yw[j] = p[8 + j]; }
+  (void)fe_from_abi(cx, xw, true);
+  (void)fe_from_abi(cy, yw, true);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { p[j] = cx[j]; p[8 + j] = cy[j]; }
+}
+void launch_xy_from_mont256(size_t n, uint8_t* xy, hipStream_t st) {
+  if (n && xy) hipLaunchKernelGGL(k_xy_from_mont256, grid_for(n), dim3(BLOCK), 0, st, n, xy);
+}
+
 }  // namespace vrf

@@ -27,7 +27,7 @@ namespace vrf {
 // ------------------------------------------------------------------------------- prep
 template <class S>
 __global__ void __launch_bounds__(BLOCK) k_msm_prep(size_t n, const uint8_t* xy, const uint8_t* scalars,
-                                                     uint32_t* pts, int16_t* digits, uint8_t* flags) {
+                                                     uint32_t* pts, int16_t* digits, uint8_t* flags, int mont256) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint32_t* p = reinterpret_cast<const uint32_t*>(xy + i * 64);
@@ -37,8 +37,9 @@ __global__ void __launch_bounds__(BLOCK) k_msm_prep(size_t n, const uint8_t* xy,
   load32(k, scalars, i);
   bool ok = !u256_ge(xw, vrfk::Q32) && !u256_ge(yw, vrfk::Q32) && fr_is_canonical<S>(k);
   PtA a;
-  a.x = fe_from_u256(xw);
-  a.y = fe_from_u256(yw);
+  uint32_t cw[8];
+  a.x = fe_from_abi(cw, xw, mont256 != 0);
+  a.y = fe_from_abi(cw, yw, mont256 != 0);
   a.dt = fe_mul(fe_mul(a.x, a.y), S::d());
   // on-curve check: a*x^2 + y^2 == 1 + d*x^2*y^2  <=>  y^2 - ANEG x^2 - 1 - (d x y) * (x y) == 0
   FeN x2 = fe_sqr(a.x), y2 = fe_sqr(a.y), xy_ = fe_mul(a.x, a.y);
@@ -463,13 +464,19 @@ void launch_msm_core(int suite, const MsmLayout& L, uint8_t* out_enc, uint8_t* o
   VRF_DISPATCH_SUITE(suite, launch_msm_core_t<S>(L, out_enc, out_xy, status, fail_flag, st, ev));
 }
 
-void launch_msm(int suite, size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t* out_enc,
-                uint8_t* out_xy, uint8_t* status, void* ws, int groups, hipStream_t st) {
+// mont256 != 0: the bases' coordinates are Montgomery images x 2^256 mod q (VRFHIP_FLAG_COORDS_MONT256); out_xy stays
+// canonical here (api.hip converts it with launch_xy_to_mont256)
+void launch_msm_coords(int suite, size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t* out_enc,
+                       uint8_t* out_xy, uint8_t* status, void* ws, int groups, int mont256, hipStream_t st) {
   MsmLayout L = msm_layout(n, n, groups, ws);
   (void)hipMemsetAsync(L.flags, 0, 256, st);
   VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_msm_prep<S>, grid_for(n), dim3(BLOCK), 0, st, n, xy, scalars,
-                                               L.pts, L.digits, L.flags));
+                                               L.pts, L.digits, L.flags, mont256));
   launch_msm_core(suite, L, out_enc, out_xy, status, nullptr, st);
+}
+void launch_msm(int suite, size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t* out_enc,
+                uint8_t* out_xy, uint8_t* status, void* ws, int groups, hipStream_t st) {
+  launch_msm_coords(suite, n, xy, scalars, out_enc, out_xy, status, ws, groups, 0, st);
 }
 
 }  // namespace vrf

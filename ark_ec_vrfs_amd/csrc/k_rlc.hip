@@ -166,13 +166,13 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_rlc_prep_affine(RlcArgs a) {
     for (int p = 0; p < 5; ++p) {
       const uint8_t* src = p == 0 ? a.h : p == 1 ? a.gamma : p == 2 ? a.pk_com : p == 3 ? a.r : a.ok;
       const uint32_t* w = reinterpret_cast<const uint32_t*>(src + item * 64);
-      uint32_t xw[8], yw[8];
+      uint32_t xin[8], yin[8], xw[8], yw[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { xw[j] = w[j]; yw[j] = w[8 + j]; }
-      valid = valid && !u256_ge(xw, vrfk::Q32) && !u256_ge(yw, vrfk::Q32);
+      for (int j = 0; j < 8; ++j) { xin[j] = w[j]; yin[j] = w[8 + j]; }
+      valid = valid && !u256_ge(xin, vrfk::Q32) && !u256_ge(yin, vrfk::Q32);
       PtA pa;
-      pa.x = fe_from_u256(xw);
-      pa.y = fe_from_u256(yw);
+      pa.x = fe_from_abi(xw, xin, a.affine_in == 2);      // xw, yw: canonical words (sign of x, encoding of y)
+      pa.y = fe_from_abi(yw, yin, a.affine_in == 2);
       FeN xyv = fe_mul(pa.x, pa.y);
       pa.dt = fe_mul(xyv, S::d());
       // a x^2 + y^2 = 1 + d x^2 y^2   <=>   y^2 - ANEG x^2 - 1 = (d x y)(x y)

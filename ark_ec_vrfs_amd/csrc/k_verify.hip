@@ -68,7 +68,8 @@ __global__ void __launch_bounds__(BLOCK) k_verify_decode_affine(VerifyArgs a) {
   const uint32_t* p2 = reinterpret_cast<const uint32_t*>(a.gamma + i * 64);
 #pragma unroll
   for (int j = 0; j < 16; ++j) { xy[0][j] = p0[j]; xy[1][j] = p1[j]; xy[2][j] = p2[j]; }
-  bool ok = verify_decode_affine_item<S>(enc, xy, a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), a.T.sq, a.check_mask);
+  bool ok = verify_decode_affine_item<S>(enc, xy, a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), a.T.sq, a.check_mask,
+                                         a.affine_in == 2);
   uint32_t* aux = a.ws.aux + i * AUX_WORDS;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { aux[j] = enc[0][j]; aux[8 + j] = enc[1][j]; aux[16 + j] = enc[2][j]; }

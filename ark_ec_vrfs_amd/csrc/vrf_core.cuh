@@ -751,18 +751,18 @@ VRF_HD void verify_finish_multi(int K, size_t first, size_t n, uint32_t* pts_bas
 // point is on the curve.
 template <class S>
 VRF_HD bool verify_decode_affine_item(uint32_t enc_out[3][8], const uint32_t (&xy)[3][16], uint32_t* tabs,
-                                      const SqrtTables& T, uint32_t check_mask = 0) {
+                                      const SqrtTables& T, uint32_t check_mask = 0, bool mont256 = false) {
   bool valid = true;
 #pragma unroll 1
   for (int p = 0; p < 3; ++p) {
-    uint32_t xw[8], yw[8];
+    uint32_t xin[8], yin[8], xw[8], yw[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      xw[j] = p == 0 ? xy[0][j] : p == 1 ? xy[1][j] : xy[2][j];
-      yw[j] = p == 0 ? xy[0][8 + j] : p == 1 ? xy[1][8 + j] : xy[2][8 + j];
+      xin[j] = p == 0 ? xy[0][j] : p == 1 ? xy[1][j] : xy[2][j];
+      yin[j] = p == 0 ? xy[0][8 + j] : p == 1 ? xy[1][8 + j] : xy[2][8 + j];
     }
-    valid = valid && !u256_ge(xw, vrfk::Q32) && !u256_ge(yw, vrfk::Q32);
-    FeN x = fe_from_u256(xw), y = fe_from_u256(yw);
+    valid = valid && !u256_ge(xin, vrfk::Q32) && !u256_ge(yin, vrfk::Q32);
+    FeN x = fe_from_abi(xw, xin, mont256), y = fe_from_abi(yw, yin, mont256);     // xw, yw: canonical words
     // a x^2 + y^2 = 1 + d x^2 y^2   <=>   y^2 - ANEG x^2 - 1 = d (x y)^2
     FeN x2 = fe_sqr(x), y2 = fe_sqr(y), xyv = fe_mul(x, y);
     auto lhs = fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(S::mul_aneg(x2), fe_one())))));

@@ -139,6 +139,13 @@ int32_t vrfhip_ctx_get_desc(const vrfhip_ctx* ctx, vrfhip_suite_desc* out);
  * CPU per point (decoding a compressed point costs the CPU more than the whole proof costs the GPU).  input_out (the
  * encoding of H), scalars and statuses are unchanged; a failed item's points are all-zero. */
 #define VRFHIP_FLAG_PROVE_POINTS_AFFINE 16u
+/* Coordinate format at the ABI (the optional fast path for arkworks' in-memory values).  With this
+ * flag every x || y pair the library reads or writes -- the *_affine verify entry points, the bases and out_xy of vrfhip_msm,
+ * xy_out of vrfhip_point_validate_batch, the provers' outputs under VRFHIP_FLAG_PROVE_POINTS_AFFINE -- holds the Montgomery
+ * images x 2^256 mod q, y 2^256 mod q as four little-endian u64 each: the limbs of `ark_ff::Fp` (`p.x.0.0`), so the Rust side
+ * copies memory instead of converting field elements (into_bigint / from_bigint are a Montgomery product each).  Compressed
+ * points, scalars, the suite descriptor and vrfhip_fq_mul_batch are unaffected.  An all-zero pair (failed item) stays all-zero. */
+#define VRFHIP_FLAG_COORDS_MONT256 32u
 int32_t vrfhip_ctx_set_flags(vrfhip_ctx* ctx, uint32_t flags);
 uint32_t vrfhip_ctx_get_flags(const vrfhip_ctx* ctx);
 

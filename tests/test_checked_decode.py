@@ -88,8 +88,11 @@ def test_flags_roundtrip_and_default_is_checked(ctx):
     ctx.set_flags(ctx.PROVE_POINTS_AFFINE)         # an output-format flag: no effect on what is checked
     assert ctx.get_flags() == 16 and ctx.prove_point_bytes() == 64
     ctx.set_flags(0)
+    ctx.set_flags(ctx.COORDS_MONT256)
+    assert ctx.get_flags() == 32
+    ctx.set_flags(0)
     with pytest.raises(Exception):
-        ctx.set_flags(32)
+        ctx.set_flags(64)
 
 
 @pytest.mark.gpu

@@ -236,3 +236,59 @@ def test_gpu_prove_points_affine_equal_the_decoded_compressed_outputs(suite_name
     finally:
         if jj:
             co.set_suite(1)
+
+
+@pytest.mark.gpu
+def test_gpu_coords_mont256_equal_the_canonical_format(ctx):
+    """VRFHIP_FLAG_COORDS_MONT256 (arkworks' in-memory field elements at the ABI): every x || y pair the
+    library reads or writes is x 2^256 mod q.  With the flag set and inputs converted, the affine verifier, the batched
+    Pedersen verifier on affine points and the MSM must give the results of the canonical format; the provers' x || y
+    outputs, point_validate's xy_out and the MSM's out_xy must be the Montgomery images of the canonical ones."""
+    from ark_ec_vrfs_amd import Context
+    Q = o.Q
+    R256 = (1 << 256) % Q
+    def to_mont(xy):                                   # (n, 64) canonical -> Montgomery-256
+        out = np.zeros_like(xy)
+        for i, row in enumerate(xy):
+            x, y = int.from_bytes(row[:32].tobytes(), "little"), int.from_bytes(row[32:].tobytes(), "little")
+            out[i] = np.frombuffer((x * R256 % Q).to_bytes(32, "little") + (y * R256 % Q).to_bytes(32, "little"), np.uint8)
+        return out
+    c = Context(0)
+    try:
+        n = 200
+        sk = np.stack([np.frombuffer(co.secret_from_seed(o.synth_seed(6000 + i)), np.uint8) for i in range(n)])
+        msgs = [o.synth_msg(i)[: 5 + i % 20] for i in range(n)]
+        ref = c.ietf_prove_batch(sk, msgs=msgs, ad=b"m256")
+        ped = c.pedersen_prove_batch(sk, msgs=msgs, ad=b"m256")
+        # canonical x || y of every point
+        _, xy = zip(*[c.point_validate_batch(ref[k], want_xy=True) for k in ("pk", "input", "output")])
+        pk_xy, in_xy, out_xy = xy
+        _, pxy = zip(*[c.point_validate_batch(ped[k], want_xy=True) for k in ("input", "output", "pk_com", "r", "ok")])
+        s_bad = ref["s"].copy(); s_bad[::9, 0] ^= 1
+        want_v = c.ietf_verify_batch_affine(pk_xy, in_xy, out_xy, ref["c"], s_bad, ad=b"m256")
+        sb_bad = ped["sb"].copy(); sb_bad[5, 1] ^= 4
+        want_r, want_ok = c.pedersen_verify_batch_rlc(*pxy, ped["s"], sb_bad, ad=b"m256", seed=bytes(32), affine=True)
+        k = np.stack([np.frombuffer(int(7 + 13 * i).to_bytes(32, "little"), np.uint8) for i in range(n)])
+        want_m = c.msm(out_xy, k)
+        c.set_flags(c.COORDS_MONT256)
+        assert (c.ietf_verify_batch_affine(to_mont(pk_xy), to_mont(in_xy), to_mont(out_xy), ref["c"], s_bad, ad=b"m256") == want_v).all()
+        assert (want_v[::9] == 1).all() and want_v.sum() == len(want_v[::9])
+        got_r, got_ok = c.pedersen_verify_batch_rlc(*[to_mont(a) for a in pxy], ped["s"], sb_bad, ad=b"m256", seed=bytes(32), affine=True)
+        assert (got_r == want_r).all() and got_ok == want_ok and want_r[5] == 1
+        got_m = c.msm(to_mont(out_xy), k)
+        assert got_m[0] == want_m[0] and got_m[1] == to_mont(np.frombuffer(want_m[1], np.uint8).reshape(1, 64)).tobytes()
+        st, vxy = c.point_validate_batch(ref["output"], want_xy=True)
+        assert (vxy == to_mont(out_xy)).all()
+        # coordinates >= q are InvalidData in this format too
+        bad = to_mont(pk_xy); bad[3, :32] = 0xff
+        assert c.ietf_verify_batch_affine(bad, to_mont(in_xy), to_mont(out_xy), ref["c"], ref["s"], ad=b"m256")[3] == 2
+        # provers: x || y outputs in Montgomery-256 form
+        c.set_flags(c.COORDS_MONT256 | c.PROVE_POINTS_AFFINE)
+        gi = c.ietf_prove_batch(sk, msgs=msgs, ad=b"m256")
+        gp = c.pedersen_prove_batch(sk, msgs=msgs, ad=b"m256")
+        assert (gi["output"] == to_mont(out_xy)).all() and (gi["pk"] == to_mont(pk_xy)).all()
+        assert (gi["c"] == ref["c"]).all() and (gi["s"] == ref["s"]).all()
+        for key, idx in (("output", 1), ("pk_com", 2), ("r", 3), ("ok", 4)):
+            assert (gp[key] == to_mont(pxy[idx])).all(), key
+    finally:
+        c.close()
