@@ -1,4 +1,4 @@
-"""Rewrites the two measurement tables of DESIGN.md section 4 from profiles/r02/bench_n1_default.json and
+"""Rewrites the two measurement tables of DESIGN.md section 4 (and the sentences that quote them) from profiles/r02/bench_n1_default.json and
 profiles/r02/rocprofv3_kernels_by_grid.json (so the document quotes the committed run, not a remembered one).
 usage: python tools/design_tables.py"""
 import json, os
@@ -51,5 +51,23 @@ a = s.index("| config | result | step | stages (ms) |"); b = s.index("\n\nPer ke
 s = s[:a] + cfg + s[b:]
 a = s.index("| kernel | grid | ms | VALU | HBM GB | VGPR / LDS / scratch |"); b = s.index("\n\n(The profiled runs are a few per cent slower")
 s = s[:a] + ktab + s[b:]
+# the sentences of section 4 that quote the same run
+import re
+f = lambda x, n=2: ("%." + str(n) + "f") % x
+s = re.sub(r"(\*\*Checked decode costs 10 %\*\*: )[0-9.]+(e7 verifies/s \()[0-9.]+( ms per 2\^20 in the committed run; 39\.5–)[0-9.]+( ms across boxes\) against\n)[0-9.]+(e7 \()[0-9.]+( ms\) with the)",
+           lambda m: m.group(1) + f(d["value"] / 1e7) + m.group(2) + f(d["ms_per_step"], 1) + m.group(3) + m.group(0).split("39.5–")[1].split(" ms")[0] + m.group(4) +
+           f(d["prevalidated"]["value"] / 1e7) + m.group(5) + f(d["prevalidated"]["ms_per_step"], 1) + m.group(6), s)
+s = re.sub(r"(161 B × 2\^20 = 169 MB per launch ÷ )[0-9.]+( ms = )[0-9.]+( GB/s: \*\*frac )[0-9.]+(\*\* of 8 TB/s\.)",
+           lambda m: m.group(1) + f(d["roofline"]["avg_launch_ms"], 1) + m.group(2) + f(d["roofline"]["achieved"], 1) + m.group(3) + f(d["roofline"]["frac"], 4) + m.group(4), s)
+s = re.sub(r"(7\.5e9 wave-instructions in )[0-9.]+( ms = \*\*)[0-9.]+( of the VALU ceiling\*\*)",
+           lambda m: m.group(1) + f(d["roofline"]["avg_launch_ms"], 1) + m.group(2) + f(d["valu"]["frac"]) + m.group(3), s)
+b14, b18, b4 = c["pairing_check_batched_shared_g2_2^14"], c["pairing_check_batched_shared_g2_2^18"], c["pairing_check_batched_shared_g2_2^18_four_in_flight"]
+sg = b14["stage_ms_per_step"]
+s = re.sub(r"Measured: 2\^14 checks [0-9.]+ ms \(digest \+ prep [0-9.]+, buckets [0-9.]+, final [0-9.]+, the one pairing [0-9.]+\) = \*\*[0-9.]+e6 checks/s",
+           lambda m: "Measured: 2^14 checks " + f(b14["ms_per_step"]) + " ms (digest + prep " + f(sg["prep"]) + ", buckets " + f(sg["msm_buckets"]) + ", final " + f(sg["msm_final"]) +
+           ", the one pairing " + f(sg["pairing"]) + ") = **" + f(b14["value"] / 1e6) + "e6 checks/s", s)
+s = re.sub(r"2\^18 checks [0-9.]+ ms = \*\*[0-9.]+e7 checks/s, 20× the", lambda m: "2^18 checks " + f(b18["ms_per_step"]) + " ms = **" + f(b18["value"] / 1e7) + "e7 checks/s, 20× the", s)
+s = re.sub(r"(overlaps one batch's tail with the others' MSMs: )[0-9.]+(e7 checks/s with)", lambda m: m.group(1) + f(b4["value"] / 1e7, 1) + m.group(2), s)
+s = re.sub(r"(the same 2\^14 checks now take )[0-9.]+( ms as one batch)", lambda m: m.group(1) + f(b14["ms_per_step"], 1) + m.group(2), s)
 open(p, "w").write(s)
-print("tables rewritten: %d config rows, %d kernel rows" % (len(rows), len(kr)))
+print("tables and quoted numbers rewritten: %d config rows, %d kernel rows" % (len(rows), len(kr)))
