@@ -279,8 +279,16 @@ __global__ void __launch_bounds__(G1_FINAL_BLOCK) k_g1_final(G1MsmLayout L) {
   const int w = t >> 2, q = t & 3;                  // window, lane inside the window's quad
   G1P acc = g1_identity();
   if (w < L.windows) {
-    for (int g = 0; g < L.groups; ++g)               // every lane of the quad forms the same sum: the quad stays replicated
+    // lane q sums the groups q, q + 4, ...; two butterfly steps (lane ^ 1, lane ^ 2) leave the total in all four lanes
+    for (int g = q; g < L.groups; g += 4)
       acc = g1_add(acc, g1p_load(L.part + (((size_t)set * L.windows + w) * L.groups + g) * G1_PT_WORDS));
+  }
+  {
+    G1P o;
+    o.X = qperm<0xb1>(acc.X); o.Y = qperm<0xb1>(acc.Y); o.Z = qperm<0xb1>(acc.Z);      // quad_perm 1,0,3,2
+    acc = g1_add(acc, o);
+    o.X = qperm<0x4e>(acc.X); o.Y = qperm<0x4e>(acc.Y); o.Z = qperm<0x4e>(acc.Z);      // quad_perm 2,3,0,1
+    acc = g1_add(acc, o);
   }
   // 2^(10 w) * R_w: the critical path is the top window's 10 (W - 1) doublings, each spread over its quad
   const int nd = w < L.windows ? G1_C * w : 0;
