@@ -1,8 +1,9 @@
 """GPU (-m gpu): bounded parity soak at the batch sizes that pick the other kernel variants.
 
-`lanes_k` (csrc/kernels.h) runs K = 1 / 2 / 4 / 8 proofs per lane for batches below 2^18 / 2^19 / 2^20 / from 2^20;
-the remaining suites cover K = 1 (<= 4096 items) and K = 8 (exactly 2^20).  Here: n = 2^18 + 5 (K = 2), 2^19 + 3
-(K = 4) and 2^20 + 7 inside ONE chunk (reserve(2^21): K = 8 with a ragged last lane), each with
+`lanes_k` (csrc/kernels.h) runs up to K proofs per lane in the inversion-sharing stages: the PROVERS K = 1 / 2 / 4 / 8 for
+batches below 2^18 / 2^19 / 2^20 / from 2^20, the VERIFIERS K = 1 / 2 (api.hip VERIFY_K_POLICY, since inversions became
+cheap).  The remaining suites cover K = 1 (<= 4096 items) and the exact 2^20.  Here: n = 2^18 + 5 (K = 2), 2^19 + 3
+(provers K = 4) and 2^20 + 7 inside ONE chunk (reserve(2^21): provers K = 8 with a ragged last lane), each with
   * proof bytes against the C oracle on a strided sample plus the whole tail (where the ragged lanes are),
   * statuses of a tampered batch against the oracle on the same sample, and the exact set of rejected items,
 and the exact 2^16 prove batch of BASELINE.json configs[1] byte for byte.  The same for Pedersen on JubJub.
@@ -50,7 +51,7 @@ def test_ietf_prove_and_verify_soak_all_lane_variants(n, reserve):
     try:
         if reserve:
             ctx.reserve(reserve)
-        assert lib.vrfhip_debug_proofs_per_lane(n if not reserve else min(n, reserve)) == {(1 << 18) + 5: 2, (1 << 19) + 3: 4, (1 << 20) + 7: 8}[n]
+        assert lib.vrfhip_debug_proofs_per_lane(n if not reserve else min(n, reserve)) == {(1 << 18) + 5: 2, (1 << 19) + 3: 2, (1 << 20) + 7: 2}[n]     # verifiers: K <= 2 (api.hip VERIFY_K_POLICY); the provers reach 4 and 8
         sk = _seeded_sk(torch, lib, _lib, ctx, n, dev)
         msg_h = _msgs(n)
         msg = torch.from_numpy(msg_h).to(dev)
