@@ -26,13 +26,13 @@ def find(name, grid):
     for v in prof["kernels"]:
         if v["kernel"].startswith(name) and v["grid"] == grid:
             return v
-want = [("vrf::k_verify_decode<vrf::SuiteBS, 2>", 131072, ""), ("vrf::k_verify_straus<vrf::SuiteBS, 1>", 1048576, ""), ("vrf::k_verify_straus<vrf::SuiteBS, 0>", 1048576, ""), ("vrf::k_verify_finish<vrf::SuiteBS, 2>", 131072, ""),
-        ("vrf::k_verify_decode_keyed<vrf::SuiteBS, 2>", 131072, ""), ("vrf::k_verify_comb_u<vrf::SuiteBS>", 1048576, ""),
+want = [("vrf::k_verify_decode<vrf::SuiteBS, 2>", 524288, ""), ("vrf::k_verify_straus<vrf::SuiteBS, 1>", 1048576, ""), ("vrf::k_verify_straus<vrf::SuiteBS, 0>", 1048576, ""), ("vrf::k_verify_finish<vrf::SuiteBS, 2>", 524288, ""),
+        ("vrf::k_verify_decode_keyed<vrf::SuiteBS, 2>", 524288, ""), ("vrf::k_verify_comb_u<vrf::SuiteBS>", 1048576, ""),
         ("vrf::k_prove_prepare_multi<vrf::SuiteBS, 1>", 65536, " (2^16)"), ("vrf::k_prove_mul<vrf::SuiteBS>", 131072, " (2^16)"), ("vrf::k_prove_prepare_multi<vrf::SuiteBS, 2>", 131072, " (2^20)"), ("vrf::k_prove_mul<vrf::SuiteBS>", 2097152, " (2^20)"),
         ("vrf::k_prove_finish<vrf::SuiteBS, 2>", 131072, " (2^20)"),
         ("vrf::k_tai_find<vrf::SuiteJJ>", 262144, ""), ("vrf::k_prove_prepare<vrf::SuiteJJ, 2>", 1048576, ""), ("vrf::k_prove_mul<vrf::SuiteJJ>", 2097152, ""),
         ("vrf::k_ped_verify_decode<vrf::SuiteJJ, 2>", 1048576, ""), ("vrf::k_ped_verify_straus<vrf::SuiteJJ, 0>", 1048576, ""), ("vrf::k_ped_verify_straus<vrf::SuiteJJ, 1>", 1048576, ""),
-        ("vrf::k_rlc_decode<vrf::SuiteJJ, 2>", 131072, ""), ("vrf::k_msm_buckets<vrf::SuiteJJ>", 261632, ""), ("vrf::k_digest_leaves", 1048576, " (2^20 × 225 B)"),
+        ("vrf::k_rlc_decode<vrf::SuiteJJ, 2>", 524288, ""), ("vrf::k_msm_buckets<vrf::SuiteJJ>", 261632, ""), ("vrf::k_digest_leaves", 1048576, " (2^20 × 225 B)"),
         ("vrf::k_pairing_check2_quad", 65536, ""), ("vrf::k_pairing_check2_quad_prepared", 65536, ""), ("void vrf::k_pairing_check2_row_prepared<true>", 64, " (ONE item: 48 lanes)"),
         ("vrf::k_g1_buckets", 119808, " (2^18 × 2 sets)"), ("vrf::k_g1_final", 256, " (2 sets × 128 lanes)")]
 kr = []
