@@ -14,7 +14,7 @@ constexpr int ROW_BLOCK = 64;        // 4 items per wave
 // TRI = false: one item per 16-lane row, 4 items per wave.  TRI = true: one item per wave, rows 0..2 each form one of the
 // three Fp products of every Fp2 product (bls12_row.cuh row_fp2_mul); row 3 leaves at once.
 template <bool TRI>
-__global__ void __launch_bounds__(ROW_BLOCK) k_pairing_check2_row_prepared(size_t n, const uint8_t* g1, const uint32_t* prep,
+__global__ void __launch_bounds__(ROW_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1))) k_pairing_check2_row_prepared(size_t n, const uint8_t* g1, const uint32_t* prep,
                                                                             uint8_t* status) {
   const size_t lane = (size_t)blockIdx.x * ROW_BLOCK + threadIdx.x;
   const size_t item = TRI ? (size_t)blockIdx.x : lane >> 4;
