@@ -50,13 +50,14 @@ class SuiteDescStruct(ctypes.Structure):
     """`vrfhip_suite_desc` (include/vrfhip.h)."""
     _fields_ = [("struct_size", c_uint32), ("curve", c_int32), ("suite_id_len", c_uint32),
                 ("suite_id", c_uint8 * 64), ("h2c_dst_len", c_uint32), ("h2c_dst", c_uint8 * 128),
-                ("generator", c_uint8 * 64), ("blinding_base", c_uint8 * 64), ("challenge_len", c_uint32)]
+                ("generator", c_uint8 * 64), ("blinding_base", c_uint8 * 64), ("challenge_len", c_uint32),
+                ("flags", c_uint32)]
 
 
 _lib = None
 
 
-ABI_VERSION = 120      # vrfhip_abi_version() of the library this binding was written against
+ABI_VERSION = 130      # vrfhip_abi_version() of the library this binding was written against
 
 
 def load() -> ctypes.CDLL:

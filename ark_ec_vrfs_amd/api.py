@@ -59,7 +59,23 @@ class JubJubSha512Tai(Suite):
     SUITE_ENUM = 2
 
 
-CURVE_BANDERSNATCH, CURVE_JUBJUB = 1, 2
+class Ed25519Sha512Tai(Suite):
+    """`suites::ed25519`: edwards25519, try-and-increment, 16-byte challenge (suite string / blinding base unpinned)."""
+    SUITE_ID = b"Ed25519_SHA-512_TAI"
+    CHALLENGE_LEN = 16
+    SUITE_ENUM = 3
+
+
+class BabyJubJubSha512Tai(Suite):
+    """`suites::baby_jubjub`: ark-ed-on-bn254 (a = 1), try-and-increment (suite string / blinding base unpinned)."""
+    SUITE_ID = b"BabyJubJub_SHA-512_TAI"
+    CHALLENGE_LEN = 32
+    SUITE_ENUM = 4
+
+
+CURVE_BANDERSNATCH, CURVE_JUBJUB, CURVE_ED25519, CURVE_BABY_JUBJUB = 1, 2, 3, 4
+# vrfhip_suite_desc.flags (VRFHIP_SUITE_FLAG_*): what separates RFC 9381's edwards suites from upstream's built-in ones
+SUITE_FLAG_SIGN_PARITY, SUITE_FLAG_CHALLENGE_LE, SUITE_FLAG_HASH_COFACTOR = 1, 2, 4
 
 
 @dataclass
@@ -72,6 +88,7 @@ class SuiteDesc:
     generator: bytes
     blinding_base: bytes
     challenge_len: int = 32
+    flags: int = 0
 
     @staticmethod
     def default(suite: type) -> "SuiteDesc":
@@ -83,7 +100,7 @@ class SuiteDesc:
     @staticmethod
     def _from_struct(d) -> "SuiteDesc":
         return SuiteDesc(int(d.curve), bytes(d.suite_id[:d.suite_id_len]), bytes(d.h2c_dst[:d.h2c_dst_len]),
-                         bytes(d.generator), bytes(d.blinding_base), int(d.challenge_len))
+                         bytes(d.generator), bytes(d.blinding_base), int(d.challenge_len), int(d.flags))
 
     def _to_struct(self):
         if len(self.suite_id) > 64 or len(self.h2c_dst) > 128 or len(self.generator) != 64 or len(self.blinding_base) != 64:
@@ -98,6 +115,7 @@ class SuiteDesc:
         ctypes.memmove(d.generator, bytes(self.generator), 64)
         ctypes.memmove(d.blinding_base, bytes(self.blinding_base), 64)
         d.challenge_len = self.challenge_len
+        d.flags = self.flags
         return d
 
 

@@ -21,13 +21,25 @@
 namespace vrf {
 // k_pairing_row.hip: the selftest operands through the row-distributed tower (bls12_row.cuh); ORs 64 / 128 into status[i]
 void launch_pairing_row_selftest(size_t n, const uint8_t* in, uint8_t* status, hipStream_t st);
-// VRFHIP_FLAG_COORDS_MONT256: k_msm.hip takes the bases in Montgomery-256 form; k_misc.hip converts x || y outputs in place
-void launch_msm_coords(int suite, size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t* out_enc, uint8_t* out_xy,
-                       uint8_t* status, void* ws, int groups, int mont256, hipStream_t st);
-void launch_xy_to_mont256(size_t n, uint8_t* xy, hipStream_t st);
-void launch_xy_from_mont256(size_t n, uint8_t* xy, hipStream_t st);
+// The kernel objects of the other base fields (field.h): this file is compiled for field 0 (kernels.h declared its
+// launchers in vrf::f_bls381fr) and reaches the 2^255 - 19 and BN254 Fr builds through the same declarations.
+namespace f_25519 {
+#include "launchers.inc"
+}
+namespace f_bn254fr {
+#include "launchers.inc"
+}
 }  // namespace vrf
 using namespace vrf;
+// CALL in the kernel objects of the context's base field
+#define FIELD_CALL(ctx_, CALL)                          \
+  do {                                                  \
+    switch ((ctx_)->field) {                            \
+      case 1: vrf::f_25519::CALL; break;                \
+      case 2: vrf::f_bn254fr::CALL; break;              \
+      default: vrf::f_bls381fr::CALL; break;            \
+    }                                                   \
+  } while (0)
 // Proofs per lane in the verifiers' inversion-sharing stages (decode, finish; the kernels take any K <= VERIFY_K).  With
 // the exponentiation a^(q-2) an inversion cost as much as a third of a proof's decode and K = 8 paid; since fe_inv is the
 // divsteps loop (~18 k instructions) the extra waves of a small K are worth more than the shared inversion: measured at
@@ -58,6 +70,7 @@ constexpr size_t DEFAULT_CHUNK = size_t(1) << 20;
 struct vrfhip_ctx {
   int device = 0;
   vrfhip_suite suite = VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2;   // selects the compiled arithmetic (= desc.curve)
+  int field = 0;                     // base field of the curve: which build of the kernels runs (field.h)
   vrfhip_suite_desc desc{};
   hipStream_t stream = nullptr;      // used by the host-pointer entry points
   std::recursive_mutex mu;
@@ -215,7 +228,7 @@ size_t blob_bytes(size_t n, const uint32_t* off, uint32_t len, bool shared) {
 
 extern "C" {
 
-int32_t vrfhip_abi_version(void) { return 120; }
+int32_t vrfhip_abi_version(void) { return 130; }
 
 const char* vrfhip_last_error(void) { return g_last_error.c_str(); }
 
@@ -228,20 +241,27 @@ int32_t vrfhip_suite_desc_default(vrfhip_suite suite, vrfhip_suite_desc* out) {
     len = (uint32_t)std::strlen(s);
     std::memcpy(dst, s, len);
   };
+  bool have = false;
   if (suite == VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2) {
     out->curve = VRFHIP_CURVE_BANDERSNATCH;
     put(out->suite_id, out->suite_id_len, "Bandersnatch_SHA-512_ELL2");
     put(out->h2c_dst, out->h2c_dst_len, "ECVRF_Bandersnatch_XMD:SHA-512_ELL2_RO_Bandersnatch_SHA-512_ELL2");
-    std::memcpy(out->generator, vrfk_tables::BS_G_XY, 64);
-    std::memcpy(out->blinding_base, vrfk_tables::BS_B_XY, 64);
+    have = vrf::f_bls381fr::field_default_points(SUITE_BS, out->generator, out->blinding_base);
   } else if (suite == VRFHIP_SUITE_JUBJUB_SHA512_TAI) {
     out->curve = VRFHIP_CURVE_JUBJUB;
     put(out->suite_id, out->suite_id_len, "JubJub_SHA-512_TAI");
-    std::memcpy(out->generator, vrfk_tables::JJ_G_XY, 64);
-    std::memcpy(out->blinding_base, vrfk_tables::JJ_B_XY, 64);
-  } else {
-    return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported suite");
+    have = vrf::f_bls381fr::field_default_points(SUITE_JJ, out->generator, out->blinding_base);
+  } else if (suite == VRFHIP_SUITE_ED25519_SHA512_TAI) {
+    out->curve = VRFHIP_CURVE_ED25519;
+    out->challenge_len = 16;                         // upstream: `CHALLENGE_LEN = 16` (RFC 9381 cLen of the edwards25519 suites)
+    put(out->suite_id, out->suite_id_len, "Ed25519_SHA-512_TAI");
+    have = vrf::f_25519::field_default_points(SUITE_ED, out->generator, out->blinding_base);
+  } else if (suite == VRFHIP_SUITE_BABY_JUBJUB_SHA512_TAI) {
+    out->curve = VRFHIP_CURVE_BABY_JUBJUB;
+    put(out->suite_id, out->suite_id_len, "BabyJubJub_SHA-512_TAI");
+    have = vrf::f_bn254fr::field_default_points(SUITE_BJ, out->generator, out->blinding_base);
   }
+  if (!have) return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported suite");
   return VRFHIP_SUCCESS;
 }
 
@@ -265,15 +285,20 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
   *out = nullptr;
   if (!desc) return fail(VRFHIP_ERR_BAD_ARG, "desc is NULL");
   if (desc->struct_size != sizeof(vrfhip_suite_desc)) return fail(VRFHIP_ERR_BAD_ARG, "desc.struct_size mismatch");
-  if (desc->curve != VRFHIP_CURVE_BANDERSNATCH && desc->curve != VRFHIP_CURVE_JUBJUB)
+  if (desc->curve < VRFHIP_CURVE_BANDERSNATCH || desc->curve > VRFHIP_CURVE_BABY_JUBJUB)
     return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported curve");
-  if (desc->challenge_len != 32) return fail(VRFHIP_ERR_UNSUPPORTED, "challenge_len must be 32");
+  if (desc->challenge_len == 0 || desc->challenge_len > 32) return fail(VRFHIP_ERR_UNSUPPORTED, "challenge_len must be 1..32");
+  if (desc->flags & ~(uint32_t)VRFHIP_SUITE_FLAG_ALL) return fail(VRFHIP_ERR_UNSUPPORTED, "unknown suite flag bits");
   if (desc->suite_id_len == 0 || desc->suite_id_len > sizeof desc->suite_id)
     return fail(VRFHIP_ERR_BAD_ARG, "suite_id_len out of range");
   const bool ell2 = desc->curve == VRFHIP_CURVE_BANDERSNATCH;
   if (ell2 && (desc->h2c_dst_len == 0 || desc->h2c_dst_len > sizeof desc->h2c_dst))
     return fail(VRFHIP_ERR_BAD_ARG, "h2c_dst_len out of range");
-  const vrfhip_suite suite = ell2 ? VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2 : VRFHIP_SUITE_JUBJUB_SHA512_TAI;
+  // one built-in suite per curve: its id names the compiled arithmetic (SUITE_* in vrf_types.h follow vrfhip_suite)
+  const vrfhip_suite suite = (vrfhip_suite)desc->curve;
+  static_assert((int)VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2 == SUITE_BS && (int)VRFHIP_SUITE_JUBJUB_SHA512_TAI == SUITE_JJ &&
+                (int)VRFHIP_SUITE_ED25519_SHA512_TAI == SUITE_ED && (int)VRFHIP_SUITE_BABY_JUBJUB_SHA512_TAI == SUITE_BJ &&
+                (int)VRFHIP_CURVE_ED25519 == SUITE_ED && (int)VRFHIP_CURVE_BABY_JUBJUB == SUITE_BJ, "suite / curve ids");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     return fail(VRFHIP_ERR_NO_DEVICE, "no HIP device visible: libvrfhip has no CPU path");
@@ -283,6 +308,7 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
   vrfhip_ctx* ctx = new vrfhip_ctx();
   ctx->device = device;
   ctx->suite = suite;
+  ctx->field = suite_field((int)suite);
   ctx->desc = *desc;
   auto cleanup = [&](int32_t rc) {
     vrfhip_ctx_destroy(ctx);
@@ -300,8 +326,14 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
       ctx->cus = cus;
   }
-  const size_t sqrt_p_bytes = sizeof(vrfk_tables::SQRT_P);
-  const size_t lut_bytes = sizeof(vrfk_tables::SQRT_LUT);
+  size_t sqrt_p_bytes = 0, lut_bytes = 0;
+  const uint32_t* h_sqrt_p = nullptr;
+  const uint8_t* h_sqrt_lut = nullptr;
+  switch (ctx->field) {
+    case 1: h_sqrt_p = vrf::f_25519::field_sqrt_p(&sqrt_p_bytes); h_sqrt_lut = vrf::f_25519::field_sqrt_lut(&lut_bytes); break;
+    case 2: h_sqrt_p = vrf::f_bn254fr::field_sqrt_p(&sqrt_p_bytes); h_sqrt_lut = vrf::f_bn254fr::field_sqrt_lut(&lut_bytes); break;
+    default: h_sqrt_p = vrf::f_bls381fr::field_sqrt_p(&sqrt_p_bytes); h_sqrt_lut = vrf::f_bls381fr::field_sqrt_lut(&lut_bytes); break;
+  }
   const size_t comb_bytes = GCOMB_WORDS * sizeof(uint32_t);            // 56.6 MB per generator (16-bit signed windows)
   const size_t prefix_bytes = (size_t)2 * GC_ROWS * GC_SEGS * GC_SEG * NL * sizeof(uint32_t);
   uint32_t* d_prefix = nullptr;
@@ -314,10 +346,8 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
   HIP_TRY_C(hipMalloc(&ctx->d_queue, 256));
   HIP_TRY_C(hipMalloc(&ctx->d_pair_prep, pairing_prep_bytes()));
   HIP_TRY_C(hipMemset(ctx->d_pair_prep, 0, pairing_prep_bytes()));
-  HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_p, vrfk_tables::SQRT_P, sqrt_p_bytes, hipMemcpyHostToDevice,
-                           ctx->stream));
-  HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_lut, vrfk_tables::SQRT_LUT, lut_bytes, hipMemcpyHostToDevice,
-                           ctx->stream));
+  HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_p, h_sqrt_p, sqrt_p_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY_C(hipMemcpyAsync(ctx->d_sqrt_lut, h_sqrt_lut, lut_bytes, hipMemcpyHostToDevice, ctx->stream));
   // the suite's byte strings, packed big-endian into the 64-bit words SHA-512 absorbs; they travel in the kernel
   // arguments (SuiteStr, fe.cuh)
   SuiteStr hs{};
@@ -325,6 +355,8 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
     for (size_t i = 0; i < n; ++i) w[i >> 3] |= (uint64_t)b[i] << (56 - 8 * (i & 7));
   };
   hs.suite_id_len = desc->suite_id_len;
+  hs.challenge_len = desc->challenge_len;
+  hs.flags = desc->flags;
   pack(hs.suite_id_w, desc->suite_id, desc->suite_id_len);
   if (ell2) {
     uint8_t dstp[129];
@@ -348,8 +380,8 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
   }
   uint32_t* d_mont = reinterpret_cast<uint32_t*>(d_init + 128);
   uint8_t* d_flags = d_init + 128 + 4 * NL * sizeof(uint32_t);
-  launch_init_tables((int)suite, ctx->d_g_win, ctx->d_g_comb, ctx->d_b_comb, d_prefix, d_init, d_mont, d_flags, ctx->T.sq,
-                     ctx->stream);
+  FIELD_CALL(ctx, launch_init_tables((int)suite, ctx->d_g_win, ctx->d_g_comb, ctx->d_b_comb, d_prefix, d_init, d_mont, d_flags, ctx->T.sq,
+                     ctx->stream));
   uint8_t base_ok[2] = {0, 0};
   {
     hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
@@ -482,7 +514,7 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
     a.status = d_status + base;
     a.ws = ctx->ws;
     a.T = ctx->T;
-    launch_ietf_verify(a, st, prof_events(ctx));
+    FIELD_CALL(ctx, launch_ietf_verify(a, st, prof_events(ctx)));
   }
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
@@ -595,7 +627,7 @@ int32_t vrfhip_keyset_create(vrfhip_ctx* ctx, size_t n_keys, const uint8_t* pks,
   HIP_TRY_K(hipMalloc(&d_prefix, prefix_bytes));
   ks->bytes = n_keys * 32 + n_keys + comb_bytes;
   HIP_TRY_K(hipMemcpyAsync(ks->d_enc, pks, n_keys * 32, hipMemcpyHostToDevice, ctx->stream));
-  launch_keyset_build((int)ctx->suite, n_keys, ks->d_enc, d_xy, ks->d_valid, ks->d_combs, d_prefix, ctx->T, ctx->stream);
+  FIELD_CALL(ctx, launch_keyset_build((int)ctx->suite, n_keys, ks->d_enc, d_xy, ks->d_valid, ks->d_combs, d_prefix, ctx->T, ctx->stream));
   HIP_TRY_K(hipGetLastError());
   if (status) {
     std::vector<uint8_t> valid(n_keys);
@@ -720,11 +752,11 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
     a.blinding_out = at(o.blinding, base, 32);
     a.ws = ctx->ws;
     a.T = ctx->T;
-    launch_ietf_prove(a, st, prof_events(ctx));
+    FIELD_CALL(ctx, launch_ietf_prove(a, st, prof_events(ctx)));
     if (a.out_affine && ctx->coords_mont256()) {       // x || y outputs in arkworks' in-memory form
-      launch_xy_to_mont256(m, a.gamma, st);
-      launch_xy_to_mont256(m, a.pk_out, st);
-      if (pedersen) { launch_xy_to_mont256(m, a.r_out, st); launch_xy_to_mont256(m, a.ok_out, st); }
+      FIELD_CALL(ctx, launch_xy_to_mont256(m, a.gamma, st));
+      FIELD_CALL(ctx, launch_xy_to_mont256(m, a.pk_out, st));
+      if (pedersen) { FIELD_CALL(ctx, launch_xy_to_mont256(m, a.r_out, st)); FIELD_CALL(ctx, launch_xy_to_mont256(m, a.ok_out, st)); }
     }
     // the aux region held the nonces k, kb and the blinding factor b of these items: wipe it (the reference's
     // `Secret` zeroizes on drop; nothing secret may outlive the call in device memory)
@@ -878,7 +910,7 @@ int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_
     a.status = d_status + base;
     a.ws = ctx->ws;
     a.T = ctx->T;
-    launch_pedersen_verify(a, st, prof_events(ctx));
+    FIELD_CALL(ctx, launch_pedersen_verify(a, st, prof_events(ctx)));
   }
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
@@ -979,7 +1011,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
     ds.ad = a.ad;
     launch_batch_digest(ds, m, base, d_digest_ws, d_root, st);
     a.root = d_root;
-    launch_pedersen_rlc(a, d_fail_flag, st, prof_events(ctx));
+    FIELD_CALL(ctx, launch_pedersen_rlc(a, d_fail_flag, st, prof_events(ctx)));
   }
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
@@ -1034,8 +1066,8 @@ int32_t rlc_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* inp
     if (affine) {
       for (int i = 0; i < 5; ++i) {
         uint8_t* enc = sg.take(n * 32);
-        if (ctx->coords_mont256()) launch_xy_from_mont256(n, d[i], ctx->stream);      // the staged copy, in place
-        launch_affine_compress(n, d[i], enc, ctx->stream);
+        if (ctx->coords_mont256()) FIELD_CALL(ctx, launch_xy_from_mont256(n, d[i], ctx->stream));      // the staged copy, in place
+        FIELD_CALL(ctx, launch_affine_compress(n, d[i], enc, ctx->stream));
         d[i] = enc;
       }
     }
@@ -1107,7 +1139,7 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
     uint8_t enc[32] = {1};
     HIP_TRY(hipMemcpyAsync(d_out_point, enc, 32, hipMemcpyHostToDevice, st));
     if (d_out_xy) HIP_TRY(hipMemcpyAsync(d_out_xy, id, 64, hipMemcpyHostToDevice, st));
-    if (d_out_xy && ctx->coords_mont256()) launch_xy_to_mont256(1, d_out_xy, st);
+    if (d_out_xy && ctx->coords_mont256()) FIELD_CALL(ctx, launch_xy_to_mont256(1, d_out_xy, st));
     HIP_TRY(hipMemsetAsync(d_status, 0, 1, st));
     HIP_TRY(hipStreamSynchronize(st));     // the sources above are stack buffers
     return VRFHIP_SUCCESS;
@@ -1115,9 +1147,9 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
   int groups = msm_groups(n, n, ctx->cus);
   int32_t rc = ensure_msm_workspace(ctx, msm_workspace_bytes(n, groups));
   if (rc) return rc;
-  launch_msm_coords((int)ctx->suite, n, d_bases_xy, d_scalars, d_out_point, d_out_xy, d_status, ctx->d_msm_ws, groups,
-                    ctx->coords_mont256() ? 1 : 0, st);
-  if (d_out_xy && ctx->coords_mont256()) launch_xy_to_mont256(1, d_out_xy, st);
+  FIELD_CALL(ctx, launch_msm_coords((int)ctx->suite, n, d_bases_xy, d_scalars, d_out_point, d_out_xy, d_status, ctx->d_msm_ws, groups,
+                    ctx->coords_mont256() ? 1 : 0, st));
+  if (d_out_xy && ctx->coords_mont256()) FIELD_CALL(ctx, launch_xy_to_mont256(1, d_out_xy, st));
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
 }
@@ -1330,8 +1362,8 @@ int32_t vrfhip_hash_to_curve_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
   if (!d_points || (!d_msg && (msg_len || d_msg_off))) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  launch_hash_to_curve((int)ctx->suite, n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T,
-                       static_cast<hipStream_t>(stream));
+  FIELD_CALL(ctx, launch_hash_to_curve((int)ctx->suite, n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T,
+                       static_cast<hipStream_t>(stream)));
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
 }
@@ -1371,7 +1403,7 @@ int32_t vrfhip_output_hash_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d
   if (!d_output || !d_hash) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  launch_output_hash((int)ctx->suite, n, d_output, d_hash, ctx->T, static_cast<hipStream_t>(stream));
+  FIELD_CALL(ctx, launch_output_hash((int)ctx->suite, n, d_output, d_hash, ctx->T, static_cast<hipStream_t>(stream)));
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
 }
@@ -1406,8 +1438,8 @@ int32_t vrfhip_secret_from_seed_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8
   if (!d_sk_out || (!d_seeds && seed_len)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  launch_secret_from_seed((int)ctx->suite, n, d_seeds, seed_len, d_sk_out, d_pk_out, ctx->T,
-                          static_cast<hipStream_t>(stream));
+  FIELD_CALL(ctx, launch_secret_from_seed((int)ctx->suite, n, d_seeds, seed_len, d_sk_out, d_pk_out, ctx->T,
+                          static_cast<hipStream_t>(stream)));
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
 }
@@ -1454,9 +1486,9 @@ int32_t vrfhip_point_validate_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t
   size_t cap = ctx->ws_cap * WS_TABS;
   for (size_t base = 0; base < n; base += cap) {
     size_t m = std::min(cap, n - base);
-    launch_point_validate((int)ctx->suite, m, d_points + base * 32, d_xy_out ? d_xy_out + base * 64 : nullptr,
-                          d_status + base, ctx->ws.tabs, ctx->T, static_cast<hipStream_t>(stream));
-    if (d_xy_out && ctx->coords_mont256()) launch_xy_to_mont256(m, d_xy_out + base * 64, static_cast<hipStream_t>(stream));
+    FIELD_CALL(ctx, launch_point_validate((int)ctx->suite, m, d_points + base * 32, d_xy_out ? d_xy_out + base * 64 : nullptr,
+                          d_status + base, ctx->ws.tabs, ctx->T, static_cast<hipStream_t>(stream)));
+    if (d_xy_out && ctx->coords_mont256()) FIELD_CALL(ctx, launch_xy_to_mont256(m, d_xy_out + base * 64, static_cast<hipStream_t>(stream)));
   }
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
@@ -1502,7 +1534,7 @@ int32_t vrfhip_fq_mul_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const u
   uint8_t* d_r = sg.take(n * 32);
   HIP_TRY(hipMemcpyAsync(d_a, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(d_b, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
-  launch_fq_mul(n, d_a, d_b, d_r, ctx->stream);
+  FIELD_CALL(ctx, launch_fq_mul(n, d_a, d_b, d_r, ctx->stream));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(r, d_r, n * 32, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1524,7 +1556,7 @@ int32_t vrfhip_test_point_add(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const
   uint8_t *d_a = sg.take(n * 32), *d_b = sg.take(n * 32), *d_o = sg.take(n * 32), *d_st = sg.take(n);
   HIP_TRY(hipMemcpyAsync(d_a, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(d_b, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
-  launch_test_point_add((int)ctx->suite, n, d_a, d_b, d_o, d_st, ctx->T, ctx->stream);
+  FIELD_CALL(ctx, launch_test_point_add((int)ctx->suite, n, d_a, d_b, d_o, d_st, ctx->T, ctx->stream));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, d_o, n * 32, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1550,8 +1582,8 @@ int32_t vrfhip_test_scalar_mul(vrfhip_ctx* ctx, size_t n, const uint8_t* scalars
   const size_t cap = ctx->ws_cap * (WS_TABS / 2);          // two window tables per item
   for (size_t base = 0; base < n; base += cap) {
     size_t m = std::min(cap, n - base);
-    launch_test_scalar_mul((int)ctx->suite, m, d_k + base * 32, d_p + base * 32, d_o + base * 32, d_st + base,
-                           ctx->ws.tabs, ctx->T, ctx->stream);
+    FIELD_CALL(ctx, launch_test_scalar_mul((int)ctx->suite, m, d_k + base * 32, d_p + base * 32, d_o + base * 32, d_st + base,
+                           ctx->ws.tabs, ctx->T, ctx->stream));
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, d_o, n * 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -1579,8 +1611,8 @@ int32_t test_hash_impl(vrfhip_ctx* ctx, size_t n, const uint8_t* msg, const uint
   uint8_t* d_out = sg.take(n * ob);
   if (msgb) HIP_TRY(hipMemcpyAsync(d_msg, msg, msgb, hipMemcpyHostToDevice, ctx->stream));
   if (msg_off) HIP_TRY(hipMemcpyAsync(d_off, msg_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  launch_test_hash((int)ctx->suite, n, make_view(d_msg, msg_off ? d_off : nullptr, msg_len, false), d_out, which, ctx->T,
-                   ctx->stream);
+  FIELD_CALL(ctx, launch_test_hash((int)ctx->suite, n, make_view(d_msg, msg_off ? d_off : nullptr, msg_len, false), d_out, which, ctx->T,
+                   ctx->stream));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, d_out, n * ob, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -22,18 +22,20 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
-#include "constants.gen.h"
+#include "field.h"
+#include "vrf_types.h"
 
-#define VRF_HD __host__ __device__ __forceinline__
-
-namespace vrf {
+VRF_NS_BEGIN
 
 using vrfk::LMASK;
 constexpr int NL = 9;
 constexpr int LW = 29;
 
-// out value bound of a Montgomery product: (a*b + m*q)/R < q * (1 + Va*Vb*q/R), q/R = 0.014152
-constexpr int mul_v(int v1, int v2) { return 1 + (v1 * v2 * 1416 + 99999) / 100000; }
+// out value bound of a Montgomery product: (a*b + m*q)/R < q * (1 + Va*Vb*q/R), q/R = MULV_NUM / 1e5 (0.014152 for
+// BLS12-381 Fr); the pseudo-Mersenne product of 2^255 - 19 always comes out below 2^255 + 2^30 < 2q
+constexpr int mul_v(int v1, int v2) {
+  return vrfk::FIELD_KIND == 2 ? 2 : 1 + (v1 * v2 * vrfk::MULV_NUM + 99999) / 100000;
+}
 
 template <int L, int V>
 struct Fe {
@@ -158,19 +160,69 @@ VRF_HD Fe<L, V> fe_select(bool c, const Fe<L, V>& a, const Fe<L, V>& b) {   // c
   return r;
 }
 
-// ------------------------------------------------------------------ Montgomery multiply
+// ------------------------------------------------------------------ multiply
 VRF_HD uint64_t mad(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
-// The Montgomery digit of a column t is m = -t mod 2^29 (q = 1 mod 2^29) and the column leaves the carry
-// (t + m) >> 29 = (t >> 29) + (t mod 2^29 != 0) = (t + 2^29 - 1) >> 29.  Carrying the bias 2^29 - 1 in the
-// accumulator turns "negate, mask, add m back (64-bit)" into one v_bitop3 (~t & mask) and no addition:
-// 17 fewer instructions per product (measured on gfx950: 1.64e11 -> 1.75e11 products/s).  The bias is far
-// below the headroom the L1 * L2 <= 6 assertion leaves (about 2^59).
-VRF_HD constexpr uint64_t mont_bias() { return LMASK; }
+// Three digit rules, chosen at compile time by the field (field.h, vrfk::FIELD_KIND):
+//
+//  kind 0 (BLS12-381 Fr, q = 1 mod 2^29): the Montgomery digit of a column t is m = -t mod 2^29 and the column leaves the
+//  carry (t + m) >> 29 = (t >> 29) + (t mod 2^29 != 0) = (t + 2^29 - 1) >> 29.  Carrying the bias 2^29 - 1 in the
+//  accumulator turns "negate, mask, add m back (64-bit)" into one v_bitop3 (~t & mask) and no addition:
+//  17 fewer instructions per product (measured on gfx950: 1.64e11 -> 1.75e11 products/s).  The bias is far
+//  below the headroom the L1 * L2 <= 6 assertion leaves (about 2^59).
+//
+//  kind 1 (BN254 Fr, general q): m = t * (-q^-1) mod 2^29 -- NINV29 = 2^28 - 1 there, a shift and a subtraction -- and
+//  the column takes m * q[0] like every other limb of q: 9 more multiply-adds per product than kind 0.
+//
+//  kind 2 (2^255 - 19): no Montgomery form at all (R = 1).  The columns 9..16 of the plain product are carried into
+//  29-bit digits h first, then 2^261 = 1216 (mod q) folds them onto the columns 0..8, and what is left above bit 255
+//  comes back as 19 * carry into limb 0: 81 + 9 multiply-adds instead of 153.  Output < 2^255 + 2^30.
+VRF_HD constexpr uint64_t mont_bias() { return vrfk::FIELD_KIND == 0 ? (uint64_t)LMASK : 0; }
+VRF_HD uint32_t mont_digit(uint32_t col) {
+  if constexpr (vrfk::FIELD_KIND == 0) return ~col & LMASK;          // the accumulator carries the bias LMASK
+  else return (col * vrfk::NINV29) & LMASK;
+}
+constexpr uint32_t PM_FOLD = 1216;      // 2^261 mod (2^255 - 19)
+constexpr int PM_TOPBITS = 23;          // bit 255 is bit 23 of limb 8
+
+// tail of the pseudo-Mersenne product: acc = bits >= 232 of the folded value; r.v[0..7] hold the digits below
+template <int V>
+VRF_HD void pm_finish(Fe<1, V>& r, uint64_t acc) {
+  r.v[NL - 1] = (uint32_t)acc & ((1u << PM_TOPBITS) - 1);
+  const uint32_t c = (uint32_t)(acc >> PM_TOPBITS);       // < 64 + 19 V1 V2 < 2^17
+  const uint32_t r0 = r.v[0] + 19u * c;                   // < 2^30
+  r.v[0] = r0 & LMASK;
+  r.v[1] += r0 >> LW;
+}
 
 template <int L1, int V1, int L2, int V2>
 VRF_HD Fe<1, mul_v(V1, V2)> fe_mul(const Fe<L1, V1>& a, const Fe<L2, V2>& b) {
   static_assert(L1 * L2 <= 6, "fe_mul: 64-bit column accumulator could overflow");
   Fe<1, mul_v(V1, V2)> r;
+  if constexpr (vrfk::FIELD_KIND == 2) {
+    uint32_t h[NL];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+      for (int i = k - NL + 1; i < NL; ++i) acc = mad(a.v[i], b.v[k - i], acc);
+      h[k - NL] = (uint32_t)acc & LMASK;
+      acc >>= LW;
+    }
+    h[NL - 1] = (uint32_t)acc;                            // < 2^30: a.v[8] b.v[8] < 2^58
+    acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+#pragma unroll
+      for (int i = 0; i <= k; ++i) acc = mad(a.v[i], b.v[k - i], acc);
+      acc = mad(h[k], PM_FOLD, acc);
+      if (k < NL - 1) {
+        r.v[k] = (uint32_t)acc & LMASK;
+        acc >>= LW;
+      }
+    }
+    pm_finish(r, acc);
+    return r;
+  } else {
   uint32_t m[NL];
   uint64_t acc = 0;
 #pragma unroll
@@ -180,8 +232,9 @@ VRF_HD Fe<1, mul_v(V1, V2)> fe_mul(const Fe<L1, V1>& a, const Fe<L2, V2>& b) {
     for (int i = 0; i <= k; ++i) acc = mad(a.v[i], b.v[k - i], acc);
 #pragma unroll
     for (int i = 0; i < k; ++i) acc = mad(m[i], vrfk::Q29[k - i], acc);
-    m[k] = ~(uint32_t)acc & LMASK;     // -(column) mod 2^29: the accumulator carries the bias LMASK
-    acc >>= LW;                        // == (column + m[k] * Q29[0]) >> LW, Q29[0] == 1 (see mont_bias)
+    m[k] = mont_digit((uint32_t)acc);
+    if constexpr (vrfk::FIELD_KIND != 0) acc = mad(m[k], vrfk::Q29[0], acc);
+    acc >>= LW;                        // kind 0: == (column + m[k] * Q29[0]) >> LW, Q29[0] == 1 (see mont_bias)
   }
 #pragma unroll
   for (int k = NL; k < 2 * NL - 1; ++k) {
@@ -194,15 +247,44 @@ VRF_HD Fe<1, mul_v(V1, V2)> fe_mul(const Fe<L1, V1>& a, const Fe<L2, V2>& b) {
   }
   r.v[NL - 1] = (uint32_t)acc;
   return r;
+  }
 }
 
 template <int L, int V>
 VRF_HD Fe<1, mul_v(V, V)> fe_sqr(const Fe<L, V>& a) {
   static_assert(L * L <= 6, "fe_sqr: 64-bit column accumulator could overflow");
   Fe<1, mul_v(V, V)> r;
-  uint32_t m[NL], a2[NL];
+  uint32_t a2[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) a2[i] = a.v[i] << 1;
+  if constexpr (vrfk::FIELD_KIND == 2) {
+    uint32_t h[NL];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; ++k) {
+#pragma unroll
+      for (int i = k - NL + 1; 2 * i < k; ++i) acc = mad(a2[i], a.v[k - i], acc);
+      if ((k & 1) == 0) acc = mad(a.v[k / 2], a.v[k / 2], acc);
+      h[k - NL] = (uint32_t)acc & LMASK;
+      acc >>= LW;
+    }
+    h[NL - 1] = (uint32_t)acc;
+    acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+#pragma unroll
+      for (int i = 0; 2 * i < k; ++i) acc = mad(a2[i], a.v[k - i], acc);
+      if ((k & 1) == 0) acc = mad(a.v[k / 2], a.v[k / 2], acc);
+      acc = mad(h[k], PM_FOLD, acc);
+      if (k < NL - 1) {
+        r.v[k] = (uint32_t)acc & LMASK;
+        acc >>= LW;
+      }
+    }
+    pm_finish(r, acc);
+    return r;
+  } else {
+  uint32_t m[NL];
   uint64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < NL; ++k) {
@@ -212,7 +294,8 @@ VRF_HD Fe<1, mul_v(V, V)> fe_sqr(const Fe<L, V>& a) {
     if ((k & 1) == 0) acc = mad(a.v[k / 2], a.v[k / 2], acc);
 #pragma unroll
     for (int i = 0; i < k; ++i) acc = mad(m[i], vrfk::Q29[k - i], acc);
-    m[k] = ~(uint32_t)acc & LMASK;
+    m[k] = mont_digit((uint32_t)acc);
+    if constexpr (vrfk::FIELD_KIND != 0) acc = mad(m[k], vrfk::Q29[0], acc);
     acc >>= LW;
   }
 #pragma unroll
@@ -227,6 +310,7 @@ VRF_HD Fe<1, mul_v(V, V)> fe_sqr(const Fe<L, V>& a) {
   }
   r.v[NL - 1] = (uint32_t)acc;
   return r;
+  }
 }
 
 // ------------------------------------------------------------------ canonical forms
@@ -305,7 +389,7 @@ VRF_HD void limbs_to_u256(uint32_t w[8], const uint32_t x[NL]) {
 
 // integer < 2^256 (need not be < q) -> Montgomery
 VRF_HD FeN fe_from_u256(const uint32_t w[8]) {
-  Fe<1, 3> t;                         // 2^256 < 2.21 q
+  Fe<1, vrfk::V256> t;                // 2^256 < 2.21 q (BLS12-381 Fr), 5.3 q (BN254 Fr)
   u256_to_limbs(t.v, w);
   return fe_mul(t, fe_const(vrfk::R2_29));
 }
@@ -327,7 +411,7 @@ VRF_HD void fe_to_u256(uint32_t w[8], const Fe<L, V>& a) {
 //   in : words -> Fe (x 2^261) and the canonical words of x (the sign of x, the encoding of y need them)
 //   out: Fe -> words
 VRF_HD FeN fe_from_abi(uint32_t canon[8], const uint32_t w[8], bool mont256) {
-  Fe<1, 3> t;
+  Fe<1, vrfk::V256> t;
   u256_to_limbs(t.v, w);
   FeN k;
 #pragma unroll
@@ -351,7 +435,7 @@ VRF_HD void fe_to_mont256(uint32_t w[8], const Fe<L, V>& a) {
 }
 // canonical words of x -> the words of its Montgomery-256 image (outputs that were produced canonically)
 VRF_HD void u256_canon_to_mont256(uint32_t w[8]) {
-  Fe<1, 3> t;
+  Fe<1, vrfk::V256> t;
   u256_to_limbs(t.v, w);
   FeN k;
 #pragma unroll
@@ -361,7 +445,7 @@ VRF_HD void u256_canon_to_mont256(uint32_t w[8]) {
 
 // 512-bit integer (16 x u32 LE) mod q -> Montgomery (hash_to_field, 48-byte inputs fit)
 VRF_HD Fe<1, 4> fe_from_u512(const uint32_t w[16]) {
-  Fe<1, 3> lo, hi;
+  Fe<1, vrfk::V256> lo, hi;
   u256_to_limbs(lo.v, w);
   u256_to_limbs(hi.v, w + 8);
   FeN a = fe_mul(lo, fe_const(vrfk::R2_29));
@@ -406,26 +490,15 @@ VRF_HD FeN fe_inv_pow(const Fe<L, V>& a) {   // a^(q-2); 0 -> 0
 }
 
 // ------------------------------------------------------------------ square root
-// Table-driven Tonelli-Shanks for 2-adicity 32.  tbl = SQRT_P (4 x 256 x 9 words, h^(j 2^(8k))),
-// lut = SQRT_LUT.  Returns is_square(w) and sets `root` to sqrt(w) if w is a square, else to
-// sqrt(Z*w) (Z = 5, the suite's Elligator non-residue).  Constant shape: 220 + 24 squarings.
-// Byte strings of the suite descriptor (include/vrfhip.h vrfhip_suite_desc), packed by the host into big-endian
-// 64-bit words -- the unit SHA-512 absorbs -- and carried BY VALUE inside the kernel arguments: uniform reads from
-// the kernarg segment are scalar loads, where a pointer into device memory cost every lane a vector load per byte.
-struct SuiteStr {
-  uint32_t suite_id_len;       // bytes, <= 64
-  uint32_t dst_prime_len;      // bytes of DST' = DST || byte(len(DST)), <= 129 (Elligator suites; 0 otherwise)
-  uint64_t suite_id_w[8];      // `Suite::SUITE_ID`, zero padded
-  uint64_t dst_prime_w[17];    // RFC 9380 DST' (upstream DST: "ECVRF_" || h2c suite id || SUITE_ID)
-};
-struct SqrtTables {
-  const uint32_t* P;     // [4][256][9]
-  const uint8_t* lut;    // [1 << SQRT_LUT_BITS]
-  // The suite's byte strings travel with these tables because the same helpers (hash-to-curve, point decoding)
-  // receive them.
-  SuiteStr str;
-};
-
+// Table-driven Tonelli-Shanks.  q - 1 = 2^S t, g = Z^t generates the 2^S-torsion (Z the field's non-residue: 5, 2, 5),
+// h = 1/g.  w^t = g^e; the discrete logarithm e is read off digit by digit: a power of w^t that depends on the digits
+// found so far and the next one only, corrected by table entries h^(j 2^level), lands in the 2^8-torsion, where a
+// perfect hash of the canonical low limb (lut = SQRT_LUT) gives the digit.  Then sqrt(w) = w^((t+1)/2) h^(e/2).
+//   S = 32 (BLS12-381 Fr): byte digits; tables k = 0..3 at levels 0, 8, 16, 24.  220 + 24 squarings.
+//   S = 28 (BN254 Fr): digits 8 | 8 | 8 | 4; the same four tables plus levels 4 and 12 (k = 4, 5).
+//   S = 2 (2^255 - 19): the 4-torsion is four constants, no table.
+// Returns is_square(w) and sets `root` to sqrt(w) if w is a square, else to sqrt(Z*w) (Z doubles as the Elligator
+// non-residue of the Bandersnatch suite).  Constant shape.
 VRF_HD uint32_t sqrt_lut_index(const SqrtTables& T, const FeN& y) {
   FeN c = fe_canon(y);
   uint32_t h = (c.v[0] * vrfk::SQRT_LUT_MULT) >> (32 - vrfk::SQRT_LUT_BITS);
@@ -434,26 +507,15 @@ VRF_HD uint32_t sqrt_lut_index(const SqrtTables& T, const FeN& y) {
 VRF_HD FeN sqrt_tbl(const SqrtTables& T, int k, uint32_t j) {
   return fe_load<1, 2>(T.P + ((size_t)k * 256 + j) * NL);
 }
+VRF_HD bool limbs_eq(const FeN& a, const uint32_t (&c)[NL]) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) o |= a.v[i] ^ c[i];
+  return o == 0;
+}
 
-template <int L, int V>
-VRF_HD bool fe_sqrt_or_zsqrt(FeN& root, const Fe<L, V>& w_in, const SqrtTables& T) {
-  FeN w = fe_mul(w_in, fe_one());
-  FeN v = fe_pow_prog(w, vrfk::POW_SQRT_PROG);        // w^((t-1)/2)
-  FeN x0 = fe_mul(w, v);                            // w^((t+1)/2)
-  FeN b = fe_mul(x0, v);                            // w^t, in the 2^32-torsion
-  FeN b8 = b;
-  for (int i = 0; i < 8; ++i) b8 = fe_sqr(b8);
-  FeN b16 = b8;
-  for (int i = 0; i < 8; ++i) b16 = fe_sqr(b16);
-  FeN b24 = b16;
-  for (int i = 0; i < 8; ++i) b24 = fe_sqr(b24);
-  // b = g^e, e = e0 + e1 2^8 + e2 2^16 + e3 2^24
-  uint32_t e0 = sqrt_lut_index(T, b24);
-  uint32_t e1 = sqrt_lut_index(T, fe_mul(b16, sqrt_tbl(T, 2, e0)));
-  uint32_t e2 = sqrt_lut_index(T, fe_mul(fe_mul(b8, sqrt_tbl(T, 1, e0)), sqrt_tbl(T, 2, e1)));
-  uint32_t e3 = sqrt_lut_index(
-      T, fe_mul(fe_mul(fe_mul(b, sqrt_tbl(T, 0, e0)), sqrt_tbl(T, 1, e1)), sqrt_tbl(T, 2, e2)));
-  uint32_t e = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+// root = w^((t+1)/2) h^(e/2) (e even) or sqrt(Z w) = Z^((t+1)/2) w^((t+1)/2) h^((e+1)/2) (e odd); returns e even
+VRF_HD bool sqrt_finish(FeN& root, const FeN& x0, uint32_t e, const SqrtTables& T) {
   bool odd = e & 1;
   uint32_t half = (e >> 1) + (e & 1);               // in [0, 2^31]
   FeN r = fe_mul(x0, sqrt_tbl(T, 0, half & 255));
@@ -465,16 +527,69 @@ VRF_HD bool fe_sqrt_or_zsqrt(FeN& root, const Fe<L, V>& w_in, const SqrtTables& 
   return !odd;    // w == 0: b = 0, lut garbage, but x0 = 0 => root = 0; caller treats 0 as square
 }
 
-
-// Low byte of the 2-adic discrete logarithm: w = (odd-order part) * g^e with g the generator of the
-// 2^32-torsion behind the square-root tables; returns e mod 256.  w (non-zero) is a 2^k-th power, k <= 8, iff
-// 2^k divides the result.  One fixed exponentiation (220 + 24 squarings), constant shape.
 template <int L, int V>
-VRF_HD uint32_t fe_dlog2_low8(const Fe<L, V>& w_in, const SqrtTables& T) {
+VRF_HD bool fe_sqrt_or_zsqrt(FeN& root, const Fe<L, V>& w_in, const SqrtTables& T) {
   FeN w = fe_mul(w_in, fe_one());
   FeN v = fe_pow_prog(w, vrfk::POW_SQRT_PROG);        // w^((t-1)/2)
-  FeN b = fe_mul(fe_mul(w, v), v);                  // w^t, in the 2^32-torsion
-  for (int i = 0; i < 24; ++i) b = fe_sqr(b);       // g^(e 2^24): depends on e mod 2^8 only
+  FeN x0 = fe_mul(w, v);                            // w^((t+1)/2)
+  FeN b = fe_mul(x0, v);                            // w^t, in the 2^S-torsion
+  if constexpr (vrfk::SQRT_S == 2) {
+#if VRF_FIELD == 1
+    uint32_t e;
+    // x0 = w^((q+3)/8); b = x0^2 / w is 1, -1 (root x0 / sqrt(-1)) or a primitive 4th root of unity (w a non-residue)
+    const FeN bc = fe_canon(b);
+    e = limbs_eq(bc, vrfk::SQRT_G1_M) ? 1u : limbs_eq(bc, vrfk::SQRT_G2_M) ? 2u : limbs_eq(bc, vrfk::SQRT_G3_M) ? 3u : 0u;
+    const bool odd = e & 1;
+    const uint32_t half = (e >> 1) + (e & 1);       // 0, 1, 1, 2
+    const FeN hm = fe_select(half == 0, fe_one(), fe_select(half == 1, fe_const(vrfk::SQRT_H1_M), fe_const(vrfk::SQRT_H2_M)));
+    FeN r = fe_mul(x0, hm);
+    FeN rz = fe_mul(r, fe_const(vrfk::SQRT_CZ_M));
+    root = fe_select(odd, rz, r);
+    return !odd;
+#endif
+  } else if constexpr (vrfk::SQRT_S == 28) {
+    FeN b4 = b;
+    for (int i = 0; i < 4; ++i) b4 = fe_sqr(b4);
+    FeN b12 = b4;
+    for (int i = 0; i < 8; ++i) b12 = fe_sqr(b12);
+    FeN b20 = b12;
+    for (int i = 0; i < 8; ++i) b20 = fe_sqr(b20);
+    // b = g^e, e = e0 + e1 2^8 + e2 2^16 + e3 2^24, e3 < 16; the 2^8-torsion is generated by g^(2^20)
+    uint32_t e0 = sqrt_lut_index(T, b20);
+    uint32_t e1 = sqrt_lut_index(T, fe_mul(b12, sqrt_tbl(T, 5, e0)));
+    uint32_t e2 = sqrt_lut_index(T, fe_mul(fe_mul(b4, sqrt_tbl(T, 4, e0)), sqrt_tbl(T, 5, e1)));
+    uint32_t e3 = sqrt_lut_index(
+        T, fe_mul(fe_mul(fe_mul(b, sqrt_tbl(T, 0, e0)), sqrt_tbl(T, 1, e1)), sqrt_tbl(T, 2, e2))) >> 4;
+    return sqrt_finish(root, x0, e0 | (e1 << 8) | (e2 << 16) | (e3 << 24), T);
+  } else {
+    static_assert(vrfk::SQRT_S == 2 || vrfk::SQRT_S == 28 || vrfk::SQRT_S == 32, "no square-root plan for this 2-adicity");
+    FeN b8 = b;
+    for (int i = 0; i < 8; ++i) b8 = fe_sqr(b8);
+    FeN b16 = b8;
+    for (int i = 0; i < 8; ++i) b16 = fe_sqr(b16);
+    FeN b24 = b16;
+    for (int i = 0; i < 8; ++i) b24 = fe_sqr(b24);
+    // b = g^e, e = e0 + e1 2^8 + e2 2^16 + e3 2^24
+    uint32_t e0 = sqrt_lut_index(T, b24);
+    uint32_t e1 = sqrt_lut_index(T, fe_mul(b16, sqrt_tbl(T, 2, e0)));
+    uint32_t e2 = sqrt_lut_index(T, fe_mul(fe_mul(b8, sqrt_tbl(T, 1, e0)), sqrt_tbl(T, 2, e1)));
+    uint32_t e3 = sqrt_lut_index(
+        T, fe_mul(fe_mul(fe_mul(b, sqrt_tbl(T, 0, e0)), sqrt_tbl(T, 1, e1)), sqrt_tbl(T, 2, e2)));
+    return sqrt_finish(root, x0, e0 | (e1 << 8) | (e2 << 16) | (e3 << 24), T);
+  }
+}
+
+
+// Low byte of the 2-adic discrete logarithm: w = (odd-order part) * g^e with g the generator of the
+// 2^S-torsion behind the square-root tables; returns e mod 256.  w (non-zero) is a 2^k-th power, k <= 8, iff
+// 2^k divides the result.  One fixed exponentiation (220 + 24 squarings for S = 32), constant shape.
+template <int L, int V>
+VRF_HD uint32_t fe_dlog2_low8(const Fe<L, V>& w_in, const SqrtTables& T) {
+  static_assert(L > 0 && vrfk::SQRT_S >= 8, "the field has no 2^8-torsion");
+  FeN w = fe_mul(w_in, fe_one());
+  FeN v = fe_pow_prog(w, vrfk::POW_SQRT_PROG);        // w^((t-1)/2)
+  FeN b = fe_mul(fe_mul(w, v), v);                  // w^t, in the 2^S-torsion
+  for (int i = 0; i < vrfk::SQRT_S - 8; ++i) b = fe_sqr(b);       // g^(e 2^(S-8)): depends on e mod 2^8 only
   return sqrt_lut_index(T, b);
 }
 
@@ -491,7 +606,9 @@ VRF_HD uint32_t fe_dlog2_low8(const Fe<L, V>& w_in, const SqrtTables& T) {
 // drops one 29-bit limb.  The step is branch-free and every lane of a wave runs the same shape; 24..30 rounds
 // for 255-bit inputs (measured on 3e4 random values; a wave pays the maximum of its lanes, ~29).  ~1000 cheap
 // 32-bit VOP2 instructions + 36 multiply-adds per round: about a third of the exponentiation.
-// chi(R) = chi(2)^261 = 1 because q = 1 (mod 8): the symbol of the Montgomery image is the symbol of the value.
+// chi(R) = chi(2)^261 = 1 because q = 1 (mod 8) for both Montgomery fields (and R = 1 for 2^255 - 19): the symbol of
+// the stored image is the symbol of the value.
+static_assert(vrfk::CHI_R == 1, "jacobi_limbs callers assume chi(R) = 1");
 constexpr int JAC_K = 29;
 constexpr int JAC_MAX_ROUNDS = 40;      // rounds needed: <= 30 in 3e4 samples, tail decays ~50x per round
 
@@ -588,7 +705,7 @@ VRF_HD bool fe_is_square_or_zero(const Fe<L, V>& w, const SqrtTables& T) {
 // 1 / a by the positive divsteps of the Jacobi symbol above with the cofactors kept: f = q, g = the canonical Montgomery
 // image a~, and f = d a~, g = e a~ (mod q) throughout.  The round's 2x2 matrix (entries <= 2^29, rows summing to at most
 // 2^29) is applied to (f, g) -- an exact division by 2^29 -- and to (d, e), where the multiple of q that makes the division
-// exact is -(low limb) because q = 1 (mod 2^29).  f = 1 ends a lane with d = a~^-1 < (rounds + 1) q.  About 27 rounds of
+// exact is (low limb) * (-q^-1 mod 2^29): -(low limb) when q = 1 (mod 2^29).  f = 1 ends a lane with d = a~^-1 < (rounds + 1) q.  About 27 rounds of
 // ~650 instructions (~18 k) against 255 squarings + 30 products (~60 k) for a^(q-2): one inversion per 8 proofs in the big
 // batches, but up to three per proof when a batch is small enough for one proof per lane.  0 -> 0, as the power gives.
 template <int L, int V>
@@ -620,8 +737,9 @@ VRF_HD FeN fe_inv(const Fe<L, V>& a) {
     uint32_t nf[NL], ng[NL], nd[NL], ne[NL];
     uint64_t af = mad(u, f[0], (uint64_t)v * g[0]) >> LW, ag = mad(q, f[0], (uint64_t)r * g[0]) >> LW;
     const uint64_t td = mad(u, d[0], (uint64_t)v * e[0]), te = mad(q, d[0], (uint64_t)r * e[0]);
-    const uint32_t md = (0u - (uint32_t)td) & LMASK, me = (0u - (uint32_t)te) & LMASK;     // Q29[0] == 1
-    uint64_t ad = (td + md) >> LW, ae = (te + me) >> LW;
+    // the multiple of q that clears the low limb: -(low limb) when q = 1 (mod 2^29), (low limb) * (-q^-1) in general
+    const uint32_t md = ((uint32_t)td * vrfk::NINV29) & LMASK, me = ((uint32_t)te * vrfk::NINV29) & LMASK;
+    uint64_t ad = mad(md, vrfk::Q29[0], td) >> LW, ae = mad(me, vrfk::Q29[0], te) >> LW;
 #pragma unroll
     for (int i = 1; i < NL; ++i) {
       af = mad(u, f[i], mad(v, g[i], af));
@@ -657,4 +775,4 @@ VRF_HD FeN fe_inv(const Fe<L, V>& a) {
   return fe_mul(fe_mul(dd, fe_const(vrfk::R2_29)), fe_const(vrfk::R2_29));
 }
 
-}  // namespace vrf
+VRF_NS_END

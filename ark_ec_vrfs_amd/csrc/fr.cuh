@@ -5,7 +5,7 @@
 #pragma once
 #include "fe.cuh"
 
-namespace vrf {
+VRF_NS_BEGIN
 
 // a * b / 2^256 mod r, a < 2^256, b < r; result in [0, r)
 template <class C>
@@ -200,7 +200,11 @@ VRF_HD GlvHalf glv_finish(const uint32_t v[5]) {
   return h;
 }
 
-// Bandersnatch constants (the only GLV curve among the suites)
+// Bandersnatch constants (the only GLV curve among the suites; the other fields' builds only see the declaration, inside
+// discarded `if constexpr (S::HAS_GLV)` branches)
+#if VRF_FIELD != 0
+VRF_HD void glv_decompose_bs(GlvHalf& k1, GlvHalf& k2, const uint32_t k[8]);
+#else
 VRF_HD void glv_decompose_bs(GlvHalf& k1, GlvHalf& k2, const uint32_t k[8]) {
   uint32_t c1[5], c2[5];
   glv_round_mul(c1, k, vrfk::BS_GLV_G1);
@@ -216,6 +220,7 @@ VRF_HD void glv_decompose_bs(GlvHalf& k1, GlvHalf& k2, const uint32_t k[8]) {
   k1 = glv_finish(v1);
   k2 = glv_finish(v2);
 }
+#endif
 
 // signed radix-16 recoding of a 128-bit magnitude (< 2^126.9): 32 digits in [-8, 7]
 VRF_HD void scalar_recode_signed4_128(uint32_t out[4], const uint32_t k[4]) {
@@ -235,4 +240,4 @@ VRF_HD int scalar_digit4_128(const uint32_t rec[4], int w) {   // w in 0..31
   return (int)((word >> ((w & 7) * 4)) & 15u) - 8;
 }
 
-}  // namespace vrf
+VRF_NS_END

@@ -1,7 +1,7 @@
 // k_misc.hip -- table construction and the small building-block kernels.
 #include "kernels.h"
 
-namespace vrf {
+VRF_NS_BEGIN
 
 // ---- one-time table construction (context creation) ----
 // gb_xy: the descriptor's generator and Pedersen blinding base, x || y as 32-byte little-endian canonical
@@ -17,7 +17,7 @@ __global__ void k_init_bases(const uint8_t* gb_xy, uint32_t* mont, uint8_t* flag
   const FeN x = fe_from_u256(xw), y = fe_from_u256(yw);
   // a x^2 + y^2 = 1 + d x^2 y^2   <=>   y^2 - ANEG x^2 - 1 = d (x y)^2
   const FeN x2 = fe_sqr(x), y2 = fe_sqr(y), xyv = fe_mul(x, y);
-  auto lhs = fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(S::mul_aneg(x2), fe_one())))));
+  auto lhs = te_curve_lhs<S>(x2, y2);
   ok = ok && fe_eq(lhs, fe_mul(fe_sqr(xyv), S::d())) && !fe_is_zero(x);
   uint32_t r[8];
 #pragma unroll
@@ -324,4 +324,22 @@ void launch_xy_from_mont256(size_t n, uint8_t* xy, hipStream_t st) {
   if (n && xy) hipLaunchKernelGGL(k_xy_from_mont256, grid_for(n), dim3(BLOCK), 0, st, n, xy);
 }
 
-}  // namespace vrf
+// ---- host copies of this field's tables and built-in descriptor points, for the C ABI (api.hip) ----
+const uint32_t* field_sqrt_p(size_t* bytes) { *bytes = sizeof(vrfk_tables::SQRT_P); return vrfk_tables::SQRT_P; }
+const uint8_t* field_sqrt_lut(size_t* bytes) { *bytes = sizeof(vrfk_tables::SQRT_LUT); return vrfk_tables::SQRT_LUT; }
+bool field_default_points(int suite, uint8_t g_xy[64], uint8_t b_xy[64]) {
+  const uint8_t *g = nullptr, *b = nullptr;
+#if VRF_FIELD == 0
+  if (suite == SUITE_BS) { g = vrfk_tables::BS_G_XY; b = vrfk_tables::BS_B_XY; }
+  if (suite == SUITE_JJ) { g = vrfk_tables::JJ_G_XY; b = vrfk_tables::JJ_B_XY; }
+#elif VRF_FIELD == 1
+  if (suite == SUITE_ED) { g = vrfk_tables::ED_G_XY; b = vrfk_tables::ED_B_XY; }
+#else
+  if (suite == SUITE_BJ) { g = vrfk_tables::BJ_G_XY; b = vrfk_tables::BJ_B_XY; }
+#endif
+  if (!g) return false;
+  for (int i = 0; i < 64; ++i) { g_xy[i] = g[i]; b_xy[i] = b[i]; }
+  return true;
+}
+
+VRF_NS_END

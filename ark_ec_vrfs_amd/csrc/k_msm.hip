@@ -22,7 +22,7 @@
 #include "msm.cuh"
 #include <cstdlib>
 
-namespace vrf {
+VRF_NS_BEGIN
 
 // ------------------------------------------------------------------------------- prep
 template <class S>
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_prep(size_t n, const uint8_t* xy,
   a.dt = fe_mul(fe_mul(a.x, a.y), S::d());
   // on-curve check: a*x^2 + y^2 == 1 + d*x^2*y^2  <=>  y^2 - ANEG x^2 - 1 - (d x y) * (x y) == 0
   FeN x2 = fe_sqr(a.x), y2 = fe_sqr(a.y), xy_ = fe_mul(a.x, a.y);
-  auto lhs = fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(S::mul_aneg(x2), fe_one())))));
+  auto lhs = te_curve_lhs<S>(x2, y2);
   ok = ok && fe_eq(lhs, fe_mul(a.dt, xy_));
   pta_store(pts + i * PTA_WORDS, a);
   if (!ok) flags[0] = 1;
@@ -278,20 +278,33 @@ VRF_HD PtE te_dbl_quad(const PtE& p, int q) {
   const FeN A = fe_assume<1, 2>(quad_bcast<0>(sq)), B = fe_assume<1, 2>(quad_bcast<1>(sq)),
             ZZ = fe_assume<1, 2>(quad_bcast<3>(sq));
   const auto Sx = quad_bcast<2>(sq);                                 // (X+Y)^2              (1,3)
-  auto E = fe_norm(fe_sub(fe_add(A, B), Sx));                        // A + B - S            (1,8)
-  auto aA = C::mul_aneg(A);
-  auto H = fe_norm(fe_add(aA, B));                                   // -a*A + B             (1,12)
-  auto G = fe_norm(fe_sub(aA, B));                                   // -a*A - B             (1,14)
-  auto F = fe_norm(fe_add(G, fe_dbl(ZZ)));                           // G + 2Z^2             (1,18)
-  static_assert(mul_v(8, 18) <= 5 && mul_v(14, 12) <= 5 && mul_v(18, 14) <= 5 && mul_v(8, 12) <= 5,
-                "quad doubling: products must stay inside FeP");
   // lane 0: X = E*F, lane 1: Y = G*H, lane 2: Z = F*G, lane 3: T = E*H.  All four factors are normalised
   // (L = 1) and each product obeys the value bounds of te_dbl, so the result fits FeP.
   Fe<1, 1> lhs, rhs;
+  auto place = [&](const auto& E, const auto& F, const auto& G, const auto& H) {
 #pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    lhs.v[i] = (q == 0 || q == 3) ? E.v[i] : q == 1 ? G.v[i] : F.v[i];
-    rhs.v[i] = q == 0 ? F.v[i] : q == 2 ? G.v[i] : H.v[i];
+    for (int i = 0; i < NL; ++i) {
+      lhs.v[i] = (q == 0 || q == 3) ? E.v[i] : q == 1 ? G.v[i] : F.v[i];
+      rhs.v[i] = q == 0 ? F.v[i] : q == 2 ? G.v[i] : H.v[i];
+    }
+  };
+  if constexpr (C::A_PLUS_ONE) {
+    auto G = fe_norm(fe_add(A, B));                                    // A + B                (1,4)
+    auto E = fe_norm(fe_sub(Sx, G));                                   // S - A - B = 2XY      (1,11)
+    auto F = fe_norm(fe_sub(G, fe_dbl(ZZ)));                           // G - 2Z^2             (1,12)
+    auto H = fe_norm(fe_sub(A, B));                                    // A - B                (1,6)
+    static_assert(mul_v(11, 12) <= 5 && mul_v(4, 6) <= 5 && mul_v(12, 4) <= 5 && mul_v(11, 6) <= 5,
+                  "quad doubling: products must stay inside FeP");
+    place(E, F, G, H);
+  } else {
+    auto E = fe_norm(fe_sub(fe_add(A, B), Sx));                        // A + B - S            (1,8)
+    auto aA = C::mul_aneg(A);
+    auto H = fe_norm(fe_add(aA, B));                                   // -a*A + B             (1,12)
+    auto G = fe_norm(fe_sub(aA, B));                                   // -a*A - B             (1,14)
+    auto F = fe_norm(fe_add(G, fe_dbl(ZZ)));                           // G + 2Z^2             (1,18)
+    static_assert(mul_v(8, 18) <= 5 && mul_v(14, 12) <= 5 && mul_v(18, 14) <= 5 && mul_v(8, 12) <= 5,
+                  "quad doubling: products must stay inside FeP");
+    place(E, F, G, H);
   }
   FeP prod = fe_mul(fe_unchecked(lhs), fe_unchecked(rhs));
   PtE r;
@@ -479,4 +492,4 @@ void launch_msm(int suite, size_t n, const uint8_t* xy, const uint8_t* scalars, 
   launch_msm_coords(suite, n, xy, scalars, out_enc, out_xy, status, ws, groups, 0, st);
 }
 
-}  // namespace vrf
+VRF_NS_END

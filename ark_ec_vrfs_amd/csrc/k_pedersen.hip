@@ -3,7 +3,7 @@
 // kernels of k_prove.hip (flag `pedersen`).
 #include "kernels.h"
 
-namespace vrf {
+VRF_NS_BEGIN
 
 template <class S, int MINW>
 __global__ void __launch_bounds__(BLOCK, MINW) k_ped_verify_decode(PedersenVerifyArgs a) {
@@ -94,4 +94,4 @@ void launch_pedersen_verify(const PedersenVerifyArgs& a, hipStream_t st, hipEven
   VRF_DISPATCH_SUITE(a.suite, launch_ped_t<S>(a, st, ev));
 }
 
-}  // namespace vrf
+VRF_NS_END

@@ -1,8 +1,8 @@
 // k_prove.hip -- IETF ECVRF batch proving kernels.
 // Replaces `Input::new`, `Secret::output` and `ietf::Prover::prove` (/root/reference src/lib.rs:14-16).
 //
-// Compiled once per (suite, stage) -- Makefile: -DVRF_PROVE_SUITE=1|2 -DVRF_PROVE_PART=1|2|3 -> k_prove_{bs,jj}_{1,2,3}.o --
-// so that the six sets of kernels build in parallel (this file was the long pole of the build).
+// Compiled once per (suite, stage) -- Makefile: -DVRF_FIELD=f -DVRF_PROVE_SUITE=1|2|3|4 -DVRF_PROVE_PART=1|2|3 ->
+// k_prove_{bs,jj,ed,bj}_{1,2,3}.o -- so that the sets of kernels build in parallel (this file was the long pole of the build).
 #include "kernels.h"
 #include <algorithm>
 
@@ -13,11 +13,17 @@
 #define VRF_PROVE_PART 1
 #endif
 
-namespace vrf {
+VRF_NS_BEGIN
 
 #if VRF_PROVE_SUITE == 2
 using ProveSuite = SuiteJJ;
 #define PROVE_STAGE(name) name##_jj
+#elif VRF_PROVE_SUITE == 3
+using ProveSuite = SuiteED;
+#define PROVE_STAGE(name) name##_ed
+#elif VRF_PROVE_SUITE == 4
+using ProveSuite = SuiteBJ;
+#define PROVE_STAGE(name) name##_bj
 #else
 using ProveSuite = SuiteBS;
 #define PROVE_STAGE(name) name##_bs
@@ -255,22 +261,30 @@ void PROVE_STAGE(launch_prove_stage3)(const ProveArgs& a, hipStream_t st) {
 }
 #endif  // part 3
 
-// the dispatcher lives in one object (Bandersnatch, stage 2)
-#if VRF_PROVE_SUITE == 1 && VRF_PROVE_PART == 2
+// the dispatcher of a field lives in one object (stage 2 of the field's first suite)
+#if VRF_PROVE_PART == 2 && (VRF_PROVE_SUITE == 1 || VRF_PROVE_SUITE == 3 || VRF_PROVE_SUITE == 4)
+#if VRF_PROVE_SUITE == 1
 void launch_prove_stage1_jj(const ProveArgs& a, hipStream_t st);
 void launch_prove_stage2_jj(const ProveArgs& a, hipStream_t st);
 void launch_prove_stage3_jj(const ProveArgs& a, hipStream_t st);
+#endif
 void launch_ietf_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (a.n == 0) return;
+#if VRF_PROVE_SUITE == 1
   const bool jj = a.suite == SUITE_JJ;
+#define PROVE_CALL(stage) do { if (jj) stage##_jj(a, st); else stage##_bs(a, st); } while (0)
+#else
+#define PROVE_CALL(stage) PROVE_STAGE(stage)(a, st)
+#endif
   if (ev) (void)hipEventRecord(ev[0], st);
-  if (jj) launch_prove_stage1_jj(a, st); else launch_prove_stage1_bs(a, st);
+  PROVE_CALL(launch_prove_stage1);
   if (ev) (void)hipEventRecord(ev[1], st);
-  if (jj) launch_prove_stage2_jj(a, st); else launch_prove_stage2_bs(a, st);
+  PROVE_CALL(launch_prove_stage2);
   if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
-  if (jj) launch_prove_stage3_jj(a, st); else launch_prove_stage3_bs(a, st);
+  PROVE_CALL(launch_prove_stage3);
   if (ev) (void)hipEventRecord(ev[4], st);
+#undef PROVE_CALL
 }
 #endif
 
-}  // namespace vrf
+VRF_NS_END

@@ -25,7 +25,7 @@
 #include "kernels.h"
 #include "msm.cuh"
 
-namespace vrf {
+VRF_NS_BEGIN
 
 constexpr int RLC_SLOT = 4 * NL + 1;     // y | num | den | prefix | (flag, ok)
 
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_rlc_prep_affine(RlcArgs a) {
       pa.dt = fe_mul(xyv, S::d());
       // a x^2 + y^2 = 1 + d x^2 y^2   <=>   y^2 - ANEG x^2 - 1 = (d x y)(x y)
       FeN x2 = fe_sqr(pa.x), y2 = fe_sqr(pa.y);
-      auto lhs = fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(S::mul_aneg(x2), fe_one())))));
+      auto lhs = te_curve_lhs<S>(x2, y2);
       valid = fe_eq(lhs, fe_mul(pa.dt, xyv)) && valid;
       if (a.check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF))
         valid = in_prime_subgroup<S>(pa.x, pa.y, a.T.sq) && valid;
@@ -267,4 +267,4 @@ void launch_pedersen_rlc(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, h
   VRF_DISPATCH_SUITE(a.suite, launch_rlc_t<S>(a, fail_flag, st, ev));
 }
 
-}  // namespace vrf
+VRF_NS_END

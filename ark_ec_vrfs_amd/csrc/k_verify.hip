@@ -2,7 +2,7 @@
 // Replaces the body of `ietf::Verifier::verify` (/root/reference src/lib.rs:14).
 #include "kernels.h"
 
-namespace vrf {
+VRF_NS_BEGIN
 
 // the proof's scalars for the Straus stages: c mod r (upstream decodes `Proof::c` with from_le_bytes_mod_order), s as is;
 // a non-canonical s is reported InvalidData by the finish stage: keep the digits in range here
@@ -142,4 +142,4 @@ void launch_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
   VRF_DISPATCH_SUITE(a.suite, launch_verify_t<S>(a, st, ev));
 }
 
-}  // namespace vrf
+VRF_NS_END

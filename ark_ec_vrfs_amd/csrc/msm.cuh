@@ -8,7 +8,7 @@
 #pragma once
 #include "vrf_core.cuh"
 
-namespace vrf {
+VRF_NS_BEGIN
 
 constexpr int MSM_C = 11;                         // window bits
 constexpr int MSM_W = 23;                         // windows: 11*23 = 253 bits
@@ -22,24 +22,7 @@ constexpr size_t MSM_MAX_PER_GROUP = size_t(1) << MSM_IDX_BITS;
 // Device-side layout of one MSM over n points (all regions inside one workspace allocation).
 constexpr int MSM_W_SHORT = 12;                   // windows a scalar < 2^128 can reach (11*12 = 132 bits)
 
-struct MsmLayout {
-  size_t n;
-  // Points [0, n_long) carry full-size scalars, points [n_long, n) scalars < 2^128 whose digits in the
-  // windows >= MSM_W_SHORT are zero by construction: those windows only partition [0, n_long), with
-  // proportionally fewer groups, so that every workgroup sorts and folds about the same number of points.
-  size_t n_long;
-  int groups;            // point groups per low window (w < MSM_W_SHORT); also the stride of `part`
-  int groups_hi;         // point groups per high window
-  size_t per_group;      // points per group in the low windows (<= MSM_MAX_PER_GROUP)
-  size_t per_group_hi;   // points per group in the high windows
-  size_t list_cap;       // list entries reserved per workgroup (max per-group size + MSM_BLOCK)
-  uint32_t* pts;         // [n][PTA_WORDS]   Montgomery affine-cached (x, y, d*x*y)
-  int16_t* digits;       // [MSM_W][n]       signed digits in [-1024, 1024]
-  uint32_t* lists;       // [MSM_W*groups][list_cap] bucket-sorted entries, lane-transposed
-  uint32_t* heads;       // [MSM_W*groups][MSM_BLOCK][MSM_PT_WORDS] first-run partial sums
-  uint32_t* part;        // [MSM_W][groups][MSM_PT_WORDS] per-workgroup window sums
-  uint8_t* flags;        // [256] flags[0] != 0: some input was invalid
-};
+// MsmLayout (device-side layout of one MSM over n points): vrf_types.h
 
 // canonical scalar k (< r) -> folded signed radix-2^11 digits of point i.  `negate` flips the sign of the
 // term (callers that subtract a term); `zero` drops the point from the sum.
@@ -116,36 +99,6 @@ VRF_HD void rlc_weights(uint32_t z[8], uint32_t zp[8], const uint8_t* seed, cons
 int msm_groups(size_t n, size_t n_long, int cus);
 size_t msm_workspace_bytes(size_t n, int groups);
 MsmLayout msm_layout(size_t n, size_t n_long, int groups, void* ws);
-// buckets + final over prepared points / digits.  out_enc: 32 B compressed sum (nullable); out_xy: 64 B
-// affine (nullable); status: 1 byte (nullable; 0 ok, 2 if flags[0] is set); fail_flag: 1 byte (nullable),
-// set to 1 unless the sum is the neutral element (never cleared here: callers OR several MSMs into it).
-// ev (nullable): ev[0] recorded after the bucket kernel, ev[1] and ev[2] after the final kernel.
-void launch_msm_core(int suite, const MsmLayout& L, uint8_t* out_enc, uint8_t* out_xy, uint8_t* status,
-                     uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev = nullptr);
+// launch_msm_core, launch_pedersen_rlc, launch_affine_compress: launchers.inc
 
-// Batched Pedersen verification by random linear combination (k_rlc.hip)
-struct RlcArgs {
-  int suite;
-  int k_lane;                 // proofs per lane in the decode stage
-  size_t n;                   // proofs in this launch group
-  uint64_t index0;            // index of the first proof in the caller's batch (weights depend on it)
-  const uint8_t *h, *gamma, *pk_com, *r, *ok, *s, *sb;   // affine_in: the five point arrays are 64-byte x || y
-  int affine_in;
-  uint32_t check_mask;        // CHK_INPUT | CHK_OUTPUT | CHK_PROOF: subgroup test of the decoded points
-  BytesViewLite ad;
-  uint8_t* status;            // [n] 0 = part of the batch sum, 2 = InvalidData (left out of it)
-  uint32_t* scratch;          // per-proof scratch, scratch_stride words each (>= 5 * 37)
-  int scratch_stride;
-  MsmLayout L;                // over 5n + 2 points
-  uint64_t* fixed_cols;       // [2][8] limb columns of sum z'_i s_i and sum z'_i sb_i
-  DevTables T;
-  uint8_t seed[32];
-  const uint8_t* root;        // [32] device memory: batch digest of this launch group (digest.cuh)
-};
-// enqueues decode + MSM; fail_flag[0] becomes 1 if the batch equation does not hold.
-// ev (nullable, 5 events): start | decode | buckets | final | final.
-void launch_pedersen_rlc(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev = nullptr);
-// n x 64 B affine x || y -> n x 32 B compressed encodings
-void launch_affine_compress(size_t n, const uint8_t* xy, uint8_t* enc, hipStream_t st);
-
-}  // namespace vrf
+VRF_NS_END

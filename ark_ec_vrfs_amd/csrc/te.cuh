@@ -12,10 +12,14 @@
 #pragma once
 #include "fe.cuh"
 
-namespace vrf {
+VRF_NS_BEGIN
 
+// A curve tag states: a (as A_SIGN * ANEG: -5, -1, -1, +1), the cofactor, d and the default bases as field constants,
+// and the subgroup order r for fr.cuh.  Only the curves of this translation unit's base field exist (field.h).
+#if VRF_FIELD == 0
 struct CurveBS {   // Bandersnatch
   static constexpr int ANEG = 5;
+  static constexpr bool A_PLUS_ONE = false;
   static constexpr int COFACTOR_LOG2 = 2;
   static VRF_HD FeN d() { return fe_const(vrfk::BS_D_M); }
   static VRF_HD FeN aneg_m() { return fe_const(vrfk::FIVE_M); }
@@ -33,6 +37,7 @@ struct CurveBS {   // Bandersnatch
 
 struct CurveJJ {   // JubJub (a = -1)
   static constexpr int ANEG = 1;
+  static constexpr bool A_PLUS_ONE = false;
   static constexpr int COFACTOR_LOG2 = 3;
   static VRF_HD FeN d() { return fe_const(vrfk::JJ_D_M); }
   static VRF_HD FeN aneg_m() { return fe_const(vrfk::ONE_M); }
@@ -47,6 +52,40 @@ struct CurveJJ {   // JubJub (a = -1)
   static VRF_HD uint32_t r_r2(int i) { return vrfk::JJ_R_R2[i]; }
   static constexpr uint32_t R_NINV32 = vrfk::JJ_R_NINV32;
 };
+#elif VRF_FIELD == 1
+struct CurveED {   // Ed25519 (RFC 8032): a = -1, cofactor 8
+  static constexpr int ANEG = 1;
+  static constexpr bool A_PLUS_ONE = false;
+  static constexpr int COFACTOR_LOG2 = 3;
+  static VRF_HD FeN d() { return fe_const(vrfk::ED_D_M); }
+  static VRF_HD FeN aneg_m() { return fe_const(vrfk::ONE_M); }
+  static VRF_HD FeN gx() { return fe_const(vrfk::ED_GX_M); }
+  static VRF_HD FeN gy() { return fe_const(vrfk::ED_GY_M); }
+  static VRF_HD FeN bx() { return fe_const(vrfk::ED_BX_M); }
+  static VRF_HD FeN by() { return fe_const(vrfk::ED_BY_M); }
+  template <int L, int V>
+  static VRF_HD Fe<L, V> mul_aneg(const Fe<L, V>& a) { return a; }
+  static VRF_HD uint32_t r32(int i) { return vrfk::ED_R32[i]; }
+  static VRF_HD uint32_t r_r1(int i) { return vrfk::ED_R_R1[i]; }
+  static VRF_HD uint32_t r_r2(int i) { return vrfk::ED_R_R2[i]; }
+  static constexpr uint32_t R_NINV32 = vrfk::ED_R_NINV32;
+};
+#elif VRF_FIELD == 2
+struct CurveBJ {   // Baby-JubJub as ark-ed-on-bn254 states it: a = +1, cofactor 8
+  static constexpr int ANEG = -1;               // -a
+  static constexpr bool A_PLUS_ONE = true;      // the group law below switches to its a = 1 form
+  static constexpr int COFACTOR_LOG2 = 3;
+  static VRF_HD FeN d() { return fe_const(vrfk::BJ_D_M); }
+  static VRF_HD FeN gx() { return fe_const(vrfk::BJ_GX_M); }
+  static VRF_HD FeN gy() { return fe_const(vrfk::BJ_GY_M); }
+  static VRF_HD FeN bx() { return fe_const(vrfk::BJ_BX_M); }
+  static VRF_HD FeN by() { return fe_const(vrfk::BJ_BY_M); }
+  static VRF_HD uint32_t r32(int i) { return vrfk::BJ_R32[i]; }
+  static VRF_HD uint32_t r_r1(int i) { return vrfk::BJ_R_R1[i]; }
+  static VRF_HD uint32_t r_r2(int i) { return vrfk::BJ_R_R2[i]; }
+  static constexpr uint32_t R_NINV32 = vrfk::BJ_R_NINV32;
+};
+#endif
 
 struct PtE {   // extended projective: x = X/Z, y = Y/Z, T = X*Y/Z
   FeP X, Y, Z, T;
@@ -98,18 +137,45 @@ VRF_HD PtE te_dbl(const PtE& p, bool need_t) {
   auto B = fe_sqr(p.Y);                               // (1,2)
   auto S = fe_sqr(fe_add(p.X, p.Y));                  // (1,3)
   auto ZZ = fe_sqr(p.Z);                              // (1,2)
-  auto E = fe_norm(fe_sub(fe_add(A, B), S));          // A + B - S            (1,8)
-  auto aA = C::mul_aneg(A);                           // -a*A
-  auto H = fe_add(aA, B);                             // -a*A + B             (<=6,12)
-  auto G = fe_norm(fe_sub(aA, B));                    // -a*A - B             (1,14)
-  auto F = fe_add(G, fe_dbl(ZZ));                     // G + 2Z^2             (3,18)
   PtE r;
-  r.X = fe_mul(E, F);
-  r.Y = fe_mul(G, H);
-  r.Z = fe_mul(F, G);
-  r.T = fe_zero();
-  if (need_t) r.T = fe_mul(E, H);
+  if constexpr (C::A_PLUS_ONE) {
+    // a = 1: E = 2XY = S - A - B, G = A + B, F = G - 2Z^2, H = A - B; X3 = E F, Y3 = G H, Z3 = F G, T3 = E H
+    auto G = fe_add(A, B);                            // (2,4)
+    auto E = fe_norm(fe_sub(S, G));                   // (1,11)
+    auto F = fe_norm(fe_sub(G, fe_norm(fe_dbl(ZZ)))); // (1,12)
+    auto H = fe_norm(fe_sub(A, B));                   // (1,6)
+    r.X = fe_mul(E, F);
+    r.Y = fe_mul(G, H);
+    r.Z = fe_mul(F, G);
+    r.T = fe_zero();
+    if (need_t) r.T = fe_mul(E, H);
+  } else {
+    auto E = fe_norm(fe_sub(fe_add(A, B), S));          // A + B - S            (1,8)
+    auto aA = C::mul_aneg(A);                           // -a*A
+    auto H = fe_add(aA, B);                             // -a*A + B             (<=6,12)
+    auto G = fe_norm(fe_sub(aA, B));                    // -a*A - B             (1,14)
+    auto F = fe_add(G, fe_dbl(ZZ));                     // G + 2Z^2             (3,18)
+    r.X = fe_mul(E, F);
+    r.Y = fe_mul(G, H);
+    r.Z = fe_mul(F, G);
+    r.T = fe_zero();
+    if (need_t) r.T = fe_mul(E, H);
+  }
   return r;
+}
+
+// H = B - a*A of the addition laws: B + ANEG*A, or B - A for a = 1
+template <class C, int L1, int V1, int L2, int V2>
+VRF_HD auto te_b_minus_aa(const Fe<L1, V1>& B, const Fe<L2, V2>& A) {
+  if constexpr (C::A_PLUS_ONE) return fe_norm(fe_sub(B, A));
+  else return fe_norm(fe_add(B, C::mul_aneg(A)));
+}
+
+// a x^2 + y^2 - 1 from x^2, y^2: the left side of the curve equation a x^2 + y^2 - 1 = d x^2 y^2 (on-curve tests)
+template <class C>
+VRF_HD auto te_curve_lhs(const FeN& x2, const FeN& y2) {
+  if constexpr (C::A_PLUS_ONE) return fe_norm(fe_sub(fe_add(y2, x2), fe_one()));
+  else return fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(C::mul_aneg(x2), fe_one())))));    // y^2 - (ANEG x^2 + 1)
 }
 
 // conditional negation of a storage-type element; result type covers both branches
@@ -136,7 +202,7 @@ VRF_HD PtE te_add_cached(const PtE& p, const PtC& q, bool neg, bool need_t = tru
   auto E = fe_norm(fe_sub(S, fe_add(A, B)));          // (1,11)
   auto F = fe_sub(D, Cc);                             // (3,6)
   auto G = fe_add(D, Cc);                             // (2,4)
-  auto H = fe_norm(fe_add(B, C::mul_aneg(A)));        // B - a*A              (1,12)
+  auto H = te_b_minus_aa<C>(B, A);                    // B - a*A              (1,12)
   PtE r;
   r.X = fe_mul(E, F);
   r.Y = fe_mul(G, H);
@@ -176,7 +242,7 @@ VRF_HD PtE te_add_affine(const PtE& p, const PtA& q, bool neg) {
   auto E = fe_norm(fe_sub(S, fe_add(A, B)));
   auto F = fe_sub(p.Z, Cc);                           // (3,9)
   auto G = fe_add(p.Z, Cc);                           // (2,7)
-  auto H = fe_norm(fe_add(B, C::mul_aneg(A)));
+  auto H = te_b_minus_aa<C>(B, A);
   PtE r;
   r.X = fe_mul(E, F);
   r.Y = fe_mul(G, H);
@@ -185,6 +251,7 @@ VRF_HD PtE te_add_affine(const PtE& p, const PtA& q, bool neg) {
   return r;
 }
 
+#if VRF_FIELD == 0
 // Bandersnatch GLV endomorphism psi(x, y) = (c(1 - y^2)/(xy), b(y^2 + b)/(y^2 - b)); on the
 // prime-order subgroup psi(P) = LAMBDA * P.  Projective: 2S + 8M.  x*y = 0 happens in the
 // subgroup only for the identity, which maps to the identity.
@@ -213,6 +280,11 @@ VRF_HD PtE te_psi(const PtE& p) {
   r.T = fe_select(exc, id.T, r.T);
   return r;
 }
+
+#else
+template <class C>
+VRF_HD PtE te_psi(const PtE& p);      // no endomorphism in this field's suites: named only in discarded branches
+#endif  // VRF_FIELD == 0
 
 // general extended + extended (used off the hot loop: table building, h2c)
 template <class C>
@@ -247,4 +319,4 @@ VRF_HD void te_encode_affine(uint32_t out[8], const FeN& x, const FeN& y) {
   if (u256_gt(xw, vrfk::QM1H32)) out[7] |= 0x80000000u;
 }
 
-}  // namespace vrf
+VRF_NS_END

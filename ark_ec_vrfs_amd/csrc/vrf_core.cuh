@@ -9,35 +9,11 @@
 #include "sha512.cuh"
 #include "te.cuh"
 
-namespace vrf {
+VRF_NS_BEGIN
 
 enum : uint32_t { ST_OK = 0, ST_VERIFICATION_FAILURE = 1, ST_INVALID_DATA = 2 };
 
-// variable-length byte strings: shared blob, per-item offsets, or fixed stride
-struct BytesViewLite {
-  const uint8_t* blob;
-  const uint32_t* off;   // n+1 offsets, or nullptr
-  uint32_t len;          // off == nullptr: length of every item
-  uint32_t stride;       // off == nullptr: distance between items (0 = all items share blob)
-};
-VRF_HD void bytes_lite_get(const BytesViewLite& v, size_t i, const uint8_t*& p, uint32_t& n) {
-  if (v.off) {
-    uint32_t a = v.off[i], b = v.off[i + 1];
-    p = v.blob + a;
-    n = b - a;
-  } else {
-    p = v.blob + i * (size_t)v.stride;
-    n = v.len;
-  }
-}
-
-// Shared, read-only device tables (built once per context, see kernels.hip: k_init_tables)
-struct DevTables {
-  SqrtTables sq;
-  const uint32_t* g_win;     // [2][8][PTC_WORDS]    j*G and j*psi(G), j = 1..8, cached form
-  const uint32_t* g_comb;    // [GC_ROWS][GC_COLS][PTA_WORDS] j*2^(GCB*w)*G affine, signed windows (gcomb_*)
-  const uint32_t* b_comb;    // same for the Pedersen blinding base
-};
+// BytesViewLite, DevTables (shared, read-only device tables built once per context): vrf_types.h
 
 constexpr int WIN_ENTRIES = 8;                       // signed radix-16: |digit| in 1..8
 constexpr int WIN_TABLE_WORDS = WIN_ENTRIES * PTC_WORDS;   // 288 words = 1152 B per base
@@ -48,18 +24,55 @@ constexpr int WIN_TABLE_WORDS = WIN_ENTRIES * PTC_WORDS;   // 288 words = 1152 B
 // construction runs.  Everything a `Suite` impl states as data -- SUITE_ID, the hash-to-curve DST, the generator
 // and the Pedersen blinding base -- comes from the context's descriptor (vrfhip_suite_desc): the byte strings
 // (SuiteStr, fe.cuh), and the fixed-base tables built from the descriptor's points at context creation.
+// How prime-order subgroup membership of a decoded point is decided (in_prime_subgroup)
+enum : int { SUBGROUP_2DESCENT = 0, SUBGROUP_TATE8 = 1, SUBGROUP_ORDER = 2 };
+
+#if VRF_FIELD == 0
 struct SuiteBS : CurveBS {
   static constexpr bool HAS_GLV = true;        // Bandersnatch endomorphism (te_psi, glv_decompose_bs)
-  static constexpr bool SUBGROUP_2DESCENT = true;   // E(Fq) = Z2 x Z2 x Zr: the prime-order subgroup is 2E
+  static constexpr int SUBGROUP = SUBGROUP_2DESCENT;   // E(Fq) = Z2 x Z2 x Zr: the prime-order subgroup is 2E
   static constexpr bool H2C_ELL2 = true;       // Input::new = Elligator 2 (else try-and-increment)
 };
 
 // JubJub: a = -1, cofactor 8, try-and-increment hash-to-curve, no GLV.
 struct SuiteJJ : CurveJJ {
   static constexpr bool HAS_GLV = false;
-  static constexpr bool SUBGROUP_2DESCENT = false;  // cofactor 8 with a point of order 4: check r*P = O
+  static constexpr int SUBGROUP = SUBGROUP_TATE8;   // cyclic 8-torsion, 8 | q - 1: Tate pairing with a point of order 8
+  static constexpr bool H2C_ELL2 = false;
+  static VRF_HD FeN tate_a3() { return fe_const(vrfk::JJ_TATE_A3_M); }
+  static VRF_HD FeN tate_b() { return fe_const(vrfk::JJ_TATE_B_M); }
+  static VRF_HD FeN tate_c4() { return fe_const(vrfk::JJ_TATE_C4_M); }
+  static VRF_HD FeN tate_c8() { return fe_const(vrfk::JJ_TATE_C8_M); }
+  static VRF_HD FeN tate_y4() { return fe_const(vrfk::JJ_TATE_Y4_M); }
+  static VRF_HD FeN tate_y8() { return fe_const(vrfk::JJ_TATE_Y8_M); }
+  static VRF_HD FeN tate_lam4() { return fe_const(vrfk::JJ_TATE_LAM4_M); }
+  static VRF_HD FeN tate_lam8() { return fe_const(vrfk::JJ_TATE_LAM8_M); }
+};
+#elif VRF_FIELD == 1
+// Ed25519 (`suites::ed25519`, upstream "Ed25519_SHA-512_TAI"): a = -1, cofactor 8, try-and-increment, no GLV.  The
+// rational 2-power torsion is cyclic of order 8 but 8 does not divide q - 1 (q = 5 mod 8), so the order-8 Tate pairing
+// does not exist over Fq: membership is arkworks' own test, r * P = O, with the fixed scalar's bits as scalar control flow.
+struct SuiteED : CurveED {
+  static constexpr bool HAS_GLV = false;
+  static constexpr int SUBGROUP = SUBGROUP_ORDER;
   static constexpr bool H2C_ELL2 = false;
 };
+#elif VRF_FIELD == 2
+// Baby-JubJub (`suites::baby_jubjub`, upstream "BabyJubJub_SHA-512_TAI"): a = 1, cofactor 8, try-and-increment, no GLV.
+struct SuiteBJ : CurveBJ {
+  static constexpr bool HAS_GLV = false;
+  static constexpr int SUBGROUP = SUBGROUP_TATE8;   // same torsion structure as JubJub; q - 1 has 2-adicity 28
+  static constexpr bool H2C_ELL2 = false;
+  static VRF_HD FeN tate_a3() { return fe_const(vrfk::BJ_TATE_A3_M); }
+  static VRF_HD FeN tate_b() { return fe_const(vrfk::BJ_TATE_B_M); }
+  static VRF_HD FeN tate_c4() { return fe_const(vrfk::BJ_TATE_C4_M); }
+  static VRF_HD FeN tate_c8() { return fe_const(vrfk::BJ_TATE_C8_M); }
+  static VRF_HD FeN tate_y4() { return fe_const(vrfk::BJ_TATE_Y4_M); }
+  static VRF_HD FeN tate_y8() { return fe_const(vrfk::BJ_TATE_Y8_M); }
+  static VRF_HD FeN tate_lam4() { return fe_const(vrfk::BJ_TATE_LAM4_M); }
+  static VRF_HD FeN tate_lam8() { return fe_const(vrfk::BJ_TATE_LAM8_M); }
+};
+#endif
 
 VRF_HD void put_suite_id(Sha512& h, const SuiteStr& ss) { sha512_put_packed(h, ss.suite_id_w, ss.suite_id_len); }
 
@@ -99,7 +112,9 @@ VRF_HD DecodeA decode_phase_a(const uint32_t enc[8]) {
   r.y = fe_from_u256(w);
   FeN y2 = fe_sqr(r.y);
   r.num = fe_norm(fe_sub(y2, fe_one()));                                 // y^2 - 1
-  FeN den = fe_canon(fe_add(fe_mul(y2, C::d()), C::aneg_m()));           // d*y^2 - a
+  FeN den;                                                               // d*y^2 - a
+  if constexpr (C::A_PLUS_ONE) den = fe_canon(fe_sub(fe_mul(y2, C::d()), fe_one()));
+  else den = fe_canon(fe_add(fe_mul(y2, C::d()), C::aneg_m()));
   bool dz = true;
 #pragma unroll
   for (int i = 0; i < NL; ++i) dz = dz && (den.v[i] == 0);
@@ -132,6 +147,7 @@ VRF_HD bool decode_phase_b(Fe<1, 4>& x_out, const DecodeA& a, const FeN& den_inv
 //     B (1 - y^2)   and   B (1 - y) ((1 + e2) y + (1 - e2))   are non-zero squares   (or y = 1: identity).
 // Two Jacobi symbols (fe.cuh: ~0.04 M instruction slots) instead of r*P = O (~0.6 M).  [codec: arkworks'
 // checked deserialisation, `codec` src/lib.rs:14]; tests compare with r*P = O on every coset.
+#if VRF_FIELD == 0
 template <class S>
 VRF_HD bool subgroup_by_2descent(const FeN& y, const SqrtTables& T) {
   const FeN one = fe_one();
@@ -144,6 +160,7 @@ VRF_HD bool subgroup_by_2descent(const FeN& y, const SqrtTables& T) {
   const bool s2 = fe_is_nonzero_square(t2, T);
   return is_identity || (s1 && s2);
 }
+#endif
 
 // check_mask bits (= the complement of include/vrfhip.h VRFHIP_FLAG_PREVALIDATED_*): which point classes get
 // the prime-order-subgroup test when they are decoded
@@ -300,14 +317,14 @@ VRF_HD bool subgroup_by_tate8(const FeN& x, const FeN& y, const SqrtTables& T) {
   const FeN Yn = fe_mul(fe_add(one, y), one);                              // 1 + y (reduced)
   const FeN W = fe_mul(fe_sub(one, y), x);                                 // (1 - y) x
   const FeN V2 = fe_mul(Yn, x);                                            // (1 + y) x
-  const FeN Xn = fe_mul(fe_add(V2, fe_mul(W, fe_const(vrfk::JJ_TATE_A3_M))), one);
-  const FeN V4 = fe_mul(fe_sub(Xn, fe_mul(W, fe_const(vrfk::JJ_TATE_C4_M))), one);
-  const FeN V8 = fe_mul(fe_sub(Xn, fe_mul(W, fe_const(vrfk::JJ_TATE_C8_M))), one);
-  const FeN t4 = fe_mul(fe_add(fe_mul(W, fe_const(vrfk::JJ_TATE_Y4_M)), fe_mul(V4, fe_const(vrfk::JJ_TATE_LAM4_M))), one);
-  const FeN t8 = fe_mul(fe_add(fe_mul(W, fe_const(vrfk::JJ_TATE_Y8_M)), fe_mul(V8, fe_const(vrfk::JJ_TATE_LAM8_M))), one);
+  const FeN Xn = fe_mul(fe_add(V2, fe_mul(W, S::tate_a3())), one);
+  const FeN V4 = fe_mul(fe_sub(Xn, fe_mul(W, S::tate_c4())), one);
+  const FeN V8 = fe_mul(fe_sub(Xn, fe_mul(W, S::tate_c8())), one);
+  const FeN t4 = fe_mul(fe_add(fe_mul(W, S::tate_y4()), fe_mul(V4, S::tate_lam4())), one);
+  const FeN t8 = fe_mul(fe_add(fe_mul(W, S::tate_y8()), fe_mul(V8, S::tate_lam8())), one);
   const FeN L4 = fe_mul(fe_sub(Yn, t4), one);
   const FeN L8 = fe_mul(fe_sub(Yn, t8), one);
-  const FeN Z = fe_mul(fe_mul(V2, W), fe_const(vrfk::JJ_TATE_B_M));
+  const FeN Z = fe_mul(fe_mul(V2, W), S::tate_b());
   const FeN Z2 = fe_sqr(Z), Z4 = fe_sqr(Z2);
   const FeN Z7 = fe_mul(fe_mul(Z4, Z2), Z);
   const FeN L8_4 = fe_sqr(fe_sqr(L8)), V4_4 = fe_sqr(fe_sqr(V4)), L4_2 = fe_sqr(L4);
@@ -317,11 +334,35 @@ VRF_HD bool subgroup_by_tate8(const FeN& x, const FeN& y, const SqrtTables& T) {
 }
 
 // Prime-order subgroup membership of a decoded point (x, y) [ref src/lib.rs:14 `codec`: arkworks' checked
-// deserialisation].  Bandersnatch: 2-descent on y (two Jacobi symbols).  JubJub: Tate pairing with the 8-torsion.
+// deserialisation].  Bandersnatch: 2-descent on y (two Jacobi symbols).  JubJub, Baby-JubJub: Tate pairing with the
+// 8-torsion.  Ed25519: r * P = O.
+// r * P = O by double-and-add over the bits of the (fixed) subgroup order: scalar control flow, every lane the same
+// shape.  arkworks' own `is_in_correct_subgroup_assuming_on_curve`; used where no cheaper character exists (Ed25519:
+// 252 doublings + 63 additions, the order 2^252 + 2^124.4.. is sparse at the top).
+template <class S>
+VRF_HD bool subgroup_by_order(const FeN& x, const FeN& y) {
+  const PtC pc = te_to_cached<S>(te_from_affine(x, y));
+  PtE acc = te_identity();
+#pragma unroll 1
+  for (int i = 255; i >= 0; --i) {
+    const bool bit = (S::r32(i >> 5) >> (i & 31)) & 1u;          // wave-uniform
+    acc = te_dbl<S>(acc, bit);
+    if (bit) acc = te_add_cached<S>(acc, pc, false);
+  }
+  return fe_is_zero(acc.X) && fe_eq(acc.Y, acc.Z);
+}
+
 template <class S>
 VRF_HD bool in_prime_subgroup(const FeN& x, const FeN& y, const SqrtTables& T) {
-  if constexpr (S::SUBGROUP_2DESCENT) return subgroup_by_2descent<S>(y, T);
-  else return subgroup_by_tate8<S>(x, y, T);
+  if constexpr (S::SUBGROUP == SUBGROUP_ORDER) return subgroup_by_order<S>(x, y);
+  else if constexpr (S::SUBGROUP == SUBGROUP_TATE8) return subgroup_by_tate8<S>(x, y, T);
+  else {
+#if VRF_FIELD == 0
+    return subgroup_by_2descent<S>(y, T);
+#else
+    return false;
+#endif
+  }
 }
 
 // ---- fixed-base tables of the suite's generators G and B: signed GCB-bit windows, no doublings ----
@@ -529,7 +570,8 @@ VRF_HD void comb_build_row(uint32_t* row /*[255][27]*/, uint32_t* prefix /*[255]
 
 // ------------------------------------------------------------------------ challenge
 // [ref src/lib.rs:14,16 `Suite::challenge` / utils::challenge_rfc_9381]  SURVEY.md A.4:
-// c = int_be(SHA512(suite_id || 0x02 || enc(P1..P5) || ad || 0x00)[0..32]) mod r
+// c = int_be(SHA512(suite_id || 0x02 || enc(P1..P5) || ad || 0x00)[0..CHALLENGE_LEN]) mod r   (32 bytes for the
+// Bandersnatch / JubJub / Baby-JubJub suites, 16 for Ed25519)
 // The transcript hashes take `point_encode` of the TYPED point.  arkworks decodes a compressed point with x = 0 (y = 1 or
 // y = q - 1) whatever its sign flag says and encodes it with the flag clear, so wire bytes are brought to that form
 // before they are hashed; every other accepted encoding is already canonical.  (parity on crafted inputs.)
@@ -539,6 +581,24 @@ VRF_HD void enc_canonical(uint32_t w[8]) {
 #pragma unroll
   for (int i = 1; i < 7; ++i) { d1 |= w[i]; dm |= w[i] ^ vrfk::Q32[i]; }
   if (d1 == 0 || dm == 0) w[7] = top;
+}
+
+// w >> (8 * nbytes), nbytes wave-uniform in 0..31
+VRF_HD void u256_shr_bytes(uint32_t w[8], uint32_t nbytes) {
+  const uint32_t ws = nbytes >> 2, bs = (nbytes & 3u) * 8u;
+  uint32_t t[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if ((uint32_t)j == i + ws) lo = w[j];
+      if ((uint32_t)j == i + ws + 1) hi = w[j];
+    }
+    t[i] = bs ? (lo >> bs) | (hi << (32u - bs)) : lo;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = t[i];
 }
 
 template <class S>
@@ -563,6 +623,7 @@ VRF_HD void challenge5(uint32_t c_out[8], const uint32_t (&pts)[5][8], const uin
   sha512_final(h);
   uint32_t be[8];
   sha512_be256(be, h);
+  if (ss.challenge_len != 32u) u256_shr_bytes(be, 32u - ss.challenge_len);    // `Suite::CHALLENGE_LEN` leading bytes only
   fr_reduce256<S>(c_out, be);
 }
 
@@ -763,9 +824,9 @@ VRF_HD bool verify_decode_affine_item(uint32_t enc_out[3][8], const uint32_t (&x
     }
     valid = valid && !u256_ge(xin, vrfk::Q32) && !u256_ge(yin, vrfk::Q32);
     FeN x = fe_from_abi(xw, xin, mont256), y = fe_from_abi(yw, yin, mont256);     // xw, yw: canonical words
-    // a x^2 + y^2 = 1 + d x^2 y^2   <=>   y^2 - ANEG x^2 - 1 = d (x y)^2
+    // a x^2 + y^2 = 1 + d x^2 y^2   <=>   a x^2 + y^2 - 1 = d (x y)^2
     FeN x2 = fe_sqr(x), y2 = fe_sqr(y), xyv = fe_mul(x, y);
-    auto lhs = fe_norm(fe_add(y2, fe_neg(fe_norm(fe_add(S::mul_aneg(x2), fe_one())))));
+    auto lhs = te_curve_lhs<S>(x2, y2);
     valid = fe_eq(lhs, fe_mul(fe_mul(fe_sqr(xyv), S::d()), fe_one())) && valid;
     build_glv_tables<S>(tabs + p * 2 * WIN_TABLE_WORDS, x, y);
     if ((check_mask >> p) & 1u) valid = in_prime_subgroup<S>(x, y, T) && valid;
@@ -934,6 +995,7 @@ VRF_HD bool fe_parity(const FeN& a) {       // canonical integer is odd
   return w[0] & 1;
 }
 
+#if VRF_FIELD == 0
 // Elligator 2 for one u, given D = 1 + Z*u^2 (already replaced by 1 if zero) and 1/D.
 template <class S>
 VRF_HD PtE ell2_map(const Fe<1, 4>& u, const FeN& Dinv, const SqrtTables& T) {
@@ -1001,6 +1063,11 @@ VRF_HD PtE hash_to_curve_ell2(const uint8_t* msg, uint32_t msg_len, const SqrtTa
   for (int i = 0; i < S::COFACTOR_LOG2; ++i) acc = te_dbl<S>(acc, true);
   return acc;
 }
+
+#else
+template <class S>
+VRF_HD PtE hash_to_curve_ell2(const uint8_t* msg, uint32_t msg_len, const SqrtTables& T);   // Elligator suites: field 0 only
+#endif
 
 // [ref src/lib.rs:14 `utils::hash_to_curve_tai_rfc_9381`]  SURVEY.md A.6 (unpinned): for ctr = 0..255:
 // h = SHA512(suite_id || 0x01 || data || ctr || 0x00); decode h[0..32] as a point; clear the
@@ -1082,6 +1149,7 @@ VRF_HD void nonce_rfc8032(uint32_t k[8], const uint32_t sk[8], const uint32_t h_
   fr_reduce512<S>(k, le);
 }
 
+#if VRF_FIELD == 0
 // Elligator-2 denominator D = 1 + Z*u^2 (replaced by 1 if zero)
 VRF_HD FeN ell2_den(const Fe<1, 4>& u) {
   FeN d = fe_canon(fe_add(fe_mul5(fe_sqr(u)), fe_one()));
@@ -1090,6 +1158,7 @@ VRF_HD FeN ell2_den(const Fe<1, 4>& u) {
   for (int k = 0; k < NL; ++k) dz = dz && (d.v[k] == 0);
   return fe_select(dz, fe_one(), d);
 }
+#endif
 
 // affine coordinates of a projective point (one inversion)
 VRF_HD void te_to_affine(FeN& x, FeN& y, const PtE& p) {
@@ -1218,6 +1287,7 @@ VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, 
 // (the 2K Elligator denominators, then the K projective Z of H).  scratch: the lane's K pts slots
 // (108 words per item): u0 | u1 | D0 | D1 | pre0 | pre1 | X | Y | Z | preZ.
 constexpr int PROVE_K = 8;
+#if VRF_FIELD == 0
 template <class S>
 VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t n, const uint8_t* sk_arr,
                                 const BytesViewLite& msgs, uint32_t* tabs_base, uint32_t* pts_base,
@@ -1301,6 +1371,12 @@ VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t 
     }
   }
 }
+#else
+template <class S>
+VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t n, const uint8_t* sk_arr,
+                                const BytesViewLite& msgs, uint32_t* tabs_base, uint32_t* pts_base,
+                                uint32_t* aux_base, int aux_stride, uint8_t* flags);   // the Elligator path: field 0 only
+#endif
 
 // scalar * P from the GLV table pair {P, psi P} (or the single 253-bit table of a suite without endomorphism)
 template <class S>
@@ -1626,4 +1702,4 @@ VRF_HD void public_from_secret_item(uint32_t pk[8], const DevTables& T, const ui
   te_encode_affine(pk, x, y);
 }
 
-}  // namespace vrf
+VRF_NS_END

@@ -54,7 +54,18 @@ typedef enum vrfhip_suite {
    * descriptor uses the suite string "JubJub_SHA-512_TAI" and, as blinding base, the TAI hash of
    * "vrfhip-jubjub-blinding-base" -- a caller that knows the upstream constants supplies them through
    * vrfhip_ctx_create_desc. */
-  VRFHIP_SUITE_JUBJUB_SHA512_TAI = 2
+  VRFHIP_SUITE_JUBJUB_SHA512_TAI = 2,
+  /* `suites::ed25519` ("Ed25519_SHA-512_TAI"): edwards25519 over 2^255 - 19, cofactor 8, try-and-increment, ArkworksCodec,
+   * `CHALLENGE_LEN = 16`.  The suite string, the challenge length and the (absent) salt are recollections of upstream and the
+   * built-in blinding base is the TAI hash of "vrfhip-ed25519-blinding-base": parity with upstream unpinned.  The SAME
+   * kernels run RFC 9381's ECVRF-EDWARDS25519-SHA512-TAI when the descriptor says so (suite string 0x03, the three
+   * VRFHIP_SUITE_FLAG_* below, the public key prepended to the message as salt), and that suite's published vectors
+   * (RFC 9381 Appendix B.3) are golden vectors of this library: tests/golden/rfc9381_edwards25519_sha512_tai.json. */
+  VRFHIP_SUITE_ED25519_SHA512_TAI = 3,
+  /* `suites::baby_jubjub` ("BabyJubJub_SHA-512_TAI"): ark-ed-on-bn254 (a = 1, d = 168696/168700 over BN254 Fr), cofactor 8,
+   * try-and-increment, `CHALLENGE_LEN = 32`.  Suite string and blinding base as for JubJub: recollection / built-in TAI
+   * point, replaceable through the descriptor; parity unpinned. */
+  VRFHIP_SUITE_BABY_JUBJUB_SHA512_TAI = 4
 } vrfhip_suite;
 
 /* Suite descriptor: what a `Suite` / `PedersenSuite` impl states as DATA (src/lib.rs:16 `Suite`, :14 `suites`):
@@ -65,8 +76,17 @@ typedef enum vrfhip_suite {
  *  -- and makes the built-in suites nothing more than two pre-filled descriptors. */
 typedef enum vrfhip_curve {
   VRFHIP_CURVE_BANDERSNATCH = 1, /* ark-ed-on-bls12-381-bandersnatch: a = -5, cofactor 4; Elligator 2 (RFC 9380) */
-  VRFHIP_CURVE_JUBJUB = 2        /* ark-ed-on-bls12-381 (JubJub): a = -1, cofactor 8; try-and-increment (RFC 9381) */
+  VRFHIP_CURVE_JUBJUB = 2,       /* ark-ed-on-bls12-381 (JubJub): a = -1, cofactor 8; try-and-increment (RFC 9381) */
+  VRFHIP_CURVE_ED25519 = 3,      /* ark-ed25519: q = 2^255 - 19, a = -1, cofactor 8; try-and-increment */
+  VRFHIP_CURVE_BABY_JUBJUB = 4   /* ark-ed-on-bn254: q = BN254 Fr, a = 1, cofactor 8; try-and-increment */
 } vrfhip_curve;
+
+/* What a `Suite` impl may override besides its constants (`Suite::Codec`, `Suite::challenge`, `Suite::point_to_hash`):
+ * the deviations of RFC 9381's edwards suites from upstream's built-in ones.  0 for every built-in descriptor. */
+#define VRFHIP_SUITE_FLAG_SIGN_PARITY 1u   /* compressed points carry x mod 2 in bit 255 (RFC 8032) instead of x > q - x */
+#define VRFHIP_SUITE_FLAG_CHALLENGE_LE 2u  /* the truncated challenge hash is a little-endian integer */
+#define VRFHIP_SUITE_FLAG_HASH_COFACTOR 4u /* Output::hash hashes cofactor * Gamma (RFC 9381 proof_to_hash) */
+#define VRFHIP_SUITE_FLAG_ALL 7u
 
 typedef struct vrfhip_suite_desc {
   uint32_t struct_size;      /* sizeof(vrfhip_suite_desc) of the caller's header */
@@ -74,11 +94,13 @@ typedef struct vrfhip_suite_desc {
   uint32_t suite_id_len;     /* 1..64 */
   uint8_t suite_id[64];      /* `Suite::SUITE_ID` */
   uint32_t h2c_dst_len;      /* Bandersnatch: 1..128, the RFC 9380 DST (upstream: "ECVRF_" || h2c suite id || SUITE_ID);
-                                JubJub: ignored */
+                                try-and-increment curves: ignored */
   uint8_t h2c_dst[128];
   uint8_t generator[64];     /* `Suite::generator()`: x || y, 32-byte little-endian canonical integers */
   uint8_t blinding_base[64]; /* `PedersenSuite::BLINDING_BASE`, same form */
-  uint32_t challenge_len;    /* `Suite::CHALLENGE_LEN`; 32 is the only supported value */
+  uint32_t challenge_len;    /* `Suite::CHALLENGE_LEN`, 1..32: c = the first challenge_len bytes of the challenge hash
+                                (big-endian unless VRFHIP_SUITE_FLAG_CHALLENGE_LE) mod r; `Proof::c` stays a 32-byte scalar */
+  uint32_t flags;            /* VRFHIP_SUITE_FLAG_* */
 } vrfhip_suite_desc;
 
 typedef enum vrfhip_status {

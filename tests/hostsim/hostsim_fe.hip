@@ -13,6 +13,7 @@ static void hs_pack(uint64_t* w, const uint8_t* b, size_t n) {
 }
 static SuiteStr hs_make_str(const uint8_t* id, uint32_t id_len, const uint8_t* dst, uint32_t dst_len) {
   SuiteStr s{};
+  s.challenge_len = 32;
   s.suite_id_len = id_len; hs_pack(s.suite_id_w, id, id_len);
   if (dst_len) {
     uint8_t dp[129]; memcpy(dp, dst, dst_len); dp[dst_len] = (uint8_t)dst_len;

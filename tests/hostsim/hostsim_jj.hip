@@ -7,6 +7,7 @@ typedef SuiteJJ SJ;
 namespace {
 static SuiteStr hj_make_str(const uint8_t* id, uint32_t id_len) {
   SuiteStr s{};
+  s.challenge_len = 32;
   s.suite_id_len = id_len;
   for (uint32_t i = 0; i < id_len; ++i) s.suite_id_w[i >> 3] |= (uint64_t)id[i] << (56 - 8 * (i & 7));
   return s;

@@ -115,7 +115,7 @@ def test_descriptor_layout_enums_and_constants_match():
     r_fields = []
     for m in re.finditer(r"pub (\w+): (?:\[(\w+); (\d+)\]|(\w+)),", rb):
         r_fields.append((m.group(1), R_WIDTH[m.group(2) or m.group(4)], int(m.group(3) or 0)))
-    assert c_fields == r_fields and len(c_fields) == 9
+    assert c_fields == r_fields and len(c_fields) == 10
     assert "#[repr(C)]" in FFI.split("pub struct vrfhip_suite_desc")[0][-60:]
     # same layout as the ctypes mirror, whose size is checked against the library in test_abi
     from ark_ec_vrfs_amd import _lib

@@ -1,80 +1,42 @@
 #!/usr/bin/env python3
-"""Build-time generator for ark_ec_vrfs_amd/csrc/constants.gen.h.
+"""Build-time generator for the constant headers of ark_ec_vrfs_amd/csrc:
 
-Derives every numeric constant the HIP kernels need from the curve parameters of
-SURVEY.md Appendix C with Python big ints: radix-2^29 limb forms, Montgomery (R = 2^261)
-images, the lazy-subtraction bias words, the fixed exponents, and the 2-Sylow discrete-log
-tables of the table-driven square root.  Build tooling only: nothing here runs on the
-product path, and it does not import the oracle.
+    constants.gen.h          field 0: BLS12-381 Fr      (Bandersnatch, JubJub; + the BLS12-381 Fp tower constants)
+    constants_f25519.gen.h   field 1: 2^255 - 19        (Ed25519)
+    constants_fbn254.gen.h   field 2: BN254 Fr          (Baby-JubJub)
 
-Run:  python tools/gen_constants.py   (rewrites the header in place; output is committed)
+One header per BASE FIELD: the kernels are compiled once per field (-DVRF_FIELD=n, fe.cuh) and every header defines
+the same names in `namespace vrfk`.  Everything is derived with Python big ints from the curve parameters (SURVEY.md
+Appendix C for field 0; RFC 8032 / ark-ed-on-bn254 for the others, each checked algebraically below): radix-2^29 limb
+forms, the images x*R mod q (R = 2^261 for the Montgomery fields, R = 1 for the pseudo-Mersenne field 2^255 - 19), the
+lazy-subtraction bias words, the fixed exponents, the 2-Sylow discrete-log tables of the table-driven square root, the
+subgroup-test constants.  Build tooling only: nothing here runs on the product path, and it does not import the oracle.
+
+Run:  python tools/gen_constants.py   (rewrites the headers in place; output is committed)
 """
+import hashlib
+import math
 import os
-import sys
 
-Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 NL, W = 9, 29
 MASK = (1 << W) - 1
 RBITS = NL * W                      # 261
-R = 1 << RBITS
 U_SLACK = 1 << 13                   # "L = 1" means every limb < 2^29 + 2^13
 
-BS = dict(
-    a=Q - 5,
-    d=45022363124591815672509500913686876175488063829319466900776701791074614335719,
-    r=0x1CFB69D4CA675F520CCE760202687600FF8F87007419047174FD06B52876E7E1,
-    gx=18886178867200960497001835917649091219057080094937609519140440539760939937304,
-    gy=19188667384257783945677642223292697773471335439753913231509108946878080696678,
-    bx=6150229251051246713677296363717454238956877613358614224171740096471278798312,
-    by=28442734166467795856797249030329035618871580593056783094884474814923353898473,
-    J=29978822694968839326280996386011761570173833766074948509196803838190355340952,
-    K=25465760566081946422412445027709227188579564747101592991722834452325077642517,
-    Z=5,
-)
-JJ = dict(
-    a=Q - 1,
-    d=19257038036680949359750312669786877991949435402254120286184196891950884077233,
-    r=6554484396890773809930967563523245729705921265872317281365359162392183254199,
-    gx=8076246640662884909881801758704306714034609987455869804520522091855516602923,
-    gy=13262374693698910701929044844600465831413122818447359594527400194675274060458,
-)
+Q_BLS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+Q_25519 = (1 << 255) - 19
+Q_BN254 = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
-
-def inv(x, p=Q):
-    return pow(x, p - 2, p)
-
-
-def limbs29(x, n=NL):
-    out = []
-    for i in range(n):
-        if i == n - 1:
-            out.append(x)
-        else:
-            out.append(x & MASK)
-            x >>= W
-    assert out[-1] < (1 << 32)
-    return out
-
-
-def mont(x):
-    return x * R % Q
+KIND_MONT_Q1, KIND_MONT, KIND_PM25519 = 0, 1, 2
 
 
 def words32(x, n=8):
     return [(x >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
 
 
-def bias(k, lb):
-    """k*q written with limbs 0..7 >= lb*(2^29 + 2^13) (so a limb-wise subtraction of any
-    value whose limbs are < lb*(2^29+2^13) and whose top limb is <= ours never borrows)."""
-    off = lb * ((1 << W) + U_SLACK)
-    t = k * Q - sum(off << (W * i) for i in range(NL - 1))
-    assert t >= 0
-    dig = limbs29(t)
-    out = [off + dig[i] for i in range(NL - 1)] + [dig[NL - 1]]
-    assert sum(v << (W * i) for i, v in enumerate(out)) == k * Q
-    assert all(v < (lb + 1) * ((1 << W) + U_SLACK) for v in out[:-1])
-    return out
+def carr(name, vals, ty="uint32_t"):
+    body = ", ".join("0x%08xu" % v for v in vals)
+    return "constexpr %s %s[%d] = {%s};" % (ty, name, len(vals), body)
 
 
 def pow_program(e, w=4):
@@ -112,54 +74,287 @@ def pow_program(e, w=4):
     return ops
 
 
-def carr(name, vals, ty="uint32_t"):
-    body = ", ".join("0x%08xu" % v for v in vals)
-    return "constexpr %s %s[%d] = {%s};" % (ty, name, len(vals), body)
+class Field:
+    def __init__(self, q, kind, z):
+        self.q, self.kind, self.z = q, kind, z
+        self.R = 1 if kind == KIND_PM25519 else 1 << RBITS
+        assert pow(z, (q - 1) // 2, q) == q - 1, "z must be a non-residue"
+        s, t = 0, q - 1
+        while t % 2 == 0:
+            s, t = s + 1, t // 2
+        self.s, self.t = s, t
+        if kind == KIND_MONT_Q1:
+            assert q % (1 << W) == 1
+        if kind == KIND_PM25519:
+            assert q == (1 << 255) - 19
 
+    def inv(self, x):
+        return pow(x % self.q, self.q - 2, self.q)
 
-def sqrt_tables():
-    """2-Sylow subgroup (order 2^32) tables for the table-driven Tonelli-Shanks."""
-    t = (Q - 1) >> 32
-    assert t & 1 and (t << 32) == Q - 1
-    z = BS["Z"]
-    assert pow(z, (Q - 1) // 2, Q) == Q - 1        # non-residue
-    g = pow(z, t, Q)                                # generator of the 2^32 subgroup
-    h = inv(g)
-    # P[k][j] = h^(j * 2^(8k)), k = 0..3
-    P = [[pow(h, j << (8 * k), Q) for j in range(256)] for k in range(4)]
-    # order-256 subgroup generated by g^(2^24); lookup canonical value -> exponent
-    g24 = pow(g, 1 << 24, Q)
-    sub = [pow(g24, j, Q) for j in range(256)]
-    assert len(set(sub)) == 256
-    # perfect hash on the low 29-bit limb of the canonical *Montgomery* image
-    found = None
-    for bits in (9, 10, 11, 12):
-        for mult in range(1, 200000, 2):
-            seen = {}
-            ok = True
-            for j, v in enumerate(sub):
-                hsh = (((mont(v) & MASK) * mult) & 0xFFFFFFFF) >> (32 - bits)
-                if hsh in seen:
-                    ok = False
+    def mont(self, x):
+        return x * self.R % self.q
+
+    def limbs(self, x, n=NL):
+        out = []
+        for i in range(n):
+            if i == n - 1:
+                out.append(x)
+            else:
+                out.append(x & MASK)
+                x >>= W
+        assert out[-1] < (1 << 32)
+        return out
+
+    def lm(self, x):
+        return self.limbs(self.mont(x % self.q))
+
+    def bias(self, k, lb):
+        """k*q written with limbs 0..7 >= lb*(2^29 + 2^13) (so a limb-wise subtraction of any
+        value whose limbs are < lb*(2^29+2^13) and whose top limb is <= ours never borrows)."""
+        off = lb * ((1 << W) + U_SLACK)
+        t = k * self.q - sum(off << (W * i) for i in range(NL - 1))
+        assert t >= 0
+        dig = self.limbs(t)
+        out = [off + dig[i] for i in range(NL - 1)] + [dig[NL - 1]]
+        assert sum(v << (W * i) for i, v in enumerate(out)) == k * self.q
+        assert all(v < (lb + 1) * ((1 << W) + U_SLACK) for v in out[:-1])
+        return out
+
+    def sqrt(self, n):
+        """Tonelli-Shanks (generator tooling); None for a non-residue."""
+        q = self.q
+        n %= q
+        if n == 0:
+            return 0
+        if pow(n, (q - 1) // 2, q) != 1:
+            return None
+        m_, c_, tt, rr = self.s, pow(self.z, self.t, q), pow(n, self.t, q), pow(n, (self.t + 1) // 2, q)
+        while tt != 1:
+            i, t2 = 0, tt
+            while t2 != 1:
+                t2 = t2 * t2 % q
+                i += 1
+            b_ = pow(c_, 1 << (m_ - i - 1), q)
+            m_, c_, tt, rr = i, b_ * b_ % q, tt * b_ * b_ % q, rr * b_ % q
+        return rr
+
+    def sqrt_tables(self):
+        """2-Sylow subgroup (order 2^s) tables for the table-driven Tonelli-Shanks (fe.cuh fe_sqrt_or_zsqrt).
+        s = 32: byte digits, tables h^(j 2^(8k)), k = 0..3.  s = 28: digits 8 | 8 | 8 | 4, the same four tables plus
+        h^(j 2^4) and h^(j 2^12) (indices 4, 5).  s = 2: no tables, the four torsion elements are constants."""
+        q, s, t, z = self.q, self.s, self.t, self.z
+        g = pow(z, t, q)                                # generator of the 2^s subgroup
+        h = self.inv(g)
+        cz = pow(z, (t + 1) // 2, q)                    # sqrt(Z * w) correction: Z^((t+1)/2)
+        if s == 2:
+            return dict(t=t, g=g, h=h, P=[], lut=[0, 0], lut_bits=1, lut_mult=1, cz=cz, levels=[])
+        assert s in (28, 32)
+        levels = [0, 8, 16, 24] + ([4, 12] if s == 28 else [])
+        P = [[pow(h, j << lv, q) for j in range(256)] for lv in levels]
+        # order-256 subgroup generated by g^(2^(s-8)); lookup canonical value -> exponent
+        gg = pow(g, 1 << (s - 8), q)
+        sub = [pow(gg, j, q) for j in range(256)]
+        assert len(set(sub)) == 256
+        # perfect hash on the low 29-bit limb of the canonical image (x R mod q)
+        found = None
+        for bits in (9, 10, 11, 12):
+            for mult in range(1, 200000, 2):
+                seen = {}
+                ok = True
+                for j, v in enumerate(sub):
+                    hsh = (((self.mont(v) & MASK) * mult) & 0xFFFFFFFF) >> (32 - bits)
+                    if hsh in seen:
+                        ok = False
+                        break
+                    seen[hsh] = j
+                if ok:
+                    found = (bits, mult, seen)
                     break
-                seen[hsh] = j
-            if ok:
-                found = (bits, mult, seen)
+            if found:
                 break
-        if found:
-            break
-    assert found, "no perfect hash"
-    bits, mult, seen = found
-    lut = [0] * (1 << bits)
-    for hsh, j in seen.items():
-        lut[hsh] = j
-    cz = pow(z, (t + 1) // 2, Q)                    # sqrt(Z * w) correction: Z^((t+1)/2)
-    return dict(t=t, g=g, h=h, P=P, lut=lut, lut_bits=bits, lut_mult=mult, cz=cz)
+        assert found, "no perfect hash"
+        bits, mult, seen = found
+        lut = [0] * (1 << bits)
+        for hsh, j in seen.items():
+            lut[hsh] = j
+        return dict(t=t, g=g, h=h, P=P, lut=lut, lut_bits=bits, lut_mult=mult, cz=cz, levels=levels)
+
+
+# ------------------------------------------------------------------------------------------------ curves
+class Curve:
+    """Twisted Edwards a x^2 + y^2 = 1 + d x^2 y^2 over F (affine tuples, generator tooling only)."""
+
+    def __init__(self, F, a, d, r, cofactor, gx, gy):
+        self.F, self.a, self.d, self.r, self.cofactor, self.gx, self.gy = F, a % F.q, d % F.q, r, cofactor, gx, gy
+        assert self.on_curve((gx, gy)), "generator not on the curve"
+        assert self.mul(r, (gx, gy)) == (0, 1), "generator order"
+        assert self.mul(cofactor, (gx, gy)) != (0, 1)
+
+    def on_curve(self, P):
+        x, y = P
+        q = self.F.q
+        return (self.a * x * x + y * y - 1 - self.d * x * x % q * y * y) % q == 0
+
+    def add(self, P1, P2):
+        q, inv = self.F.q, self.F.inv
+        x1, y1 = P1
+        x2, y2 = P2
+        k = self.d * x1 % q * x2 % q * y1 % q * y2 % q
+        return ((x1 * y2 + y1 * x2) * inv(1 + k) % q, (y1 * y2 - self.a * x1 % q * x2) * inv(1 - k) % q)
+
+    def mul(self, k, P):
+        acc = (0, 1)
+        for bit in bin(k)[2:]:
+            acc = self.add(acc, acc)
+            if bit == "1":
+                acc = self.add(acc, P)
+        return acc
+
+    def decode(self, raw32):
+        """ArkworksCodec point decoding (y little-endian, bit 255 = x > q - x), no subgroup test."""
+        q = self.F.q
+        raw = bytearray(raw32)
+        flag = bool(raw[31] & 0x80)
+        raw[31] &= 0x7F
+        y = int.from_bytes(raw, "little")
+        if y >= q:
+            return None
+        den = (self.a - self.d * y * y) % q
+        if den == 0:
+            return None
+        x = self.F.sqrt((1 - y * y) * self.F.inv(den) % q)
+        if x is None:
+            return None
+        lo, hi = min(x, q - x), max(x, q - x) % q
+        return (hi if flag else lo, y)
+
+    def tai_base(self, suite_id, label):
+        """Nothing-up-my-sleeve point: try-and-increment hash (RFC 9381 5.4.1.1 shape) of a fixed label.  Used as the
+        built-in Pedersen blinding base of the suites whose upstream constant could not be authenticated (SURVEY.md
+        A.6): the suite descriptor carries it, a caller that knows upstream's replaces it."""
+        for ctr in range(256):
+            h = hashlib.sha512(suite_id + b"\x01" + label + bytes([ctr]) + b"\x00").digest()
+            P = self.decode(h[:32])
+            if P is None:
+                continue
+            P = self.mul(self.cofactor, P)
+            if P != (0, 1):
+                return P
+        raise AssertionError
+
+    def tate8(self):
+        """Constants of the subgroup test by the reduced Tate pairing with a point of order 8 (vrf_core.cuh
+        subgroup_by_tate8), for curves whose rational 2-power torsion is cyclic of order 8 and whose field holds the
+        8th roots of unity.  E(Fq)[2^inf] = Z8 (one rational point of order 2), so P is in the prime-order subgroup 8E iff
+        t_8(T8, P) = f_{8,T8}(P)^((q-1)/8) = 1 for a generator T8 of the 8-torsion.  On the short Weierstrass model
+        (via Montgomery: u = (1+y)/(1-y), v = u/x; X = (u + A/3)/B, Y = v/B) the Miller function is
+          f = l8^4 l4^2 / (v4^4 v2),   l_R = tangent at R, v_R = vertical through R, R in {T8, T4 = 2T8, T2 = 4T8},
+        and with Yn = 1 + y, W = (1 - y) x, Xn = (1 + y) x + (A/3) W every line is a polynomial over B W:
+          V2 = (1+y) x, V4 = Xn - c4 W, L4 = Yn - y4 W - lam4 V4, V8 = Xn - c8 W, L8 = Yn - y8 W - lam8 V8,
+          f = L8^4 L4^2 V4^4 (B V2 W)^7   modulo 8th powers."""
+        F, q, inv = self.F, self.F.q, self.F.inv
+        assert self.cofactor == 8 and (q - 1) % 8 == 0
+        ja, jd = self.a, self.d
+        jA = 2 * (ja + jd) * inv(ja - jd) % q
+        jB = 4 * inv(ja - jd) % q
+        jaW = (3 - jA * jA) * inv(3 * jB * jB) % q
+        T8 = None
+        yy = 2
+        while T8 is None:
+            den = (ja - jd * yy * yy) % q
+            x2 = (1 - yy * yy) * inv(den) % q
+            if den and pow(x2, (q - 1) // 2, q) == 1:
+                xx = F.sqrt(x2)
+                cand = self.mul(self.r, (min(xx, q - xx), yy))
+                if self.mul(4, cand) != (0, 1):
+                    T8 = cand
+            yy += 1
+        T4 = self.mul(2, T8)
+        assert self.mul(4, T8) == (0, q - 1) and self.mul(8, T8) == (0, 1)
+
+        def te2w(P):
+            u = (1 + P[1]) * inv(1 - P[1]) % q
+            v = u * inv(P[0]) % q
+            return ((u + jA * inv(3)) * inv(jB) % q, v * inv(jB) % q)
+        W8, W4 = te2w(T8), te2w(T4)
+        lam = lambda R: (3 * R[0] * R[0] + jaW) * inv(2 * R[1]) % q
+        c = dict(A3=jA * inv(3) % q, B=jB, C8=W8[0] * jB % q, Y8=W8[1] * jB % q, LAM8=lam(W8),
+                 C4=W4[0] * jB % q, Y4=W4[1] * jB % q, LAM4=lam(W4))
+        self._check_tate8(c, T8)
+        return c
+
+    def _check_tate8(self, c, T8):
+        """The formula of subgroup_by_tate8 in Python ints against r*P = O on every coset of the 8-torsion."""
+        import random
+        q = self.F.q
+        rnd = random.Random(8)
+
+        def test(P):
+            x, y = P
+            if (x, y) == (0, 1):
+                return True
+            Yn, Wv, V2 = (1 + y) % q, (1 - y) * x % q, (1 + y) * x % q
+            Xn = (V2 + Wv * c["A3"]) % q
+            V4, V8 = (Xn - Wv * c["C4"]) % q, (Xn - Wv * c["C8"]) % q
+            L4 = (Yn - Wv * c["Y4"] - V4 * c["LAM4"]) % q
+            L8 = (Yn - Wv * c["Y8"] - V8 * c["LAM8"]) % q
+            Z = V2 * Wv % q * c["B"] % q
+            f = pow(L8, 4, q) * pow(L4, 2, q) % q * pow(V4, 4, q) % q * pow(Z, 7, q) % q
+            return f != 0 and pow(f, (q - 1) // 8, q) == 1
+        G = (self.gx, self.gy)
+        for _ in range(6):
+            P = self.mul(rnd.randrange(1, self.r), G)
+            for j in range(8):
+                Pj = self.add(P, self.mul(j, T8))
+                assert test(Pj) == (self.mul(self.r, Pj) == (0, 1)), "tate8 formula disagrees with r*P = O"
+
+
+F0 = Field(Q_BLS, KIND_MONT_Q1, 5)
+F1 = Field(Q_25519, KIND_PM25519, 2)
+F2 = Field(Q_BN254, KIND_MONT, 5)
+
+BS = dict(
+    a=Q_BLS - 5,
+    d=45022363124591815672509500913686876175488063829319466900776701791074614335719,
+    r=0x1CFB69D4CA675F520CCE760202687600FF8F87007419047174FD06B52876E7E1,
+    gx=18886178867200960497001835917649091219057080094937609519140440539760939937304,
+    gy=19188667384257783945677642223292697773471335439753913231509108946878080696678,
+    bx=6150229251051246713677296363717454238956877613358614224171740096471278798312,
+    by=28442734166467795856797249030329035618871580593056783094884474814923353898473,
+    J=29978822694968839326280996386011761570173833766074948509196803838190355340952,
+    K=25465760566081946422412445027709227188579564747101592991722834452325077642517,
+    Z=5,
+)
+JJ = dict(
+    a=Q_BLS - 1,
+    d=19257038036680949359750312669786877991949435402254120286184196891950884077233,
+    r=6554484396890773809930967563523245729705921265872317281365359162392183254199,
+    gx=8076246640662884909881801758704306714034609987455869804520522091855516602923,
+    gy=13262374693698910701929044844600465831413122818447359594527400194675274060458,
+)
+# Ed25519 (RFC 8032 section 5.1): a = -1, d = -121665/121666, base point with y = 4/5 and even x, order
+# l = 2^252 + 27742317777372353535851937790883648493, cofactor 8.
+ED = dict(
+    a=Q_25519 - 1,
+    d=(-121665 * pow(121666, Q_25519 - 2, Q_25519)) % Q_25519,
+    r=(1 << 252) + 27742317777372353535851937790883648493,
+    gx=15112221349535400772501151409588531511454012693041857206046113283949847762202,
+    gy=46316835694926478169428394003475163141307993866256225615783033603165251855960,
+)
+# Baby-JubJub as ark-ed-on-bn254 states it: a = 1, d = 168696/168700 over BN254 Fr, cofactor 8.
+BJ = dict(
+    a=1,
+    d=168696 * pow(168700, Q_BN254 - 2, Q_BN254) % Q_BN254,
+    r=2736030358979909402780800718157159386076813972158567259200215660948447373041,
+    gx=19698561148652590122159747500897617769866003486955115824547446575314762165298,
+    gy=19298250018296453272277890825869354524455968081175474282777126169995084727839,
+)
 
 
 def glv_constants():
     """Bandersnatch endomorphism psi (degree 2, psi^2 = -2), derived numerically and self-checked:
     psi(x, y) = (c (1 - y^2) / (x y), b (y^2 + b) / (y^2 - b)), psi(P) = lambda P on the subgroup."""
+    Q, inv = Q_BLS, F0.inv
     r = BS["r"]
     lam = 0x13b4f3dc4a39a493edf849562b38c72bcfc49db970a5056ed13d21408783df05
     b = 37446463827641770816307242315180085052603635617490163568005256780843403514036
@@ -176,7 +371,6 @@ def glv_constants():
         (r0, s0, t0), (r1, s1, t1) = rs[-2], rs[-1]
         qq = r0 // r1
         rs.append((r0 - qq * r1, s0 - qq * s1, t0 - qq * t1))
-    import math
     sq = math.isqrt(r)
     i = next(k for k, e in enumerate(rs) if e[0] < sq)
     v1 = (rs[i][0], -rs[i][2])
@@ -195,63 +389,6 @@ def glv_constants():
     g2 = (abs(b1) << 256) // r
     return dict(lam=lam, b=b, c=c, a1=a1, b1=b1, a2=a2, b2=b2, g1=g1, g2=g2,
                 sg1=1 if b2 >= 0 else -1, sg2=1 if -b1 >= 0 else -1)
-
-
-def jubjub_blinding_base():
-    """Nothing-up-my-sleeve JubJub blinding base: try-and-increment hash of a fixed label
-    (the upstream constant is unknown, so the suite descriptor carries this one)."""
-    import hashlib
-    a, d, r = JJ["a"], JJ["d"], JJ["r"]
-
-    def add(P1, P2):
-        x1, y1 = P1
-        x2, y2 = P2
-        k = d * x1 % Q * x2 % Q * y1 % Q * y2 % Q
-        return ((x1 * y2 + y1 * x2) * inv((1 + k) % Q) % Q, (y1 * y2 - a * x1 % Q * x2) * inv((1 - k) % Q) % Q)
-
-    def sqrt_q(n):
-        n %= Q
-        if n == 0:
-            return 0
-        if pow(n, (Q - 1) // 2, Q) != 1:
-            return None
-        s_, t_ = 32, (Q - 1) >> 32
-        c = pow(5, t_, Q)
-        x = pow(n, (t_ + 1) // 2, Q)
-        b = pow(n, t_, Q)
-        m = s_
-        while b != 1:
-            i, b2 = 0, b
-            while b2 != 1:
-                b2 = b2 * b2 % Q
-                i += 1
-            e = pow(c, 1 << (m - i - 1), Q)
-            x, c = x * e % Q, e * e % Q
-            b, m = b * c % Q, i
-        return x
-    label = b"vrfhip-jubjub-blinding-base"
-    for ctr in range(256):
-        h = hashlib.sha512(b"JubJub_SHA-512_TAI" + b"\x01" + label + bytes([ctr]) + b"\x00").digest()
-        raw = bytearray(h[:32])
-        flag = bool(raw[31] & 0x80)
-        raw[31] &= 0x7F
-        y = int.from_bytes(raw, "little")
-        if y >= Q:
-            continue
-        den = (a - d * y * y) % Q
-        if den == 0:
-            continue
-        x = sqrt_q((1 - y * y) * inv(den) % Q)
-        if x is None:
-            continue
-        lo, hi = min(x, Q - x), max(x, Q - x) % Q
-        x = hi if flag else lo
-        P1 = (x, y)
-        for _ in range(3):
-            P1 = add(P1, P1)
-        if P1 != (0, 1):
-            return P1
-    raise AssertionError
 
 
 def bls_constants():
@@ -300,72 +437,152 @@ def bls_constants():
                 pinv=(-pow(P, -1, 1 << WB)) % (1 << WB))
 
 
-def main():
-    st = sqrt_tables()
-    out = []
-    ap = out.append
+def xy_le(x, y):
+    b = int(x).to_bytes(32, "little") + int(y).to_bytes(32, "little")
+    return ",".join(str(v) for v in b)
+
+
+def emit_field_core(ap, F, st, title):
+    """The names fe.cuh reads: identical in every field's header."""
+    q, R = F.q, F.R
     ap("// GENERATED by tools/gen_constants.py -- do not edit by hand.")
-    ap("// Radix-2^29, 9-limb field constants for Fq = BLS12-381 Fr (SURVEY.md Appendix C),")
-    ap("// Montgomery radix R = 2^261.  *_M = Montgomery image (x*R mod q), 29-bit limbs.")
+    for line in title:
+        ap(line)
     ap("#pragma once")
     ap("#include <cstdint>")
     ap("namespace vrfk {")
     ap("constexpr int NL = 9;")
     ap("constexpr int LW = 29;")
     ap("constexpr uint32_t LMASK = 0x%08xu;" % MASK)
-    ap(carr("Q29", limbs29(Q)))
-    ap(carr("Q32", words32(Q)))
-    ap(carr("QM1H32", words32((Q - 1) // 2)))
-    ap(carr("ONE_M", limbs29(mont(1))))
-    ap(carr("FIVE_M", limbs29(mont(5))))
-    ap(carr("R2_29", limbs29(R * R % Q)))
-    ap(carr("R3_29", limbs29(R * R * R % Q)))
+    ap(carr("Q29", F.limbs(q)))
+    ap(carr("Q32", words32(q)))
+    ap(carr("QM1H32", words32((q - 1) // 2)))
+    ap(carr("ONE_M", F.lm(1)))
+    if F.kind == KIND_MONT_Q1:
+        ap(carr("FIVE_M", F.lm(5)))
+    ap(carr("R2_29", F.limbs(R * R % q)))
+    ap(carr("R3_29", F.limbs(R * R * R % q)))
     ap("// 2^256 * R mod q: multiplier that folds the high half of a 512-bit integer")
-    ap(carr("TWO256_R2", limbs29((1 << 256) * R * R % Q)))
-    # coordinates in arkworks' in-memory form (Montgomery, radix 2^256) at the ABI: x 2^256 -> x 2^261 is a Montgomery
-    # product by 2^266; x 2^261 -> x 2^256 (as a plain integer) is a Montgomery product by 2^256
-    ap(carr("TWO266_29", limbs29((1 << 266) % Q)))
-    ap(carr("TWO256_29", limbs29((1 << 256) % Q)))
+    ap(carr("TWO256_R2", F.limbs((1 << 256) * R * R % q)))
+    # coordinates in arkworks' in-memory form (Montgomery, radix 2^256) at the ABI: x 2^256 -> x R is a product by
+    # R^2 / 2^256 (2^266 when R = 2^261); x R -> x 2^256 (as a plain integer) is a product by 2^256
+    ap(carr("TWO266_29", F.limbs(R * R * F.inv(1 << 256) % q)))
+    ap(carr("TWO256_29", F.limbs((1 << 256) % q)))
     for lb in (1, 2):
         for k in (4, 8, 16, 32, 64):
-            ap(carr("BIAS_L%d_K%d" % (lb, k), bias(k, lb)))
+            ap(carr("BIAS_L%d_K%d" % (lb, k), F.bias(k, lb)))
     # exponents (uniform across lanes -> scalar loop control), little-endian 32-bit words
-    ap(carr("EXP_INV", words32(Q - 2)))
+    ap(carr("EXP_INV", words32(q - 2)))
     ap(carr("EXP_SQRT", words32((st["t"] - 1) // 2)))
-    ap(carr("EXP_LEGENDRE", words32((Q - 1) // 2)))
+    ap(carr("EXP_LEGENDRE", words32((q - 1) // 2)))
     ap("// sliding-window (w = 4) programs for the fixed exponents: (squarings << 4) | odd-power index, 15 = none")
-    ap(carr("POW_INV_PROG", pow_program(Q - 2), "uint16_t"))
+    ap(carr("POW_INV_PROG", pow_program(q - 2), "uint16_t"))
     ap(carr("POW_SQRT_PROG", pow_program((st["t"] - 1) // 2), "uint16_t"))
-    ap(carr("SQRT_CZ_M", limbs29(mont(st["cz"]))))
-    ap(carr("SQRT_G_M", limbs29(mont(st["g"]))))
+    ap(carr("SQRT_CZ_M", F.lm(st["cz"])))
+    ap(carr("SQRT_G_M", F.lm(st["g"])))
     ap("constexpr int SQRT_LUT_BITS = %d;" % st["lut_bits"])
     ap("constexpr uint32_t SQRT_LUT_MULT = %du;" % st["lut_mult"])
-    # suites
-    for tag, C in (("BS", BS), ("JJ", JJ)):
-        ap("// ---- %s ----" % ("Bandersnatch" if tag == "BS" else "JubJub"))
-        ap(carr(tag + "_D_M", limbs29(mont(C["d"]))))
-        ap(carr(tag + "_GX_M", limbs29(mont(C["gx"]))))
-        ap(carr(tag + "_GY_M", limbs29(mont(C["gy"]))))
-        ap(carr(tag + "_GDT_M", limbs29(mont(C["d"] * C["gx"] * C["gy"] % Q))))
-        r = C["r"]
-        ap(carr(tag + "_R32", words32(r)))
-        ap("constexpr uint32_t %s_R_NINV32 = 0x%08xu;" % (tag, (-pow(r, -1, 1 << 32)) % (1 << 32)))
-        ap(carr(tag + "_R_R1", words32((1 << 256) % r)))
-        ap(carr(tag + "_R_R2", words32((1 << 512) % r)))
-    jbx, jby = jubjub_blinding_base()
-    ap(carr("JJ_BX_M", limbs29(mont(jbx))))
-    ap(carr("JJ_BY_M", limbs29(mont(jby))))
-    ap(carr("BS_BX_M", limbs29(mont(BS["bx"]))))
-    ap(carr("BS_BY_M", limbs29(mont(BS["by"]))))
-    ap(carr("BS_BDT_M", limbs29(mont(BS["d"] * BS["bx"] * BS["by"] % Q))))
+
+
+def emit_field_traits(ap, F, st):
+    """What makes fe.cuh field-generic (appended after the historical block so that field 0's header only grows)."""
+    q = F.q
+    ap("// ---- field traits (fe.cuh) ----")
+    ap("// FIELD_KIND 0: Montgomery R = 2^261 with q = 1 (mod 2^29) (digit = -column, no multiply); 1: Montgomery R = 2^261,")
+    ap("// general q (digit = column * NINV29); 2: q = 2^255 - 19, R = 1 (2^261 = 1216 folds the high columns)")
+    ap("constexpr int FIELD_KIND = %d;" % F.kind)
+    ap("constexpr uint32_t NINV29 = 0x%08xu;   // -q^-1 mod 2^29" % ((-pow(q, -1, 1 << W)) % (1 << W)))
+    mulv = 0 if F.kind == KIND_PM25519 else -((-q * 100000) // F.R)      # ceil(q / R * 1e5)
+    ap("constexpr int MULV_NUM = %d;           // ceil(1e5 q / R): value bound of a product, mul_v()" % mulv)
+    ap("constexpr int V256 = %d;               // 2^256 < V256 q" % ((1 << 256) // q + 1))
+    chi_r = 1 if F.R == 1 else (1 if pow(2, (q - 1) // 2, q) == 1 else -1)     # R = 2 (2^130)^2
+    ap("constexpr int CHI_R = %d;              // quadratic character of R: symbol(x R) = CHI_R symbol(x)" % chi_r)
+    ap("constexpr int SQRT_S = %d;             // 2-adicity of q - 1" % F.s)
+    ap("constexpr int SQRT_TABLES = %d;        // 256-entry tables h^(j 2^level); levels %s" % (len(st["levels"]), st["levels"]))
+    if F.s == 2:
+        g, h = st["g"], st["h"]
+        ap("// the 4-torsion g^e, e = 1..3 (canonical images) and h^e = g^-e, e = 1, 2")
+        for e in (1, 2, 3):
+            ap(carr("SQRT_G%d_M" % e, F.lm(pow(g, e, q))))
+        for e in (1, 2):
+            ap(carr("SQRT_H%d_M" % e, F.lm(pow(h, e, q))))
+
+
+def emit_curve(ap, F, tag, name, C, with_gdt=True):
+    ap("// ---- %s ----" % name)
+    q = F.q
+    ap(carr(tag + "_D_M", F.lm(C["d"])))
+    ap(carr(tag + "_GX_M", F.lm(C["gx"])))
+    ap(carr(tag + "_GY_M", F.lm(C["gy"])))
+    ap(carr(tag + "_GDT_M", F.lm(C["d"] * C["gx"] * C["gy"] % q)))
+    r = C["r"]
+    ap(carr(tag + "_R32", words32(r)))
+    ap("constexpr uint32_t %s_R_NINV32 = 0x%08xu;" % (tag, (-pow(r, -1, 1 << 32)) % (1 << 32)))
+    ap(carr(tag + "_R_R1", words32((1 << 256) % r)))
+    ap(carr(tag + "_R_R2", words32((1 << 512) % r)))
+
+
+def emit_tate8(ap, F, tag, name, c):
+    ap("// %s subgroup test by the Tate pairing with a point of order 8 (vrf_core.cuh subgroup_by_tate8)" % name)
+    for k in ("A3", "B", "C8", "Y8", "LAM8", "C4", "Y4", "LAM4"):
+        ap(carr("%s_TATE_%s_M" % (tag, k), F.lm(c[k])))
+
+
+def emit_tables(ap, F, st, points):
+    ap("} // namespace vrfk")
+    ap("")
+    ap("// ---- square-root tables (host copies; uploaded to HBM at context creation) ----")
+    ap("namespace vrfk_tables {")
+    flat = []
+    for tab in st["P"]:
+        for j in range(256):
+            flat += F.lm(tab[j])
+    if not flat:
+        flat = [0] * NL                      # fields without tables (2-adicity 2): one unused entry
+    ap("// SQRT_P[k][j] = h^(j*2^level_k) (image x R), h = 1/g, j=0..255, 9 limbs each; levels: see SQRT_TABLES")
+    ap("static const uint32_t SQRT_P[%d] = {%s};" % (len(flat), ",".join("0x%xu" % v for v in flat)))
+    ap("static const uint8_t SQRT_LUT[%d] = {%s};" % (len(st["lut"]), ",".join(str(v) for v in st["lut"])))
+    ap("// built-in suite descriptors (vrfhip_suite_desc_default): generator and Pedersen blinding base as x || y,")
+    ap("// 32-byte little-endian canonical integers")
+    for nm, (x, y) in points:
+        ap("static const uint8_t %s[64] = {%s};" % (nm, xy_le(x, y)))
+    ap("} // namespace vrfk_tables")
+
+
+def write(name, out):
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ark_ec_vrfs_amd", "csrc", name)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+    print("wrote", os.path.normpath(path))
+
+
+def gen_field0():
+    F, Q, inv, mont = F0, Q_BLS, F0.inv, F0.mont
+    st = F.sqrt_tables()
+    out = []
+    ap = out.append
+    emit_field_core(ap, F, st, [
+        "// Radix-2^29, 9-limb field constants for Fq = BLS12-381 Fr (SURVEY.md Appendix C),",
+        "// Montgomery radix R = 2^261.  *_M = Montgomery image (x*R mod q), 29-bit limbs."])
+    cbs = Curve(F, BS["a"], BS["d"], BS["r"], 4, BS["gx"], BS["gy"])
+    cjj = Curve(F, JJ["a"], JJ["d"], JJ["r"], 8, JJ["gx"], JJ["gy"])
+    emit_curve(ap, F, "BS", "Bandersnatch", BS)
+    emit_curve(ap, F, "JJ", "JubJub", JJ)
+    jbx, jby = cjj.tai_base(b"JubJub_SHA-512_TAI", b"vrfhip-jubjub-blinding-base")
+    ap(carr("JJ_BX_M", F.lm(jbx)))
+    ap(carr("JJ_BY_M", F.lm(jby)))
+    ap(carr("BS_BX_M", F.lm(BS["bx"])))
+    ap(carr("BS_BY_M", F.lm(BS["by"])))
+    ap(carr("BS_BDT_M", F.lm(BS["d"] * BS["bx"] * BS["by"] % Q)))
     J, K, Z = BS["J"], BS["K"], BS["Z"]
     jk = J * inv(K) % Q
     ap("// Elligator 2 (SURVEY.md A.3): J/K, 1/K^2, K, Z (all Montgomery)")
-    ap(carr("BS_ELL2_JK_M", limbs29(mont(jk))))
-    ap(carr("BS_ELL2_NJK_M", limbs29(mont(Q - jk))))
-    ap(carr("BS_ELL2_K2I_M", limbs29(mont(inv(K * K % Q)))))
-    ap(carr("BS_ELL2_K_M", limbs29(mont(K))))
-    ap(carr("BS_ELL2_Z_M", limbs29(mont(Z))))
+    ap(carr("BS_ELL2_JK_M", F.lm(jk)))
+    ap(carr("BS_ELL2_NJK_M", F.lm(Q - jk)))
+    ap(carr("BS_ELL2_K2I_M", F.lm(inv(K * K % Q))))
+    ap(carr("BS_ELL2_K_M", F.lm(K)))
+    ap(carr("BS_ELL2_Z_M", F.lm(Z)))
     # ---- subgroup membership by 2-descent (Bandersnatch: E(Fq) = Z2 x Z2 x Zr, so the prime-order subgroup is 2E) ----
     # Montgomery model B v^2 = u (u - e2)(u - e3), u = (1 + y)/(1 - y), A = 2(a + d)/(a - d), B = 4/(a - d);
     # P in 2E  <=>  B u, B (u - e2), B (u - e3) are squares (their product is one, so two tests suffice).
@@ -374,86 +591,23 @@ def main():
     B_m = 4 * inv((a_bs - d_bs) % Q) % Q
     disc = (A_m * A_m - 4) % Q
     assert pow(disc, (Q - 1) // 2, Q) == 1, "full rational 2-torsion expected"
-    # square root of disc by Tonelli-Shanks (q = 1 mod 2^32)
-    def _sqrt(n):
-        s_, t_ = 32, (Q - 1) >> 32
-        z = 5
-        m_, c_, tt, rr = s_, pow(z, t_, Q), pow(n, t_, Q), pow(n, (t_ + 1) // 2, Q)
-        while tt != 1:
-            i, t2 = 0, tt
-            while t2 != 1:
-                t2 = t2 * t2 % Q
-                i += 1
-            b_ = pow(c_, 1 << (m_ - i - 1), Q)
-            m_, c_, tt, rr = i, b_ * b_ % Q, tt * b_ * b_ % Q, rr * b_ % Q
-        return rr
-    sd = _sqrt(disc)
+    sd = F.sqrt(disc)
     assert sd * sd % Q == disc
     e2 = (-A_m + sd) * inv(2) % Q
     assert (e2 * e2 + A_m * e2 + 1) % Q == 0
     ap("// subgroup test by 2-descent: B = 4/(a-d), 1 + e2, 1 - e2 with e2 a root of u^2 + A u + 1 (Montgomery model)")
-    ap(carr("BS_DESC_B_M", limbs29(mont(B_m))))
-    ap(carr("BS_DESC_1PE2_M", limbs29(mont((1 + e2) % Q))))
-    ap(carr("BS_DESC_1ME2_M", limbs29(mont((1 - e2) % Q))))
-    # ---- JubJub subgroup membership by the reduced Tate pairing with a point of order 8 ----
-    # E(Fq)[2^inf] = Z8 (one rational point of order 2), so P is in the prime-order subgroup 8E iff
-    # t_8(T8, P) = f_{8,T8}(P)^((q-1)/8) = 1 for a generator T8 of the 8-torsion.  On the short Weierstrass model
-    # (via Montgomery: u = (1+y)/(1-y), v = u/x; X = (u + A/3)/B, Y = v/B) the Miller function is
-    #   f = l8^4 l4^2 / (v4^4 v2),   l_R = tangent at R, v_R = vertical through R, R in {T8, T4 = 2T8, T2 = 4T8},
-    # and with Yn = 1 + y, W = (1 - y) x, Xn = (1 + y) x + (A/3) W every line is a polynomial over B W:
-    #   V2 = (1+y) x, V4 = Xn - c4 W, L4 = Yn - y4 W - lam4 V4, V8 = Xn - c8 W, L8 = Yn - y8 W - lam8 V8,
-    #   f = L8^4 L4^2 V4^4 (B V2 W)^7   modulo 8th powers.
-    jq = Q
-    ja, jd = (jq - 1) % jq, JJ["d"]
-    jA = 2 * (ja + jd) * inv((ja - jd) % jq) % jq
-    jB = 4 * inv((ja - jd) % jq) % jq
-    jaW = (3 - jA * jA) * inv(3 * jB * jB % jq) % jq
-    def jj_add(P1, P2):
-        (x1, y1), (x2, y2) = P1, P2
-        t = jd * x1 * x2 * y1 * y2 % jq
-        return ((x1 * y2 + y1 * x2) * inv((1 + t) % jq) % jq, (y1 * y2 - ja * x1 * x2) * inv((1 - t) % jq) % jq)
-    def jj_mul(k, P):
-        acc = (0, 1)
-        for bit in bin(k)[2:]:
-            acc = jj_add(acc, acc)
-            if bit == "1":
-                acc = jj_add(acc, P)
-        return acc
-    T8 = None
-    yy = 2
-    while T8 is None:
-        den = (ja - jd * yy * yy) % jq
-        x2 = (1 - yy * yy) * inv(den) % jq
-        if pow(x2, (jq - 1) // 2, jq) == 1:
-            xx = _sqrt(x2)
-            cand = jj_mul(JJ["r"], (min(xx, jq - xx), yy))
-            if jj_mul(4, cand) != (0, 1):
-                T8 = cand
-        yy += 1
-    T4 = jj_mul(2, T8)
-    assert jj_mul(4, T8) == (0, jq - 1) and jj_mul(8, T8) == (0, 1)
-    def te2w(P):
-        u = (1 + P[1]) * inv((1 - P[1]) % jq) % jq
-        v = u * inv(P[0]) % jq
-        return ((u + jA * inv(3)) * inv(jB) % jq, v * inv(jB) % jq)
-    W8, W4 = te2w(T8), te2w(T4)
-    lam = lambda R: (3 * R[0] * R[0] + jaW) * inv(2 * R[1]) % jq
-    ap("// JubJub subgroup test by the Tate pairing with a point of order 8 (vrf_core.cuh subgroup_by_tate8)")
-    ap(carr("JJ_TATE_A3_M", limbs29(mont(jA * inv(3) % jq))))
-    ap(carr("JJ_TATE_B_M", limbs29(mont(jB))))
-    ap(carr("JJ_TATE_C8_M", limbs29(mont(W8[0] * jB % jq))))
-    ap(carr("JJ_TATE_Y8_M", limbs29(mont(W8[1] * jB % jq))))
-    ap(carr("JJ_TATE_LAM8_M", limbs29(mont(lam(W8)))))
-    ap(carr("JJ_TATE_C4_M", limbs29(mont(W4[0] * jB % jq))))
-    ap(carr("JJ_TATE_Y4_M", limbs29(mont(W4[1] * jB % jq))))
-    ap(carr("JJ_TATE_LAM4_M", limbs29(mont(lam(W4)))))
+    ap(carr("BS_DESC_B_M", F.lm(B_m)))
+    ap(carr("BS_DESC_1PE2_M", F.lm((1 + e2) % Q)))
+    ap(carr("BS_DESC_1ME2_M", F.lm((1 - e2) % Q)))
+    emit_tate8(ap, F, "JJ", "JubJub", cjj.tate8())
     gl = glv_constants()
     ap("// ---- GLV (Bandersnatch endomorphism psi, psi(P) = LAMBDA * P on the prime-order subgroup) ----")
     ap(carr("BS_GLV_LAMBDA32", words32(gl["lam"])))
-    ap(carr("BS_PSI_B_M", limbs29(mont(gl["b"]))))
-    ap(carr("BS_PSI_C_M", limbs29(mont(gl["c"]))))
+    ap(carr("BS_PSI_B_M", F.lm(gl["b"])))
+    ap(carr("BS_PSI_C_M", F.lm(gl["c"])))
     ap("// k = k1 + k2*LAMBDA: c1 = sign1 * ((k*G1) >> 256), c2 = sign2 * ((k*G2) >> 256) (rounded),")
     ap("// k1 = k - c1*A1 - c2*A2, k2 = -c1*B1 - c2*B2; lattice vectors as magnitude (5 words) + sign")
+
     def w5(x):
         assert abs(x) < (1 << 160)
         return [(abs(x) >> (32 * i)) & 0xFFFFFFFF for i in range(5)]
@@ -479,33 +633,56 @@ def main():
     for i in range(1, 6):
         ap(carr("BLS_GAMMA%d_RE_M" % i, bl["lim"](bl["mont"](bl["gam"][i][0]))))
         ap(carr("BLS_GAMMA%d_IM_M" % i, bl["lim"](bl["mont"](bl["gam"][i][1]))))
-    ap("} // namespace vrfk")
-    ap("")
-    ap("// ---- square-root tables (host copies; uploaded to HBM at context creation) ----")
-    ap("namespace vrfk_tables {")
-    flat = []
-    for k in range(4):
-        for j in range(256):
-            flat += limbs29(mont(st["P"][k][j]))
-    ap("// SQRT_P[k][j] = h^(j*2^(8k)) (Montgomery), h = 1/g, k=0..3, j=0..255, 9 limbs each")
-    ap("static const uint32_t SQRT_P[%d] = {%s};" % (len(flat), ",".join("0x%xu" % v for v in flat)))
-    ap("static const uint8_t SQRT_LUT[%d] = {%s};" % (len(st["lut"]), ",".join(str(v) for v in st["lut"])))
-    ap("// built-in suite descriptors (vrfhip_suite_desc_default): generator and Pedersen blinding base as x || y,")
-    ap("// 32-byte little-endian canonical integers")
-    def xy_le(x, y):
-        b = int(x).to_bytes(32, "little") + int(y).to_bytes(32, "little")
-        return ",".join(str(v) for v in b)
-    ap("static const uint8_t BS_G_XY[64] = {%s};" % xy_le(BS["gx"], BS["gy"]))
-    ap("static const uint8_t BS_B_XY[64] = {%s};" % xy_le(BS["bx"], BS["by"]))
-    ap("static const uint8_t JJ_G_XY[64] = {%s};" % xy_le(JJ["gx"], JJ["gy"]))
-    ap("static const uint8_t JJ_B_XY[64] = {%s};" % xy_le(jbx, jby))
-    ap("} // namespace vrfk_tables")
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ark_ec_vrfs_amd", "csrc",
-                        "constants.gen.h")
-    os.makedirs(os.path.dirname(path), exist_ok=True)
-    with open(path, "w") as f:
-        f.write("\n".join(out) + "\n")
-    print("wrote", os.path.normpath(path), "lut_bits", st["lut_bits"], "mult", st["lut_mult"])
+    emit_field_traits(ap, F, st)
+    emit_tables(ap, F, st, [("BS_G_XY", (BS["gx"], BS["gy"])), ("BS_B_XY", (BS["bx"], BS["by"])),
+                            ("JJ_G_XY", (JJ["gx"], JJ["gy"])), ("JJ_B_XY", (jbx, jby))])
+    write("constants.gen.h", out)
+    print("  field 0: lut_bits", st["lut_bits"], "mult", st["lut_mult"])
+
+
+def gen_field1():
+    F = F1
+    st = F.sqrt_tables()
+    out = []
+    ap = out.append
+    emit_field_core(ap, F, st, [
+        "// Radix-2^29, 9-limb field constants for Fq = 2^255 - 19 (Ed25519, RFC 8032 section 5.1).",
+        "// Pseudo-Mersenne arithmetic: R = 1, *_M = the value itself (x mod q), 29-bit limbs."])
+    ced = Curve(F, ED["a"], ED["d"], ED["r"], 8, ED["gx"], ED["gy"])
+    assert ED["gy"] == 4 * F.inv(5) % F.q and ED["gx"] % 2 == 0
+    emit_curve(ap, F, "ED", "Ed25519", ED)
+    bx, by = ced.tai_base(b"Ed25519_SHA-512_TAI", b"vrfhip-ed25519-blinding-base")
+    ap(carr("ED_BX_M", F.lm(bx)))
+    ap(carr("ED_BY_M", F.lm(by)))
+    emit_field_traits(ap, F, st)
+    emit_tables(ap, F, st, [("ED_G_XY", (ED["gx"], ED["gy"])), ("ED_B_XY", (bx, by))])
+    write("constants_f25519.gen.h", out)
+
+
+def gen_field2():
+    F = F2
+    st = F.sqrt_tables()
+    out = []
+    ap = out.append
+    emit_field_core(ap, F, st, [
+        "// Radix-2^29, 9-limb field constants for Fq = BN254 Fr (Baby-JubJub, ark-ed-on-bn254),",
+        "// Montgomery radix R = 2^261.  *_M = Montgomery image (x*R mod q), 29-bit limbs."])
+    cbj = Curve(F, BJ["a"], BJ["d"], BJ["r"], 8, BJ["gx"], BJ["gy"])
+    emit_curve(ap, F, "BJ", "Baby-JubJub", BJ)
+    bx, by = cbj.tai_base(b"BabyJubJub_SHA-512_TAI", b"vrfhip-babyjubjub-blinding-base")
+    ap(carr("BJ_BX_M", F.lm(bx)))
+    ap(carr("BJ_BY_M", F.lm(by)))
+    emit_tate8(ap, F, "BJ", "Baby-JubJub", cbj.tate8())
+    emit_field_traits(ap, F, st)
+    emit_tables(ap, F, st, [("BJ_G_XY", (BJ["gx"], BJ["gy"])), ("BJ_B_XY", (bx, by))])
+    write("constants_fbn254.gen.h", out)
+    print("  field 2: lut_bits", st["lut_bits"], "mult", st["lut_mult"])
+
+
+def main():
+    gen_field0()
+    gen_field1()
+    gen_field2()
 
 
 if __name__ == "__main__":
