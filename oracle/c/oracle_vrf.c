@@ -28,17 +28,24 @@
 typedef unsigned __int128 u128;
 typedef struct { uint64_t v[4]; } fp;          /* Montgomery form */
 typedef struct { uint64_t m[4]; uint64_t ninv; uint64_t r2[4]; uint64_t one[4]; } field;
+/* A base field with what Tonelli-Shanks needs: q - 1 = 2^s t, c = z^t for a non-residue z, (t + 1) / 2. */
+typedef struct { field f; fp ts_c; uint64_t ts_t[4], ts_e[4]; int s; } basefield;
 
 /* Suite descriptor [ref src/lib.rs:16 `Suite`]: Bandersnatch_SHA-512_ELL2 (pinned by the KATs) and
  * JubJub_SHA-512_TAI (recollection only: parity unpinned). */
 typedef struct {
+  basefield* bf;                 /* base field: BLS12-381 Fr (Bandersnatch, JubJub), 2^255 - 19 (Ed25519), BN254 Fr (Baby-JubJub) */
   field fr;                      /* scalar field */
   fp d, a, gx, gy, bx, by;       /* curve a x^2 + y^2 = 1 + d x^2 y^2, generator, blinding base */
   const char* suite_id; size_t suite_id_len;
   const char* h2c_dst; size_t h2c_dst_len;     /* RFC 9380 DST (Elligator suites) */
   int h2c_tai, cofactor_log2;
+  int challenge_len;             /* `Suite::CHALLENGE_LEN`: leading bytes of the challenge hash */
+  int flags;                     /* vrfhip_suite_desc.flags: 1 sign = x mod 2 (RFC 8032), 2 challenge little-endian,
+                                    4 output hash of cofactor * Gamma (RFC 9381); 0 for upstream's suites */
 } suite_t;
-static suite_t SUITE_BS, SUITE_JJ, SUITE_CUSTOM;
+static basefield BF_BLS, BF_25519, BF_BN254;
+static suite_t SUITE_BS, SUITE_JJ, SUITE_ED, SUITE_BJ, SUITE_CUSTOM;
 static char CUSTOM_ID[64], CUSTOM_DST[128];
 static suite_t* S_ = &SUITE_BS;   /* current suite (tests select it with oracle_set_suite) */
 #define FR (S_->fr)
@@ -48,10 +55,11 @@ static suite_t* S_ = &SUITE_BS;   /* current suite (tests select it with oracle_
 #define BS_GY_M (S_->gy)
 #define BS_BX_M (S_->bx)
 #define BS_BY_M (S_->by)
-static field FQ;
-static fp ELL_J_M, ELL_K_M, ELL_Z_M, ELL_JK_M, ELL_K2I_M;
-static fp TS_C_M;                 /* 5^t, generator of the 2^32-torsion (Tonelli-Shanks) */
-static uint64_t TS_T[4], TS_E[4];  /* t = (q-1)/2^32, (t+1)/2 */
+#define FQ (S_->bf->f)
+#define TS_C_M (S_->bf->ts_c)     /* z^t, generator of the 2^s-torsion (Tonelli-Shanks) */
+#define TS_T (S_->bf->ts_t)       /* t = (q-1)/2^s */
+#define TS_E (S_->bf->ts_e)       /* (t+1)/2 */
+static fp ELL_J_M, ELL_K_M, ELL_Z_M, ELL_JK_M, ELL_K2I_M;      /* Bandersnatch only (BLS12-381 Fr images) */
 static int g_init_done = 0;
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
 
@@ -161,14 +169,14 @@ static int q_legendre(const fp* a) {
   fp t; f_pow(&FQ, t.v, a->v, e);
   return cmp4(t.v, FQ.one) == 0 ? 1 : -1;
 }
-/* Tonelli-Shanks, loop form (q - 1 = 2^32 * t).  Returns 0 if a is not a square. */
+/* Tonelli-Shanks, loop form (q - 1 = 2^s * t).  Returns 0 if a is not a square. */
 static int q_sqrt(fp* r, const fp* a) {
   if (q_is_zero(a)) { q_zero(r); return 1; }
   if (q_legendre(a) != 1) return 0;
   fp c = TS_C_M, tt, rr;
   f_pow(&FQ, tt.v, a->v, TS_T);
   f_pow(&FQ, rr.v, a->v, TS_E);
-  int m = 32;
+  int m = S_->bf->s;
   while (cmp4(tt.v, FQ.one) != 0) {
     int i = 0; fp t2 = tt;
     while (cmp4(t2.v, FQ.one) != 0) { q_sqr(&t2, &t2); ++i; }
@@ -231,6 +239,7 @@ static void point_encode(uint8_t out[32], const fp* x, const fp* y) {
   uint64_t xi[4], yi[4], nx[4];
   q_to_int(xi, x); q_to_int(yi, y);
   store_le(out, yi);
+  if (S_->flags & 1) { if (xi[0] & 1) out[31] |= 0x80; return; }           /* RFC 8032: x mod 2 */
   if (!is_zero4(xi)) { sub4(nx, FQ.m, xi); if (cmp4(xi, nx) > 0) out[31] |= 0x80; }
 }
 static int point_decode(fp* x, fp* y, const uint8_t in[32]) {
@@ -248,6 +257,11 @@ static int point_decode(fp* x, fp* y, const uint8_t in[32]) {
   if (!q_sqrt(&r, &x2)) return 0;
   uint64_t ri[4], ni[4]; q_to_int(ri, &r);
   fp nr; q_neg(&nr, &r); q_to_int(ni, &nr);
+  if (S_->flags & 1) {                          /* RFC 8032 5.1.3: the root with the flagged parity; x = 0 with the flag fails */
+    if (is_zero4(ri) && flag) return 0;
+    *x = ((int)(ri[0] & 1) == flag) ? r : nr;
+    return 1;
+  }
   int r_is_greater = cmp4(ri, ni) > 0;
   *x = (r_is_greater == flag) ? r : nr;
   return 1;
@@ -341,8 +355,23 @@ static void r_muladd(uint64_t out[4], const uint64_t a[4], const uint64_t b[4], 
 #define SUITE_ID_LEN (S_->suite_id_len)
 static const char H2C_DST[] = "ECVRF_Bandersnatch_XMD:SHA-512_ELL2_RO_Bandersnatch_SHA-512_ELL2";
 
+static void basefield_init(basefield* b, const uint64_t m[4], uint64_t z) {
+  field_init(&b->f, m);
+  uint64_t one[4] = {1, 0, 0, 0}, zz[4] = {z, 0, 0, 0};
+  sub4(b->ts_t, m, one);
+  b->s = 0;
+  while (!(b->ts_t[0] & 1)) { for (int i = 0; i < 4; ++i) b->ts_t[i] = (b->ts_t[i] >> 1) | (i < 3 ? b->ts_t[i + 1] << 63 : 0); b->s++; }
+  add4(b->ts_e, b->ts_t, one);
+  for (int i = 0; i < 4; ++i) b->ts_e[i] = (b->ts_e[i] >> 1) | (i < 3 ? b->ts_e[i + 1] << 63 : 0);
+  fp zm; f_to_mont(&b->f, zm.v, zz);
+  f_pow(&b->f, b->ts_c.v, zm.v, b->ts_t);      /* z is a non-residue: 5 (BLS12-381 Fr, BN254 Fr), 2 (2^255 - 19) */
+}
+static void suite_point(suite_t* s, fp* dst, const uint64_t v[4]) { f_to_mont(&s->bf->f, dst->v, v); }
 static void do_init(void) {
-  field_init(&FQ, P_Q);
+  basefield_init(&BF_BLS, P_Q, 5); basefield_init(&BF_25519, P_ED_Q, 2); basefield_init(&BF_BN254, P_BJ_Q, 5);
+  SUITE_BS.bf = &BF_BLS; SUITE_JJ.bf = &BF_BLS; SUITE_ED.bf = &BF_25519; SUITE_BJ.bf = &BF_BN254;
+  SUITE_BS.challenge_len = SUITE_JJ.challenge_len = SUITE_BJ.challenge_len = 32; SUITE_ED.challenge_len = 16;
+  S_ = &SUITE_BS;
   fp five, fone; q_from_u64(&five, 5); q_from_u64(&fone, 1);
   field_init(&SUITE_BS.fr, P_R_ORDER);
   q_from_int(&SUITE_BS.d, P_BS_D); q_neg(&SUITE_BS.a, &five);
@@ -357,12 +386,17 @@ static void do_init(void) {
   SUITE_JJ.suite_id = "JubJub_SHA-512_TAI"; SUITE_JJ.suite_id_len = 18; SUITE_JJ.h2c_tai = 1; SUITE_JJ.cofactor_log2 = 3;
   q_from_int(&ELL_J_M, P_BS_J); q_from_int(&ELL_K_M, P_BS_K); q_from_u64(&ELL_Z_M, 5);
   fp ki; q_inv(&ki, &ELL_K_M); q_mul(&ELL_JK_M, &ELL_J_M, &ki); q_sqr(&ELL_K2I_M, &ki);
-  uint64_t one[4] = {1, 0, 0, 0};
-  sub4(TS_T, FQ.m, one);
-  while (!(TS_T[0] & 1)) for (int i = 0; i < 4; ++i) TS_T[i] = (TS_T[i] >> 1) | (i < 3 ? TS_T[i + 1] << 63 : 0);
-  add4(TS_E, TS_T, one);
-  for (int i = 0; i < 4; ++i) TS_E[i] = (TS_E[i] >> 1) | (i < 3 ? TS_E[i + 1] << 63 : 0);
-  f_pow(&FQ, TS_C_M.v, five.v, TS_T);         /* 5 is a non-residue mod q */
+  /* Ed25519: a = -1; Baby-JubJub: a = +1 (each in its own base field) */
+  field_init(&SUITE_ED.fr, P_ED_R_ORDER);
+  { uint64_t o1[4] = {1, 0, 0, 0}; fp t; suite_point(&SUITE_ED, &t, o1); fp z; memset(&z, 0, sizeof z); f_sub(&BF_25519.f, SUITE_ED.a.v, z.v, t.v);
+    suite_point(&SUITE_BJ, &SUITE_BJ.a, o1); }
+  suite_point(&SUITE_ED, &SUITE_ED.d, P_ED_D); suite_point(&SUITE_ED, &SUITE_ED.gx, P_ED_GX); suite_point(&SUITE_ED, &SUITE_ED.gy, P_ED_GY);
+  suite_point(&SUITE_ED, &SUITE_ED.bx, P_ED_BX); suite_point(&SUITE_ED, &SUITE_ED.by, P_ED_BY);
+  SUITE_ED.suite_id = "Ed25519_SHA-512_TAI"; SUITE_ED.suite_id_len = 19; SUITE_ED.h2c_tai = 1; SUITE_ED.cofactor_log2 = 3;
+  field_init(&SUITE_BJ.fr, P_BJ_R_ORDER);
+  suite_point(&SUITE_BJ, &SUITE_BJ.d, P_BJ_D); suite_point(&SUITE_BJ, &SUITE_BJ.gx, P_BJ_GX); suite_point(&SUITE_BJ, &SUITE_BJ.gy, P_BJ_GY);
+  suite_point(&SUITE_BJ, &SUITE_BJ.bx, P_BJ_BX); suite_point(&SUITE_BJ, &SUITE_BJ.by, P_BJ_BY);
+  SUITE_BJ.suite_id = "BabyJubJub_SHA-512_TAI"; SUITE_BJ.suite_id_len = 22; SUITE_BJ.h2c_tai = 1; SUITE_BJ.cofactor_log2 = 3;
   g_init_done = 1;
 }
 static void ensure_init(void) { pthread_once(&g_once, do_init); }
@@ -461,7 +495,7 @@ static void challenge(uint64_t c_out[4], const uint8_t pts[5][32], const uint8_t
   sha512_init(&c); sha512_update(&c, SUITE_ID, SUITE_ID_LEN); sha512_update(&c, &two, 1);
   for (int i = 0; i < 5; ++i) { uint8_t e[32]; enc_canonical(e, pts[i]); sha512_update(&c, e, 32); }
   sha512_update(&c, ad, ad_len); sha512_update(&c, &zero, 1); sha512_final(&c, h);
-  r_from_bytes_wide(c_out, h, 32, 1);
+  r_from_bytes_wide(c_out, h, (size_t)S_->challenge_len, !(S_->flags & 2));   /* CHALLENGE_LEN leading bytes, big-endian upstream */
 }
 
 /* Checked deserialisation [ref src/lib.rs:14 `codec`: arkworks validates on-curve AND subgroup membership when
@@ -480,17 +514,28 @@ static int point_decode_chk(fp* x, fp* y, const uint8_t in[32], int bit) {
 }
 
 /* ------------------------------------------------------------------ exported API */
-/* 1 = Bandersnatch_SHA-512_ELL2 (default), 2 = JubJub_SHA-512_TAI.  Process-global: tests only. */
+/* 1 = Bandersnatch_SHA-512_ELL2 (default), 2 = JubJub_SHA-512_TAI, 3 = Ed25519_SHA-512_TAI, 4 = BabyJubJub_SHA-512_TAI.
+ * Process-global: tests only. */
 void oracle_set_check_mask(int mask) { g_check_mask = mask; }
 /* A suite from a descriptor (include/vrfhip.h vrfhip_suite_desc): curve 1 = Bandersnatch (Elligator 2), 2 = JubJub
  * (try-and-increment); suite string, hash-to-curve DST, generator and blinding base (x || y, 32-byte little-endian)
  * supplied by the caller.  Selects it as the current suite.  Returns -1 on a bad argument (the points are not
  * validated here: the product does that). */
+int oracle_set_suite_desc2(int curve, const uint8_t* suite_id, size_t id_len, const uint8_t* dst, size_t dst_len,
+                           const uint8_t g_xy[64], const uint8_t b_xy[64], int challenge_len, int flags);
 int oracle_set_suite_desc(int curve, const uint8_t* suite_id, size_t id_len, const uint8_t* dst, size_t dst_len,
                           const uint8_t g_xy[64], const uint8_t b_xy[64]) {
+  return oracle_set_suite_desc2(curve, suite_id, id_len, dst, dst_len, g_xy, b_xy, curve == 3 ? 16 : 32, 0);
+}
+/* curve: 1 Bandersnatch, 2 JubJub, 3 Ed25519, 4 Baby-JubJub (vrfhip_curve); challenge_len 1..32; flags as suite_t.flags */
+int oracle_set_suite_desc2(int curve, const uint8_t* suite_id, size_t id_len, const uint8_t* dst, size_t dst_len,
+                           const uint8_t g_xy[64], const uint8_t b_xy[64], int challenge_len, int flags) {
   ensure_init();
-  if ((curve != 1 && curve != 2) || id_len == 0 || id_len > sizeof CUSTOM_ID || dst_len > sizeof CUSTOM_DST) return -1;
-  SUITE_CUSTOM = curve == 1 ? SUITE_BS : SUITE_JJ;
+  if (curve < 1 || curve > 4 || id_len == 0 || id_len > sizeof CUSTOM_ID || dst_len > sizeof CUSTOM_DST) return -1;
+  if (challenge_len < 1 || challenge_len > 32 || (flags & ~7)) return -1;
+  SUITE_CUSTOM = curve == 1 ? SUITE_BS : curve == 2 ? SUITE_JJ : curve == 3 ? SUITE_ED : SUITE_BJ;
+  SUITE_CUSTOM.challenge_len = challenge_len; SUITE_CUSTOM.flags = flags;
+  S_ = &SUITE_CUSTOM;                          /* the conversions below run in the suite's base field */
   memcpy(CUSTOM_ID, suite_id, id_len); SUITE_CUSTOM.suite_id = CUSTOM_ID; SUITE_CUSTOM.suite_id_len = id_len;
   if (dst_len) memcpy(CUSTOM_DST, dst, dst_len);
   SUITE_CUSTOM.h2c_dst = CUSTOM_DST; SUITE_CUSTOM.h2c_dst_len = dst_len;
@@ -502,7 +547,8 @@ int oracle_set_suite_desc(int curve, const uint8_t* suite_id, size_t id_len, con
 }
 int oracle_set_suite(int id) {
   ensure_init();
-  if (id == 1) S_ = &SUITE_BS; else if (id == 2) S_ = &SUITE_JJ; else return -1;
+  if (id == 1) S_ = &SUITE_BS; else if (id == 2) S_ = &SUITE_JJ; else if (id == 3) S_ = &SUITE_ED;
+  else if (id == 4) S_ = &SUITE_BJ; else return -1;
   return 0;
 }
 int oracle_secret_from_seed(const uint8_t* seed, size_t len, uint8_t sk_out[32]) {
@@ -528,6 +574,13 @@ int oracle_output_hash(const uint8_t gamma[32], uint8_t out[64]) {
   ensure_init();
   uint8_t three = 3, zero = 0; sha512_ctx c;
   uint8_t e[32]; enc_canonical(e, gamma);       /* `Output::hash` encodes the typed point */
+  if (S_->flags & 4) {                          /* RFC 9381 proof_to_hash: cofactor * Gamma */
+    fp x, y; pt p;
+    if (!point_decode(&x, &y, gamma)) return 2;
+    pt_from_affine(&p, &x, &y);
+    for (int i = 0; i < S_->cofactor_log2; ++i) pt_double(&p, &p);
+    pt_to_affine(&x, &y, &p); point_encode(e, &x, &y);
+  }
   sha512_init(&c); sha512_update(&c, SUITE_ID, SUITE_ID_LEN); sha512_update(&c, &three, 1); sha512_update(&c, e, 32);
   sha512_update(&c, &zero, 1); sha512_final(&c, out);
   return 0;

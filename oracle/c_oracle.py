@@ -47,25 +47,33 @@ def load() -> ctypes.CDLL:
         lib.oracle_sha512.argtypes = [P, c_size_t, P]
         lib.oracle_set_suite_desc.argtypes = [c_int, P, c_size_t, P, c_size_t, P, P]
         lib.oracle_set_suite_desc.restype = c_int
+        lib.oracle_set_suite_desc2.argtypes = [c_int, P, c_size_t, P, c_size_t, P, P, c_int, c_int]
+        lib.oracle_set_suite_desc2.restype = c_int
         lib.oracle_set_check_mask.argtypes = [c_int]
         _lib = lib
     return _lib
 
 
 def set_suite(suite_id: int) -> None:
-    """1 = Bandersnatch_SHA-512_ELL2 (default), 2 = JubJub_SHA-512_TAI (process-global selection)."""
+    """1 = Bandersnatch_SHA-512_ELL2 (default), 2 = JubJub_SHA-512_TAI, 3 = Ed25519_SHA-512_TAI,
+    4 = BabyJubJub_SHA-512_TAI (process-global selection)."""
     if load().oracle_set_suite(int(suite_id)) != 0:
         raise ValueError("unknown suite")
 
 
-def set_suite_desc(curve: int, suite_id: bytes, h2c_dst: bytes, g_xy: bytes, b_xy: bytes) -> None:
+def set_suite_desc(curve: int, suite_id: bytes, h2c_dst: bytes, g_xy: bytes, b_xy: bytes, challenge_len: int = None,
+                   flags: int = 0) -> None:
     """Select a suite given as a descriptor (the fields of include/vrfhip.h vrfhip_suite_desc): curve 1 = Bandersnatch,
-    2 = JubJub; g_xy / b_xy = generator / blinding base as x || y, 32-byte little-endian.  set_suite(1) goes back."""
+    2 = JubJub, 3 = Ed25519, 4 = Baby-JubJub; g_xy / b_xy = generator / blinding base as x || y, 32-byte little-endian;
+    challenge_len defaults to the curve's built-in suite (16 for Ed25519, else 32); flags = vrfhip_suite_desc.flags.
+    set_suite(1) goes back."""
     a = lambda b: np.frombuffer(bytes(b) + b"\0", np.uint8)
     sid, dst, g, bb = a(suite_id), a(h2c_dst), a(g_xy), a(b_xy)
     assert len(g_xy) == 64 and len(b_xy) == 64
-    if load().oracle_set_suite_desc(int(curve), sid.ctypes.data, len(suite_id), dst.ctypes.data, len(h2c_dst),
-                                    g.ctypes.data, bb.ctypes.data) != 0:
+    if challenge_len is None:
+        challenge_len = 16 if int(curve) == 3 else 32
+    if load().oracle_set_suite_desc2(int(curve), sid.ctypes.data, len(suite_id), dst.ctypes.data, len(h2c_dst),
+                                     g.ctypes.data, bb.ctypes.data, int(challenge_len), int(flags)) != 0:
         raise ValueError("bad suite descriptor")
 
 

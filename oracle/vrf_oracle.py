@@ -59,6 +59,11 @@ class SuiteParams:
     mont_k: int = 0
     ell2_z: int = 0
     challenge_len: int = 32
+    # What a `Suite` impl may override besides its constants (vrfhip_suite_desc.flags): the three deviations that separate
+    # RFC 9381's ECVRF-EDWARDS25519-SHA512-TAI from upstream's built-in Ed25519 suite.  False for every upstream suite.
+    sign_parity: bool = False      # compressed points carry x mod 2 in bit 255 (RFC 8032) instead of x > q - x
+    challenge_le: bool = False     # the truncated challenge hash is a little-endian integer
+    hash_cofactor: bool = False    # Output::hash hashes cofactor * Gamma (RFC 9381 proof_to_hash)
 
 
 BANDERSNATCH = SuiteParams(
@@ -221,7 +226,7 @@ def challenge_decode(b: bytes, r: int) -> int:
 def point_encode(S: SuiteParams, P: Point) -> bytes:
     x, y = P
     out = bytearray(y.to_bytes(32, "little"))
-    if x > (S.q - x) % S.q:
+    if (x & 1) if S.sign_parity else (x > (S.q - x) % S.q):
         out[31] |= 0x80
     return bytes(out)
 
@@ -246,6 +251,10 @@ def point_decode(S: SuiteParams, b: bytes) -> Optional[Point]:
     if x is None:
         return None
     neg = (q - x) % q
+    if S.sign_parity:               # RFC 8032 5.1.3: the root whose low bit is the flag; x = 0 with the flag set fails
+        if x == 0 and flag:
+            return None
+        return (x if (x & 1) == flag else neg, y)
     lo, hi = (x, neg) if x <= neg else (neg, x)
     x = hi if flag else lo          # x == 0 with the flag set is accepted, as arkworks does
     return (x, y)
@@ -365,11 +374,13 @@ def nonce_rfc8032(S: SuiteParams, sk: int, H: Point) -> int:
 
 def challenge_rfc9381(S: SuiteParams, pts, ad: bytes) -> int:
     buf = S.suite_id + b"\x02" + b"".join(point_encode(S, P) for P in pts) + ad + b"\x00"
-    return int.from_bytes(sha512(buf)[: S.challenge_len], "big") % S.r
+    return int.from_bytes(sha512(buf)[: S.challenge_len], "little" if S.challenge_le else "big") % S.r
 
 
 def output_hash(S: SuiteParams, gamma: Point) -> bytes:
-    """[ref src/lib.rs:15 `Output::hash`] point_to_hash_rfc_9381, no cofactor clearing."""
+    """[ref src/lib.rs:15 `Output::hash`] point_to_hash_rfc_9381, no cofactor clearing (upstream; RFC 9381 clears it)."""
+    if S.hash_cofactor:
+        gamma = te_mul(S, S.cofactor, gamma)
     return sha512(S.suite_id + b"\x03" + point_encode(S, gamma) + b"\x00")
 
 
@@ -445,6 +456,89 @@ def jubjub_params() -> SuiteParams:
     # host-supplied blinding base: TAI hash of a fixed label (nothing-up-my-sleeve)
     B = hash_to_curve_tai(base, b"vrfhip-jubjub-blinding-base")
     return SuiteParams(**{**base.__dict__, "bx": B[0], "by": B[1]})
+
+
+# --------------------------------------------------------------------------------------
+# Ed25519 and Baby-JubJub descriptors  [ref src/lib.rs:14 `suites`]  
+# Curve constants: RFC 8032 section 5.1 / ark-ed-on-bn254, checked algebraically (tests/test_oracle_kat.py: on the curve,
+# order r, cofactor).  Suite strings, CHALLENGE_LEN and the absence of a salt are recollections of upstream; the blinding
+# bases are this repository's (TAI hash of a fixed label, as for JubJub): parity with upstream unpinned.
+# --------------------------------------------------------------------------------------
+
+Q_25519 = (1 << 255) - 19
+Q_BN254 = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def _with_tai_blinding(base: SuiteParams, label: bytes) -> SuiteParams:
+    B = hash_to_curve_tai(base, label)
+    return SuiteParams(**{**base.__dict__, "bx": B[0], "by": B[1]})
+
+
+def ed25519_params() -> SuiteParams:
+    q = Q_25519
+    base = SuiteParams(
+        name="ed25519_sha512_tai", suite_id=b"Ed25519_SHA-512_TAI", q=q, a=q - 1,
+        d=(-121665 * pow(121666, q - 2, q)) % q, r=(1 << 252) + 27742317777372353535851937790883648493, cofactor=8,
+        gx=15112221349535400772501151409588531511454012693041857206046113283949847762202,
+        gy=46316835694926478169428394003475163141307993866256225615783033603165251855960,
+        bx=0, by=1, h2c="tai", challenge_len=16)
+    return _with_tai_blinding(base, b"vrfhip-ed25519-blinding-base")
+
+
+def baby_jubjub_params() -> SuiteParams:
+    q = Q_BN254
+    base = SuiteParams(
+        name="babyjubjub_sha512_tai", suite_id=b"BabyJubJub_SHA-512_TAI", q=q, a=1,
+        d=168696 * pow(168700, q - 2, q) % q,
+        r=2736030358979909402780800718157159386076813972158567259200215660948447373041, cofactor=8,
+        gx=19698561148652590122159747500897617769866003486955115824547446575314762165298,
+        gy=19298250018296453272277890825869354524455968081175474282777126169995084727839,
+        bx=0, by=1, h2c="tai")
+    return _with_tai_blinding(base, b"vrfhip-babyjubjub-blinding-base")
+
+
+# --------------------------------------------------------------------------------------
+# RFC 9381 ECVRF-EDWARDS25519-SHA512-TAI (section 5.5, suite_string 0x03) through the functions above.
+# The suite differs from upstream's Ed25519 suite in data (suite string 0x03; the public key prepended to alpha as the
+# encode_to_curve salt) and in the three flags of SuiteParams -- and in how a secret key becomes a scalar and a nonce
+# prefix, which is the only part restated here on its own (RFC 8032 key expansion).  Its published vectors (RFC 9381
+# Appendix B.3, tests/golden/rfc9381_edwards25519_sha512_tai.json) therefore pin try-and-increment, the codec with
+# cofactor clearing, the challenge layout, s = k + c x and the output hash of this oracle -- the code paths that the
+# JubJub-family suites have no external vector for.
+# --------------------------------------------------------------------------------------
+
+def ed25519_rfc9381_params() -> SuiteParams:
+    e = ed25519_params()
+    return SuiteParams(**{**e.__dict__, "name": "rfc9381_edwards25519_sha512_tai", "suite_id": b"\x03",
+                          "sign_parity": True, "challenge_le": True, "hash_cofactor": True})
+
+
+def rfc9381_ed25519_expand_key(S: SuiteParams, sk_seed: bytes):
+    """RFC 8032 5.1.5: (x, nonce prefix, public key point)."""
+    h = sha512(sk_seed)
+    a = bytearray(h[:32])
+    a[0] &= 248
+    a[31] &= 127
+    a[31] |= 64
+    x = int.from_bytes(a, "little")
+    return x, h[32:], te_mul(S, x, (S.gx, S.gy))
+
+
+def rfc9381_ed25519_prove(sk_seed: bytes, alpha: bytes):
+    """ECVRF_prove of RFC 9381 section 5.1 for suite 0x03 -> dict of the vector's fields (bytes)."""
+    S = ed25519_rfc9381_params()
+    x, prefix, Y = rfc9381_ed25519_expand_key(S, sk_seed)
+    pk = point_encode(S, Y)
+    H = hash_to_curve_tai(S, pk + alpha)                       # encode_to_curve_salt = PK_string
+    h_string = point_encode(S, H)
+    gamma = te_mul(S, x, H)
+    k = int.from_bytes(sha512(prefix + h_string), "little") % S.r      # RFC 8032-style nonce (section 5.4.2.2)
+    U, V = te_mul(S, k, (S.gx, S.gy)), te_mul(S, k, H)
+    c = challenge_rfc9381(S, [Y, H, gamma, U, V], b"")
+    s = (k + c * x) % S.r
+    pi = point_encode(S, gamma) + c.to_bytes(16, "little") + s.to_bytes(32, "little")
+    return dict(pk=pk, x=x.to_bytes(32, "little"), h=h_string, k=k.to_bytes(32, "little"), u=point_encode(S, U),
+                v=point_encode(S, V), pi=pi, beta=output_hash(S, gamma))
 
 
 # --------------------------------------------------------------------------------------

@@ -204,7 +204,8 @@ def test_invalid_descriptors_are_refused():
     cases = [dataclasses.replace(good, blinding_base=off_curve), dataclasses.replace(good, blinding_base=not_subgroup),
              dataclasses.replace(good, generator=xy((0, 1))), dataclasses.replace(good, generator=le(S.q) + le(1)),
              dataclasses.replace(good, suite_id=b""), dataclasses.replace(good, h2c_dst=b""),
-             dataclasses.replace(good, challenge_len=16), dataclasses.replace(good, curve=7)]
+             dataclasses.replace(good, challenge_len=0), dataclasses.replace(good, challenge_len=33),
+             dataclasses.replace(good, flags=8), dataclasses.replace(good, curve=7)]
     for d in cases:
         with pytest.raises(VrfHipError):
             Context(0, desc=d).close()
