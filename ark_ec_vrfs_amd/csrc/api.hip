@@ -1067,7 +1067,7 @@ int32_t rlc_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* inp
       for (int i = 0; i < 5; ++i) {
         uint8_t* enc = sg.take(n * 32);
         if (ctx->coords_mont256()) FIELD_CALL(ctx, launch_xy_from_mont256(n, d[i], ctx->stream));      // the staged copy, in place
-        FIELD_CALL(ctx, launch_affine_compress(n, d[i], enc, ctx->stream));
+        FIELD_CALL(ctx, launch_affine_compress(n, d[i], enc, ctx->T.sq.str.flags, ctx->stream));
         d[i] = enc;
       }
     }
@@ -1148,7 +1148,7 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
   int32_t rc = ensure_msm_workspace(ctx, msm_workspace_bytes(n, groups));
   if (rc) return rc;
   FIELD_CALL(ctx, launch_msm_coords((int)ctx->suite, n, d_bases_xy, d_scalars, d_out_point, d_out_xy, d_status, ctx->d_msm_ws, groups,
-                    ctx->coords_mont256() ? 1 : 0, st));
+                    ctx->coords_mont256() ? 1 : 0, ctx->T.sq.str.flags, st));
   if (d_out_xy && ctx->coords_mont256()) FIELD_CALL(ctx, launch_xy_to_mont256(1, d_out_xy, st));
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;

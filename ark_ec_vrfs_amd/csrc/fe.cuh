@@ -173,9 +173,9 @@ VRF_HD uint64_t mad(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b
 //  kind 1 (BN254 Fr, general q): m = t * (-q^-1) mod 2^29 -- NINV29 = 2^28 - 1 there, a shift and a subtraction -- and
 //  the column takes m * q[0] like every other limb of q: 9 more multiply-adds per product than kind 0.
 //
-//  kind 2 (2^255 - 19): no Montgomery form at all (R = 1).  The columns 9..16 of the plain product are carried into
-//  29-bit digits h first, then 2^261 = 1216 (mod q) folds them onto the columns 0..8, and what is left above bit 255
-//  comes back as 19 * carry into limb 0: 81 + 9 multiply-adds instead of 153.  Output < 2^255 + 2^30.
+//  kind 2 (2^255 - 19): no Montgomery form at all (R = 1).  The 17 columns of the plain product are carried into 29-bit
+//  digits, then 2^261 = 1216 (mod q) folds digit k + 9 onto digit k in a second carry pass, and what is left above bit
+//  255 comes back as 19 * carry into limb 0: 81 + 9 multiply-adds instead of 153.  Output < 2^255 + 2^30.
 VRF_HD constexpr uint64_t mont_bias() { return vrfk::FIELD_KIND == 0 ? (uint64_t)LMASK : 0; }
 VRF_HD uint32_t mont_digit(uint32_t col) {
   if constexpr (vrfk::FIELD_KIND == 0) return ~col & LMASK;          // the accumulator carries the bias LMASK
@@ -184,11 +184,21 @@ VRF_HD uint32_t mont_digit(uint32_t col) {
 constexpr uint32_t PM_FOLD = 1216;      // 2^261 mod (2^255 - 19)
 constexpr int PM_TOPBITS = 23;          // bit 255 is bit 23 of limb 8
 
-// tail of the pseudo-Mersenne product: acc = bits >= 232 of the folded value; r.v[0..7] hold the digits below
+// second pass of the pseudo-Mersenne product: d = the plain product in 18 digits (d[17] < 2^29 because the operands are
+// < 64 q); digit k + 9 folds onto digit k with the factor 2^261 = 1216, and what then lies above bit 255 (bit 23 of
+// limb 8) comes back as 19 * carry into limb 0.  Out: limbs < 2^29 + 2, value < 2^255 + 2^30 < 2q.
 template <int V>
-VRF_HD void pm_finish(Fe<1, V>& r, uint64_t acc) {
+VRF_HD void pm_fold(Fe<1, V>& r, const uint32_t (&d)[2 * NL]) {
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < NL - 1; ++k) {
+    acc = mad(d[k + NL], PM_FOLD, acc + d[k]);            // < 2^41
+    r.v[k] = (uint32_t)acc & LMASK;
+    acc >>= LW;
+  }
+  acc = mad(d[2 * NL - 1], PM_FOLD, acc + d[NL - 1]);
   r.v[NL - 1] = (uint32_t)acc & ((1u << PM_TOPBITS) - 1);
-  const uint32_t c = (uint32_t)(acc >> PM_TOPBITS);       // < 64 + 19 V1 V2 < 2^17
+  const uint32_t c = (uint32_t)(acc >> PM_TOPBITS);       // < 2^18
   const uint32_t r0 = r.v[0] + 19u * c;                   // < 2^30
   r.v[0] = r0 & LMASK;
   r.v[1] += r0 >> LW;
@@ -199,28 +209,17 @@ VRF_HD Fe<1, mul_v(V1, V2)> fe_mul(const Fe<L1, V1>& a, const Fe<L2, V2>& b) {
   static_assert(L1 * L2 <= 6, "fe_mul: 64-bit column accumulator could overflow");
   Fe<1, mul_v(V1, V2)> r;
   if constexpr (vrfk::FIELD_KIND == 2) {
-    uint32_t h[NL];
+    uint32_t d[2 * NL];                                   // the plain product in 29-bit digits: < 2^522
     uint64_t acc = 0;
 #pragma unroll
-    for (int k = NL; k < 2 * NL - 1; ++k) {
+    for (int k = 0; k < 2 * NL - 1; ++k) {
 #pragma unroll
-      for (int i = k - NL + 1; i < NL; ++i) acc = mad(a.v[i], b.v[k - i], acc);
-      h[k - NL] = (uint32_t)acc & LMASK;
+      for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); ++i) acc = mad(a.v[i], b.v[k - i], acc);
+      d[k] = (uint32_t)acc & LMASK;
       acc >>= LW;
     }
-    h[NL - 1] = (uint32_t)acc;                            // < 2^30: a.v[8] b.v[8] < 2^58
-    acc = 0;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-#pragma unroll
-      for (int i = 0; i <= k; ++i) acc = mad(a.v[i], b.v[k - i], acc);
-      acc = mad(h[k], PM_FOLD, acc);
-      if (k < NL - 1) {
-        r.v[k] = (uint32_t)acc & LMASK;
-        acc >>= LW;
-      }
-    }
-    pm_finish(r, acc);
+    d[2 * NL - 1] = (uint32_t)acc;
+    pm_fold(r, d);
     return r;
   } else {
   uint32_t m[NL];
@@ -258,30 +257,18 @@ VRF_HD Fe<1, mul_v(V, V)> fe_sqr(const Fe<L, V>& a) {
 #pragma unroll
   for (int i = 0; i < NL; ++i) a2[i] = a.v[i] << 1;
   if constexpr (vrfk::FIELD_KIND == 2) {
-    uint32_t h[NL];
+    uint32_t d[2 * NL];
     uint64_t acc = 0;
 #pragma unroll
-    for (int k = NL; k < 2 * NL - 1; ++k) {
+    for (int k = 0; k < 2 * NL - 1; ++k) {
 #pragma unroll
-      for (int i = k - NL + 1; 2 * i < k; ++i) acc = mad(a2[i], a.v[k - i], acc);
+      for (int i = (k < NL ? 0 : k - NL + 1); 2 * i < k; ++i) acc = mad(a2[i], a.v[k - i], acc);
       if ((k & 1) == 0) acc = mad(a.v[k / 2], a.v[k / 2], acc);
-      h[k - NL] = (uint32_t)acc & LMASK;
+      d[k] = (uint32_t)acc & LMASK;
       acc >>= LW;
     }
-    h[NL - 1] = (uint32_t)acc;
-    acc = 0;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-#pragma unroll
-      for (int i = 0; 2 * i < k; ++i) acc = mad(a2[i], a.v[k - i], acc);
-      if ((k & 1) == 0) acc = mad(a.v[k / 2], a.v[k / 2], acc);
-      acc = mad(h[k], PM_FOLD, acc);
-      if (k < NL - 1) {
-        r.v[k] = (uint32_t)acc & LMASK;
-        acc >>= LW;
-      }
-    }
-    pm_finish(r, acc);
+    d[2 * NL - 1] = (uint32_t)acc;
+    pm_fold(r, d);
     return r;
   } else {
   uint32_t m[NL];

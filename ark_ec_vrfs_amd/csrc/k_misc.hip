@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(BLOCK, 2) k_hash_to_curve(size_t n, BytesView 
   FeN x, y;
   te_to_affine(x, y, h);
   uint32_t e[8];
-  te_encode_affine(e, x, y);
+  te_encode_affine(e, x, y, T.sq.str.flags);
   store32(points, i, e);
 }
 void launch_hash_to_curve(int suite, size_t n, BytesView msg, uint8_t* points, DevTables T, hipStream_t st) {
@@ -76,19 +76,30 @@ void launch_hash_to_curve(int suite, size_t n, BytesView msg, uint8_t* points, D
 
 // ---- Output::hash ----
 template <class S>
-__global__ void __launch_bounds__(BLOCK) k_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash, SuiteStr ss) {
+__global__ void __launch_bounds__(BLOCK) k_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash, SqrtTables T) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t g[8], o[16];
   load32(g, gamma, i);
   enc_canonical(g);                              // `Output::hash` encodes the typed point
-  output_hash_item<S>(o, g, ss);
+  bool ok = true;
+  if (T.str.flags & SS_HASH_COFACTOR) {          // RFC 9381 proof_to_hash: cofactor * Gamma (wave-uniform branch)
+    uint32_t e[8];
+    ok = output_cofactor_encoding<S>(e, g, T);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = e[j];
+  }
+  output_hash_item<S>(o, g, T.str);
+  if (!ok) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j] = 0;       // an output that does not decode has no hash
+  }
   uint32_t* p = reinterpret_cast<uint32_t*>(hash + i * 64);
 #pragma unroll
   for (int j = 0; j < 16; ++j) p[j] = o[j];
 }
 void launch_output_hash(int suite, size_t n, const uint8_t* gamma, uint8_t* hash, DevTables T, hipStream_t st) {
-  if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_output_hash<S>, grid_for(n), dim3(BLOCK), 0, st, n, gamma, hash, T.sq.str));
+  if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_output_hash<S>, grid_for(n), dim3(BLOCK), 0, st, n, gamma, hash, T.sq));
 }
 
 // ---- Secret::from_seed / Secret::public ----
@@ -201,7 +212,7 @@ __global__ void __launch_bounds__(BLOCK) k_test_point_add(size_t n, const uint8_
   PtE r = te_add<S>(te_from_affine(xa, da.y), te_from_affine(xb, db.y));
   FeN x, y;
   te_to_affine(x, y, r);
-  te_encode_affine(e, x, y);
+  te_encode_affine(e, x, y, T.sq.str.flags);
   if (!ok) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[j] = 0;
@@ -230,7 +241,7 @@ __global__ void __launch_bounds__(BLOCK) k_test_scalar_mul(size_t n, const uint8
   PtE r = var_base_mul<S>(tab, kw);
   FeN rx, ry;
   te_to_affine(rx, ry, r);
-  te_encode_affine(e, rx, ry);
+  te_encode_affine(e, rx, ry, T.sq.str.flags);
   if (!ok) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[j] = 0;

@@ -318,7 +318,7 @@ template <class S>
 __global__ void __launch_bounds__(MSM_FINAL_BLOCK) k_msm_final(const uint32_t* part, int groups, int groups_hi,
                                                                uint8_t* out_enc, uint8_t* out_xy,
                                                                const uint8_t* flags, uint8_t* status,
-                                                               uint8_t* fail_flag) {
+                                                               uint8_t* fail_flag, uint32_t sflags) {
   __shared__ uint32_t stage[32 * MSM_PT_WORDS];
   const int t = threadIdx.x, w = t >> 2, q = t & 3;
   // quad w < 23: R_w = sum over the groups (lane q takes groups q, q+4, ...; two butterfly steps join
@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(MSM_FINAL_BLOCK) k_msm_final(const uint32_t* p
     FeN x, y;
     te_to_affine(x, y, acc);
     uint32_t e[8], xw[8], yw[8];
-    te_encode_affine(e, x, y);
+    te_encode_affine(e, x, y, sflags);
     fe_to_u256(xw, x); fe_to_u256(yw, y);
     // neutral element: x == 0 and y == 1
     uint32_t nz = 0;
@@ -429,6 +429,7 @@ size_t msm_workspace_bytes(size_t n, int groups) {
 
 MsmLayout msm_layout(size_t n, size_t n_long, int groups, void* ws) {
   MsmLayout L;
+  L.sflags = 0;
   L.n = n;
   L.n_long = n_long < n ? n_long : n;
   L.groups = groups;
@@ -468,7 +469,7 @@ static void launch_msm_core_t(const MsmLayout& L, uint8_t* out_enc, uint8_t* out
   hipLaunchKernelGGL(k_msm_buckets<S>, dim3(wgs), dim3(MSM_BLOCK), lds_bytes, st, L);
   if (ev) (void)hipEventRecord(ev[0], st);
   hipLaunchKernelGGL(k_msm_final<S>, dim3(1), dim3(MSM_FINAL_BLOCK), 0, st, L.part, L.groups, L.groups_hi, out_enc, out_xy, L.flags,
-                     status, fail_flag);
+                     status, fail_flag, L.sflags);
   if (ev) { (void)hipEventRecord(ev[1], st); (void)hipEventRecord(ev[2], st); }
 }
 
@@ -480,8 +481,10 @@ void launch_msm_core(int suite, const MsmLayout& L, uint8_t* out_enc, uint8_t* o
 // mont256 != 0: the bases' coordinates are Montgomery images x 2^256 mod q (VRFHIP_FLAG_COORDS_MONT256); out_xy stays
 // canonical here (api.hip converts it with launch_xy_to_mont256)
 void launch_msm_coords(int suite, size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t* out_enc,
-                       uint8_t* out_xy, uint8_t* status, void* ws, int groups, int mont256, hipStream_t st) {
+                       uint8_t* out_xy, uint8_t* status, void* ws, int groups, int mont256, uint32_t sflags,
+                       hipStream_t st) {
   MsmLayout L = msm_layout(n, n, groups, ws);
+  L.sflags = sflags;
   (void)hipMemsetAsync(L.flags, 0, 256, st);
   VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_msm_prep<S>, grid_for(n), dim3(BLOCK), 0, st, n, xy, scalars,
                                                L.pts, L.digits, L.flags, mont256));
@@ -489,7 +492,7 @@ void launch_msm_coords(int suite, size_t n, const uint8_t* xy, const uint8_t* sc
 }
 void launch_msm(int suite, size_t n, const uint8_t* xy, const uint8_t* scalars, uint8_t* out_enc,
                 uint8_t* out_xy, uint8_t* status, void* ws, int groups, hipStream_t st) {
-  launch_msm_coords(suite, n, xy, scalars, out_enc, out_xy, status, ws, groups, 0, st);
+  launch_msm_coords(suite, n, xy, scalars, out_enc, out_xy, status, ws, groups, 0, 0, st);
 }
 
 VRF_NS_END

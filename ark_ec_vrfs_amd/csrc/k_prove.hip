@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_prove_finish(ProveArgs a) {
   size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   if (first >= a.n) return;
   const int tstride = ProveLayout<S>::TAB_WORDS;
-  prove_encode_multi<S>(a.k_lane, first, a.n, a.ws.pts, a.ws.tabs, tstride);
+  prove_encode_multi<S>(a.k_lane, first, a.n, a.ws.pts, a.ws.tabs, tstride, a.T.sq.str.flags);
 #pragma unroll 1
   for (int jj = 0; jj < a.k_lane; ++jj) {
     size_t i = first + jj;

@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_rlc_prep_affine(RlcArgs a) {
       uint32_t e[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) e[j] = yw[j];
-      if (u256_gt(xw, vrfk::QM1H32)) e[7] |= 0x80000000u;
+      if (te_x_sign(xw, a.T.sq.str.flags)) e[7] |= 0x80000000u;
       const int slot = p == 0 ? 1 : p == 1 ? 2 : p == 2 ? 0 : p;
 #pragma unroll
       for (int q = 0; q < 5; ++q)
@@ -226,7 +226,7 @@ __global__ void k_rlc_fixed(RlcArgs a) {
 
 // x || y (64 B) -> ArkworksCodec compressed (32 B); used when a failed affine batch falls back to the
 // per-proof kernels
-__global__ void __launch_bounds__(BLOCK) k_affine_compress(size_t n, const uint8_t* xy, uint8_t* enc) {
+__global__ void __launch_bounds__(BLOCK) k_affine_compress(size_t n, const uint8_t* xy, uint8_t* enc, uint32_t sflags) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint32_t* w = reinterpret_cast<const uint32_t*>(xy + i * 64);
@@ -235,15 +235,15 @@ __global__ void __launch_bounds__(BLOCK) k_affine_compress(size_t n, const uint8
   for (int j = 0; j < 8; ++j) { xw[j] = w[j]; e[j] = w[8 + j]; }
   // coordinates >= q cannot be encoded: poison the encoding (y = 2^255 - 1 >= q) so that decode rejects it
   const bool bad = u256_ge(xw, vrfk::Q32) || u256_ge(e, vrfk::Q32);
-  if (u256_gt(xw, vrfk::QM1H32)) e[7] |= 0x80000000u;
+  if (te_x_sign(xw, sflags)) e[7] |= 0x80000000u;
   if (bad) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[j] = 0xffffffffu;
   }
   store32(enc, i, e);
 }
-void launch_affine_compress(size_t n, const uint8_t* xy, uint8_t* enc, hipStream_t st) {
-  if (n) hipLaunchKernelGGL(k_affine_compress, grid_for(n), dim3(BLOCK), 0, st, n, xy, enc);
+void launch_affine_compress(size_t n, const uint8_t* xy, uint8_t* enc, uint32_t sflags, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(k_affine_compress, grid_for(n), dim3(BLOCK), 0, st, n, xy, enc, sflags);
 }
 
 template <class S>

@@ -293,7 +293,7 @@ VRF_HD PtE te_add(const PtE& p, const PtE& q) {
 }
 
 // -------------------------------------------------------------------------------- codec
-// ArkworksCodec: y little-endian, bit 255 = (x > q - x).
+// ArkworksCodec: y little-endian, bit 255 = (x > q - x) -- or x mod 2, see te_x_sign.
 VRF_HD bool u256_gt(const uint32_t a[8], const uint32_t (&b)[8]) {   // a > b
   bool gt = false, decided = false;
 #pragma unroll
@@ -312,11 +312,16 @@ VRF_HD bool u256_ge(const uint32_t a[8], const uint32_t (&b)[8]) {   // a >= b
 }
 
 // affine (Montgomery) -> 32-byte compressed encoding as 8 LE u32 words
-VRF_HD void te_encode_affine(uint32_t out[8], const FeN& x, const FeN& y) {
+// the sign flag of a compressed point from the canonical words of x: arkworks' "x > q - x", or RFC 8032's x mod 2 when the
+// suite descriptor says so (SS_SIGN_PARITY; wave-uniform)
+VRF_HD bool te_x_sign(const uint32_t xw[8], uint32_t sflags) {
+  return (sflags & SS_SIGN_PARITY) ? (xw[0] & 1u) != 0 : u256_gt(xw, vrfk::QM1H32);
+}
+VRF_HD void te_encode_affine(uint32_t out[8], const FeN& x, const FeN& y, uint32_t sflags) {
   uint32_t xw[8];
   fe_to_u256(xw, x);
   fe_to_u256(out, y);
-  if (u256_gt(xw, vrfk::QM1H32)) out[7] |= 0x80000000u;
+  if (te_x_sign(xw, sflags)) out[7] |= 0x80000000u;
 }
 
 VRF_NS_END

@@ -134,9 +134,11 @@ VRF_HD bool decode_phase_b(Fe<1, 4>& x_out, const DecodeA& a, const FeN& den_inv
 #pragma unroll
   for (int i = 0; i < 8; ++i) nz |= xw[i];
   sq = sq || (nz == 0);
-  bool greater = u256_gt(xw, vrfk::QM1H32);
+  bool greater = te_x_sign(xw, T.str.flags);
   x_out = fe_norm(fe_cneg(greater != a.flag, root));
-  // x == 0: -0 = K*q, still a valid representation of zero
+  // x == 0: -0 = K*q, still a valid representation of zero.  arkworks accepts x = 0 with either flag; RFC 8032's decoding
+  // (SS_SIGN_PARITY) rejects x = 0 with the flag set
+  if ((T.str.flags & SS_SIGN_PARITY) && nz == 0 && a.flag) sq = false;
   return a.ok && sq;
 }
 
@@ -622,8 +624,18 @@ VRF_HD void challenge5(uint32_t c_out[8], const uint32_t (&pts)[5][8], const uin
   sha512_put_byte(h, 0x00);
   sha512_final(h);
   uint32_t be[8];
-  sha512_be256(be, h);
-  if (ss.challenge_len != 32u) u256_shr_bytes(be, 32u - ss.challenge_len);    // `Suite::CHALLENGE_LEN` leading bytes only
+  if (ss.flags & SS_CHALLENGE_LE) {
+    // the same leading bytes read as a little-endian integer (RFC 9381's edwards suites): the digest as it sits in memory,
+    // cut after CHALLENGE_LEN bytes
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t w = sha512_word_mem(h, j), have = ss.challenge_len > 4u * j ? ss.challenge_len - 4u * j : 0u;
+      be[j] = have >= 4u ? w : have == 0u ? 0u : (w & ((1u << (8u * have)) - 1u));
+    }
+  } else {
+    sha512_be256(be, h);
+    if (ss.challenge_len != 32u) u256_shr_bytes(be, 32u - ss.challenge_len);    // `Suite::CHALLENGE_LEN` leading bytes only
+  }
   fr_reduce256<S>(c_out, be);
 }
 
@@ -768,7 +780,7 @@ VRF_HD void verify_finish_multi(int K, size_t first, size_t n, uint32_t* pts_bas
       FeN zi = fe_mul(inv, prefix);
       inv = fe_mul(inv, z);
       uint32_t e[8];
-      te_encode_affine(e, fe_mul(fe_load<1, 5>(uv), zi), fe_mul(fe_load<1, 5>(uv + NL), zi));
+      te_encode_affine(e, fe_mul(fe_load<1, 5>(uv), zi), fe_mul(fe_load<1, 5>(uv + NL), zi), ss.flags);
       if (j & 1) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) encv[k] = e[k];          // V first (reverse order), U completes the item
@@ -833,7 +845,7 @@ VRF_HD bool verify_decode_affine_item(uint32_t enc_out[3][8], const uint32_t (&x
     uint32_t e[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[j] = yw[j];
-    if (u256_gt(xw, vrfk::QM1H32)) e[7] |= 0x80000000u;
+    if (te_x_sign(xw, T.str.flags)) e[7] |= 0x80000000u;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (p == 0) enc_out[0][j] = e[j];
@@ -916,9 +928,9 @@ VRF_HD uint32_t verify_finish_item(const uint32_t* uv, const uint32_t pk[8], con
   uint32_t pts[5][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { pts[0][i] = pk[i]; pts[1][i] = hh[i]; pts[2][i] = gamma[i]; }
-  te_encode_affine(pts[3], fe_mul(fe_load<1, 5>(uv), zi[0]), fe_mul(fe_load<1, 5>(uv + NL), zi[0]));
+  te_encode_affine(pts[3], fe_mul(fe_load<1, 5>(uv), zi[0]), fe_mul(fe_load<1, 5>(uv + NL), zi[0]), ss.flags);
   te_encode_affine(pts[4], fe_mul(fe_load<1, 5>(uv + UV_WORDS), zi[1]),
-                   fe_mul(fe_load<1, 5>(uv + UV_WORDS + NL), zi[1]));
+                   fe_mul(fe_load<1, 5>(uv + UV_WORDS + NL), zi[1]), ss.flags);
   uint32_t c2[8];
   challenge5<S>(c2, pts, ad, ad_len, ss);
   uint32_t diff = 0;
@@ -1275,7 +1287,7 @@ VRF_HD bool prove_prepare_item(uint32_t h_enc[8], uint32_t k[8], uint32_t* tab, 
     PtE hp = data_to_point<S>(msg, msg_len, T.sq, tai_start);
     te_to_affine(x, y, hp);
   }
-  te_encode_affine(h_enc, x, y);
+  te_encode_affine(h_enc, x, y, T.sq.str.flags);
   nonce_rfc8032<S>(k, sk, h_enc);
   build_prove_tables<S>(tab, x, y);        // ProveLayout<S>::TAB_WORDS words
   if (h_given && (check_mask & CHK_INPUT)) valid = in_prime_subgroup<S>(x, y, T.sq) && valid;   // a given H is wire data
@@ -1361,7 +1373,7 @@ VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t 
       const uint32_t* w = reinterpret_cast<const uint32_t*>(sk_arr + item * 32);
 #pragma unroll
       for (int i = 0; i < 8; ++i) sk[i] = w[i];
-      te_encode_affine(h_enc, x, y);
+      te_encode_affine(h_enc, x, y, T.sq.str.flags);
       nonce_rfc8032<S>(k, sk, h_enc);
       build_prove_tables<S>(tabs_base + item * ProveLayout<S>::TAB_WORDS, x, y);
       uint32_t* aux = aux_base + item * aux_stride;
@@ -1441,7 +1453,7 @@ VRF_HD void prove_finish_item(uint32_t gamma_out[8], uint32_t c_out[8], uint32_t
     FeN z = fe_select(i == 0, zi[0], fe_select(i == 1, zi[1], fe_select(i == 2, zi[2], zi[3])));
     uint32_t e[8];
     te_encode_affine(e, fe_mul(fe_load<1, 5>(pts_in + i * UV_WORDS), z),
-                     fe_mul(fe_load<1, 5>(pts_in + i * UV_WORDS + NL), z));
+                     fe_mul(fe_load<1, 5>(pts_in + i * UV_WORDS + NL), z), ss.flags);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (i == 0) enc[0][j] = e[j];
@@ -1614,7 +1626,7 @@ constexpr int PROVE_ENC_OFF = 64;     // word offset of the 4 x 8-word encodings
 constexpr int PROVE_X_OFF = 32;       // the canonical x of encoding j sits PROVE_X_OFF words after it (affine outputs)
 template <class S>
 VRF_HD void prove_encode_multi(int K, size_t first, size_t n, const uint32_t* pts_base, uint32_t* tabs_base,
-                               int tabs_stride) {
+                               int tabs_stride, uint32_t sflags) {
   FeN run = fe_one();
 #pragma unroll 1
   for (int j = 0; j < 4 * K; ++j) {
@@ -1636,7 +1648,7 @@ VRF_HD void prove_encode_multi(int K, size_t first, size_t n, const uint32_t* pt
       uint32_t e[8], xw[8];
       fe_to_u256(xw, fe_mul(fe_load<1, 5>(pt), zi));
       fe_to_u256(e, fe_mul(fe_load<1, 5>(pt + NL), zi));
-      if (u256_gt(xw, vrfk::QM1H32)) e[7] |= 0x80000000u;         // te_encode_affine, keeping the canonical x
+      if (te_x_sign(xw, sflags)) e[7] |= 0x80000000u;             // te_encode_affine, keeping the canonical x
       uint32_t* dst = tabs_base + item * tabs_stride + PROVE_ENC_OFF + (j & 3) * 8;
 #pragma unroll
       for (int k = 0; k < 8; ++k) { dst[k] = e[k]; dst[PROVE_X_OFF + k] = xw[k]; }
@@ -1662,6 +1674,23 @@ VRF_HD void prove_respond_item(uint32_t c_out[8], uint32_t s_out[8], const uint3
   challenge5<S>(c_out, pts, ad, ad_len, ss);
   fr_mul<S>(cs, c_out, sk);
   fr_add<S>(s_out, cs, k);
+}
+
+// RFC 9381 proof_to_hash hashes cofactor * Gamma (SS_HASH_COFACTOR; upstream does not): decode, COFACTOR_LOG2 doublings,
+// encode.  Returns false if gamma does not decode (the caller reports an all-zero hash).
+template <class S>
+VRF_HD bool output_cofactor_encoding(uint32_t enc[8], const uint32_t gamma[8], const SqrtTables& T) {
+  DecodeA a = decode_phase_a<S>(gamma);
+  FeN di = fe_inv(a.den);
+  Fe<1, 4> xx;
+  const bool ok = decode_phase_b<S>(xx, a, di, T);
+  PtE p = te_from_affine(xx, a.y);
+#pragma unroll 1
+  for (int i = 0; i < S::COFACTOR_LOG2; ++i) p = te_dbl<S>(p, true);
+  FeN x, y;
+  te_to_affine(x, y, p);
+  te_encode_affine(enc, x, y, T.str.flags);
+  return ok;
 }
 
 // [ref src/lib.rs:15 `Output::hash` / utils::point_to_hash_rfc_9381]  SURVEY.md A.4:
@@ -1699,7 +1728,7 @@ VRF_HD void public_from_secret_item(uint32_t pk[8], const DevTables& T, const ui
   PtE p = gcomb_mul<S>(T.g_comb, sk);
   FeN x, y;
   te_to_affine(x, y, p);
-  te_encode_affine(pk, x, y);
+  te_encode_affine(pk, x, y, T.sq.str.flags);
 }
 
 VRF_NS_END

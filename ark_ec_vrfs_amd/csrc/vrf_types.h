@@ -141,6 +141,7 @@ struct MsmLayout {
   uint32_t* heads;       // [MSM_W*groups][MSM_BLOCK][MSM_PT_WORDS] first-run partial sums
   uint32_t* part;        // [MSM_W][groups][MSM_PT_WORDS] per-workgroup window sums
   uint8_t* flags;        // [256] flags[0] != 0: some input was invalid
+  uint32_t sflags;       // SuiteStr::flags of the context (sign convention of the compressed result)
 };
 
 // Batched Pedersen verification by random linear combination (k_rlc.hip)

@@ -55,7 +55,7 @@ void hj_configure(const uint8_t* id, uint32_t id_len, const uint8_t* g_xy, const
 void hj_hash_to_curve(const uint8_t* msg, uint32_t len, uint8_t* out) {
   PtE h = data_to_point<SJ>(msg, len, HJ().t.sq);
   FeN x, y; te_to_affine(x, y, h);
-  uint32_t e[8]; te_encode_affine(e, x, y); memcpy(out, e, 32);
+  uint32_t e[8]; te_encode_affine(e, x, y, 0); memcpy(out, e, 32);
 }
 // out: gamma | c | s | pk | h  (IETF, pedersen = 0)  or  gamma | pk_com | r | ok | s | sb | blinding (pedersen = 1)
 // first counter whose candidate decodes (the verdict k_tai_find uses), and hash-to-curve started from a hint
@@ -69,7 +69,7 @@ void hj_hash_to_curve_from(const uint8_t* msg, uint32_t len, uint32_t start, uin
   FeN x, y;
   te_to_affine(x, y, h);
   uint32_t e[8];
-  te_encode_affine(e, x, y);
+  te_encode_affine(e, x, y, 0);
   memcpy(out, e, 32);
 }
 int hj_prove(int pedersen, const uint8_t* sk, const uint8_t* msg, uint32_t len, const uint8_t* ad, uint32_t ad_len, uint8_t* out) {

@@ -58,7 +58,7 @@ int hs_gcomb_geometry(int* rows, int* cols) { *rows = GC_ROWS; *cols = GC_COLS; 
 void hs_hash_to_curve(const uint8_t* msg, uint32_t len, uint8_t* out) {
   PtE h = hash_to_curve_ell2<SuiteBS>(msg, len, HT().t.sq);
   FeN x, y; te_to_affine(x, y, h);
-  uint32_t e[8]; te_encode_affine(e, x, y); memcpy(out, e, 32);
+  uint32_t e[8]; te_encode_affine(e, x, y, 0); memcpy(out, e, 32);
 }
 static int prove_any(bool pedersen, const uint8_t* sk, const uint8_t* msg, uint32_t len, const uint8_t* h_given,
                      const uint8_t* ad, uint32_t ad_len, uint32_t o[6][8], uint32_t h_enc[8], uint32_t sb[8], uint32_t b[8]) {
@@ -123,7 +123,7 @@ void hs_ietf_prove_multi(uint32_t n, const uint8_t* sk, const uint8_t* msgs, uin
     prove_mul_item<SuiteBS>(pts.data() + i * PROVE_PTS_WORDS + 2 * UV_WORDS, HT().t, tabs.data() + i * ProveLayout<SuiteBS>::TAB_WORDS, k, nullptr);
   }
   for (size_t first = 0; first < n; first += PROVE_K)
-    prove_encode_multi<SuiteBS>(PROVE_K, first, n, pts.data(), tabs.data(), ProveLayout<SuiteBS>::TAB_WORDS);
+    prove_encode_multi<SuiteBS>(PROVE_K, first, n, pts.data(), tabs.data(), ProveLayout<SuiteBS>::TAB_WORDS, 0);
   for (size_t i = 0; i < n; ++i) {
     uint32_t skw[8], h_enc[8], k[8], c[8], s2[8];
     memcpy(skw, sk + 32 * i, 32); memcpy(h_enc, aux.data() + 32 * i, 32); memcpy(k, aux.data() + 32 * i + 8, 32);

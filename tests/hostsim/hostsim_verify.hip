@@ -59,7 +59,7 @@ int hs_psi(const uint8_t* enc, uint8_t* out) {
   Fe<1,4> x; bool ok = decode_phase_b<SuiteBS>(x, a, di, HT().t.sq);
   PtE q = te_psi<SuiteBS>(te_from_affine(x, a.y));
   FeN qx, qy; te_to_affine(qx, qy, q);
-  uint32_t e[8]; te_encode_affine(e, qx, qy); memcpy(out, e, 32);
+  uint32_t e[8]; te_encode_affine(e, qx, qy, 0); memcpy(out, e, 32);
   return ok;
 }
 uint32_t hs_ietf_verify_affine(const uint8_t* pk_xy, const uint8_t* h_xy, const uint8_t* g_xy, const uint8_t* c,
