@@ -57,6 +57,11 @@ def parse_args():
     ap.add_argument("--prevalidated", action="store_true",
                     help="headline without the subgroup check (inputs declared validated by the caller)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU time budget per cpu_baseline leg")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="what `value` measures at N > 1: weak = 2^log2_batch items per GPU (global batch grows with N); strong = "
+                         "ONE global batch of 2^log2_batch items cut into N contiguous shards (BASELINE.json: '2^20 ... sharded "
+                         "8x').  The other mode is measured in the same run and reported under `scaling_modes`.")
+    ap.add_argument("--only", default="", help="comma-separated secondary legs to run (default: all)")
     return ap.parse_args()
 
 
@@ -154,13 +159,16 @@ class Dist:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def gather(self, t, n_per_rank):
+    def gather(self, t, n_per_rank, n_global=None):
+        """n_global: items of the whole job when the ranks hold the contiguous shards of ONE batch (strong scaling:
+        sharding.shard_range sizes); default world * n_per_rank (weak scaling: every rank its own batch)."""
         if self.world == 1:
             return t
         from ark_ec_vrfs_amd.sharding import gather_results
+        total = self.world * n_per_rank if n_global is None else n_global
         if self.backend == "nccl":
-            return gather_results(t, self.world * n_per_rank, self.rank, self.world)   # RCCL: result gather only
-        return gather_results(t.cpu(), self.world * n_per_rank, self.rank, self.world).to(self.dev)
+            return gather_results(t, total, self.rank, self.world)   # RCCL: result gather only
+        return gather_results(t.cpu(), total, self.rank, self.world).to(self.dev)
 
     def max_elapsed(self, elapsed):
         if self.world == 1:
@@ -175,7 +183,7 @@ class Dist:
             self.dist.destroy_process_group()
 
 
-def timed(D, fn, steps, warmup, gather_t=None, n_per_rank=0):
+def timed(D, fn, steps, warmup, gather_t=None, n_per_rank=0, n_global=None):
     """warmup untimed calls, then exactly `steps` calls between barrier + synchronize; max over ranks.
     Inside a secondary leg of a multi-rank run (D.local_legs) the bracket is this rank's own synchronize and nothing
     is gathered: a leg that fails on one rank must not leave the others waiting at a barrier -- the ranks' results meet
@@ -193,13 +201,13 @@ def timed(D, fn, steps, warmup, gather_t=None, n_per_rank=0):
     for _ in range(warmup):
         fn()
         if gather_t is not None:
-            D.gather(gather_t, n_per_rank)
+            D.gather(gather_t, n_per_rank, n_global)
     D.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
         if gather_t is not None:
-            out = D.gather(gather_t, n_per_rank)
+            out = D.gather(gather_t, n_per_rank, n_global)
     D.barrier()
     return D.max_elapsed(time.perf_counter() - t0), out
 
@@ -423,6 +431,109 @@ def cfg_pedersen_jubjub(D, args, msg, lo, want_cpu):
     return res
 
 
+def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
+    """IETF prove + verify for a suite of another base field (Ed25519 over 2^255 - 19, Baby-JubJub over
+    BN254 Fr), batch 2^20 per GPU, wire format, checked decode -- the headline's operation on that curve."""
+    torch = D.torch
+    from ark_ec_vrfs_amd import Context, _lib
+    lib = _lib.load()
+    n = 1 << args.log2_batch
+    cx = Context(D.local, suite=suite_cls)
+    res = {}
+    try:
+        stream = torch.cuda.current_stream().cuda_stream
+        mk = lambda: torch.empty((n, 32), dtype=torch.uint8, device=D.dev)
+        seeds = (torch.arange(n, dtype=torch.int64, device=D.dev) + lo).view(torch.uint8).reshape(n, 8)
+        sk = mk()
+        _lib.check(lib.vrfhip_secret_from_seed_batch_dev(cx.handle, n, seeds.data_ptr(), 8, sk.data_ptr(), None, stream), "seed")
+        gen = torch.Generator(device=D.dev); gen.manual_seed(1234 + lo)
+        msg = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=D.dev, generator=gen)
+        g, c, s_, pk, hh = mk(), mk(), mk(), mk(), mk()
+        st = torch.empty(n, dtype=torch.uint8, device=D.dev)
+        lg = args.log2_batch
+        fn = lambda: cx.ietf_prove_batch_dev(sk, msg, 32, g, c, s_, pk, hh, st)
+        fn(); torch.cuda.synchronize()
+        cx.profile(True)
+        el, _ = timed(D, fn, args.config_steps, 1)
+        cx.profile(False)
+        ms, groups = stage_avg(cx)
+        assert int(st.sum()) == 0
+        rf, v = roofline("k_prove_mul (sk*H, sk*G, k*H, k*G: 2 lanes per proof)", B_PROVE, n, ms[1], groups, pmc_for("ietf_prove_" + tag, lg))
+        res["ietf_prove_" + tag] = {
+            "workload": "IETF ECVRF prove, %s, batch 2^%d per GPU (SURVEY.md section 8 f4)" % (title, lg),
+            "value": D.world * n * args.config_steps / el, "unit": "proofs/s", "ms_per_step": el / args.config_steps * 1e3,
+            "bytes_per_unit": B_PROVE, "roofline": rf, "valu": v,
+            "stage_ms_per_step": {"tai_find+prepare": ms[0], "mul": ms[1], "finish": ms[3]}}
+        fn = lambda: cx.ietf_verify_batch_dev(pk, hh, g, c, s_, st)
+        fn(); torch.cuda.synchronize()
+        cx.profile(True)
+        el, _ = timed(D, fn, args.config_steps, 1, gather_t=st, n_per_rank=n)
+        cx.profile(False)
+        ms, groups = stage_avg(cx)
+        assert int(st.sum()) == 0
+        heavy = max(range(4), key=lambda k: ms[k])
+        kname = ("k_verify_decode (3 decompressions + subgroup tests + tables)", "k_verify_straus<1> (V = s*H - c*Gamma)",
+                 "k_verify_straus<0> (U = s*G - c*Y)", "k_verify_finish")[heavy]
+        rf, v = roofline(kname, B_VERIFY, n, ms[heavy], groups, pmc_for("ietf_verify_" + tag, lg))
+        res["ietf_verify_" + tag] = {
+            "workload": "IETF ECVRF verify, %s, batch 2^%d per GPU, compressed points, checked decode (SURVEY.md section 8 f4)" % (title, lg),
+            "value": D.world * n * args.config_steps / el, "unit": "verifies/s", "ms_per_step": el / args.config_steps * 1e3,
+            "bytes_per_unit": B_VERIFY, "roofline": rf, "valu": v,
+            "stage_ms_per_step": {"decode": ms[0], "straus_v": ms[1], "straus_u": ms[2], "finish": ms[3]}}
+        cx.set_prevalidated(True)
+        el_p, _ = timed(D, fn, max(2, args.config_steps), 1)
+        cx.set_prevalidated(False)
+        res["ietf_verify_" + tag]["prevalidated"] = {"value": D.world * n * max(2, args.config_steps) / el_p, "unit": "verifies/s",
+                                                     "ms_per_step": el_p / max(2, args.config_steps) * 1e3}
+        if want_cpu:
+            from oracle import c_oracle as co
+            cap = 1 << 15
+            host = lambda t: t[:cap].cpu().numpy()
+            skh, msgh, gh, ch, sh, pkh, hhh = (host(t) for t in (sk, msg, g, c, s_, pk, hh))
+            co.set_suite(oracle_suite)
+            try:
+                def leg_p(k):
+                    ref = co.ietf_prove_batch(skh[:k], msgs=msgh[:k], ad=b"", threads=cpu_cores())
+                    assert (ref["output"] == gh[:k]).all() and (ref["c"] == ch[:k]).all() and (ref["s"] == sh[:k]).all(), \
+                        "GPU proofs differ from the CPU oracle on the sample"
+                res["ietf_prove_" + tag]["cpu_baseline"] = cpu_leg(leg_p, 16 * cpu_cores(), args.cpu_seconds / 2, cap, "proofs/s",
+                                                                   "proof bytes equal the GPU's")
+
+                def leg_v(k):
+                    stv = co.ietf_verify_batch(pkh[:k], hhh[:k], gh[:k], ch[:k], sh[:k], b"", threads=cpu_cores())
+                    assert not stv.any(), "CPU oracle rejects GPU-made proofs"
+                res["ietf_verify_" + tag]["cpu_baseline"] = cpu_leg(leg_v, 16 * cpu_cores(), args.cpu_seconds / 2, cap, "verifies/s",
+                                                                    "statuses equal the GPU's")
+            finally:
+                co.set_suite(1)
+    finally:
+        cx.close()
+    return res
+
+
+def cfg_shard_sizes(D, args, ctx, pk, hh, gamma, c, s):
+    """The headline's operation at the per-GPU shard sizes of a strong-scaled 2^20 job (BASELINE.json: "2^20 ... sharded"):
+    2^19 (N = 2), 2^18 (N = 4), 2^17 (N = 8) items on ONE GPU.  value / 2^20-per-GPU value is the per-GPU efficiency a
+    strong-scaled job can reach at that N: what SCALE_rNN will show once an 8-GPU node is available."""
+    torch = D.torch
+    out = {}
+    for lg in (19, 18, 17):
+        m = 1 << lg
+        if m >= pk.shape[0]:
+            continue
+        st = torch.empty(m, dtype=torch.uint8, device=D.dev)
+        fn = lambda: ctx.ietf_verify_batch_dev(pk[:m], hh[:m], gamma[:m], c[:m], s[:m], st)
+        fn(); torch.cuda.synchronize()
+        steps = max(3, args.config_steps)
+        el, _ = timed(D, fn, steps, 1)
+        assert int(st.sum()) == 0
+        out["ietf_verify_shard_2^%d" % lg] = {
+            "workload": "the headline's verify on a 2^%d-item shard (per-GPU share of a 2^20 batch strong-scaled over %d GPUs)"
+                        % (lg, 1 << (20 - lg)),
+            "value": D.world * m * steps / el, "unit": "verifies/s", "ms_per_step": el / steps * 1e3}
+    return out
+
+
 def cfg_pairing(D, args, ctx, want_cpu):
     """BASELINE.json configs[4]: 2^14 pairing checks e(P0,Q0) e(P1,Q1) == 1 (Miller loop + final exponentiation)."""
     torch = D.torch
@@ -575,34 +686,66 @@ def run_rank(args):
     lib = _lib.load()
     stream = torch.cuda.current_stream().cuda_stream
 
-    # ---- synthetic inputs, produced on the GPU and left resident in HBM ----
-    seeds = (torch.arange(n, dtype=torch.int64, device=dev) + lo).view(torch.uint8).reshape(n, 8)
-    sk = torch.empty((n, 32), dtype=torch.uint8, device=dev)
-    _lib.check(lib.vrfhip_secret_from_seed_batch_dev(ctx.handle, n, seeds.data_ptr(), 8, sk.data_ptr(), None, stream), "seed")
-    msg = torch.from_numpy(synth_msgs(lo, n)).to(dev)
-    mk = lambda: torch.empty((n, 32), dtype=torch.uint8, device=dev)
-    gamma, c, s, pk, hh = mk(), mk(), mk(), mk(), mk()
-    pst = torch.empty(n, dtype=torch.uint8, device=dev)
-    prove_s = 1e30
-    for _ in range(2):                              # the first call includes first-touch of the workspace
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ctx.ietf_prove_batch_dev(sk, msg, 32, gamma, c, s, pk, hh, pst)
-        torch.cuda.synchronize()
-        prove_s = min(prove_s, time.perf_counter() - t0)
-    assert int(pst.sum()) == 0
-    status = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    def make_batch(first, m):
+        """Synthetic items [first, first + m), produced on the GPU and left resident in HBM."""
+        seeds = (torch.arange(m, dtype=torch.int64, device=dev) + first).view(torch.uint8).reshape(m, 8)
+        sk_ = torch.empty((m, 32), dtype=torch.uint8, device=dev)
+        _lib.check(lib.vrfhip_secret_from_seed_batch_dev(ctx.handle, m, seeds.data_ptr(), 8, sk_.data_ptr(), None, stream), "seed")
+        msg_ = torch.from_numpy(synth_msgs(first, m)).to(dev)
+        mk_ = lambda: torch.empty((m, 32), dtype=torch.uint8, device=dev)
+        b = {"sk": sk_, "msg": msg_, "gamma": mk_(), "c": mk_(), "s": mk_(), "pk": mk_(), "hh": mk_()}
+        pst_ = torch.empty(m, dtype=torch.uint8, device=dev)
+        best = 1e30
+        for _ in range(2):                              # the first call includes first-touch of the workspace
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.ietf_prove_batch_dev(sk_, msg_, 32, b["gamma"], b["c"], b["s"], b["pk"], b["hh"], pst_)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        assert int(pst_.sum()) == 0
+        b["prove_s"] = best
+        b["status"] = torch.full((m,), 255, dtype=torch.uint8, device=dev)
+        return b
 
-    step = lambda: ctx.ietf_verify_batch_dev(pk, hh, gamma, c, s, status)
+    def verify_step(b):
+        return lambda: ctx.ietf_verify_batch_dev(b["pk"], b["hh"], b["gamma"], b["c"], b["s"], b["status"])
+
+    # weak: every rank its own 2^log2_batch items.  strong: ONE global batch of 2^log2_batch items, rank g verifies the
+    # contiguous shard sharding.shard_range gives it (BASELINE.json configs: "2^20 ... sharded 8x").  At N = 1 they coincide.
+    from ark_ec_vrfs_amd.sharding import shard_range
+    weak = make_batch(lo, n)
+    s_lo, s_hi = shard_range(n, rank, world)
+    strong = weak if world == 1 else make_batch(s_lo, s_hi - s_lo)
+    main_b, other_b = (strong, weak) if args.scaling == "strong" else (weak, strong)
+    main_n = (s_hi - s_lo) if args.scaling == "strong" else n
+    main_global = n if args.scaling == "strong" else world * n
+    sk, msg, gamma, c, s, pk, hh, status = (weak[k] for k in ("sk", "msg", "gamma", "c", "s", "pk", "hh", "status"))
+    prove_s = weak["prove_s"]
+
+    step = verify_step(main_b)
     for _ in range(args.warmup):
         step()
-        D.gather(status, n)
+        D.gather(main_b["status"], main_n, main_global)
     ctx.profile(True)
-    elapsed, full = timed(D, step, args.steps, 0, gather_t=status, n_per_rank=n)
+    elapsed, full = timed(D, step, args.steps, 0, gather_t=main_b["status"], n_per_rank=main_n, n_global=main_global)
     ctx.profile(False)
     stage_ms, groups = stage_avg(ctx)
     n_bad = int((full != 0).sum())
-    assert n_bad == 0, f"{n_bad} synthetic proofs failed to verify"
+    assert n_bad == 0 and full.shape[0] == main_global, f"{n_bad} synthetic proofs failed to verify"
+    modes = {args.scaling: {"value": main_global * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+                            "global_batch": main_global, "items_per_gpu": main_global // world, "steps": args.steps}}
+    other = "weak" if args.scaling == "strong" else "strong"
+    if world == 1:
+        modes[other] = dict(modes[args.scaling])
+    else:
+        o_n = n if other == "weak" else (s_hi - s_lo)
+        o_global = world * n if other == "weak" else n
+        o_steps = max(3, args.config_steps)
+        el_o, full_o = timed(D, verify_step(other_b), o_steps, 1, gather_t=other_b["status"], n_per_rank=o_n, n_global=o_global)
+        assert int((full_o != 0).sum()) == 0 and full_o.shape[0] == o_global
+        modes[other] = {"value": o_global * o_steps / el_o, "ms_per_step": el_o / o_steps * 1e3, "global_batch": o_global,
+                        "items_per_gpu": o_global // world, "steps": o_steps}
+    step = verify_step(weak)                         # the secondary legs below run on the rank's own 2^log2_batch items
 
     # the same batch with the points declared validated (typed Public/Input/Output values): round 1's operation
     preval = None
@@ -618,12 +761,21 @@ def run_rank(args):
     want_cpu = (not args.no_cpu_baseline) and world == 1
     configs = {}
     if not args.no_configs:
+        from ark_ec_vrfs_amd import BabyJubJubSha512Tai, Ed25519Sha512Tai
         legs = (("ietf_prove", lambda: {"ietf_prove": cfg_ietf_prove(D, args, ctx, sk, msg, want_cpu and rank == 0)}),
+                ("shard_sizes", lambda: cfg_shard_sizes(D, args, ctx, pk, hh, gamma, c, s)),
                 ("ietf_verify_keyed", lambda: {"ietf_verify_keyed": cfg_ietf_keyed(D, args, ctx, msg, lo)}),
                 ("pedersen_jubjub", lambda: cfg_pedersen_jubjub(D, args, msg, lo, want_cpu and rank == 0)),
+                ("ed25519", lambda: cfg_suite_ietf(D, args, "ed25519", Ed25519Sha512Tai, 3, "Ed25519_SHA-512_TAI", lo,
+                                                   want_cpu and rank == 0)),
+                ("babyjubjub", lambda: cfg_suite_ietf(D, args, "babyjubjub", BabyJubJubSha512Tai, 4, "BabyJubJub_SHA-512_TAI", lo,
+                                                      want_cpu and rank == 0)),
                 ("pairing", lambda: cfg_pairing(D, args, ctx, want_cpu and rank == 0)))
+        only = [x for x in args.only.split(",") if x]
         D.local_legs = world > 1
         for name, leg in legs:
+            if only and name not in only:
+                continue
             try:
                 res = leg()
             except Exception as e:                  # the headline number must not depend on a secondary leg
@@ -632,20 +784,23 @@ def run_rank(args):
         D.local_legs = False
 
     if rank == 0:
-        value = world * n * args.steps / elapsed
+        value = main_global * args.steps / elapsed
         checked = can_check and not args.prevalidated
-        r, v = roofline("k_verify_straus<1> (V = s*H - c*Gamma, the longest kernel)", B_VERIFY, n, stage_ms[1], groups,
+        r, v = roofline("k_verify_straus<1> (V = s*H - c*Gamma, the longest kernel)", B_VERIFY, main_n, stage_ms[1], groups,
                         pmc_for("ietf_verify", args.log2_batch))
         out = {
-            "metric": "Bandersnatch IETF-ECVRF verifies/sec, 2^%d batch per GPU" % args.log2_batch,
+            "metric": "Bandersnatch IETF-ECVRF verifies/sec, 2^%d batch %s" % (
+                args.log2_batch, "sharded over the GPUs" if args.scaling == "strong" else "per GPU"),
             "value": value, "unit": "verifies/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "scaling_modes": modes,
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "IETF ECVRF verify, Bandersnatch_SHA-512_ELL2, batch 2^%d per GPU, compressed points "
+            "config": {"workload": "IETF ECVRF verify, Bandersnatch_SHA-512_ELL2, batch 2^%d %s, compressed points "
                                    "(161 B/verify), %s, ad=\"\" (BASELINE.json configs[2])"
-                                   % (args.log2_batch, "checked decode: on curve + prime-order subgroup, as arkworks' "
+                                   % (args.log2_batch, "in total, cut into contiguous shards" if args.scaling == "strong" else "per GPU",
+                                      "checked decode: on curve + prime-order subgroup, as arkworks' "
                                       "deserialisation" if checked else "inputs declared pre-validated (no subgroup check)"),
-                       "global_batch": world * n, "parallelism": "items sharded x%d, result gather only" % world,
+                       "global_batch": main_global, "parallelism": "items sharded x%d, result gather only" % world,
                        "subgroup_check": checked},
             "roofline": r, "valu": v,
             "stage_ms_per_step": {"decode": stage_ms[0], "straus_v": stage_ms[1], "straus_u": stage_ms[2],

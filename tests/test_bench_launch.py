@@ -27,6 +27,27 @@ def test_gpus_n_self_launches_through_torch_distributed_run():
     assert d["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_scaling_flag_reaches_the_ranks_and_both_modes_are_in_the_line():
+    """--scaling strong (ONE 2^20 batch cut into N shards, BASELINE.json "2^20 ... sharded 8x") is passed through to the
+    ranks; the JSON line states which mode `value` is and carries both under `scaling_modes`."""
+    env = dict(os.environ, VRFHIP_BENCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--scaling", "strong"],
+                         env=env, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:] == ["--gpus", "8", "--scaling", "strong"]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"scaling": args.scaling' in src and '"scaling_modes": modes' in src and "shard_range(n, rank, world)" in src
+    # a recorded two-rank strong-scaling rehearsal (gloo ranks sharing the one GPU of the box): both modes, shard sizes add up
+    f = os.path.join(ROOT, "profiles", "r03", "bench_n2_gloo_strong_rehearsal_2_18.json")
+    d = json.loads(open(f).read().strip().splitlines()[-1])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2 and set(d["scaling_modes"]) == {"weak", "strong"}
+    st, wk = d["scaling_modes"]["strong"], d["scaling_modes"]["weak"]
+    assert st["global_batch"] == 1 << 18 and st["items_per_gpu"] == 1 << 17 and wk["global_batch"] == 2 << 18
+    assert abs(d["value"] - st["value"]) < 1e-6 and d["config"]["global_batch"] == 1 << 18
+
+
 def test_parent_process_imports_no_gpu_runtime_before_spawning():
     src = open(os.path.join(ROOT, "bench.py")).read()
     head = src[:src.index("def self_launch")]
