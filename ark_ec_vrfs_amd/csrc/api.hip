@@ -1289,7 +1289,10 @@ int32_t vrfhip_pairing_check_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint
   if (ev) (void)hipEventRecord(ev[0], st);
   DigestSrc ds{};
   ds.p[0] = d_g1; ds.w[0] = 192; ds.n_arr = 1;
-  launch_batch_digest(ds, n, 0, d_digest_ws, d_root, st);   // the weights depend on every item of the batch
+  // ... and on the shared G2 pair, absorbed as the leaves' common byte string (with the pair outside the digest a
+  // caller-influenced pair could be chosen after the weights, Q1 = a Q0 with a = -(sum z alpha) / (sum z beta))
+  ds.ad = make_view(d_g2_shared, nullptr, 384, true);
+  launch_batch_digest(ds, n, 0, d_digest_ws, d_root, st);   // the weights depend on every byte of the batch
   launch_g1_rlc(L, d_g1, seed, d_root, 0, d_status, st, ev ? ev + 1 : nullptr);
   // one pairing check for the whole batch: (sum z A, sum z B) against the shared pair (prepared lines)
   launch_pairing_check2(1, L.sums, d_g2_shared, 0, d_verdict, st, ctx->d_pair_prep);
@@ -1629,15 +1632,22 @@ int32_t run_sharded(vrfhip_ctx* const* ctxs, int32_t n_ctx, size_t n, F fn) {
   std::vector<int32_t> rcs(n_ctx, VRFHIP_SUCCESS);
   std::vector<std::string> errs(n_ctx);
   std::vector<std::thread> th;
-  for (int32_t g = 0; g < n_ctx; ++g) {
-    const size_t lo = n * (size_t)g / (size_t)n_ctx, hi = n * (size_t)(g + 1) / (size_t)n_ctx;
-    if (lo == hi) continue;
-    th.emplace_back([&, g, lo, hi] {
-      rcs[g] = fn(ctxs[g], lo, hi);
-      if (rcs[g]) errs[g] = g_last_error;        // thread-local in the worker: carry it to the caller's thread
-    });
+  bool spawn_failed = false;
+  try {                                          // nothing may unwind across the C ABI, and a joinable std::thread must
+    th.reserve((size_t)n_ctx);                   // not be destroyed: a failed creation joins what has started
+    for (int32_t g = 0; g < n_ctx; ++g) {
+      const size_t lo = n * (size_t)g / (size_t)n_ctx, hi = n * (size_t)(g + 1) / (size_t)n_ctx;
+      if (lo == hi) continue;
+      th.emplace_back([&, g, lo, hi] {
+        rcs[g] = fn(ctxs[g], lo, hi);
+        if (rcs[g]) errs[g] = g_last_error;      // thread-local in the worker: carry it to the caller's thread
+      });
+    }
+  } catch (...) {
+    spawn_failed = true;
   }
   for (auto& t : th) t.join();
+  if (spawn_failed) return fail(VRFHIP_ERR_HIP, "could not start a worker thread per context");
   for (int32_t g = 0; g < n_ctx; ++g)
     if (rcs[g]) return fail(rcs[g], "device slice " + std::to_string(g) + ": " + errs[g]);
   return VRFHIP_SUCCESS;

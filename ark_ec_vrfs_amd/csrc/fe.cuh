@@ -695,7 +695,10 @@ VRF_HD bool fe_is_square_or_zero(const Fe<L, V>& w, const SqrtTables& T) {
 // exact is (low limb) * (-q^-1 mod 2^29): -(low limb) when q = 1 (mod 2^29).  f = 1 ends a lane with d = a~^-1 < (rounds + 1) q.  About 27 rounds of
 // ~650 instructions (~18 k) against 255 squarings + 30 products (~60 k) for a^(q-2): one inversion per 8 proofs in the big
 // batches, but up to three per proof when a batch is small enough for one proof per lane.  0 -> 0, as the power gives.
-template <int L, int V>
+// CT = true (the prover's inversions: the Z coordinates of sk*H, k*H, k*G depend on secrets): every lane runs all
+// JAC_MAX_ROUNDS rounds, so the time no longer follows the operand.  Verification and decoding invert public
+// data and keep the early exit (~27 rounds instead of 40).
+template <bool CT = false, int L, int V>
 VRF_HD FeN fe_inv(const Fe<L, V>& a) {
   const FeN c = fe_canon(a);
   uint32_t f[NL], g[NL], d[NL], e[NL];
@@ -706,7 +709,7 @@ VRF_HD FeN fe_inv(const Fe<L, V>& a) {
   bool done = nz == 0;
 #pragma unroll 1
   for (int round = 0; round < JAC_MAX_ROUNDS; ++round) {
-    if (!vrf_any(!done)) break;
+    if (!CT && !vrf_any(!done)) break;
     uint32_t f0 = f[0] | (f[1] << LW), g0 = g[0] | (g[1] << LW);
     uint32_t u = 1, v = 0, q = 0, r = 1;
     int32_t et = eta;

@@ -1,4 +1,4 @@
-// k_digest.hip -- batch digest kernels (digest.cuh): one leaf hash per item, then levels of 128-ary nodes.
+// k_digest.hip -- batch digest kernels (digest.cuh): one leaf hash per item, then levels of 16-ary nodes (DIGEST_FAN).
 #include "digest.cuh"
 #include "kernels.h"
 

@@ -77,13 +77,13 @@ struct SuiteBJ : CurveBJ {
 VRF_HD void put_suite_id(Sha512& h, const SuiteStr& ss) { sha512_put_packed(h, ss.suite_id_w, ss.suite_id_len); }
 
 // ------------------------------------------------------------------------ batch inversion
-template <int N, int L, int V>
+template <bool CT = false, int N, int L, int V>
 VRF_HD void fe_batch_inv(FeN (&out)[N], const Fe<L, V> (&in)[N]) {
   FeN pre[N];
   pre[0] = fe_mul(in[0], fe_one());
 #pragma unroll
   for (int i = 1; i < N; ++i) pre[i] = fe_mul(pre[i - 1], in[i]);
-  FeN acc = fe_inv(pre[N - 1]);
+  FeN acc = fe_inv<CT>(pre[N - 1]);
 #pragma unroll
   for (int i = N - 1; i > 0; --i) {
     out[i] = fe_mul(acc, pre[i - 1]);
@@ -1172,9 +1172,10 @@ VRF_HD FeN ell2_den(const Fe<1, 4>& u) {
 }
 #endif
 
-// affine coordinates of a projective point (one inversion)
+// affine coordinates of a projective point (one inversion; CT: fixed shape, for points derived from secrets)
+template <bool CT = false>
 VRF_HD void te_to_affine(FeN& x, FeN& y, const PtE& p) {
-  FeN zi = fe_inv(p.Z);
+  FeN zi = fe_inv<CT>(p.Z);
   x = fe_mul(p.X, zi);
   y = fe_mul(p.Y, zi);
 }
@@ -1446,7 +1447,7 @@ VRF_HD void prove_finish_item(uint32_t gamma_out[8], uint32_t c_out[8], uint32_t
 #pragma unroll
   for (int i = 0; i < 4; ++i) zin[i] = fe_load<1, 5>(pts_in + i * UV_WORDS + 2 * NL);
   FeN zi[4];
-  fe_batch_inv(zi, zin);
+  fe_batch_inv<true>(zi, zin);                  // secret-dependent Z: fixed-shape inversion
   uint32_t enc[4][8];
 #pragma unroll 1
   for (int i = 0; i < 4; ++i) {
@@ -1636,7 +1637,7 @@ VRF_HD void prove_encode_multi(int K, size_t first, size_t n, const uint32_t* pt
       run = fe_mul(run, fe_load<1, 5>(pts_base + item * PROVE_PTS_WORDS + (j & 3) * UV_WORDS + 2 * NL));
     }
   }
-  FeN inv = fe_inv(run);
+  FeN inv = fe_inv<true>(run);                  // Z of sk*H, k*H, k*G: fixed-shape inversion
 #pragma unroll 1
   for (int j = 4 * K - 1; j >= 0; --j) {
     const size_t item = first + j / 4;
@@ -1727,7 +1728,7 @@ template <class S>
 VRF_HD void public_from_secret_item(uint32_t pk[8], const DevTables& T, const uint32_t sk[8]) {
   PtE p = gcomb_mul<S>(T.g_comb, sk);
   FeN x, y;
-  te_to_affine(x, y, p);
+  te_to_affine<true>(x, y, p);
   te_encode_affine(pk, x, y, T.sq.str.flags);
 }
 

@@ -624,29 +624,15 @@ def cfg_pairing(D, args, ctx, want_cpu):
     for cx in extra:
         cx.close()
     if want_cpu:
-        from oracle import bls_oracle as bo
+        from oracle import c_oracle as co
+        g1h, g2h = np.tile(g1, (reps, 1)), np.tile(g2, (reps, 1))
 
-        def dec1(raw):
-            v = [int.from_bytes(bytes(raw[48 * i:48 * i + 48]), "little") for i in range(4)]
-            return (v[0], v[1]), (v[2], v[3])
-
-        def dec2(raw):
-            v = [int.from_bytes(bytes(raw[48 * i:48 * i + 48]), "little") for i in range(8)]
-            return (bo.Fp2(v[0], v[1]), bo.Fp2(v[2], v[3])), (bo.Fp2(v[4], v[5]), bo.Fp2(v[6], v[7]))
-        items = []
-        for a, b in zip(g1, g2):
-            (p0, p1), (q0, q1) = dec1(a), dec2(b)
-            items.append([(p0, q0), (p1, q1)])
-        t0 = time.perf_counter()
-        cnt = 0
-        while time.perf_counter() - t0 < args.cpu_seconds:
-            assert bo.pairing_check(items[cnt % len(items)])
-            cnt += 1
-        dt = time.perf_counter() - t0
-        leg = {"value": cnt / dt, "unit": "checks/s", "cores": 1, "kind": "port",
-               "sample": "%d checks of the fixture items, %.1f s on 1 thread; verdicts equal the GPU's" % (cnt, dt),
-               "note": "pure-Python big-int restatement (oracle/bls_oracle.py), not arkworks: orders of magnitude slower than "
-                       "a native CPU pairing (arkworks / blst: roughly 1e3 checks/s/core)"}
+        def leg_c(m):
+            stc = co.pairing_check_batch(g1h[:m], g2h[:m], threads=cpu_cores())
+            assert not stc.any(), "CPU oracle rejects the fixture items"
+        leg = cpu_leg(leg_c, 4 * cpu_cores(), args.cpu_seconds, k, "checks/s", "verdicts equal the GPU's")
+        leg["note"] = ("CPU restatement in C (oracle/c/oracle_bls.c: 6 x 64-bit Montgomery limbs, Karatsuba tower, plain "
+                       "square-and-multiply final exponentiation), not arkworks: no Rust toolchain on this box")
         for k in res:
             res[k]["cpu_baseline"] = leg
     return res

@@ -50,6 +50,16 @@ def load() -> ctypes.CDLL:
         lib.oracle_set_suite_desc2.argtypes = [c_int, P, c_size_t, P, c_size_t, P, P, c_int, c_int]
         lib.oracle_set_suite_desc2.restype = c_int
         lib.oracle_set_check_mask.argtypes = [c_int]
+        lib.oracle_pairing_check2.argtypes = [P, P]
+        lib.oracle_pairing_check2.restype = c_int
+        lib.oracle_pairing_check2_batch.argtypes = [c_size_t, P, P, c_size_t, P, c_int]
+        lib.oracle_pairing_check2_batch.restype = None
+        lib.oracle_g1_mul.argtypes = [P, P, P]
+        lib.oracle_g1_mul.restype = c_int
+        lib.oracle_g2_mul.argtypes = [P, P, P]
+        lib.oracle_g2_mul.restype = c_int
+        lib.oracle_g1_add.argtypes = [P, P, P]
+        lib.oracle_g1_add.restype = c_int
         _lib = lib
     return _lib
 
@@ -251,4 +261,41 @@ def sha512(m: bytes) -> bytes:
     out = np.empty(64, np.uint8)
     x = np.frombuffer(bytes(m) + b"\0", np.uint8)
     load().oracle_sha512(x.ctypes.data, len(m), out.ctypes.data)
+    return out.tobytes()
+
+
+# ---- BLS12-381 pairing-product check (oracle/c/oracle_bls.c): the native twin of oracle/bls_oracle.py ----
+def pairing_check_batch(g1, g2, shared: bool = False, threads: int = 1) -> np.ndarray:
+    """status per item of e(P0, Q0) e(P1, Q1) == 1 (0 / 1 / 2 as vrfhip_pairing_check_batch).  g1: (n, 192) bytes;
+    g2: (n, 384) bytes, or one 384-byte pair when shared."""
+    g1 = _a(g1).reshape(-1, 192)
+    g2 = _a(g2).reshape(-1, 384)
+    n = g1.shape[0]
+    assert g2.shape[0] == (1 if shared else n)
+    st = np.empty(n, np.uint8)
+    load().oracle_pairing_check2_batch(n, g1.ctypes.data, g2.ctypes.data, 0 if shared else 384, st.ctypes.data, int(threads))
+    return st
+
+
+def g1_mul(k: int, pt96: bytes) -> bytes:
+    out = np.empty(96, np.uint8)
+    kk, p = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8), np.frombuffer(bytes(pt96), np.uint8)
+    if load().oracle_g1_mul(kk.ctypes.data, p.ctypes.data, out.ctypes.data) != 0:
+        raise ValueError("G1 point does not decode")
+    return out.tobytes()
+
+
+def g2_mul(k: int, pt192: bytes) -> bytes:
+    out = np.empty(192, np.uint8)
+    kk, p = np.frombuffer(int(k).to_bytes(32, "little"), np.uint8), np.frombuffer(bytes(pt192), np.uint8)
+    if load().oracle_g2_mul(kk.ctypes.data, p.ctypes.data, out.ctypes.data) != 0:
+        raise ValueError("G2 point does not decode")
+    return out.tobytes()
+
+
+def g1_add(a96: bytes, b96: bytes) -> bytes:
+    out = np.empty(96, np.uint8)
+    x, y = np.frombuffer(bytes(a96), np.uint8), np.frombuffer(bytes(b96), np.uint8)
+    if load().oracle_g1_add(x.ctypes.data, y.ctypes.data, out.ctypes.data) != 0:
+        raise ValueError("G1 point does not decode")
     return out.tobytes()

@@ -160,13 +160,14 @@ impl<S: GpuSuite> GpuBatch<S> {
         Ok(())
     }
 
-    /// `Secret::output` + `ietf::Prover::prove` for every (secret, input) pair.
+    /// `Secret::output` + `ietf::Prover::prove` for every (secret, input) pair.  Per item: the proof, or the `Error` the
+    /// library's status byte names (a failed item's points come back all-zero and are never turned into typed values).
     pub fn ietf_prove(
         &self,
         secrets: &[Secret<S>],
         inputs: &[Input<S>],
         ad: &[u8],
-    ) -> Result<Vec<(Output<S>, ietf::Proof<S>)>, GpuError> {
+    ) -> Result<Vec<Result<(Output<S>, ietf::Proof<S>), Error>>, GpuError> {
         let n = secrets.len();
         assert_eq!(n, inputs.len());
         let (mut sk, mut h) = (vec![0u8; n * 32], vec![0u8; n * 32]);
@@ -186,12 +187,13 @@ impl<S: GpuSuite> GpuBatch<S> {
         sk.iter_mut().for_each(|b| *b = 0); // the staged copy of the secrets
         Ok((0..n)
             .map(|i| {
+                status_to_result(status[i])?;
                 let out = Output::<S>::from(point_from_xy::<S>(&gamma[i * 64..(i + 1) * 64]));
                 let proof = ietf::Proof::<S> {
                     c: codec::scalar_decode::<S>(&c[i * 32..(i + 1) * 32]),
                     s: codec::scalar_decode::<S>(&s[i * 32..(i + 1) * 32]),
                 };
-                (out, proof)
+                Ok((out, proof))
             })
             .collect())
     }
@@ -234,13 +236,13 @@ impl<S: GpuSuite> GpuBatch<S> {
         Ok(status.into_iter().map(status_to_result).collect())
     }
 
-    /// `pedersen::Prover::prove`: (output, proof, blinding factor) per item.
+    /// `pedersen::Prover::prove`: (output, proof, blinding factor) per item, or the item's `Error`.
     pub fn pedersen_prove(
         &self,
         secrets: &[Secret<S>],
         inputs: &[Input<S>],
         ad: &[u8],
-    ) -> Result<Vec<(Output<S>, pedersen::Proof<S>, ScalarField<S>)>, GpuError> {
+    ) -> Result<Vec<Result<(Output<S>, pedersen::Proof<S>, ScalarField<S>), Error>>, GpuError> {
         let n = secrets.len();
         assert_eq!(n, inputs.len());
         let (mut sk, mut h) = (vec![0u8; n * 32], vec![0u8; n * 32]);
@@ -265,8 +267,9 @@ impl<S: GpuSuite> GpuBatch<S> {
         let sc = |k: usize, i: usize| codec::scalar_decode::<S>(&o[(k * n + i) * 32..(k * n + i + 1) * 32]);
         let res = (0..n)
             .map(|i| {
+                status_to_result(status[i])?;
                 let proof = pedersen::Proof::<S> { pk_com: pt(1, i), r: pt(2, i), ok: pt(3, i), s: sc(0, i), sb: sc(1, i) };
-                (Output::<S>::from(pt(0, i)), proof, sc(2, i))
+                Ok((Output::<S>::from(pt(0, i)), proof, sc(2, i)))
             })
             .collect();
         o.iter_mut().for_each(|b| *b = 0); // blinding factors

@@ -270,7 +270,8 @@ def test_gpu_pairing_shared_g2_prepared_lines(ctx):
 
 @pytest.mark.gpu
 def test_gpu_pairing_batch_2_14_tiled(ctx):
-    """BASELINE.json config 5 size: 2^14 checks (64 distinct oracle-made items tiled), every 97th corrupted."""
+    """BASELINE.json config 5 size: 2^14 checks (8 distinct oracle-made items tiled), every 97th corrupted; the soak below
+    runs 2^12 DISTINCT items."""
     import torch
     items = kzg_like_items(8, seed=21)
     g1, g2 = pack(items)
@@ -460,3 +461,154 @@ def test_gpu_batched_pairing_check_2_14_and_2_18(ctx):
         ctx.pairing_check_batch_rlc_dev(d1, dsh, dst, dv, os.urandom(32))
         torch.cuda.synchronize()
         assert int(dv[0]) == 1 and int(dst.sum()) == 0
+
+
+
+# ---------------------------------------------------------------------------------------------- native oracle + soak
+def test_c_pairing_oracle_equals_the_python_oracle():
+    """oracle/c/oracle_bls.c (the native twin used for the soak below and as bench.py's cpu_baseline) against
+    oracle/bls_oracle.py: scalar multiplication on G1 / G2, the committed fixture, and constructed items of every kind."""
+    import json
+    from oracle import c_oracle as co
+    rnd = random.Random(4)
+    G1b, G2b = enc_g1(b.G1), enc_g2(b.G2)
+    for k in (0, 1, 2, b.R - 1, b.R, rnd.randrange(b.R), rnd.randrange(b.R)):
+        assert co.g1_mul(k, G1b) == enc_g1(b.g1_mul(k % b.R, b.G1)) and co.g2_mul(k, G2b) == enc_g2(b.g2_mul(k % b.R, b.G2))
+    items = kzg_like_items(4, seed=33)
+    g1, g2 = pack(items)
+    g1, g2 = g1.copy(), g2.copy()
+    (p0, q0), (p1, q1) = items[1]
+    g1[1] = np.frombuffer(enc_g1(p0) + enc_g1(b.g1_add(p1, b.G1)), np.uint8)      # wrong relation
+    g1[2, 7] ^= 1                                                                  # off the curve
+    g2[3, 48:96] = np.frombuffer(w(P), np.uint8)                                   # coordinate >= p
+    st = co.pairing_check_batch(g1, g2, threads=2)
+    assert list(st) == [0, 1, 2, 2]
+    assert b.pairing_check(list(items[0])) and not b.pairing_check([(p0, q0), (b.g1_add(p1, b.G1), q1)])
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pairing_items.json")))
+    hx = lambda h: np.frombuffer(bytes.fromhex(h), np.uint8)
+    f1 = np.stack([hx(it["g1"]) for it in fx["per_item"]]); f2 = np.stack([hx(it["g2"]) for it in fx["per_item"]])
+    assert not co.pairing_check_batch(f1, f2).any()
+    sh = np.stack([hx(h) for h in fx["shared"]])
+    assert not co.pairing_check_batch(sh, hx(fx["shared_g2"]), shared=True).any()
+    if fx.get("shared_bad"):
+        assert co.pairing_check_batch(np.stack([hx(h) for h in fx["shared_bad"]]), hx(fx["shared_g2"]), shared=True).all()
+    # infinity conventions: both G1 points at infinity -> product one; one of them -> the other pairing alone
+    z = g1[:1].copy(); z[:] = 0
+    assert co.pairing_check_batch(z, g2[:1])[0] == 0
+    z = g1[:1].copy(); z[0, 96:] = 0
+    assert co.pairing_check_batch(z, g2[:1])[0] == 1
+
+
+TAMPER = ("none", "wrong_scalar", "swapped", "shifted", "off_curve_g1", "coord_ge_p", "inf_p0", "inf_both", "inf_q1",
+          "off_curve_g2")
+
+
+def _soak_items(n, shared_pair=None, seed=5):
+    """n DISTINCT items built from scalar relations with the native oracle's g1_mul / g2_mul, every third one tampered
+    with (kind cycling through TAMPER).  shared_pair = (Q0, Q1 = tau Q0) bytes and tau: the KZG shape A = -tau b G1,
+    B = b G1 against one pair; else a fresh pair of G2 points per item.  Returns g1 (n, 192), g2 (n, 384) or (384,),
+    and the status each item must get -- known by construction, and confirmed by the native oracle in the test."""
+    from oracle import c_oracle as co
+    rnd = random.Random(seed)
+    G1b, G2b = enc_g1(b.G1), enc_g2(b.G2)
+    g1 = np.empty((n, 192), np.uint8)
+    g2 = None if shared_pair else np.empty((n, 384), np.uint8)
+    want = np.zeros(n, np.uint8)
+    kinds = []
+    for i in range(n):
+        kind = TAMPER[(i // 3) % len(TAMPER)] if i % 3 == 0 else "none"
+        if shared_pair:
+            (pair, tau) = shared_pair
+            bsc = rnd.randrange(1, b.R)
+            a_sc = (-tau * bsc) % b.R
+            if kind == "wrong_scalar":
+                a_sc = (a_sc + 1 + rnd.randrange(1 << 64)) % b.R
+            p0, p1 = co.g1_mul(a_sc, G1b), co.g1_mul(bsc, G1b)
+            q = pair
+        else:
+            a1, b1, b2 = (rnd.randrange(1, b.R) for _ in range(3))
+            a2 = (-a1 * b1 * pow(b2, -1, b.R)) % b.R
+            if kind == "wrong_scalar":
+                a2 = (a2 + 1 + rnd.randrange(1 << 64)) % b.R
+            p0, p1 = co.g1_mul(a1, G1b), co.g1_mul(a2, G1b)
+            q = co.g2_mul(b1, G2b) + co.g2_mul(b2, G2b)
+        row, st = bytearray(p0 + p1), 0
+        qq = bytearray(q)
+        if kind == "wrong_scalar":
+            st = 1
+        elif kind == "swapped":
+            row = bytearray(p1 + p0); st = 1                       # (P1, Q0), (P0, Q1): another relation (distinct scalars)
+        elif kind == "shifted":
+            row[96:] = co.g1_add(bytes(row[96:]), G1b); st = 1     # P1 + G1
+        elif kind == "off_curve_g1":
+            row[48 + rnd.randrange(40)] ^= 1 << rnd.randrange(8); st = 2
+        elif kind == "coord_ge_p":
+            row[96:144] = w(P + rnd.randrange(1000)); st = 2
+        elif kind == "inf_p0":
+            row[:96] = bytes(96); st = 1                           # only e(P1, Q1) is left: not one
+        elif kind == "inf_both":
+            row[:] = bytes(192); st = 0                            # empty product
+        elif kind == "inf_q1" and not shared_pair:
+            qq[192:] = bytes(192); st = 1                          # only e(P0, Q0) is left
+        elif kind == "off_curve_g2" and not shared_pair:
+            qq[96 + rnd.randrange(40)] ^= 1 << rnd.randrange(8); st = 2
+        g1[i] = np.frombuffer(bytes(row), np.uint8)
+        if g2 is not None:
+            g2[i] = np.frombuffer(bytes(qq), np.uint8)
+        want[i] = st
+        kinds.append(kind)
+    if shared_pair:
+        g2 = np.frombuffer(shared_pair[0], np.uint8).copy()
+    return g1, g2, want, kinds
+
+
+@pytest.mark.gpu
+def test_gpu_pairing_soak_distinct_items_every_path(ctx):
+    """2^12 DISTINCT items per shape, a third of them tampered with in ten ways (wrong scalar, swapped and shifted points,
+    off-curve and out-of-range coordinates on either side, infinity on each side and on both): the verdict of EVERY device
+    path equals the native oracle's and the status known by construction.  Paths: one item per lane, per quad (independent
+    G2 points); for a shared pair the prepared lines with one item per wave (tri, n <= 1024), per row (n <= 4096), per quad
+    (beyond), the unprepared kernel, and the batched check (two G1 MSMs + one pairing, per-item fallback)."""
+    from oracle import c_oracle as co
+    ncpu = min(8, os.cpu_count() or 1)
+    n = 1 << 12
+    # independent G2 points per item
+    g1, g2, want, kinds = _soak_items(n, seed=6)
+    ref = co.pairing_check_batch(g1, g2, threads=ncpu)
+    assert (ref == want).all(), [(k, int(a), int(c)) for k, a, c in zip(kinds, ref, want) if a != c][:5]
+    assert len({bytes(r) for r in g1}) > n - n // 20 and len({bytes(r) for r in g2}) > n - n // 20     # distinct (but for the zeroed ones)
+    assert (ctx.pairing_check_batch(g1, g2) == want).all()
+    os.environ["VRFHIP_PAIRING"] = "lane"
+    try:
+        assert (ctx.pairing_check_batch(g1, g2) == want).all()
+    finally:
+        del os.environ["VRFHIP_PAIRING"]
+    # one shared pair (Q0, tau Q0): the KZG verifier's shape
+    tau = 0x1D3A5F7C9B2E4F6A8C0E1B3D5F7A9C0E2B4D6F8A1C3E5A7C9E0B2D4F6A8C1E3
+    q0 = co.g2_mul(0xC0FFEE1234567, enc_g2(b.G2))
+    pair = q0 + co.g2_mul(tau, q0)
+    m = n + 64                                                         # crosses the row / quad switch (4096)
+    s1, sg2, swant, skinds = _soak_items(m, shared_pair=(pair, tau), seed=7)
+    sref = co.pairing_check_batch(s1, sg2, shared=True, threads=ncpu)
+    assert (sref == swant).all(), [(k, int(a), int(c)) for k, a, c in zip(skinds, sref, swant) if a != c][:5]
+    assert set(np.unique(swant)) == {0, 1, 2}
+    for cnt in (1000, 4096, m):                                        # one item per wave | per row | per quad
+        assert (ctx.pairing_check_batch(s1[:cnt], sg2, g2_shared=True) == swant[:cnt]).all(), cnt
+    for mode in ("noprep", "quad", "row"):
+        os.environ["VRFHIP_PAIRING"] = mode
+        try:
+            assert (ctx.pairing_check_batch(s1[:1500], sg2, g2_shared=True) == swant[:1500]).all(), mode
+        finally:
+            del os.environ["VRFHIP_PAIRING"]
+    assert (ctx.pairing_check_batch(s1, np.tile(sg2, (m, 1))) == swant).all()       # the same items through the per-item kernel
+    # batched: a batch with false items fails as a whole and falls back to the per-item verdicts ...
+    st, batch_ok = ctx.pairing_check_batch_rlc(s1, sg2, seed=bytes(range(32)))
+    assert not batch_ok and (st == swant).all()
+    # ... the valid items alone (and the harmless all-infinity ones) pass as ONE pairing; one false item among 2^12 is caught
+    good = np.flatnonzero(swant == 0)
+    st, batch_ok = ctx.pairing_check_batch_rlc(s1[good], sg2, seed=bytes(range(1, 33)))
+    assert batch_ok and not st.any() and len(good) > 2800
+    one_bad = s1[good].copy()
+    one_bad[1234, 96:] = np.frombuffer(co.g1_add(bytes(one_bad[1234, 96:]), enc_g1(b.G1)), np.uint8)
+    st, batch_ok = ctx.pairing_check_batch_rlc(one_bad, sg2, seed=bytes(range(2, 34)))
+    assert not batch_ok and st[1234] == 1 and st.sum() == 1
