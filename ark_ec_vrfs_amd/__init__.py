@@ -5,7 +5,7 @@ Host-side mirror (Python) of the Rust surface re-exported at /root/reference src
 over the C ABI of ``csrc/libvrfhip.so``.  All arithmetic runs in hand-written HIP kernels.
 """
 from .api import (  # noqa: F401
-    KeySet, SuiteDesc, ietf_verify_batch_multi, ietf_prove_batch_multi, pedersen_prove_batch_multi,
+    KeySet, SuiteDesc, PinnedBuffer, ietf_verify_batch_multi, ietf_prove_batch_multi, pedersen_prove_batch_multi,
     pedersen_verify_batch_multi, CURVE_BANDERSNATCH, CURVE_JUBJUB,
     BandersnatchSha512Ell2, JubJubSha512Tai, Ed25519Sha512Tai, BabyJubJubSha512Tai, Context, Error, IetfProof, Input, Output, Public, Secret, Suite,
     VerificationFailure, InvalidData, ietf, pedersen, PedersenProof, default_context,

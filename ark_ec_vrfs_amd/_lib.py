@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvrfhip.so")
 SYMBOLS = [
     "vrfhip_abi_version", "vrfhip_last_error", "vrfhip_ctx_create", "vrfhip_ctx_destroy",
     "vrfhip_suite_desc_default", "vrfhip_ctx_create_desc", "vrfhip_ctx_get_desc",
-    "vrfhip_ctx_reserve", "vrfhip_ctx_workspace_bytes", "vrfhip_ctx_profile", "vrfhip_ctx_profile_read",
+    "vrfhip_ctx_reserve", "vrfhip_ctx_workspace_bytes", "vrfhip_host_alloc", "vrfhip_host_free",
+    "vrfhip_ctx_profile", "vrfhip_ctx_profile_read",
     "vrfhip_ctx_set_flags", "vrfhip_ctx_get_flags",
     "vrfhip_ietf_verify_batch", "vrfhip_ietf_verify_batch_dev",
     "vrfhip_ietf_verify_batch_affine", "vrfhip_ietf_verify_batch_affine_dev",
@@ -93,6 +94,9 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_ctx_reserve.restype = c_int32
     lib.vrfhip_ctx_workspace_bytes.argtypes = [c_void_p]
     lib.vrfhip_ctx_workspace_bytes.restype = c_size_t
+    lib.vrfhip_host_alloc.argtypes = [c_size_t, POINTER(c_void_p)]
+    lib.vrfhip_host_free.argtypes = [c_void_p]
+    lib.vrfhip_host_free.restype = None
     lib.vrfhip_ctx_profile.argtypes = [c_void_p, c_int32]
     lib.vrfhip_ctx_profile_read.argtypes = [c_void_p, POINTER(ctypes.c_double), POINTER(ctypes.c_uint64)]
     lib.vrfhip_ctx_set_flags.argtypes = [c_void_p, c_uint32]
@@ -161,7 +165,7 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_test_batch_digest.argtypes = [c_void_p, c_size_t, c_int32, P, P, P, P, c_uint32, ctypes.c_uint64, P]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("vrfhip_last_error", "vrfhip_ctx_destroy", "vrfhip_ctx_workspace_bytes",
+        if name not in ("vrfhip_last_error", "vrfhip_ctx_destroy", "vrfhip_ctx_workspace_bytes", "vrfhip_host_free",
                         "vrfhip_keyset_destroy", "vrfhip_keyset_bytes", "vrfhip_ctx_get_flags"):
             fn.restype = c_int32
     _lib = lib

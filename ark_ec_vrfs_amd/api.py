@@ -119,6 +119,30 @@ class SuiteDesc:
         return d
 
 
+class PinnedBuffer:
+    """Page-locked host memory (vrfhip_host_alloc) viewed as a numpy uint8 array: arrays handed to the host-pointer
+    entry points from here leave by DMA as they lie instead of through the pinned staging ring."""
+
+    def __init__(self, shape):
+        self.shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        n = int(np.prod(self.shape))
+        self._p = ctypes.c_void_p()
+        _lib.check(_lib.load().vrfhip_host_alloc(max(n, 1), ctypes.byref(self._p)), "vrfhip_host_alloc")
+        self.array = np.ctypeslib.as_array((ctypes.c_uint8 * max(n, 1)).from_address(self._p.value))[:n].reshape(self.shape)
+
+    def free(self) -> None:
+        if self._p:
+            self.array = None
+            _lib.load().vrfhip_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def _np_u8(b, n_bytes: Optional[int] = None) -> np.ndarray:
     a = np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else b
     a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)

@@ -18,8 +18,9 @@ and against a shared G2 pair), each with its own `roofline` (dominant kernel, HI
 and, at N = 1, a `cpu_baseline` leg (the plain-C / Python oracle under oracle/, kind "port", bounded sample).
 
 `roofline` prices the longest kernel against HBM as the contract asks; the path is VALU-integer bound, so
-`valu` gives the ceiling that matters: executed vector instructions per second (rocprofv3 --pmc, profiles/)
-against 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz.
+`valu` gives the ceiling that matters: the fraction of the SIMDs' vector issue slots the kernel fills, from the
+counters of the profiled run (SQ_INSTS_VALU, SQ_INSTS_VALU_INT64, GRBM_GUI_ACTIVE: profiles/pmc_kernels.json) at the
+clock the chip actually held.
 """
 import argparse
 import hashlib
@@ -231,9 +232,16 @@ def roofline(kernel, bytes_per_unit, units, kernel_ms, launches, pmc):
          "avg_launch_ms": kernel_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": bytes_per_unit * units}
     v = None
     if pmc and pmc.get("valu_lane_instructions_per_launch") and sec > 0:
+        # The ceiling that matters for this integer path: how many of the SIMDs' VALU issue slots the kernel fills.  From
+        # the counters of the profiled run (tools/profile_round3.sh): clock = GRBM_GUI_ACTIVE / 8 XCDs / duration,
+        # issue_slot_frac = SQ_INSTS_VALU x 4 cycles / (cycles x 1024 SIMDs); issue_cycle_frac prices the non-64-bit
+        # instructions at 2 cycles (the lower bound).  `achieved` scales the profiled instruction count to THIS run's
+        # kernel time; no nominal-clock peak is assumed any more.
         lanes = pmc["valu_lane_instructions_per_launch"]
-        v = {"bound": "valu_int", "achieved": lanes / sec, "peak": VALU_INT_PEAK, "unit": "lane-instr/s",
-             "frac": lanes / sec / VALU_INT_PEAK, "source": pmc.get("source")}
+        v = {"bound": "valu_issue", "achieved": lanes / sec, "unit": "lane-instr/s",
+             "clock_ghz_observed": pmc.get("clock_ghz_observed"), "issue_slot_frac": pmc.get("issue_slot_frac"),
+             "issue_cycle_frac": pmc.get("issue_cycle_frac"), "frac": pmc.get("issue_slot_frac"),
+             "scratch_bytes_per_lane": pmc.get("scratch_bytes_per_lane"), "source": pmc.get("source")}
     return r, v
 
 

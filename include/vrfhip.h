@@ -180,6 +180,13 @@ int32_t vrfhip_ctx_reserve(vrfhip_ctx* ctx, size_t max_items);
 /* Bytes of device workspace currently held by the context. */
 size_t vrfhip_ctx_workspace_bytes(const vrfhip_ctx* ctx);
 
+/* Page-locked host memory for the arrays handed to the host-pointer entry points.  Those entry points cut a batch into
+ * chunks of 2^18 items and send chunk k + 1 while chunk k is computed; arrays in pinned memory (from here, hipHostMalloc or
+ * hipHostRegister) leave by DMA as they lie, pageable arrays are first gathered into a pinned staging ring by the calling
+ * thread.  Replaces nothing in the reference: it is where a Rust caller would put its `Vec<u8>` of wire bytes. */
+int32_t vrfhip_host_alloc(size_t bytes, void** out);
+void vrfhip_host_free(void* p);
+
 /* Per-stage device timing.  While enabled, every prove / verify launch group records hipEvents
  * on its launch stream around its kernels: verify = {decode, straus V, straus U, finish},
  * Pedersen verify = {decode, straus A, straus B, finish}, prove = {prepare, mul, (empty), finish}.

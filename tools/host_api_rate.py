@@ -5,7 +5,7 @@ import os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ark_ec_vrfs_amd import Context, _lib
+from ark_ec_vrfs_amd import Context, PinnedBuffer, _lib
 n = 1 << 20
 ctx = Context(0)
 lib = _lib.load()
@@ -21,9 +21,31 @@ pst = torch.empty(n, dtype=torch.uint8, device=dev)
 ctx.ietf_prove_batch_dev(sk, msg, 32, g, c, s, pk, hh, pst)
 torch.cuda.synchronize()
 host = [t.cpu().numpy() for t in (pk, hh, g, c, s)]
+pins = [PinnedBuffer((n, 32)) for _ in range(5)]
+for p, h in zip(pins, host):
+    p.array[:] = h
+pinned = [p.array for p in pins]
 status = torch.empty(n, dtype=torch.uint8, device=dev)
+import threading
+others = [Context(0) for _ in range(2)]          # the _multi shape: three contexts on one device, a third of the batch each
+
+
+def three_contexts():
+    cs = [ctx] + others
+    th = []
+    for k, cx in enumerate(cs):
+        lo, hi = n * k // 3, n * (k + 1) // 3
+        th.append(threading.Thread(target=lambda cx=cx, lo=lo, hi=hi: cx.ietf_verify_batch(*[h[lo:hi] for h in host], ad=b"")))
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+
+
 for name, fn in (("device pointers", lambda: (ctx.ietf_verify_batch_dev(pk, hh, g, c, s, status), torch.cuda.synchronize())),
-                 ("host pointers (pageable numpy)", lambda: ctx.ietf_verify_batch(*host, ad=b""))):
+                 ("host pointers (pageable numpy)", lambda: ctx.ietf_verify_batch(*host, ad=b"")),
+                 ("host pointers (vrfhip_host_alloc)", lambda: ctx.ietf_verify_batch(*pinned, ad=b"")),
+                 ("3 contexts x 1/3 batch, pageable", three_contexts)):
     fn()
     best = 1e9
     for _ in range(5):

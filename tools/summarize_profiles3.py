@@ -1,10 +1,20 @@
-"""Condense tools/profile_round2.sh's rocprofv3 output (gpurun_out/r02prof/) into the tracked summaries:
-  profiles/r02/rocprofv3_kernel_stats_bench.csv       the --stats table of the bench command, as rocprofv3 wrote it
-  profiles/r02/rocprofv3_kernels_by_grid.json         per (kernel, grid size): launches, average duration from the kernel
-                                                      trace, counters per launch, corrected HBM bytes, VALU fraction
-  profiles/pmc_kernels.json                           what bench.py attaches to each config's roofline object
-Kernels are keyed by (name, grid) because the bench launches the same kernel at several batch sizes in one process.
-usage: python tools/summarize_profiles2.py gpurun_out/r02prof profiles/r02"""
+"""Condense tools/profile_round3.sh's rocprofv3 output (gpurun_out/r03prof/) into the tracked summaries:
+  <dst>/rocprofv3_kernel_stats_bench.csv       the --stats table of the bench command, as rocprofv3 wrote it
+  <dst>/rocprofv3_kernels_by_grid.json         per (kernel, grid size): launches, average duration from the kernel trace,
+                                               counters per launch, corrected HBM bytes, clock and issue-slot occupancy
+  <dst>/pmc_kernels.json                       what bench.py attaches to each config's roofline / valu objects (copied to
+                                               profiles/pmc_kernels.json when the round's profile is committed)
+Kernels are keyed by (name, grid) because the bench launches the same kernel at several batch sizes in one process.  The
+inline namespace of the base field (vrf::f_bls381fr:: ...) is dropped from the names: the suite tag tells the field.
+
+Issue-slot occupancy instead of a nominal-clock "fraction of peak": GRBM_GUI_ACTIVE sums the busy
+cycles of the 8 XCDs, so cycles = GRBM_GUI_ACTIVE / 8 and clock = cycles / duration; a SIMD starts one wave-instruction
+per 4 cycles for the 64-bit / VOP3 class (v_mad_u64_u32: what these kernels are made of) and per 2 cycles for plain
+32-bit VOP1/VOP2 (profiles/r01_instr_rate_microbench.jsonl), so with 256 CU x 4 SIMD
+    issue_slot_frac  = SQ_INSTS_VALU * 4 / (cycles * 1024)                          every VALU instruction priced at 4 cycles
+    issue_cycle_frac = (INT64 * 4 + (SQ_INSTS_VALU - INT64) * 2) / (cycles * 1024)  the mixed-rate lower bound
+The truth lies between the two (not every non-INT64 instruction dual-issues).
+usage: python tools/summarize_profiles3.py gpurun_out/r03prof profiles/r03"""
 import collections, csv, glob, json, os, re, shutil, sys
 
 src, dst = sys.argv[1], sys.argv[2]
@@ -18,7 +28,8 @@ def find(sub, suffix):
 
 
 def short(name):
-    return re.sub(r"^void ", "", name).split("(")[0]
+    name = re.sub(r"^void ", "", name).split("(")[0]
+    return re.sub(r"f_(bls381fr|25519|bn254fr)::", "", name)
 
 
 stats = find("stats", "kernel_stats.csv")
@@ -61,17 +72,29 @@ for e in table.values():
     if "SQ_INSTS_VALU" in e and "avg_duration_ns" in e:
         e["valu_lane_instructions_per_launch"] = e["SQ_INSTS_VALU"] * 64
         e["valu_frac_of_peak"] = e["SQ_INSTS_VALU"] * 64 / (e["avg_duration_ns"] * 1e-9) / VALU_PEAK
+    if "GRBM_GUI_ACTIVE" in e and "avg_duration_ns" in e and "SQ_INSTS_VALU" in e:
+        cycles = e["GRBM_GUI_ACTIVE"] / 8.0
+        e["clock_ghz_observed"] = cycles / e["avg_duration_ns"]
+        e["issue_slot_frac"] = e["SQ_INSTS_VALU"] * 4.0 / (cycles * 1024.0) if cycles else None
+        if "SQ_INSTS_VALU_INT64" in e and cycles:
+            n64 = e["SQ_INSTS_VALU_INT64"]
+            e["issue_cycle_frac"] = (n64 * 4.0 + max(e["SQ_INSTS_VALU"] - n64, 0.0) * 2.0) / (cycles * 1024.0)
 rows = sorted(table.values(), key=lambda e: -e.get("avg_duration_ns", 0) * e.get("launches", 1))
 json.dump({"command": "rocprofv3 {--kernel-trace --stats | --pmc <one group per pass> --kernel-trace} -- python3 bench.py --steps 3 "
-                      "--warmup 1 --config-steps 2 --no-cpu-baseline",
+                      "--warmup 1 --config-steps 2 --no-cpu-baseline  (tools/profile_round3.sh)",
            "passes": ["SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE",
                       "SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_SALU SQ_WAVE_CYCLES"],
-           "note": "averages per launch; valu_frac_of_peak = SQ_INSTS_VALU x 64 / duration / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz)",
+           "note": "averages per launch; valu_frac_of_peak = SQ_INSTS_VALU x 64 / duration / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz); "
+                   "clock_ghz_observed = GRBM_GUI_ACTIVE / 8 / duration; issue_slot_frac = SQ_INSTS_VALU x 4 / (cycles x 1024 SIMDs); "
+                   "issue_cycle_frac prices non-INT64 instructions at 2 cycles",
            "kernels": rows}, open(os.path.join(dst, "rocprofv3_kernels_by_grid.json"), "w"), indent=1)
 
 # config -> (kernel substring, grid) of its dominant kernel
 N20, N16, N14 = 1 << 20, 1 << 16, 1 << 14
 CONFIGS = [("ietf_verify", "k_verify_straus<vrf::SuiteBS, 1>", N20, 20), ("ietf_prove", "k_prove_mul<vrf::SuiteBS>", 2 * N16, 16),
+           ("ietf_prove_ed25519", "k_prove_mul<vrf::SuiteED>", 2 * N20, 20), ("ietf_verify_ed25519", "k_verify_decode<vrf::SuiteED, 2>", None, 20),
+           ("ietf_prove_babyjubjub", "k_prove_mul<vrf::SuiteBJ>", 2 * N20, 20),
+           ("ietf_verify_babyjubjub", "k_verify_straus<vrf::SuiteBJ, 1>", N20, 20),
            ("pedersen_prove_jubjub", "k_prove_mul<vrf::SuiteJJ>", 2 * N20, 20),
            ("pedersen_verify_jubjub", "k_ped_verify_straus<vrf::SuiteJJ, 0>", N20, 20),
            ("pedersen_rlc_jubjub", "k_rlc_decode<vrf::SuiteJJ, 2>", None, 20),
@@ -87,10 +110,14 @@ for cfg, pat, grid, lg in CONFIGS:
     out[cfg] = {"kernel": e["kernel"], "grid": e["grid"], "log2_batch": lg, "hbm_bytes_per_launch": e.get("hbm_bytes_per_launch"),
                 "valu_lane_instructions_per_launch": e.get("valu_lane_instructions_per_launch"),
                 "avg_duration_ns_kernel_trace": e.get("avg_duration_ns"), "valu_frac_of_peak": e.get("valu_frac_of_peak"),
-                "source": "%s/rocprofv3_kernels_by_grid.json (tools/profile_round2.sh)" % dst}
-json.dump(out, open(os.path.join(os.path.dirname(dst.rstrip("/")), "pmc_kernels.json"), "w"), indent=1)
-for e in rows[:40]:
-    print("%-66s grid %-9d x%-3d %9.3f ms  valu %.3g  hbm %.3g B  frac %.2f" % (
-        e["kernel"][:66], e["grid"], e.get("launches", 0), e.get("avg_duration_ns", 0) / 1e6, e.get("SQ_INSTS_VALU", 0),
-        e.get("hbm_bytes_per_launch", 0), e.get("valu_frac_of_peak", 0)))
+                "clock_ghz_observed": e.get("clock_ghz_observed"), "issue_slot_frac": e.get("issue_slot_frac"),
+                "issue_cycle_frac": e.get("issue_cycle_frac"),
+                "scratch_bytes_per_lane": (e.get("dispatch") or {}).get("Scratch_Size"),
+                "source": "profiles/r03/rocprofv3_kernels_by_grid.json (tools/profile_round3.sh)"}
+json.dump(out, open(os.path.join(dst, "pmc_kernels.json"), "w"), indent=1)
+for e in rows[:60]:
+    print("%-62s grid %-9d x%-3d %9.3f ms  hbm %.3g B  %.2f GHz  slot %.2f  cyc %.2f  scratch %s" % (
+        e["kernel"][:62], e["grid"], e.get("launches", 0), e.get("avg_duration_ns", 0) / 1e6,
+        e.get("hbm_bytes_per_launch", 0), e.get("clock_ghz_observed") or 0, e.get("issue_slot_frac") or 0,
+        e.get("issue_cycle_frac") or 0, (e.get("dispatch") or {}).get("Scratch_Size")))
 print(json.dumps(out, indent=1)[:1500])
