@@ -638,8 +638,12 @@ int32_t verify_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* 
     rc = pipe_prepare(ctx, std::max<size_t>(slot_bytes, 256));
     if (rc) return rc;
     int slot = 0;
-    for (size_t base = 0; base < n; base += PIPE_CHUNK, slot ^= 1) {
-      const size_t m = std::min(PIPE_CHUNK, n - base);
+    // the first chunk's copy is the only one nothing hides: it is a smaller chunk (tuning hooks: VRFHIP_PIPE_FIRST_LOG2,
+    // VRFHIP_PIPE_CHUNK_LOG2 <= 18)
+    static const size_t first_chunk = [] { const char* e = getenv("VRFHIP_PIPE_FIRST_LOG2"); int v = e ? atoi(e) : 17; return size_t(1) << std::min(std::max(v, 12), 18); }();
+    static const size_t chunk = [] { const char* e = getenv("VRFHIP_PIPE_CHUNK_LOG2"); int v = e ? atoi(e) : 18; return size_t(1) << std::min(std::max(v, 12), 18); }();
+    for (size_t base = 0, m = 0; base < n; base += m, slot ^= 1) {
+      m = std::min(base == 0 ? first_chunk : chunk, n - base);
       rc = pipe_send(ctx, arrs, pinned, 5, base, m, slot);
       if (rc) return rc;
       rc = verify_dev_impl(ctx, m, affine, d_pk + base * pw, d_h + base * pw, d_g + base * pw, d_c + base * 32, d_s + base * 32,
