@@ -72,6 +72,7 @@ pub trait GpuSuite: Suite + PedersenSuite {
             generator: [0u8; 64],
             blinding_base: [0u8; 64],
             challenge_len: Self::CHALLENGE_LEN as u32,
+            flags: 0, // upstream's suites: ArkworksCodec sign flag, big-endian challenge, no cofactor in `Output::hash`
         };
         d.suite_id[..Self::SUITE_ID.len()].copy_from_slice(Self::SUITE_ID);
         let dst = Self::h2c_dst();
@@ -93,6 +94,23 @@ impl GpuSuite for suites::bandersnatch::BandersnatchSha512Ell2 {
 
 impl GpuSuite for suites::jubjub::JubJubSha512Tai {
     const CURVE: i32 = ffi::VRFHIP_CURVE_JUBJUB;
+    fn h2c_dst() -> Vec<u8> {
+        Vec::new()
+    }
+}
+
+// The suites over the other base fields (`full` feature upstream): Ed25519 (2^255 - 19, `CHALLENGE_LEN` 16) and
+// Baby-JubJub (BN254 Fr).  Suite string, challenge length, generator and blinding base travel in the descriptor,
+// taken from the trait, so the library's own recollections of them (vrfhip_suite_desc_default) never matter here.
+impl GpuSuite for suites::ed25519::Ed25519Sha512Tai {
+    const CURVE: i32 = ffi::VRFHIP_CURVE_ED25519;
+    fn h2c_dst() -> Vec<u8> {
+        Vec::new()
+    }
+}
+
+impl GpuSuite for suites::baby_jubjub::BabyJubJubSha512Tai {
+    const CURVE: i32 = ffi::VRFHIP_CURVE_BABY_JUBJUB;
     fn h2c_dst() -> Vec<u8> {
         Vec::new()
     }
