@@ -557,3 +557,116 @@ def test_gpu_soak_2_18_plus_tail(gpu):
     ctx.ietf_verify_batch_dev(pk, hh, out, c, s2, st)
     torch.cuda.synchronize()
     assert torch.equal(torch.nonzero(st).flatten(), torch.arange(0, n, 1021, device=dev)) and int(st.max()) == 1
+
+
+@pytest.mark.gpu
+def test_gpu_every_other_entry_point_on_the_new_suites(gpu):
+    """The entry points the tests above do not touch, on Ed25519 and Baby-JubJub: ragged messages with per-item `ad`,
+    prove from a given input point, empty batches, keyed verification, three contexts in one `_multi` call, the provers'
+    x || y output mode and the Montgomery-256 coordinate format (x 2^256 mod q: arkworks' in-memory `Fp`)."""
+    from ark_ec_vrfs_amd import (Context, ietf_prove_batch_multi, ietf_verify_batch_multi, pedersen_prove_batch_multi,
+                                 pedersen_verify_batch_multi)
+    ctx, S, sid = gpu
+    rnd = random.Random(31)
+    n = 257
+    sk = np.stack([np.frombuffer(co.secret_from_seed(bytes([i & 255, i >> 8, 77])), np.uint8) for i in range(n)])
+    msgs = [bytes(rnd.getrandbits(8) for _ in range(rnd.choice([0, 1, 31, 32, 33, 111, 200]))) for _ in range(n)]
+    ads = [bytes(rnd.getrandbits(8) for _ in range(rnd.choice([0, 3, 16, 70, 129]))) for _ in range(n)]
+    got = ctx.ietf_prove_batch(sk, msgs=msgs, ad=ads)
+    for i in range(0, n, 5):                                   # per-item oracle calls (ragged shapes)
+        if msgs[i]:
+            r = co.ietf_prove_batch(sk[i:i + 1], msgs=np.frombuffer(msgs[i], np.uint8).reshape(1, -1), ad=ads[i])
+            for k in ("output", "c", "s", "pk", "input"):
+                assert (got[k][i] == r[k][0]).all(), (i, k)
+    empty = [i for i in range(n) if not msgs[i]][:3]
+    assert empty
+    for i in empty:                                            # the empty message through the Python oracle
+        H = o.data_to_point(S, b"")
+        g, c, s_ = o.ietf_prove(S, int.from_bytes(sk[i].tobytes(), "little"), H, ads[i])
+        assert got["input"][i].tobytes() == o.point_encode(S, H) and got["output"][i].tobytes() == o.point_encode(S, g)
+        assert got["c"][i].tobytes() == le(c) and got["s"][i].tobytes() == le(s_)
+    st = ctx.ietf_verify_batch(got["pk"], got["input"], got["output"], got["c"], got["s"], ad=ads)
+    assert not st.any()
+    ads2 = list(ads); ads2[7] = ads2[7] + b"x"
+    st = ctx.ietf_verify_batch(got["pk"], got["input"], got["output"], got["c"], got["s"], ad=ads2)
+    assert st[7] == 1 and st.sum() == 1
+    # prove from given input points == prove from the messages
+    again = ctx.ietf_prove_batch(sk, inputs=got["input"], ad=ads)
+    for k in ("output", "c", "s"):
+        assert (again[k] == got[k]).all(), k
+    # empty batches are fine everywhere
+    e32 = np.zeros((0, 32), np.uint8)
+    assert ctx.ietf_verify_batch(e32, e32, e32, e32, e32, ad=b"").shape == (0,)
+    assert ctx.ietf_prove_batch(e32, inputs=e32, ad=b"")["c"].shape == (0, 32)
+    # keyed verification
+    nk = 9
+    ksk = sk[:nk]
+    kpk = np.stack([np.frombuffer(co.public_from_secret(ksk[i].tobytes()), np.uint8) for i in range(nk)])
+    key = (np.arange(n, dtype=np.uint32) * 5) % nk
+    kp = ctx.ietf_prove_batch(ksk[key], msgs=msgs, ad=b"k")
+    ks, kst = ctx.keyset_create(kpk)
+    try:
+        assert not kst.any()
+        s_bad = kp["s"].copy(); s_bad[::6, 1] ^= 2
+        key2 = key.copy(); key2[1::6] = (key2[1::6] + 1) % nk
+        want = co.ietf_verify_batch(kpk[key2], kp["input"], kp["output"], kp["c"], s_bad, b"k", threads=NCPU)
+        stk = ctx.ietf_verify_batch_keyed(ks, key2, kp["input"], kp["output"], kp["c"], s_bad, ad=b"k")
+        assert (stk == want).all() and want[::6].all() and want[1::6].all() and not want[2::6].any()
+    finally:
+        ks.close()
+    # three contexts, one call
+    extra = [Context(0, suite=ctx.suite), Context(0, suite=ctx.suite)]
+    ctxs = [ctx] + extra
+    try:
+        many = ietf_prove_batch_multi(ctxs, sk, msgs, ad=ads)
+        for k in ("output", "c", "s", "pk", "input", "status"):
+            assert (many[k] == got[k]).all() if k != "status" else not many[k].any(), k
+        s_bad = got["s"].copy(); s_bad[::3, 2] ^= 1
+        st1 = ctx.ietf_verify_batch(got["pk"], got["input"], got["output"], got["c"], s_bad, ad=ads)
+        assert (ietf_verify_batch_multi(ctxs, got["pk"], got["input"], got["output"], got["c"], s_bad, ad=ads) == st1).all()
+        p1 = ctx.pedersen_prove_batch(sk, msgs=msgs, ad=b"shared")
+        pm = pedersen_prove_batch_multi(ctxs, sk, msgs, ad=b"shared")
+        for k in ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input"):
+            assert (p1[k] == pm[k]).all(), k
+        args = [p1[k] for k in ("input", "output", "pk_com", "r", "ok", "s", "sb")]
+        args[6] = args[6].copy(); args[6][::4, 0] ^= 8
+        v1 = ctx.pedersen_verify_batch(*args, ad=b"shared")
+        assert (pedersen_verify_batch_multi(ctxs, *args, ad=b"shared") == v1).all() and v1[::4].all()
+        assert (pedersen_verify_batch_multi(ctxs, *args, ad=b"shared", rlc_seed=os.urandom(32)) == v1).all()
+    finally:
+        for c in extra:
+            c.close()
+    # x || y outputs and the Montgomery-256 coordinate format
+    Q, R256 = S.q, (1 << 256) % S.q
+
+    def to_mont(a):
+        out = np.zeros_like(a)
+        for i, row in enumerate(a):
+            x, y = int.from_bytes(row[:32].tobytes(), "little"), int.from_bytes(row[32:].tobytes(), "little")
+            out[i] = np.frombuffer(le(x * R256 % Q) + le(y * R256 % Q), np.uint8)
+        return out
+    c2 = Context(0, suite=ctx.suite)
+    try:
+        m = 64
+        ref = c2.ietf_prove_batch(sk[:m], msgs=msgs[:m], ad=b"m")
+        _, xys = zip(*[c2.point_validate_batch(ref[k], want_xy=True) for k in ("pk", "input", "output")])
+        for k, a in zip(("pk", "input", "output"), xys):
+            for i in (0, 17, 63):
+                assert a[i].tobytes() == xy(o.point_decode(S, ref[k][i].tobytes()))
+        s_bad = ref["s"].copy(); s_bad[::9, 0] ^= 1
+        want_v = c2.ietf_verify_batch_affine(*xys, ref["c"], s_bad, ad=b"m")
+        assert (want_v[::9] == 1).all() and want_v.sum() == len(want_v[::9])
+        c2.set_flags(c2.PROVE_POINTS_AFFINE)
+        ga = c2.ietf_prove_batch(sk[:m], msgs=msgs[:m], ad=b"m")
+        assert (ga["output"] == xys[2]).all() and (ga["pk"] == xys[0]).all() and (ga["c"] == ref["c"]).all()
+        c2.set_flags(c2.COORDS_MONT256)
+        assert (c2.ietf_verify_batch_affine(*[to_mont(a) for a in xys], ref["c"], s_bad, ad=b"m") == want_v).all()
+        _, vxy = c2.point_validate_batch(ref["output"], want_xy=True)
+        assert (vxy == to_mont(xys[2])).all()
+        k = np.stack([np.frombuffer(le(7 + 13 * i), np.uint8) for i in range(m)])
+        got_m = c2.msm(to_mont(xys[2]), k)
+        c2.set_flags(0)
+        want_m = c2.msm(xys[2], k)
+        assert got_m[0] == want_m[0] and got_m[1] == to_mont(np.frombuffer(want_m[1], np.uint8).reshape(1, 64)).tobytes()
+    finally:
+        c2.close()
