@@ -25,7 +25,7 @@ constexpr int WIN_TABLE_WORDS = WIN_ENTRIES * PTC_WORDS;   // 288 words = 1152 B
 // and the Pedersen blinding base -- comes from the context's descriptor (vrfhip_suite_desc): the byte strings
 // (SuiteStr, fe.cuh), and the fixed-base tables built from the descriptor's points at context creation.
 // How prime-order subgroup membership of a decoded point is decided (in_prime_subgroup)
-enum : int { SUBGROUP_2DESCENT = 0, SUBGROUP_TATE8 = 1, SUBGROUP_ORDER = 2 };
+enum : int { SUBGROUP_2DESCENT = 0, SUBGROUP_TATE8 = 1, SUBGROUP_ORDER = 2, SUBGROUP_HALVE_TATE4 = 3 };
 
 #if VRF_FIELD == 0
 struct SuiteBS : CurveBS {
@@ -51,10 +51,11 @@ struct SuiteJJ : CurveJJ {
 #elif VRF_FIELD == 1
 // Ed25519 (`suites::ed25519`, upstream "Ed25519_SHA-512_TAI"): a = -1, cofactor 8, try-and-increment, no GLV.  The
 // rational 2-power torsion is cyclic of order 8 but 8 does not divide q - 1 (q = 5 mod 8), so the order-8 Tate pairing
-// does not exist over Fq: membership is arkworks' own test, r * P = O, with the fixed scalar's bits as scalar control flow.
+// does not exist over Fq: membership is one halving and the order-4 pairing (subgroup_by_halving_tate4 below; arkworks'
+// own test, r * P = O, stays compiled as subgroup_by_order and the tests hold the two against each other).
 struct SuiteED : CurveED {
   static constexpr bool HAS_GLV = false;
-  static constexpr int SUBGROUP = SUBGROUP_ORDER;
+  static constexpr int SUBGROUP = SUBGROUP_HALVE_TATE4;
   static constexpr bool H2C_ELL2 = false;
 };
 #elif VRF_FIELD == 2
@@ -337,7 +338,7 @@ VRF_HD bool subgroup_by_tate8(const FeN& x, const FeN& y, const SqrtTables& T) {
 
 // Prime-order subgroup membership of a decoded point (x, y) [ref src/lib.rs:14 `codec`: arkworks' checked
 // deserialisation].  Bandersnatch: 2-descent on y (two Jacobi symbols).  JubJub, Baby-JubJub: Tate pairing with the
-// 8-torsion.  Ed25519: r * P = O.
+// 8-torsion.  Ed25519: one halving + the order-4 Tate pairing.
 // r * P = O by double-and-add over the bits of the (fixed) subgroup order: scalar control flow, every lane the same
 // shape.  arkworks' own `is_in_correct_subgroup_assuming_on_curve`; used where no cheaper character exists (Ed25519:
 // 252 doublings + 63 additions, the order 2^252 + 2^124.4.. is sparse at the top).
@@ -354,9 +355,73 @@ VRF_HD bool subgroup_by_order(const FeN& x, const FeN& y) {
   return fe_is_zero(acc.X) && fe_eq(acc.Y, acc.Z);
 }
 
+#if VRF_FIELD == 1
+// w^((q-1)/4) == 1: w is a non-zero 4th power.  q = 2^255 - 19 = 5 (mod 8): the exponent is the t of the square-root
+// plan (q - 1 = 4 t), so this is the root's exponentiation without the root.
+VRF_HD bool fe_is_nonzero_fourth_power(const FeN& w) {
+  const FeN v = fe_pow_prog(w, vrfk::POW_SQRT_PROG);        // w^((t-1)/2)
+  const FeN b = fe_mul(fe_mul(w, v), v);                    // w^t
+  return limbs_eq(fe_canon(b), vrfk::ONE_M);
+}
+
+// Prime-order subgroup membership on Ed25519 without the 252-bit multiplication.  The rational 2-power torsion is cyclic
+// of order 8 but q = 5 (mod 8): Fq holds the 4th roots of unity and not the 8th, so the order-8 Tate pairing that decides
+// JubJub and Baby-JubJub does not exist here.  What exists is one level of 2-descent and the order-4 pairing:
+//   on v^2 = u^3 + A u^2 + u (u = (1+y)/(1-y), v = c u/x, c = sqrt(-(A+2))) the only rational point of order 2 is (0,0),
+//   P is in 2E iff u is a square, and a half Q of P is rational: through the 2-isogeny with kernel (0,0) and its dual,
+//     s = sqrt(u), X = A + 2u +- 2v/s (the one of the two that is a square), T = X - A, x_Q = (T + sqrt(T^2 - 4))/2,
+//     Y' = 8 X^2 v / ((A^2 - 4) - X^2), y_Q = Y' x_Q^2 / (1 - x_Q^2).
+//   Q is defined up to (0,0), which lies in 4E, so P is in 8E iff Q is in 4E iff the reduced Tate pairing with
+//   T4 = (1, y4), y4 = sqrt(A+2), is trivial: f_{4,T4}(Q) = x_Q l^2 modulo 4th powers, l = y_Q - y4 x_Q (the tangent at T4
+//   passes through (0,0)), i.e. chi_4(x_Q l^2) = 1.
+// No quotient is ever formed: s, sqrt(T^2 - 4) are roots of numerators over known denominators and everything else only
+// feeds a character.  With n = 1+y, m = 1-y, s' = sqrt(n m), Td = m x s':
+//   Tn = 2 n (x s' +- c m), Xn = A Td + Tn (sign: chi(Xn Td) = 1), xn = Tn + sqrt(Tn^2 - 4 Td^2), xd = 2 Td,
+//   Bd = Td ((A^2-4) Td^2 - Xn^2)(xd^2 - xn^2), Bn = 8c Xn^2 n s' xn xd - y4 Bd,   accept iff chi_4(xn^3 xd (Bn Bd)^2) = 1.
+// Three fixed exponentiations and one Jacobi symbol (~1050 products) against 252 doublings + 63 additions (~2600);
+// tools/gen_constants.py (Curve.halve_tate4) derives the constants and checks this formula against r*P = O on every
+// coset of the 8-torsion; tests/test_new_suites.py does the same through the compiled code.
+template <class S>
+VRF_HD bool subgroup_by_halving_tate4(const FeN& x, const FeN& y, const SqrtTables& T) {
+  const FeN one = fe_one();
+  const bool is_identity = fe_is_zero(x) && fe_eq(y, one);
+  const FeN n = fe_mul(fe_add(one, y), one), m = fe_mul(fe_sub(one, y), one);
+  const FeN N = fe_mul(n, m);                                              // 1 - y^2: chi(N) = chi(u)
+  FeN sp;
+  bool ok = fe_sqrt_or_zsqrt(sp, N, T) && !fe_is_zero(N);                  // u = 0 is the point of order 2
+  const FeN xs = fe_mul(x, sp), cm = fe_mul(m, fe_const(vrfk::ED_HALVE_C_M));
+  const FeN Td = fe_mul(fe_mul(m, x), sp);
+  const FeN Tnp = fe_mul(fe_dbl(n), fe_add(xs, cm)), Tnm = fe_mul(fe_dbl(n), fe_sub(xs, cm));
+  const FeN ATd = fe_mul(Td, fe_const(vrfk::ED_HALVE_A_M));
+  const bool plus = fe_is_nonzero_square(fe_mul(fe_add(ATd, Tnp), Td), T);
+  const FeN Tn = fe_select(plus, Tnp, Tnm);
+  const FeN Xn = fe_mul(fe_add(ATd, Tn), one);
+  const FeN xd = fe_mul(fe_dbl(Td), one);
+  const FeN Dn = fe_mul(fe_sub(Tn, xd), fe_add(Tn, xd));                   // Tn^2 - 4 Td^2
+  FeN rD;
+  ok = fe_sqrt_or_zsqrt(rD, Dn, T) && ok;
+  const FeN xn = fe_mul(fe_add(Tn, rD), one);
+  const FeN Xn2 = fe_sqr(Xn), xn2 = fe_sqr(xn);
+  const FeN K1 = fe_mul(fe_sub(fe_mul(fe_sqr(Td), fe_const(vrfk::ED_HALVE_BP_M)), Xn2), one);
+  const FeN K2 = fe_mul(fe_sub(fe_sqr(xd), xn2), one);
+  const FeN Bd = fe_mul(fe_mul(Td, K1), K2);
+  const FeN t8 = fe_mul(fe_mul(fe_mul(Xn2, fe_const(vrfk::ED_HALVE_C8_M)), fe_mul(n, sp)), fe_mul(xn, xd));
+  const FeN Bn = fe_mul(fe_sub(t8, fe_mul(Bd, fe_const(vrfk::ED_HALVE_Y4_M))), one);
+  const FeN W = fe_mul(fe_mul(fe_mul(xn2, xn), xd), fe_sqr(fe_mul(Bn, Bd)));
+  ok = fe_is_nonzero_fourth_power(W) && ok;                                // W = 0 fails: 0^t = 0
+  return is_identity || ok;
+}
+#endif
+
 template <class S>
 VRF_HD bool in_prime_subgroup(const FeN& x, const FeN& y, const SqrtTables& T) {
-  if constexpr (S::SUBGROUP == SUBGROUP_ORDER) return subgroup_by_order<S>(x, y);
+  if constexpr (S::SUBGROUP == SUBGROUP_HALVE_TATE4) {
+#if VRF_FIELD == 1
+    return subgroup_by_halving_tate4<S>(x, y, T);
+#else
+    return false;
+#endif
+  } else if constexpr (S::SUBGROUP == SUBGROUP_ORDER) return subgroup_by_order<S>(x, y);
   else if constexpr (S::SUBGROUP == SUBGROUP_TATE8) return subgroup_by_tate8<S>(x, y, T);
   else {
 #if VRF_FIELD == 0

@@ -112,6 +112,11 @@ int hx_decode_checked(const uint8_t* enc) {
   ok = ok && in_prime_subgroup<SX>(fe_mul(x, fe_one()), a.y, HX().t.sq);
   return ok ? 0 : 2;
 }
+// the suite's subgroup test and arkworks' own (r * P = O through the compiled group law) on an affine point: bit 0 / bit 1
+int hx_subgroup_both(const uint8_t* x, const uint8_t* y) {
+  const FeN xx = in(x), yy = in(y);
+  return (in_prime_subgroup<SX>(xx, yy, HX().t.sq) ? 1 : 0) | (subgroup_by_order<SX>(xx, yy) ? 2 : 0);
+}
 // (x1, y1) + (x2, y2) and 2 (x1, y1) through the extended-coordinate laws, affine out
 void hx_point_add(const uint8_t* x1, const uint8_t* y1, const uint8_t* x2, const uint8_t* y2, uint8_t* ox, uint8_t* oy) {
   PtE p = te_from_affine(in(x1), in(y1)), q = te_from_affine(in(x2), in(y2));

@@ -246,6 +246,33 @@ def test_group_law_decode_and_subgroup_test(hx):
             assert (int.from_bytes(x.raw, "little"), int.from_bytes(y.raw, "little")) == P
 
 
+def test_subgroup_test_equals_r_times_p_on_every_coset_and_small_order_point(hx):
+    """The cheap membership tests (Ed25519: one halving + the order-4 Tate pairing; Baby-JubJub: the order-8 pairing)
+    against r * P = O through the compiled group law and through the oracle: 40 subgroup points on all 8 cosets of the
+    torsion, the 8 torsion points themselves, points with special coordinates (y = 0, the generator, its negation)."""
+    lib, S, _ = hx
+    rnd = random.Random(11)
+    G, T8 = (S.gx, S.gy), _torsion8(S)
+    tors = [o.te_mul(S, j, T8) for j in range(8)]
+    pts = [o.te_mul(S, rnd.randrange(1, S.r), G) for _ in range(40)] + [(0, 1), G, o.te_neg(S, G)]
+    for P in pts:
+        for j, Tj in enumerate(tors):
+            Pj = o.te_add(S, P, Tj)
+            want = 3 if (j == 0) else 0
+            assert o.te_in_prime_subgroup(S, Pj) == (j == 0)
+            assert lib.hx_subgroup_both(le(Pj[0]), le(Pj[1])) == want, (P, j)
+    # every coset representative above has a random-looking y; points decoded from random strings have random cosets
+    seen = set()
+    for _ in range(200):
+        P = o.point_decode(S, rnd.getrandbits(256).to_bytes(32, "little"))
+        if P is None:
+            continue
+        got = lib.hx_subgroup_both(le(P[0]), le(P[1]))
+        assert got in (0, 3) and (got == 3) == o.te_in_prime_subgroup(S, P)
+        seen.add(got)
+    assert seen == {0, 3}
+
+
 def test_schemes_on_the_host_build_equal_the_oracle(hx):
     lib, S, _ = hx
     lib.hx_set_check_mask(15)

@@ -308,6 +308,77 @@ class Curve:
                 Pj = self.add(P, self.mul(j, T8))
                 assert test(Pj) == (self.mul(self.r, Pj) == (0, 1)), "tate8 formula disagrees with r*P = O"
 
+    def halve_tate4(self):
+        """Constants of the subgroup test by one halving and the reduced Tate pairing with a point of order 4 (vrf_core.cuh
+        subgroup_by_halving_tate4), for a = -1 curves whose rational 2-power torsion is cyclic of order 8 over a field with
+        q = 5 (mod 8) (Ed25519): Fq holds the 4th roots of unity but not the 8th, so the order-8 pairing of tate8() does not
+        exist.  On the Montgomery model v^2 = u^3 + A u^2 + u (u = (1+y)/(1-y), v = c u/x, c = sqrt(-(A+2))):
+          P in 2E  iff  u is a square (the curve has ONE rational point of order 2, (0,0), and u generates its descent);
+          a half Q of P through the 2-isogeny with kernel (0,0) and its dual: s = sqrt(u), X = A + 2u +- 2v/s (the square
+          one of the two), T = X - A, x_Q = (T + sqrt(T^2 - 4))/2, Y' = 8 X^2 v/((A^2-4) - X^2), y_Q = Y' x_Q^2/(1 - x_Q^2);
+          Q is defined up to the point of order 2, which lies in 4E, so: P in 8E iff Q in 4E iff t_4(T4, Q) = 1 with
+          T4 = (1, y4), y4 = sqrt(A+2): f_{4,T4}(Q) = l^2 / (x_Q ...) = x_Q l^2 modulo 4th powers, l = y_Q - y4 x_Q the
+          tangent at T4 (it passes through (0,0)), so the test is chi_4(x_Q l^2) = 1.
+        The device code runs the same steps without inversions (every quotient only feeds a character)."""
+        F, q, inv = self.F, self.F.q, self.F.inv
+        assert self.cofactor == 8 and q % 8 == 5 and self.a == q - 1
+        A = 2 * (self.a + self.d) * inv(self.a - self.d) % q
+        c = F.sqrt((-(A + 2)) % q)
+        y4 = F.sqrt((A + 2) % q)
+        assert c is not None and y4 is not None
+        k = dict(A=A, C=c, C8=8 * c % q, Y4=y4, BP=(A * A - 4) % q)
+        self._check_halve_tate4(k)
+        return k
+
+    def _check_halve_tate4(self, k):
+        """The inversion-free formula of subgroup_by_halving_tate4 in Python ints against r*P = O on every coset of the
+        8-torsion, on the torsion points themselves and on random decodable strings."""
+        import random
+        F, q = self.F, self.F.q
+        rnd = random.Random(4)
+        chi = lambda z: pow(z % q, (q - 1) // 2, q)
+
+        def test(P):
+            x, y = P
+            if (x, y) == (0, 1):
+                return True
+            n, m = (1 + y) % q, (1 - y) % q
+            N = n * m % q
+            if chi(N) != 1:
+                return False
+            sp = F.sqrt(N)
+            Td = m * x % q * sp % q
+            Tnp, Tnm = 2 * n * (x * sp + k["C"] * m) % q, 2 * n * (x * sp - k["C"] * m) % q
+            ATd = k["A"] * Td % q
+            Tn = Tnp if chi((ATd + Tnp) * Td) == 1 else Tnm
+            Xn = (ATd + Tn) % q
+            Dn = (Tn - 2 * Td) * (Tn + 2 * Td) % q
+            if chi(Dn) != 1:
+                return False
+            xn, xd = (Tn + F.sqrt(Dn)) % q, 2 * Td % q
+            Bd = Td * ((k["BP"] * Td * Td - Xn * Xn) % q) % q * ((xd * xd - xn * xn) % q) % q
+            Bn = (k["C8"] * Xn * Xn % q * n % q * sp % q * xn % q * xd - k["Y4"] * Bd) % q
+            BB = Bn * Bd % q
+            W = pow(xn, 3, q) * xd % q * BB % q * BB % q
+            return W != 0 and pow(W, (q - 1) // 4, q) == 1
+        G = (self.gx, self.gy)
+        T8 = None
+        while T8 is None:
+            P = self.decode(rnd.getrandbits(256).to_bytes(32, "little"))
+            if P is not None and self.mul(4, self.mul(self.r, P)) != (0, 1):
+                T8 = self.mul(self.r, P)
+        for j in range(8):
+            assert test(self.mul(j, T8)) == (j == 0), "halving/tate4 on the torsion"
+        for _ in range(6):
+            P = self.mul(rnd.randrange(1, self.r), G)
+            for j in range(8):
+                Pj = self.add(P, self.mul(j, T8))
+                assert test(Pj) == (j == 0), "halving/tate4 formula disagrees with r*P = O"
+        for _ in range(24):
+            P = self.decode(rnd.getrandbits(256).to_bytes(32, "little"))
+            if P is not None:
+                assert test(P) == (self.mul(self.r, P) == (0, 1))
+
 
 F0 = Field(Q_BLS, KIND_MONT_Q1, 5)
 F1 = Field(Q_25519, KIND_PM25519, 2)
@@ -654,6 +725,10 @@ def gen_field1():
     bx, by = ced.tai_base(b"Ed25519_SHA-512_TAI", b"vrfhip-ed25519-blinding-base")
     ap(carr("ED_BX_M", F.lm(bx)))
     ap(carr("ED_BY_M", F.lm(by)))
+    ap("// ---- subgroup test by one halving + the order-4 Tate pairing (vrf_core.cuh subgroup_by_halving_tate4) ----")
+    ap("// Montgomery A, c = sqrt(-(A+2)), 8c, y4 = sqrt(A+2) (T4 = (1, y4) has order 4), A^2 - 4")
+    for nm, v in sorted(ced.halve_tate4().items()):
+        ap(carr("ED_HALVE_%s_M" % nm, F.lm(v)))
     emit_field_traits(ap, F, st)
     emit_tables(ap, F, st, [("ED_G_XY", (ED["gx"], ED["gy"])), ("ED_B_XY", (bx, by))])
     write("constants_f25519.gen.h", out)
