@@ -40,7 +40,7 @@ constexpr int mul_v(int v1, int v2) {
 template <int L, int V>
 struct Fe {
   static_assert(L >= 1 && L <= 7, "limb bound out of range");
-  static_assert(V >= 1 && V <= 64, "value bound out of range (top limb must stay < 2^29)");
+  static_assert(V >= 1 && V <= vrfk::VMAX, "value bound out of range (top limb must stay < 2^29)");
   uint32_t v[NL];
   Fe() = default;
   template <int L2, int V2>
@@ -151,6 +151,39 @@ VRF_HD Fe<1, V> fe_norm(const Fe<L, V>& a) {
   r.v[NL - 1] = a.v[NL - 1] + (a.v[NL - 2] >> LW);
   return r;
 }
+
+#if VRF_FIELD == 3
+// Weak reduction for P-256, where a 256-bit modulus leaves the lazy sums only V <= 32 of headroom (2^261 / 2^256):
+// any value < 32 q comes back below 2^256 + 2^229 < 2 q with exact limbs.  k = floor(v / 2^256) <= 31 and
+// v - k q = (v mod 2^256) + k (2^224 - 2^192 - 2^96 + 1): one exact carry pass to read k, one signed pass to add the
+// four terms.  ~60 32-bit instructions, a third of a product by one (the only reduction the other fields need).
+template <int L, int V>
+VRF_HD Fe<1, 2> fe_wred(const Fe<L, V>& a) {
+  uint32_t x[NL];
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < NL - 1; ++i) {
+    const uint32_t t = a.v[i] + c;
+    x[i] = t & LMASK;
+    c = t >> LW;
+  }
+  x[NL - 1] = a.v[NL - 1] + c;
+  const int32_t k = (int32_t)(x[NL - 1] >> 24);          // bit 256 is bit 24 of limb 8
+  x[NL - 1] &= 0x00ffffffu;
+  Fe<1, 2> r;
+  int32_t cc = k;                                        // + k at bit 0
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    int32_t t = (int32_t)x[i] + cc;
+    if (i == 3) t -= k << 9;                             // - k 2^96  (96 = 3 * 29 + 9)
+    if (i == 6) t -= k << 18;                            // - k 2^192 (192 = 6 * 29 + 18)
+    if (i == 7) t += k << 21;                            // + k 2^224 (224 = 7 * 29 + 21)
+    r.v[i] = (i < NL - 1) ? ((uint32_t)t & LMASK) : (uint32_t)t;
+    cc = t >> LW;
+  }
+  return r;
+}
+#endif
 
 template <int L, int V>
 VRF_HD Fe<L, V> fe_select(bool c, const Fe<L, V>& a, const Fe<L, V>& b) {   // c ? a : b
@@ -484,6 +517,7 @@ VRF_HD FeN fe_inv_pow(const Fe<L, V>& a) {   // a^(q-2); 0 -> 0
 //   S = 32 (BLS12-381 Fr): byte digits; tables k = 0..3 at levels 0, 8, 16, 24.  220 + 24 squarings.
 //   S = 28 (BN254 Fr): digits 8 | 8 | 8 | 4; the same four tables plus levels 4 and 12 (k = 4, 5).
 //   S = 2 (2^255 - 19): the 4-torsion is four constants, no table.
+//   S = 1 (P-256): the exponentiation is the root.
 // Returns is_square(w) and sets `root` to sqrt(w) if w is a square, else to sqrt(Z*w) (Z doubles as the Elligator
 // non-residue of the Bandersnatch suite).  Constant shape.
 VRF_HD uint32_t sqrt_lut_index(const SqrtTables& T, const FeN& y) {
@@ -520,7 +554,15 @@ VRF_HD bool fe_sqrt_or_zsqrt(FeN& root, const Fe<L, V>& w_in, const SqrtTables& 
   FeN v = fe_pow_prog(w, vrfk::POW_SQRT_PROG);        // w^((t-1)/2)
   FeN x0 = fe_mul(w, v);                            // w^((t+1)/2)
   FeN b = fe_mul(x0, v);                            // w^t, in the 2^S-torsion
-  if constexpr (vrfk::SQRT_S == 2) {
+  if constexpr (vrfk::SQRT_S == 1) {
+    // q = 3 (mod 4), Z = -1: x0 = w^((q+1)/4) squares to w chi(w), i.e. it is sqrt(w) or sqrt(Z w) as it stands
+    root = x0;
+    const FeN bc = fe_canon(b);                       // chi(w): 1, -1 or 0
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) nz |= bc.v[i];
+    return limbs_eq(bc, vrfk::ONE_M) || nz == 0;
+  } else if constexpr (vrfk::SQRT_S == 2) {
 #if VRF_FIELD == 1
     uint32_t e;
     // x0 = w^((q+3)/8); b = x0^2 / w is 1, -1 (root x0 / sqrt(-1)) or a primitive 4th root of unity (w a non-residue)
@@ -549,7 +591,7 @@ VRF_HD bool fe_sqrt_or_zsqrt(FeN& root, const Fe<L, V>& w_in, const SqrtTables& 
         T, fe_mul(fe_mul(fe_mul(b, sqrt_tbl(T, 0, e0)), sqrt_tbl(T, 1, e1)), sqrt_tbl(T, 2, e2))) >> 4;
     return sqrt_finish(root, x0, e0 | (e1 << 8) | (e2 << 16) | (e3 << 24), T);
   } else {
-    static_assert(vrfk::SQRT_S == 2 || vrfk::SQRT_S == 28 || vrfk::SQRT_S == 32, "no square-root plan for this 2-adicity");
+    static_assert(vrfk::SQRT_S <= 2 || vrfk::SQRT_S == 28 || vrfk::SQRT_S == 32, "no square-root plan for this 2-adicity");
     FeN b8 = b;
     for (int i = 0; i < 8; ++i) b8 = fe_sqr(b8);
     FeN b16 = b8;
@@ -758,7 +800,10 @@ VRF_HD FeN fe_inv(const Fe<L, V>& a) {
     const FeN slow = fe_inv_pow(a);
     if (!done) return slow;
   }
-  Fe<1, 64> dd;                               // d < (JAC_MAX_ROUNDS + 1) q
+  // d < (JAC_MAX_ROUNDS + 1) q = 41 q.  A 256-bit q (P-256, VMAX = 32) puts that above the typed range: there the top
+  // limb is < 2^30 (declared as L = 2) and the first product below is by the constant R^2 mod q < q, so its value is
+  // < q (1 + 41 q / R) < 2.3 q, inside what mul_v(32, 2) = 3 claims for it.
+  Fe<(vrfk::VMAX < 64 ? 2 : 1), (vrfk::VMAX < 64 ? vrfk::VMAX : 64)> dd;
 #pragma unroll
   for (int i = 0; i < NL; ++i) dd.v[i] = nz == 0 ? 0u : d[i];
   // d = a^-1 / R as an integer: two Montgomery products by R^2 give a^-1 R

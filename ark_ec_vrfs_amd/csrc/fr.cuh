@@ -37,7 +37,7 @@ VRF_HD void fr_montmul(uint32_t out[8], const uint32_t a[8], const uint32_t b[8]
     t[7] = (uint32_t)x;
     t[8] = t[9] + (uint32_t)(x >> 32);
   }
-  // t < 2r < 2^256: one conditional subtraction
+  // t < 2r: one conditional subtraction (t[8] is the 257th bit, set only when r > 2^255: secp256r1's order)
   uint32_t d[8];
   uint32_t borrow = 0;
 #pragma unroll
@@ -46,8 +46,9 @@ VRF_HD void fr_montmul(uint32_t out[8], const uint32_t a[8], const uint32_t b[8]
     d[i] = (uint32_t)y;
     borrow = (uint32_t)(y >> 63);
   }
+  const bool keep = borrow && t[8] == 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) out[i] = borrow ? t[i] : d[i];
+  for (int i = 0; i < 8; ++i) out[i] = keep ? t[i] : d[i];
 }
 
 template <class C>
@@ -75,8 +76,9 @@ VRF_HD void fr_add(uint32_t out[8], const uint32_t a[8], const uint32_t b[8]) { 
     d[i] = (uint32_t)y;
     borrow = (uint32_t)(y >> 63);
   }
+  const bool keep = borrow && c == 0;          // c: the sum's 257th bit (r > 2^255 only)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) out[i] = borrow ? s[i] : d[i];
+  for (int i = 0; i < 8; ++i) out[i] = keep ? s[i] : d[i];
 }
 
 template <class C>

@@ -1,0 +1,397 @@
+// p256_core.cuh -- the secp256r1 suite ("P256_SHA256_TAI", RFC 9381 suite 0x01; upstream `suites::secp256r1`,
+// /root/reference src/lib.rs:14): Sec1 codec, try-and-increment hash-to-curve, RFC 6979 nonce, challenge, output hash and
+// the per-item prove / verify steps, on top of sw.cuh (group law) and sha256.cuh.
+//
+// Wire format of this suite at the C ABI (include/vrfhip.h): points are 33-byte Sec1 compressed strings (`Sec1Codec`),
+// scalars 32-byte BIG-endian integers (`int_to_string` = I2OSP); the challenge is 16 bytes on the wire, carried here in
+// a 32-byte big-endian field like every scalar.
+//
+// Pinned by RFC 9381 Appendix B.1 (tests/golden/rfc9381_p256_sha256_tai.json): the three published examples' H, k, U, V,
+// pi and beta come out of these functions bit for bit (tests/test_secp256r1.py, on the host build and through the GPU).
+#pragma once
+#include "sha256.cuh"
+#include "sw.cuh"
+
+VRF_NS_BEGIN
+
+constexpr int SEC1_LEN = 33;
+
+VRF_HD bool u256_ge_q(const uint32_t a[8]) {   // a >= p
+  bool ge = true, decided = false;
+#pragma unroll
+  for (int i = 7; i >= 0; --i) {
+    const uint32_t b = vrfk::Q32[i];
+    if (!decided && a[i] != b) { ge = a[i] > b; decided = true; }
+  }
+  return ge;
+}
+// 32 big-endian bytes <-> 8 little-endian u32 words
+VRF_HD void load_be256(uint32_t w[8], const uint8_t* p) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint8_t* q = p + 4 * (7 - j);
+    w[j] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+  }
+}
+VRF_HD void store_be256(uint8_t* p, const uint32_t w[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    uint8_t* q = p + 4 * (7 - j);
+    q[0] = (uint8_t)(w[j] >> 24); q[1] = (uint8_t)(w[j] >> 16); q[2] = (uint8_t)(w[j] >> 8); q[3] = (uint8_t)w[j];
+  }
+}
+
+// y from x and the parity bit: the root of x^3 - 3x + b whose lowest bit is `odd`.  false: x is not on the curve.
+VRF_HD bool sw_lift_x(FeN& y, const FeN& x, bool odd) {
+  const SqrtTables none{};                       // q = 3 (mod 4): the root is one exponentiation, no tables
+  FeN root;
+  const bool sq = fe_sqrt_or_zsqrt(root, sw_rhs(x), none);
+  uint32_t yw[8];
+  fe_to_u256(yw, root);
+  y = fe_select(((yw[0] & 1u) != 0) != odd, fe_wred(fe_neg(root)), root);
+  return sq;
+}
+
+// [ref src/lib.rs:14 `codec`] Sec1Codec::point_decode of a 33-byte string: 0x02 / 0x03 || x (big-endian), x < p, on the
+// curve.  The cofactor is 1: being on the curve is being in the group.  (The one-byte encoding 0x00 of the point at
+// infinity has no 33-byte form: a key, input or output at infinity is not representable at this ABI, and upstream
+// rejects such a `Public` / `Input` anyway.)
+VRF_HD bool sec1_decode(FeN& x, FeN& y, const uint8_t* enc) {
+  const uint32_t tag = enc[0];
+  uint32_t xw[8];
+  load_be256(xw, enc + 1);
+  const bool ok = (tag == 2u || tag == 3u) && !u256_ge_q(xw);
+  x = fe_from_u256(xw);
+  return sw_lift_x(y, x, (tag & 1u) != 0) && ok;
+}
+
+// affine (x, y) -> tag and the big-endian integer x as 8 LE words
+VRF_HD uint32_t sec1_words(uint32_t xw[8], const FeN& x, const FeN& y) {
+  uint32_t yw[8];
+  fe_to_u256(xw, x);
+  fe_to_u256(yw, y);
+  return 2u + (yw[0] & 1u);
+}
+VRF_HD void sec1_store(uint8_t* out, uint32_t tag, const uint32_t xw[8]) {
+  out[0] = (uint8_t)tag;
+  store_be256(out + 1, xw);
+}
+// a point of the transcript: tag 0 = the point at infinity, which Sec1Codec::point_encode writes as the single byte 0x00
+VRF_HD void sha256_put_sec1(Sha256& h, uint32_t tag, const uint32_t xw[8]) {
+  sha256_put_byte(h, (uint8_t)tag);
+  if (tag != 0) sha256_put_be256(h, xw);
+}
+
+VRF_HD void p256_put_suite(Sha256& h, const SuiteStr& ss) { sha256_put_packed64(h, ss.suite_id_w, ss.suite_id_len); }
+
+// [ref src/lib.rs:14 `utils`] hash_to_curve_tai_rfc_9381 (RFC 9381 5.4.1.1): H = string_to_point(0x02 || Hash(suite ||
+// 0x01 || data || ctr || 0x00)) for the first ctr in 0..255 that decodes; cofactor 1.  `data` is what the caller passes
+// to `Input::new` (RFC 9381's own use: encode_to_curve_salt || alpha with the salt = the public key string).
+VRF_HD bool p256_hash_to_curve(FeN& x, FeN& y, uint32_t xw[8], const uint8_t* data, uint32_t len, const SuiteStr& ss) {
+  Sha256 pre;
+  sha256_init(pre);
+  p256_put_suite(pre, ss);
+  sha256_put_byte(pre, 0x01);
+  sha256_put_bytes(pre, data, len);
+  bool found = false;
+  x = fe_zero(); y = fe_zero();
+#pragma unroll 1
+  for (uint32_t ctr = 0; ctr < 256 && !found; ++ctr) {
+    Sha256 h = pre;
+    sha256_put_byte(h, (uint8_t)ctr);
+    sha256_put_byte(h, 0x00);
+    sha256_final(h);
+    uint32_t w[8];
+    sha256_be256(w, h);
+    if (u256_ge_q(w)) continue;
+    const FeN xc = fe_from_u256(w);
+    FeN yc;
+    if (!sw_lift_x(yc, xc, false)) continue;            // 0x02: the even root
+    x = xc; y = yc; found = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xw[i] = w[i];
+  }
+  return found;
+}
+
+// [ref src/lib.rs:14 `utils`] nonce_rfc_6979 (RFC 9381 5.4.2.1 / RFC 6979 3.2 with HMAC-SHA-256), as upstream runs it:
+// h1 = Hash(point_to_string(H)) enters the HMAC input as it is (RFC 6979's bits2octets would reduce it mod n first: the
+// two differ when h1 >= n, 2^-32 of the inputs) and the first candidate T = V is taken mod n (RFC 6979 retries when
+// T >= n or T = 0: again 2^-32).  DESIGN.md section 2 lists this among the laxities held the upstream way.
+VRF_HD void p256_nonce(uint32_t k[8], const uint32_t sk[8], uint32_t htag, const uint32_t hxw[8]) {
+  Sha256 s;
+  sha256_init(s);
+  sha256_put_sec1(s, htag, hxw);
+  sha256_final(s);
+  uint32_t h1[8], V[8], K[8];
+  sha256_be256(h1, s);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { V[i] = 0x01010101u; K[i] = 0; }
+#pragma unroll 1
+  for (uint32_t sep = 0; sep < 2; ++sep) {
+    hmac256_begin(s, K);                                // K = HMAC_K(V || sep || int2octets(x) || h1)
+    sha256_put_be256(s, V);
+    sha256_put_byte(s, (uint8_t)sep);
+    sha256_put_be256(s, sk);
+    sha256_put_be256(s, h1);
+    uint32_t Kn[8];
+    hmac256_end(Kn, s, K);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) K[i] = Kn[i];
+    hmac256_begin(s, K);                                // V = HMAC_K(V)
+    sha256_put_be256(s, V);
+    hmac256_end(V, s, K);
+  }
+  hmac256_begin(s, K);
+  sha256_put_be256(s, V);
+  hmac256_end(V, s, K);
+  fr_reduce256<CurveP256>(k, V);
+}
+
+// [ref src/lib.rs:14 `utils`] challenge_rfc_9381 (RFC 9381 5.4.3): the first `challenge_len` bytes of Hash(suite || 0x02
+// || pk || H || Gamma || U || V || ad || 0x00) as a big-endian integer.
+struct Sec1W {
+  uint32_t tag;
+  uint32_t xw[8];
+};
+VRF_HD void p256_challenge(uint32_t c[8], const Sec1W (&pts)[5], const uint8_t* ad, uint32_t ad_len, const SuiteStr& ss) {
+  Sha256 h;
+  sha256_init(h);
+  p256_put_suite(h, ss);
+  sha256_put_byte(h, 0x02);
+#pragma unroll 1
+  for (int j = 0; j < 5; ++j) {
+    Sec1W p = pts[0];
+#pragma unroll
+    for (int k = 1; k < 5; ++k)
+      if (j == k) p = pts[k];
+    sha256_put_sec1(h, p.tag, p.xw);
+  }
+  sha256_put_bytes(h, ad, ad_len);
+  sha256_put_byte(h, 0x00);
+  sha256_final(h);
+  uint32_t w[8];
+  sha256_be256(w, h);
+  // the first L bytes of the digest = the top 8 L bits of the 256-bit big-endian integer
+  const uint32_t sh = 256u - 8u * ss.challenge_len;     // 0..248, a multiple of 8
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t bit = 32u * (uint32_t)i + sh, j = bit >> 5, r = bit & 31u;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (j == (uint32_t)k) lo = w[k];
+      if (j + 1 == (uint32_t)k) hi = w[k];
+    }
+    c[i] = bit >= 256u ? 0u : (r ? (lo >> r) | (hi << (32u - r)) : lo);
+  }
+}
+
+// [ref src/lib.rs:14 `utils`] point_to_hash_rfc_9381: Hash(suite || 0x03 || point_to_string(Gamma) || 0x00) (cofactor 1)
+VRF_HD void p256_output_hash(uint32_t out[8], uint32_t tag, const uint32_t xw[8], const SuiteStr& ss) {
+  Sha256 h;
+  sha256_init(h);
+  p256_put_suite(h, ss);
+  sha256_put_byte(h, 0x03);
+  sha256_put_sec1(h, tag, xw);
+  sha256_put_byte(h, 0x00);
+  sha256_final(h);
+  sha256_be256(out, h);
+}
+
+// [ref src/lib.rs:16 `Secret::from_seed`] sk = Hash(seed) read little-endian, mod n (upstream's from_le_bytes_mod_order of
+// the hasher's output, whatever the codec's endianness); 0 -> 1 is not reachable from a hash in practice
+VRF_HD void p256_secret_from_seed(uint32_t sk[8], const uint8_t* seed, uint32_t len) {
+  Sha256 h;
+  sha256_init(h);
+  sha256_put_bytes(h, seed, len);
+  sha256_final(h);
+  uint32_t w[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {                         // digest byte 4j.. -> little-endian word j
+    const uint32_t v = h.h[j];
+    w[j] = (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24);
+  }
+  fr_reduce256<CurveP256>(sk, w);
+}
+
+// ---- scalar multiplication ----
+// Signed radix-16 digits of a full 256-bit scalar: k + 0x88..8 has nibbles d_w + 8 with d_w in [-8, 7]; the order of
+// secp256r1 is just below 2^256, so -- unlike the 253-bit orders of the Edwards suites -- the addition can carry out of
+// the top nibble: that carry is digit 64 (0 or 1) and every ladder below has 65 windows.
+VRF_HD uint32_t sw_recode(uint32_t rec[8], const uint32_t k[8]) {
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t x = (uint64_t)k[i] + 0x88888888u + c;
+    rec[i] = (uint32_t)x;
+    c = (uint32_t)(x >> 32);
+  }
+  return c;
+}
+VRF_HD int sw_digit(const uint32_t rec[8], uint32_t top, int w) { return w == 64 ? (int)top : scalar_digit4(rec, w); }
+constexpr int SW_WINDOWS = 65;
+
+// k * P against a window table (sw_build_table), negated if `negate`
+VRF_HD PtW sw_win_mul(const uint32_t* tab, size_t stride, const uint32_t k[8], bool negate) {
+  uint32_t rec[8];
+  const uint32_t top = sw_recode(rec, k);
+  PtW acc = sw_identity();
+#pragma unroll 1
+  for (int w = SW_WINDOWS - 1; w >= 0; --w) {
+    if (w != SW_WINDOWS - 1) {
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) acc = sw_dbl(acc);
+    }
+    const int d = sw_digit(rec, top, w);
+    acc = sw_add(acc, sw_lookup(tab, stride, negate ? -d : d));
+  }
+  return acc;
+}
+
+// the fixed-base comb of the generator: row w holds j * 16^w * G, j = 1..8 (projective, Z = 1), so k*G is 65 additions
+// and no doubling.  [65][8][PTW_WORDS] words, built once per context (k_p256.hip k_p256_init_comb).
+constexpr int P256_COMB_ROWS = SW_WINDOWS;
+constexpr size_t P256_COMB_WORDS = (size_t)P256_COMB_ROWS * SW_TABLE_WORDS;
+VRF_HD PtW sw_comb_mul(const uint32_t* comb, const uint32_t k[8]) {
+  uint32_t rec[8];
+  const uint32_t top = sw_recode(rec, k);
+  PtW acc = sw_identity();
+#pragma unroll 1
+  for (int w = 0; w < P256_COMB_ROWS; ++w)
+    acc = sw_add(acc, sw_lookup(comb + (size_t)w * SW_TABLE_WORDS, 1, sw_digit(rec, top, w)));
+  return acc;
+}
+
+// s * P - c * Q with c < 2^128 (the challenge): Straus over the two tables: 256 doublings, 65 + 33 additions
+VRF_HD PtW sw_straus_sc(const uint32_t* tabP, const uint32_t* tabQ, size_t stride, const uint32_t s[8], const uint32_t c[8]) {
+  uint32_t srec[8], crec[8];
+  const uint32_t stop = sw_recode(srec, s);
+  (void)sw_recode(crec, c);                              // c < 2^128: only digits 0..32 can be non-zero
+  PtW acc = sw_identity();
+#pragma unroll 1
+  for (int w = SW_WINDOWS - 1; w >= 0; --w) {
+    if (w != SW_WINDOWS - 1) {
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) acc = sw_dbl(acc);
+    }
+    acc = sw_add(acc, sw_lookup(tabP, stride, sw_digit(srec, stop, w)));
+    if (w <= 32)                                         // wave-uniform
+      acc = sw_add(acc, sw_lookup(tabQ, stride, -scalar_digit4(crec, w)));
+  }
+  return acc;
+}
+// s * G - c * Q: the generator's half comes from the comb after the ladder (no doublings for it)
+VRF_HD PtW sw_comb_minus_win(const uint32_t* comb, const uint32_t* tabQ, size_t stride, const uint32_t s[8], const uint32_t c[8]) {
+  uint32_t crec[8];
+  (void)sw_recode(crec, c);
+  PtW acc = sw_identity();
+#pragma unroll 1
+  for (int w = 32; w >= 0; --w) {
+    if (w != 32) {
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) acc = sw_dbl(acc);
+    }
+    acc = sw_add(acc, sw_lookup(tabQ, stride, -scalar_digit4(crec, w)));
+  }
+  return sw_add(acc, sw_comb_mul(comb, s));
+}
+
+// ---- projective -> Sec1 with one shared inversion ----
+template <bool CT, int N>
+VRF_HD void sw_to_sec1(Sec1W (&out)[N], const PtW (&p)[N]) {
+  FeN z[N], pre[N];
+  bool inf[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    inf[i] = fe_is_zero(p[i].Z);
+    z[i] = fe_select(inf[i], fe_one(), p[i].Z);
+    pre[i] = i == 0 ? z[0] : fe_mul(pre[i - 1], z[i]);
+  }
+  FeN acc = fe_inv<CT>(pre[N - 1]);
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    const FeN zi = i == 0 ? acc : fe_mul(acc, pre[i - 1]);
+    acc = fe_mul(acc, z[i]);
+    const uint32_t tag = sec1_words(out[i].xw, fe_mul(p[i].X, zi), fe_mul(p[i].Y, zi));
+    out[i].tag = inf[i] ? 0u : tag;
+  }
+}
+
+// 32-byte big-endian scalar -> words mod n (`Sec1Codec::scalar_decode` = from_be_bytes_mod_order)
+VRF_HD void p256_scalar_decode(uint32_t out[8], const uint8_t* be) {
+  uint32_t w[8];
+  load_be256(w, be);
+  fr_reduce256<CurveP256>(out, w);
+}
+
+// ---- IETF verify, per item [ref src/lib.rs:14 `ietf::Verifier::verify`, RFC 9381 5.3] ----
+// stage 1: decode pk, H, Gamma (33-byte Sec1) and the proof scalars; false = InvalidData
+VRF_HD bool p256_verify_decode_item(FeN (&x)[3], FeN (&y)[3], Sec1W (&enc)[3], uint32_t c[8], uint32_t s[8],
+                                    const uint8_t* pk, const uint8_t* h, const uint8_t* gamma, const uint8_t* cb,
+                                    const uint8_t* sb) {
+  bool ok = true;
+#pragma unroll 1
+  for (int j = 0; j < 3; ++j) {
+    const uint8_t* e = j == 0 ? pk : j == 1 ? h : gamma;
+    FeN xx, yy;
+    ok = sec1_decode(xx, yy, e) && ok;
+    Sec1W w;
+    w.tag = e[0];
+    load_be256(w.xw, e + 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (j == k) { x[k] = xx; y[k] = yy; enc[k] = w; }
+  }
+  p256_scalar_decode(c, cb);
+  p256_scalar_decode(s, sb);
+  return ok;
+}
+// stage 3: c' = challenge(pk, H, Gamma, U, V, ad) == c.  1 = the proof does not verify
+VRF_HD uint8_t p256_verify_finish_item(const PtW& U, const PtW& V, const Sec1W (&enc)[3], const uint32_t c[8],
+                                       const uint8_t* ad, uint32_t ad_len, const SuiteStr& ss) {
+  const PtW uv[2] = {U, V};
+  Sec1W w[2];
+  sw_to_sec1<false>(w, uv);
+  const Sec1W pts[5] = {enc[0], enc[1], enc[2], w[0], w[1]};
+  uint32_t cc[8];
+  p256_challenge(cc, pts, ad, ad_len, ss);
+  uint32_t diff = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) diff |= cc[i] ^ c[i];
+  return diff ? 1 : 0;
+}
+
+// ---- IETF prove, per item [ref src/lib.rs:14 `ietf::Prover::prove`, RFC 9381 5.1] ----
+// stage 1: sk, H = Input::new(msg) (or the given, decoded H), nonce k.  false = InvalidData (no H within 256 tries, an
+// undecodable given H)
+VRF_HD bool p256_prove_prepare_item(uint32_t sk[8], uint32_t k[8], FeN& hx, FeN& hy, Sec1W& henc, const uint8_t* sk_be,
+                                    const uint8_t* msg, uint32_t msg_len, const uint8_t* h_given, const SuiteStr& ss) {
+  p256_scalar_decode(sk, sk_be);
+  bool ok;
+  if (h_given) {
+    ok = sec1_decode(hx, hy, h_given);
+    henc.tag = h_given[0];
+    load_be256(henc.xw, h_given + 1);
+  } else {
+    ok = p256_hash_to_curve(hx, hy, henc.xw, msg, msg_len, ss);
+    henc.tag = 2u;
+  }
+  p256_nonce(k, sk, henc.tag, henc.xw);
+  return ok;
+}
+// stage 3: res = {pk = sk G, Gamma = sk H, U = k G, V = k H}: c = challenge, s = k + c sk (mod n)
+VRF_HD void p256_prove_finish_item(Sec1W& pk, Sec1W& gamma, uint32_t c[8], uint32_t s[8], const PtW (&res)[4],
+                                   const Sec1W& henc, const uint32_t sk[8], const uint32_t k[8], const uint8_t* ad,
+                                   uint32_t ad_len, const SuiteStr& ss) {
+  Sec1W w[4];
+  sw_to_sec1<true>(w, res);
+  pk = w[0]; gamma = w[1];
+  const Sec1W pts[5] = {w[0], henc, w[1], w[2], w[3]};
+  p256_challenge(c, pts, ad, ad_len, ss);
+  uint32_t cs[8];
+  fr_mul<CurveP256>(cs, c, sk);
+  fr_add<CurveP256>(s, cs, k);
+}
+
+VRF_NS_END

@@ -1,0 +1,237 @@
+"""secp256r1 ("P256_SHA256_TAI", RFC 9381 suite 0x01): SURVEY.md section 8 row f4, the short-Weierstrass suite.
+
+CPU tier: RFC 9381 Appendix B.1 pins the Python oracle (oracle/sw_oracle.py); the device headers compiled for the host
+(tests/hostsim/hostsim_p256.hip: P-256 field, complete projective law, SHA-256 / HMAC, Sec1 codec, try-and-increment,
+RFC 6979 nonce, the per-item prove / verify steps) against Python big ints, hashlib, the oracle and the RFC vectors.
+GPU tier (-m gpu): the HIP path through the C ABI: RFC vectors, prove bytes and verify statuses against the oracle,
+tampering, undecodable points, batches that straddle launch groups."""
+import ctypes
+import hashlib
+import hmac
+import json
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import sw_oracle as sw
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HS = os.path.join(HERE, "hostsim")
+RFC = json.load(open(os.path.join(HERE, "golden", "rfc9381_p256_sha256_tai.json")))
+P, N, G = sw.P, sw.N, sw.G
+
+
+def be(x):
+    return int(x).to_bytes(32, "big")
+
+
+def xy(pt):
+    return bytes(64) if pt is None else be(pt[0]) + be(pt[1])
+
+
+def unxy(raw):
+    return None if raw == bytes(64) else (int.from_bytes(raw[:32], "big"), int.from_bytes(raw[32:], "big"))
+
+
+@pytest.fixture(scope="module")
+def hp():
+    so = os.path.join(HS, "libhostsim_p256.so")
+    subprocess.run(["make", "-C", HS, "-j4", os.path.basename(so)], check=True, stdout=subprocess.DEVNULL)
+    return ctypes.CDLL(so)
+
+
+def _fe(f, *a):
+    r = ctypes.create_string_buffer(32)
+    ret = f(*[be(x) for x in a], r)
+    return int.from_bytes(r.raw, "big"), ret
+
+
+def _pt(f, *a):
+    r = ctypes.create_string_buffer(64)
+    f(*a, r)
+    return unxy(r.raw)
+
+
+# ---------------------------------------------------------------------------------------------- oracle pinned by the RFC
+def test_rfc9381_b1_vectors_pin_the_python_oracle():
+    for v in RFC["vectors"]:
+        out = sw.rfc9381_prove(bytes.fromhex(v["sk"]), bytes.fromhex(v["alpha"]))
+        for k in ("pk", "h", "k", "u", "v", "pi", "beta"):
+            assert out[k].hex() == v[k], k
+        assert out["ctr"] == v["ctr"]
+        pi = bytes.fromhex(v["pi"])
+        Y, H, Gm = (sw.point_decode(b) for b in (out["pk"], out["h"], pi[:33]))
+        c, s = int.from_bytes(pi[33:49], "big"), int.from_bytes(pi[49:], "big")
+        assert sw.ietf_verify(Y, H, Gm, b"", c, s)
+        assert not sw.ietf_verify(Y, H, Gm, b"", c, s ^ 1) and not sw.ietf_verify(Y, H, Gm, b"x", c, s)
+        assert not sw.ietf_verify(Y, H, sw.add(Gm, G), b"", c, s)
+
+
+def test_curve_constants():
+    assert sw.is_on_curve(G) and sw.mul(N, G) is None and sw.mul(N - 1, G) == sw.neg(G)
+    assert abs(N - (P + 1)) <= 2 * int(P ** 0.5) + 2 and P % 4 == 3
+
+
+# ---------------------------------------------------------------------------------------------- device headers on the host
+def test_field_ops_against_python_ints(hp):
+    rnd = random.Random(1)
+    edge = [0, 1, 2, 3, P - 1, P - 2, P, P + 1, (1 << 256) - 1, 1 << 255, (1 << 29) - 1, 1 << 232, 1 << 224, (1 << 224) - 1,
+            1 << 192, 1 << 96, (1 << 96) - 1, P - (1 << 96), P - (1 << 224)]
+    for it in range(3000):
+        x = rnd.choice(edge) if it % 7 == 0 else rnd.getrandbits(256)
+        y = rnd.choice(edge) if it % 11 == 0 else rnd.getrandbits(256)
+        assert _fe(hp.hp_fe_mul, x, y)[0] == x * y % P
+        assert _fe(hp.hp_fe_sqr, x)[0] == x * x % P
+        assert _fe(hp.hp_fe_sub, x, y)[0] == (x - y) % P
+    for it in range(400):
+        x = rnd.choice(edge) if it % 5 == 0 else rnd.getrandbits(256)
+        assert _fe(hp.hp_fe_inv, x)[0] == pow(x % P, P - 2, P)
+        r, sq = _fe(hp.hp_fe_sqrt, x)
+        want = pow(x % P, (P - 1) // 2, P) in (0, 1)
+        assert bool(sq) == want
+        assert r * r % P == (x % P if want else (-x) % P)
+        assert hp.hp_fe_jacobi(be(x % P)) == {0: 0, 1: 1, P - 1: -1}[pow(x % P, (P - 1) // 2, P)]
+
+
+def test_weak_reduction_over_its_whole_input_range(hp):
+    """fe_wred takes any lazily accumulated value < 32 p back below 2 p: k * x for k = 1..15 (x < 2 p: up to 30 p) and x near 0, p and 2^256."""
+    rnd = random.Random(2)
+    xs = [0, 1, P - 1, P, P + 1, (1 << 256) - 1, (1 << 256) - (1 << 224), (1 << 224) + 5] + [rnd.getrandbits(256) for _ in range(40)]
+    for x in xs:
+        xm = x % P                                  # the value that enters is the FeN image of x (< 2 p)
+        for k in list(range(1, 16)):
+            r = ctypes.create_string_buffer(32)
+            hp.hp_fe_wred_chain(be(x), k, r)
+            assert int.from_bytes(r.raw, "big") == k * xm % P, (hex(x), k)
+
+
+def test_scalar_ops(hp):
+    rnd = random.Random(3)
+    edge = [0, 1, N - 1, N, N + 1, (1 << 256) - 1, 1 << 255, N >> 1, (N >> 1) + 1]
+    for it in range(600):
+        a, b, c = (rnd.choice(edge) if (it + j) % 5 == 0 else rnd.getrandbits(256) for j in range(3))
+        r = ctypes.create_string_buffer(32)
+        hp.hp_fr_mul_add(be(a), be(b), be(c), r)
+        assert int.from_bytes(r.raw, "big") == (a * b + c) % N
+
+
+def test_complete_group_law(hp):
+    rnd = random.Random(4)
+    pts = [sw.mul(rnd.randrange(1, N), G) for _ in range(10)] + [None, G, sw.neg(G)]
+    for A in pts:
+        for B in (pts[0], A, sw.neg(A), None, sw.add(A, A), G):
+            assert _pt(hp.hp_add, xy(A), xy(B)) == sw.add(A, B)
+            za, zb = rnd.randrange(1, P), rnd.randrange(1, P)
+            assert _pt(hp.hp_add_scaled, xy(A), xy(B), be(za), be(zb)) == sw.add(A, B)
+        assert _pt(hp.hp_dbl, xy(A)) == sw.add(A, A)
+    for it in range(24):
+        k = [0, 1, 2, N - 1, N - 2, (1 << 255), (1 << 256) - 1 - (1 << 32), 0x8888888888888888888888888888888888888888888888888888888888888888,
+             0x7777777777777777777777777777777777777777777777777777777777777777][it] if it < 9 else rnd.getrandbits(256)
+        A = pts[it % 10]
+        # scalars enter the ladders reduced mod n; k >= n is reduced by the caller (p256_scalar_decode)
+        kk = k % N
+        assert _pt(hp.hp_mul, be(kk), xy(A)) == sw.mul(kk, A)
+        assert _pt(hp.hp_mul_base, be(kk)) == sw.mul(kk, G)
+
+
+def test_sha256_and_hmac(hp):
+    rnd = random.Random(5)
+    for n in list(range(0, 140)) + [255, 256, 1000]:
+        m = bytes(rnd.getrandbits(8) for _ in range(n))
+        d = ctypes.create_string_buffer(32)
+        hp.hp_sha256(m, n, d)
+        assert d.raw == hashlib.sha256(m).digest(), n
+        key = bytes(rnd.getrandbits(8) for _ in range(32))
+        hp.hp_hmac256(key, m, n, d)
+        assert d.raw == hmac.new(key, m, "sha256").digest(), n
+
+
+def test_codec_and_suite_functions(hp):
+    rnd = random.Random(6)
+    # decode: both tags, x >= p, x off the curve, bad tags
+    for _ in range(60):
+        raw = bytes([rnd.choice([2, 3, 2, 3, 0, 4, 5])]) + rnd.getrandbits(256).to_bytes(32, "big")
+        out = ctypes.create_string_buffer(64)
+        ok = hp.hp_decode(raw, out)
+        try:
+            want = sw.point_decode(raw)
+        except ValueError:
+            want = None
+        assert bool(ok) == (want is not None)
+        if want is not None:
+            assert unxy(out.raw) == want
+    assert not hp.hp_decode(b"\x02" + be(P), ctypes.create_string_buffer(64))
+    assert not hp.hp_decode(b"\x02" + be(P + 5), ctypes.create_string_buffer(64))      # x = 5 as an integer is valid, p + 5 is not
+    for i in range(40):
+        data = bytes(rnd.getrandbits(8) for _ in range(rnd.choice([0, 1, 31, 32, 33, 55, 56, 64, 100, 200])))
+        enc = ctypes.create_string_buffer(33)
+        assert hp.hp_hash_to_curve(data, len(data), enc)
+        assert enc.raw == sw.point_encode(sw.hash_to_curve_tai(data)[0])
+        sk = rnd.randrange(1, N)
+        k = ctypes.create_string_buffer(32)
+        hp.hp_nonce(be(sk), enc.raw, k)
+        assert int.from_bytes(k.raw, "big") == sw.nonce_rfc6979(sk, sw.point_decode(enc.raw))
+        beta = ctypes.create_string_buffer(32)
+        hp.hp_output_hash(enc.raw, beta)
+        assert beta.raw == sw.output_hash(sw.point_decode(enc.raw))
+        s = ctypes.create_string_buffer(32)
+        hp.hp_secret_from_seed(data, len(data), s)
+        assert int.from_bytes(s.raw, "big") == sw.secret_from_seed(data)
+
+
+def test_rfc9381_b1_vectors_through_the_host_build(hp):
+    for v in RFC["vectors"]:
+        sk, alpha, pk = bytes.fromhex(v["sk"]), bytes.fromhex(v["alpha"]), bytes.fromhex(v["pk"])
+        out = ctypes.create_string_buffer(261)
+        assert hp.hp_prove(sk, pk + alpha, len(pk + alpha), None, b"", 0, out) == 1
+        o = out.raw
+        assert o[:33].hex() == v["pk"] and o[33:66].hex() == v["h"] and o[163:195].hex() == v["k"]
+        assert o[195:228].hex() == v["u"] and o[228:261].hex() == v["v"]
+        pi = o[66:99] + o[99 + 16:131] + o[131:163]
+        assert o[99:99 + 16] == bytes(16) and pi.hex() == v["pi"]
+        beta = ctypes.create_string_buffer(32)
+        hp.hp_output_hash(o[66:99], beta)
+        assert beta.raw.hex() == v["beta"]
+        assert hp.hp_verify(o[:33], o[33:66], o[66:99], o[99:131], o[131:163], b"", 0) == 0
+        # given H instead of the message
+        out2 = ctypes.create_string_buffer(261)
+        assert hp.hp_prove(sk, None, 0, o[33:66], b"", 0, out2) == 1 and out2.raw == o
+
+
+def test_host_build_prove_and_verify_equal_the_oracle(hp):
+    rnd = random.Random(7)
+    for i in range(6):
+        sk = sw.secret_from_seed(b"seed%d" % i)
+        msg, ad = b"message %d" % i * (i + 1), b"ad" * i
+        H, _ = sw.hash_to_curve_tai(msg)
+        gamma, c, s = sw.ietf_prove(sk, H, ad)
+        out = ctypes.create_string_buffer(261)
+        assert hp.hp_prove(be(sk), msg, len(msg), None, ad, len(ad), out) == 1
+        o = out.raw
+        assert o[:33] == sw.point_encode(sw.mul(sk, G)) and o[33:66] == sw.point_encode(H) and o[66:99] == sw.point_encode(gamma)
+        assert o[99:131] == be(c) and o[131:163] == be(s)
+        pk, h, g = o[:33], o[33:66], o[66:99]
+        assert hp.hp_verify(pk, h, g, be(c), be(s), ad, len(ad)) == 0
+        assert hp.hp_verify(pk, h, g, be(c), be(s), ad + b"x", len(ad) + 1) == 1
+        assert hp.hp_verify(pk, h, g, be(c ^ 1), be(s), ad, len(ad)) == 1
+        assert hp.hp_verify(pk, h, g, be(c), be((s + 1) % N), ad, len(ad)) == 1
+        assert hp.hp_verify(pk, h, g, be(c), be(s + N) if s + N < (1 << 256) else be(s), ad, len(ad)) == 0     # s mod n, as upstream
+        assert hp.hp_verify(pk, h, g, be(c + (1 << 128)), be(s), ad, len(ad)) == 1                           # c is 16 bytes
+        other = sw.point_encode(sw.mul(rnd.randrange(1, N), G))
+        assert hp.hp_verify(other, h, g, be(c), be(s), ad, len(ad)) == 1
+        assert hp.hp_verify(pk, other, g, be(c), be(s), ad, len(ad)) == 1
+        assert hp.hp_verify(pk, h, other, be(c), be(s), ad, len(ad)) == 1
+        bad = b"\x02" + be(next(x for x in range(2, 50) if not _on_curve_x(x)))
+        assert hp.hp_verify(bad, h, g, be(c), be(s), ad, len(ad)) == 2
+        assert hp.hp_verify(pk, h, b"\x04" + g[1:], be(c), be(s), ad, len(ad)) == 2
+        # crafted corner of the group law: s G = c Y makes U the point at infinity; the verdict is still the oracle's
+        assert hp.hp_verify(pk, h, g, be(1), be(sk), ad, len(ad)) == (0 if sw.ietf_verify(sw.mul(sk, G), H, gamma, ad, 1, sk) else 1)
+        assert hp.hp_verify(pk, pk, pk, be(c), be(s), ad, len(ad)) == (0 if sw.ietf_verify(sw.mul(sk, G), sw.mul(sk, G), sw.mul(sk, G), ad, c, s) else 1)
+
+
+def _on_curve_x(x):
+    y2 = (x ** 3 - 3 * x + sw.B) % P
+    return pow(y2, (P - 1) // 2, P) in (0, 1)

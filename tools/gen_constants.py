@@ -4,6 +4,7 @@
     constants.gen.h          field 0: BLS12-381 Fr      (Bandersnatch, JubJub; + the BLS12-381 Fp tower constants)
     constants_f25519.gen.h   field 1: 2^255 - 19        (Ed25519)
     constants_fbn254.gen.h   field 2: BN254 Fr          (Baby-JubJub)
+    constants_fp256.gen.h    field 3: NIST P-256 Fp     (secp256r1, short Weierstrass: sw.cuh)
 
 One header per BASE FIELD: the kernels are compiled once per field (-DVRF_FIELD=n, fe.cuh) and every header defines
 the same names in `namespace vrfk`.  Everything is derived with Python big ints from the curve parameters (SURVEY.md
@@ -26,6 +27,7 @@ U_SLACK = 1 << 13                   # "L = 1" means every limb < 2^29 + 2^13
 Q_BLS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 Q_25519 = (1 << 255) - 19
 Q_BN254 = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+Q_P256 = (1 << 256) - (1 << 224) + (1 << 192) + (1 << 96) - 1
 
 KIND_MONT_Q1, KIND_MONT, KIND_PM25519 = 0, 1, 2
 
@@ -146,7 +148,7 @@ class Field:
         g = pow(z, t, q)                                # generator of the 2^s subgroup
         h = self.inv(g)
         cz = pow(z, (t + 1) // 2, q)                    # sqrt(Z * w) correction: Z^((t+1)/2)
-        if s == 2:
+        if s <= 2:      # s = 1 (q = 3 mod 4): sqrt(w) = w^((q+1)/4), no torsion to walk
             return dict(t=t, g=g, h=h, P=[], lut=[0, 0], lut_bits=1, lut_mult=1, cz=cz, levels=[])
         assert s in (28, 32)
         levels = [0, 8, 16, 24] + ([4, 12] if s == 28 else [])
@@ -383,6 +385,7 @@ class Curve:
 F0 = Field(Q_BLS, KIND_MONT_Q1, 5)
 F1 = Field(Q_25519, KIND_PM25519, 2)
 F2 = Field(Q_BN254, KIND_MONT, 5)
+F3 = Field(Q_P256, KIND_MONT, Q_P256 - 1)         # q = 3 (mod 4): -1 is the non-residue
 
 BS = dict(
     a=Q_BLS - 5,
@@ -566,6 +569,7 @@ def emit_field_traits(ap, F, st):
     mulv = 0 if F.kind == KIND_PM25519 else -((-q * 100000) // F.R)      # ceil(q / R * 1e5)
     ap("constexpr int MULV_NUM = %d;           // ceil(1e5 q / R): value bound of a product, mul_v()" % mulv)
     ap("constexpr int V256 = %d;               // 2^256 < V256 q" % ((1 << 256) // q + 1))
+    ap("constexpr int VMAX = %d;               // largest value bound V: V q < 2^261 (the top limb stays below 2^29)" % min(64, (1 << RBITS) // q))
     chi_r = 1 if F.R == 1 else (1 if pow(2, (q - 1) // 2, q) == 1 else -1)     # R = 2 (2^130)^2
     ap("constexpr int CHI_R = %d;              // quadratic character of R: symbol(x R) = CHI_R symbol(x)" % chi_r)
     ap("constexpr int SQRT_S = %d;             // 2-adicity of q - 1" % F.s)
@@ -754,7 +758,73 @@ def gen_field2():
     print("  field 2: lut_bits", st["lut_bits"], "mult", st["lut_mult"])
 
 
+# NIST P-256 / secp256r1 (SP 800-186 3.2.1.3, SEC 2 2.4.2): y^2 = x^3 - 3x + b over Fp, prime order n, cofactor 1.
+P256 = dict(
+    b=0x5AC635D8AA3A93E7B3EBBD55769886BC651D06B0CC53B0F63BCE3C3E27D2604B,
+    n=0xFFFFFFFF00000000FFFFFFFFFFFFFFFFBCE6FAADA7179E84F3B9CAC2FC632551,
+    gx=0x6B17D1F2E12C4247F8BCE6E563A440F277037D812DEB33A0F4A13945D898C296,
+    gy=0x4FE342E2FE1A7F9B8EE7EB4A7C0F9E162BCE33576B315ECECBB6406837BF51F5,
+)
+
+
+def sw_add(F, P1, P2):
+    """Affine short-Weierstrass addition with a = -3 (None = the point at infinity); generator tooling."""
+    q = F.q
+    if P1 is None:
+        return P2
+    if P2 is None:
+        return P1
+    if P1[0] == P2[0]:
+        if (P1[1] + P2[1]) % q == 0:
+            return None
+        lam = (3 * P1[0] * P1[0] - 3) * F.inv(2 * P1[1]) % q
+    else:
+        lam = (P2[1] - P1[1]) * F.inv(P2[0] - P1[0]) % q
+    x = (lam * lam - P1[0] - P2[0]) % q
+    return (x, (lam * (P1[0] - x) - P1[1]) % q)
+
+
+def sw_mul(F, k, P):
+    acc = None
+    for bit in bin(k)[2:]:
+        acc = sw_add(F, acc, acc)
+        if bit == "1":
+            acc = sw_add(F, acc, P)
+    return acc
+
+
+def gen_field3():
+    F = F3
+    q = F.q
+    st = F.sqrt_tables()
+    out = []
+    ap = out.append
+    emit_field_core(ap, F, st, [
+        "// Radix-2^29, 9-limb field constants for Fp = NIST P-256 (secp256r1), Montgomery radix R = 2^261.",
+        "// *_M = Montgomery image (x*R mod p), 29-bit limbs.  p = -1 (mod 2^96): the Montgomery digit is the column itself."])
+    G = (P256["gx"], P256["gy"])
+    n = P256["n"]
+    assert (G[1] * G[1] - (G[0] ** 3 - 3 * G[0] + P256["b"])) % q == 0, "generator not on the curve"
+    assert sw_mul(F, n, G) is None and sw_mul(F, n - 1, G) == (G[0], q - G[1]), "generator order"
+    assert abs(n - (q + 1)) <= 2 * math.isqrt(q) + 1 and all(n % s for s in (2, 3, 5, 7, 11, 13))   # cofactor 1 by Hasse
+    ap("// ---- secp256r1: y^2 = x^3 - 3x + b, prime order n, cofactor 1 ----")
+    ap(carr("P256_B_M", F.lm(P256["b"])))
+    ap(carr("P256_B3_M", F.lm(3 * P256["b"])))
+    ap(carr("P256_THREE_M", F.lm(3)))
+    ap(carr("P256_GX_M", F.lm(G[0])))
+    ap(carr("P256_GY_M", F.lm(G[1])))
+    ap(carr("P256_R32", words32(n)))
+    ap("constexpr uint32_t P256_R_NINV32 = 0x%08xu;" % ((-pow(n, -1, 1 << 32)) % (1 << 32)))
+    ap(carr("P256_R_R1", words32((1 << 256) % n)))
+    ap(carr("P256_R_R2", words32((1 << 512) % n)))
+    ap(carr("P256_RH32", words32(n >> 1)))
+    emit_field_traits(ap, F, st)
+    emit_tables(ap, F, st, [("P256_G_XY", G)])
+    write("constants_fp256.gen.h", out)
+
+
 def main():
+    gen_field3()
     gen_field0()
     gen_field1()
     gen_field2()
