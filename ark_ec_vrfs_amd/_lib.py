@@ -19,7 +19,7 @@ SYMBOLS = [
     "vrfhip_suite_desc_default", "vrfhip_ctx_create_desc", "vrfhip_ctx_get_desc",
     "vrfhip_ctx_reserve", "vrfhip_ctx_workspace_bytes", "vrfhip_host_alloc", "vrfhip_host_free",
     "vrfhip_ctx_profile", "vrfhip_ctx_profile_read",
-    "vrfhip_ctx_set_flags", "vrfhip_ctx_get_flags",
+    "vrfhip_ctx_set_flags", "vrfhip_ctx_get_flags", "vrfhip_ctx_point_bytes", "vrfhip_ctx_hash_bytes",
     "vrfhip_ietf_verify_batch", "vrfhip_ietf_verify_batch_dev",
     "vrfhip_ietf_verify_batch_affine", "vrfhip_ietf_verify_batch_affine_dev",
     "vrfhip_keyset_create", "vrfhip_keyset_destroy", "vrfhip_keyset_bytes",
@@ -58,7 +58,7 @@ class SuiteDescStruct(ctypes.Structure):
 _lib = None
 
 
-ABI_VERSION = 130      # vrfhip_abi_version() of the library this binding was written against
+ABI_VERSION = 140      # vrfhip_abi_version() of the library this binding was written against
 
 
 def load() -> ctypes.CDLL:
@@ -102,6 +102,10 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_ctx_set_flags.argtypes = [c_void_p, c_uint32]
     lib.vrfhip_ctx_get_flags.argtypes = [c_void_p]
     lib.vrfhip_ctx_get_flags.restype = c_uint32
+    lib.vrfhip_ctx_point_bytes.argtypes = [c_void_p]
+    lib.vrfhip_ctx_point_bytes.restype = c_size_t
+    lib.vrfhip_ctx_hash_bytes.argtypes = [c_void_p]
+    lib.vrfhip_ctx_hash_bytes.restype = c_size_t
     P = c_void_p  # raw addresses (host buffers or device pointers)
     lib.vrfhip_ietf_verify_batch.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P]
     lib.vrfhip_ietf_verify_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P, c_void_p]
@@ -166,7 +170,8 @@ def load() -> ctypes.CDLL:
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("vrfhip_last_error", "vrfhip_ctx_destroy", "vrfhip_ctx_workspace_bytes", "vrfhip_host_free",
-                        "vrfhip_keyset_destroy", "vrfhip_keyset_bytes", "vrfhip_ctx_get_flags"):
+                        "vrfhip_keyset_destroy", "vrfhip_keyset_bytes", "vrfhip_ctx_get_flags", "vrfhip_ctx_point_bytes",
+                        "vrfhip_ctx_hash_bytes"):
             fn.restype = c_int32
     _lib = lib
     return lib

@@ -73,7 +73,15 @@ class BabyJubJubSha512Tai(Suite):
     SUITE_ENUM = 4
 
 
-CURVE_BANDERSNATCH, CURVE_JUBJUB, CURVE_ED25519, CURVE_BABY_JUBJUB = 1, 2, 3, 4
+class Secp256r1Sha256Tai(Suite):
+    """`suites::secp256r1` = RFC 9381 ECVRF-P256-SHA256-TAI (suite_string 0x01).  Own wire format: points are 33-byte SEC1
+    compressed strings, scalars 32-byte BIG-endian integers, `Output::hash` is 32 bytes (SHA-256); IETF scheme only."""
+    SUITE_ID = b"\x01"
+    CHALLENGE_LEN = 16
+    SUITE_ENUM = 5
+
+
+CURVE_BANDERSNATCH, CURVE_JUBJUB, CURVE_ED25519, CURVE_BABY_JUBJUB, CURVE_SECP256R1 = 1, 2, 3, 4, 5
 # vrfhip_suite_desc.flags (VRFHIP_SUITE_FLAG_*): what separates RFC 9381's edwards suites from upstream's built-in ones
 SUITE_FLAG_SIGN_PARITY, SUITE_FLAG_CHALLENGE_LE, SUITE_FLAG_HASH_COFACTOR = 1, 2, 4
 
@@ -207,9 +215,17 @@ class Context:
     PROVE_POINTS_AFFINE = 16        # VRFHIP_FLAG_PROVE_POINTS_AFFINE: the provers write points as x || y (64 B)
     COORDS_MONT256 = 32             # VRFHIP_FLAG_COORDS_MONT256: x || y pairs are arkworks' in-memory Montgomery limbs
 
+    def point_bytes(self) -> int:
+        """Bytes of one compressed point on the wire: 32 (ArkworksCodec), 33 for secp256r1 (Sec1Codec)."""
+        return int(self._lib.vrfhip_ctx_point_bytes(self._h))
+
+    def hash_bytes(self) -> int:
+        """Bytes of `Output::hash`: 64 (SHA-512), 32 for secp256r1 (SHA-256)."""
+        return int(self._lib.vrfhip_ctx_hash_bytes(self._h))
+
     def prove_point_bytes(self) -> int:
-        """Bytes per point in the provers' outputs (output, pk / pk_com, r, ok): 32 compressed, 64 with PROVE_POINTS_AFFINE."""
-        return 64 if self.get_flags() & self.PROVE_POINTS_AFFINE else 32
+        """Bytes per point in the provers' outputs (output, pk / pk_com, r, ok): the wire width, 64 with PROVE_POINTS_AFFINE."""
+        return 64 if self.get_flags() & self.PROVE_POINTS_AFFINE else self.point_bytes()
 
     def set_flags(self, flags: int) -> None:
         """Point classes whose prime-order-subgroup membership the caller vouches for (their test is skipped)."""
@@ -251,7 +267,9 @@ class Context:
         return blob, off, 0
 
     def ietf_verify_batch(self, pk, inp, out, c, s, ad=b"") -> np.ndarray:
-        pk, inp, out, c, s = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (pk, inp, out, c, s))
+        pw = self.point_bytes()
+        pk, inp, out = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, pw) for x in (pk, inp, out))
+        c, s = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (c, s))
         n = pk.shape[0]
         if not all(x.shape[0] == n for x in (inp, out, c, s)):
             raise ValueError("ragged batch")
@@ -326,8 +344,9 @@ class Context:
         n = sk.shape[0]
         msg_blob = msg_off = inp = None
         msg_len = 0
+        ipw = self.point_bytes()
         if inputs is not None:
-            inp = np.ascontiguousarray(inputs, dtype=np.uint8).reshape(-1, 32)
+            inp = np.ascontiguousarray(inputs, dtype=np.uint8).reshape(-1, ipw)
             if inp.shape[0] != n:
                 raise ValueError("ragged batch")
         elif isinstance(msgs, np.ndarray):
@@ -339,7 +358,8 @@ class Context:
                 raise ValueError("msgs must have n entries")
             msg_blob, msg_off = _pack_var([bytes(x) for x in msgs])
         pw = self.prove_point_bytes()
-        res = {k: np.empty((n, pw if k in ("output", "pk") else 32), dtype=np.uint8) for k in ("output", "c", "s", "pk", "input")}
+        res = {k: np.empty((n, pw if k in ("output", "pk") else ipw if k == "input" else 32), dtype=np.uint8)
+               for k in ("output", "c", "s", "pk", "input")}
         status = np.empty(n, dtype=np.uint8)
         blob, off, ad_len = self._ad_args(ad, n)
         _lib.check(self._lib.vrfhip_ietf_prove_batch(
@@ -536,14 +556,14 @@ class Context:
         else:
             n, msg_len = len(msgs), 0
             blob, off = _pack_var([bytes(x) for x in msgs])
-        pts = np.empty((n, 32), dtype=np.uint8)
+        pts = np.empty((n, self.point_bytes()), dtype=np.uint8)
         _lib.check(self._lib.vrfhip_hash_to_curve_batch(self._h, n, _ptr(blob), _ptr(off), msg_len, _ptr(pts)),
                    "vrfhip_hash_to_curve_batch")
         return pts
 
     def output_hash_batch(self, outputs) -> np.ndarray:
-        o = np.ascontiguousarray(outputs, dtype=np.uint8).reshape(-1, 32)
-        h = np.empty((o.shape[0], 64), dtype=np.uint8)
+        o = np.ascontiguousarray(outputs, dtype=np.uint8).reshape(-1, self.point_bytes())
+        h = np.empty((o.shape[0], self.hash_bytes()), dtype=np.uint8)
         _lib.check(self._lib.vrfhip_output_hash_batch(self._h, o.shape[0], _ptr(o), _ptr(h)),
                    "vrfhip_output_hash_batch")
         return h
@@ -552,13 +572,13 @@ class Context:
         sd = np.ascontiguousarray(seeds, dtype=np.uint8)
         n, seed_len = sd.shape
         sk = np.empty((n, 32), dtype=np.uint8)
-        pk = np.empty((n, 32), dtype=np.uint8) if with_public else None
+        pk = np.empty((n, self.point_bytes()), dtype=np.uint8) if with_public else None
         _lib.check(self._lib.vrfhip_secret_from_seed_batch(self._h, n, _ptr(sd), seed_len, _ptr(sk), _ptr(pk)),
                    "vrfhip_secret_from_seed_batch")
         return sk, pk
 
     def point_validate_batch(self, points, want_xy: bool = False):
-        p = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, 32)
+        p = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, self.point_bytes())
         n = p.shape[0]
         st = np.empty(n, dtype=np.uint8)
         xy = np.empty((n, 64), dtype=np.uint8) if want_xy else None
@@ -650,7 +670,9 @@ def _ctx_array(ctxs):
 
 def ietf_verify_batch_multi(ctxs, pk, inp, out, c, s, ad=b"") -> np.ndarray:
     """vrfhip_ietf_verify_batch_multi: one call, one context per GPU, contiguous slices, one host thread each."""
-    pk, inp, out, c, s = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (pk, inp, out, c, s))
+    pw = ctxs[0].point_bytes()
+    pk, inp, out = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, pw) for x in (pk, inp, out))
+    c, s = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (c, s))
     n = pk.shape[0]
     blob, off, ad_len = Context._ad_args(ad, n)
     st = np.empty(n, np.uint8)
@@ -666,8 +688,8 @@ def ietf_prove_batch_multi(ctxs, sk, msgs, ad=b""):
     n = sk.shape[0]
     mblob, moff = _pack_var([bytes(m) for m in msgs])
     blob, off, ad_len = Context._ad_args(ad, n)
-    pw = ctxs[0].prove_point_bytes()
-    res = {k: np.empty((n, pw if k in ("output", "pk") else 32), np.uint8) for k in ("output", "c", "s", "pk", "input")}
+    pw, ipw = ctxs[0].prove_point_bytes(), ctxs[0].point_bytes()
+    res = {k: np.empty((n, pw if k in ("output", "pk") else ipw if k == "input" else 32), np.uint8) for k in ("output", "c", "s", "pk", "input")}
     res["status"] = np.empty(n, np.uint8)
     arr, k = _ctx_array(ctxs)
     _lib.check(_lib.load().vrfhip_ietf_prove_batch_multi(

@@ -17,6 +17,7 @@
 #include "digest.cuh"
 #include "msm.cuh"
 #include "msm_g1.h"
+#include "p256.h"
 
 namespace vrf {
 // k_pairing_row.hip: the selftest operands through the row-distributed tower (bls12_row.cuh); ORs 64 / 128 into status[i]
@@ -95,7 +96,15 @@ struct vrfhip_ctx {
   int cus = 256;
   uint32_t flags = 0;                      // VRFHIP_FLAG_PREVALIDATED_* (vrfhip_ctx_set_flags)
   uint32_t check_mask() const { return ~flags & (uint32_t)VRFHIP_FLAG_PREVALIDATED_ALL; }
-  size_t prove_point_bytes() const { return (flags & VRFHIP_FLAG_PROVE_POINTS_AFFINE) ? 64 : 32; }
+  // secp256r1 (`suites::secp256r1`): short-Weierstrass law, Sec1 wire format (33-byte points, big-endian scalars), SHA-256.
+  // Its kernels (k_p256.hip) have their own tables and workspace; the entry points below branch on `sw` where the
+  // Edwards suites go through FIELD_CALL, and the byte widths of the arrays come from the two functions that follow.
+  bool sw = false;
+  uint32_t* d_p256_comb = nullptr;
+  p256::Ws p256_ws{};
+  size_t pt_bytes() const { return sw ? 33 : 32; }        // one compressed point on the wire
+  size_t hash_bytes() const { return sw ? 32 : 64; }      // `Output::hash`: the suite hasher's output
+  size_t prove_point_bytes() const { return sw ? 33 : (flags & VRFHIP_FLAG_PROVE_POINTS_AFFINE) ? 64 : 32; }
   bool coords_mont256() const { return (flags & VRFHIP_FLAG_COORDS_MONT256) != 0; }
   // optional per-stage timing (hipEvents on the launch stream), see vrfhip_ctx_profile
   bool prof = false;
@@ -140,6 +149,14 @@ int32_t alloc_workspace(vrfhip_ctx* ctx, size_t cap) {
     ctx->d_ws = nullptr;
     ctx->ws_cap = 0;
     ctx->ws_bytes = 0;
+  }
+  if (ctx->sw) {
+    const size_t total = p256::ws_bytes(cap);
+    HIP_TRY(hipMalloc(&ctx->d_ws, total));
+    ctx->p256_ws = p256::ws_carve(ctx->d_ws, cap);
+    ctx->ws_cap = cap;
+    ctx->ws_bytes = total;
+    return VRFHIP_SUCCESS;
   }
   size_t tabs_b = cap * WS_TABS * WIN_TABLE_WORDS * sizeof(uint32_t);
   size_t pts_b = cap * PROVE_PTS_WORDS * sizeof(uint32_t);
@@ -288,7 +305,7 @@ size_t blob_bytes(size_t n, const uint32_t* off, uint32_t len, bool shared) {
 
 extern "C" {
 
-int32_t vrfhip_abi_version(void) { return 130; }
+int32_t vrfhip_abi_version(void) { return 140; }
 
 const char* vrfhip_last_error(void) { return g_last_error.c_str(); }
 
@@ -321,6 +338,14 @@ int32_t vrfhip_suite_desc_default(vrfhip_suite suite, vrfhip_suite_desc* out) {
     put(out->suite_id, out->suite_id_len, "BabyJubJub_SHA-512_TAI");
     have = vrf::f_bn254fr::field_default_points(SUITE_BJ, out->generator, out->blinding_base);
   }
+  else if (suite == VRFHIP_SUITE_SECP256R1_SHA256_TAI) {
+    out->curve = VRFHIP_CURVE_SECP256R1;
+    out->challenge_len = 16;                         // RFC 9381 cLen of ECVRF-P256-SHA256-TAI
+    out->suite_id[0] = 0x01;                         // RFC 9381 suite_string
+    out->suite_id_len = 1;
+    p256::default_generator(out->generator);         // no Pedersen blinding base: zeros
+    have = true;
+  }
   if (!have) return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported suite");
   return VRFHIP_SUCCESS;
 }
@@ -345,8 +370,9 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
   *out = nullptr;
   if (!desc) return fail(VRFHIP_ERR_BAD_ARG, "desc is NULL");
   if (desc->struct_size != sizeof(vrfhip_suite_desc)) return fail(VRFHIP_ERR_BAD_ARG, "desc.struct_size mismatch");
-  if (desc->curve < VRFHIP_CURVE_BANDERSNATCH || desc->curve > VRFHIP_CURVE_BABY_JUBJUB)
+  if (desc->curve < VRFHIP_CURVE_BANDERSNATCH || desc->curve > VRFHIP_CURVE_SECP256R1)
     return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported curve");
+  if (desc->curve == VRFHIP_CURVE_SECP256R1 && desc->flags) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1 takes no suite flags");
   if (desc->challenge_len == 0 || desc->challenge_len > 32) return fail(VRFHIP_ERR_UNSUPPORTED, "challenge_len must be 1..32");
   if (desc->flags & ~(uint32_t)VRFHIP_SUITE_FLAG_ALL) return fail(VRFHIP_ERR_UNSUPPORTED, "unknown suite flag bits");
   if (desc->suite_id_len == 0 || desc->suite_id_len > sizeof desc->suite_id)
@@ -385,6 +411,28 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
       ctx->cus = cus;
+  }
+  if (desc->curve == VRFHIP_CURVE_SECP256R1) {
+    // the short-Weierstrass suite: its one table is the generator's comb; its strings travel in ctx->T.sq.str like the others'
+    ctx->sw = true;
+    SuiteStr hs{};
+    hs.suite_id_len = desc->suite_id_len;
+    hs.challenge_len = desc->challenge_len;
+    for (size_t i = 0; i < desc->suite_id_len; ++i) hs.suite_id_w[i >> 3] |= (uint64_t)desc->suite_id[i] << (56 - 8 * (i & 7));
+    ctx->T.sq.str = hs;
+    uint8_t* d_gen = nullptr;
+    HIP_TRY_C(hipMalloc(&ctx->d_p256_comb, p256::comb_bytes()));
+    HIP_TRY_C(hipMalloc(&d_gen, 256));
+    uint8_t gen_ok = 0;
+    hipError_t e0 = hipMemcpy(d_gen, desc->generator, 64, hipMemcpyHostToDevice);
+    p256::launch_init_comb(ctx->d_p256_comb, d_gen, d_gen + 128, ctx->stream);
+    hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
+    hipError_t e3 = hipMemcpy(&gen_ok, d_gen + 128, 1, hipMemcpyDeviceToHost);
+    (void)hipFree(d_gen);
+    HIP_TRY_C(e0); HIP_TRY_C(e1); HIP_TRY_C(e2); HIP_TRY_C(e3);
+    if (!gen_ok) return cleanup(fail(VRFHIP_ERR_BAD_ARG, "desc.generator is not a point of the curve"));
+    *out = ctx;
+    return VRFHIP_SUCCESS;
   }
   size_t sqrt_p_bytes = 0, lut_bytes = 0;
   const uint32_t* h_sqrt_p = nullptr;
@@ -480,6 +528,7 @@ void vrfhip_ctx_destroy(vrfhip_ctx* ctx) {
     if (ctx->d_b_comb) (void)hipFree(ctx->d_b_comb);
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->d_pair_prep) (void)hipFree(ctx->d_pair_prep);
+    if (ctx->d_p256_comb) (void)hipFree(ctx->d_p256_comb);
     if (ctx->h_pin) {
       std::memset(ctx->h_pin, 0, 2 * ctx->pin_slot_bytes);     // may have staged caller data
       (void)hipHostFree(ctx->h_pin);
@@ -518,11 +567,15 @@ int32_t vrfhip_ctx_set_flags(vrfhip_ctx* ctx, uint32_t flags) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (flags & ~(uint32_t)(VRFHIP_FLAG_PREVALIDATED_ALL | VRFHIP_FLAG_PROVE_POINTS_AFFINE | VRFHIP_FLAG_COORDS_MONT256))
     return fail(VRFHIP_ERR_BAD_ARG, "unknown flag bits");
+  if (ctx->sw && (flags & (VRFHIP_FLAG_PROVE_POINTS_AFFINE | VRFHIP_FLAG_COORDS_MONT256)))
+    return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: points travel as 33-byte Sec1 strings only");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   ctx->flags = flags;
   return VRFHIP_SUCCESS;
 }
 uint32_t vrfhip_ctx_get_flags(const vrfhip_ctx* ctx) { return ctx ? ctx->flags : 0; }
+size_t vrfhip_ctx_point_bytes(const vrfhip_ctx* ctx) { return ctx ? ctx->pt_bytes() : 0; }
+size_t vrfhip_ctx_hash_bytes(const vrfhip_ctx* ctx) { return ctx ? ctx->hash_bytes() : 0; }
 
 int32_t vrfhip_debug_proofs_per_lane(size_t n) { return lanes_k(n, VERIFY_K_POLICY); }
 
@@ -562,6 +615,7 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
                         const vrfhip_keyset* ks = nullptr, const uint32_t* d_key_index = nullptr) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ks && (ks->ctx != ctx || !d_key_index)) return fail(VRFHIP_ERR_BAD_ARG, "key set of another context, or NULL key index");
+  if (ctx->sw && (affine || ks)) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: compressed (Sec1) points only, no key sets");
   if (n == 0) return VRFHIP_SUCCESS;
   if (ks) d_pk = ks->d_enc;
   if (!d_pk || !d_input || !d_output || !d_c || !d_s || !d_status)
@@ -572,6 +626,23 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
   int32_t rc = ensure_workspace(ctx, n);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (ctx->sw) {
+    for (size_t base = 0; base < n; base += ctx->ws_cap) {
+      const size_t m = std::min(ctx->ws_cap, n - base);
+      p256::VerifyArgs a;
+      a.n = m;
+      a.pk = d_pk + base * 33; a.h = d_input + base * 33; a.gamma = d_output + base * 33;
+      a.c = d_c + base * 32; a.s = d_s + base * 32;
+      a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
+      a.status = d_status + base;
+      a.ws = ctx->p256_ws;
+      a.comb = ctx->d_p256_comb;
+      a.str = ctx->T.sq.str;
+      p256::launch_verify(a, st, prof_events(ctx));
+    }
+    HIP_TRY(hipGetLastError());
+    return VRFHIP_SUCCESS;
+  }
   const size_t pw = affine ? 64 : 32;
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     size_t m = std::min(ctx->ws_cap, n - base);
@@ -605,7 +676,8 @@ int32_t verify_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* 
   if (!pk || !input || !output || !c || !s || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
   size_t adb = blob_bytes(n, ad_off, ad_len, true);
-  const size_t pw = affine ? 64 : 32;
+  if (ctx->sw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: compressed (Sec1) points only");
+  const size_t pw = affine ? 64 : ctx->pt_bytes();
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   size_t need = 3 * Stage::pad(n * pw) + 2 * Stage::pad(n * 32) + Stage::pad(adb + 1) +
@@ -694,6 +766,7 @@ int32_t vrfhip_keyset_create(vrfhip_ctx* ctx, size_t n_keys, const uint8_t* pks,
   if (!out) return fail(VRFHIP_ERR_BAD_ARG, "out is NULL");
   *out = nullptr;
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (n_keys == 0 || !pks) return fail(VRFHIP_ERR_BAD_ARG, "no keys");
   if (n_keys > (size_t(1) << 24)) return fail(VRFHIP_ERR_BAD_ARG, "too many keys");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -819,12 +892,35 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
   if (pedersen ? (!o.pk || !o.r || !o.ok || !o.sb) : !o.c) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if (!d_input && !d_msg && (msg_len || d_msg_off)) return fail(VRFHIP_ERR_BAD_ARG, "msg is NULL");
   if ((ad_len || d_ad_off) && !d_ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  if (ctx->sw && pedersen) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the Pedersen scheme is not built for this suite");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   int32_t rc = ensure_workspace(ctx, n);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   auto at = [](uint8_t* p, size_t base, size_t w) -> uint8_t* { return p ? p + base * w : nullptr; };
+  if (ctx->sw) {
+    for (size_t base = 0; base < n; base += ctx->ws_cap) {
+      const size_t m = std::min(ctx->ws_cap, n - base);
+      p256::ProveArgs a;
+      a.n = m;
+      a.sk = d_sk + base * 32;
+      if (d_msg_off) a.msg = make_view(d_msg, d_msg_off + base, 0, false);
+      else a.msg = make_view(d_msg ? d_msg + base * (size_t)msg_len : nullptr, nullptr, msg_len, false);
+      a.h_given = d_input ? d_input + base * 33 : nullptr;
+      a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
+      a.gamma = at(o.output, base, 33); a.c = at(o.c, base, 32); a.s = at(o.s, base, 32);
+      a.pk_out = at(o.pk, base, 33); a.h_out = at(o.input, base, 33); a.status = at(o.status, base, 1);
+      a.ws = ctx->p256_ws;
+      a.comb = ctx->d_p256_comb;
+      a.str = ctx->T.sq.str;
+      p256::launch_prove(a, st, prof_events(ctx));
+      // sk and the nonce k of these items lay in the scalar region: nothing secret outlives the call in device memory
+      HIP_TRY(hipMemsetAsync(ctx->p256_ws.sc, 0, ctx->p256_ws.cap * p256::WS_SC_WORDS * sizeof(uint32_t), st));
+    }
+    HIP_TRY(hipGetLastError());
+    return VRFHIP_SUCCESS;
+  }
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     size_t m = std::min(ctx->ws_cap, n - base);
     ProveArgs a;
@@ -877,17 +973,17 @@ int32_t prove_host_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t*
   size_t msgb = input ? 0 : blob_bytes(n, msg_off, msg_len, false);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  const size_t ptw = ctx->prove_point_bytes();
-  size_t need = 7 * Stage::pad(n * 32) + 4 * Stage::pad(n * ptw) + Stage::pad(msgb + 1) + Stage::pad(adb + 1) +
+  const size_t ptw = ctx->prove_point_bytes(), ipw = ctx->pt_bytes();     // outputs (maybe x || y) and input points
+  size_t need = 5 * Stage::pad(n * 32) + 2 * Stage::pad(n * ipw) + 4 * Stage::pad(n * ptw) + Stage::pad(msgb + 1) + Stage::pad(adb + 1) +
                 2 * Stage::pad((n + 1) * 4) + Stage::pad(n);
   int32_t rc = ensure_stage(ctx, need);
   if (rc) return rc;
   Stage sg(ctx->d_stage);
   uint8_t* d_sk = sg.take(n * 32);
-  uint8_t* d_in = sg.take(n * 32);
+  uint8_t* d_in = sg.take(n * ipw);
   ProveOut d{};
   d.output = sg.take(n * ptw); d.c = sg.take(n * 32); d.s = sg.take(n * 32);
-  d.pk = sg.take(n * ptw); d.input = sg.take(n * 32);
+  d.pk = sg.take(n * ptw); d.input = sg.take(n * ipw);
   d.r = sg.take(n * ptw); d.ok = sg.take(n * ptw); d.sb = sg.take(n * 32); d.blinding = sg.take(n * 32);
   uint8_t* d_msg = sg.take(msgb + 1);
   uint8_t* d_ad = sg.take(adb + 1);
@@ -895,7 +991,7 @@ int32_t prove_host_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t*
   uint32_t* d_aoff = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
   d.status = sg.take(n);
   HIP_TRY(hipMemcpyAsync(d_sk, sk, n * 32, hipMemcpyHostToDevice, ctx->stream));
-  if (input) HIP_TRY(hipMemcpyAsync(d_in, input, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (input) HIP_TRY(hipMemcpyAsync(d_in, input, n * ipw, hipMemcpyHostToDevice, ctx->stream));
   if (msgb) HIP_TRY(hipMemcpyAsync(d_msg, msg, msgb, hipMemcpyHostToDevice, ctx->stream));
   if (adb) HIP_TRY(hipMemcpyAsync(d_ad, ad, adb, hipMemcpyHostToDevice, ctx->stream));
   if (msg_off && !input)
@@ -910,7 +1006,7 @@ int32_t prove_host_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t*
   HIP_TRY(back(h.output, d.output, n * ptw));
   HIP_TRY(back(h.s, d.s, n * 32));
   HIP_TRY(back(h.pk, d.pk, n * ptw));
-  HIP_TRY(back(h.input, d.input, n * 32));
+  HIP_TRY(back(h.input, d.input, n * ipw));
   HIP_TRY(back(h.status, d.status, n));
   if (pedersen) {
     HIP_TRY(back(h.r, d.r, n * ptw));
@@ -986,6 +1082,7 @@ int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_
                                          const uint32_t* d_ad_off, uint32_t ad_len,
                                          uint8_t* d_status, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!d_input || !d_output || !d_pk_com || !d_r || !d_ok || !d_s || !d_sb || !d_status)
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
@@ -1019,6 +1116,7 @@ int32_t vrfhip_pedersen_verify_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* i
                                      const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
                                      uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!input || !output || !pk_com || !r || !ok || !s || !sb || !status)
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
@@ -1060,6 +1158,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
                      const uint8_t seed[32], uint8_t* d_status,
                      uint8_t* d_fail_flag, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (!d_fail_flag || !seed) return fail(VRFHIP_ERR_BAD_ARG, "NULL fail flag or seed");
   if (n && (!d_input || !d_output || !d_pk_com || !d_r || !d_ok || !d_s || !d_sb || !d_status))
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
@@ -1120,6 +1219,7 @@ int32_t rlc_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* inp
                       const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
                       const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (!seed) return fail(VRFHIP_ERR_BAD_ARG, "seed is NULL");
   if (batch_ok) *batch_ok = 1;
   if (n == 0) return VRFHIP_SUCCESS;
@@ -1225,6 +1325,7 @@ int32_t vrfhip_pedersen_verify_batch_rlc_affine(vrfhip_ctx* ctx, size_t n, const
 int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, const uint8_t* d_scalars,
                        uint8_t* d_out_point, uint8_t* d_out_xy, uint8_t* d_status, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (!d_out_point || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!d_bases_xy || !d_scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1254,6 +1355,7 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
 int32_t vrfhip_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases_xy, const uint8_t* scalars,
                    uint8_t* out_point, uint8_t* out_xy, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (!out_point || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!bases_xy || !scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1284,6 +1386,7 @@ int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
                                        const uint8_t* d_g2, int32_t g2_shared, uint8_t* d_status,
                                        void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!d_g1 || !d_g2 || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1297,6 +1400,7 @@ int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
 int32_t vrfhip_pairing_check_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2,
                                    int32_t g2_shared, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!g1 || !g2 || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1321,6 +1425,7 @@ int32_t vrfhip_pairing_check_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* g1,
 int32_t vrfhip_g1_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases, const uint8_t* d_scalars, uint8_t* d_out,
                           uint8_t* d_status, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (!d_out || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!d_bases || !d_scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if (n > (size_t(1) << 28)) return fail(VRFHIP_ERR_BAD_ARG, "batch too large");
@@ -1340,6 +1445,7 @@ int32_t vrfhip_g1_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases, con
 int32_t vrfhip_g1_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases, const uint8_t* scalars, uint8_t* out,
                       uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (!out || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!bases || !scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1367,6 +1473,7 @@ int32_t vrfhip_g1_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases, const uin
 int32_t vrfhip_pairing_check_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_g1, const uint8_t* d_g2_shared,
                                            const uint8_t seed[32], uint8_t* d_status, uint8_t* d_verdict, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (!d_verdict || !seed) return fail(VRFHIP_ERR_BAD_ARG, "NULL verdict or seed");
   if (n && (!d_g1 || !d_g2_shared || !d_status)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if (n > (size_t(1) << 28)) return fail(VRFHIP_ERR_BAD_ARG, "batch too large");
@@ -1401,6 +1508,7 @@ int32_t vrfhip_pairing_check_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint
 int32_t vrfhip_pairing_check_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2_shared,
                                        const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (!seed) return fail(VRFHIP_ERR_BAD_ARG, "seed is NULL");
   if (batch_ok) *batch_ok = 1;
   if (n == 0) return VRFHIP_SUCCESS;
@@ -1435,6 +1543,7 @@ int32_t vrfhip_pairing_check_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t*
 // Test-only: quad-distributed Fp12 tower operations against the one-lane operations (k_pairing.hip)
 int32_t vrfhip_test_pairing_quad_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp12_pairs, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!fp12_pairs || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1462,6 +1571,8 @@ int32_t vrfhip_hash_to_curve_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
   if (!d_points || (!d_msg && (msg_len || d_msg_off))) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
+  if (ctx->sw) p256::launch_hash_to_curve(n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T.sq.str, static_cast<hipStream_t>(stream));
+  else
   FIELD_CALL(ctx, launch_hash_to_curve((int)ctx->suite, n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T,
                        static_cast<hipStream_t>(stream)));
   HIP_TRY(hipGetLastError());
@@ -1479,19 +1590,19 @@ int32_t vrfhip_hash_to_curve_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* msg
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   {
-    int32_t rc = ensure_stage(ctx, Stage::pad(msgb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n * 32));
+    int32_t rc = ensure_stage(ctx, Stage::pad(msgb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n * ctx->pt_bytes()));
     if (rc) return rc;
     Stage sg(ctx->d_stage);
     d_msg = sg.take(msgb + 1);
     d_off = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
-    d_pts = sg.take(n * 32);
+    d_pts = sg.take(n * ctx->pt_bytes());
     if (msgb) HIP_TRY(hipMemcpyAsync(d_msg, msg, msgb, hipMemcpyHostToDevice, ctx->stream));
     if (msg_off) HIP_TRY(hipMemcpyAsync(d_off, msg_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
   }
   int32_t rc = vrfhip_hash_to_curve_batch_dev(ctx, n, d_msg, msg_off ? d_off : nullptr, msg_len, d_pts,
                                               ctx->stream);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(points, d_pts, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(points, d_pts, n * ctx->pt_bytes(), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return VRFHIP_SUCCESS;
 }
@@ -1503,6 +1614,8 @@ int32_t vrfhip_output_hash_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d
   if (!d_output || !d_hash) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
+  if (ctx->sw) p256::launch_output_hash(n, d_output, d_hash, ctx->T.sq.str, static_cast<hipStream_t>(stream));
+  else
   FIELD_CALL(ctx, launch_output_hash((int)ctx->suite, n, d_output, d_hash, ctx->T, static_cast<hipStream_t>(stream)));
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
@@ -1516,16 +1629,16 @@ int32_t vrfhip_output_hash_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* outpu
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   {
-    int32_t rc = ensure_stage(ctx, Stage::pad(n * 32) + Stage::pad(n * 64));
+    int32_t rc = ensure_stage(ctx, Stage::pad(n * ctx->pt_bytes()) + Stage::pad(n * 64));
     if (rc) return rc;
     Stage sg(ctx->d_stage);
-    d_in = sg.take(n * 32);
+    d_in = sg.take(n * ctx->pt_bytes());
     d_out = sg.take(n * 64);
-    HIP_TRY(hipMemcpyAsync(d_in, output, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_in, output, n * ctx->pt_bytes(), hipMemcpyHostToDevice, ctx->stream));
   }
   int32_t rc = vrfhip_output_hash_batch_dev(ctx, n, d_in, d_out, ctx->stream);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(hash, d_out, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(hash, d_out, n * ctx->hash_bytes(), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return VRFHIP_SUCCESS;
 }
@@ -1538,6 +1651,8 @@ int32_t vrfhip_secret_from_seed_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8
   if (!d_sk_out || (!d_seeds && seed_len)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
+  if (ctx->sw) p256::launch_secret_from_seed(n, d_seeds, seed_len, d_sk_out, d_pk_out, ctx->d_p256_comb, static_cast<hipStream_t>(stream));
+  else
   FIELD_CALL(ctx, launch_secret_from_seed((int)ctx->suite, n, d_seeds, seed_len, d_sk_out, d_pk_out, ctx->T,
                           static_cast<hipStream_t>(stream)));
   HIP_TRY(hipGetLastError());
@@ -1553,12 +1668,12 @@ int32_t vrfhip_secret_from_seed_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* 
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   {
-    int32_t rc = ensure_stage(ctx, Stage::pad(n * (size_t)seed_len + 1) + 2 * Stage::pad(n * 32));
+    int32_t rc = ensure_stage(ctx, Stage::pad(n * (size_t)seed_len + 1) + Stage::pad(n * 32) + Stage::pad(n * ctx->pt_bytes()));
     if (rc) return rc;
     Stage sg(ctx->d_stage);
     d_seed = sg.take(n * (size_t)seed_len + 1);
     d_sk = sg.take(n * 32);
-    d_pk = sg.take(n * 32);
+    d_pk = sg.take(n * ctx->pt_bytes());
     if (seed_len)
       HIP_TRY(hipMemcpyAsync(d_seed, seeds, n * (size_t)seed_len, hipMemcpyHostToDevice, ctx->stream));
   }
@@ -1566,7 +1681,7 @@ int32_t vrfhip_secret_from_seed_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* 
                                                  ctx->stream);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(sk_out, d_sk, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-  if (pk_out) HIP_TRY(hipMemcpyAsync(pk_out, d_pk, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (pk_out) HIP_TRY(hipMemcpyAsync(pk_out, d_pk, n * ctx->pt_bytes(), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemsetAsync(d_sk, 0, n * 32, ctx->stream));                // staged secrets and their seeds
   if (seed_len) HIP_TRY(hipMemsetAsync(d_seed, 0, n * (size_t)seed_len, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1580,6 +1695,11 @@ int32_t vrfhip_point_validate_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t
   if (!d_points || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
+  if (ctx->sw) {
+    p256::launch_point_validate(n, d_points, d_xy_out, d_status, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return VRFHIP_SUCCESS;
+  }
   int32_t rc = ensure_workspace(ctx, n);
   if (rc) return rc;
   // one window table per item: the tabs region holds WS_TABS per workspace item
@@ -1603,13 +1723,13 @@ int32_t vrfhip_point_validate_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* po
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   {
-    int32_t rc = ensure_stage(ctx, Stage::pad(n * 32) + Stage::pad(n * 64) + Stage::pad(n));
+    int32_t rc = ensure_stage(ctx, Stage::pad(n * ctx->pt_bytes()) + Stage::pad(n * 64) + Stage::pad(n));
     if (rc) return rc;
     Stage sg(ctx->d_stage);
-    d_in = sg.take(n * 32);
+    d_in = sg.take(n * ctx->pt_bytes());
     d_xy = sg.take(n * 64);
     d_st = sg.take(n);
-    HIP_TRY(hipMemcpyAsync(d_in, points, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_in, points, n * ctx->pt_bytes(), hipMemcpyHostToDevice, ctx->stream));
   }
   int32_t rc = vrfhip_point_validate_batch_dev(ctx, n, d_in, xy_out ? d_xy : nullptr, d_st, ctx->stream);
   if (rc) return rc;
@@ -1622,6 +1742,7 @@ int32_t vrfhip_point_validate_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* po
 int32_t vrfhip_fq_mul_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b,
                             uint8_t* r) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!a || !b || !r) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1646,6 +1767,7 @@ int32_t vrfhip_fq_mul_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const u
 int32_t vrfhip_test_point_add(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out,
                               uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!a || !b || !out || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1667,6 +1789,7 @@ int32_t vrfhip_test_point_add(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const
 int32_t vrfhip_test_scalar_mul(vrfhip_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out,
                                uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!scalars || !points || !out || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1697,6 +1820,7 @@ namespace {
 int32_t test_hash_impl(vrfhip_ctx* ctx, size_t n, const uint8_t* msg, const uint32_t* msg_off, uint32_t msg_len,
                        uint8_t* out, int which) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!out || (!msg && (msg_len || msg_off))) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   const size_t ob = which ? 96 : 64;
@@ -1769,6 +1893,14 @@ struct BlobSlice {
 const uint8_t* at32(const uint8_t* p, size_t i) { return p ? p + i * 32 : nullptr; }
 uint8_t* at32(uint8_t* p, size_t i) { return p ? p + i * 32 : nullptr; }
 uint8_t* at_w(uint8_t* p, size_t i, size_t w) { return p ? p + i * w : nullptr; }
+// width of a compressed point on the wire for a set of contexts (32; 33 for secp256r1): all must agree
+size_t point_bytes_of(vrfhip_ctx* const* ctxs, int32_t n_ctx) {
+  if (!ctxs || n_ctx < 1 || !ctxs[0]) return 32;              // run_sharded reports the bad argument
+  const size_t w = ctxs[0]->pt_bytes();
+  for (int32_t g = 1; g < n_ctx; ++g)
+    if (!ctxs[g] || ctxs[g]->pt_bytes() != w) return 0;
+  return w;
+}
 // width of the provers' point outputs for a set of contexts: all must agree on VRFHIP_FLAG_PROVE_POINTS_AFFINE
 size_t prove_point_bytes_of(vrfhip_ctx* const* ctxs, int32_t n_ctx) {
   if (!ctxs || n_ctx < 1 || !ctxs[0]) return 32;              // run_sharded reports the bad argument
@@ -1794,6 +1926,7 @@ int32_t vrfhip_test_batch_digest(vrfhip_ctx* ctx, size_t n, int32_t n_arr, const
                                  const uint32_t* widths, const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
                                  uint64_t index0, uint8_t root[32]) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (!root || !arrays || !widths || n == 0) return fail(VRFHIP_ERR_BAD_ARG, "NULL argument or empty batch");
   if (n_arr < 1 || n_arr > DIGEST_MAX_ARRAYS) return fail(VRFHIP_ERR_BAD_ARG, "1..8 arrays");
   if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
@@ -1835,9 +1968,11 @@ int32_t vrfhip_ietf_verify_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx, s
                                        const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len, uint8_t* status) {
   if (n == 0) return VRFHIP_SUCCESS;
   if (!pk || !input || !output || !c || !s || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  const size_t pw = point_bytes_of(ctxs, n_ctx);
+  if (!pw) return fail(VRFHIP_ERR_BAD_ARG, "contexts disagree on the suite's point encoding");
   return run_sharded(ctxs, n_ctx, n, [&](vrfhip_ctx* ctx, size_t lo, size_t hi) {
     BlobSlice a(ad, ad_off, ad_len, true, lo, hi);
-    return vrfhip_ietf_verify_batch(ctx, hi - lo, at32(pk, lo), at32(input, lo), at32(output, lo), at32(c, lo), at32(s, lo),
+    return vrfhip_ietf_verify_batch(ctx, hi - lo, pk + lo * pw, input + lo * pw, output + lo * pw, at32(c, lo), at32(s, lo),
                                     a.blob, a.off, ad_len, status + lo);
   });
 }
@@ -1848,13 +1983,13 @@ int32_t vrfhip_ietf_prove_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx, si
                                       uint8_t* c, uint8_t* s, uint8_t* pk_out, uint8_t* input_out, uint8_t* status) {
   if (n == 0) return VRFHIP_SUCCESS;
   if (!sk || !output || !c || !s) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
-  const size_t w = prove_point_bytes_of(ctxs, n_ctx);
-  if (!w) return fail(VRFHIP_ERR_BAD_ARG, "contexts disagree on VRFHIP_FLAG_PROVE_POINTS_AFFINE");
+  const size_t w = prove_point_bytes_of(ctxs, n_ctx), pw = point_bytes_of(ctxs, n_ctx);
+  if (!w || !pw) return fail(VRFHIP_ERR_BAD_ARG, "contexts disagree on VRFHIP_FLAG_PROVE_POINTS_AFFINE or on the suite's point encoding");
   return run_sharded(ctxs, n_ctx, n, [&](vrfhip_ctx* ctx, size_t lo, size_t hi) {
     BlobSlice m(msg, input ? nullptr : msg_off, msg_len, false, lo, hi), a(ad, ad_off, ad_len, true, lo, hi);
-    return vrfhip_ietf_prove_batch(ctx, hi - lo, at32(sk, lo), m.blob, m.off, msg_len, at32(input, lo), a.blob, a.off,
+    return vrfhip_ietf_prove_batch(ctx, hi - lo, at32(sk, lo), m.blob, m.off, msg_len, input ? input + lo * pw : nullptr, a.blob, a.off,
                                    ad_len, at_w(output, lo, w), at32(c, lo), at32(s, lo), at_w(pk_out, lo, w),
-                                   at32(input_out, lo), status ? status + lo : nullptr);
+                                   at_w(input_out, lo, pw), status ? status + lo : nullptr);
   });
 }
 

@@ -1,7 +1,7 @@
 // field.h -- which BASE FIELD this translation unit is compiled for.
 //
 // The VRF kernels are compiled once per base field (Makefile: -DVRF_FIELD=n): the suites of `suites`
-// (/root/reference src/lib.rs:14) live over three different fields, and a field's arithmetic -- Montgomery digit rule,
+// (/root/reference src/lib.rs:14) live over four different fields, and a field's arithmetic -- Montgomery digit rule,
 // reduction, square-root tables -- is chosen at compile time so that the inner loop carries no field switch:
 //
 //   VRF_FIELD 0  BLS12-381 Fr   Bandersnatch (a = -5), JubJub (a = -1)        constants.gen.h

@@ -1,0 +1,318 @@
+// k_p256.hip -- kernels of the secp256r1 suite ("P256_SHA256_TAI"; `suites::secp256r1`, /root/reference src/lib.rs:14):
+// IETF prove / verify in three stages each, hash-to-curve, output hash, key derivation, point validation.
+// Compiled once, with -DVRF_FIELD=3 (csrc/field.h): the NIST P-256 prime under the same 9 x 29-bit typed limbs as the
+// Edwards suites' fields, with the short-Weierstrass law of sw.cuh in place of te.cuh.
+//
+// Shape: one item per lane.  The stages are separate kernels because their register needs differ by a factor of three
+// (the ladders hold a projective accumulator, a table entry and the temporaries of the complete addition; the hash
+// stages hold a SHA-256 block); what passes between them lies word-major in the context's workspace (p256.h), so every
+// inter-stage load and store is coalesced.  The ladders' window tables live there too: 216 words per table and item,
+// written once and read 65 (+33) times by the lane that wrote them.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include "p256.h"
+#include "p256_core.cuh"
+
+VRF_NS_BEGIN
+namespace {
+
+constexpr int P256_BLOCK = 128;
+
+__device__ __forceinline__ void ws_store_fe(uint32_t* base, size_t cap, size_t i, int w0, const FeN& a) {
+#pragma unroll
+  for (int k = 0; k < NL; ++k) base[(size_t)(w0 + k) * cap + i] = a.v[k];
+}
+__device__ __forceinline__ FeN ws_load_fe(const uint32_t* base, size_t cap, size_t i, int w0) {
+  FeN a;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) a.v[k] = base[(size_t)(w0 + k) * cap + i];
+  return a;
+}
+__device__ __forceinline__ void ws_store8(uint32_t* base, size_t cap, size_t i, int w0, const uint32_t (&a)[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) base[(size_t)(w0 + k) * cap + i] = a[k];
+}
+__device__ __forceinline__ void ws_load8(uint32_t (&a)[8], const uint32_t* base, size_t cap, size_t i, int w0) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = base[(size_t)(w0 + k) * cap + i];
+}
+__device__ __forceinline__ void ws_store_enc(uint32_t* base, size_t cap, size_t i, int slot, const Sec1W& e) {
+  base[(size_t)(slot * 9) * cap + i] = e.tag;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) base[(size_t)(slot * 9 + 1 + k) * cap + i] = e.xw[k];
+}
+__device__ __forceinline__ Sec1W ws_load_enc(const uint32_t* base, size_t cap, size_t i, int slot) {
+  Sec1W e;
+  e.tag = base[(size_t)(slot * 9) * cap + i];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e.xw[k] = base[(size_t)(slot * 9 + 1 + k) * cap + i];
+  return e;
+}
+__device__ __forceinline__ uint32_t* ws_tab(uint32_t* tabs, size_t cap, size_t i, int slot) {
+  return tabs + (size_t)slot * SW_TABLE_WORDS * cap + i;
+}
+__device__ __forceinline__ uint32_t* ws_pt(uint32_t* pts, size_t cap, size_t i, int slot) {
+  return pts + (size_t)slot * PTW_WORDS * cap + i;
+}
+
+// ------------------------------------------------------------------------------------------------ context tables
+// One lane walks the 65 rows: row w = 16 * row (w - 1).  ~1000 point operations, once per context.
+__global__ void k_p256_init_comb(uint32_t* comb, const uint8_t* gen_xy, uint8_t* ok) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  uint32_t xw[8], yw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    xw[j] = (uint32_t)gen_xy[4 * j] | ((uint32_t)gen_xy[4 * j + 1] << 8) | ((uint32_t)gen_xy[4 * j + 2] << 16) | ((uint32_t)gen_xy[4 * j + 3] << 24);
+    yw[j] = (uint32_t)gen_xy[32 + 4 * j] | ((uint32_t)gen_xy[33 + 4 * j] << 8) | ((uint32_t)gen_xy[34 + 4 * j] << 16) | ((uint32_t)gen_xy[35 + 4 * j] << 24);
+  }
+  const FeN x = fe_from_u256(xw), y = fe_from_u256(yw);
+  ok[0] = (!u256_ge_q(xw) && !u256_ge_q(yw) && sw_on_curve(x, y)) ? 1 : 0;
+  PtW base = sw_from_affine(x, y);
+#pragma unroll 1
+  for (int w = 0; w < P256_COMB_ROWS; ++w) {
+    sw_build_table(comb + (size_t)w * SW_TABLE_WORDS, 1, base);
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) base = sw_dbl(base);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ IETF verify
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_verify_decode(p256::VerifyArgs a) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  const size_t cap = a.ws.cap;
+  FeN x[3], y[3];
+  Sec1W enc[3];
+  uint32_t c[8], s[8];
+  const bool ok = p256_verify_decode_item(x, y, enc, c, s, a.pk + i * SEC1_LEN, a.h + i * SEC1_LEN, a.gamma + i * SEC1_LEN,
+                                          a.c + i * 32, a.s + i * 32);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    ws_store_fe(a.ws.aff, cap, i, j * 18, x[j]);
+    ws_store_fe(a.ws.aff, cap, i, j * 18 + 9, y[j]);
+    ws_store_enc(a.ws.enc, cap, i, j, enc[j]);
+  }
+  ws_store8(a.ws.sc, cap, i, 0, c);
+  ws_store8(a.ws.sc, cap, i, 8, s);
+  a.ws.flags[i] = ok ? 1 : 0;
+}
+
+// blockIdx.y = 0: U = s G - c Y (comb + one table); 1: V = s H - c Gamma (two tables)
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_verify_mul(p256::VerifyArgs a) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= a.n || !a.ws.flags[i]) return;
+  const size_t cap = a.ws.cap;
+  uint32_t c[8], s[8];
+  ws_load8(c, a.ws.sc, cap, i, 0);
+  ws_load8(s, a.ws.sc, cap, i, 8);
+  if (blockIdx.y == 0) {
+    uint32_t* ty = ws_tab(a.ws.tabs, cap, i, 0);
+    sw_build_table(ty, cap, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 0), ws_load_fe(a.ws.aff, cap, i, 9)));
+    ptw_store(ws_pt(a.ws.pts, cap, i, 0), cap, sw_comb_minus_win(a.comb, ty, cap, s, c));
+  } else {
+    uint32_t* th = ws_tab(a.ws.tabs, cap, i, 1);
+    uint32_t* tg = ws_tab(a.ws.tabs, cap, i, 2);
+    sw_build_table(th, cap, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 18), ws_load_fe(a.ws.aff, cap, i, 27)));
+    sw_build_table(tg, cap, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 36), ws_load_fe(a.ws.aff, cap, i, 45)));
+    ptw_store(ws_pt(a.ws.pts, cap, i, 1), cap, sw_straus_sc(th, tg, cap, s, c));
+  }
+}
+
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_verify_finish(p256::VerifyArgs a) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  const size_t cap = a.ws.cap;
+  if (!a.ws.flags[i]) { a.status[i] = 2; return; }
+  const PtW U = ptw_load(ws_pt(a.ws.pts, cap, i, 0), cap), V = ptw_load(ws_pt(a.ws.pts, cap, i, 1), cap);
+  const Sec1W enc[3] = {ws_load_enc(a.ws.enc, cap, i, 0), ws_load_enc(a.ws.enc, cap, i, 1), ws_load_enc(a.ws.enc, cap, i, 2)};
+  uint32_t c[8];
+  ws_load8(c, a.ws.sc, cap, i, 0);
+  const uint8_t* ad;
+  uint32_t ad_len;
+  bytes_lite_get(a.ad, i, ad, ad_len);
+  a.status[i] = p256_verify_finish_item(U, V, enc, c, ad, ad_len, a.str);
+}
+
+// ------------------------------------------------------------------------------------------------ IETF prove
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_prepare(p256::ProveArgs a) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  const size_t cap = a.ws.cap;
+  const uint8_t* msg = nullptr;
+  uint32_t msg_len = 0;
+  if (!a.h_given) bytes_lite_get(a.msg, i, msg, msg_len);
+  uint32_t sk[8], k[8];
+  FeN hx, hy;
+  Sec1W henc;
+  const bool ok = p256_prove_prepare_item(sk, k, hx, hy, henc, a.sk + i * 32, msg, msg_len,
+                                          a.h_given ? a.h_given + i * SEC1_LEN : nullptr, a.str);
+  ws_store8(a.ws.sc, cap, i, 0, sk);
+  ws_store8(a.ws.sc, cap, i, 8, k);
+  ws_store_fe(a.ws.aff, cap, i, 0, hx);
+  ws_store_fe(a.ws.aff, cap, i, 9, hy);
+  ws_store_enc(a.ws.enc, cap, i, 0, henc);
+  a.ws.flags[i] = ok ? 1 : 0;
+}
+
+// blockIdx.y = 0: pk = sk G, 1: Gamma = sk H, 2: U = k G, 3: V = k H.  The two H ladders each build their own copy of
+// H's table (7 additions) rather than wait for one another.
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_mul(p256::ProveArgs a) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= a.n || !a.ws.flags[i]) return;
+  const size_t cap = a.ws.cap;
+  const int job = blockIdx.y;
+  uint32_t k[8];
+  ws_load8(k, a.ws.sc, cap, i, (job & 2) ? 8 : 0);
+  PtW r;
+  if (job & 1) {
+    uint32_t* th = ws_tab(a.ws.tabs, cap, i, job >> 1);
+    sw_build_table(th, cap, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 0), ws_load_fe(a.ws.aff, cap, i, 9)));
+    r = sw_win_mul(th, cap, k, false);
+  } else {
+    r = sw_comb_mul(a.comb, k);
+  }
+  ptw_store(ws_pt(a.ws.pts, cap, i, job), cap, r);
+}
+
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_finish(p256::ProveArgs a) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  const size_t cap = a.ws.cap;
+  if (!a.ws.flags[i]) {
+    if (a.status) a.status[i] = 2;
+    for (int k = 0; k < SEC1_LEN; ++k) {
+      a.gamma[i * SEC1_LEN + k] = 0;
+      if (a.pk_out) a.pk_out[i * SEC1_LEN + k] = 0;
+      if (a.h_out) a.h_out[i * SEC1_LEN + k] = 0;
+    }
+    for (int k = 0; k < 32; ++k) { a.c[i * 32 + k] = 0; a.s[i * 32 + k] = 0; }
+    return;
+  }
+  const PtW res[4] = {ptw_load(ws_pt(a.ws.pts, cap, i, 0), cap), ptw_load(ws_pt(a.ws.pts, cap, i, 1), cap),
+                      ptw_load(ws_pt(a.ws.pts, cap, i, 2), cap), ptw_load(ws_pt(a.ws.pts, cap, i, 3), cap)};
+  const Sec1W henc = ws_load_enc(a.ws.enc, cap, i, 0);
+  uint32_t sk[8], k[8], c[8], s[8];
+  ws_load8(sk, a.ws.sc, cap, i, 0);
+  ws_load8(k, a.ws.sc, cap, i, 8);
+  const uint8_t* ad;
+  uint32_t ad_len;
+  bytes_lite_get(a.ad, i, ad, ad_len);
+  Sec1W pk, gamma;
+  p256_prove_finish_item(pk, gamma, c, s, res, henc, sk, k, ad, ad_len, a.str);
+  sec1_store(a.gamma + i * SEC1_LEN, gamma.tag, gamma.xw);
+  store_be256(a.c + i * 32, c);
+  store_be256(a.s + i * 32, s);
+  if (a.pk_out) sec1_store(a.pk_out + i * SEC1_LEN, pk.tag, pk.xw);
+  if (a.h_out) sec1_store(a.h_out + i * SEC1_LEN, henc.tag, henc.xw);
+  if (a.status) a.status[i] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ building blocks
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_hash_to_curve(size_t n, BytesViewLite msg, uint8_t* out, SuiteStr str) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* m;
+  uint32_t len;
+  bytes_lite_get(msg, i, m, len);
+  FeN x, y;
+  uint32_t xw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool ok = p256_hash_to_curve(x, y, xw, m, len, str);
+  sec1_store(out + i * SEC1_LEN, ok ? 2u : 0u, xw);       // 256 failed attempts (2^-256): an all-zero string
+}
+
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_output_hash(size_t n, const uint8_t* gamma, uint8_t* out, SuiteStr str) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t xw[8], h[8];
+  load_be256(xw, gamma + i * SEC1_LEN + 1);
+  p256_output_hash(h, gamma[i * SEC1_LEN], xw, str);
+  store_be256(out + i * 32, h);
+}
+
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk_out,
+                                                                      uint8_t* pk_out, const uint32_t* comb) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t sk[8];
+  p256_secret_from_seed(sk, seeds + i * (size_t)seed_len, seed_len);
+  store_be256(sk_out + i * 32, sk);
+  if (pk_out) {
+    const PtW p[1] = {sw_comb_mul(comb, sk)};
+    Sec1W w[1];
+    sw_to_sec1<true>(w, p);
+    sec1_store(pk_out + i * SEC1_LEN, w[0].tag, w[0].xw);
+  }
+}
+
+// [ref src/lib.rs:14 `codec`] point_decode: 0 = a point of the curve (cofactor 1: of the group), 2 = InvalidData.
+// xy_out (nullable): x || y as 32-byte LITTLE-endian canonical integers, the form every *_xy array of this ABI has
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_point_validate(size_t n, const uint8_t* pts, uint8_t* xy_out, uint8_t* status) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  FeN x, y;
+  const bool ok = sec1_decode(x, y, pts + i * SEC1_LEN);
+  status[i] = ok ? 0 : 2;
+  if (xy_out) {
+    uint32_t xw[8], yw[8];
+    fe_to_u256(xw, x);
+    fe_to_u256(yw, y);
+    uint32_t* o = reinterpret_cast<uint32_t*>(xy_out + i * 64);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { o[k] = ok ? xw[k] : 0u; o[8 + k] = ok ? yw[k] : 0u; }
+  }
+}
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + P256_BLOCK - 1) / P256_BLOCK); }
+
+}  // namespace
+VRF_NS_END
+
+namespace vrf {
+namespace p256 {
+
+size_t comb_bytes() { return P256_COMB_WORDS * sizeof(uint32_t); }
+
+void default_generator(uint8_t xy[64]) { std::memcpy(xy, vrfk_tables::P256_G_XY, 64); }
+
+void launch_init_comb(uint32_t* comb, const uint8_t* d_gen_xy, uint8_t* d_ok, hipStream_t st) {
+  hipLaunchKernelGGL(k_p256_init_comb, dim3(1), dim3(64), 0, st, comb, d_gen_xy, d_ok);
+}
+
+void launch_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
+  const unsigned g = blocks_for(a.n);
+  if (ev) (void)hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(k_p256_verify_decode, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  hipLaunchKernelGGL(k_p256_verify_mul, dim3(g, 2), dim3(P256_BLOCK), 0, st, a);
+  if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
+  hipLaunchKernelGGL(k_p256_verify_finish, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[4], st);
+}
+
+void launch_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
+  const unsigned g = blocks_for(a.n);
+  if (ev) (void)hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(k_p256_prove_prepare, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  hipLaunchKernelGGL(k_p256_prove_mul, dim3(g, 4), dim3(P256_BLOCK), 0, st, a);
+  if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
+  hipLaunchKernelGGL(k_p256_prove_finish, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[4], st);
+}
+
+void launch_hash_to_curve(size_t n, BytesViewLite msg, uint8_t* points33, const SuiteStr& str, hipStream_t st) {
+  hipLaunchKernelGGL(k_p256_hash_to_curve, dim3(blocks_for(n)), dim3(P256_BLOCK), 0, st, n, msg, points33, str);
+}
+void launch_output_hash(size_t n, const uint8_t* gamma33, uint8_t* hash32, const SuiteStr& str, hipStream_t st) {
+  hipLaunchKernelGGL(k_p256_output_hash, dim3(blocks_for(n)), dim3(P256_BLOCK), 0, st, n, gamma33, hash32, str);
+}
+void launch_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk32, uint8_t* pk33, const uint32_t* comb,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(k_p256_secret_from_seed, dim3(blocks_for(n)), dim3(P256_BLOCK), 0, st, n, seeds, seed_len, sk32, pk33, comb);
+}
+void launch_point_validate(size_t n, const uint8_t* points33, uint8_t* xy_out, uint8_t* status, hipStream_t st) {
+  hipLaunchKernelGGL(k_p256_point_validate, dim3(blocks_for(n)), dim3(P256_BLOCK), 0, st, n, points33, xy_out, status);
+}
+
+}  // namespace p256
+}  // namespace vrf

