@@ -456,9 +456,12 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
         _lib.check(lib.vrfhip_secret_from_seed_batch_dev(cx.handle, n, seeds.data_ptr(), 8, sk.data_ptr(), None, stream), "seed")
         gen = torch.Generator(device=D.dev); gen.manual_seed(1234 + lo)
         msg = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=D.dev, generator=gen)
-        g, c, s_, pk, hh = mk(), mk(), mk(), mk(), mk()
+        pw = cx.point_bytes()                      # 32; 33 for secp256r1 (Sec1)
+        mkp = lambda: torch.empty((n, pw), dtype=torch.uint8, device=D.dev)
+        g, c, s_, pk, hh = mkp(), mk(), mk(), mkp(), mkp()
         st = torch.empty(n, dtype=torch.uint8, device=D.dev)
         lg = args.log2_batch
+        sw = tag == "secp256r1"
         fn = lambda: cx.ietf_prove_batch_dev(sk, msg, 32, g, c, s_, pk, hh, st)
         fn(); torch.cuda.synchronize()
         cx.profile(True)
@@ -482,6 +485,9 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
         heavy = max(range(4), key=lambda k: ms[k])
         kname = ("k_verify_decode (3 decompressions + subgroup tests + tables)", "k_verify_straus<1> (V = s*H - c*Gamma)",
                  "k_verify_straus<0> (U = s*G - c*Y)", "k_verify_finish")[heavy]
+        if sw:
+            kname = ("k_p256_verify_decode", "k_p256_verify_mul (U = s*G - c*Y and V = s*H - c*Gamma, one launch, grid.y = 2)", "-",
+                     "k_p256_verify_finish")[heavy]
         rf, v = roofline(kname, B_VERIFY, n, ms[heavy], groups, pmc_for("ietf_verify_" + tag, lg))
         res["ietf_verify_" + tag] = {
             "workload": "IETF ECVRF verify, %s, batch 2^%d per GPU, compressed points, checked decode (SURVEY.md section 8 f4)" % (title, lg),
@@ -498,22 +504,26 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
             cap = 1 << 15
             host = lambda t: t[:cap].cpu().numpy()
             skh, msgh, gh, ch, sh, pkh, hhh = (host(t) for t in (sk, msg, g, c, s_, pk, hh))
-            co.set_suite(oracle_suite)
+            if not sw:
+                co.set_suite(oracle_suite)
+            c_prove = co.p256_ietf_prove_batch if sw else co.ietf_prove_batch
+            c_verify = co.p256_ietf_verify_batch if sw else co.ietf_verify_batch
             try:
                 def leg_p(k):
-                    ref = co.ietf_prove_batch(skh[:k], msgs=msgh[:k], ad=b"", threads=cpu_cores())
+                    ref = c_prove(skh[:k], msgs=msgh[:k], ad=b"", threads=cpu_cores())
                     assert (ref["output"] == gh[:k]).all() and (ref["c"] == ch[:k]).all() and (ref["s"] == sh[:k]).all(), \
                         "GPU proofs differ from the CPU oracle on the sample"
                 res["ietf_prove_" + tag]["cpu_baseline"] = cpu_leg(leg_p, 16 * cpu_cores(), args.cpu_seconds / 2, cap, "proofs/s",
                                                                    "proof bytes equal the GPU's")
 
                 def leg_v(k):
-                    stv = co.ietf_verify_batch(pkh[:k], hhh[:k], gh[:k], ch[:k], sh[:k], b"", threads=cpu_cores())
+                    stv = c_verify(pkh[:k], hhh[:k], gh[:k], ch[:k], sh[:k], b"", threads=cpu_cores())
                     assert not stv.any(), "CPU oracle rejects GPU-made proofs"
                 res["ietf_verify_" + tag]["cpu_baseline"] = cpu_leg(leg_v, 16 * cpu_cores(), args.cpu_seconds / 2, cap, "verifies/s",
                                                                     "statuses equal the GPU's")
             finally:
-                co.set_suite(1)
+                if not sw:
+                    co.set_suite(1)
     finally:
         cx.close()
     return res
@@ -755,7 +765,7 @@ def run_rank(args):
     want_cpu = (not args.no_cpu_baseline) and world == 1
     configs = {}
     if not args.no_configs:
-        from ark_ec_vrfs_amd import BabyJubJubSha512Tai, Ed25519Sha512Tai
+        from ark_ec_vrfs_amd import BabyJubJubSha512Tai, Ed25519Sha512Tai, Secp256r1Sha256Tai
         legs = (("ietf_prove", lambda: {"ietf_prove": cfg_ietf_prove(D, args, ctx, sk, msg, want_cpu and rank == 0)}),
                 ("shard_sizes", lambda: cfg_shard_sizes(D, args, ctx, pk, hh, gamma, c, s)),
                 ("ietf_verify_keyed", lambda: {"ietf_verify_keyed": cfg_ietf_keyed(D, args, ctx, msg, lo)}),
@@ -764,6 +774,8 @@ def run_rank(args):
                                                    want_cpu and rank == 0)),
                 ("babyjubjub", lambda: cfg_suite_ietf(D, args, "babyjubjub", BabyJubJubSha512Tai, 4, "BabyJubJub_SHA-512_TAI", lo,
                                                       want_cpu and rank == 0)),
+                ("secp256r1", lambda: cfg_suite_ietf(D, args, "secp256r1", Secp256r1Sha256Tai, 5, "P256_SHA256_TAI (RFC 9381 suite 0x01)", lo,
+                                                     want_cpu and rank == 0)),
                 ("pairing", lambda: cfg_pairing(D, args, ctx, want_cpu and rank == 0)))
         only = [x for x in args.only.split(",") if x]
         D.local_legs = world > 1

@@ -54,6 +54,15 @@ def load() -> ctypes.CDLL:
         lib.oracle_pairing_check2.restype = c_int
         lib.oracle_pairing_check2_batch.argtypes = [c_size_t, P, P, c_size_t, P, c_int]
         lib.oracle_pairing_check2_batch.restype = None
+        lib.p256_ietf_verify_batch.argtypes = [c_size_t, P, P, P, P, P, P, c_size_t, P, c_int]
+        lib.p256_ietf_verify_batch.restype = None
+        lib.p256_ietf_prove_batch.argtypes = [c_size_t, P, P, c_size_t, P, P, c_size_t, P, P, P, P, P, P, c_int]
+        lib.p256_ietf_prove_batch.restype = None
+        lib.p256_secret_from_seed.argtypes = [P, c_size_t, P]
+        lib.p256_public_from_secret.argtypes = [P, P]
+        lib.p256_hash_to_curve.argtypes = [P, c_size_t, P]
+        lib.p256_output_hash.argtypes = [P, P]
+        lib.p256_point_decode.argtypes = [P]
         lib.oracle_g1_mul.argtypes = [P, P, P]
         lib.oracle_g1_mul.restype = c_int
         lib.oracle_g2_mul.argtypes = [P, P, P]
@@ -299,3 +308,65 @@ def g1_add(a96: bytes, b96: bytes) -> bytes:
     if load().oracle_g1_add(x.ctypes.data, y.ctypes.data, out.ctypes.data) != 0:
         raise ValueError("G1 point does not decode")
     return out.tobytes()
+
+
+# ---- secp256r1 (oracle/c/oracle_p256.c; wire format: 33-byte Sec1 points, 32-byte big-endian scalars) ----
+def p256_ietf_verify_batch(pk, h, gamma, c, s, ad: bytes = b"", threads: int = 1) -> np.ndarray:
+    pk, h, gamma = (_a(x).reshape(-1, 33) for x in (pk, h, gamma))
+    c, s = (_a(x).reshape(-1, 32) for x in (c, s))
+    n = pk.shape[0]
+    st = np.empty(n, dtype=np.uint8)
+    adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
+    load().p256_ietf_verify_batch(n, pk.ctypes.data, h.ctypes.data, gamma.ctypes.data, c.ctypes.data, s.ctypes.data,
+                                  adb.ctypes.data, len(ad), st.ctypes.data, threads)
+    return st
+
+
+def p256_ietf_prove_batch(sk, msgs: np.ndarray = None, inputs=None, ad: bytes = b"", threads: int = 1):
+    sk = _a(sk).reshape(-1, 32)
+    n = sk.shape[0]
+    res = {k: np.empty((n, 32 if k in ("c", "s") else 33), dtype=np.uint8) for k in ("output", "c", "s", "pk", "input")}
+    st = np.empty(n, dtype=np.uint8)
+    adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
+    mp, ml, ip = None, 0, None
+    if inputs is not None:
+        inputs = _a(inputs).reshape(n, 33)
+        ip = inputs.ctypes.data
+    else:
+        msgs = _a(msgs).reshape(n, -1)
+        ml = msgs.shape[1]
+        msgs = np.concatenate([msgs.reshape(-1), np.zeros(1, np.uint8)])
+        mp = msgs.ctypes.data
+    load().p256_ietf_prove_batch(n, sk.ctypes.data, mp, ml, ip, adb.ctypes.data, len(ad), res["output"].ctypes.data,
+                                 res["c"].ctypes.data, res["s"].ctypes.data, res["pk"].ctypes.data, res["input"].ctypes.data,
+                                 st.ctypes.data, threads)
+    res["status"] = st
+    return res
+
+
+def p256_secret_from_seed(seed: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    load().p256_secret_from_seed(bytes(seed), len(seed), out)
+    return out.raw
+
+
+def p256_public_from_secret(sk_be: bytes) -> bytes:
+    out = ctypes.create_string_buffer(33)
+    load().p256_public_from_secret(bytes(sk_be), out)
+    return out.raw
+
+
+def p256_hash_to_curve(data: bytes) -> bytes:
+    out = ctypes.create_string_buffer(33)
+    load().p256_hash_to_curve(bytes(data), len(data), out)
+    return out.raw
+
+
+def p256_output_hash(gamma33: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    load().p256_output_hash(bytes(gamma33), out)
+    return out.raw
+
+
+def p256_point_decode(enc33: bytes) -> int:
+    return load().p256_point_decode(bytes(enc33))

@@ -16,6 +16,7 @@ import subprocess
 import numpy as np
 import pytest
 
+from oracle import c_oracle as co
 from oracle import sw_oracle as sw
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -73,6 +74,38 @@ def test_rfc9381_b1_vectors_pin_the_python_oracle():
 def test_curve_constants():
     assert sw.is_on_curve(G) and sw.mul(N, G) is None and sw.mul(N - 1, G) == sw.neg(G)
     assert abs(N - (P + 1)) <= 2 * int(P ** 0.5) + 2 and P % 4 == 3
+
+
+def test_c_oracle_equals_the_python_oracle_and_the_rfc_vectors():
+    """oracle/c/oracle_p256.c (the checker of the big GPU samples and the bench's CPU baseline) against RFC 9381 B.1 and
+    against oracle/sw_oracle.py on random items, tampered proofs and undecodable points."""
+    for v in RFC["vectors"]:
+        sk, pk, alpha = bytes.fromhex(v["sk"]), bytes.fromhex(v["pk"]), bytes.fromhex(v["alpha"])
+        assert co.p256_public_from_secret(sk).hex() == v["pk"] and co.p256_hash_to_curve(pk + alpha).hex() == v["h"]
+        r = co.p256_ietf_prove_batch(np.frombuffer(sk, np.uint8), msgs=np.frombuffer(pk + alpha, np.uint8).reshape(1, -1))
+        assert (r["output"][0].tobytes() + r["c"][0].tobytes()[16:] + r["s"][0].tobytes()).hex() == v["pi"]
+        assert co.p256_output_hash(r["output"][0].tobytes()).hex() == v["beta"]
+        assert co.p256_ietf_verify_batch(r["pk"], r["input"], r["output"], r["c"], r["s"])[0] == 0
+    rng = np.random.default_rng(3)
+    n = 12
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msg = rng.integers(0, 256, (n, 19), dtype=np.uint8)
+    r = co.p256_ietf_prove_batch(sk, msgs=msg, ad=b"ad", threads=4)
+    for i in range(n):
+        k = sw.scalar_decode(sk[i].tobytes())
+        H, _ = sw.hash_to_curve_tai(msg[i].tobytes())
+        g, c, s = sw.ietf_prove(k, H, b"ad")
+        assert r["input"][i].tobytes() == sw.point_encode(H) and r["output"][i].tobytes() == sw.point_encode(g)
+        assert r["c"][i].tobytes() == be(c) and r["s"][i].tobytes() == be(s) and r["pk"][i].tobytes() == sw.point_encode(sw.mul(k, G))
+        assert co.p256_secret_from_seed(msg[i].tobytes()) == be(sw.secret_from_seed(msg[i].tobytes()))
+    s2 = r["s"].copy(); s2[1, 5] ^= 1
+    g2 = r["output"].copy(); g2[2, 0] = 7
+    st = co.p256_ietf_verify_batch(r["pk"], r["input"], g2, r["c"], s2, ad=b"ad", threads=2)
+    assert list(st[:4]) == [0, 1, 2, 0]
+    # the group law's corner: s G = c Y (U at infinity) gets the oracle's verdict, whatever it is
+    k0 = sw.scalar_decode(sk[0].tobytes())
+    want = 0 if sw.ietf_verify(sw.mul(k0, G), sw.point_decode(r["input"][0].tobytes()), sw.point_decode(r["output"][0].tobytes()), b"ad", 1, k0) else 1
+    assert co.p256_ietf_verify_batch(r["pk"][:1], r["input"][:1], r["output"][:1], np.frombuffer(be(1), np.uint8), np.frombuffer(be(k0), np.uint8), ad=b"ad")[0] == want
 
 
 # ---------------------------------------------------------------------------------------------- device headers on the host
@@ -352,6 +385,47 @@ def test_gpu_batch_round_trip_across_launch_groups(gpu):
         assert (stm == st[:m]).all() if False else (stm[::3] == 1).all()
     finally:
         other.close()
+        gpu.reserve(1 << 20)
+
+
+@pytest.mark.gpu
+def test_gpu_whole_batch_equals_the_c_oracle(gpu):
+    """Every byte of 6000 proofs (ragged: two launch groups of a 4096 workspace) and every status of a batch with each
+    kind of defect, against oracle/c/oracle_p256.c."""
+    n = 6000
+    gpu.reserve(4096)
+    try:
+        rng = np.random.default_rng(21)
+        sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        sk[0] = 0; sk[0, 31] = 1                       # sk = 1
+        sk[1] = np.frombuffer(be(N - 1), np.uint8)     # sk = n - 1
+        sk[2] = np.frombuffer(be(N + 5), np.uint8)     # reduced mod n, as scalar_decode does
+        msg = rng.integers(0, 256, (n, 40), dtype=np.uint8)
+        r = gpu.ietf_prove_batch(sk, msgs=msg, ad=b"soak")
+        ref = co.p256_ietf_prove_batch(sk, msgs=msg, ad=b"soak", threads=8)
+        for k in ("output", "c", "s", "pk", "input"):
+            assert (r[k] == ref[k]).all(), k
+        assert (r["status"] == 0).all() and (ref["status"] == 0).all()
+        pkt, ht, gt, ct, st_ = (x.copy() for x in (r["pk"], r["input"], r["output"], r["c"], r["s"]))
+        kind = rng.integers(0, 9, n)
+        for i in range(n):
+            if kind[i] == 1: st_[i, rng.integers(0, 32)] ^= 1 << rng.integers(0, 8)
+            elif kind[i] == 2: ct[i, rng.integers(16, 32)] ^= 1 << rng.integers(0, 8)
+            elif kind[i] == 3: gt[i, rng.integers(1, 33)] ^= 1 << rng.integers(0, 8)      # a different x: another point or none
+            elif kind[i] == 4: pkt[i, 0] ^= 1                                             # the other root: -Y
+            elif kind[i] == 5: ht[i, 0] = rng.integers(4, 256)
+            elif kind[i] == 6: ct[i, rng.integers(0, 16)] |= 1 << rng.integers(0, 8)      # c >= 2^128
+            elif kind[i] == 7: gt[i, 1:] = 0xff                                           # x >= p
+            elif kind[i] == 8: pkt[i] = r["pk"][(i + 1) % n]
+        got = gpu.ietf_verify_batch(pkt, ht, gt, ct, st_, ad=b"soak")
+        want = co.p256_ietf_verify_batch(pkt, ht, gt, ct, st_, ad=b"soak", threads=8)
+        assert (got == want).all(), np.nonzero(got != want)[0][:10]
+        assert set(np.unique(want)) == {0, 1, 2}
+        assert (gpu.hash_to_curve_batch(msg[:512]) == r["input"][:512]).all()
+        assert [h.tobytes() for h in gpu.output_hash_batch(r["output"][:64])] == [co.p256_output_hash(x.tobytes()) for x in r["output"][:64]]
+        stv = gpu.point_validate_batch(gt)
+        assert list(stv) == [co.p256_point_decode(x.tobytes()) for x in gt]
+    finally:
         gpu.reserve(1 << 20)
 
 
