@@ -104,13 +104,22 @@ VRF_HD bool p256_hash_to_curve(FeN& x, FeN& y, uint32_t xw[8], const uint8_t* da
     uint32_t w[8];
     sha256_be256(w, h);
     if (u256_ge_q(w)) continue;
+    // A wave runs as many trips as its unluckiest lane (about 7 of the 64 where one lane expects 2), so a trip only
+    // decides -- the Jacobi symbol of x^3 - 3x + b, a third of the exponentiation -- and the root is taken once, after.
     const FeN xc = fe_from_u256(w);
-    FeN yc;
-    if (!sw_lift_x(yc, xc, false)) continue;            // 0x02: the even root
-    x = xc; y = yc; found = true;
+    const FeN rc = fe_canon(sw_rhs(xc));
+    const int j = jacobi_limbs(rc.v);
+    bool on = j == 1 || j == 0;
+    if (j == 2) {                                        // rounds exhausted (not observed): decide by the root itself
+      FeN yt;
+      on = sw_lift_x(yt, xc, false);
+    }
+    if (!on) continue;
+    x = xc; found = true;
 #pragma unroll
     for (int i = 0; i < 8; ++i) xw[i] = w[i];
   }
+  if (found) (void)sw_lift_x(y, x, false);               // 0x02: the even root
   return found;
 }
 
@@ -240,8 +249,7 @@ VRF_HD PtW sw_win_mul(const uint32_t* tab, size_t stride, const uint32_t k[8], b
 #pragma unroll 1
   for (int w = SW_WINDOWS - 1; w >= 0; --w) {
     if (w != SW_WINDOWS - 1) {
-#pragma unroll 1
-      for (int j = 0; j < 4; ++j) acc = sw_dbl(acc);
+      acc = sw_dbl4(acc);
     }
     const int d = sw_digit(rec, top, w);
     acc = sw_add(acc, sw_lookup(tab, stride, negate ? -d : d));
@@ -272,8 +280,7 @@ VRF_HD PtW sw_straus_sc(const uint32_t* tabP, const uint32_t* tabQ, size_t strid
 #pragma unroll 1
   for (int w = SW_WINDOWS - 1; w >= 0; --w) {
     if (w != SW_WINDOWS - 1) {
-#pragma unroll 1
-      for (int j = 0; j < 4; ++j) acc = sw_dbl(acc);
+      acc = sw_dbl4(acc);
     }
     acc = sw_add(acc, sw_lookup(tabP, stride, sw_digit(srec, stop, w)));
     if (w <= 32)                                         // wave-uniform
@@ -289,8 +296,7 @@ VRF_HD PtW sw_comb_minus_win(const uint32_t* comb, const uint32_t* tabQ, size_t 
 #pragma unroll 1
   for (int w = 32; w >= 0; --w) {
     if (w != 32) {
-#pragma unroll 1
-      for (int j = 0; j < 4; ++j) acc = sw_dbl(acc);
+      acc = sw_dbl4(acc);
     }
     acc = sw_add(acc, sw_lookup(tabQ, stride, -scalar_digit4(crec, w)));
   }

@@ -122,6 +122,58 @@ VRF_HD PtW sw_dbl(const PtW& p) {
   return r;
 }
 
+// ---- runs of doublings in Jacobian coordinates ----
+// The complete doubling above costs 13 products; dbl-2001-b on Jacobian coordinates (x = X/Z^2, y = Y/Z^3; Bernstein-Lange
+// EFD, a = -3) costs 3 + 5 squarings and has no exceptional case on a curve without 2-torsion: the point at infinity is
+// (0 : Y != 0 : 0) and stays of that shape (Y -> -8 Y^4).  The ladders therefore double four times in Jacobian form between
+// the (complete, homogeneous) additions of a window; the two changes of coordinates cost 2 products + 1 squaring each.
+struct PtJ {
+  FeN X, Y, Z;
+};
+// exact-limbed values below 2p (what fe_wred returns): zero mod p is the integer 0 or p
+VRF_HD bool fe_is_zero_exact(const FeN& a) {
+  uint32_t z = 0, q = 0;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { z |= a.v[i]; q |= a.v[i] ^ vrfk::Q29[i]; }
+  return z == 0 || q == 0;
+}
+VRF_HD PtJ sw_to_jac(const PtW& p) {                 // (X : Y : Z) -> (X Z, Y Z^2, Z); infinity (0 : Y : 0) -> (0, 1, 0)
+  const FeN zz = fe_sqr(p.Z);
+  PtJ r;
+  r.X = fe_mul(p.X, p.Z);
+  r.Y = fe_select(fe_is_zero_exact(p.Z), fe_one(), fe_mul(p.Y, zz));
+  r.Z = p.Z;
+  return r;
+}
+VRF_HD PtW sw_from_jac(const PtJ& p) {               // (X, Y, Z) -> (X Z : Y : Z^3)
+  const FeN zz = fe_sqr(p.Z);
+  PtW r;
+  r.X = fe_mul(p.X, p.Z);
+  r.Y = p.Y;
+  r.Z = fe_mul(zz, p.Z);
+  return r;
+}
+VRF_HD PtJ sw_dbl_jac(const PtJ& p) {
+  const FeN delta = fe_sqr(p.Z), gamma = fe_sqr(p.Y);
+  const FeN b4 = fe_mul(fe_dbl(p.X), fe_dbl(gamma));                                      // 4 X Y^2
+  const FeN t = fe_mul(fe_sub(p.X, delta), fe_add(p.X, delta));                           // X^2 - Z^4
+  const auto alpha = fe_norm(fe_add(fe_dbl(t), t));                                       // 3 (...)        (1, 6)
+  PtJ r;
+  const auto x3 = fe_sub(fe_sqr(alpha), fe_dbl(b4));                                      // alpha^2 - 8 X Y^2
+  r.X = fe_wred(x3);
+  r.Z = fe_wred(fe_sub(fe_sqr(fe_add(p.Y, p.Z)), fe_add(gamma, delta)));                  // (Y + Z)^2 - Y^2 - Z^2 = 2 Y Z
+  const auto g8 = fe_dbl(fe_sqr(fe_dbl(gamma)));                                          // 8 Y^4          (2, 4)
+  r.Y = fe_wred(fe_sub(fe_mul(alpha, fe_sub(b4, r.X)), g8));                              // alpha (4 X Y^2 - X3) - 8 Y^4
+  return r;
+}
+// 16 P on a homogeneous point: the ladders' step between windows
+VRF_HD PtW sw_dbl4(const PtW& p) {
+  PtJ j = sw_to_jac(p);
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) j = sw_dbl_jac(j);
+  return sw_from_jac(j);
+}
+
 // y^2 = x^3 - 3x + b
 VRF_HD FeN sw_rhs(const FeN& x) {
   const FeN x2 = fe_sqr(x);

@@ -66,6 +66,12 @@ void hp_fr_mul_add(const uint8_t* a, const uint8_t* b, const uint8_t* c, uint8_t
 // ---- group law (affine big-endian x || y; all zero = infinity) ----
 void hp_add(const uint8_t* a, const uint8_t* b, uint8_t* r) { pout(r, sw_add(pin(a), pin(b))); }
 void hp_dbl(const uint8_t* a, uint8_t* r) { pout(r, sw_dbl(pin(a))); }
+// 16 P through the Jacobian doubling run, from a point with Z = z (z = 0: the point at infinity as (0 : 1 : 0) scaled)
+void hp_dbl4(const uint8_t* a, const uint8_t* z, uint8_t* r) {
+  PtW p = pin(a); FeN u = in(z);
+  p.X = fe_wred(fe_mul(p.X, u)); p.Y = fe_wred(fe_mul(p.Y, u)); p.Z = fe_wred(fe_mul(p.Z, u));
+  pout(r, sw_dbl4(p));
+}
 // the same through non-trivial Z (both operands scaled)
 void hp_add_scaled(const uint8_t* a, const uint8_t* b, const uint8_t* za, const uint8_t* zb, uint8_t* r) {
   PtW p = pin(a), q = pin(b); FeN u = in(za), v = in(zb);

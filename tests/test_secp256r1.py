@@ -160,6 +160,8 @@ def test_complete_group_law(hp):
             za, zb = rnd.randrange(1, P), rnd.randrange(1, P)
             assert _pt(hp.hp_add_scaled, xy(A), xy(B), be(za), be(zb)) == sw.add(A, B)
         assert _pt(hp.hp_dbl, xy(A)) == sw.add(A, A)
+        for z in (1, rnd.randrange(1, P), P - 1):       # the Jacobian doubling run between windows; infinity stays infinity
+            assert _pt(hp.hp_dbl4, xy(A), be(z)) == sw.mul(16, A)
     for it in range(24):
         k = [0, 1, 2, N - 1, N - 2, (1 << 255), (1 << 256) - 1 - (1 << 32), 0x8888888888888888888888888888888888888888888888888888888888888888,
              0x7777777777777777777777777777777777777777777777777777777777777777][it] if it < 9 else rnd.getrandbits(256)
