@@ -6,8 +6,8 @@
 // Shape: one item per lane.  The stages are separate kernels because their register needs differ by a factor of three
 // (the ladders hold a projective accumulator, a table entry and the temporaries of the complete addition; the hash
 // stages hold a SHA-256 block); what passes between them lies word-major in the context's workspace (p256.h), so every
-// inter-stage load and store is coalesced.  The ladders' window tables live there too: 216 words per table and item,
-// written once and read 65 (+33) times by the lane that wrote them.
+// inter-stage load and store is coalesced.  The ladders' window tables live there too, contiguous per item (224 words per
+// table): written once and read 65 (+33) times, an entry at a time, by the lane that wrote them.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include "p256.h"
@@ -17,6 +17,9 @@ VRF_NS_BEGIN
 namespace {
 
 constexpr int P256_BLOCK = 128;
+// p256.h states the workspace record sizes as plain numbers (the C ABI's translation unit does not see the device headers)
+static_assert(p256::WS_TAB_WORDS == 3 * SW_TABLE_WORDS && p256::WS_PTS_WORDS == 4 * PTW_WORDS && p256::WS_AFF_WORDS == 6 * NL &&
+              p256::WS_ENC_WORDS == 3 * 9, "p256.h workspace layout");
 
 __device__ __forceinline__ void ws_store_fe(uint32_t* base, size_t cap, size_t i, int w0, const FeN& a) {
 #pragma unroll
@@ -49,16 +52,18 @@ __device__ __forceinline__ Sec1W ws_load_enc(const uint32_t* base, size_t cap, s
   return e;
 }
 __device__ __forceinline__ uint32_t* ws_tab(uint32_t* tabs, size_t cap, size_t i, int slot) {
-  return tabs + (size_t)slot * SW_TABLE_WORDS * cap + i;
+  return tabs + ((size_t)slot * cap + i) * SW_TABLE_WORDS;      // contiguous per item (sw.cuh)
 }
 __device__ __forceinline__ uint32_t* ws_pt(uint32_t* pts, size_t cap, size_t i, int slot) {
   return pts + (size_t)slot * PTW_WORDS * cap + i;
 }
 
 // ------------------------------------------------------------------------------------------------ context tables
-// One lane walks the 65 rows: row w = 16 * row (w - 1).  ~1000 point operations, once per context.
+// One lane per row of the comb (33 rows of 128 entries: p256_core.cuh); lane 0 also reports whether the generator is a
+// point of the curve.
 __global__ void k_p256_init_comb(uint32_t* comb, const uint8_t* gen_xy, uint8_t* ok) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (w >= P256_COMB_ROWS) return;
   uint32_t xw[8], yw[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -66,14 +71,8 @@ __global__ void k_p256_init_comb(uint32_t* comb, const uint8_t* gen_xy, uint8_t*
     yw[j] = (uint32_t)gen_xy[32 + 4 * j] | ((uint32_t)gen_xy[33 + 4 * j] << 8) | ((uint32_t)gen_xy[34 + 4 * j] << 16) | ((uint32_t)gen_xy[35 + 4 * j] << 24);
   }
   const FeN x = fe_from_u256(xw), y = fe_from_u256(yw);
-  ok[0] = (!u256_ge_q(xw) && !u256_ge_q(yw) && sw_on_curve(x, y)) ? 1 : 0;
-  PtW base = sw_from_affine(x, y);
-#pragma unroll 1
-  for (int w = 0; w < P256_COMB_ROWS; ++w) {
-    sw_build_table(comb + (size_t)w * SW_TABLE_WORDS, 1, base);
-#pragma unroll 1
-    for (int j = 0; j < 4; ++j) base = sw_dbl(base);
-  }
+  if (w == 0) ok[0] = (!u256_ge_q(xw) && !u256_ge_q(yw) && sw_on_curve(x, y)) ? 1 : 0;
+  p256_comb_build_row(comb, w, x, y);
 }
 
 // ------------------------------------------------------------------------------------------------ IETF verify
@@ -97,24 +96,29 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_verify_decode(p256::VerifyA
   a.ws.flags[i] = ok ? 1 : 0;
 }
 
-// blockIdx.y = 0: U = s G - c Y (comb + one table); 1: V = s H - c Gamma (two tables)
-__global__ void __launch_bounds__(P256_BLOCK) k_p256_verify_mul(p256::VerifyArgs a) {
+// WHICH = 0: U = s G - c Y (comb + one table); 1: V = s H - c Gamma (two tables).  Two kernels rather than one launch with
+// blockIdx.y choosing: the V ladder needs every register there is (two table entries in flight), the U ladder does not,
+// and a shared body would run both at the V ladder's occupancy.
+// amdgpu_waves_per_eu(3): left alone the register allocator takes all 256 VGPRs and 34 AGPRs for these bodies -- one wave
+// per SIMD, 0.78 of the issue slots -- although 168 registers and 104 B of scratch serve them as well (three waves).
+template <int WHICH>
+__global__ void __launch_bounds__(P256_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_p256_verify_mul(p256::VerifyArgs a) {
   const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
   if (i >= a.n || !a.ws.flags[i]) return;
   const size_t cap = a.ws.cap;
   uint32_t c[8], s[8];
   ws_load8(c, a.ws.sc, cap, i, 0);
   ws_load8(s, a.ws.sc, cap, i, 8);
-  if (blockIdx.y == 0) {
+  if constexpr (WHICH == 0) {
     uint32_t* ty = ws_tab(a.ws.tabs, cap, i, 0);
-    sw_build_table(ty, cap, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 0), ws_load_fe(a.ws.aff, cap, i, 9)));
-    ptw_store(ws_pt(a.ws.pts, cap, i, 0), cap, sw_comb_minus_win(a.comb, ty, cap, s, c));
+    sw_build_table(ty, 1, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 0), ws_load_fe(a.ws.aff, cap, i, 9)));
+    ptw_store(ws_pt(a.ws.pts, cap, i, 0), cap, sw_comb_minus_win(a.comb, ty, 1, s, c));
   } else {
     uint32_t* th = ws_tab(a.ws.tabs, cap, i, 1);
     uint32_t* tg = ws_tab(a.ws.tabs, cap, i, 2);
-    sw_build_table(th, cap, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 18), ws_load_fe(a.ws.aff, cap, i, 27)));
-    sw_build_table(tg, cap, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 36), ws_load_fe(a.ws.aff, cap, i, 45)));
-    ptw_store(ws_pt(a.ws.pts, cap, i, 1), cap, sw_straus_sc(th, tg, cap, s, c));
+    sw_build_table(th, 1, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 18), ws_load_fe(a.ws.aff, cap, i, 27)));
+    sw_build_table(tg, 1, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 36), ws_load_fe(a.ws.aff, cap, i, 45)));
+    ptw_store(ws_pt(a.ws.pts, cap, i, 1), cap, sw_straus_sc(th, tg, 1, s, c));
   }
 }
 
@@ -166,8 +170,8 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_mul(p256::ProveArgs a
   PtW r;
   if (job & 1) {
     uint32_t* th = ws_tab(a.ws.tabs, cap, i, job >> 1);
-    sw_build_table(th, cap, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 0), ws_load_fe(a.ws.aff, cap, i, 9)));
-    r = sw_win_mul(th, cap, k, false);
+    sw_build_table(th, 1, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 0), ws_load_fe(a.ws.aff, cap, i, 9)));
+    r = sw_win_mul(th, 1, k, false);
   } else {
     r = sw_comb_mul(a.comb, k);
   }
@@ -283,8 +287,10 @@ void launch_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (ev) (void)hipEventRecord(ev[0], st);
   hipLaunchKernelGGL(k_p256_verify_decode, dim3(g), dim3(P256_BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(k_p256_verify_mul, dim3(g, 2), dim3(P256_BLOCK), 0, st, a);
-  if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
+  hipLaunchKernelGGL(k_p256_verify_mul<1>, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[2], st);
+  hipLaunchKernelGGL(k_p256_verify_mul<0>, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[3], st);
   hipLaunchKernelGGL(k_p256_verify_finish, dim3(g), dim3(P256_BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[4], st);
 }

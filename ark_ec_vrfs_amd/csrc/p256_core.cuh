@@ -257,17 +257,53 @@ VRF_HD PtW sw_win_mul(const uint32_t* tab, size_t stride, const uint32_t k[8], b
   return acc;
 }
 
-// the fixed-base comb of the generator: row w holds j * 16^w * G, j = 1..8 (projective, Z = 1), so k*G is 65 additions
-// and no doubling.  [65][8][PTW_WORDS] words, built once per context (k_p256.hip k_p256_init_comb).
-constexpr int P256_COMB_ROWS = SW_WINDOWS;
-constexpr size_t P256_COMB_WORDS = (size_t)P256_COMB_ROWS * SW_TABLE_WORDS;
+// The fixed-base comb of the generator: signed radix-256 digits, row w holds j * 256^w * G for j = 1..128 (projective,
+// entries of SW_ENTRY_WORDS words), so k * G is 33 additions and no doubling (a radix-16 comb took 65).  33 x 128 x 112 B =
+// 473 KB, resident in L2; built once per context, one lane per row (p256_comb_build_row).
+constexpr int P256_COMB_ROWS = 33;          // 32 byte digits + the carry out of the top one
+constexpr int P256_COMB_WIN = 128;
+constexpr size_t P256_COMB_ROW_WORDS = (size_t)P256_COMB_WIN * SW_ENTRY_WORDS;
+constexpr size_t P256_COMB_WORDS = (size_t)P256_COMB_ROWS * P256_COMB_ROW_WORDS;
+VRF_HD void p256_comb_build_row(uint32_t* comb, int w, const FeN& gx, const FeN& gy) {
+  PtW base = sw_from_affine(gx, gy);
+#pragma unroll 1
+  for (int k = 0; k < 2 * w; ++k) base = sw_dbl4(base);              // 256^w * G
+  uint32_t* row = comb + (size_t)w * P256_COMB_ROW_WORDS;
+  PtW acc = base;
+  ptw_store(row, 1, acc);
+#pragma unroll 1
+  for (int jj = 1; jj < P256_COMB_WIN; ++jj) {
+    acc = sw_add(acc, base);
+    ptw_store(row + (size_t)jj * SW_ENTRY_WORDS, 1, acc);
+  }
+}
+// k + 0x80..80 has bytes d_w + 128 with d_w in [-128, 127]; the carry out of the top byte is digit 32
+VRF_HD uint32_t sw_recode8(uint32_t rec[8], const uint32_t k[8]) {
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t x = (uint64_t)k[i] + 0x80808080u + c;
+    rec[i] = (uint32_t)x;
+    c = (uint32_t)(x >> 32);
+  }
+  return c;
+}
 VRF_HD PtW sw_comb_mul(const uint32_t* comb, const uint32_t k[8]) {
   uint32_t rec[8];
-  const uint32_t top = sw_recode(rec, k);
+  const uint32_t top = sw_recode8(rec, k);
   PtW acc = sw_identity();
 #pragma unroll 1
-  for (int w = 0; w < P256_COMB_ROWS; ++w)
-    acc = sw_add(acc, sw_lookup(comb + (size_t)w * SW_TABLE_WORDS, 1, sw_digit(rec, top, w)));
+  for (int w = 0; w < P256_COMB_ROWS; ++w) {
+    uint32_t word = rec[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+      if ((w >> 2) == i) word = rec[i];
+    const int d = w == 32 ? (int)top : (int)((word >> ((w & 3) * 8)) & 255u) - 128;
+    const int mag = d < 0 ? -d : d;
+    PtW e = ptw_load(comb + (size_t)w * P256_COMB_ROW_WORDS + (size_t)(mag > 0 ? mag - 1 : 0) * SW_ENTRY_WORDS, 1);
+    e = sw_select(mag == 0, sw_identity(), e);
+    acc = sw_add(acc, sw_cneg(d < 0, e));
+  }
   return acc;
 }
 

@@ -183,9 +183,15 @@ VRF_HD FeN sw_rhs(const FeN& x) {
 }
 VRF_HD bool sw_on_curve(const FeN& x, const FeN& y) { return fe_eq(fe_sqr(y), sw_rhs(x)); }
 
-// ---- signed radix-16 window tables: j * P for j = 1..8, projective, laid out word-major over the batch ----
+// ---- signed radix-16 window tables: j * P for j = 1..8, projective ----
+// An entry is 27 words padded to 28 (112 B, 16-byte aligned) and a table is CONTIGUOUS per item: a lookup is indexed by
+// a digit of the item's own scalar, so the 64 lanes of a wave read 64 different entries anyway, and what matters is that
+// each lane's 27 words share two cache lines.  (The first layout spread a table word-major over the batch like the other
+// workspace regions: every word of every lookup then pulled its own 64-byte line, 116 GB of HBM traffic per 2^20
+// verifications where the tables hold 2.7 -- profiles/r03.)
 constexpr int SW_WIN = 8;
-constexpr int SW_TABLE_WORDS = SW_WIN * PTW_WORDS;      // 216
+constexpr int SW_ENTRY_WORDS = 28;
+constexpr int SW_TABLE_WORDS = SW_WIN * SW_ENTRY_WORDS;      // 224
 
 VRF_HD void sw_build_table(uint32_t* tab, size_t stride, const PtW& p) {
   PtW acc = p;
@@ -193,13 +199,13 @@ VRF_HD void sw_build_table(uint32_t* tab, size_t stride, const PtW& p) {
 #pragma unroll 1
   for (int j = 1; j < SW_WIN; ++j) {
     acc = sw_add(acc, p);
-    ptw_store(tab + (size_t)j * PTW_WORDS * stride, stride, acc);
+    ptw_store(tab + (size_t)j * SW_ENTRY_WORDS * stride, stride, acc);
   }
 }
 VRF_HD PtW sw_lookup(const uint32_t* tab, size_t stride, int digit) {      // digit in [-8, 8]
   const int mag = digit < 0 ? -digit : digit;
   const int idx = mag > 0 ? mag - 1 : 0;
-  PtW e = ptw_load(tab + (size_t)idx * PTW_WORDS * stride, stride);
+  PtW e = ptw_load(tab + (size_t)idx * SW_ENTRY_WORDS * stride, stride);
   e = sw_select(mag == 0, sw_identity(), e);
   return sw_cneg(digit < 0, e);
 }

@@ -257,7 +257,7 @@ def cpu_cores():
     return min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0)))
 
 
-def cpu_leg(fn, probe, budget_s, cap, unit, what):
+def cpu_leg(fn, probe, budget_s, cap, unit, what, src="oracle/c/oracle_vrf.c"):
     """fn(m) runs the oracle on the first m items.  Probe, then one bounded run of about budget_s seconds."""
     cores = cpu_cores()
     t0 = time.perf_counter()
@@ -269,7 +269,7 @@ def cpu_leg(fn, probe, budget_s, cap, unit, what):
     dt = time.perf_counter() - t0
     return {"value": m / dt, "unit": unit, "cores": cores, "kind": "port",
             "sample": "first %d items of the same batch, %.1f s wall on %d threads; %s" % (m, dt, cores, what),
-            "note": "CPU restatement in C (oracle/c/oracle_vrf.c), not arkworks: no Rust toolchain on this box"}
+            "note": "CPU restatement in C (%s), not arkworks: no Rust toolchain on this box" % src}
 
 
 # ------------------------------------------------------------------------------------------- configs
@@ -462,6 +462,7 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
         st = torch.empty(n, dtype=torch.uint8, device=D.dev)
         lg = args.log2_batch
         sw = tag == "secp256r1"
+        b_prove, b_verify = B_PROVE + (pw - 32), B_VERIFY + 3 * (pw - 32)      # one / three points of pw bytes instead of 32
         fn = lambda: cx.ietf_prove_batch_dev(sk, msg, 32, g, c, s_, pk, hh, st)
         fn(); torch.cuda.synchronize()
         cx.profile(True)
@@ -469,11 +470,12 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
         cx.profile(False)
         ms, groups = stage_avg(cx)
         assert int(st.sum()) == 0
-        rf, v = roofline("k_prove_mul (sk*H, sk*G, k*H, k*G: 2 lanes per proof)", B_PROVE, n, ms[1], groups, pmc_for("ietf_prove_" + tag, lg))
+        rf, v = roofline("k_p256_prove_mul (sk*G, sk*H, k*G, k*H: 4 lanes per proof, grid.y = 4)" if sw else
+                         "k_prove_mul (sk*H, sk*G, k*H, k*G: 2 lanes per proof)", b_prove, n, ms[1], groups, pmc_for("ietf_prove_" + tag, lg))
         res["ietf_prove_" + tag] = {
             "workload": "IETF ECVRF prove, %s, batch 2^%d per GPU (SURVEY.md section 8 f4)" % (title, lg),
             "value": D.world * n * args.config_steps / el, "unit": "proofs/s", "ms_per_step": el / args.config_steps * 1e3,
-            "bytes_per_unit": B_PROVE, "roofline": rf, "valu": v,
+            "bytes_per_unit": b_prove, "roofline": rf, "valu": v,
             "stage_ms_per_step": {"tai_find+prepare": ms[0], "mul": ms[1], "finish": ms[3]}}
         fn = lambda: cx.ietf_verify_batch_dev(pk, hh, g, c, s_, st)
         fn(); torch.cuda.synchronize()
@@ -486,13 +488,13 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
         kname = ("k_verify_decode (3 decompressions + subgroup tests + tables)", "k_verify_straus<1> (V = s*H - c*Gamma)",
                  "k_verify_straus<0> (U = s*G - c*Y)", "k_verify_finish")[heavy]
         if sw:
-            kname = ("k_p256_verify_decode", "k_p256_verify_mul (U = s*G - c*Y and V = s*H - c*Gamma, one launch, grid.y = 2)", "-",
+            kname = ("k_p256_verify_decode", "k_p256_verify_mul<1> (V = s*H - c*Gamma)", "k_p256_verify_mul<0> (U = s*G - c*Y)",
                      "k_p256_verify_finish")[heavy]
-        rf, v = roofline(kname, B_VERIFY, n, ms[heavy], groups, pmc_for("ietf_verify_" + tag, lg))
+        rf, v = roofline(kname, b_verify, n, ms[heavy], groups, pmc_for("ietf_verify_" + tag, lg))
         res["ietf_verify_" + tag] = {
             "workload": "IETF ECVRF verify, %s, batch 2^%d per GPU, compressed points, checked decode (SURVEY.md section 8 f4)" % (title, lg),
             "value": D.world * n * args.config_steps / el, "unit": "verifies/s", "ms_per_step": el / args.config_steps * 1e3,
-            "bytes_per_unit": B_VERIFY, "roofline": rf, "valu": v,
+            "bytes_per_unit": b_verify, "roofline": rf, "valu": v,
             "stage_ms_per_step": {"decode": ms[0], "straus_v": ms[1], "straus_u": ms[2], "finish": ms[3]}}
         cx.set_prevalidated(True)
         el_p, _ = timed(D, fn, max(2, args.config_steps), 1)
@@ -513,14 +515,15 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
                     ref = c_prove(skh[:k], msgs=msgh[:k], ad=b"", threads=cpu_cores())
                     assert (ref["output"] == gh[:k]).all() and (ref["c"] == ch[:k]).all() and (ref["s"] == sh[:k]).all(), \
                         "GPU proofs differ from the CPU oracle on the sample"
+                csrc = "oracle/c/oracle_p256.c" if sw else "oracle/c/oracle_vrf.c"
                 res["ietf_prove_" + tag]["cpu_baseline"] = cpu_leg(leg_p, 16 * cpu_cores(), args.cpu_seconds / 2, cap, "proofs/s",
-                                                                   "proof bytes equal the GPU's")
+                                                                   "proof bytes equal the GPU's", csrc)
 
                 def leg_v(k):
                     stv = c_verify(pkh[:k], hhh[:k], gh[:k], ch[:k], sh[:k], b"", threads=cpu_cores())
                     assert not stv.any(), "CPU oracle rejects GPU-made proofs"
                 res["ietf_verify_" + tag]["cpu_baseline"] = cpu_leg(leg_v, 16 * cpu_cores(), args.cpu_seconds / 2, cap, "verifies/s",
-                                                                    "statuses equal the GPU's")
+                                                                    "statuses equal the GPU's", csrc)
             finally:
                 if not sw:
                     co.set_suite(1)

@@ -339,3 +339,117 @@ impl<S: GpuSuite> Drop for GpuBatch<S> {
         }
     }
 }
+
+/// `suites::secp256r1` ("P256_SHA256_TAI"): the suite whose codec is `Sec1Codec` -- 33-byte compressed points, big-endian
+/// scalars -- and whose hash is SHA-256.  libvrfhip runs it behind the same entry points with that wire format
+/// (`VRFHIP_SUITE_SECP256R1_SHA256_TAI`; `vrfhip_ctx_point_bytes` = 33), IETF scheme only, so this type moves encoded
+/// values instead of coordinates: `codec::point_encode` / `scalar_encode` in, `codec::point_decode` / `scalar_decode` out.
+pub struct GpuBatchSec1 {
+    ctxs: Vec<*mut ffi::vrfhip_ctx>,
+}
+
+unsafe impl Send for GpuBatchSec1 {}
+unsafe impl Sync for GpuBatchSec1 {}
+
+type P256 = suites::secp256r1::P256Sha256Tai;
+const SEC1: usize = 33;
+
+impl GpuBatchSec1 {
+    pub fn new(devices: &[i32]) -> Result<Self, GpuError> {
+        let mut this = GpuBatchSec1 { ctxs: Vec::new() };
+        for &dev in devices {
+            let mut ctx: *mut ffi::vrfhip_ctx = core::ptr::null_mut();
+            check(unsafe { ffi::vrfhip_ctx_create(ffi::VRFHIP_SUITE_SECP256R1_SHA256_TAI, dev, &mut ctx) })?;
+            debug_assert_eq!(unsafe { ffi::vrfhip_ctx_point_bytes(ctx) }, SEC1);
+            this.ctxs.push(ctx);
+        }
+        Ok(this)
+    }
+
+    fn put_point(p: &AffinePoint<P256>, out: &mut [u8]) {
+        let mut v = Vec::with_capacity(SEC1);
+        codec::point_encode_into::<P256>(p, &mut v);
+        out.copy_from_slice(&v); // a `Public` / `Input` / `Output` is never the point at infinity: always 33 bytes
+    }
+
+    fn put_scalar(k: &ScalarField<P256>, out: &mut [u8]) {
+        let mut v = Vec::with_capacity(32);
+        codec::scalar_encode_into::<P256>(k, &mut v);
+        out.copy_from_slice(&v);
+    }
+
+    /// `Secret::output` + `ietf::Prover::prove` per (secret, input) pair.
+    pub fn ietf_prove(
+        &self,
+        secrets: &[Secret<P256>],
+        inputs: &[Input<P256>],
+        ad: &[u8],
+    ) -> Result<Vec<Result<(Output<P256>, ietf::Proof<P256>), Error>>, GpuError> {
+        let n = secrets.len();
+        assert_eq!(n, inputs.len());
+        let (mut sk, mut h) = (vec![0u8; n * 32], vec![0u8; n * SEC1]);
+        for i in 0..n {
+            Self::put_scalar(&secrets[i].scalar, &mut sk[i * 32..(i + 1) * 32]);
+            Self::put_point(&inputs[i].0, &mut h[i * SEC1..(i + 1) * SEC1]);
+        }
+        let (mut gamma, mut c, mut s) = (vec![0u8; n * SEC1], vec![0u8; n * 32], vec![0u8; n * 32]);
+        let mut status = vec![0u8; n];
+        check(unsafe {
+            ffi::vrfhip_ietf_prove_batch_multi(
+                self.ctxs.as_ptr(), self.ctxs.len() as i32, n, sk.as_ptr(), core::ptr::null(), core::ptr::null(), 0,
+                h.as_ptr(), ad.as_ptr(), core::ptr::null(), ad.len() as u32, gamma.as_mut_ptr(), c.as_mut_ptr(),
+                s.as_mut_ptr(), core::ptr::null_mut(), core::ptr::null_mut(), status.as_mut_ptr(),
+            )
+        })?;
+        sk.iter_mut().for_each(|b| *b = 0);
+        Ok((0..n)
+            .map(|i| {
+                status_to_result(status[i])?;
+                let out = Output::<P256>::from(codec::point_decode::<P256>(&gamma[i * SEC1..(i + 1) * SEC1])?);
+                let proof = ietf::Proof::<P256> {
+                    c: codec::scalar_decode::<P256>(&c[i * 32 + 16..(i + 1) * 32]), // the challenge's 16 significant bytes
+                    s: codec::scalar_decode::<P256>(&s[i * 32..(i + 1) * 32]),
+                };
+                Ok((out, proof))
+            })
+            .collect())
+    }
+
+    /// `ietf::Verifier::verify` per item.
+    pub fn ietf_verify(
+        &self,
+        publics: &[Public<P256>],
+        inputs: &[Input<P256>],
+        outputs: &[Output<P256>],
+        ad: &[u8],
+        proofs: &[ietf::Proof<P256>],
+    ) -> Result<Vec<Result<(), Error>>, GpuError> {
+        let n = publics.len();
+        assert!(n == inputs.len() && n == outputs.len() && n == proofs.len());
+        let (mut pk, mut h, mut g) = (vec![0u8; n * SEC1], vec![0u8; n * SEC1], vec![0u8; n * SEC1]);
+        let (mut c, mut s) = (vec![0u8; n * 32], vec![0u8; n * 32]);
+        for i in 0..n {
+            Self::put_point(&publics[i].0, &mut pk[i * SEC1..(i + 1) * SEC1]);
+            Self::put_point(&inputs[i].0, &mut h[i * SEC1..(i + 1) * SEC1]);
+            Self::put_point(&outputs[i].0, &mut g[i * SEC1..(i + 1) * SEC1]);
+            Self::put_scalar(&proofs[i].c, &mut c[i * 32..(i + 1) * 32]);
+            Self::put_scalar(&proofs[i].s, &mut s[i * 32..(i + 1) * 32]);
+        }
+        let mut status = vec![0u8; n];
+        check(unsafe {
+            ffi::vrfhip_ietf_verify_batch_multi(
+                self.ctxs.as_ptr(), self.ctxs.len() as i32, n, pk.as_ptr(), h.as_ptr(), g.as_ptr(), c.as_ptr(), s.as_ptr(),
+                ad.as_ptr(), core::ptr::null(), ad.len() as u32, status.as_mut_ptr(),
+            )
+        })?;
+        Ok(status.into_iter().map(status_to_result).collect())
+    }
+}
+
+impl Drop for GpuBatchSec1 {
+    fn drop(&mut self) {
+        for &c in &self.ctxs {
+            unsafe { ffi::vrfhip_ctx_destroy(c) };
+        }
+    }
+}

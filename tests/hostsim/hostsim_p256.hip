@@ -19,11 +19,7 @@ std::vector<uint32_t>& comb() {
   static std::vector<uint32_t> c;
   if (c.empty()) {
     c.assign(P256_COMB_WORDS, 0);
-    PtW base = sw_from_affine(fe_const(vrfk::P256_GX_M), fe_const(vrfk::P256_GY_M));
-    for (int w = 0; w < P256_COMB_ROWS; ++w) {
-      sw_build_table(c.data() + (size_t)w * SW_TABLE_WORDS, 1, base);
-      for (int j = 0; j < 4; ++j) base = sw_dbl(base);
-    }
+    for (int w = 0; w < P256_COMB_ROWS; ++w) p256_comb_build_row(c.data(), w, fe_const(vrfk::P256_GX_M), fe_const(vrfk::P256_GY_M));
   }
   return c;
 }

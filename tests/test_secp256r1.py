@@ -162,9 +162,10 @@ def test_complete_group_law(hp):
         assert _pt(hp.hp_dbl, xy(A)) == sw.add(A, A)
         for z in (1, rnd.randrange(1, P), P - 1):       # the Jacobian doubling run between windows; infinity stays infinity
             assert _pt(hp.hp_dbl4, xy(A), be(z)) == sw.mul(16, A)
-    for it in range(24):
-        k = [0, 1, 2, N - 1, N - 2, (1 << 255), (1 << 256) - 1 - (1 << 32), 0x8888888888888888888888888888888888888888888888888888888888888888,
-             0x7777777777777777777777777777777777777777777777777777777777777777][it] if it < 9 else rnd.getrandbits(256)
+    special = [0, 1, 2, N - 1, N - 2, (1 << 255), (1 << 256) - 1 - (1 << 32), int("88" * 32, 16), int("77" * 32, 16),
+               int("80" * 32, 16), int("7f" * 32, 16), int("7f80" * 16, 16), int("ff" * 31 + "00", 16) % N, 128, 127, 255, 256]
+    for it in range(len(special) + 15):
+        k = special[it] if it < len(special) else rnd.getrandbits(256)
         A = pts[it % 10]
         # scalars enter the ladders reduced mod n; k >= n is reduced by the caller (p256_scalar_decode)
         kk = k % N
