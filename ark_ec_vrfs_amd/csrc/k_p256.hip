@@ -112,13 +112,13 @@ __global__ void __launch_bounds__(P256_BLOCK) __attribute__((amdgpu_waves_per_eu
   if constexpr (WHICH == 0) {
     uint32_t* ty = ws_tab(a.ws.tabs, cap, i, 0);
     sw_build_table(ty, 1, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 0), ws_load_fe(a.ws.aff, cap, i, 9)));
-    ptw_store(ws_pt(a.ws.pts, cap, i, 0), cap, sw_comb_minus_win(a.comb, ty, 1, s, c));
+    ptw_store(ws_pt(a.ws.pts, cap, i, 0), cap, sw_comb_minus_win(a.comb, ty, 1, s, c, sw_challenge_windows(a.str)));
   } else {
     uint32_t* th = ws_tab(a.ws.tabs, cap, i, 1);
     uint32_t* tg = ws_tab(a.ws.tabs, cap, i, 2);
     sw_build_table(th, 1, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 18), ws_load_fe(a.ws.aff, cap, i, 27)));
     sw_build_table(tg, 1, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 36), ws_load_fe(a.ws.aff, cap, i, 45)));
-    ptw_store(ws_pt(a.ws.pts, cap, i, 1), cap, sw_straus_sc(th, tg, 1, s, c));
+    ptw_store(ws_pt(a.ws.pts, cap, i, 1), cap, sw_straus_sc(th, tg, 1, s, c, sw_challenge_windows(a.str)));
   }
 }
 

@@ -307,11 +307,16 @@ VRF_HD PtW sw_comb_mul(const uint32_t* comb, const uint32_t k[8]) {
   return acc;
 }
 
-// s * P - c * Q with c < 2^128 (the challenge): Straus over the two tables: 256 doublings, 65 + 33 additions
-VRF_HD PtW sw_straus_sc(const uint32_t* tabP, const uint32_t* tabQ, size_t stride, const uint32_t s[8], const uint32_t c[8]) {
+// Windows the challenge can occupy: it is the first `challenge_len` bytes of a hash, so digits 0 .. 2 challenge_len (the
+// last one is the recoding's carry); 33 for the suite's 16 bytes, all 65 when a descriptor asks for 32.  A proof whose c
+// field is larger than that cannot verify whatever the ladders compute (the recomputed challenge is below the bound).
+VRF_HD int sw_challenge_windows(const SuiteStr& ss) { return (int)(2u * ss.challenge_len + 1u); }
+
+// s * P - c * Q with c the challenge (cw windows): Straus over the two tables: 256 doublings, 65 + cw additions
+VRF_HD PtW sw_straus_sc(const uint32_t* tabP, const uint32_t* tabQ, size_t stride, const uint32_t s[8], const uint32_t c[8], int cw) {
   uint32_t srec[8], crec[8];
   const uint32_t stop = sw_recode(srec, s);
-  (void)sw_recode(crec, c);                              // c < 2^128: only digits 0..32 can be non-zero
+  const uint32_t ctop = sw_recode(crec, c);
   PtW acc = sw_identity();
 #pragma unroll 1
   for (int w = SW_WINDOWS - 1; w >= 0; --w) {
@@ -319,22 +324,22 @@ VRF_HD PtW sw_straus_sc(const uint32_t* tabP, const uint32_t* tabQ, size_t strid
       acc = sw_dbl4(acc);
     }
     acc = sw_add(acc, sw_lookup(tabP, stride, sw_digit(srec, stop, w)));
-    if (w <= 32)                                         // wave-uniform
-      acc = sw_add(acc, sw_lookup(tabQ, stride, -scalar_digit4(crec, w)));
+    if (w < cw)                                          // wave-uniform
+      acc = sw_add(acc, sw_lookup(tabQ, stride, -sw_digit(crec, ctop, w)));
   }
   return acc;
 }
 // s * G - c * Q: the generator's half comes from the comb after the ladder (no doublings for it)
-VRF_HD PtW sw_comb_minus_win(const uint32_t* comb, const uint32_t* tabQ, size_t stride, const uint32_t s[8], const uint32_t c[8]) {
+VRF_HD PtW sw_comb_minus_win(const uint32_t* comb, const uint32_t* tabQ, size_t stride, const uint32_t s[8], const uint32_t c[8], int cw) {
   uint32_t crec[8];
-  (void)sw_recode(crec, c);
+  const uint32_t ctop = sw_recode(crec, c);
   PtW acc = sw_identity();
 #pragma unroll 1
-  for (int w = 32; w >= 0; --w) {
-    if (w != 32) {
+  for (int w = cw - 1; w >= 0; --w) {
+    if (w != cw - 1) {
       acc = sw_dbl4(acc);
     }
-    acc = sw_add(acc, sw_lookup(tabQ, stride, -scalar_digit4(crec, w)));
+    acc = sw_add(acc, sw_lookup(tabQ, stride, -sw_digit(crec, ctop, w)));
   }
   return sw_add(acc, sw_comb_mul(comb, s));
 }
@@ -360,11 +365,14 @@ VRF_HD void sw_to_sec1(Sec1W (&out)[N], const PtW (&p)[N]) {
   }
 }
 
-// 32-byte big-endian scalar -> words mod n (`Sec1Codec::scalar_decode` = from_be_bytes_mod_order)
-VRF_HD void p256_scalar_decode(uint32_t out[8], const uint8_t* be) {
+// 32-byte big-endian scalar -> words mod n (`Sec1Codec::scalar_decode` = from_be_bytes_mod_order); returns whether the
+// integer was canonical (< n).  As for the Edwards suites (and RFC 9381 5.4.4: "if s >= q, output INVALID"), the proof's s
+// and a secret key must be canonical; the challenge c is taken mod n, which is what upstream's `Proof` decoding does.
+VRF_HD bool p256_scalar_decode(uint32_t out[8], const uint8_t* be) {
   uint32_t w[8];
   load_be256(w, be);
   fr_reduce256<CurveP256>(out, w);
+  return fr_is_canonical<CurveP256>(w);
 }
 
 // ---- IETF verify, per item [ref src/lib.rs:14 `ietf::Verifier::verify`, RFC 9381 5.3] ----
@@ -385,9 +393,8 @@ VRF_HD bool p256_verify_decode_item(FeN (&x)[3], FeN (&y)[3], Sec1W (&enc)[3], u
     for (int k = 0; k < 3; ++k)
       if (j == k) { x[k] = xx; y[k] = yy; enc[k] = w; }
   }
-  p256_scalar_decode(c, cb);
-  p256_scalar_decode(s, sb);
-  return ok;
+  (void)p256_scalar_decode(c, cb);
+  return p256_scalar_decode(s, sb) && ok;
 }
 // stage 3: c' = challenge(pk, H, Gamma, U, V, ad) == c.  1 = the proof does not verify
 VRF_HD uint8_t p256_verify_finish_item(const PtW& U, const PtW& V, const Sec1W (&enc)[3], const uint32_t c[8],
@@ -409,7 +416,7 @@ VRF_HD uint8_t p256_verify_finish_item(const PtW& U, const PtW& V, const Sec1W (
 // undecodable given H)
 VRF_HD bool p256_prove_prepare_item(uint32_t sk[8], uint32_t k[8], FeN& hx, FeN& hy, Sec1W& henc, const uint8_t* sk_be,
                                     const uint8_t* msg, uint32_t msg_len, const uint8_t* h_given, const SuiteStr& ss) {
-  p256_scalar_decode(sk, sk_be);
+  const bool sk_ok = p256_scalar_decode(sk, sk_be);
   bool ok;
   if (h_given) {
     ok = sec1_decode(hx, hy, h_given);
@@ -420,7 +427,7 @@ VRF_HD bool p256_prove_prepare_item(uint32_t sk[8], uint32_t k[8], FeN& hx, FeN&
     henc.tag = 2u;
   }
   p256_nonce(k, sk, henc.tag, henc.xw);
-  return ok;
+  return ok && sk_ok;
 }
 // stage 3: res = {pk = sk G, Gamma = sk H, U = k G, V = k H}: c = challenge, s = k + c sk (mod n)
 VRF_HD void p256_prove_finish_item(Sec1W& pk, Sec1W& gamma, uint32_t c[8], uint32_t s[8], const PtW (&res)[4],

@@ -70,7 +70,9 @@ typedef enum vrfhip_suite {
    * Weierstrass curve of prime order (cofactor 1), SHA-256, `Sec1Codec`, `nonce_rfc_6979`, try-and-increment,
    * `CHALLENGE_LEN = 16`.  This suite has its OWN WIRE FORMAT at every entry point that accepts it: points are 33-byte SEC1
    * compressed strings (0x02 / 0x03 || x big-endian), scalars (secret keys, `c`, `s`) 32-byte BIG-endian integers (`c` has
-   * 16 significant bytes), `Output::hash` is 32 bytes (vrfhip_ctx_point_bytes / vrfhip_ctx_hash_bytes tell).  Entry points:
+   * 16 significant bytes), `Output::hash` is 32 bytes (vrfhip_ctx_point_bytes / vrfhip_ctx_hash_bytes tell).  As in the
+   * other suites a secret key and the proof's `s` must be canonical (< n, else InvalidData: RFC 9381 5.4.4) while `c` is taken
+   * mod n; a point needs tag 0x02 / 0x03, x < p and to lie on the curve (cofactor 1: no subgroup test).  Entry points:
    * vrfhip_ietf_prove_batch / _verify_batch (+ _dev, _multi), vrfhip_hash_to_curve_batch, vrfhip_output_hash_batch,
    * vrfhip_secret_from_seed_batch, vrfhip_point_validate_batch (+ _dev); everything else returns VRFHIP_ERR_UNSUPPORTED
    * (Pedersen / MSM / key sets / x||y forms are not built for it).  Pinned by RFC 9381 Appendix B.1, which upstream's own

@@ -320,6 +320,7 @@ int p256_ietf_prove(const uint8_t sk_be[32], const uint8_t* msg, size_t msg_len,
   ensure_init();
   uint64_t t[4], sk[4], k[4];
   load_be(t, sk_be); reduce256(&FN, sk, t);
+  if (cmp4(t, N_M) >= 0) return 2;               /* a secret key is a canonical scalar (as the Edwards suites hold it) */
   jac H, G, Y, Gam, U, V;
   uint8_t henc[33], pk[33], uenc[33], venc[33];
   if (h_given) { if (!sec1_decode(&H, h_given)) return 2; memcpy(henc, h_given, 33); }
@@ -350,6 +351,7 @@ int p256_ietf_verify(const uint8_t pk[33], const uint8_t h[33], const uint8_t ga
   uint64_t t[4], c[4], s[4], cc[4];
   load_be(t, c_be); reduce256(&FN, c, t);
   load_be(t, s_be); reduce256(&FN, s, t);
+  if (cmp4(t, N_M) >= 0) return 2;               /* RFC 9381 5.4.4: s >= q is INVALID (upstream deserialises s strictly) */
   jac_from_affine(&G, &GX_M, &GY_M);
   jac_mul(&t1, &G, s); jac_mul(&t2, &Y, c); jac_neg(&t2, &t2); jac_add(&U, &t1, &t2);
   jac_mul(&t1, &H, s); jac_mul(&t2, &Gam, c); jac_neg(&t2, &t2); jac_add(&V, &t1, &t2);

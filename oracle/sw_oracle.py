@@ -142,18 +142,20 @@ def output_hash(gamma: Point, suite_id: bytes = SUITE_ID) -> bytes:
     return sha256(suite_id + b"\x03" + point_encode(gamma) + b"\x00")
 
 
-def ietf_prove(sk: int, h: Point, ad: bytes):
-    """[ref src/lib.rs:14 `ietf::Prover::prove`] -> (gamma, c, s)."""
+def ietf_prove(sk: int, h: Point, ad: bytes, suite_id: bytes = SUITE_ID, challenge_len: int = CHALLENGE_LEN, gen: Point = G):
+    """[ref src/lib.rs:14 `ietf::Prover::prove`] -> (gamma, c, s).  suite_id / challenge_len / gen: what a `Suite` impl
+    states as data (the product takes them from the descriptor)."""
     gamma, k = mul(sk, h), nonce_rfc6979(sk, h)
-    c = challenge([mul(sk, G), h, gamma, mul(k, G), mul(k, h)], ad)
+    c = challenge([mul(sk, gen), h, gamma, mul(k, gen), mul(k, h)], ad, suite_id, challenge_len)
     return gamma, c, (k + c * sk) % N
 
 
-def ietf_verify(pk: Point, h: Point, gamma: Point, ad: bytes, c: int, s: int) -> bool:
+def ietf_verify(pk: Point, h: Point, gamma: Point, ad: bytes, c: int, s: int, suite_id: bytes = SUITE_ID,
+                challenge_len: int = CHALLENGE_LEN, gen: Point = G) -> bool:
     """[ref src/lib.rs:14 `ietf::Verifier::verify`]"""
-    u = add(mul(s, G), neg(mul(c, pk)))
+    u = add(mul(s, gen), neg(mul(c, pk)))
     v = add(mul(s, h), neg(mul(c, gamma)))
-    return challenge([pk, h, gamma, u, v], ad) == c % N
+    return challenge([pk, h, gamma, u, v], ad, suite_id, challenge_len) == c % N
 
 
 def rfc9381_prove(sk_bytes: bytes, alpha: bytes) -> dict:

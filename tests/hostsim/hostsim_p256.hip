@@ -56,7 +56,7 @@ int hp_fe_jacobi(const uint8_t* a) { FeN c = fe_canon(in(a)); return jacobi_limb
 // ---- scalars mod n (big-endian) ----
 void hp_fr_mul_add(const uint8_t* a, const uint8_t* b, const uint8_t* c, uint8_t* r) {
   uint32_t x[8], y[8], z[8], t[8], o[8];
-  p256_scalar_decode(x, a); p256_scalar_decode(y, b); p256_scalar_decode(z, c);
+  (void)p256_scalar_decode(x, a); (void)p256_scalar_decode(y, b); (void)p256_scalar_decode(z, c);
   fr_mul<CurveP256>(t, x, y); fr_add<CurveP256>(o, t, z); store_be256(r, o);
 }
 // ---- group law (affine big-endian x || y; all zero = infinity) ----
@@ -99,7 +99,7 @@ int hp_hash_to_curve(const uint8_t* data, uint32_t len, uint8_t* enc33) {
   return ok;
 }
 void hp_nonce(const uint8_t* sk_be, const uint8_t* h33, uint8_t* k_be) {
-  uint32_t sk[8], k[8], xw[8]; p256_scalar_decode(sk, sk_be); load_be256(xw, h33 + 1);
+  uint32_t sk[8], k[8], xw[8]; (void)p256_scalar_decode(sk, sk_be); load_be256(xw, h33 + 1);
   p256_nonce(k, sk, h33[0], xw); store_be256(k_be, k);
 }
 void hp_output_hash(const uint8_t* g33, uint8_t* beta) {
@@ -131,8 +131,8 @@ int hp_verify(const uint8_t* pk, const uint8_t* h, const uint8_t* gamma, const u
   sw_build_table(ty.data(), 1, sw_from_affine(x[0], y[0]));
   sw_build_table(th.data(), 1, sw_from_affine(x[1], y[1]));
   sw_build_table(tg.data(), 1, sw_from_affine(x[2], y[2]));
-  PtW U = sw_comb_minus_win(comb().data(), ty.data(), 1, s, c);
-  PtW V = sw_straus_sc(th.data(), tg.data(), 1, s, c);
+  PtW U = sw_comb_minus_win(comb().data(), ty.data(), 1, s, c, sw_challenge_windows(g_str));
+  PtW V = sw_straus_sc(th.data(), tg.data(), 1, s, c, sw_challenge_windows(g_str));
   return p256_verify_finish_item(U, V, enc, c, ad, ad_len, g_str);
 }
 }

@@ -237,6 +237,32 @@ def test_rfc9381_b1_vectors_through_the_host_build(hp):
         assert hp.hp_prove(sk, None, 0, o[33:66], b"", 0, out2) == 1 and out2.raw == o
 
 
+@pytest.mark.parametrize("clen", [20, 32, 1])
+def test_host_build_with_another_suite_string_and_challenge_length(hp, clen):
+    sid = b"custom-p256-suite"
+    hp.hp_set_suite(sid, len(sid), clen)
+    try:
+        for i in range(3):
+            sk = sw.secret_from_seed(b"q%d" % i)
+            msg = b"abc" * (i + 1)
+            H, _ = sw.hash_to_curve_tai(msg, sid)
+            g, c, s = sw.ietf_prove(sk, H, b"x", sid, clen)
+            out = ctypes.create_string_buffer(261)
+            assert hp.hp_prove(be(sk), msg, len(msg), None, b"x", 1, out) == 1
+            o = out.raw
+            assert o[33:66] == sw.point_encode(H) and o[66:99] == sw.point_encode(g) and o[99:131] == be(c) and o[131:163] == be(s)
+            assert (c >> 128) or clen < 17                      # a 20-byte challenge really is longer than 16
+            assert hp.hp_verify(o[:33], o[33:66], o[66:99], o[99:131], o[131:163], b"x", 1) == 0
+            assert hp.hp_verify(o[:33], o[33:66], o[66:99], be(c ^ (1 << (8 * clen - 1))), o[131:163], b"x", 1) == 1
+            if clen < 32:
+                assert hp.hp_verify(o[:33], o[33:66], o[66:99], be(c | (1 << (8 * clen + 3))), o[131:163], b"x", 1) == 1
+            beta = ctypes.create_string_buffer(32)
+            hp.hp_output_hash(o[66:99], beta)
+            assert beta.raw == sw.output_hash(g, sid)
+    finally:
+        hp.hp_set_suite(b"\x01", 1, 16)
+
+
 def test_host_build_prove_and_verify_equal_the_oracle(hp):
     rnd = random.Random(7)
     for i in range(6):
@@ -254,7 +280,9 @@ def test_host_build_prove_and_verify_equal_the_oracle(hp):
         assert hp.hp_verify(pk, h, g, be(c), be(s), ad + b"x", len(ad) + 1) == 1
         assert hp.hp_verify(pk, h, g, be(c ^ 1), be(s), ad, len(ad)) == 1
         assert hp.hp_verify(pk, h, g, be(c), be((s + 1) % N), ad, len(ad)) == 1
-        assert hp.hp_verify(pk, h, g, be(c), be(s + N) if s + N < (1 << 256) else be(s), ad, len(ad)) == 0     # s mod n, as upstream
+        if s + N < (1 << 256):
+            assert hp.hp_verify(pk, h, g, be(c), be(s + N), ad, len(ad)) == 2                                 # s >= n: RFC 9381 5.4.4
+        assert hp.hp_verify(pk, h, g, be(c + N) if c + N < (1 << 256) else be(c), be(s), ad, len(ad)) == 0   # c mod n, as upstream
         assert hp.hp_verify(pk, h, g, be(c + (1 << 128)), be(s), ad, len(ad)) == 1                           # c is 16 bytes
         other = sw.point_encode(sw.mul(rnd.randrange(1, N), G))
         assert hp.hp_verify(other, h, g, be(c), be(s), ad, len(ad)) == 1
@@ -341,11 +369,13 @@ def test_gpu_prove_and_verify_equal_the_oracle(gpu):
         want[i] = [0, 1, 1, 1, 2, 2, 1, 2][kind]
     got = gpu.ietf_verify_batch(pkt, ht, gt, ct, st_, ad=ads)
     assert (got == want).all(), (got, want)
-    # s taken mod n, as upstream's scalar_decode: s + n verifies when it still fits 256 bits
-    s0 = int.from_bytes(r["s"][0].tobytes(), "big")
+    # a non-canonical s is InvalidData (RFC 9381 5.4.4; upstream deserialises s strictly), c is taken mod n
+    s0, c0 = int.from_bytes(r["s"][0].tobytes(), "big"), int.from_bytes(r["c"][0].tobytes(), "big")
     if s0 + N < (1 << 256):
         s2 = r["s"].copy(); s2[0] = np.frombuffer(be(s0 + N), np.uint8)
-        assert gpu.ietf_verify_batch(pk, r["input"], r["output"], r["c"], s2, ad=ads)[0] == 0
+        assert gpu.ietf_verify_batch(pk, r["input"], r["output"], r["c"], s2, ad=ads)[0] == 2
+    c2 = r["c"].copy(); c2[0] = np.frombuffer(be(c0 + N), np.uint8)
+    assert gpu.ietf_verify_batch(pk, r["input"], r["output"], c2, r["s"], ad=ads)[0] == 0
     # point validation
     pts = _u8([sw.point_encode(sw.mul(7, G)), b"\x02" + be(offx), b"\x05" + be(G[0]), b"\x03" + be(P), b"\x03" + be(G[0])])
     stv, xyv = gpu.point_validate_batch(pts, want_xy=True)
@@ -402,13 +432,18 @@ def test_gpu_whole_batch_equals_the_c_oracle(gpu):
         sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
         sk[0] = 0; sk[0, 31] = 1                       # sk = 1
         sk[1] = np.frombuffer(be(N - 1), np.uint8)     # sk = n - 1
-        sk[2] = np.frombuffer(be(N + 5), np.uint8)     # reduced mod n, as scalar_decode does
+        sk[2] = np.frombuffer(be(N + 5), np.uint8)     # not a canonical scalar: InvalidData
+        sk[3] = np.frombuffer(be(N), np.uint8)
         msg = rng.integers(0, 256, (n, 40), dtype=np.uint8)
         r = gpu.ietf_prove_batch(sk, msgs=msg, ad=b"soak")
         ref = co.p256_ietf_prove_batch(sk, msgs=msg, ad=b"soak", threads=8)
+        good = np.ones(n, bool); good[2:4] = False
         for k in ("output", "c", "s", "pk", "input"):
-            assert (r[k] == ref[k]).all(), k
-        assert (r["status"] == 0).all() and (ref["status"] == 0).all()
+            assert (r[k][good] == ref[k][good]).all(), k
+            assert not r[k][~good].any()                      # a failed item's outputs are all-zero
+        assert (r["status"] == ref["status"]).all() and list(r["status"][:5]) == [0, 0, 2, 2, 0]
+        for k in ("output", "c", "s", "pk", "input"):         # the verifier below gets decodable bytes for those two
+            r[k][~good] = r[k][4]
         pkt, ht, gt, ct, st_ = (x.copy() for x in (r["pk"], r["input"], r["output"], r["c"], r["s"]))
         kind = rng.integers(0, 9, n)
         for i in range(n):
@@ -424,12 +459,50 @@ def test_gpu_whole_batch_equals_the_c_oracle(gpu):
         want = co.p256_ietf_verify_batch(pkt, ht, gt, ct, st_, ad=b"soak", threads=8)
         assert (got == want).all(), np.nonzero(got != want)[0][:10]
         assert set(np.unique(want)) == {0, 1, 2}
-        assert (gpu.hash_to_curve_batch(msg[:512]) == r["input"][:512]).all()
+        assert (gpu.hash_to_curve_batch(msg[:512]) == ref["input"][:512])[good[:512]].all()
         assert [h.tobytes() for h in gpu.output_hash_batch(r["output"][:64])] == [co.p256_output_hash(x.tobytes()) for x in r["output"][:64]]
         stv = gpu.point_validate_batch(gt)
         assert list(stv) == [co.p256_point_decode(x.tobytes()) for x in gt]
     finally:
         gpu.reserve(1 << 20)
+
+
+@pytest.mark.gpu
+def test_gpu_descriptor_supplies_suite_string_challenge_length_and_generator():
+    """The suite's data comes from the descriptor: a 17-byte suite string (not a multiple of the hash's word), a 20-byte
+    challenge and another generator, against the oracle given the same data; a generator off the curve is refused."""
+    from ark_ec_vrfs_amd import Context, SuiteDesc, CURVE_SECP256R1, VrfHipError
+    sid, clen, gen = b"custom-p256-suite", 20, sw.mul(7, G)
+    le64 = lambda pt: int(pt[0]).to_bytes(32, "little") + int(pt[1]).to_bytes(32, "little")
+    ctx = Context(0, desc=SuiteDesc(CURVE_SECP256R1, sid, b"", le64(gen), bytes(64), challenge_len=clen))
+    try:
+        d = ctx.desc()
+        assert d.suite_id == sid and d.challenge_len == clen and d.curve == CURVE_SECP256R1
+        n = 6
+        sks = [sw.secret_from_seed(b"k%d" % i) for i in range(n)]
+        msgs = [b"m%d" % i * (i + 1) for i in range(n)]
+        r = ctx.ietf_prove_batch(_u8(be(k) for k in sks), msgs=msgs, ad=b"dd")
+        assert (r["status"] == 0).all()
+        for i in range(n):
+            H, _ = sw.hash_to_curve_tai(msgs[i], sid)
+            g, c, s = sw.ietf_prove(sks[i], H, b"dd", sid, clen, gen)
+            assert r["input"][i].tobytes() == sw.point_encode(H) and r["output"][i].tobytes() == sw.point_encode(g)
+            assert r["pk"][i].tobytes() == sw.point_encode(sw.mul(sks[i], gen))
+            assert r["c"][i].tobytes() == be(c) and r["s"][i].tobytes() == be(s) and c >= (1 << 128) or r["c"][i].tobytes() == be(c)
+            assert ctx.output_hash_batch(r["output"][i:i + 1])[0].tobytes() == sw.output_hash(g, sid)
+        assert (ctx.ietf_verify_batch(r["pk"], r["input"], r["output"], r["c"], r["s"], ad=b"dd") == 0).all()
+        assert (ctx.ietf_verify_batch(r["pk"], r["input"], r["output"], r["c"], r["s"], ad=b"de") == 1).all()
+        seeds = _u8(b"seed%04d" % i for i in range(4))
+        sk2, pk2 = ctx.secret_from_seed_batch(seeds)
+        for i in range(4):
+            k = sw.secret_from_seed(seeds[i].tobytes())
+            assert sk2[i].tobytes() == be(k) and pk2[i].tobytes() == sw.point_encode(sw.mul(k, gen))
+    finally:
+        ctx.close()
+    with pytest.raises(VrfHipError):
+        Context(0, desc=SuiteDesc(CURVE_SECP256R1, sid, b"", le64((gen[0], gen[1] ^ 1)), bytes(64), challenge_len=clen))
+    with pytest.raises(VrfHipError):
+        Context(0, desc=SuiteDesc(CURVE_SECP256R1, sid, b"", le64(gen), bytes(64), challenge_len=clen, flags=1))
 
 
 @pytest.mark.gpu
