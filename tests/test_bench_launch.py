@@ -59,8 +59,9 @@ def test_parent_process_imports_no_gpu_runtime_before_spawning():
 
 
 def test_recorded_bench_lines_carry_the_contract_keys():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02", "bench_n1*.json")))
-    assert files, "no recorded bench line under profiles/r02"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02", "bench_n1*.json")) +
+                   glob.glob(os.path.join(ROOT, "profiles", "r03", "bench_n1*.json")))
+    assert any("r03" in f for f in files), "no recorded bench line under profiles/r03"
     for f in files:
         d = json.loads(open(f).read().strip().splitlines()[-1])
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -69,6 +70,12 @@ def test_recorded_bench_lines_carry_the_contract_keys():
         assert d["config"]["workload"] and d["roofline"]["bound"] == "hbm" and d["vs_baseline"] is None
         r = d["roofline"]
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        if "r03" in f:              # this round's line: the CPU leg, the issue-slot block, both scaling modes, every f4 suite
+            assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+            assert 0.5 < d["valu"]["issue_slot_frac"] < 1.2 and set(d["scaling_modes"]) == {"weak", "strong"}
+            for leg in ("ietf_prove", "pedersen_verify_jubjub", "ietf_verify_ed25519", "ietf_verify_babyjubjub",
+                        "ietf_prove_secp256r1", "ietf_verify_secp256r1", "pairing_check"):
+                assert d["configs"][leg]["value"] > 0, leg
 
 
 def test_secondary_leg_results_merge_across_ranks():

@@ -376,6 +376,17 @@ def test_gpu_prove_and_verify_equal_the_oracle(gpu):
         assert gpu.ietf_verify_batch(pk, r["input"], r["output"], r["c"], s2, ad=ads)[0] == 2
     c2 = r["c"].copy(); c2[0] = np.frombuffer(be(c0 + N), np.uint8)
     assert gpu.ietf_verify_batch(pk, r["input"], r["output"], c2, r["s"], ad=ads)[0] == 0
+    # corners of the group law built from valid bytes: c = 1, s = sk makes U = s G - c Y the point at infinity (hashed as
+    # the single byte 0x00, as Sec1Codec encodes it); pk = H = Gamma makes both ladders add a point to itself
+    k0 = sw.secret_from_seed(seeds[0].tobytes())
+    one = np.frombuffer(be(1), np.uint8).reshape(1, 32)
+    got = gpu.ietf_verify_batch(pk[:1], r["input"][:1], r["output"][:1], one, np.frombuffer(be(k0), np.uint8).reshape(1, 32), ad=ads[:1])
+    H0, G0 = sw.point_decode(r["input"][0].tobytes()), sw.point_decode(r["output"][0].tobytes())
+    assert got[0] == (0 if sw.ietf_verify(sw.mul(k0, G), H0, G0, ads[0], 1, k0) else 1)
+    got = gpu.ietf_verify_batch(pk[:1], pk[:1], pk[:1], r["c"][:1], r["s"][:1], ad=ads[:1])
+    c0, s0 = int.from_bytes(r["c"][0].tobytes(), "big"), int.from_bytes(r["s"][0].tobytes(), "big")
+    Y0 = sw.mul(k0, G)
+    assert got[0] == (0 if sw.ietf_verify(Y0, Y0, Y0, ads[0], c0, s0) else 1)
     # point validation
     pts = _u8([sw.point_encode(sw.mul(7, G)), b"\x02" + be(offx), b"\x05" + be(G[0]), b"\x03" + be(P), b"\x03" + be(G[0])])
     stv, xyv = gpu.point_validate_batch(pts, want_xy=True)
