@@ -422,6 +422,7 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
     ctx->T.sq.str = hs;
     uint8_t* d_gen = nullptr;
     HIP_TRY_C(hipMalloc(&ctx->d_p256_comb, p256::comb_bytes()));
+    HIP_TRY_C(hipMalloc(&ctx->d_queue, 256));
     HIP_TRY_C(hipMalloc(&d_gen, 256));
     uint8_t gen_ok = 0;
     hipError_t e0 = hipMemcpy(d_gen, desc->generator, 64, hipMemcpyHostToDevice);
@@ -911,6 +912,7 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
       a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
       a.gamma = at(o.output, base, 33); a.c = at(o.c, base, 32); a.s = at(o.s, base, 32);
       a.pk_out = at(o.pk, base, 33); a.h_out = at(o.input, base, 33); a.status = at(o.status, base, 1);
+      a.tai_queue = ctx->d_queue;
       a.ws = ctx->p256_ws;
       a.comb = ctx->d_p256_comb;
       a.str = ctx->T.sq.str;

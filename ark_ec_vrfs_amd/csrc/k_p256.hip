@@ -9,6 +9,7 @@
 // inter-stage load and store is coalesced.  The ladders' window tables live there too, contiguous per item (224 words per
 // table): written once and read 65 (+33) times, an entry at a time, by the lane that wrote them.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstring>
 #include "p256.h"
 #include "p256_core.cuh"
@@ -138,6 +139,47 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_verify_finish(p256::VerifyA
 }
 
 // ------------------------------------------------------------------------------------------------ IETF prove
+// Stage 0: every item's first counter whose candidate decodes.  The lanes of a persistent wave draw items from a global
+// queue: a lane whose attempt succeeded records the counter and takes the next item at once, so a wave performs about
+// two attempts per item instead of the seven its unluckiest lane would impose (the same schedule as k_tai_find of the
+// Edwards suites, k_prove.hip).  ctr_out = the item's flag byte; the prepare stage starts its search there.
+__global__ void __launch_bounds__(64, 2) k_p256_tai_find(size_t n, BytesViewLite msg, uint8_t* ctr_out, SuiteStr str,
+                                                         unsigned long long* queue) {
+  constexpr size_t NONE = ~size_t(0);
+  const int lane = threadIdx.x;
+  size_t item = NONE;
+  uint32_t ctr = 0;
+  bool drained = false;                                    // the queue has no items left (wave-uniform)
+  while (true) {
+    const bool need = item == NONE && !drained;
+    const unsigned long long mask = __ballot(need);
+    if (mask) {
+      const uint32_t cnt = (uint32_t)__popcll(mask);
+      const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(queue, (unsigned long long)cnt);
+      base = __shfl(base, 0, 64);
+      if (need && base + rank < n) { item = (size_t)(base + rank); ctr = 0; }
+      if (base + cnt >= n) drained = true;
+    }
+    if (!__any(item != NONE)) break;                       // every lane idle and nothing left to draw
+    if (item != NONE) {
+      const uint8_t* m;
+      uint32_t len;
+      bytes_lite_get(msg, item, m, len);
+      Sha256 pre;
+      p256_tai_prefix(pre, m, len, str);
+      uint32_t w[8];
+      if (p256_tai_attempt(w, pre, ctr) || ctr == 255) {
+        ctr_out[item] = (uint8_t)ctr;
+        item = NONE;
+      } else {
+        ++ctr;
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_prepare(p256::ProveArgs a) {
   const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
   if (i >= a.n) return;
@@ -148,8 +190,9 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_prepare(p256::ProveAr
   uint32_t sk[8], k[8];
   FeN hx, hy;
   Sec1W henc;
+  const uint32_t tai_start = a.h_given ? 0u : a.ws.flags[i];          // k_p256_tai_find left the counter there
   const bool ok = p256_prove_prepare_item(sk, k, hx, hy, henc, a.sk + i * 32, msg, msg_len,
-                                          a.h_given ? a.h_given + i * SEC1_LEN : nullptr, a.str);
+                                          a.h_given ? a.h_given + i * SEC1_LEN : nullptr, a.str, tai_start);
   ws_store8(a.ws.sc, cap, i, 0, sk);
   ws_store8(a.ws.sc, cap, i, 8, k);
   ws_store_fe(a.ws.aff, cap, i, 0, hx);
@@ -298,6 +341,11 @@ void launch_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
 void launch_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
   const unsigned g = blocks_for(a.n);
   if (ev) (void)hipEventRecord(ev[0], st);
+  if (!a.h_given) {
+    (void)hipMemsetAsync(a.tai_queue, 0, sizeof(unsigned long long), st);
+    const size_t waves = std::min<size_t>((a.n + 63) / 64, 4096);          // persistent: 4 waves per SIMD
+    hipLaunchKernelGGL(k_p256_tai_find, dim3((unsigned)waves), dim3(64), 0, st, a.n, a.msg, a.ws.flags, a.str, a.tai_queue);
+  }
   hipLaunchKernelGGL(k_p256_prove_prepare, dim3(g), dim3(P256_BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
   hipLaunchKernelGGL(k_p256_prove_mul, dim3(g, 4), dim3(P256_BLOCK), 0, st, a);

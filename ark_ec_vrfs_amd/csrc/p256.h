@@ -53,6 +53,7 @@ struct ProveArgs {
   BytesViewLite ad;
   uint8_t *gamma, *c, *s;            // n x 33, n x 32, n x 32
   uint8_t *pk_out, *h_out, *status;  // nullable: n x 33, n x 33, n
+  unsigned long long* tai_queue;     // 8-byte device counter of k_p256_tai_find
   Ws ws;
   const uint32_t* comb;
   SuiteStr str;

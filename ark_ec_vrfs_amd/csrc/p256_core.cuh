@@ -87,35 +87,44 @@ VRF_HD void p256_put_suite(Sha256& h, const SuiteStr& ss) { sha256_put_packed64(
 // [ref src/lib.rs:14 `utils`] hash_to_curve_tai_rfc_9381 (RFC 9381 5.4.1.1): H = string_to_point(0x02 || Hash(suite ||
 // 0x01 || data || ctr || 0x00)) for the first ctr in 0..255 that decodes; cofactor 1.  `data` is what the caller passes
 // to `Input::new` (RFC 9381's own use: encode_to_curve_salt || alpha with the salt = the public key string).
-VRF_HD bool p256_hash_to_curve(FeN& x, FeN& y, uint32_t xw[8], const uint8_t* data, uint32_t len, const SuiteStr& ss) {
-  Sha256 pre;
+// one attempt: the candidate x of counter `ctr` (as words) and whether it is the abscissa of a point.  `pre` has absorbed
+// suite || 0x01 || data.  The decision is the Jacobi symbol of x^3 - 3x + b -- a third of the exponentiation a root costs.
+VRF_HD bool p256_tai_attempt(uint32_t w[8], const Sha256& pre, uint32_t ctr) {
+  Sha256 h = pre;
+  sha256_put_byte(h, (uint8_t)ctr);
+  sha256_put_byte(h, 0x00);
+  sha256_final(h);
+  sha256_be256(w, h);
+  if (u256_ge_q(w)) return false;
+  const FeN xc = fe_from_u256(w);
+  const FeN rc = fe_canon(sw_rhs(xc));
+  const int j = jacobi_limbs(rc.v);
+  if (j == 2) {                                          // rounds exhausted (not observed): decide by the root itself
+    FeN yt;
+    return sw_lift_x(yt, xc, false);
+  }
+  return j == 1 || j == 0;
+}
+VRF_HD void p256_tai_prefix(Sha256& pre, const uint8_t* data, uint32_t len, const SuiteStr& ss) {
   sha256_init(pre);
   p256_put_suite(pre, ss);
   sha256_put_byte(pre, 0x01);
   sha256_put_bytes(pre, data, len);
+}
+// `start`: the first counter to try (0, or the counter k_p256_tai_find already found to decode).  A wave runs as many
+// trips as its unluckiest lane (about 7 of the 64 where one lane expects 2), so a trip only decides and the root is
+// taken once, after; the batch prover goes further and finds the counters with a work queue (k_p256.hip).
+VRF_HD bool p256_hash_to_curve(FeN& x, FeN& y, uint32_t xw[8], const uint8_t* data, uint32_t len, const SuiteStr& ss,
+                               uint32_t start = 0) {
+  Sha256 pre;
+  p256_tai_prefix(pre, data, len, ss);
   bool found = false;
   x = fe_zero(); y = fe_zero();
 #pragma unroll 1
-  for (uint32_t ctr = 0; ctr < 256 && !found; ++ctr) {
-    Sha256 h = pre;
-    sha256_put_byte(h, (uint8_t)ctr);
-    sha256_put_byte(h, 0x00);
-    sha256_final(h);
+  for (uint32_t ctr = start; ctr < 256 && !found; ++ctr) {
     uint32_t w[8];
-    sha256_be256(w, h);
-    if (u256_ge_q(w)) continue;
-    // A wave runs as many trips as its unluckiest lane (about 7 of the 64 where one lane expects 2), so a trip only
-    // decides -- the Jacobi symbol of x^3 - 3x + b, a third of the exponentiation -- and the root is taken once, after.
-    const FeN xc = fe_from_u256(w);
-    const FeN rc = fe_canon(sw_rhs(xc));
-    const int j = jacobi_limbs(rc.v);
-    bool on = j == 1 || j == 0;
-    if (j == 2) {                                        // rounds exhausted (not observed): decide by the root itself
-      FeN yt;
-      on = sw_lift_x(yt, xc, false);
-    }
-    if (!on) continue;
-    x = xc; found = true;
+    if (!p256_tai_attempt(w, pre, ctr)) continue;
+    x = fe_from_u256(w); found = true;
 #pragma unroll
     for (int i = 0; i < 8; ++i) xw[i] = w[i];
   }
@@ -415,7 +424,8 @@ VRF_HD uint8_t p256_verify_finish_item(const PtW& U, const PtW& V, const Sec1W (
 // stage 1: sk, H = Input::new(msg) (or the given, decoded H), nonce k.  false = InvalidData (no H within 256 tries, an
 // undecodable given H)
 VRF_HD bool p256_prove_prepare_item(uint32_t sk[8], uint32_t k[8], FeN& hx, FeN& hy, Sec1W& henc, const uint8_t* sk_be,
-                                    const uint8_t* msg, uint32_t msg_len, const uint8_t* h_given, const SuiteStr& ss) {
+                                    const uint8_t* msg, uint32_t msg_len, const uint8_t* h_given, const SuiteStr& ss,
+                                    uint32_t tai_start = 0) {
   const bool sk_ok = p256_scalar_decode(sk, sk_be);
   bool ok;
   if (h_given) {
@@ -423,7 +433,7 @@ VRF_HD bool p256_prove_prepare_item(uint32_t sk[8], uint32_t k[8], FeN& hx, FeN&
     henc.tag = h_given[0];
     load_be256(henc.xw, h_given + 1);
   } else {
-    ok = p256_hash_to_curve(hx, hy, henc.xw, msg, msg_len, ss);
+    ok = p256_hash_to_curve(hx, hy, henc.xw, msg, msg_len, ss, tai_start);
     henc.tag = 2u;
   }
   p256_nonce(k, sk, henc.tag, henc.xw);
