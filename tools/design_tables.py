@@ -54,7 +54,7 @@ want = [("vrf::k_verify_decode<vrf::SuiteBS, 2>", 524288, " (checked and pre-val
         ("vrf::k_verify_decode<vrf::SuiteBJ, 2>", 524288, " (averaged)"), ("vrf::k_verify_straus<vrf::SuiteBJ, 1>", 1048576, ""), ("vrf::k_verify_straus<vrf::SuiteBJ, 0>", 1048576, ""),
         ("vrf::k_prove_prepare<vrf::SuiteBJ, 2>", 1048576, ""), ("vrf::k_prove_mul<vrf::SuiteBJ>", 2097152, ""),
         ("vrf::k_p256_verify_decode", 1048576, ""), ("vrf::k_p256_verify_mul<1>", 1048576, " (V = sH − cΓ)"), ("vrf::k_p256_verify_mul<0>", 1048576, " (U = sG − cY)"),
-        ("vrf::k_p256_verify_finish", 1048576, ""), ("vrf::k_p256_prove_prepare", 1048576, ""), ("vrf::k_p256_prove_mul", 4194304, " (4 ladders per proof)"),
+        ("vrf::k_p256_verify_finish", 1048576, ""), ("vrf::k_p256_tai_find", 262144, " (work queue, 4096 persistent waves)"), ("vrf::k_p256_prove_prepare", 1048576, ""), ("vrf::k_p256_prove_mul", 4194304, " (4 ladders per proof)"),
         ("vrf::k_p256_prove_finish", 1048576, ""),
         ("vrf::k_pairing_check2_quad", 65536, ""), ("vrf::k_pairing_check2_quad_prepared", 65536, ""), ("vrf::k_pairing_check2_row_prepared<true>", 64, " (ONE item: 48 lanes)"),
         ("vrf::k_g1_buckets", 119808, " (2^18 × 2 sets)"), ("vrf::k_g1_final", 256, " (2 sets × 128 lanes)")]
