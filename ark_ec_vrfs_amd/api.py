@@ -373,7 +373,7 @@ class Context:
         msg_blob = msg_off = inp = None
         msg_len = 0
         if inputs is not None:
-            inp = np.ascontiguousarray(inputs, dtype=np.uint8).reshape(-1, 32)
+            inp = np.ascontiguousarray(inputs, dtype=np.uint8).reshape(-1, self.point_bytes())
             if inp.shape[0] != n:
                 raise ValueError("ragged batch")
         elif isinstance(msgs, np.ndarray):
@@ -391,8 +391,8 @@ class Context:
         sk = np.ascontiguousarray(sk, dtype=np.uint8).reshape(-1, 32)
         n = sk.shape[0]
         msg_blob, msg_off, msg_len, inp = self._msg_args(n, msgs, inputs)
-        pw = self.prove_point_bytes()
-        res = {k: np.empty((n, pw if k in ("output", "pk_com", "r", "ok") else 32), dtype=np.uint8)
+        pw, ipw = self.prove_point_bytes(), self.point_bytes()
+        res = {k: np.empty((n, pw if k in ("output", "pk_com", "r", "ok") else ipw if k == "input" else 32), dtype=np.uint8)
                for k in ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input")}
         status = np.empty(n, dtype=np.uint8)
         blob, off, ad_len = self._ad_args(ad, n)
@@ -405,7 +405,9 @@ class Context:
 
     def pedersen_verify_batch(self, inp, out, pk_com, r, ok, s, sb, ad=b"") -> np.ndarray:
         """`pedersen::Verifier::verify`."""
-        arrs = [np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (inp, out, pk_com, r, ok, s, sb)]
+        pw = self.point_bytes()
+        arrs = [np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, pw) for x in (inp, out, pk_com, r, ok)]
+        arrs += [np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (s, sb)]
         n = arrs[0].shape[0]
         if not all(x.shape[0] == n for x in arrs):
             raise ValueError("ragged batch")
@@ -705,8 +707,8 @@ def pedersen_prove_batch_multi(ctxs, sk, msgs, ad=b""):
     mblob, moff = _pack_var([bytes(m) for m in msgs])
     blob, off, ad_len = Context._ad_args(ad, n)
     names = ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input")
-    pw = ctxs[0].prove_point_bytes()
-    res = {k: np.empty((n, pw if k in ("output", "pk_com", "r", "ok") else 32), np.uint8) for k in names}
+    pw, ipw = ctxs[0].prove_point_bytes(), ctxs[0].point_bytes()
+    res = {k: np.empty((n, pw if k in ("output", "pk_com", "r", "ok") else ipw if k == "input" else 32), np.uint8) for k in names}
     res["status"] = np.empty(n, np.uint8)
     arr, k = _ctx_array(ctxs)
     _lib.check(_lib.load().vrfhip_pedersen_prove_batch_multi(
@@ -716,7 +718,9 @@ def pedersen_prove_batch_multi(ctxs, sk, msgs, ad=b""):
 
 
 def pedersen_verify_batch_multi(ctxs, inp, out, pk_com, r, ok, s, sb, ad=b"", rlc_seed: Optional[bytes] = None) -> np.ndarray:
-    arrs = [np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (inp, out, pk_com, r, ok, s, sb)]
+    pw = ctxs[0].point_bytes()
+    arrs = [np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, pw) for x in (inp, out, pk_com, r, ok)]
+    arrs += [np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (s, sb)]
     n = arrs[0].shape[0]
     blob, off, ad_len = Context._ad_args(ad, n)
     st = np.empty(n, np.uint8)

@@ -101,6 +101,7 @@ struct vrfhip_ctx {
   // Edwards suites go through FIELD_CALL, and the byte widths of the arrays come from the two functions that follow.
   bool sw = false;
   uint32_t* d_p256_comb = nullptr;
+  uint32_t* d_p256_comb_b = nullptr;       // comb of the Pedersen blinding base (nullptr: the descriptor's base is all-zero)
   p256::Ws p256_ws{};
   size_t pt_bytes() const { return sw ? 33 : 32; }        // one compressed point on the wire
   size_t hash_bytes() const { return sw ? 32 : 64; }      // `Output::hash`: the suite hasher's output
@@ -343,7 +344,8 @@ int32_t vrfhip_suite_desc_default(vrfhip_suite suite, vrfhip_suite_desc* out) {
     out->challenge_len = 16;                         // RFC 9381 cLen of ECVRF-P256-SHA256-TAI
     out->suite_id[0] = 0x01;                         // RFC 9381 suite_string
     out->suite_id_len = 1;
-    p256::default_generator(out->generator);         // no Pedersen blinding base: zeros
+    p256::default_generator(out->generator);
+    p256::default_blinding_base(out->blinding_base); // nothing-up-my-sleeve: upstream's constant is not known here
     have = true;
   }
   if (!have) return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported suite");
@@ -432,6 +434,21 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
     (void)hipFree(d_gen);
     HIP_TRY_C(e0); HIP_TRY_C(e1); HIP_TRY_C(e2); HIP_TRY_C(e3);
     if (!gen_ok) return cleanup(fail(VRFHIP_ERR_BAD_ARG, "desc.generator is not a point of the curve"));
+    bool have_b = false;
+    for (size_t i = 0; i < 64; ++i) have_b = have_b || desc->blinding_base[i] != 0;
+    if (have_b) {                               // `PedersenSuite::BLINDING_BASE`; all-zero = a suite without the Pedersen scheme
+      uint8_t* d_b = nullptr;
+      HIP_TRY_C(hipMalloc(&ctx->d_p256_comb_b, p256::comb_bytes()));
+      HIP_TRY_C(hipMalloc(&d_b, 256));
+      uint8_t b_ok = 0;
+      hipError_t f0 = hipMemcpy(d_b, desc->blinding_base, 64, hipMemcpyHostToDevice);
+      p256::launch_init_comb(ctx->d_p256_comb_b, d_b, d_b + 128, ctx->stream);
+      hipError_t f1 = hipGetLastError(), f2 = hipStreamSynchronize(ctx->stream);
+      hipError_t f3 = hipMemcpy(&b_ok, d_b + 128, 1, hipMemcpyDeviceToHost);
+      (void)hipFree(d_b);
+      HIP_TRY_C(f0); HIP_TRY_C(f1); HIP_TRY_C(f2); HIP_TRY_C(f3);
+      if (!b_ok) return cleanup(fail(VRFHIP_ERR_BAD_ARG, "desc.blinding_base is not a point of the curve"));
+    }
     *out = ctx;
     return VRFHIP_SUCCESS;
   }
@@ -530,6 +547,7 @@ void vrfhip_ctx_destroy(vrfhip_ctx* ctx) {
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->d_pair_prep) (void)hipFree(ctx->d_pair_prep);
     if (ctx->d_p256_comb) (void)hipFree(ctx->d_p256_comb);
+    if (ctx->d_p256_comb_b) (void)hipFree(ctx->d_p256_comb_b);
     if (ctx->h_pin) {
       std::memset(ctx->h_pin, 0, 2 * ctx->pin_slot_bytes);     // may have staged caller data
       (void)hipHostFree(ctx->h_pin);
@@ -893,7 +911,7 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
   if (pedersen ? (!o.pk || !o.r || !o.ok || !o.sb) : !o.c) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if (!d_input && !d_msg && (msg_len || d_msg_off)) return fail(VRFHIP_ERR_BAD_ARG, "msg is NULL");
   if ((ad_len || d_ad_off) && !d_ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
-  if (ctx->sw && pedersen) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the Pedersen scheme is not built for this suite");
+  if (ctx->sw && pedersen && !ctx->d_p256_comb_b) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the descriptor carries no Pedersen blinding base");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   int32_t rc = ensure_workspace(ctx, n);
@@ -912,6 +930,10 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
       a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
       a.gamma = at(o.output, base, 33); a.c = at(o.c, base, 32); a.s = at(o.s, base, 32);
       a.pk_out = at(o.pk, base, 33); a.h_out = at(o.input, base, 33); a.status = at(o.status, base, 1);
+      a.pedersen = pedersen ? 1 : 0;
+      a.r_out = at(o.r, base, 33); a.ok_out = at(o.ok, base, 33); a.sb_out = at(o.sb, base, 32);
+      a.blinding_out = at(o.blinding, base, 32);
+      a.comb_b = ctx->d_p256_comb_b;
       a.tai_queue = ctx->d_queue;
       a.ws = ctx->p256_ws;
       a.comb = ctx->d_p256_comb;
@@ -1084,16 +1106,33 @@ int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_
                                          const uint32_t* d_ad_off, uint32_t ad_len,
                                          uint8_t* d_status, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!d_input || !d_output || !d_pk_com || !d_r || !d_ok || !d_s || !d_sb || !d_status)
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if ((ad_len || d_ad_off) && !d_ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  if (ctx->sw && !ctx->d_p256_comb_b) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the descriptor carries no Pedersen blinding base");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   int32_t rc = ensure_workspace(ctx, n);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (ctx->sw) {
+    for (size_t base = 0; base < n; base += ctx->ws_cap) {
+      const size_t m = std::min(ctx->ws_cap, n - base);
+      p256::PedVerifyArgs a;
+      a.n = m;
+      a.h = d_input + base * 33; a.gamma = d_output + base * 33; a.pk_com = d_pk_com + base * 33;
+      a.r = d_r + base * 33; a.ok = d_ok + base * 33; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
+      a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
+      a.status = d_status + base;
+      a.ws = ctx->p256_ws;
+      a.comb = ctx->d_p256_comb; a.comb_b = ctx->d_p256_comb_b;
+      a.str = ctx->T.sq.str;
+      p256::launch_pedersen_verify(a, st, prof_events(ctx));
+    }
+    HIP_TRY(hipGetLastError());
+    return VRFHIP_SUCCESS;
+  }
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     size_t m = std::min(ctx->ws_cap, n - base);
     PedersenVerifyArgs a;
@@ -1118,7 +1157,6 @@ int32_t vrfhip_pedersen_verify_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* i
                                      const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
                                      uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!input || !output || !pk_com || !r || !ok || !s || !sb || !status)
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
@@ -1126,15 +1164,17 @@ int32_t vrfhip_pedersen_verify_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* i
   size_t adb = blob_bytes(n, ad_off, ad_len, true);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  size_t need = 7 * Stage::pad(n * 32) + Stage::pad(adb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n);
+  const size_t pw = ctx->pt_bytes();
+  size_t need = 5 * Stage::pad(n * pw) + 2 * Stage::pad(n * 32) + Stage::pad(adb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n);
   int32_t rc = ensure_stage(ctx, need);
   if (rc) return rc;
   Stage sg(ctx->d_stage);
   const uint8_t* src[7] = {input, output, pk_com, r, ok, s, sb};
   uint8_t* d[7];
   for (int i = 0; i < 7; ++i) {
-    d[i] = sg.take(n * 32);
-    HIP_TRY(hipMemcpyAsync(d[i], src[i], n * 32, hipMemcpyHostToDevice, ctx->stream));
+    const size_t w = i < 5 ? pw : 32;
+    d[i] = sg.take(n * w);
+    HIP_TRY(hipMemcpyAsync(d[i], src[i], n * w, hipMemcpyHostToDevice, ctx->stream));
   }
   uint8_t* d_ad = sg.take(adb + 1);
   uint32_t* d_off = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
@@ -2002,13 +2042,13 @@ int32_t vrfhip_pedersen_prove_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ctx
                                           uint8_t* sb, uint8_t* blinding_out, uint8_t* input_out, uint8_t* status) {
   if (n == 0) return VRFHIP_SUCCESS;
   if (!sk || !output || !pk_com || !r || !ok || !s || !sb) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
-  const size_t w = prove_point_bytes_of(ctxs, n_ctx);
-  if (!w) return fail(VRFHIP_ERR_BAD_ARG, "contexts disagree on VRFHIP_FLAG_PROVE_POINTS_AFFINE");
+  const size_t w = prove_point_bytes_of(ctxs, n_ctx), pw = point_bytes_of(ctxs, n_ctx);
+  if (!w || !pw) return fail(VRFHIP_ERR_BAD_ARG, "contexts disagree on VRFHIP_FLAG_PROVE_POINTS_AFFINE or on the suite's point encoding");
   return run_sharded(ctxs, n_ctx, n, [&](vrfhip_ctx* ctx, size_t lo, size_t hi) {
     BlobSlice m(msg, input ? nullptr : msg_off, msg_len, false, lo, hi), a(ad, ad_off, ad_len, true, lo, hi);
-    return vrfhip_pedersen_prove_batch(ctx, hi - lo, at32(sk, lo), m.blob, m.off, msg_len, at32(input, lo), a.blob, a.off,
+    return vrfhip_pedersen_prove_batch(ctx, hi - lo, at32(sk, lo), m.blob, m.off, msg_len, input ? input + lo * pw : nullptr, a.blob, a.off,
                                        ad_len, at_w(output, lo, w), at_w(pk_com, lo, w), at_w(r, lo, w), at_w(ok, lo, w), at32(s, lo),
-                                       at32(sb, lo), at32(blinding_out, lo), at32(input_out, lo),
+                                       at32(sb, lo), at32(blinding_out, lo), at_w(input_out, lo, pw),
                                        status ? status + lo : nullptr);
   });
 }
@@ -2020,14 +2060,16 @@ int32_t vrfhip_pedersen_verify_batch_multi(vrfhip_ctx* const* ctxs, int32_t n_ct
                                            uint8_t* status) {
   if (n == 0) return VRFHIP_SUCCESS;
   if (!input || !output || !pk_com || !r || !ok || !s || !sb || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  const size_t pw = point_bytes_of(ctxs, n_ctx);
+  if (!pw) return fail(VRFHIP_ERR_BAD_ARG, "contexts disagree on the suite's point encoding");
   return run_sharded(ctxs, n_ctx, n, [&](vrfhip_ctx* ctx, size_t lo, size_t hi) {
     BlobSlice a(ad, ad_off, ad_len, true, lo, hi);
     if (rlc_seed)      // one multi-scalar multiplication per device slice; per-proof fallback inside the slice
-      return vrfhip_pedersen_verify_batch_rlc(ctx, hi - lo, at32(input, lo), at32(output, lo), at32(pk_com, lo), at32(r, lo),
-                                              at32(ok, lo), at32(s, lo), at32(sb, lo), a.blob, a.off, ad_len, rlc_seed,
+      return vrfhip_pedersen_verify_batch_rlc(ctx, hi - lo, input + lo * pw, output + lo * pw, pk_com + lo * pw, r + lo * pw,
+                                              ok + lo * pw, at32(s, lo), at32(sb, lo), a.blob, a.off, ad_len, rlc_seed,
                                               status + lo, nullptr);
-    return vrfhip_pedersen_verify_batch(ctx, hi - lo, at32(input, lo), at32(output, lo), at32(pk_com, lo), at32(r, lo),
-                                        at32(ok, lo), at32(s, lo), at32(sb, lo), a.blob, a.off, ad_len, status + lo);
+    return vrfhip_pedersen_verify_batch(ctx, hi - lo, input + lo * pw, output + lo * pw, pk_com + lo * pw, r + lo * pw,
+                                        ok + lo * pw, at32(s, lo), at32(sb, lo), a.blob, a.off, ad_len, status + lo);
   });
 }
 

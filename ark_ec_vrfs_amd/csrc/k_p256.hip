@@ -19,7 +19,7 @@ namespace {
 
 constexpr int P256_BLOCK = 128;
 // p256.h states the workspace record sizes as plain numbers (the C ABI's translation unit does not see the device headers)
-static_assert(p256::WS_TAB_WORDS == 3 * SW_TABLE_WORDS && p256::WS_PTS_WORDS == 4 * PTW_WORDS && p256::WS_AFF_WORDS == 6 * NL &&
+static_assert(p256::WS_TAB_WORDS == 3 * SW_TABLE_WORDS && p256::WS_PTS_WORDS == 4 * PTW_WORDS && p256::WS_AFF_WORDS == 10 * NL &&
               p256::WS_ENC_WORDS == 3 * 9, "p256.h workspace layout");
 
 __device__ __forceinline__ void ws_store_fe(uint32_t* base, size_t cap, size_t i, int w0, const FeN& a) {
@@ -180,6 +180,8 @@ __global__ void __launch_bounds__(64, 2) k_p256_tai_find(size_t n, BytesViewLite
   }
 }
 
+// PED = 1: the Pedersen prover (a compile-time switch: the IETF kernels keep the code and the registers they had)
+template <int PED>
 __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_prepare(p256::ProveArgs a) {
   const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
   if (i >= a.n) return;
@@ -195,6 +197,16 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_prepare(p256::ProveAr
                                           a.h_given ? a.h_given + i * SEC1_LEN : nullptr, a.str, tai_start);
   ws_store8(a.ws.sc, cap, i, 0, sk);
   ws_store8(a.ws.sc, cap, i, 8, k);
+  if constexpr (PED != 0) {                               // blinding factor b and its nonce kb
+    const uint8_t* ad;
+    uint32_t ad_len;
+    bytes_lite_get(a.ad, i, ad, ad_len);
+    uint32_t b[8], kb[8];
+    p256_blinding(b, sk, henc, ad, ad_len, a.str);
+    p256_nonce(kb, b, henc.tag, henc.xw);
+    ws_store8(a.ws.sc, cap, i, 16, b);
+    ws_store8(a.ws.sc, cap, i, 24, kb);
+  }
   ws_store_fe(a.ws.aff, cap, i, 0, hx);
   ws_store_fe(a.ws.aff, cap, i, 9, hy);
   ws_store_enc(a.ws.enc, cap, i, 0, henc);
@@ -202,8 +214,10 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_prepare(p256::ProveAr
 }
 
 // blockIdx.y = 0: pk = sk G, 1: Gamma = sk H, 2: U = k G, 3: V = k H.  The two H ladders each build their own copy of
-// H's table (7 additions) rather than wait for one another.
-__global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_mul(p256::ProveArgs a) {
+// H's table (7 additions) rather than wait for one another.  Pedersen: job 0 is pk_com = sk G + b B, job 2 is
+// R = k G + kb B (a second comb walk over the blinding base's table), jobs 1 and 3 are Gamma and Ok = k H.
+template <int PED>
+__global__ void __launch_bounds__(P256_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_p256_prove_mul(p256::ProveArgs a) {
   const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
   if (i >= a.n || !a.ws.flags[i]) return;
   const size_t cap = a.ws.cap;
@@ -217,10 +231,16 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_mul(p256::ProveArgs a
     r = sw_win_mul(th, 1, k, false);
   } else {
     r = sw_comb_mul(a.comb, k);
+    if constexpr (PED != 0) {
+      uint32_t kb[8];
+      ws_load8(kb, a.ws.sc, cap, i, (job & 2) ? 24 : 16);
+      r = sw_add(r, sw_comb_mul(a.comb_b, kb));
+    }
   }
   ptw_store(ws_pt(a.ws.pts, cap, i, job), cap, r);
 }
 
+template <int PED>
 __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_finish(p256::ProveArgs a) {
   const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
   if (i >= a.n) return;
@@ -231,8 +251,13 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_finish(p256::ProveArg
       a.gamma[i * SEC1_LEN + k] = 0;
       if (a.pk_out) a.pk_out[i * SEC1_LEN + k] = 0;
       if (a.h_out) a.h_out[i * SEC1_LEN + k] = 0;
+      if (PED != 0) { a.r_out[i * SEC1_LEN + k] = 0; a.ok_out[i * SEC1_LEN + k] = 0; }
     }
-    for (int k = 0; k < 32; ++k) { a.c[i * 32 + k] = 0; a.s[i * 32 + k] = 0; }
+    for (int k = 0; k < 32; ++k) {
+      a.s[i * 32 + k] = 0;
+      if (PED != 0) { a.sb_out[i * 32 + k] = 0; if (a.blinding_out) a.blinding_out[i * 32 + k] = 0; }
+      else a.c[i * 32 + k] = 0;
+    }
     return;
   }
   const PtW res[4] = {ptw_load(ws_pt(a.ws.pts, cap, i, 0), cap), ptw_load(ws_pt(a.ws.pts, cap, i, 1), cap),
@@ -244,14 +269,88 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_finish(p256::ProveArg
   const uint8_t* ad;
   uint32_t ad_len;
   bytes_lite_get(a.ad, i, ad, ad_len);
-  Sec1W pk, gamma;
-  p256_prove_finish_item(pk, gamma, c, s, res, henc, sk, k, ad, ad_len, a.str);
-  sec1_store(a.gamma + i * SEC1_LEN, gamma.tag, gamma.xw);
-  store_be256(a.c + i * 32, c);
-  store_be256(a.s + i * 32, s);
-  if (a.pk_out) sec1_store(a.pk_out + i * SEC1_LEN, pk.tag, pk.xw);
-  if (a.h_out) sec1_store(a.h_out + i * SEC1_LEN, henc.tag, henc.xw);
-  if (a.status) a.status[i] = 0;
+  if constexpr (PED != 0) {
+    uint32_t b[8], kb[8], sb[8];
+    ws_load8(b, a.ws.sc, cap, i, 16);
+    ws_load8(kb, a.ws.sc, cap, i, 24);
+    Sec1W enc[4];
+    p256_ped_prove_finish_item(enc, s, sb, res, henc, sk, k, b, kb, ad, ad_len, a.str);
+    sec1_store(a.pk_out + i * SEC1_LEN, enc[0].tag, enc[0].xw);
+    sec1_store(a.gamma + i * SEC1_LEN, enc[1].tag, enc[1].xw);
+    sec1_store(a.r_out + i * SEC1_LEN, enc[2].tag, enc[2].xw);
+    sec1_store(a.ok_out + i * SEC1_LEN, enc[3].tag, enc[3].xw);
+    store_be256(a.s + i * 32, s);
+    store_be256(a.sb_out + i * 32, sb);
+    if (a.blinding_out) store_be256(a.blinding_out + i * 32, b);
+    if (a.h_out) sec1_store(a.h_out + i * SEC1_LEN, henc.tag, henc.xw);
+    if (a.status) a.status[i] = 0;
+  } else {
+    Sec1W pk, gamma;
+    p256_prove_finish_item(pk, gamma, c, s, res, henc, sk, k, ad, ad_len, a.str);
+    sec1_store(a.gamma + i * SEC1_LEN, gamma.tag, gamma.xw);
+    store_be256(a.c + i * 32, c);
+    store_be256(a.s + i * 32, s);
+    if (a.pk_out) sec1_store(a.pk_out + i * SEC1_LEN, pk.tag, pk.xw);
+    if (a.h_out) sec1_store(a.h_out + i * SEC1_LEN, henc.tag, henc.xw);
+    if (a.status) a.status[i] = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Pedersen verify
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_ped_verify_decode(p256::PedVerifyArgs a) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  const size_t cap = a.ws.cap;
+  const uint8_t* ad;
+  uint32_t ad_len;
+  bytes_lite_get(a.ad, i, ad, ad_len);
+  FeN x[5], y[5];
+  uint32_t c[8], s[8], sb[8];
+  const bool ok = p256_ped_verify_decode_item(x, y, c, s, sb, a.h + i * SEC1_LEN, a.gamma + i * SEC1_LEN, a.pk_com + i * SEC1_LEN,
+                                              a.r + i * SEC1_LEN, a.ok + i * SEC1_LEN, a.s + i * 32, a.sb + i * 32, ad, ad_len, a.str);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    ws_store_fe(a.ws.aff, cap, i, j * 18, x[j]);
+    ws_store_fe(a.ws.aff, cap, i, j * 18 + 9, y[j]);
+  }
+  ws_store8(a.ws.sc, cap, i, 0, c);
+  ws_store8(a.ws.sc, cap, i, 8, s);
+  ws_store8(a.ws.sc, cap, i, 16, sb);
+  a.ws.flags[i] = ok ? 1 : 0;
+}
+// WHICH = 0: s H - c Gamma - Ok = O (two tables); 1: s G + sb B - c pk_com - R = O (two comb walks, one table).  The
+// verdict of each equation goes to word WHICH of the item's result record.
+template <int WHICH>
+__global__ void __launch_bounds__(P256_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_p256_ped_verify_mul(p256::PedVerifyArgs a) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= a.n || !a.ws.flags[i]) return;
+  const size_t cap = a.ws.cap;
+  const int cw = sw_challenge_windows(a.str);
+  uint32_t c[8], s[8];
+  ws_load8(c, a.ws.sc, cap, i, 0);
+  ws_load8(s, a.ws.sc, cap, i, 8);
+  auto pt = [&](int j) { return sw_from_affine(ws_load_fe(a.ws.aff, cap, i, j * 18), ws_load_fe(a.ws.aff, cap, i, j * 18 + 9)); };
+  bool holds;
+  if constexpr (WHICH == 0) {
+    uint32_t* th = ws_tab(a.ws.tabs, cap, i, 0);
+    uint32_t* tg = ws_tab(a.ws.tabs, cap, i, 1);
+    sw_build_table(th, 1, pt(0));
+    sw_build_table(tg, 1, pt(1));
+    holds = p256_ped_verify_eq_h(th, tg, 1, ws_load_fe(a.ws.aff, cap, i, 72), ws_load_fe(a.ws.aff, cap, i, 81), s, c, cw);
+  } else {
+    uint32_t sb[8];
+    ws_load8(sb, a.ws.sc, cap, i, 16);
+    uint32_t* tp = ws_tab(a.ws.tabs, cap, i, 2);
+    sw_build_table(tp, 1, pt(2));
+    holds = p256_ped_verify_eq_g(a.comb, a.comb_b, tp, 1, ws_load_fe(a.ws.aff, cap, i, 54), ws_load_fe(a.ws.aff, cap, i, 63), s, sb, c, cw);
+  }
+  a.ws.pts[(size_t)WHICH * cap + i] = holds ? 1u : 0u;
+}
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_ped_verify_finish(p256::PedVerifyArgs a) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  const size_t cap = a.ws.cap;
+  a.status[i] = !a.ws.flags[i] ? 2 : (a.ws.pts[i] && a.ws.pts[cap + i]) ? 0 : 1;
 }
 
 // ------------------------------------------------------------------------------------------------ building blocks
@@ -320,6 +419,7 @@ namespace p256 {
 size_t comb_bytes() { return P256_COMB_WORDS * sizeof(uint32_t); }
 
 void default_generator(uint8_t xy[64]) { std::memcpy(xy, vrfk_tables::P256_G_XY, 64); }
+void default_blinding_base(uint8_t xy[64]) { std::memcpy(xy, vrfk_tables::P256_B_XY, 64); }
 
 void launch_init_comb(uint32_t* comb, const uint8_t* d_gen_xy, uint8_t* d_ok, hipStream_t st) {
   hipLaunchKernelGGL(k_p256_init_comb, dim3(1), dim3(64), 0, st, comb, d_gen_xy, d_ok);
@@ -346,11 +446,27 @@ void launch_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
     const size_t waves = std::min<size_t>((a.n + 63) / 64, 4096);          // persistent: 4 waves per SIMD
     hipLaunchKernelGGL(k_p256_tai_find, dim3((unsigned)waves), dim3(64), 0, st, a.n, a.msg, a.ws.flags, a.str, a.tai_queue);
   }
-  hipLaunchKernelGGL(k_p256_prove_prepare, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  if (a.pedersen) hipLaunchKernelGGL(k_p256_prove_prepare<1>, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  else hipLaunchKernelGGL(k_p256_prove_prepare<0>, dim3(g), dim3(P256_BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
-  hipLaunchKernelGGL(k_p256_prove_mul, dim3(g, 4), dim3(P256_BLOCK), 0, st, a);
+  if (a.pedersen) hipLaunchKernelGGL(k_p256_prove_mul<1>, dim3(g, 4), dim3(P256_BLOCK), 0, st, a);
+  else hipLaunchKernelGGL(k_p256_prove_mul<0>, dim3(g, 4), dim3(P256_BLOCK), 0, st, a);
   if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
-  hipLaunchKernelGGL(k_p256_prove_finish, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  if (a.pedersen) hipLaunchKernelGGL(k_p256_prove_finish<1>, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  else hipLaunchKernelGGL(k_p256_prove_finish<0>, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[4], st);
+}
+
+void launch_pedersen_verify(const PedVerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
+  const unsigned g = blocks_for(a.n);
+  if (ev) (void)hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(k_p256_ped_verify_decode, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  hipLaunchKernelGGL(k_p256_ped_verify_mul<0>, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[2], st);
+  hipLaunchKernelGGL(k_p256_ped_verify_mul<1>, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[3], st);
+  hipLaunchKernelGGL(k_p256_ped_verify_finish, dim3(g), dim3(P256_BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[4], st);
 }
 

@@ -13,13 +13,14 @@ namespace p256 {
 struct Ws {
   uint32_t* tabs;    // [3][cap][224]  window tables (verify: Y, H, Gamma; prove: H twice)
   uint32_t* pts;     // [4][27][cap]   projective results (verify: U, V; prove: pk, Gamma, U, V)
-  uint32_t* aff;     // [3][18][cap]   decoded affine points, Montgomery limbs (prove: H)
-  uint32_t* sc;      // [4][8][cap]    scalars (verify: c, s; prove: sk, k -- wiped after every prove)
+  uint32_t* aff;     // [5][18][cap]   decoded affine points, Montgomery limbs (IETF verify: pk, H, Gamma; Pedersen verify: H,
+                     //                Gamma, pk_com, R, Ok; prove: H)
+  uint32_t* sc;      // [4][8][cap]    scalars (verify: c, s [, sb]; prove: sk, k [, b, kb] -- wiped after every prove)
   uint32_t* enc;     // [3][9][cap]    tag + x of the wire encodings that enter the challenge hash (prove: H)
   uint8_t* flags;    // [cap]          1 = the item's inputs decoded
   size_t cap;
 };
-constexpr size_t WS_TAB_WORDS = 3 * 224, WS_PTS_WORDS = 4 * 27, WS_AFF_WORDS = 3 * 18, WS_SC_WORDS = 4 * 8, WS_ENC_WORDS = 3 * 9;
+constexpr size_t WS_TAB_WORDS = 3 * 224, WS_PTS_WORDS = 4 * 27, WS_AFF_WORDS = 5 * 18, WS_SC_WORDS = 4 * 8, WS_ENC_WORDS = 3 * 9;
 constexpr size_t WS_WORDS_PER_ITEM = WS_TAB_WORDS + WS_PTS_WORDS + WS_AFF_WORDS + WS_SC_WORDS + WS_ENC_WORDS;
 inline size_t ws_bytes(size_t cap) { return cap * WS_WORDS_PER_ITEM * sizeof(uint32_t) + ((cap + 255) & ~size_t(255)); }
 inline Ws ws_carve(void* base, size_t cap) {
@@ -53,9 +54,25 @@ struct ProveArgs {
   BytesViewLite ad;
   uint8_t *gamma, *c, *s;            // n x 33, n x 32, n x 32
   uint8_t *pk_out, *h_out, *status;  // nullable: n x 33, n x 33, n
+  // Pedersen (pedersen != 0): c is unused, pk_out receives pk_com, and the outputs below are written
+  int pedersen;
+  uint8_t *r_out, *ok_out, *sb_out;  // n x 33, n x 33, n x 32
+  uint8_t* blinding_out;             // nullable: n x 32
+  const uint32_t* comb_b;            // fixed-base comb of the blinding base
   unsigned long long* tai_queue;     // 8-byte device counter of k_p256_tai_find
   Ws ws;
   const uint32_t* comb;
+  SuiteStr str;
+};
+
+struct PedVerifyArgs {
+  size_t n;
+  const uint8_t *h, *gamma, *pk_com, *r, *ok;   // n x 33 B Sec1
+  const uint8_t *s, *sb;                        // n x 32 B big-endian
+  BytesViewLite ad;
+  uint8_t* status;
+  Ws ws;
+  const uint32_t *comb, *comb_b;
   SuiteStr str;
 };
 
@@ -63,10 +80,13 @@ size_t comb_bytes();
 // comb of the point gen_xy (x || y, 32-byte little-endian canonical integers, as vrfhip_suite_desc carries it);
 // ok[0] = 1 if it is a point of the curve other than the point at infinity
 void launch_init_comb(uint32_t* comb, const uint8_t* d_gen_xy, uint8_t* d_ok, hipStream_t st);
-// the built-in generator (SEC 2 2.4.2) as the descriptor carries it
+// the built-in generator (SEC 2 2.4.2) and Pedersen blinding base (a nothing-up-my-sleeve point: tools/gen_constants.py)
+// as the descriptor carries them
 void default_generator(uint8_t xy[64]);
+void default_blinding_base(uint8_t xy[64]);
 void launch_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev);    // ev: nullptr or 5 events (stage boundaries)
-void launch_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev);
+void launch_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev);      // IETF, or Pedersen when a.pedersen
+void launch_pedersen_verify(const PedVerifyArgs& a, hipStream_t st, hipEvent_t* ev);
 void launch_hash_to_curve(size_t n, BytesViewLite msg, uint8_t* points33, const SuiteStr& str, hipStream_t st);
 void launch_output_hash(size_t n, const uint8_t* gamma33, uint8_t* hash32, const SuiteStr& str, hipStream_t st);
 void launch_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk32, uint8_t* pk33,

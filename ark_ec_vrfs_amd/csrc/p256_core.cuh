@@ -453,4 +453,74 @@ VRF_HD void p256_prove_finish_item(Sec1W& pk, Sec1W& gamma, uint32_t c[8], uint3
   fr_add<CurveP256>(s, cs, k);
 }
 
+// ---- Pedersen VRF, per item [ref src/lib.rs:14 `pedersen::{Prover, Verifier}`; SURVEY.md Appendix A.5 with this suite's
+// codec and hash].  Unpinned on this suite: no published vector, and upstream's BLINDING_BASE is not known here (the
+// descriptor carries the base; the built-in one is a nothing-up-my-sleeve point, tools/gen_constants.py). ----
+// `PedersenSuite::blinding`: Hash(suite || 0xCC || scalar_encode(sk) || point_encode(H) || ad || 0x00) mod n
+VRF_HD void p256_blinding(uint32_t b[8], const uint32_t sk[8], const Sec1W& henc, const uint8_t* ad, uint32_t ad_len, const SuiteStr& ss) {
+  Sha256 h;
+  sha256_init(h);
+  p256_put_suite(h, ss);
+  sha256_put_byte(h, 0xCC);
+  sha256_put_be256(h, sk);
+  sha256_put_sec1(h, henc.tag, henc.xw);
+  sha256_put_bytes(h, ad, ad_len);
+  sha256_put_byte(h, 0x00);
+  sha256_final(h);
+  uint32_t w[8];
+  sha256_be256(w, h);
+  fr_reduce256<CurveP256>(b, w);
+}
+// prove, stage 3: res = {pk_com = sk G + b B, Gamma = sk H, R = k G + kb B, Ok = k H}
+VRF_HD void p256_ped_prove_finish_item(Sec1W (&enc)[4], uint32_t s[8], uint32_t sb[8], const PtW (&res)[4], const Sec1W& henc,
+                                       const uint32_t sk[8], const uint32_t k[8], const uint32_t b[8], const uint32_t kb[8],
+                                       const uint8_t* ad, uint32_t ad_len, const SuiteStr& ss) {
+  sw_to_sec1<true>(enc, res);
+  const Sec1W pts[5] = {enc[0], henc, enc[1], enc[2], enc[3]};
+  uint32_t c[8], t[8];
+  p256_challenge(c, pts, ad, ad_len, ss);
+  fr_mul<CurveP256>(t, c, sk);
+  fr_add<CurveP256>(s, t, k);
+  fr_mul<CurveP256>(t, c, b);
+  fr_add<CurveP256>(sb, t, kb);
+}
+// verify, stage 1: decode H, Gamma, pk_com, R, Ok and the scalars; c = challenge(pk_com, H, Gamma, R, Ok, ad).
+// x / y / enc order: H, Gamma, pk_com, R, Ok.  false = InvalidData (a point off the curve, s or sb >= n)
+VRF_HD bool p256_ped_verify_decode_item(FeN (&x)[5], FeN (&y)[5], uint32_t c[8], uint32_t s[8], uint32_t sb[8], const uint8_t* h,
+                                        const uint8_t* gamma, const uint8_t* pk_com, const uint8_t* r, const uint8_t* ok_pt,
+                                        const uint8_t* s_be, const uint8_t* sb_be, const uint8_t* ad, uint32_t ad_len,
+                                        const SuiteStr& ss) {
+  bool ok = true;
+  Sec1W enc[5];
+#pragma unroll 1
+  for (int j = 0; j < 5; ++j) {
+    const uint8_t* e = j == 0 ? h : j == 1 ? gamma : j == 2 ? pk_com : j == 3 ? r : ok_pt;
+    FeN xx, yy;
+    ok = sec1_decode(xx, yy, e) && ok;
+    Sec1W w;
+    w.tag = e[0];
+    load_be256(w.xw, e + 1);
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+      if (j == k) { x[k] = xx; y[k] = yy; enc[k] = w; }
+  }
+  const Sec1W pts[5] = {enc[2], enc[0], enc[1], enc[3], enc[4]};
+  p256_challenge(c, pts, ad, ad_len, ss);
+  const bool s_ok = p256_scalar_decode(s, s_be), sb_ok = p256_scalar_decode(sb, sb_be);
+  return ok && s_ok && sb_ok;
+}
+// verify, stage 2: the two equations as "is the point at infinity":  s H - c Gamma - Ok  and  s G + sb B - c pk_com - R
+VRF_HD bool sw_is_infinity(const PtW& p) { return fe_is_zero(p.Z); }
+VRF_HD bool p256_ped_verify_eq_h(const uint32_t* tabH, const uint32_t* tabG, size_t stride, const FeN& okx, const FeN& oky,
+                                 const uint32_t s[8], const uint32_t c[8], int cw) {
+  const PtW v = sw_straus_sc(tabH, tabG, stride, s, c, cw);
+  return sw_is_infinity(sw_add(v, sw_cneg(true, sw_from_affine(okx, oky))));
+}
+VRF_HD bool p256_ped_verify_eq_g(const uint32_t* comb_g, const uint32_t* comb_b, const uint32_t* tabP, size_t stride, const FeN& rx,
+                                 const FeN& ry, const uint32_t s[8], const uint32_t sb[8], const uint32_t c[8], int cw) {
+  PtW u = sw_comb_minus_win(comb_g, tabP, stride, s, c, cw);
+  u = sw_add(u, sw_comb_mul(comb_b, sb));
+  return sw_is_infinity(sw_add(u, sw_cneg(true, sw_from_affine(rx, ry))));
+}
+
 VRF_NS_END

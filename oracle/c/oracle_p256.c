@@ -362,18 +362,103 @@ int p256_ietf_verify(const uint8_t pk[33], const uint8_t h[33], const uint8_t ga
   return cmp4(cc, c) == 0 ? 0 : 1;
 }
 
+/* ---- Pedersen VRF (oracle/sw_oracle.py pedersen_*; unpinned on this suite) ---- */
+static jac BB_;                                   /* the blinding base the tests set (p256_set_blinding_base) */
+static int have_bb = 0;
+int p256_set_blinding_base(const uint8_t bx_be[32], const uint8_t by_be[32]) {
+  ensure_init();
+  uint64_t xi[4], yi[4]; fe x, y;
+  load_be(xi, bx_be); load_be(yi, by_be);
+  to_mont(&FP, x.v, xi); to_mont(&FP, y.v, yi);
+  jac_from_affine(&BB_, &x, &y);
+  have_bb = 1;
+  return 0;
+}
+static void blinding(uint64_t b[4], const uint64_t sk[4], const uint8_t henc[33], const uint8_t* ad, size_t ad_len) {
+  sha256_ctx c; uint8_t pre[2] = {SUITE_ID, 0xCC}, z = 0, skb[32], h[32];
+  store_be(skb, sk);
+  sha256_init(&c); sha256_update(&c, pre, 2); sha256_update(&c, skb, 32); sha256_update(&c, henc, 33);
+  sha256_update(&c, ad, ad_len); sha256_update(&c, &z, 1); sha256_final(&c, h);
+  uint64_t t[4]; load_be(t, h); reduce256(&FN, b, t);
+}
+static void n_muladd(uint64_t out[4], const uint64_t a[4], const uint64_t b[4], const uint64_t c[4]) {   /* a b + c mod n */
+  uint64_t am[4], bm[4], cm[4], p[4], r[4];
+  to_mont(&FN, am, a); to_mont(&FN, bm, b); to_mont(&FN, cm, c);
+  f_mul(&FN, p, am, bm); f_add(&FN, r, p, cm); from_mont(&FN, out, r);
+}
+/* outputs: gamma, pk_com, r, ok 33 each; s, sb 32; blinding 32 (nullable); h_out 33 (nullable) */
+int p256_pedersen_prove(const uint8_t sk_be[32], const uint8_t* msg, size_t msg_len, const uint8_t* h_given, const uint8_t* ad,
+                        size_t ad_len, uint8_t gamma[33], uint8_t pk_com[33], uint8_t r_out[33], uint8_t ok_out[33], uint8_t s_be[32],
+                        uint8_t sb_be[32], uint8_t* blinding_out, uint8_t* h_out) {
+  ensure_init();
+  if (!have_bb) return 2;
+  uint64_t t[4], sk[4], k[4], kb[4], b[4];
+  load_be(t, sk_be); reduce256(&FN, sk, t);
+  if (cmp4(t, N_M) >= 0) return 2;
+  jac H, G, Gam, t1, t2, PC, R, OK;
+  uint8_t henc[33];
+  if (h_given) { if (!sec1_decode(&H, h_given)) return 2; memcpy(henc, h_given, 33); }
+  else if (!hash_to_curve_tai(&H, henc, msg, msg_len)) return 2;
+  jac_from_affine(&G, &GX_M, &GY_M);
+  blinding(b, sk, henc, ad, ad_len);
+  nonce_rfc6979(k, sk, henc, 33); nonce_rfc6979(kb, b, henc, 33);
+  jac_mul(&Gam, &H, sk);
+  jac_mul(&t1, &G, sk); jac_mul(&t2, &BB_, b); jac_add(&PC, &t1, &t2);
+  jac_mul(&t1, &G, k); jac_mul(&t2, &BB_, kb); jac_add(&R, &t1, &t2);
+  jac_mul(&OK, &H, k);
+  size_t lens[5] = {sec1_encode(pk_com, &PC), 33, sec1_encode(gamma, &Gam), sec1_encode(r_out, &R), sec1_encode(ok_out, &OK)};
+  const uint8_t* encs[5] = {pk_com, henc, gamma, r_out, ok_out};
+  uint64_t c[4], s[4], sb[4];
+  challenge(c, encs, lens, ad, ad_len);
+  n_muladd(s, c, sk, k); n_muladd(sb, c, b, kb);
+  store_be(s_be, s); store_be(sb_be, sb);
+  if (blinding_out) store_be(blinding_out, b);
+  if (h_out) memcpy(h_out, henc, 33);
+  return 0;
+}
+int p256_pedersen_verify(const uint8_t h[33], const uint8_t gamma[33], const uint8_t pk_com[33], const uint8_t r[33],
+                         const uint8_t ok[33], const uint8_t s_be[32], const uint8_t sb_be[32], const uint8_t* ad, size_t ad_len) {
+  ensure_init();
+  if (!have_bb) return 2;
+  jac H, Gam, PC, R, OK, G, t1, t2, lhs, rhs;
+  if (!sec1_decode(&H, h) || !sec1_decode(&Gam, gamma) || !sec1_decode(&PC, pk_com) || !sec1_decode(&R, r) || !sec1_decode(&OK, ok)) return 2;
+  uint64_t t[4], s[4], sb[4], c[4];
+  load_be(t, s_be); reduce256(&FN, s, t); if (cmp4(t, N_M) >= 0) return 2;
+  load_be(t, sb_be); reduce256(&FN, sb, t); if (cmp4(t, N_M) >= 0) return 2;
+  size_t lens[5] = {33, 33, 33, 33, 33};
+  const uint8_t* encs[5] = {pk_com, h, gamma, r, ok};
+  challenge(c, encs, lens, ad, ad_len);
+  uint8_t e1[33], e2[33];
+  jac_from_affine(&G, &GX_M, &GY_M);
+  jac_mul(&t1, &Gam, c); jac_add(&lhs, &t1, &OK); jac_mul(&rhs, &H, s);           /* c Gamma + Ok == s H */
+  size_t l1 = sec1_encode(e1, &lhs), l2 = sec1_encode(e2, &rhs);
+  if (l1 != l2 || memcmp(e1, e2, l1)) return 1;
+  jac_mul(&t1, &PC, c); jac_add(&lhs, &t1, &R);                                   /* c pk_com + R == s G + sb B */
+  jac_mul(&t1, &G, s); jac_mul(&t2, &BB_, sb); jac_add(&rhs, &t1, &t2);
+  l1 = sec1_encode(e1, &lhs); l2 = sec1_encode(e2, &rhs);
+  return (l1 == l2 && !memcmp(e1, e2, l1)) ? 0 : 1;
+}
+
 /* ---- batch drivers ---- */
 typedef struct {
   int kind; size_t lo, hi;
-  const uint8_t *a0, *a1, *a2, *a3, *a4, *ad; size_t ad_len, msg_len;
-  uint8_t *o0, *o1, *o2, *o3, *o4, *st;
+  const uint8_t *a0, *a1, *a2, *a3, *a4, *a5, *a6, *ad; size_t ad_len, msg_len;
+  uint8_t *o0, *o1, *o2, *o3, *o4, *o5, *o6, *o7, *st;
 } pjob;
 static void* p_run(void* arg) {
   pjob* j = (pjob*)arg;
   for (size_t i = j->lo; i < j->hi; ++i) {
     if (j->kind == 0)
       j->st[i] = (uint8_t)p256_ietf_verify(j->a0 + 33 * i, j->a1 + 33 * i, j->a2 + 33 * i, j->a3 + 32 * i, j->a4 + 32 * i, j->ad, j->ad_len);
-    else {
+    else if (j->kind == 2)          /* a0..a4: h, gamma, pk_com, r, ok; a5, a6: s, sb */
+      j->st[i] = (uint8_t)p256_pedersen_verify(j->a0 + 33 * i, j->a1 + 33 * i, j->a2 + 33 * i, j->a3 + 33 * i, j->a4 + 33 * i,
+                                               j->a5 + 32 * i, j->a6 + 32 * i, j->ad, j->ad_len);
+    else if (j->kind == 3) {        /* o0..o3: gamma, pk_com, r, ok; o4, o5: s, sb; o6: blinding; o7: h */
+      int rc = p256_pedersen_prove(j->a0 + 32 * i, j->a1 ? j->a1 + j->msg_len * i : NULL, j->msg_len, j->a2 ? j->a2 + 33 * i : NULL,
+                                   j->ad, j->ad_len, j->o0 + 33 * i, j->o1 + 33 * i, j->o2 + 33 * i, j->o3 + 33 * i, j->o4 + 32 * i,
+                                   j->o5 + 32 * i, j->o6 ? j->o6 + 32 * i : NULL, j->o7 ? j->o7 + 33 * i : NULL);
+      if (j->st) j->st[i] = (uint8_t)rc;
+    } else {
       int rc = p256_ietf_prove(j->a0 + 32 * i, j->a1 ? j->a1 + j->msg_len * i : NULL, j->msg_len, j->a2 ? j->a2 + 33 * i : NULL, j->ad,
                                j->ad_len, j->o0 + 33 * i, j->o1 + 32 * i, j->o2 + 32 * i, j->o3 ? j->o3 + 33 * i : NULL,
                                j->o4 ? j->o4 + 33 * i : NULL);
@@ -407,5 +492,20 @@ void p256_ietf_prove_batch(size_t n, const uint8_t* sk, const uint8_t* msg, size
   pjob j; memset(&j, 0, sizeof j);
   j.kind = 1; j.a0 = sk; j.a1 = msg; j.msg_len = msg_len; j.a2 = h_given; j.ad = ad; j.ad_len = ad_len;
   j.o0 = gamma; j.o1 = c; j.o2 = s; j.o3 = pk_out; j.o4 = h_out; j.st = status;
+  p_batch(j, n, threads);
+}
+void p256_pedersen_verify_batch(size_t n, const uint8_t* h, const uint8_t* gamma, const uint8_t* pk_com, const uint8_t* r,
+                                const uint8_t* ok, const uint8_t* s, const uint8_t* sb, const uint8_t* ad, size_t ad_len,
+                                uint8_t* status, int threads) {
+  pjob j; memset(&j, 0, sizeof j);
+  j.kind = 2; j.a0 = h; j.a1 = gamma; j.a2 = pk_com; j.a3 = r; j.a4 = ok; j.a5 = s; j.a6 = sb; j.ad = ad; j.ad_len = ad_len; j.st = status;
+  p_batch(j, n, threads);
+}
+void p256_pedersen_prove_batch(size_t n, const uint8_t* sk, const uint8_t* msg, size_t msg_len, const uint8_t* h_given,
+                               const uint8_t* ad, size_t ad_len, uint8_t* gamma, uint8_t* pk_com, uint8_t* r, uint8_t* ok, uint8_t* s,
+                               uint8_t* sb, uint8_t* blinding_out, uint8_t* h_out, uint8_t* status, int threads) {
+  pjob j; memset(&j, 0, sizeof j);
+  j.kind = 3; j.a0 = sk; j.a1 = msg; j.msg_len = msg_len; j.a2 = h_given; j.ad = ad; j.ad_len = ad_len;
+  j.o0 = gamma; j.o1 = pk_com; j.o2 = r; j.o3 = ok; j.o4 = s; j.o5 = sb; j.o6 = blinding_out; j.o7 = h_out; j.st = status;
   p_batch(j, n, threads);
 }

@@ -58,6 +58,11 @@ def load() -> ctypes.CDLL:
         lib.p256_ietf_verify_batch.restype = None
         lib.p256_ietf_prove_batch.argtypes = [c_size_t, P, P, c_size_t, P, P, c_size_t, P, P, P, P, P, P, c_int]
         lib.p256_ietf_prove_batch.restype = None
+        lib.p256_set_blinding_base.argtypes = [P, P]
+        lib.p256_pedersen_verify_batch.argtypes = [c_size_t, P, P, P, P, P, P, P, P, c_size_t, P, c_int]
+        lib.p256_pedersen_verify_batch.restype = None
+        lib.p256_pedersen_prove_batch.argtypes = [c_size_t, P, P, c_size_t, P, P, c_size_t, P, P, P, P, P, P, P, P, P, c_int]
+        lib.p256_pedersen_prove_batch.restype = None
         lib.p256_secret_from_seed.argtypes = [P, c_size_t, P]
         lib.p256_public_from_secret.argtypes = [P, P]
         lib.p256_hash_to_curve.argtypes = [P, c_size_t, P]
@@ -370,3 +375,40 @@ def p256_output_hash(gamma33: bytes) -> bytes:
 
 def p256_point_decode(enc33: bytes) -> int:
     return load().p256_point_decode(bytes(enc33))
+
+
+def p256_set_blinding_base(pt) -> None:
+    """The Pedersen blinding base (affine (x, y) ints) the p256_pedersen_* functions use."""
+    load().p256_set_blinding_base(int(pt[0]).to_bytes(32, "big"), int(pt[1]).to_bytes(32, "big"))
+
+
+def p256_pedersen_prove_batch(sk, msgs: np.ndarray = None, inputs=None, ad: bytes = b"", threads: int = 1):
+    sk = _a(sk).reshape(-1, 32)
+    n = sk.shape[0]
+    res = {k: np.empty((n, 32 if k in ("s", "sb", "blinding") else 33), dtype=np.uint8)
+           for k in ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input")}
+    st = np.empty(n, dtype=np.uint8)
+    adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
+    mp, ml, ip = None, 0, None
+    if inputs is not None:
+        inputs = _a(inputs).reshape(n, 33)
+        ip = inputs.ctypes.data
+    else:
+        msgs = _a(msgs).reshape(n, -1)
+        ml = msgs.shape[1]
+        msgs = np.concatenate([msgs.reshape(-1), np.zeros(1, np.uint8)])
+        mp = msgs.ctypes.data
+    load().p256_pedersen_prove_batch(n, sk.ctypes.data, mp, ml, ip, adb.ctypes.data, len(ad), *[res[k].ctypes.data for k in
+                                     ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input")], st.ctypes.data, threads)
+    res["status"] = st
+    return res
+
+
+def p256_pedersen_verify_batch(h, gamma, pk_com, r, ok, s, sb, ad: bytes = b"", threads: int = 1) -> np.ndarray:
+    pts = [_a(x).reshape(-1, 33) for x in (h, gamma, pk_com, r, ok)]
+    sc = [_a(x).reshape(-1, 32) for x in (s, sb)]
+    n = pts[0].shape[0]
+    st = np.empty(n, dtype=np.uint8)
+    adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
+    load().p256_pedersen_verify_batch(n, *[x.ctypes.data for x in pts + sc], adb.ctypes.data, len(ad), st.ctypes.data, threads)
+    return st

@@ -158,6 +158,46 @@ def ietf_verify(pk: Point, h: Point, gamma: Point, ad: bytes, c: int, s: int, su
     return challenge([pk, h, gamma, u, v], ad, suite_id, challenge_len) == c % N
 
 
+# ---- Pedersen VRF  [ref src/lib.rs:14 `pedersen`]  (SURVEY.md Appendix A.5, with this suite's codec and hash) ----
+# No vector pins this scheme on this suite, and upstream's BLINDING_BASE for it is not known here: the product's built-in
+# descriptor carries a nothing-up-my-sleeve point (tools/gen_constants.py), a caller that knows upstream's passes it in.
+def default_blinding_base() -> Point:
+    for ctr in range(256):
+        try:
+            return point_decode(b"\x02" + sha256(b"\x01\x01" + b"vrfhip-p256-blinding-base" + bytes([ctr]) + b"\x00"))
+        except ValueError:
+            continue
+    raise AssertionError
+
+
+def pedersen_blinding(sk: int, h: Point, ad: bytes, suite_id: bytes = SUITE_ID) -> int:
+    """[ref src/lib.rs:14 `pedersen::PedersenSuite::blinding`]"""
+    return scalar_decode(sha256(suite_id + b"\xCC" + scalar_encode(sk) + point_encode(h) + ad + b"\x00"))
+
+
+def pedersen_prove(sk: int, h: Point, ad: bytes, bb: Point, suite_id: bytes = SUITE_ID, challenge_len: int = CHALLENGE_LEN,
+                   gen: Point = G):
+    """[ref src/lib.rs:14 `pedersen::Prover::prove`] -> (gamma, (pk_com, r, ok, s, sb), blinding)."""
+    gamma = mul(sk, h)
+    b = pedersen_blinding(sk, h, ad, suite_id)
+    k, kb = nonce_rfc6979(sk, h), nonce_rfc6979(b, h)
+    pk_com = add(mul(sk, gen), mul(b, bb))
+    r = add(mul(k, gen), mul(kb, bb))
+    ok = mul(k, h)
+    c = challenge([pk_com, h, gamma, r, ok], ad, suite_id, challenge_len)
+    return gamma, (pk_com, r, ok, (k + c * sk) % N, (kb + c * b) % N), b
+
+
+def pedersen_verify(h: Point, gamma: Point, proof, ad: bytes, bb: Point, suite_id: bytes = SUITE_ID,
+                    challenge_len: int = CHALLENGE_LEN, gen: Point = G) -> bool:
+    """[ref src/lib.rs:14 `pedersen::Verifier::verify`]"""
+    pk_com, r, ok, s, sb = proof
+    c = challenge([pk_com, h, gamma, r, ok], ad, suite_id, challenge_len)
+    if add(mul(c, gamma), ok) != mul(s, h):
+        return False
+    return add(mul(c, pk_com), r) == add(mul(s, gen), mul(sb, bb))
+
+
 def rfc9381_prove(sk_bytes: bytes, alpha: bytes) -> dict:
     """ECVRF_prove(SK, alpha) of RFC 9381 with every intermediate the appendix prints, through the functions above
     (encode_to_curve_salt = PK_string)."""

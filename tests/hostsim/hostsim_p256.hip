@@ -23,6 +23,7 @@ std::vector<uint32_t>& comb() {
   }
   return c;
 }
+std::vector<uint32_t> g_comb_b;          // comb of the Pedersen blinding base (hp_set_blinding_base)
 FeN in(const uint8_t* b) { uint32_t w[8]; load_be256(w, b); return fe_from_u256(w); }
 template <int L, int V> void out(uint8_t* b, const Fe<L, V>& a) { uint32_t w[8]; fe_to_u256(w, a); store_be256(b, w); }
 // affine big-endian x || y (all zero = the point at infinity)
@@ -134,5 +135,40 @@ int hp_verify(const uint8_t* pk, const uint8_t* h, const uint8_t* gamma, const u
   PtW U = sw_comb_minus_win(comb().data(), ty.data(), 1, s, c, sw_challenge_windows(g_str));
   PtW V = sw_straus_sc(th.data(), tg.data(), 1, s, c, sw_challenge_windows(g_str));
   return p256_verify_finish_item(U, V, enc, c, ad, ad_len, g_str);
+}
+// ---- Pedersen, staged as k_p256.hip stages it ----
+void hp_set_blinding_base(const uint8_t* xy) {       // affine big-endian x || y
+  g_comb_b.assign(P256_COMB_WORDS, 0);
+  for (int w = 0; w < P256_COMB_ROWS; ++w) p256_comb_build_row(g_comb_b.data(), w, in(xy), in(xy + 32));
+}
+// out: gamma 33 | pk_com 33 | r 33 | ok 33 | s 32 | sb 32 | blinding 32 | h 33
+int hp_ped_prove(const uint8_t* sk_be, const uint8_t* msg, uint32_t msg_len, const uint8_t* ad, uint32_t ad_len, uint8_t* o) {
+  uint32_t sk[8], k[8], b[8], kb[8]; FeN hx, hy; Sec1W henc;
+  if (!p256_prove_prepare_item(sk, k, hx, hy, henc, sk_be, msg, msg_len, nullptr, g_str)) return 0;
+  p256_blinding(b, sk, henc, ad, ad_len, g_str);
+  p256_nonce(kb, b, henc.tag, henc.xw);
+  std::vector<uint32_t> tab(SW_TABLE_WORDS);
+  sw_build_table(tab.data(), 1, sw_from_affine(hx, hy));
+  const PtW res[4] = {sw_add(sw_comb_mul(comb().data(), sk), sw_comb_mul(g_comb_b.data(), b)), sw_win_mul(tab.data(), 1, sk, false),
+                      sw_add(sw_comb_mul(comb().data(), k), sw_comb_mul(g_comb_b.data(), kb)), sw_win_mul(tab.data(), 1, k, false)};
+  Sec1W enc[4]; uint32_t s[8], sb[8];
+  p256_ped_prove_finish_item(enc, s, sb, res, henc, sk, k, b, kb, ad, ad_len, g_str);
+  sec1_store(o, enc[1].tag, enc[1].xw); sec1_store(o + 33, enc[0].tag, enc[0].xw); sec1_store(o + 66, enc[2].tag, enc[2].xw);
+  sec1_store(o + 99, enc[3].tag, enc[3].xw); store_be256(o + 132, s); store_be256(o + 164, sb); store_be256(o + 196, b);
+  sec1_store(o + 228, henc.tag, henc.xw);
+  return 1;
+}
+int hp_ped_verify(const uint8_t* h, const uint8_t* gamma, const uint8_t* pk_com, const uint8_t* r, const uint8_t* ok, const uint8_t* s_be,
+                  const uint8_t* sb_be, const uint8_t* ad, uint32_t ad_len) {
+  FeN x[5], y[5]; uint32_t c[8], s[8], sb[8];
+  if (!p256_ped_verify_decode_item(x, y, c, s, sb, h, gamma, pk_com, r, ok, s_be, sb_be, ad, ad_len, g_str)) return 2;
+  std::vector<uint32_t> th(SW_TABLE_WORDS), tg(SW_TABLE_WORDS), tp(SW_TABLE_WORDS);
+  sw_build_table(th.data(), 1, sw_from_affine(x[0], y[0]));
+  sw_build_table(tg.data(), 1, sw_from_affine(x[1], y[1]));
+  sw_build_table(tp.data(), 1, sw_from_affine(x[2], y[2]));
+  const int cw = sw_challenge_windows(g_str);
+  const bool e1 = p256_ped_verify_eq_h(th.data(), tg.data(), 1, x[4], y[4], s, c, cw);
+  const bool e2 = p256_ped_verify_eq_g(comb().data(), g_comb_b.data(), tp.data(), 1, x[3], y[3], s, sb, c, cw);
+  return (e1 && e2) ? 0 : 1;
 }
 }

@@ -296,6 +296,40 @@ def test_host_build_prove_and_verify_equal_the_oracle(hp):
         assert hp.hp_verify(pk, pk, pk, be(c), be(s), ad, len(ad)) == (0 if sw.ietf_verify(sw.mul(sk, G), sw.mul(sk, G), sw.mul(sk, G), ad, c, s) else 1)
 
 
+def test_pedersen_host_build_and_c_oracle_equal_the_python_oracle(hp):
+    """The Pedersen scheme on this suite (unpinned: no vector, upstream's blinding base unknown) -- three restatements of
+    the same algorithm held against each other: Python, C, and the device headers on the host; then tampering."""
+    B = sw.default_blinding_base()
+    assert sw.is_on_curve(B) and sw.mul(N, B) is None
+    hp.hp_set_blinding_base(xy(B))
+    co.p256_set_blinding_base(B)
+    rnd = random.Random(12)
+    for i in range(4):
+        sk = sw.secret_from_seed(b"ped%d" % i)
+        msg, ad = b"pm%d" % i * (i + 2), b"a" * i
+        H, _ = sw.hash_to_curve_tai(msg)
+        g, (pc, R, Ok, s, sb), b = sw.pedersen_prove(sk, H, ad, B)
+        assert sw.pedersen_verify(H, g, (pc, R, Ok, s, sb), ad, B) and not sw.pedersen_verify(H, g, (pc, R, Ok, s, sb ^ 1), ad, B)
+        out = ctypes.create_string_buffer(261)
+        assert hp.hp_ped_prove(be(sk), msg, len(msg), ad, len(ad), out) == 1
+        o = out.raw
+        enc = sw.point_encode
+        assert o == enc(g) + enc(pc) + enc(R) + enc(Ok) + be(s) + be(sb) + be(b) + enc(H)
+        rc = co.p256_pedersen_prove_batch(np.frombuffer(be(sk), np.uint8), msgs=np.frombuffer(msg, np.uint8).reshape(1, -1), ad=ad)
+        assert b"".join(rc[k][0].tobytes() for k in ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input")) == o
+        h33, g33, pc33, r33, ok33 = o[228:261], o[:33], o[33:66], o[66:99], o[99:132]
+        args = (h33, g33, pc33, r33, ok33, o[132:164], o[164:196])
+        assert hp.hp_ped_verify(*args, ad, len(ad)) == 0
+        assert hp.hp_ped_verify(*args, ad + b"x", len(ad) + 1) == 1
+        for j in range(7):                                    # every field tampered with: a wrong point, a wrong scalar
+            bad = list(args)
+            bad[j] = enc(sw.mul(rnd.randrange(1, N), G)) if j < 5 else be((int.from_bytes(args[j], "big") + 1) % N)
+            want = co.p256_pedersen_verify_batch(*[np.frombuffer(x, np.uint8) for x in bad], ad=ad)[0]
+            assert want == 1 and hp.hp_ped_verify(*bad, ad, len(ad)) == 1, j
+        assert hp.hp_ped_verify(h33, g33, b"\x04" + pc33[1:], r33, ok33, o[132:164], o[164:196], ad, len(ad)) == 2
+        assert hp.hp_ped_verify(h33, g33, pc33, r33, ok33, be(N), o[164:196], ad, len(ad)) == 2            # s >= n
+
+
 def _on_curve_x(x):
     y2 = (x ** 3 - 3 * x + sw.B) % P
     return pow(y2, (P - 1) // 2, P) in (0, 1)
@@ -517,11 +551,69 @@ def test_gpu_descriptor_supplies_suite_string_challenge_length_and_generator():
 
 
 @pytest.mark.gpu
+def test_gpu_pedersen_equals_the_c_oracle(gpu):
+    """Pedersen prove bytes and verify statuses on the GPU against oracle/c/oracle_p256.c (itself held against the Python
+    oracle on CPU), with the built-in blinding base; mixed defects; a context whose descriptor has no base refuses."""
+    from ark_ec_vrfs_amd import Context, SuiteDesc, CURVE_SECP256R1, VrfHipError, pedersen_prove_batch_multi, pedersen_verify_batch_multi
+    B = sw.default_blinding_base()
+    co.p256_set_blinding_base(B)
+    d = gpu.desc()
+    assert d.blinding_base == int(B[0]).to_bytes(32, "little") + int(B[1]).to_bytes(32, "little")
+    n = 3000
+    gpu.reserve(2048)
+    try:
+        rng = np.random.default_rng(33)
+        sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        sk[5] = np.frombuffer(be(N + 1), np.uint8)                      # not canonical: InvalidData
+        msg = rng.integers(0, 256, (n, 28), dtype=np.uint8)
+        r = gpu.pedersen_prove_batch(sk, msgs=msg, ad=b"ped")
+        ref = co.p256_pedersen_prove_batch(sk, msgs=msg, ad=b"ped", threads=8)
+        names = ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input")
+        good = np.ones(n, bool); good[5] = False
+        assert (r["status"] == ref["status"]).all() and r["status"][5] == 2 and r["status"].sum() == 2
+        for k in names:
+            assert (r[k][good] == ref[k][good]).all(), k
+            assert not r[k][5].any()
+            r[k][5] = r[k][6]
+        pts = [r[k].copy() for k in ("input", "output", "pk_com", "r", "ok")]
+        sc = [r[k].copy() for k in ("s", "sb")]
+        kind = rng.integers(0, 10, n)
+        for i in range(n):
+            j = kind[i]
+            if j < 5: pts[j][i, rng.integers(1, 33)] ^= 1 << rng.integers(0, 8)          # another x: another point or none
+            elif j < 7: sc[j - 5][i, rng.integers(0, 32)] ^= 1 << rng.integers(0, 8)
+            elif j == 7: pts[rng.integers(0, 5)][i, 0] = 9                                # bad tag
+        got = gpu.pedersen_verify_batch(*pts, *sc, ad=b"ped")
+        want = co.p256_pedersen_verify_batch(*pts, *sc, ad=b"ped", threads=8)
+        assert (got == want).all(), np.nonzero(got != want)[0][:10]
+        assert set(np.unique(want)) == {0, 1, 2} and (want[kind >= 8] == 0).all()
+        assert (gpu.pedersen_verify_batch(*[r[k] for k in ("input", "output", "pk_com", "r", "ok", "s", "sb")], ad=b"pee") == 1).all()
+        other = Context(0, gpu.suite)
+        try:
+            m = 1001
+            rm = pedersen_prove_batch_multi([gpu, other], sk[6:6 + m], [x.tobytes() for x in msg[6:6 + m]], ad=b"ped")
+            assert all((rm[k] == ref[k][6:6 + m]).all() for k in names)
+            stm = pedersen_verify_batch_multi([gpu, other], *[p_[6:6 + m] for p_ in pts], *[s_[6:6 + m] for s_ in sc], ad=b"ped")
+            assert (stm == want[6:6 + m]).all()
+        finally:
+            other.close()
+    finally:
+        gpu.reserve(1 << 20)
+    nob = Context(0, desc=SuiteDesc(CURVE_SECP256R1, b"\x01", b"", d.generator, bytes(64), challenge_len=16))
+    try:
+        with pytest.raises(VrfHipError):
+            nob.pedersen_prove_batch(np.zeros((1, 32), np.uint8), msgs=[b"a"])
+        assert nob.ietf_prove_batch(np.frombuffer(be(7), np.uint8), msgs=[b"a"])["status"][0] == 0
+    finally:
+        nob.close()
+
+
+@pytest.mark.gpu
 def test_gpu_entry_points_outside_the_suite_are_refused(gpu):
     from ark_ec_vrfs_amd import VrfHipError
     z32, z33 = np.zeros((2, 32), np.uint8), np.zeros((2, 33), np.uint8)
     with pytest.raises(VrfHipError):
-        gpu.pedersen_prove_batch(z32, msgs=[b"a", b"b"])
+        gpu.pedersen_verify_batch_rlc(z32, z32, z32, z32, z32, z32, z32, seed=bytes(32))    # refused before any byte is read
     with pytest.raises(VrfHipError):
         gpu.msm(np.zeros((2, 64), np.uint8), z32)
     with pytest.raises(VrfHipError):

@@ -818,8 +818,24 @@ def gen_field3():
     ap(carr("P256_R_R1", words32((1 << 256) % n)))
     ap(carr("P256_R_R2", words32((1 << 512) % n)))
     ap(carr("P256_RH32", words32(n >> 1)))
+    # built-in Pedersen blinding base: upstream's constant for this suite is not known here, so -- as for JubJub, Ed25519
+    # and Baby-JubJub -- a nothing-up-my-sleeve point: try-and-increment (RFC 9381 5.4.1.1 with this suite's own string
+    # and interpret_hash_value_as_a_point = 0x02 || hash) of a fixed label.  A caller that knows upstream's passes it in
+    # the descriptor.
+    Bp = None
+    for ctr in range(256):
+        h = hashlib.sha256(b"\x01\x01" + b"vrfhip-p256-blinding-base" + bytes([ctr]) + b"\x00").digest()
+        x = int.from_bytes(h, "big")
+        if x >= q:
+            continue
+        y = F.sqrt((x * x * x - 3 * x + P256["b"]) % q)
+        if y is None:
+            continue
+        Bp = (x, y if y % 2 == 0 else q - y)
+        break
+    assert Bp and sw_mul(F, n, Bp) is None and Bp != G
     emit_field_traits(ap, F, st)
-    emit_tables(ap, F, st, [("P256_G_XY", G)])
+    emit_tables(ap, F, st, [("P256_G_XY", G), ("P256_B_XY", Bp)])
     write("constants_fp256.gen.h", out)
 
 
