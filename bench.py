@@ -501,6 +501,33 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
         cx.set_prevalidated(False)
         res["ietf_verify_" + tag]["prevalidated"] = {"value": D.world * n * max(2, args.config_steps) / el_p, "unit": "verifies/s",
                                                      "ms_per_step": el_p / max(2, args.config_steps) * 1e3}
+        if sw:
+            # the Pedersen scheme on this suite (built-in nothing-up-my-sleeve blinding base), per proof
+            pc, rr, okp, sbb = mkp(), mkp(), mkp(), mk()
+            fn = lambda: cx.pedersen_prove_batch_dev(sk, msg, 32, g, pc, rr, okp, s_, sbb, None, hh, st)
+            fn(); torch.cuda.synchronize()
+            cx.profile(True)
+            el, _ = timed(D, fn, args.config_steps, 1)
+            cx.profile(False)
+            ms, groups = stage_avg(cx)
+            assert int(st.sum()) == 0
+            res["pedersen_prove_" + tag] = {
+                "workload": "Pedersen VRF prove, %s, batch 2^%d per GPU" % (title, lg),
+                "value": D.world * n * args.config_steps / el, "unit": "proofs/s", "ms_per_step": el / args.config_steps * 1e3,
+                "stage_ms_per_step": {"tai_find+prepare": ms[0], "mul": ms[1], "finish": ms[3]}}
+            fn = lambda: cx.pedersen_verify_batch_dev(hh, g, pc, rr, okp, s_, sbb, st)
+            fn(); torch.cuda.synchronize()
+            cx.profile(True)
+            el, _ = timed(D, fn, args.config_steps, 1)
+            cx.profile(False)
+            ms, groups = stage_avg(cx)
+            assert int(st.sum()) == 0
+            res["pedersen_verify_" + tag] = {
+                "workload": "Pedersen VRF verify, %s, batch 2^%d per GPU, per proof, Sec1 wire format" % (title, lg),
+                "value": D.world * n * args.config_steps / el, "unit": "verifies/s", "ms_per_step": el / args.config_steps * 1e3,
+                "stage_ms_per_step": {"decode": ms[0], "eq_h": ms[1], "eq_g": ms[2], "finish": ms[3]}}
+            fn = lambda: cx.ietf_prove_batch_dev(sk, msg, 32, g, c, s_, pk, hh, st)        # the IETF proofs back for the CPU leg
+            fn(); torch.cuda.synchronize()
         if want_cpu:
             from oracle import c_oracle as co
             cap = 1 << 15

@@ -74,8 +74,11 @@ typedef enum vrfhip_suite {
    * other suites a secret key and the proof's `s` must be canonical (< n, else InvalidData: RFC 9381 5.4.4) while `c` is taken
    * mod n; a point needs tag 0x02 / 0x03, x < p and to lie on the curve (cofactor 1: no subgroup test).  Entry points:
    * vrfhip_ietf_prove_batch / _verify_batch (+ _dev, _multi), vrfhip_hash_to_curve_batch, vrfhip_output_hash_batch,
-   * vrfhip_secret_from_seed_batch, vrfhip_point_validate_batch (+ _dev); everything else returns VRFHIP_ERR_UNSUPPORTED
-   * (Pedersen / MSM / key sets / x||y forms are not built for it).  Pinned by RFC 9381 Appendix B.1, which upstream's own
+   * vrfhip_secret_from_seed_batch, vrfhip_point_validate_batch (+ _dev), and the Pedersen scheme per proof:
+   * vrfhip_pedersen_prove_batch / vrfhip_pedersen_verify_batch (+ _dev, _multi) when the descriptor carries a blinding base
+   * (the built-in one is a nothing-up-my-sleeve point: upstream's `BLINDING_BASE` for this suite is not known here; a
+   * descriptor with an all-zero base makes a context without the scheme).  Everything else returns VRFHIP_ERR_UNSUPPORTED
+   * (the batched Pedersen verifier, MSM, key sets and the x||y forms are not built for it).  Pinned by RFC 9381 Appendix B.1, which upstream's own
    * tests run: tests/golden/rfc9381_p256_sha256_tai.json (the RFC's use: message = PK_string || alpha).  As upstream, the
    * RFC 6979 nonce takes h1 unreduced and the first HMAC_DRBG candidate mod n (each differs from the RFC text with
    * probability 2^-32). */
@@ -94,8 +97,9 @@ typedef enum vrfhip_curve {
   VRFHIP_CURVE_ED25519 = 3,      /* ark-ed25519: q = 2^255 - 19, a = -1, cofactor 8; try-and-increment */
   VRFHIP_CURVE_BABY_JUBJUB = 4,  /* ark-ed-on-bn254: q = BN254 Fr, a = 1, cofactor 8; try-and-increment */
   VRFHIP_CURVE_SECP256R1 = 5     /* ark-secp256r1: y^2 = x^3 - 3x + b over the NIST P-256 prime, cofactor 1; try-and-increment,
-                                    SHA-256, Sec1 wire format.  Descriptor: suite_id, challenge_len and generator are read
-                                    (generator still x || y little-endian); flags must be 0, blinding_base is ignored */
+                                    SHA-256, Sec1 wire format.  Descriptor: suite_id, challenge_len, generator and
+                                    blinding_base are read (points still x || y little-endian; an all-zero blinding_base =
+                                    no Pedersen scheme); flags must be 0 */
 } vrfhip_curve;
 
 /* What a `Suite` impl may override besides its constants (`Suite::Codec`, `Suite::challenge`, `Suite::point_to_hash`):

@@ -446,6 +446,101 @@ impl GpuBatchSec1 {
     }
 }
 
+impl GpuBatchSec1 {
+    /// `pedersen::Prover::prove` per (secret, input) pair: (output, proof, blinding factor) or the item's `Error`.  The
+    /// contexts must have been made from a descriptor that carries upstream's `BLINDING_BASE` for the suite
+    /// ([`GpuBatchSec1::with_blinding_base`]); the library's built-in base is a placeholder.
+    pub fn pedersen_prove(
+        &self,
+        secrets: &[Secret<P256>],
+        inputs: &[Input<P256>],
+        ad: &[u8],
+    ) -> Result<Vec<Result<(Output<P256>, pedersen::Proof<P256>, ScalarField<P256>), Error>>, GpuError> {
+        let n = secrets.len();
+        assert_eq!(n, inputs.len());
+        let (mut sk, mut h) = (vec![0u8; n * 32], vec![0u8; n * SEC1]);
+        for i in 0..n {
+            Self::put_scalar(&secrets[i].scalar, &mut sk[i * 32..(i + 1) * 32]);
+            Self::put_point(&inputs[i].0, &mut h[i * SEC1..(i + 1) * SEC1]);
+        }
+        let mut p = vec![0u8; 4 * n * SEC1]; // gamma | pk_com | r | ok
+        let mut o = vec![0u8; 3 * n * 32]; // s | sb | blinding
+        let mut status = vec![0u8; n];
+        let (q, w) = (p.as_mut_ptr(), o.as_mut_ptr());
+        check(unsafe {
+            ffi::vrfhip_pedersen_prove_batch_multi(
+                self.ctxs.as_ptr(), self.ctxs.len() as i32, n, sk.as_ptr(), core::ptr::null(), core::ptr::null(), 0,
+                h.as_ptr(), ad.as_ptr(), core::ptr::null(), ad.len() as u32, q, q.add(n * SEC1), q.add(2 * n * SEC1),
+                q.add(3 * n * SEC1), w, w.add(n * 32), w.add(2 * n * 32), core::ptr::null_mut(),
+                status.as_mut_ptr(),
+            )
+        })?;
+        sk.iter_mut().for_each(|b| *b = 0);
+        let pt = |k: usize, i: usize| codec::point_decode::<P256>(&p[(k * n + i) * SEC1..(k * n + i + 1) * SEC1]);
+        let sc = |k: usize, i: usize| codec::scalar_decode::<P256>(&o[(k * n + i) * 32..(k * n + i + 1) * 32]);
+        let res = (0..n)
+            .map(|i| {
+                status_to_result(status[i])?;
+                let proof = pedersen::Proof::<P256> { pk_com: pt(1, i)?, r: pt(2, i)?, ok: pt(3, i)?, s: sc(0, i), sb: sc(1, i) };
+                Ok((Output::<P256>::from(pt(0, i)?), proof, sc(2, i)))
+            })
+            .collect();
+        o.iter_mut().for_each(|b| *b = 0); // blinding factors
+        Ok(res)
+    }
+
+    /// `pedersen::Verifier::verify` per item (per-proof kernels; the batched verifier is not built for this suite).
+    pub fn pedersen_verify(
+        &self,
+        inputs: &[Input<P256>],
+        outputs: &[Output<P256>],
+        ad: &[u8],
+        proofs: &[pedersen::Proof<P256>],
+    ) -> Result<Vec<Result<(), Error>>, GpuError> {
+        let n = inputs.len();
+        assert!(n == outputs.len() && n == proofs.len());
+        let mut pts = vec![0u8; 5 * n * SEC1]; // h | gamma | pk_com | r | ok
+        let mut sc = vec![0u8; 2 * n * 32]; // s | sb
+        for i in 0..n {
+            let at = |k: usize| (k * n + i) * SEC1..(k * n + i + 1) * SEC1;
+            Self::put_point(&inputs[i].0, &mut pts[at(0)]);
+            Self::put_point(&outputs[i].0, &mut pts[at(1)]);
+            Self::put_point(&proofs[i].pk_com, &mut pts[at(2)]);
+            Self::put_point(&proofs[i].r, &mut pts[at(3)]);
+            Self::put_point(&proofs[i].ok, &mut pts[at(4)]);
+            Self::put_scalar(&proofs[i].s, &mut sc[i * 32..(i + 1) * 32]);
+            Self::put_scalar(&proofs[i].sb, &mut sc[(n + i) * 32..(n + i + 1) * 32]);
+        }
+        let mut status = vec![0u8; n];
+        let (p, q) = (pts.as_ptr(), sc.as_ptr());
+        check(unsafe {
+            ffi::vrfhip_pedersen_verify_batch_multi(
+                self.ctxs.as_ptr(), self.ctxs.len() as i32, n, p, p.add(n * SEC1), p.add(2 * n * SEC1), p.add(3 * n * SEC1),
+                p.add(4 * n * SEC1), q, q.add(n * 32), ad.as_ptr(), core::ptr::null(), ad.len() as u32, core::ptr::null(),
+                status.as_mut_ptr(),
+            )
+        })?;
+        Ok(status.into_iter().map(status_to_result).collect())
+    }
+
+    /// Contexts whose descriptor carries the suite's own `PedersenSuite::BLINDING_BASE` (x || y, little-endian, as the
+    /// descriptor states every point) instead of the library's placeholder.
+    pub fn with_blinding_base(devices: &[i32]) -> Result<Self, GpuError> {
+        let mut desc: ffi::vrfhip_suite_desc = unsafe { core::mem::zeroed() };
+        check(unsafe { ffi::vrfhip_suite_desc_default(ffi::VRFHIP_SUITE_SECP256R1_SHA256_TAI, &mut desc) })?;
+        let b = <P256 as pedersen::PedersenSuite>::BLINDING_BASE;
+        b.x.serialize_uncompressed(&mut desc.blinding_base[..32]).expect("32-byte base field");
+        b.y.serialize_uncompressed(&mut desc.blinding_base[32..]).expect("32-byte base field");
+        let mut this = GpuBatchSec1 { ctxs: Vec::new() };
+        for &dev in devices {
+            let mut ctx: *mut ffi::vrfhip_ctx = core::ptr::null_mut();
+            check(unsafe { ffi::vrfhip_ctx_create_desc(&desc, dev, &mut ctx) })?;
+            this.ctxs.push(ctx);
+        }
+        Ok(this)
+    }
+}
+
 impl Drop for GpuBatchSec1 {
     fn drop(&mut self) {
         for &c in &self.ctxs {
