@@ -809,15 +809,12 @@ def gen_field3():
     assert abs(n - (q + 1)) <= 2 * math.isqrt(q) + 1 and all(n % s for s in (2, 3, 5, 7, 11, 13))   # cofactor 1 by Hasse
     ap("// ---- secp256r1: y^2 = x^3 - 3x + b, prime order n, cofactor 1 ----")
     ap(carr("P256_B_M", F.lm(P256["b"])))
-    ap(carr("P256_B3_M", F.lm(3 * P256["b"])))
-    ap(carr("P256_THREE_M", F.lm(3)))
     ap(carr("P256_GX_M", F.lm(G[0])))
     ap(carr("P256_GY_M", F.lm(G[1])))
     ap(carr("P256_R32", words32(n)))
     ap("constexpr uint32_t P256_R_NINV32 = 0x%08xu;" % ((-pow(n, -1, 1 << 32)) % (1 << 32)))
     ap(carr("P256_R_R1", words32((1 << 256) % n)))
     ap(carr("P256_R_R2", words32((1 << 512) % n)))
-    ap(carr("P256_RH32", words32(n >> 1)))
     # built-in Pedersen blinding base: upstream's constant for this suite is not known here, so -- as for JubJub, Ed25519
     # and Baby-JubJub -- a nothing-up-my-sleeve point: try-and-increment (RFC 9381 5.4.1.1 with this suite's own string
     # and interpret_hash_value_as_a_point = 0x02 || hash) of a fixed label.  A caller that knows upstream's passes it in
