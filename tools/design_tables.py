@@ -31,6 +31,8 @@ row("f4 IETF verify 2^20, Baby-JubJub, checked", c["ietf_verify_babyjubjub"], "v
 row("… pre-validated", c["ietf_verify_babyjubjub"]["prevalidated"], "verifies/s")
 row("f4 IETF prove 2^20, secp256r1 (RFC 9381 P256-SHA256-TAI)", c["ietf_prove_secp256r1"], "proofs/s", ["tai_find+prepare", "mul", "finish"])
 row("f4 IETF verify 2^20, secp256r1, Sec1 wire format", c["ietf_verify_secp256r1"], "verifies/s", ["decode", "straus_v", "straus_u", "finish"])
+row("… Pedersen prove 2^20, secp256r1 (unpinned; built-in blinding base)", c["pedersen_prove_secp256r1"], "proofs/s", ["tai_find+prepare", "mul", "finish"])
+row("… Pedersen verify 2^20, secp256r1, per proof", c["pedersen_verify_secp256r1"], "verifies/s", ["decode", "eq_h", "eq_g", "finish"])
 row("configs[4] pairing check 2^14, per item", c["pairing_check"], "checks/s", None, 1e6, "e6")
 row("… shared G2 pair (prepared lines)", c["pairing_check_shared_g2"], "checks/s", None, 1e6, "e6")
 row("… shared G2 pair, ONE batch (two G1 MSMs + one pairing), 2^14", c["pairing_check_batched_shared_g2_2^14"], "checks/s", ["prep", "msm_buckets", "msm_final", "pairing"], 1e6, "e6")
@@ -54,8 +56,10 @@ want = [("vrf::k_verify_decode<vrf::SuiteBS, 2>", 524288, " (checked and pre-val
         ("vrf::k_verify_decode<vrf::SuiteBJ, 2>", 524288, " (averaged)"), ("vrf::k_verify_straus<vrf::SuiteBJ, 1>", 1048576, ""), ("vrf::k_verify_straus<vrf::SuiteBJ, 0>", 1048576, ""),
         ("vrf::k_prove_prepare<vrf::SuiteBJ, 2>", 1048576, ""), ("vrf::k_prove_mul<vrf::SuiteBJ>", 2097152, ""),
         ("vrf::k_p256_verify_decode", 1048576, ""), ("vrf::k_p256_verify_mul<1>", 1048576, " (V = sH − cΓ)"), ("vrf::k_p256_verify_mul<0>", 1048576, " (U = sG − cY)"),
-        ("vrf::k_p256_verify_finish", 1048576, ""), ("vrf::k_p256_tai_find", 262144, " (work queue, 4096 persistent waves)"), ("vrf::k_p256_prove_prepare", 1048576, ""), ("vrf::k_p256_prove_mul", 4194304, " (4 ladders per proof)"),
-        ("vrf::k_p256_prove_finish", 1048576, ""),
+        ("vrf::k_p256_verify_finish", 1048576, ""), ("vrf::k_p256_tai_find", 262144, " (work queue, 4096 persistent waves)"), ("vrf::k_p256_prove_prepare<0>", 1048576, ""), ("vrf::k_p256_prove_mul<0>", 4194304, " (4 ladders per proof)"),
+        ("vrf::k_p256_prove_finish<0>", 1048576, ""), ("vrf::k_p256_prove_mul<1>", 4194304, " (Pedersen)"),
+        ("vrf::k_p256_ped_verify_decode", 1048576, ""), ("vrf::k_p256_ped_verify_mul<0>", 1048576, " (sH − cΓ − Ok = O)"),
+        ("vrf::k_p256_ped_verify_mul<1>", 1048576, " (sG + sbB − c·pk_com − R = O)"),
         ("vrf::k_pairing_check2_quad", 65536, ""), ("vrf::k_pairing_check2_quad_prepared", 65536, ""), ("vrf::k_pairing_check2_row_prepared<true>", 64, " (ONE item: 48 lanes)"),
         ("vrf::k_g1_buckets", 119808, " (2^18 × 2 sets)"), ("vrf::k_g1_final", 256, " (2 sets × 128 lanes)")]
 kr = []

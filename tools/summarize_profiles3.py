@@ -95,7 +95,7 @@ CONFIGS = [("ietf_verify", "k_verify_straus<vrf::SuiteBS, 1>", N20, 20), ("ietf_
            ("ietf_prove_ed25519", "k_prove_mul<vrf::SuiteED>", 2 * N20, 20), ("ietf_verify_ed25519", "k_verify_decode<vrf::SuiteED, 2>", None, 20),
            ("ietf_prove_babyjubjub", "k_prove_mul<vrf::SuiteBJ>", 2 * N20, 20),
            ("ietf_verify_babyjubjub", "k_verify_straus<vrf::SuiteBJ, 1>", N20, 20),
-           ("ietf_prove_secp256r1", "k_p256_prove_mul", 4 * N20, 20), ("ietf_verify_secp256r1", "k_p256_verify_mul<1>", N20, 20),
+           ("ietf_prove_secp256r1", "k_p256_prove_mul<0>", 4 * N20, 20), ("ietf_verify_secp256r1", "k_p256_verify_mul<1>", N20, 20),
            ("pedersen_prove_jubjub", "k_prove_mul<vrf::SuiteJJ>", 2 * N20, 20),
            ("pedersen_verify_jubjub", "k_ped_verify_straus<vrf::SuiteJJ, 0>", N20, 20),
            ("pedersen_rlc_jubjub", "k_rlc_decode<vrf::SuiteJJ, 2>", None, 20),
