@@ -58,3 +58,36 @@ def test_sharded_verify_equals_single_process(tmp_path, synth, world):
     for rank in range(world):
         got = np.load(os.path.join(tmp_path, f"out{rank}.npy"))
         assert got.shape == (n,) and (got == ref).all()
+
+
+def _worker_p256(rank, world, port, n, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import c_oracle as co
+        d = np.load(os.path.join(tmp, "batch.npz"))
+        lo, hi = shard_range(n, rank, world)
+        r = co.p256_ietf_prove_batch(d["sk"][lo:hi], msgs=d["msg"][lo:hi], ad=b"shard")
+        rows = np.concatenate([r["output"], r["c"], r["s"]], axis=1)          # 33 + 32 + 32 bytes per item
+        full = gather_results(torch.from_numpy(rows), n, rank, world)
+        dist.barrier()
+        np.save(os.path.join(tmp, f"out{rank}.npy"), full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_secp256r1_prove_gathers_sec1_rows(tmp_path):
+    """The gather is width-agnostic: 97-byte rows (a 33-byte Sec1 output + two big-endian scalars) from ragged shards."""
+    from oracle import c_oracle as co
+    n, world = 11, 2
+    rng = np.random.default_rng(4)
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    msg = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    np.savez(os.path.join(tmp_path, "batch.npz"), sk=sk, msg=msg)
+    r = co.p256_ietf_prove_batch(sk, msgs=msg, ad=b"shard", threads=2)
+    ref = np.concatenate([r["output"], r["c"], r["s"]], axis=1)
+    mp.spawn(_worker_p256, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        got = np.load(os.path.join(tmp_path, f"out{rank}.npy"))
+        assert got.shape == (n, 97) and (got == ref).all()
