@@ -62,6 +62,17 @@ struct JubJubSha512Tai {
   static constexpr vrfhip_suite ID = VRFHIP_SUITE_JUBJUB_SHA512_TAI;
   static constexpr const char* SUITE_ID = "JubJub_SHA-512_TAI";
 };
+struct Ed25519Sha512Tai {
+  static constexpr vrfhip_suite ID = VRFHIP_SUITE_ED25519_SHA512_TAI;
+  static constexpr const char* SUITE_ID = "Ed25519_SHA-512_TAI";
+};
+struct BabyJubJubSha512Tai {
+  static constexpr vrfhip_suite ID = VRFHIP_SUITE_BABY_JUBJUB_SHA512_TAI;
+  static constexpr const char* SUITE_ID = "BabyJubJub_SHA-512_TAI";
+};
+// `suites::secp256r1` (VRFHIP_SUITE_SECP256R1_SHA256_TAI) has no tag here: the value types below are 32-byte
+// ArkworksCodec encodings, that suite's are 33-byte Sec1 strings with big-endian scalars.  A C++ caller reaches it through
+// the C ABI itself (include/vrfhip.h: the same batch entry points, widths from vrfhip_ctx_point_bytes / _hash_bytes).
 
 // API / runtime failure of the library (negative vrfhip_error): not a per-item outcome
 struct ApiError : std::runtime_error {
