@@ -1173,6 +1173,16 @@ VRF_HD bool tai_attempt_decodes(const uint8_t* msg, uint32_t msg_len, uint32_t c
   DecodeA a = decode_phase_a<S>(enc);
   return a.ok && fe_is_square_or_zero(fe_mul(a.num, a.den), T);       // Jacobi symbol: no exponentiation
 }
+// The same verdict in two steps, for k_tai_find: the cheap half (hash, y < q, denominator non-zero) leaves the value whose
+// quadratic character decides; the expensive half is fe_is_square_or_zero of it.
+template <class S>
+VRF_HD bool tai_attempt_candidate(FeN& w, const uint8_t* msg, uint32_t msg_len, uint32_t ctr, const SqrtTables& T) {
+  uint32_t enc[8];
+  tai_candidate<S>(enc, msg, msg_len, ctr, T.str);
+  DecodeA a = decode_phase_a<S>(enc);
+  w = fe_mul(a.num, a.den);
+  return a.ok;
+}
 
 // start: first counter to try (0, or the hint of k_tai_find: every smaller counter is known not to decode)
 template <class S>
