@@ -1,5 +1,5 @@
 // k_p256.hip -- kernels of the secp256r1 suite ("P256_SHA256_TAI"; `suites::secp256r1`, /root/reference src/lib.rs:14):
-// IETF prove / verify in three stages each, hash-to-curve, output hash, key derivation, point validation.
+// IETF and Pedersen prove / verify in three stages each, hash-to-curve, output hash, key derivation, point validation.
 // Compiled once, with -DVRF_FIELD=3 (csrc/field.h): the NIST P-256 prime under the same 9 x 29-bit typed limbs as the
 // Edwards suites' fields, with the short-Weierstrass law of sw.cuh in place of te.cuh.
 //
@@ -19,7 +19,7 @@ namespace {
 
 constexpr int P256_BLOCK = 128;
 // p256.h states the workspace record sizes as plain numbers (the C ABI's translation unit does not see the device headers)
-static_assert(p256::WS_TAB_WORDS == 3 * SW_TABLE_WORDS && p256::WS_PTS_WORDS == 4 * PTW_WORDS && p256::WS_AFF_WORDS == 10 * NL &&
+static_assert(p256::WS_TAB_WORDS == 4 * SW_TABLE_WORDS && SW_QUAD_TABLES == 4 && p256::WS_PTS_WORDS == 4 * PTW_WORDS && p256::WS_AFF_WORDS == 10 * NL &&
               p256::WS_ENC_WORDS == 3 * 9, "p256.h workspace layout");
 
 __device__ __forceinline__ void ws_store_fe(uint32_t* base, size_t cap, size_t i, int w0, const FeN& a) {
@@ -54,6 +54,10 @@ __device__ __forceinline__ Sec1W ws_load_enc(const uint32_t* base, size_t cap, s
 }
 __device__ __forceinline__ uint32_t* ws_tab(uint32_t* tabs, size_t cap, size_t i, int slot) {
   return tabs + ((size_t)slot * cap + i) * SW_TABLE_WORDS;      // contiguous per item (sw.cuh)
+}
+// the prover's four tables of one base, contiguous per item (the same region, cut as [cap][4 x 224])
+__device__ __forceinline__ uint32_t* ws_quad_tab(uint32_t* tabs, size_t i) {
+  return tabs + i * (size_t)(SW_QUAD_TABLES * SW_TABLE_WORDS);
 }
 __device__ __forceinline__ uint32_t* ws_pt(uint32_t* pts, size_t cap, size_t i, int slot) {
   return pts + (size_t)slot * PTW_WORDS * cap + i;
@@ -213,8 +217,18 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_prepare(p256::ProveAr
   a.ws.flags[i] = ok ? 1 : 0;
 }
 
-// blockIdx.y = 0: pk = sk G, 1: Gamma = sk H, 2: U = k G, 3: V = k H.  The two H ladders each build their own copy of
-// H's table (7 additions) rather than wait for one another.  Pedersen: job 0 is pk_com = sk G + b B, job 2 is
+// The four tables both H ladders of the next stage walk (p256_core.cuh sw_build_quad_tables): 192 doublings + 28
+// additions per proof.  A kernel of its own: the hashing of the prepare stage keeps a SHA-256 state in scratch and runs two
+// waves per SIMD, this is pure curve arithmetic and runs three.
+__global__ void __launch_bounds__(P256_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_p256_prove_tables(p256::ProveArgs a) {
+  const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
+  if (i >= a.n || !a.ws.flags[i]) return;
+  const size_t cap = a.ws.cap;
+  sw_build_quad_tables(ws_quad_tab(a.ws.tabs, i), 1, ws_load_fe(a.ws.aff, cap, i, 0), ws_load_fe(a.ws.aff, cap, i, 9));
+}
+
+// blockIdx.y = 0: pk = sk G, 1: Gamma = sk H, 2: U = k G, 3: V = k H; the two H jobs walk the tables of H, 2^64 H, 2^128 H,
+// 2^192 H that the prepare stage built (60 doublings each instead of 256).  Pedersen: job 0 is pk_com = sk G + b B, job 2 is
 // R = k G + kb B (a second comb walk over the blinding base's table), jobs 1 and 3 are Gamma and Ok = k H.
 template <int PED>
 __global__ void __launch_bounds__(P256_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_p256_prove_mul(p256::ProveArgs a) {
@@ -226,9 +240,7 @@ __global__ void __launch_bounds__(P256_BLOCK) __attribute__((amdgpu_waves_per_eu
   ws_load8(k, a.ws.sc, cap, i, (job & 2) ? 8 : 0);
   PtW r;
   if (job & 1) {
-    uint32_t* th = ws_tab(a.ws.tabs, cap, i, job >> 1);
-    sw_build_table(th, 1, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 0), ws_load_fe(a.ws.aff, cap, i, 9)));
-    r = sw_win_mul(th, 1, k, false);
+    r = sw_quad_mul(ws_quad_tab(a.ws.tabs, i), 1, k);
   } else {
     r = sw_comb_mul(a.comb, k);
     if constexpr (PED != 0) {
@@ -448,6 +460,7 @@ void launch_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
   }
   if (a.pedersen) hipLaunchKernelGGL(k_p256_prove_prepare<1>, dim3(g), dim3(P256_BLOCK), 0, st, a);
   else hipLaunchKernelGGL(k_p256_prove_prepare<0>, dim3(g), dim3(P256_BLOCK), 0, st, a);
+  hipLaunchKernelGGL(k_p256_prove_tables, dim3(g), dim3(P256_BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
   if (a.pedersen) hipLaunchKernelGGL(k_p256_prove_mul<1>, dim3(g, 4), dim3(P256_BLOCK), 0, st, a);
   else hipLaunchKernelGGL(k_p256_prove_mul<0>, dim3(g, 4), dim3(P256_BLOCK), 0, st, a);

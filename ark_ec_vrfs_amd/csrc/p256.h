@@ -11,7 +11,7 @@ namespace p256 {
 // sits at base[w * cap + i] -- so that a wave's 64 lanes read 64 consecutive words whatever the per-item record size is;
 // the window tables are contiguous per item, because a lookup is indexed by the item's own digit (sw.cuh).
 struct Ws {
-  uint32_t* tabs;    // [3][cap][224]  window tables (verify: Y, H, Gamma; prove: H twice)
+  uint32_t* tabs;    // [4][cap][224]  window tables (verify: Y, H, Gamma; prove: H, 2^64 H, 2^128 H, 2^192 H)
   uint32_t* pts;     // [4][27][cap]   projective results (verify: U, V; prove: pk, Gamma, U, V)
   uint32_t* aff;     // [5][18][cap]   decoded affine points, Montgomery limbs (IETF verify: pk, H, Gamma; Pedersen verify: H,
                      //                Gamma, pk_com, R, Ok; prove: H)
@@ -20,7 +20,7 @@ struct Ws {
   uint8_t* flags;    // [cap]          1 = the item's inputs decoded
   size_t cap;
 };
-constexpr size_t WS_TAB_WORDS = 3 * 224, WS_PTS_WORDS = 4 * 27, WS_AFF_WORDS = 5 * 18, WS_SC_WORDS = 4 * 8, WS_ENC_WORDS = 3 * 9;
+constexpr size_t WS_TAB_WORDS = 4 * 224, WS_PTS_WORDS = 4 * 27, WS_AFF_WORDS = 5 * 18, WS_SC_WORDS = 4 * 8, WS_ENC_WORDS = 3 * 9;
 constexpr size_t WS_WORDS_PER_ITEM = WS_TAB_WORDS + WS_PTS_WORDS + WS_AFF_WORDS + WS_SC_WORDS + WS_ENC_WORDS;
 inline size_t ws_bytes(size_t cap) { return cap * WS_WORDS_PER_ITEM * sizeof(uint32_t) + ((cap + 255) & ~size_t(255)); }
 inline Ws ws_carve(void* base, size_t cap) {

@@ -1,6 +1,6 @@
 // p256_core.cuh -- the secp256r1 suite ("P256_SHA256_TAI", RFC 9381 suite 0x01; upstream `suites::secp256r1`,
 // /root/reference src/lib.rs:14): Sec1 codec, try-and-increment hash-to-curve, RFC 6979 nonce, challenge, output hash and
-// the per-item prove / verify steps, on top of sw.cuh (group law) and sha256.cuh.
+// the per-item prove / verify steps of the IETF and Pedersen schemes, on top of sw.cuh (group law) and sha256.cuh.
 //
 // Wire format of this suite at the C ABI (include/vrfhip.h): points are 33-byte Sec1 compressed strings (`Sec1Codec`),
 // scalars 32-byte BIG-endian integers (`int_to_string` = I2OSP); the challenge is 16 bytes on the wire, carried here in
@@ -262,6 +262,64 @@ VRF_HD PtW sw_win_mul(const uint32_t* tab, size_t stride, const uint32_t k[8], b
     }
     const int d = sw_digit(rec, top, w);
     acc = sw_add(acc, sw_lookup(tab, stride, negate ? -d : d));
+  }
+  return acc;
+}
+
+// ---- the prover's two multiplications of ONE base (Gamma = sk H, V = k H) ----
+// Both scalars multiply the same H, so the doublings are spent once, on H, instead of twice, on the accumulators: four
+// window tables of H, 2^64 H, 2^128 H, 2^192 H (192 Jacobian doublings + 4 x 7 additions), then each scalar is a 4-way
+// Straus sum over 16 windows -- 60 doublings + 64 additions instead of 256 + 65.  (The Edwards provers do the same:
+// vrf_core.cuh ProveLayout.)  Per proof 4980 product-equivalents for the two H ladders instead of 6980.
+// A scalar enters as |k'| <= n/2 with its sign (k > n/2 becomes n - k, the result negated), so |k'| < 2^255 and the signed
+// radix-16 recoding can carry out of the top nibble only as (digit 64, digit 63) = (1, -8), which is digit 63 = +8: the
+// 64 digits then split into four rows of 16, row j against the table of 2^(64 j) H.
+constexpr int SW_QUAD_TABLES = 4;
+VRF_HD void sw_build_quad_tables(uint32_t* tabs, size_t stride, const FeN& x, const FeN& y) {
+  PtJ base;
+  base.X = x; base.Y = y; base.Z = fe_one();
+#pragma unroll 1
+  for (int j = 0; j < SW_QUAD_TABLES; ++j) {
+    sw_build_table(tabs + (size_t)j * SW_TABLE_WORDS * stride, stride, sw_from_jac(base));
+    if (j + 1 < SW_QUAD_TABLES) {
+#pragma unroll 1
+      for (int k = 0; k < 64; ++k) base = sw_dbl_jac(base);
+    }
+  }
+}
+// |k| and sign with |k| <= n/2 (k < n)
+VRF_HD bool sw_scalar_fold(uint32_t out[8], const uint32_t k[8]) {
+  // n - k < k  <=>  the subtraction (n - k) - k does not borrow ... decided on the halves: compare k with n - k
+  uint32_t nk[8];
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t d = (uint64_t)CurveP256::r32(i) - k[i] - borrow;
+    nk[i] = (uint32_t)d;
+    borrow = (uint32_t)(d >> 63);
+  }
+  bool lt = false, decided = false;                       // nk < k
+#pragma unroll
+  for (int i = 7; i >= 0; --i)
+    if (!decided && nk[i] != k[i]) { lt = nk[i] < k[i]; decided = true; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = lt ? nk[i] : k[i];
+  return lt;
+}
+VRF_HD PtW sw_quad_mul(const uint32_t* tabs, size_t stride, const uint32_t k[8]) {
+  uint32_t mag[8], rec[8];
+  const bool neg = sw_scalar_fold(mag, k);
+  const uint32_t top = sw_recode(rec, mag);
+  PtW acc = sw_identity();
+#pragma unroll 1
+  for (int i = 15; i >= 0; --i) {
+    if (i != 15) acc = sw_dbl4(acc);
+#pragma unroll 1
+    for (int j = 0; j < SW_QUAD_TABLES; ++j) {
+      int d = scalar_digit4(rec, 16 * j + i);
+      if (top && j == 3 && i == 15) d = 8;               // (digit 64, digit 63) = (1, -8)  ->  digit 63 = +8
+      acc = sw_add(acc, sw_lookup(tabs + (size_t)j * SW_TABLE_WORDS * stride, stride, neg ? -d : d));
+    }
   }
   return acc;
 }

@@ -82,6 +82,13 @@ void hp_mul(const uint8_t* k_be, const uint8_t* a, uint8_t* r) {
   uint32_t k[8]; load_be256(k, k_be);
   pout(r, sw_win_mul(tab.data(), 1, k, false));
 }
+// k * P through the prover's four tables (P, 2^64 P, 2^128 P, 2^192 P) and the folded, patched recoding
+void hp_mul_quad(const uint8_t* k_be, const uint8_t* a, uint8_t* r) {
+  std::vector<uint32_t> tab(SW_QUAD_TABLES * SW_TABLE_WORDS);
+  sw_build_quad_tables(tab.data(), 1, in(a), in(a + 32));
+  uint32_t k[8]; load_be256(k, k_be);
+  pout(r, sw_quad_mul(tab.data(), 1, k));
+}
 void hp_mul_base(const uint8_t* k_be, uint8_t* r) { uint32_t k[8]; load_be256(k, k_be); pout(r, sw_comb_mul(comb().data(), k)); }
 // ---- hashes ----
 void hp_sha256(const uint8_t* m, uint32_t len, uint8_t* digest) {
@@ -113,9 +120,9 @@ int hp_prove(const uint8_t* sk_be, const uint8_t* msg, uint32_t msg_len, const u
   uint32_t sk[8], k[8]; FeN hx, hy; Sec1W henc;
   bool ok = p256_prove_prepare_item(sk, k, hx, hy, henc, sk_be, msg, msg_len, h_given, g_str);
   if (!ok) return 0;
-  std::vector<uint32_t> tab(SW_TABLE_WORDS);
-  sw_build_table(tab.data(), 1, sw_from_affine(hx, hy));
-  const PtW res[4] = {sw_comb_mul(comb().data(), sk), sw_win_mul(tab.data(), 1, sk, false), sw_comb_mul(comb().data(), k), sw_win_mul(tab.data(), 1, k, false)};
+  std::vector<uint32_t> tab(SW_QUAD_TABLES * SW_TABLE_WORDS);
+  sw_build_quad_tables(tab.data(), 1, hx, hy);
+  const PtW res[4] = {sw_comb_mul(comb().data(), sk), sw_quad_mul(tab.data(), 1, sk), sw_comb_mul(comb().data(), k), sw_quad_mul(tab.data(), 1, k)};
   Sec1W pk, gamma; uint32_t c[8], s[8];
   p256_prove_finish_item(pk, gamma, c, s, res, henc, sk, k, ad, ad_len, g_str);
   sec1_store(o, pk.tag, pk.xw); sec1_store(o + 33, henc.tag, henc.xw); sec1_store(o + 66, gamma.tag, gamma.xw);
@@ -147,10 +154,10 @@ int hp_ped_prove(const uint8_t* sk_be, const uint8_t* msg, uint32_t msg_len, con
   if (!p256_prove_prepare_item(sk, k, hx, hy, henc, sk_be, msg, msg_len, nullptr, g_str)) return 0;
   p256_blinding(b, sk, henc, ad, ad_len, g_str);
   p256_nonce(kb, b, henc.tag, henc.xw);
-  std::vector<uint32_t> tab(SW_TABLE_WORDS);
-  sw_build_table(tab.data(), 1, sw_from_affine(hx, hy));
-  const PtW res[4] = {sw_add(sw_comb_mul(comb().data(), sk), sw_comb_mul(g_comb_b.data(), b)), sw_win_mul(tab.data(), 1, sk, false),
-                      sw_add(sw_comb_mul(comb().data(), k), sw_comb_mul(g_comb_b.data(), kb)), sw_win_mul(tab.data(), 1, k, false)};
+  std::vector<uint32_t> tab(SW_QUAD_TABLES * SW_TABLE_WORDS);
+  sw_build_quad_tables(tab.data(), 1, hx, hy);
+  const PtW res[4] = {sw_add(sw_comb_mul(comb().data(), sk), sw_comb_mul(g_comb_b.data(), b)), sw_quad_mul(tab.data(), 1, sk),
+                      sw_add(sw_comb_mul(comb().data(), k), sw_comb_mul(g_comb_b.data(), kb)), sw_quad_mul(tab.data(), 1, k)};
   Sec1W enc[4]; uint32_t s[8], sb[8];
   p256_ped_prove_finish_item(enc, s, sb, res, henc, sk, k, b, kb, ad, ad_len, g_str);
   sec1_store(o, enc[1].tag, enc[1].xw); sec1_store(o + 33, enc[0].tag, enc[0].xw); sec1_store(o + 66, enc[2].tag, enc[2].xw);

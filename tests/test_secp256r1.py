@@ -171,6 +171,10 @@ def test_complete_group_law(hp):
         kk = k % N
         assert _pt(hp.hp_mul, be(kk), xy(A)) == sw.mul(kk, A)
         assert _pt(hp.hp_mul_base, be(kk)) == sw.mul(kk, G)
+        assert _pt(hp.hp_mul_quad, be(kk), xy(A)) == sw.mul(kk, A)
+    # the folded recoding's corner: |k'| just below n/2 with a carry into the top nibble (digit 63 becomes +8)
+    for kk in (N >> 1, (N >> 1) + 1, (N >> 1) - 1, int("7" + "f" * 63, 16), int("78" + "8" * 62, 16), int("77" + "8" * 62, 16), N - int("78" + "8" * 62, 16)):
+        assert _pt(hp.hp_mul_quad, be(kk % N), xy(pts[3])) == sw.mul(kk % N, pts[3]), hex(kk)
 
 
 def test_sha256_and_hmac(hp):
