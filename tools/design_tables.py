@@ -56,7 +56,7 @@ want = [("vrf::k_verify_decode<vrf::SuiteBS, 2>", 524288, " (checked and pre-val
         ("vrf::k_verify_decode<vrf::SuiteBJ, 2>", 524288, " (averaged)"), ("vrf::k_verify_straus<vrf::SuiteBJ, 1>", 1048576, ""), ("vrf::k_verify_straus<vrf::SuiteBJ, 0>", 1048576, ""),
         ("vrf::k_prove_prepare<vrf::SuiteBJ, 2>", 1048576, ""), ("vrf::k_prove_mul<vrf::SuiteBJ>", 2097152, ""),
         ("vrf::k_p256_verify_decode", 1048576, ""), ("vrf::k_p256_verify_mul<1>", 1048576, " (V = sH − cΓ)"), ("vrf::k_p256_verify_mul<0>", 1048576, " (U = sG − cY)"),
-        ("vrf::k_p256_verify_finish", 1048576, ""), ("vrf::k_p256_tai_find", 262144, " (work queue, 4096 persistent waves)"), ("vrf::k_p256_prove_prepare<0>", 1048576, ""), ("vrf::k_p256_prove_mul<0>", 4194304, " (4 ladders per proof)"),
+        ("vrf::k_p256_verify_finish", 1048576, ""), ("vrf::k_p256_tai_find", 262144, " (work queue, 4096 persistent waves)"), ("vrf::k_p256_prove_prepare<0>", 1048576, ""), ("vrf::k_p256_prove_tables", 1048576, " (H, 2^64 H, 2^128 H, 2^192 H)"), ("vrf::k_p256_prove_mul<0>", 4194304, " (4 ladders per proof)"),
         ("vrf::k_p256_prove_finish<0>", 1048576, ""), ("vrf::k_p256_prove_mul<1>", 4194304, " (Pedersen)"),
         ("vrf::k_p256_ped_verify_decode", 1048576, ""), ("vrf::k_p256_ped_verify_mul<0>", 1048576, " (sH − cΓ − Ok = O)"),
         ("vrf::k_p256_ped_verify_mul<1>", 1048576, " (sG + sbB − c·pk_com − R = O)"),
