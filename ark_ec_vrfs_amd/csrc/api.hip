@@ -105,7 +105,7 @@ struct vrfhip_ctx {
   p256::Ws p256_ws{};
   size_t pt_bytes() const { return sw ? 33 : 32; }        // one compressed point on the wire
   size_t hash_bytes() const { return sw ? 32 : 64; }      // `Output::hash`: the suite hasher's output
-  size_t prove_point_bytes() const { return sw ? 33 : (flags & VRFHIP_FLAG_PROVE_POINTS_AFFINE) ? 64 : 32; }
+  size_t prove_point_bytes() const { return (flags & VRFHIP_FLAG_PROVE_POINTS_AFFINE) ? 64 : pt_bytes(); }
   bool coords_mont256() const { return (flags & VRFHIP_FLAG_COORDS_MONT256) != 0; }
   // optional per-stage timing (hipEvents on the launch stream), see vrfhip_ctx_profile
   bool prof = false;
@@ -586,8 +586,6 @@ int32_t vrfhip_ctx_set_flags(vrfhip_ctx* ctx, uint32_t flags) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (flags & ~(uint32_t)(VRFHIP_FLAG_PREVALIDATED_ALL | VRFHIP_FLAG_PROVE_POINTS_AFFINE | VRFHIP_FLAG_COORDS_MONT256))
     return fail(VRFHIP_ERR_BAD_ARG, "unknown flag bits");
-  if (ctx->sw && (flags & (VRFHIP_FLAG_PROVE_POINTS_AFFINE | VRFHIP_FLAG_COORDS_MONT256)))
-    return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: points travel as 33-byte Sec1 strings only");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   ctx->flags = flags;
   return VRFHIP_SUCCESS;
@@ -634,7 +632,7 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
                         const vrfhip_keyset* ks = nullptr, const uint32_t* d_key_index = nullptr) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ks && (ks->ctx != ctx || !d_key_index)) return fail(VRFHIP_ERR_BAD_ARG, "key set of another context, or NULL key index");
-  if (ctx->sw && (affine || ks)) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: compressed (Sec1) points only, no key sets");
+  if (ctx->sw && ks) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: no key sets");
   if (n == 0) return VRFHIP_SUCCESS;
   if (ks) d_pk = ks->d_enc;
   if (!d_pk || !d_input || !d_output || !d_c || !d_s || !d_status)
@@ -650,7 +648,9 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
       const size_t m = std::min(ctx->ws_cap, n - base);
       p256::VerifyArgs a;
       a.n = m;
-      a.pk = d_pk + base * 33; a.h = d_input + base * 33; a.gamma = d_output + base * 33;
+      const size_t pw = affine ? 64 : 33;
+      a.pk = d_pk + base * pw; a.h = d_input + base * pw; a.gamma = d_output + base * pw;
+      a.affine_in = affine ? (ctx->coords_mont256() ? 2 : 1) : 0;
       a.c = d_c + base * 32; a.s = d_s + base * 32;
       a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
       a.status = d_status + base;
@@ -695,7 +695,6 @@ int32_t verify_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* 
   if (!pk || !input || !output || !c || !s || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
   size_t adb = blob_bytes(n, ad_off, ad_len, true);
-  if (ctx->sw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: compressed (Sec1) points only");
   const size_t pw = affine ? 64 : ctx->pt_bytes();
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
@@ -928,10 +927,12 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
       else a.msg = make_view(d_msg ? d_msg + base * (size_t)msg_len : nullptr, nullptr, msg_len, false);
       a.h_given = d_input ? d_input + base * 33 : nullptr;
       a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
-      a.gamma = at(o.output, base, 33); a.c = at(o.c, base, 32); a.s = at(o.s, base, 32);
-      a.pk_out = at(o.pk, base, 33); a.h_out = at(o.input, base, 33); a.status = at(o.status, base, 1);
+      const size_t ptw = ctx->prove_point_bytes();       // 33: Sec1, 64: x || y (VRFHIP_FLAG_PROVE_POINTS_AFFINE)
+      a.out_affine = ptw == 64 ? (ctx->coords_mont256() ? 2 : 1) : 0;
+      a.gamma = at(o.output, base, ptw); a.c = at(o.c, base, 32); a.s = at(o.s, base, 32);
+      a.pk_out = at(o.pk, base, ptw); a.h_out = at(o.input, base, 33); a.status = at(o.status, base, 1);
       a.pedersen = pedersen ? 1 : 0;
-      a.r_out = at(o.r, base, 33); a.ok_out = at(o.ok, base, 33); a.sb_out = at(o.sb, base, 32);
+      a.r_out = at(o.r, base, ptw); a.ok_out = at(o.ok, base, ptw); a.sb_out = at(o.sb, base, 32);
       a.blinding_out = at(o.blinding, base, 32);
       a.comb_b = ctx->d_p256_comb_b;
       a.tai_queue = ctx->d_queue;
@@ -1738,7 +1739,7 @@ int32_t vrfhip_point_validate_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   if (ctx->sw) {
-    p256::launch_point_validate(n, d_points, d_xy_out, d_status, static_cast<hipStream_t>(stream));
+    p256::launch_point_validate(n, d_points, d_xy_out, ctx->coords_mont256() ? 1 : 0, d_status, static_cast<hipStream_t>(stream));
     HIP_TRY(hipGetLastError());
     return VRFHIP_SUCCESS;
   }

@@ -88,8 +88,11 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_verify_decode(p256::VerifyA
   FeN x[3], y[3];
   Sec1W enc[3];
   uint32_t c[8], s[8];
-  const bool ok = p256_verify_decode_item(x, y, enc, c, s, a.pk + i * SEC1_LEN, a.h + i * SEC1_LEN, a.gamma + i * SEC1_LEN,
-                                          a.c + i * 32, a.s + i * 32);
+  const bool ok = a.affine_in
+                      ? p256_verify_decode_affine_item(x, y, enc, c, s, a.pk + i * 64, a.h + i * 64, a.gamma + i * 64, a.c + i * 32,
+                                                       a.s + i * 32, a.affine_in == 2)
+                      : p256_verify_decode_item(x, y, enc, c, s, a.pk + i * SEC1_LEN, a.h + i * SEC1_LEN, a.gamma + i * SEC1_LEN,
+                                                a.c + i * 32, a.s + i * 32);
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     ws_store_fe(a.ws.aff, cap, i, j * 18, x[j]);
@@ -257,14 +260,16 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_finish(p256::ProveArg
   const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
   if (i >= a.n) return;
   const size_t cap = a.ws.cap;
+  const size_t pw = a.out_affine ? 64 : SEC1_LEN;          // width of the points this stage hands out
   if (!a.ws.flags[i]) {
     if (a.status) a.status[i] = 2;
-    for (int k = 0; k < SEC1_LEN; ++k) {
-      a.gamma[i * SEC1_LEN + k] = 0;
-      if (a.pk_out) a.pk_out[i * SEC1_LEN + k] = 0;
-      if (a.h_out) a.h_out[i * SEC1_LEN + k] = 0;
-      if (PED != 0) { a.r_out[i * SEC1_LEN + k] = 0; a.ok_out[i * SEC1_LEN + k] = 0; }
+    for (size_t k = 0; k < pw; ++k) {
+      a.gamma[i * pw + k] = 0;
+      if (a.pk_out) a.pk_out[i * pw + k] = 0;
+      if (PED != 0) { a.r_out[i * pw + k] = 0; a.ok_out[i * pw + k] = 0; }
     }
+    for (int k = 0; k < SEC1_LEN; ++k)
+      if (a.h_out) a.h_out[i * SEC1_LEN + k] = 0;
     for (int k = 0; k < 32; ++k) {
       a.s[i * 32 + k] = 0;
       if (PED != 0) { a.sb_out[i * 32 + k] = 0; if (a.blinding_out) a.blinding_out[i * 32 + k] = 0; }
@@ -286,11 +291,14 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_finish(p256::ProveArg
     ws_load8(b, a.ws.sc, cap, i, 16);
     ws_load8(kb, a.ws.sc, cap, i, 24);
     Sec1W enc[4];
-    p256_ped_prove_finish_item(enc, s, sb, res, henc, sk, k, b, kb, ad, ad_len, a.str);
-    sec1_store(a.pk_out + i * SEC1_LEN, enc[0].tag, enc[0].xw);
-    sec1_store(a.gamma + i * SEC1_LEN, enc[1].tag, enc[1].xw);
-    sec1_store(a.r_out + i * SEC1_LEN, enc[2].tag, enc[2].xw);
-    sec1_store(a.ok_out + i * SEC1_LEN, enc[3].tag, enc[3].xw);
+    uint32_t yw[4][8];
+    p256_ped_prove_finish_item(enc, s, sb, res, henc, sk, k, b, kb, ad, ad_len, a.str, a.out_affine ? yw : nullptr);
+    uint8_t* dst[4] = {a.pk_out, a.gamma, a.r_out, a.ok_out};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (a.out_affine) xy_store(dst[j] + i * 64, enc[j].tag, enc[j].xw, yw[j], a.out_affine == 2);
+      else sec1_store(dst[j] + i * SEC1_LEN, enc[j].tag, enc[j].xw);
+    }
     store_be256(a.s + i * 32, s);
     store_be256(a.sb_out + i * 32, sb);
     if (a.blinding_out) store_be256(a.blinding_out + i * 32, b);
@@ -298,11 +306,17 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_prove_finish(p256::ProveArg
     if (a.status) a.status[i] = 0;
   } else {
     Sec1W pk, gamma;
-    p256_prove_finish_item(pk, gamma, c, s, res, henc, sk, k, ad, ad_len, a.str);
-    sec1_store(a.gamma + i * SEC1_LEN, gamma.tag, gamma.xw);
+    uint32_t yw[4][8];
+    p256_prove_finish_item(pk, gamma, c, s, res, henc, sk, k, ad, ad_len, a.str, a.out_affine ? yw : nullptr);
     store_be256(a.c + i * 32, c);
     store_be256(a.s + i * 32, s);
-    if (a.pk_out) sec1_store(a.pk_out + i * SEC1_LEN, pk.tag, pk.xw);
+    if (a.out_affine) {
+      xy_store(a.gamma + i * 64, gamma.tag, gamma.xw, yw[1], a.out_affine == 2);
+      if (a.pk_out) xy_store(a.pk_out + i * 64, pk.tag, pk.xw, yw[0], a.out_affine == 2);
+    } else {
+      sec1_store(a.gamma + i * SEC1_LEN, gamma.tag, gamma.xw);
+      if (a.pk_out) sec1_store(a.pk_out + i * SEC1_LEN, pk.tag, pk.xw);
+    }
     if (a.h_out) sec1_store(a.h_out + i * SEC1_LEN, henc.tag, henc.xw);
     if (a.status) a.status[i] = 0;
   }
@@ -404,7 +418,8 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_secret_from_seed(size_t n, 
 
 // [ref src/lib.rs:14 `codec`] point_decode: 0 = a point of the curve (cofactor 1: of the group), 2 = InvalidData.
 // xy_out (nullable): x || y as 32-byte LITTLE-endian canonical integers, the form every *_xy array of this ABI has
-__global__ void __launch_bounds__(P256_BLOCK) k_p256_point_validate(size_t n, const uint8_t* pts, uint8_t* xy_out, uint8_t* status) {
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_point_validate(size_t n, const uint8_t* pts, uint8_t* xy_out, int mont256,
+                                                                    uint8_t* status) {
   const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
   if (i >= n) return;
   FeN x, y;
@@ -414,9 +429,7 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_point_validate(size_t n, co
     uint32_t xw[8], yw[8];
     fe_to_u256(xw, x);
     fe_to_u256(yw, y);
-    uint32_t* o = reinterpret_cast<uint32_t*>(xy_out + i * 64);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { o[k] = ok ? xw[k] : 0u; o[8 + k] = ok ? yw[k] : 0u; }
+    xy_store(xy_out + i * 64, ok ? 2u : 0u, xw, yw, mont256 != 0);
   }
 }
 
@@ -493,8 +506,8 @@ void launch_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len, 
                              hipStream_t st) {
   hipLaunchKernelGGL(k_p256_secret_from_seed, dim3(blocks_for(n)), dim3(P256_BLOCK), 0, st, n, seeds, seed_len, sk32, pk33, comb);
 }
-void launch_point_validate(size_t n, const uint8_t* points33, uint8_t* xy_out, uint8_t* status, hipStream_t st) {
-  hipLaunchKernelGGL(k_p256_point_validate, dim3(blocks_for(n)), dim3(P256_BLOCK), 0, st, n, points33, xy_out, status);
+void launch_point_validate(size_t n, const uint8_t* points33, uint8_t* xy_out, int xy_mont256, uint8_t* status, hipStream_t st) {
+  hipLaunchKernelGGL(k_p256_point_validate, dim3(blocks_for(n)), dim3(P256_BLOCK), 0, st, n, points33, xy_out, xy_mont256, status);
 }
 
 }  // namespace p256

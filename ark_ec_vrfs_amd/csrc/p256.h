@@ -38,7 +38,8 @@ inline Ws ws_carve(void* base, size_t cap) {
 
 struct VerifyArgs {
   size_t n;
-  const uint8_t *pk, *h, *gamma;     // n x 33 B Sec1
+  const uint8_t *pk, *h, *gamma;     // n x 33 B Sec1 (affine_in != 0: n x 64 B x || y)
+  int affine_in;                     // 0: Sec1; 1: x || y little-endian canonical; 2: x || y arkworks Montgomery limbs
   const uint8_t *c, *s;              // n x 32 B big-endian
   BytesViewLite ad;
   uint8_t* status;
@@ -54,6 +55,7 @@ struct ProveArgs {
   BytesViewLite ad;
   uint8_t *gamma, *c, *s;            // n x 33, n x 32, n x 32
   uint8_t *pk_out, *h_out, *status;  // nullable: n x 33, n x 33, n
+  int out_affine;                    // != 0: gamma, pk_out, r_out, ok_out are n x 64 B x || y (2: arkworks Montgomery limbs)
   // Pedersen (pedersen != 0): c is unused, pk_out receives pk_com, and the outputs below are written
   int pedersen;
   uint8_t *r_out, *ok_out, *sb_out;  // n x 33, n x 33, n x 32
@@ -91,7 +93,7 @@ void launch_hash_to_curve(size_t n, BytesViewLite msg, uint8_t* points33, const 
 void launch_output_hash(size_t n, const uint8_t* gamma33, uint8_t* hash32, const SuiteStr& str, hipStream_t st);
 void launch_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk32, uint8_t* pk33,
                              const uint32_t* comb, hipStream_t st);
-void launch_point_validate(size_t n, const uint8_t* points33, uint8_t* xy_out, uint8_t* status, hipStream_t st);
+void launch_point_validate(size_t n, const uint8_t* points33, uint8_t* xy_out, int xy_mont256, uint8_t* status, hipStream_t st);
 
 }  // namespace p256
 }  // namespace vrf

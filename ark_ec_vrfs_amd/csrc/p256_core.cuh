@@ -65,12 +65,27 @@ VRF_HD bool sec1_decode(FeN& x, FeN& y, const uint8_t* enc) {
   return sw_lift_x(y, x, (tag & 1u) != 0) && ok;
 }
 
-// affine (x, y) -> tag and the big-endian integer x as 8 LE words
-VRF_HD uint32_t sec1_words(uint32_t xw[8], const FeN& x, const FeN& y) {
+// affine (x, y) -> tag and the big-endian integer x as 8 LE words (and y's words, for callers that hand out x || y)
+VRF_HD uint32_t sec1_words(uint32_t xw[8], const FeN& x, const FeN& y, uint32_t* yw_out = nullptr) {
   uint32_t yw[8];
   fe_to_u256(xw, x);
   fe_to_u256(yw, y);
+  if (yw_out) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) yw_out[i] = yw[i];
+  }
   return 2u + (yw[0] & 1u);
+}
+// x || y as the ABI's 64-byte pairs: 32-byte little-endian canonical integers, or (mont256) arkworks' in-memory limbs
+// x 2^256 mod p.  tag 0 (the point at infinity) is written as all zeros.
+VRF_HD void xy_store(uint8_t* out, uint32_t tag, const uint32_t xw[8], const uint32_t yw[8], bool mont256) {
+  uint32_t a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = tag ? xw[i] : 0u; b[i] = tag ? yw[i] : 0u; }
+  if (mont256) { u256_canon_to_mont256(a); u256_canon_to_mont256(b); }
+  uint32_t* o = reinterpret_cast<uint32_t*>(out);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { o[i] = a[i]; o[8 + i] = b[i]; }
 }
 VRF_HD void sec1_store(uint8_t* out, uint32_t tag, const uint32_t xw[8]) {
   out[0] = (uint8_t)tag;
@@ -413,7 +428,7 @@ VRF_HD PtW sw_comb_minus_win(const uint32_t* comb, const uint32_t* tabQ, size_t 
 
 // ---- projective -> Sec1 with one shared inversion ----
 template <bool CT, int N>
-VRF_HD void sw_to_sec1(Sec1W (&out)[N], const PtW (&p)[N]) {
+VRF_HD void sw_to_sec1(Sec1W (&out)[N], const PtW (&p)[N], uint32_t (*yw)[8] = nullptr) {
   FeN z[N], pre[N];
   bool inf[N];
 #pragma unroll
@@ -427,7 +442,7 @@ VRF_HD void sw_to_sec1(Sec1W (&out)[N], const PtW (&p)[N]) {
   for (int i = N - 1; i >= 0; --i) {
     const FeN zi = i == 0 ? acc : fe_mul(acc, pre[i - 1]);
     acc = fe_mul(acc, z[i]);
-    const uint32_t tag = sec1_words(out[i].xw, fe_mul(p[i].X, zi), fe_mul(p[i].Y, zi));
+    const uint32_t tag = sec1_words(out[i].xw, fe_mul(p[i].X, zi), fe_mul(p[i].Y, zi), yw ? yw[i] : nullptr);
     out[i].tag = inf[i] ? 0u : tag;
   }
 }
@@ -456,6 +471,32 @@ VRF_HD bool p256_verify_decode_item(FeN (&x)[3], FeN (&y)[3], Sec1W (&enc)[3], u
     Sec1W w;
     w.tag = e[0];
     load_be256(w.xw, e + 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (j == k) { x[k] = xx; y[k] = yy; enc[k] = w; }
+  }
+  (void)p256_scalar_decode(c, cb);
+  return p256_scalar_decode(s, sb) && ok;
+}
+// stage 1 for callers that hold the points as arkworks `Affine { x, y }`: pk, H, Gamma as 64-byte x || y (little-endian
+// canonical integers, or arkworks' Montgomery limbs when mont256).  No square root: a coordinate >= p or a point off the
+// curve is InvalidData; the encodings the challenge hashes are rebuilt from (x, parity of y).
+VRF_HD bool p256_verify_decode_affine_item(FeN (&x)[3], FeN (&y)[3], Sec1W (&enc)[3], uint32_t c[8], uint32_t s[8],
+                                           const uint8_t* pk_xy, const uint8_t* h_xy, const uint8_t* gamma_xy, const uint8_t* cb,
+                                           const uint8_t* sb, bool mont256) {
+  bool ok = true;
+#pragma unroll 1
+  for (int j = 0; j < 3; ++j) {
+    const uint32_t* e = reinterpret_cast<const uint32_t*>(j == 0 ? pk_xy : j == 1 ? h_xy : gamma_xy);
+    uint32_t xin[8], yin[8], xc[8], yc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xin[i] = e[i]; yin[i] = e[8 + i]; }
+    const FeN xx = fe_from_abi(xc, xin, mont256), yy = fe_from_abi(yc, yin, mont256);
+    ok = !u256_ge_q(xin) && !u256_ge_q(yin) && sw_on_curve(xx, yy) && ok;
+    Sec1W w;
+    w.tag = 2u + (yc[0] & 1u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w.xw[i] = xc[i];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       if (j == k) { x[k] = xx; y[k] = yy; enc[k] = w; }
@@ -500,9 +541,9 @@ VRF_HD bool p256_prove_prepare_item(uint32_t sk[8], uint32_t k[8], FeN& hx, FeN&
 // stage 3: res = {pk = sk G, Gamma = sk H, U = k G, V = k H}: c = challenge, s = k + c sk (mod n)
 VRF_HD void p256_prove_finish_item(Sec1W& pk, Sec1W& gamma, uint32_t c[8], uint32_t s[8], const PtW (&res)[4],
                                    const Sec1W& henc, const uint32_t sk[8], const uint32_t k[8], const uint8_t* ad,
-                                   uint32_t ad_len, const SuiteStr& ss) {
+                                   uint32_t ad_len, const SuiteStr& ss, uint32_t (*yw)[8] = nullptr) {
   Sec1W w[4];
-  sw_to_sec1<true>(w, res);
+  sw_to_sec1<true>(w, res, yw);
   pk = w[0]; gamma = w[1];
   const Sec1W pts[5] = {w[0], henc, w[1], w[2], w[3]};
   p256_challenge(c, pts, ad, ad_len, ss);
@@ -532,8 +573,8 @@ VRF_HD void p256_blinding(uint32_t b[8], const uint32_t sk[8], const Sec1W& henc
 // prove, stage 3: res = {pk_com = sk G + b B, Gamma = sk H, R = k G + kb B, Ok = k H}
 VRF_HD void p256_ped_prove_finish_item(Sec1W (&enc)[4], uint32_t s[8], uint32_t sb[8], const PtW (&res)[4], const Sec1W& henc,
                                        const uint32_t sk[8], const uint32_t k[8], const uint32_t b[8], const uint32_t kb[8],
-                                       const uint8_t* ad, uint32_t ad_len, const SuiteStr& ss) {
-  sw_to_sec1<true>(enc, res);
+                                       const uint8_t* ad, uint32_t ad_len, const SuiteStr& ss, uint32_t (*yw)[8] = nullptr) {
+  sw_to_sec1<true>(enc, res, yw);
   const Sec1W pts[5] = {enc[0], henc, enc[1], enc[2], enc[3]};
   uint32_t c[8], t[8];
   p256_challenge(c, pts, ad, ad_len, ss);

@@ -77,8 +77,10 @@ typedef enum vrfhip_suite {
    * vrfhip_secret_from_seed_batch, vrfhip_point_validate_batch (+ _dev), and the Pedersen scheme per proof:
    * vrfhip_pedersen_prove_batch / vrfhip_pedersen_verify_batch (+ _dev, _multi) when the descriptor carries a blinding base
    * (the built-in one is a nothing-up-my-sleeve point: upstream's `BLINDING_BASE` for this suite is not known here; a
-   * descriptor with an all-zero base makes a context without the scheme).  Everything else returns VRFHIP_ERR_UNSUPPORTED
-   * (the batched Pedersen verifier, MSM, key sets and the x||y forms are not built for it).  Pinned by RFC 9381 Appendix B.1, which upstream's own
+   * descriptor with an all-zero base makes a context without the scheme).  The x || y forms work as for the other suites
+   * (vrfhip_ietf_verify_batch_affine; VRFHIP_FLAG_PROVE_POINTS_AFFINE for the provers' Gamma / pk / pk_com / R / Ok;
+   * VRFHIP_FLAG_COORDS_MONT256; always little-endian, as arkworks holds coordinates in memory).  Everything else returns
+   * VRFHIP_ERR_UNSUPPORTED (the batched Pedersen verifier, MSM and key sets are not built for it).  Pinned by RFC 9381 Appendix B.1, which upstream's own
    * tests run: tests/golden/rfc9381_p256_sha256_tai.json (the RFC's use: message = PK_string || alpha).  As upstream, the
    * RFC 6979 nonce takes h1 unreduced and the first HMAC_DRBG candidate mod n (each differs from the RFC text with
    * probability 2^-32). */

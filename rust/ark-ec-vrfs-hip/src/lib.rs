@@ -342,8 +342,9 @@ impl<S: GpuSuite> Drop for GpuBatch<S> {
 
 /// `suites::secp256r1` ("P256_SHA256_TAI"): the suite whose codec is `Sec1Codec` -- 33-byte compressed points, big-endian
 /// scalars -- and whose hash is SHA-256.  libvrfhip runs it behind the same entry points with that wire format
-/// (`VRFHIP_SUITE_SECP256R1_SHA256_TAI`; `vrfhip_ctx_point_bytes` = 33), IETF scheme only, so this type moves encoded
-/// values instead of coordinates: `codec::point_encode` / `scalar_encode` in, `codec::point_decode` / `scalar_decode` out.
+/// (`VRFHIP_SUITE_SECP256R1_SHA256_TAI`; `vrfhip_ctx_point_bytes` = 33): points go in as `codec::point_encode` strings
+/// (compressing costs no square root) and come back as x || y (`VRFHIP_FLAG_PROVE_POINTS_AFFINE`), so that a typed
+/// `Output` / proof point is two field loads, not a `codec::point_decode` (a square root per point on a CPU core).
 pub struct GpuBatchSec1 {
     ctxs: Vec<*mut ffi::vrfhip_ctx>,
 }
@@ -362,6 +363,7 @@ impl GpuBatchSec1 {
             check(unsafe { ffi::vrfhip_ctx_create(ffi::VRFHIP_SUITE_SECP256R1_SHA256_TAI, dev, &mut ctx) })?;
             debug_assert_eq!(unsafe { ffi::vrfhip_ctx_point_bytes(ctx) }, SEC1);
             this.ctxs.push(ctx);
+            check(unsafe { ffi::vrfhip_ctx_set_flags(ctx, ffi::VRFHIP_FLAG_PROVE_POINTS_AFFINE) })?;
         }
         Ok(this)
     }
@@ -392,7 +394,7 @@ impl GpuBatchSec1 {
             Self::put_scalar(&secrets[i].scalar, &mut sk[i * 32..(i + 1) * 32]);
             Self::put_point(&inputs[i].0, &mut h[i * SEC1..(i + 1) * SEC1]);
         }
-        let (mut gamma, mut c, mut s) = (vec![0u8; n * SEC1], vec![0u8; n * 32], vec![0u8; n * 32]);
+        let (mut gamma, mut c, mut s) = (vec![0u8; n * 64], vec![0u8; n * 32], vec![0u8; n * 32]); // gamma: x || y
         let mut status = vec![0u8; n];
         check(unsafe {
             ffi::vrfhip_ietf_prove_batch_multi(
@@ -405,7 +407,7 @@ impl GpuBatchSec1 {
         Ok((0..n)
             .map(|i| {
                 status_to_result(status[i])?;
-                let out = Output::<P256>::from(codec::point_decode::<P256>(&gamma[i * SEC1..(i + 1) * SEC1])?);
+                let out = Output::<P256>::from(point_from_xy::<P256>(&gamma[i * 64..(i + 1) * 64]));
                 let proof = ietf::Proof::<P256> {
                     c: codec::scalar_decode::<P256>(&c[i * 32 + 16..(i + 1) * 32]), // the challenge's 16 significant bytes
                     s: codec::scalar_decode::<P256>(&s[i * 32..(i + 1) * 32]),
@@ -463,26 +465,26 @@ impl GpuBatchSec1 {
             Self::put_scalar(&secrets[i].scalar, &mut sk[i * 32..(i + 1) * 32]);
             Self::put_point(&inputs[i].0, &mut h[i * SEC1..(i + 1) * SEC1]);
         }
-        let mut p = vec![0u8; 4 * n * SEC1]; // gamma | pk_com | r | ok
+        let mut p = vec![0u8; 4 * n * 64]; // gamma | pk_com | r | ok, x || y each
         let mut o = vec![0u8; 3 * n * 32]; // s | sb | blinding
         let mut status = vec![0u8; n];
         let (q, w) = (p.as_mut_ptr(), o.as_mut_ptr());
         check(unsafe {
             ffi::vrfhip_pedersen_prove_batch_multi(
                 self.ctxs.as_ptr(), self.ctxs.len() as i32, n, sk.as_ptr(), core::ptr::null(), core::ptr::null(), 0,
-                h.as_ptr(), ad.as_ptr(), core::ptr::null(), ad.len() as u32, q, q.add(n * SEC1), q.add(2 * n * SEC1),
-                q.add(3 * n * SEC1), w, w.add(n * 32), w.add(2 * n * 32), core::ptr::null_mut(),
+                h.as_ptr(), ad.as_ptr(), core::ptr::null(), ad.len() as u32, q, q.add(n * 64), q.add(2 * n * 64),
+                q.add(3 * n * 64), w, w.add(n * 32), w.add(2 * n * 32), core::ptr::null_mut(),
                 status.as_mut_ptr(),
             )
         })?;
         sk.iter_mut().for_each(|b| *b = 0);
-        let pt = |k: usize, i: usize| codec::point_decode::<P256>(&p[(k * n + i) * SEC1..(k * n + i + 1) * SEC1]);
+        let pt = |k: usize, i: usize| point_from_xy::<P256>(&p[(k * n + i) * 64..(k * n + i + 1) * 64]);
         let sc = |k: usize, i: usize| codec::scalar_decode::<P256>(&o[(k * n + i) * 32..(k * n + i + 1) * 32]);
         let res = (0..n)
             .map(|i| {
                 status_to_result(status[i])?;
-                let proof = pedersen::Proof::<P256> { pk_com: pt(1, i)?, r: pt(2, i)?, ok: pt(3, i)?, s: sc(0, i), sb: sc(1, i) };
-                Ok((Output::<P256>::from(pt(0, i)?), proof, sc(2, i)))
+                let proof = pedersen::Proof::<P256> { pk_com: pt(1, i), r: pt(2, i), ok: pt(3, i), s: sc(0, i), sb: sc(1, i) };
+                Ok((Output::<P256>::from(pt(0, i)), proof, sc(2, i)))
             })
             .collect();
         o.iter_mut().for_each(|b| *b = 0); // blinding factors
@@ -536,6 +538,7 @@ impl GpuBatchSec1 {
             let mut ctx: *mut ffi::vrfhip_ctx = core::ptr::null_mut();
             check(unsafe { ffi::vrfhip_ctx_create_desc(&desc, dev, &mut ctx) })?;
             this.ctxs.push(ctx);
+            check(unsafe { ffi::vrfhip_ctx_set_flags(ctx, ffi::VRFHIP_FLAG_PROVE_POINTS_AFFINE) })?;
         }
         Ok(this)
     }

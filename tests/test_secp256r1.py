@@ -613,6 +613,53 @@ def test_gpu_pedersen_equals_the_c_oracle(gpu):
 
 
 @pytest.mark.gpu
+def test_gpu_xy_forms_for_typed_callers(gpu):
+    """What a Rust caller holding arkworks values uses: the provers hand out points as x || y (VRFHIP_FLAG_PROVE_POINTS_AFFINE),
+    the verifier takes pk / input / output as x || y (no square root on either side), canonical little-endian integers or
+    arkworks' in-memory Montgomery limbs (VRFHIP_FLAG_COORDS_MONT256): same proofs, same verdicts as the Sec1 forms."""
+    le = lambda v: int(v).to_bytes(32, "little")
+    xyle = lambda pt: le(pt[0]) + le(pt[1])
+    xym = lambda pt: le(pt[0] * (1 << 256) % P) + le(pt[1] * (1 << 256) % P)
+    n = 9
+    sks = [sw.secret_from_seed(b"xy%d" % i) for i in range(n)]
+    msgs = [b"xy message %d" % i for i in range(n)]
+    sk = _u8(be(k) for k in sks)
+    ref = gpu.ietf_prove_batch(sk, msgs=msgs, ad=b"xy")
+    pts = {k: [sw.point_decode(ref[k][i].tobytes()) for i in range(n)] for k in ("pk", "input", "output")}
+    B = sw.default_blinding_base()
+    try:
+        for flags, enc in ((gpu.PROVE_POINTS_AFFINE, xyle), (gpu.PROVE_POINTS_AFFINE | gpu.COORDS_MONT256, xym)):
+            gpu.set_flags(flags)
+            assert gpu.prove_point_bytes() == 64
+            r = gpu.ietf_prove_batch(sk, msgs=msgs, ad=b"xy")
+            assert r["output"].shape == (n, 64) and r["pk"].shape == (n, 64) and r["input"].shape == (n, 33)
+            assert (r["c"] == ref["c"]).all() and (r["s"] == ref["s"]).all() and (r["input"] == ref["input"]).all()
+            for i in range(n):
+                assert r["output"][i].tobytes() == enc(pts["output"][i]) and r["pk"][i].tobytes() == enc(pts["pk"][i])
+            h_xy = _u8(enc(p_) for p_ in pts["input"])
+            st = gpu.ietf_verify_batch_affine(r["pk"], h_xy, r["output"], r["c"], r["s"], ad=b"xy")
+            assert (st == 0).all()
+            bad_pk, bad_g, bad_s = r["pk"].copy(), r["output"].copy(), r["s"].copy()
+            bad_pk[1, 5] ^= 1                                   # off the curve
+            bad_g[2] = r["pk"][2]                               # another point of the curve
+            bad_pk[3, :32] = np.frombuffer(le(P + 1) if flags == gpu.PROVE_POINTS_AFFINE else le(P), np.uint8)   # coordinate >= p
+            bad_s[4, 31] ^= 1
+            st = gpu.ietf_verify_batch_affine(bad_pk, h_xy, bad_g, r["c"], bad_s, ad=b"xy")
+            assert list(st) == [0, 2, 1, 2, 1, 0, 0, 0, 0]
+            stv, xyv = gpu.point_validate_batch(ref["output"], want_xy=True)
+            assert (stv == 0).all() and all(xyv[i].tobytes() == enc(pts["output"][i]) for i in range(n))
+            pr = gpu.pedersen_prove_batch(sk, msgs=msgs, ad=b"xy")
+            for i in range(n):
+                g, (pc, R, Ok, s_, sb_), b_ = sw.pedersen_prove(sks[i], pts["input"][i], b"xy", B)
+                assert pr["output"][i].tobytes() == enc(g) and pr["pk_com"][i].tobytes() == enc(pc)
+                assert pr["r"][i].tobytes() == enc(R) and pr["ok"][i].tobytes() == enc(Ok)
+                assert pr["s"][i].tobytes() == be(s_) and pr["sb"][i].tobytes() == be(sb_) and pr["blinding"][i].tobytes() == be(b_)
+    finally:
+        gpu.set_flags(0)
+    assert gpu.prove_point_bytes() == 33
+
+
+@pytest.mark.gpu
 def test_gpu_entry_points_outside_the_suite_are_refused(gpu):
     from ark_ec_vrfs_amd import VrfHipError
     z32, z33 = np.zeros((2, 32), np.uint8), np.zeros((2, 33), np.uint8)
@@ -620,8 +667,6 @@ def test_gpu_entry_points_outside_the_suite_are_refused(gpu):
         gpu.pedersen_verify_batch_rlc(z32, z32, z32, z32, z32, z32, z32, seed=bytes(32))    # refused before any byte is read
     with pytest.raises(VrfHipError):
         gpu.msm(np.zeros((2, 64), np.uint8), z32)
-    with pytest.raises(VrfHipError):
-        gpu.set_flags(gpu.PROVE_POINTS_AFFINE)
     gpu.set_prevalidated(True)                      # cofactor 1: nothing to skip, accepted and without effect
     assert gpu.ietf_verify_batch(z33, z33, z33, z32, z32)[0] == 2
     gpu.set_prevalidated(False)
