@@ -502,6 +502,17 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
         res["ietf_verify_" + tag]["prevalidated"] = {"value": D.world * n * max(2, args.config_steps) / el_p, "unit": "verifies/s",
                                                      "ms_per_step": el_p / max(2, args.config_steps) * 1e3}
         if sw:
+            # the same verification from typed values: pk, input, output as x || y (no decompression)
+            from ark_ec_vrfs_amd import _lib as _l
+            xy = [torch.empty((n, 64), dtype=torch.uint8, device=D.dev) for _ in range(3)]
+            for src_, dst_ in zip((pk, hh, g), xy):
+                _l.check(lib.vrfhip_point_validate_batch_dev(cx.handle, n, src_.data_ptr(), dst_.data_ptr(), st.data_ptr(), stream), "validate")
+            fn_xy = lambda: cx.ietf_verify_batch_affine_dev(xy[0], xy[1], xy[2], c, s_, st)
+            fn_xy(); torch.cuda.synchronize()
+            el_xy, _ = timed(D, fn_xy, max(2, args.config_steps), 1)
+            assert int(st.sum()) == 0
+            res["ietf_verify_" + tag]["affine_inputs"] = {"value": D.world * n * max(2, args.config_steps) / el_xy, "unit": "verifies/s",
+                                                          "ms_per_step": el_xy / max(2, args.config_steps) * 1e3}
             # the Pedersen scheme on this suite (built-in nothing-up-my-sleeve blinding base), per proof
             pc, rr, okp, sbb = mkp(), mkp(), mkp(), mk()
             fn = lambda: cx.pedersen_prove_batch_dev(sk, msg, 32, g, pc, rr, okp, s_, sbb, None, hh, st)

@@ -31,6 +31,8 @@ row("f4 IETF verify 2^20, Baby-JubJub, checked", c["ietf_verify_babyjubjub"], "v
 row("… pre-validated", c["ietf_verify_babyjubjub"]["prevalidated"], "verifies/s")
 row("f4 IETF prove 2^20, secp256r1 (RFC 9381 P256-SHA256-TAI)", c["ietf_prove_secp256r1"], "proofs/s", ["tai_find+prepare", "mul", "finish"])
 row("f4 IETF verify 2^20, secp256r1, Sec1 wire format", c["ietf_verify_secp256r1"], "verifies/s", ["decode", "straus_v", "straus_u", "finish"])
+if "affine_inputs" in c["ietf_verify_secp256r1"]:
+    row("… pk, input, output as x ‖ y (typed callers)", c["ietf_verify_secp256r1"]["affine_inputs"], "verifies/s")
 row("… Pedersen prove 2^20, secp256r1 (unpinned; built-in blinding base)", c["pedersen_prove_secp256r1"], "proofs/s", ["tai_find+prepare", "mul", "finish"])
 row("… Pedersen verify 2^20, secp256r1, per proof", c["pedersen_verify_secp256r1"], "verifies/s", ["decode", "eq_h", "eq_g", "finish"])
 row("configs[4] pairing check 2^14, per item", c["pairing_check"], "checks/s", None, 1e6, "e6")
