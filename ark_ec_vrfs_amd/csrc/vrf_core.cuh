@@ -233,9 +233,10 @@ VRF_HD void sel8(uint32_t out[8], bool c, const uint32_t a[8], const uint32_t b[
 // sa*A + sb*B by Straus with signed radix-16 digits; negB flips the sign of the B terms.
 // reca / recb are recoded scalars (scalar_recode_signed4).  One te_dbl and one te_add call
 // site: the loop body is the whole hot path of IETF verification.
+// topB: the highest window of B's scalar that can be non-zero (challenge_top_window below; 63 = all of them).
 template <class C>
 VRF_HD PtE straus2(const uint32_t* tabA, const uint32_t reca[8], const uint32_t* tabB,
-                   const uint32_t recb[8], bool negB) {
+                   const uint32_t recb[8], bool negB, int topB = 63) {
   PtE acc = te_identity();
 #pragma unroll 1
   for (int w = 63; w >= 0; --w) {
@@ -243,17 +244,25 @@ VRF_HD PtE straus2(const uint32_t* tabA, const uint32_t reca[8], const uint32_t*
 #pragma unroll 1
       for (int j = 0; j < 4; ++j) acc = te_dbl<C>(acc, j == 3);
     }
+    const int terms = w <= topB ? 2 : 1;
 #pragma unroll 1
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < terms; ++t) {
       uint32_t rec[8];
       sel8(rec, t != 0, recb, reca);
       const uint32_t* tab = t ? tabB : tabA;
       int d = scalar_digit4(rec, w);
-      acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != (t != 0 && negB), t == 0 || w == 0);
+      acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != (t != 0 && negB), t + 1 < terms || w == 0);
     }
   }
   return acc;
 }
+
+// A challenge is CHALLENGE_LEN bytes of a hash: c < 2^(8 len), and its signed radix-16 recoding has no non-zero digit
+// above window 2 len (window 2 len itself holds the recoding's carry).  Ladders over c start there: with the RFC's
+// 16-byte challenges that is half of the doublings of -c*Y.  A proof carrying a larger c (it has 32 bytes to put one
+// in) gets the ladder of its low windows: some other point, whose challenge hash -- below 2^(8 len) -- still
+// cannot equal that c; the verdict is the one the full ladder gives.
+VRF_HD int challenge_top_window(const SuiteStr& ss) { return ss.challenge_len < 32u ? (int)(2u * ss.challenge_len) : 63; }
 
 // GLV Straus: sum_{t<4} (+/-) k_t * P_t with 128-bit k_t, signed radix-16, 32 windows, 128
 // doublings.  tabs[t] are window tables, rec[t] recoded magnitudes, neg[t] the term's sign.
@@ -288,11 +297,11 @@ VRF_HD PtE straus4(const Straus4& q) {
 
 // k*P for one window table (prove: Gamma = sk*H, kH)
 template <class C>
-VRF_HD PtE win_mul(const uint32_t* tab, const uint32_t rec[8], bool negate = false) {
+VRF_HD PtE win_mul(const uint32_t* tab, const uint32_t rec[8], bool negate = false, int top = 63) {
   PtE acc = te_identity();
 #pragma unroll 1
-  for (int w = 63; w >= 0; --w) {
-    if (w != 63) {
+  for (int w = top; w >= 0; --w) {
+    if (w != top) {
 #pragma unroll 1
       for (int j = 0; j < 4; ++j) acc = te_dbl<C>(acc, j == 3);
     }
@@ -935,10 +944,10 @@ VRF_HD void verify_straus_item(uint32_t* out_uv, const DevTables& T, const uint3
     scalar_recode_signed4(recc, c);
     PtE r;
     if (HALF == 0) {
-      r = win_mul<S>(tabs, recc, true);
+      r = win_mul<S>(tabs, recc, true, challenge_top_window(T.sq.str));
       r = gcomb_add<S>(r, T.g_comb, s);
     } else {
-      r = straus2<S>(tabs + 2 * WIN_TABLE_WORDS, recs, tabs + 4 * WIN_TABLE_WORDS, recc, true);
+      r = straus2<S>(tabs + 2 * WIN_TABLE_WORDS, recs, tabs + 4 * WIN_TABLE_WORDS, recc, true, challenge_top_window(T.sq.str));
     }
     fe_store(out_uv, r.X);
     fe_store(out_uv + NL, r.Y);
@@ -1632,9 +1641,9 @@ VRF_HD void pedersen_verify_straus_item(uint32_t* out_uv, const DevTables& T, co
     scalar_recode_signed4(recc, c);
     PtE r;
     if (HALF == 0) {
-      r = straus2<S>(tabs, recs, tabs + 2 * WIN_TABLE_WORDS, recc, true);      // s*H - c*Gamma
+      r = straus2<S>(tabs, recs, tabs + 2 * WIN_TABLE_WORDS, recc, true, challenge_top_window(T.sq.str));   // s*H - c*Gamma
     } else {
-      r = win_mul<S>(tabs + 4 * WIN_TABLE_WORDS, recc, true);                   // -c*pk_com
+      r = win_mul<S>(tabs + 4 * WIN_TABLE_WORDS, recc, true, challenge_top_window(T.sq.str));                // -c*pk_com
       r = gcomb_add<S>(r, T.g_comb, s);
       r = gcomb_add<S>(r, T.b_comb, sb);
     }

@@ -389,6 +389,9 @@ def test_gpu_prove_verify_pedersen_equal_the_c_oracle(gpu, ad):
     pkv, inp, outp, c, s = (ref[k].copy() for k in ("pk", "input", "output", "c", "s"))
     s[::7, 2] ^= 1                                     # wrong s
     c[3::31, 0] ^= 1                                   # wrong c
+    c[4::37, 20] ^= 1                                  # a c above 2^(8 CHALLENGE_LEN): the 32-byte field has room for one
+    for i in range(6, n, 41):                          # c + r: the same scalar, another string
+        c[i] = np.frombuffer(le(int.from_bytes(ref["c"][i].tobytes(), "little") + S.r), np.uint8)
     s[5::61] = np.frombuffer(le(S.r), np.uint8)        # s not canonical
     outp[11::67] = ref["output"][12::67][: len(outp[11::67])]     # another proof's output
     want = co.ietf_verify_batch(pkv, inp, outp, c, s, ad, threads=NCPU)
