@@ -784,7 +784,7 @@ int32_t vrfhip_keyset_create(vrfhip_ctx* ctx, size_t n_keys, const uint8_t* pks,
   if (!out) return fail(VRFHIP_ERR_BAD_ARG, "out is NULL");
   *out = nullptr;
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (n_keys == 0 || !pks) return fail(VRFHIP_ERR_BAD_ARG, "no keys");
   if (n_keys > (size_t(1) << 24)) return fail(VRFHIP_ERR_BAD_ARG, "too many keys");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1201,7 +1201,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
                      const uint8_t seed[32], uint8_t* d_status,
                      uint8_t* d_fail_flag, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (!d_fail_flag || !seed) return fail(VRFHIP_ERR_BAD_ARG, "NULL fail flag or seed");
   if (n && (!d_input || !d_output || !d_pk_com || !d_r || !d_ok || !d_s || !d_sb || !d_status))
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
@@ -1262,7 +1262,7 @@ int32_t rlc_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* inp
                       const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
                       const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (!seed) return fail(VRFHIP_ERR_BAD_ARG, "seed is NULL");
   if (batch_ok) *batch_ok = 1;
   if (n == 0) return VRFHIP_SUCCESS;
@@ -1368,7 +1368,7 @@ int32_t vrfhip_pedersen_verify_batch_rlc_affine(vrfhip_ctx* ctx, size_t n, const
 int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, const uint8_t* d_scalars,
                        uint8_t* d_out_point, uint8_t* d_out_xy, uint8_t* d_status, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (!d_out_point || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!d_bases_xy || !d_scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1398,7 +1398,7 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
 int32_t vrfhip_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases_xy, const uint8_t* scalars,
                    uint8_t* out_point, uint8_t* out_xy, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (!out_point || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!bases_xy || !scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1429,7 +1429,7 @@ int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
                                        const uint8_t* d_g2, int32_t g2_shared, uint8_t* d_status,
                                        void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!d_g1 || !d_g2 || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1443,7 +1443,7 @@ int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
 int32_t vrfhip_pairing_check_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2,
                                    int32_t g2_shared, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!g1 || !g2 || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1468,7 +1468,7 @@ int32_t vrfhip_pairing_check_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* g1,
 int32_t vrfhip_g1_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases, const uint8_t* d_scalars, uint8_t* d_out,
                           uint8_t* d_status, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (!d_out || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!d_bases || !d_scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if (n > (size_t(1) << 28)) return fail(VRFHIP_ERR_BAD_ARG, "batch too large");
@@ -1488,7 +1488,7 @@ int32_t vrfhip_g1_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases, con
 int32_t vrfhip_g1_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases, const uint8_t* scalars, uint8_t* out,
                       uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (!out || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!bases || !scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1516,7 +1516,7 @@ int32_t vrfhip_g1_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases, const uin
 int32_t vrfhip_pairing_check_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_g1, const uint8_t* d_g2_shared,
                                            const uint8_t seed[32], uint8_t* d_status, uint8_t* d_verdict, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (!d_verdict || !seed) return fail(VRFHIP_ERR_BAD_ARG, "NULL verdict or seed");
   if (n && (!d_g1 || !d_g2_shared || !d_status)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if (n > (size_t(1) << 28)) return fail(VRFHIP_ERR_BAD_ARG, "batch too large");
@@ -1551,7 +1551,7 @@ int32_t vrfhip_pairing_check_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint
 int32_t vrfhip_pairing_check_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t* g1, const uint8_t* g2_shared,
                                        const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (!seed) return fail(VRFHIP_ERR_BAD_ARG, "seed is NULL");
   if (batch_ok) *batch_ok = 1;
   if (n == 0) return VRFHIP_SUCCESS;
@@ -1586,7 +1586,7 @@ int32_t vrfhip_pairing_check_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t*
 // Test-only: quad-distributed Fp12 tower operations against the one-lane operations (k_pairing.hip)
 int32_t vrfhip_test_pairing_quad_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp12_pairs, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!fp12_pairs || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1785,7 +1785,7 @@ int32_t vrfhip_point_validate_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* po
 int32_t vrfhip_fq_mul_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b,
                             uint8_t* r) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!a || !b || !r) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1810,7 +1810,7 @@ int32_t vrfhip_fq_mul_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const u
 int32_t vrfhip_test_point_add(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out,
                               uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!a || !b || !out || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1832,7 +1832,7 @@ int32_t vrfhip_test_point_add(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const
 int32_t vrfhip_test_scalar_mul(vrfhip_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out,
                                uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!scalars || !points || !out || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1863,7 +1863,7 @@ namespace {
 int32_t test_hash_impl(vrfhip_ctx* ctx, size_t n, const uint8_t* msg, const uint32_t* msg_off, uint32_t msg_len,
                        uint8_t* out, int which) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!out || (!msg && (msg_len || msg_off))) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   const size_t ob = which ? 96 : 64;
@@ -1969,7 +1969,7 @@ int32_t vrfhip_test_batch_digest(vrfhip_ctx* ctx, size_t n, int32_t n_arr, const
                                  const uint32_t* widths, const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
                                  uint64_t index0, uint8_t root[32]) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (IETF prove / verify, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (!root || !arrays || !widths || n == 0) return fail(VRFHIP_ERR_BAD_ARG, "NULL argument or empty batch");
   if (n_arr < 1 || n_arr > DIGEST_MAX_ARRAYS) return fail(VRFHIP_ERR_BAD_ARG, "1..8 arrays");
   if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
