@@ -8,6 +8,7 @@
 //
 //   Rust (ark-vrf)                                         here (namespace ark_vrf_hip)
 //   Secret::<S>::from_seed(seed)                           Secret<S>::from_seed(ctx, seed)
+//   Secret::<S>::from_scalar(scalar)                       Secret<S>::from_scalar(ctx, scalar)
 //   secret.public()                                        secret.public_key()
 //   Input::<S>::new(data) -> Option<Input>                 Input<S>::new_(ctx, data) -> std::optional<Input<S>>
 //   secret.output(input)                                   secret.output(ctx, input)
@@ -17,6 +18,8 @@
 //   pedersen::Prover::prove(..) -> (Proof, blinding)       pedersen::prove(..) -> std::pair<Proof, Scalar>
 //   pedersen::Verifier::verify(input, output, ad, &p)      pedersen::verify(ctx, input, output, ad, p) -> Result
 //   Error::{VerificationFailure, InvalidData}              enum class Error; Result = std::optional<Error> (nullopt = Ok(()))
+// Suites: the four twisted-Edwards ones (32-byte ArkworksCodec points, SHA-512) and `suites::secp256r1` (33-byte Sec1
+// points, big-endian scalars, SHA-256) through the same templates: Point<S> / Hash<S> carry the widths.
 // Several GPUs from one process: ietf::verify_batch_sharded over one Context per device (contiguous slices, one
 // host thread per context, no exchange) -- the single-process form of `bench.py --gpus N`.
 // Batch forms (what the GPU is for) take std::vector of the same types: ietf::verify_batch, ietf::prove_batch,
@@ -41,7 +44,7 @@
 namespace ark_vrf_hip {
 
 using Bytes32 = std::array<uint8_t, 32>;
-using Scalar = Bytes32;                       // `ScalarField`, 32-byte little-endian canonical
+using Scalar = Bytes32;                       // `ScalarField`, 32 bytes canonical: little-endian (ArkworksCodec), big-endian on secp256r1 (Sec1Codec)
 using Bytes = std::vector<uint8_t>;
 
 // `Error` (src/lib.rs:15)
@@ -54,25 +57,38 @@ inline Result result_of(uint8_t status) {
 }
 
 // `Suite` (src/lib.rs:16): compile-time suite tags
-struct BandersnatchSha512Ell2 {
+// POINT_LEN / HASH_LEN: bytes of an encoded point (`Suite::Codec`) and of `Output::hash()` (the suite's hash); EDWARDS:
+// the twisted-Edwards suites have the key sets and the single-MSM Pedersen verifier, secp256r1 verifies per proof.
+struct EdwardsSha512 {
+  static constexpr size_t POINT_LEN = 32, HASH_LEN = 64;
+  static constexpr bool EDWARDS = true;
+};
+struct BandersnatchSha512Ell2 : EdwardsSha512 {
   static constexpr vrfhip_suite ID = VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2;
   static constexpr const char* SUITE_ID = "Bandersnatch_SHA-512_ELL2";
 };
-struct JubJubSha512Tai {
+struct JubJubSha512Tai : EdwardsSha512 {
   static constexpr vrfhip_suite ID = VRFHIP_SUITE_JUBJUB_SHA512_TAI;
   static constexpr const char* SUITE_ID = "JubJub_SHA-512_TAI";
 };
-struct Ed25519Sha512Tai {
+struct Ed25519Sha512Tai : EdwardsSha512 {
   static constexpr vrfhip_suite ID = VRFHIP_SUITE_ED25519_SHA512_TAI;
   static constexpr const char* SUITE_ID = "Ed25519_SHA-512_TAI";
 };
-struct BabyJubJubSha512Tai {
+struct BabyJubJubSha512Tai : EdwardsSha512 {
   static constexpr vrfhip_suite ID = VRFHIP_SUITE_BABY_JUBJUB_SHA512_TAI;
   static constexpr const char* SUITE_ID = "BabyJubJub_SHA-512_TAI";
 };
-// `suites::secp256r1` (VRFHIP_SUITE_SECP256R1_SHA256_TAI) has no tag here: the value types below are 32-byte
-// ArkworksCodec encodings, that suite's are 33-byte Sec1 strings with big-endian scalars.  A C++ caller reaches it through
-// the C ABI itself (include/vrfhip.h: the same batch entry points, widths from vrfhip_ctx_point_bytes / _hash_bytes).
+// `suites::secp256r1` (upstream "P256_SHA256_TAI", RFC 9381 ECVRF-P256-SHA256-TAI): Sec1Codec -- 33-byte compressed
+// points, big-endian scalars (`Proof::c` has 16 significant bytes), SHA-256
+struct Secp256r1Sha256Tai {
+  static constexpr vrfhip_suite ID = VRFHIP_SUITE_SECP256R1_SHA256_TAI;
+  static constexpr const char* SUITE_ID = "\x01";
+  static constexpr size_t POINT_LEN = 33, HASH_LEN = 32;
+  static constexpr bool EDWARDS = false;
+};
+template <class S> using Point = std::array<uint8_t, S::POINT_LEN>;     // an encoded point of suite S
+template <class S> using Hash = std::array<uint8_t, S::HASH_LEN>;
 
 // API / runtime failure of the library (negative vrfhip_error): not a per-item outcome
 struct ApiError : std::runtime_error {
@@ -108,13 +124,14 @@ class Context {
   vrfhip_ctx* h_ = nullptr;
 };
 
-template <class S> struct Public { Bytes32 encoded; };     // `Public`: compressed point (ArkworksCodec)
+template <class S> struct Public { Point<S> encoded; };    // `Public`: compressed point (`Suite::Codec`)
 
 // A set of `Public` keys whose validated points and fixed-base tables stay resident in HBM (881 KB per key):
 // the verifier of a validator set builds it once and names keys by index afterwards (ietf::verify_batch_keyed).
 template <class S>
 class KeySet {
  public:
+  static_assert(S::EDWARDS, "key sets exist for the twisted-Edwards suites");
   KeySet(const Context<S>& ctx, const std::vector<Public<S>>& keys) : valid_(keys.size()) {
     Bytes flat(keys.size() * 32), st(keys.size());
     for (size_t i = 0; i < keys.size(); ++i) std::memcpy(flat.data() + 32 * i, keys[i].encoded.data(), 32);
@@ -137,7 +154,7 @@ template <class S> struct Output;
 
 template <class S>
 struct Input {                                              // `Input`
-  Bytes32 encoded;
+  Point<S> encoded;
   // `Input::new(data)`: hash-to-curve (Elligator 2 / try-and-increment); None never happens for these suites
   static std::optional<Input> new_(const Context<S>& ctx, const Bytes& data) {
     Input in;
@@ -149,9 +166,9 @@ struct Input {                                              // `Input`
 
 template <class S>
 struct Output {                                             // `Output`
-  Bytes32 encoded;
-  std::array<uint8_t, 64> hash(const Context<S>& ctx) const {   // `Output::hash()`
-    std::array<uint8_t, 64> h;
+  Point<S> encoded;
+  Hash<S> hash(const Context<S>& ctx) const {                // `Output::hash()`
+    Hash<S> h;
     check(vrfhip_output_hash_batch(ctx.handle(), 1, encoded.data(), h.data()), "vrfhip_output_hash_batch");
     return h;
   }
@@ -160,7 +177,7 @@ struct Output {                                             // `Output`
 template <class S>
 struct Secret {                                             // `Secret`
   Scalar scalar;
-  Bytes32 pk;
+  Point<S> pk;
   static Secret from_seed(const Context<S>& ctx, const Bytes& seed) {          // `Secret::from_seed`
     Secret s;
     uint8_t dummy = 0;
@@ -168,6 +185,7 @@ struct Secret {                                             // `Secret`
                                         s.scalar.data(), s.pk.data()), "vrfhip_secret_from_seed_batch");
     return s;
   }
+  static Secret from_scalar(const Context<S>& ctx, const Scalar& scalar);      // `Secret::from_scalar` (throws unless scalar < order)
   Public<S> public_key() const { return Public<S>{pk}; }                       // `Secret::public`
   Output<S> output(const Context<S>& ctx, const Input<S>& in) const;           // `Secret::output`
 };
@@ -178,11 +196,17 @@ inline const uint8_t* ad_ptr(const Bytes& ad) {
   return ad.empty() ? &zero : ad.data();
 }
 template <class T, class F>
-Bytes column(const std::vector<T>& v, F field) {
-  Bytes out(v.size() * 32);
-  for (size_t i = 0; i < v.size(); ++i) std::memcpy(out.data() + 32 * i, field(v[i]).data(), 32);
+Bytes column(const std::vector<T>& v, F field) {          // one field of every item, back to back (32- or 33-byte arrays)
+  Bytes out;
+  for (const T& t : v) {
+    const auto& a = field(t);
+    out.insert(out.end(), a.begin(), a.end());
+  }
+  if (out.empty()) out.push_back(0);
   return out;
 }
+template <class A>
+void take(A& dst, const Bytes& flat, size_t i) { std::memcpy(dst.data(), flat.data() + dst.size() * i, dst.size()); }
 }  // namespace detail
 
 // -------------------------------------------------------------------------------- `ietf` (src/lib.rs:14)
@@ -196,7 +220,7 @@ struct Item { Public<S> pub; Input<S> input; Output<S> output; Proof<S> proof; }
 template <class S>
 Proof<S> prove(const Context<S>& ctx, const Secret<S>& sk, const Input<S>& in, const Output<S>& out, const Bytes& ad) {
   Proof<S> p;
-  Bytes32 gamma;
+  Point<S> gamma;
   uint8_t st = 0;
   check(vrfhip_ietf_prove_batch(ctx.handle(), 1, sk.scalar.data(), nullptr, nullptr, 0, in.encoded.data(),
                                 detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), gamma.data(), p.c.data(), p.s.data(),
@@ -218,11 +242,11 @@ Result verify(const Context<S>& ctx, const Public<S>& pub, const Input<S>& in, c
 template <class S>
 std::vector<Result> verify_batch(const Context<S>& ctx, const std::vector<Item<S>>& items, const Bytes& ad) {
   const size_t n = items.size();
-  Bytes pk = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.pub.encoded; });
-  Bytes h = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.input.encoded; });
-  Bytes g = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.output.encoded; });
-  Bytes c = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.c; });
-  Bytes s = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.s; });
+  Bytes pk = detail::column(items, [](const Item<S>& t) -> const auto& { return t.pub.encoded; });
+  Bytes h = detail::column(items, [](const Item<S>& t) -> const auto& { return t.input.encoded; });
+  Bytes g = detail::column(items, [](const Item<S>& t) -> const auto& { return t.output.encoded; });
+  Bytes c = detail::column(items, [](const Item<S>& t) -> const auto& { return t.proof.c; });
+  Bytes s = detail::column(items, [](const Item<S>& t) -> const auto& { return t.proof.s; });
   Bytes st(n);
   check(vrfhip_ietf_verify_batch(ctx.handle(), n, pk.data(), h.data(), g.data(), c.data(), s.data(), detail::ad_ptr(ad),
                                  nullptr, (uint32_t)ad.size(), st.data()), "vrfhip_ietf_verify_batch");
@@ -259,10 +283,10 @@ std::vector<Result> verify_batch_keyed(const Context<S>& ctx, const KeySet<S>& k
                                        const std::vector<Item<S>>& items, const Bytes& ad) {
   const size_t n = items.size();
   if (key_index.size() != n) throw std::invalid_argument("verify_batch_keyed: ragged batch");
-  Bytes h = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.input.encoded; });
-  Bytes g = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.output.encoded; });
-  Bytes c = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.c; });
-  Bytes s = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.s; });
+  Bytes h = detail::column(items, [](const Item<S>& t) -> const auto& { return t.input.encoded; });
+  Bytes g = detail::column(items, [](const Item<S>& t) -> const auto& { return t.output.encoded; });
+  Bytes c = detail::column(items, [](const Item<S>& t) -> const auto& { return t.proof.c; });
+  Bytes s = detail::column(items, [](const Item<S>& t) -> const auto& { return t.proof.s; });
   Bytes st(n);
   check(vrfhip_ietf_verify_batch_keyed(ctx.handle(), keys.handle(), n, key_index.data(), h.data(), g.data(), c.data(),
                                        s.data(), detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), st.data()),
@@ -277,27 +301,41 @@ std::vector<Item<S>> prove_batch(const Context<S>& ctx, const std::vector<Secret
                                  const Bytes& ad) {
   const size_t n = sks.size();
   if (msgs.size() != n) throw std::invalid_argument("prove_batch: ragged batch");
-  Bytes sk = detail::column(sks, [](const Secret<S>& t) -> const Scalar& { return t.scalar; });
+  Bytes sk = detail::column(sks, [](const Secret<S>& t) -> const auto& { return t.scalar; });
   Bytes blob;
   std::vector<uint32_t> off(n + 1, 0);
   for (size_t i = 0; i < n; ++i) { blob.insert(blob.end(), msgs[i].begin(), msgs[i].end()); off[i + 1] = (uint32_t)blob.size(); }
   blob.push_back(0);
-  Bytes g(32 * n), c(32 * n), s(32 * n), pk(32 * n), h(32 * n), st(n);
+  constexpr size_t W = S::POINT_LEN;
+  Bytes g(W * n + 1), c(32 * n + 1), s(32 * n + 1), pk(W * n + 1), h(W * n + 1), st(n + 1);
   check(vrfhip_ietf_prove_batch(ctx.handle(), n, sk.data(), blob.data(), off.data(), 0, nullptr, detail::ad_ptr(ad), nullptr,
                                 (uint32_t)ad.size(), g.data(), c.data(), s.data(), pk.data(), h.data(), st.data()),
         "vrfhip_ietf_prove_batch");
   std::vector<Item<S>> items(n);
   for (size_t i = 0; i < n; ++i) {
     if (st[i] != VRFHIP_ST_OK) throw std::invalid_argument("prove_batch: invalid secret");
-    std::memcpy(items[i].pub.encoded.data(), pk.data() + 32 * i, 32);
-    std::memcpy(items[i].input.encoded.data(), h.data() + 32 * i, 32);
-    std::memcpy(items[i].output.encoded.data(), g.data() + 32 * i, 32);
-    std::memcpy(items[i].proof.c.data(), c.data() + 32 * i, 32);
-    std::memcpy(items[i].proof.s.data(), s.data() + 32 * i, 32);
+    detail::take(items[i].pub.encoded, pk, i);
+    detail::take(items[i].input.encoded, h, i);
+    detail::take(items[i].output.encoded, g, i);
+    detail::take(items[i].proof.c, c, i);
+    detail::take(items[i].proof.s, s, i);
   }
   return items;
 }
 }  // namespace ietf
+
+template <class S>
+Secret<S> Secret<S>::from_scalar(const Context<S>& ctx, const Scalar& scalar) {
+  Secret s;
+  s.scalar = scalar;
+  Point<S> gamma;
+  Scalar c, sv;
+  uint8_t st = 0, msg = 0;                       // the public key comes back beside a proof over a one-byte message
+  check(vrfhip_ietf_prove_batch(ctx.handle(), 1, scalar.data(), &msg, nullptr, 1, nullptr, detail::ad_ptr({}), nullptr, 0,
+                                gamma.data(), c.data(), sv.data(), s.pk.data(), nullptr, &st), "vrfhip_ietf_prove_batch");
+  if (st != VRFHIP_ST_OK) throw std::invalid_argument("Secret::from_scalar: not a canonical scalar");
+  return s;
+}
 
 template <class S>
 Output<S> Secret<S>::output(const Context<S>& ctx, const Input<S>& in) const {
@@ -313,7 +351,7 @@ Output<S> Secret<S>::output(const Context<S>& ctx, const Input<S>& in) const {
 
 // -------------------------------------------------------------------------------- `pedersen` (src/lib.rs:14)
 namespace pedersen {
-template <class S> struct Proof { Bytes32 pk_com, r, ok; Scalar s, sb; };
+template <class S> struct Proof { Point<S> pk_com, r, ok; Scalar s, sb; };
 template <class S> struct Item { Input<S> input; Output<S> output; Proof<S> proof; };
 
 // `pedersen::Prover::prove` -> (proof, blinding factor)
@@ -322,7 +360,7 @@ std::pair<Proof<S>, Scalar> prove(const Context<S>& ctx, const Secret<S>& sk, co
                                   const Bytes& ad) {
   Proof<S> p;
   Scalar blinding;
-  Bytes32 gamma;
+  Point<S> gamma;
   uint8_t st = 0;
   check(vrfhip_pedersen_prove_batch(ctx.handle(), 1, sk.scalar.data(), nullptr, nullptr, 0, in.encoded.data(),
                                     detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), gamma.data(), p.pk_com.data(),
@@ -342,26 +380,33 @@ Result verify(const Context<S>& ctx, const Input<S>& in, const Output<S>& out, c
 }
 // n x verify through ONE multi-scalar multiplication (random linear combination); a failed batch is re-checked
 // per proof inside the library, so the results are those of n calls of verify().  *fast_path (optional) tells
-// whether the single MSM sufficed.
+// whether the single MSM sufficed.  secp256r1: one launch group of per-proof checks (*fast_path = false).
 template <class S>
 std::vector<Result> verify_batch(const Context<S>& ctx, const std::vector<Item<S>>& items, const Bytes& ad,
                                  bool* fast_path = nullptr) {
   const size_t n = items.size();
-  Bytes h = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.input.encoded; });
-  Bytes g = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.output.encoded; });
-  Bytes pc = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.pk_com; });
-  Bytes r = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.r; });
-  Bytes ok = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.ok; });
-  Bytes s = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.s; });
-  Bytes sb = detail::column(items, [](const Item<S>& t) -> const Bytes32& { return t.proof.sb; });
-  std::array<uint8_t, 32> seed;
-  std::random_device rd;                                   // must be unpredictable to the provers
-  for (auto& b : seed) b = (uint8_t)rd();
-  Bytes st(n);
+  Bytes h = detail::column(items, [](const Item<S>& t) -> const auto& { return t.input.encoded; });
+  Bytes g = detail::column(items, [](const Item<S>& t) -> const auto& { return t.output.encoded; });
+  Bytes pc = detail::column(items, [](const Item<S>& t) -> const auto& { return t.proof.pk_com; });
+  Bytes r = detail::column(items, [](const Item<S>& t) -> const auto& { return t.proof.r; });
+  Bytes ok = detail::column(items, [](const Item<S>& t) -> const auto& { return t.proof.ok; });
+  Bytes s = detail::column(items, [](const Item<S>& t) -> const auto& { return t.proof.s; });
+  Bytes sb = detail::column(items, [](const Item<S>& t) -> const auto& { return t.proof.sb; });
+  Bytes st(n + 1);
   int32_t fast = 1;
-  check(vrfhip_pedersen_verify_batch_rlc(ctx.handle(), n, h.data(), g.data(), pc.data(), r.data(), ok.data(), s.data(),
-                                         sb.data(), detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), seed.data(), st.data(),
-                                         &fast), "vrfhip_pedersen_verify_batch_rlc");
+  if constexpr (S::EDWARDS) {
+    std::array<uint8_t, 32> seed;
+    std::random_device rd;                                 // must be unpredictable to the provers
+    for (auto& b : seed) b = (uint8_t)rd();
+    check(vrfhip_pedersen_verify_batch_rlc(ctx.handle(), n, h.data(), g.data(), pc.data(), r.data(), ok.data(), s.data(),
+                                           sb.data(), detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), seed.data(), st.data(),
+                                           &fast), "vrfhip_pedersen_verify_batch_rlc");
+  } else {
+    fast = 0;
+    check(vrfhip_pedersen_verify_batch(ctx.handle(), n, h.data(), g.data(), pc.data(), r.data(), ok.data(), s.data(),
+                                       sb.data(), detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), st.data()),
+          "vrfhip_pedersen_verify_batch");
+  }
   if (fast_path) *fast_path = fast != 0;
   std::vector<Result> res(n);
   for (size_t i = 0; i < n; ++i) res[i] = result_of(st[i]);

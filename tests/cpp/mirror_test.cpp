@@ -2,7 +2,9 @@
 // tests drive the Rust API: from_seed -> Input::new -> output -> prove -> verify, against the golden vector
 // handed over by tests/test_cpp_mirror.py (hex on the command line), then batches through the GPU.
 //   mirror_test <seed> <alpha> <ad> <pk> <h> <gamma> <beta> <c> <s>   <ped_ad> <blinding> <pk_com> <r> <ok> <ps> <psb>
+//               <p256_sk> <p256_pk> <p256_alpha> <p256_h> <p256_pi> <p256_beta>       (RFC 9381 B.1, example 10)
 // Exit code 0 = every check passed; prints the first failing check otherwise.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -29,8 +31,82 @@ static std::string hex(const A& a) {
     if (!(cond)) { std::printf("FAILED: %s (line %d)\n", #cond, __LINE__); return 1; } \
   } while (0)
 
+// `suites::secp256r1` through the same templates: 33-byte Sec1 points, big-endian scalars, 32-byte hashes.  RFC 9381 passes
+// PK_string || alpha to encode_to_curve (the salt), so that is the message here.
+static int p256_section(char** a) {
+  using P = Secp256r1Sha256Tai;
+  const std::string sk = a[0], pk = a[1], alpha = a[2], h = a[3], pi = a[4], beta = a[5];
+  Context<P> ctx(0);
+  Scalar skb;
+  const Bytes skv = unhex(sk);
+  std::copy(skv.begin(), skv.end(), skb.begin());
+  const auto secret = Secret<P>::from_scalar(ctx, skb);
+  CHECK(hex(secret.public_key().encoded) == pk);
+  Bytes msg = unhex(pk), al = unhex(alpha);
+  msg.insert(msg.end(), al.begin(), al.end());
+  const auto input = Input<P>::new_(ctx, msg);
+  CHECK(input.has_value() && hex(input->encoded) == h);
+  const auto output = secret.output(ctx, *input);
+  CHECK(hex(output.encoded) == pi.substr(0, 66));
+  CHECK(hex(output.hash(ctx)) == beta);
+  const auto proof = ietf::prove(ctx, secret, *input, output, {});
+  CHECK(hex(proof.c) == std::string(32, '0') + pi.substr(66, 32) && hex(proof.s) == pi.substr(98, 64));   // pi = Gamma || c (16 B) || s
+  CHECK(!ietf::verify(ctx, secret.public_key(), *input, output, {}, proof).has_value());
+  CHECK(ietf::verify(ctx, secret.public_key(), *input, output, Bytes{1}, proof) == Error::VerificationFailure);
+  auto bad = proof;
+  bad.s.fill(0xff);                                                                                     // s >= n
+  CHECK(ietf::verify(ctx, secret.public_key(), *input, output, {}, bad) == Error::InvalidData);
+  Scalar big;
+  big.fill(0xff);                                                                                       // sk >= n
+  bool threw = false;
+  try { Secret<P>::from_scalar(ctx, big); } catch (const std::invalid_argument&) { threw = true; }
+  CHECK(threw);
+  // batches: ragged messages, one launch group; Pedersen per proof (no single-MSM verifier on this suite)
+  const size_t n = 600;
+  std::vector<Secret<P>> sks;
+  std::vector<Bytes> msgs;
+  for (size_t i = 0; i < n; ++i) {
+    Bytes sd(8);
+    for (int k = 0; k < 8; ++k) sd[k] = (uint8_t)(i >> (8 * k));
+    sks.push_back(Secret<P>::from_seed(ctx, sd));
+    msgs.push_back(Bytes(1 + i % 70, (uint8_t)(i * 3)));
+  }
+  auto items = ietf::prove_batch(ctx, sks, msgs, Bytes{7, 7});
+  for (size_t i = 0; i < n; i += 59) {
+    const auto in_i = Input<P>::new_(ctx, msgs[i]);
+    CHECK(in_i->encoded == items[i].input.encoded && sks[i].pk == items[i].pub.encoded);
+    const auto p_i = ietf::prove(ctx, sks[i], *in_i, sks[i].output(ctx, *in_i), Bytes{7, 7});
+    CHECK(p_i.c == items[i].proof.c && p_i.s == items[i].proof.s);
+    CHECK(Secret<P>::from_scalar(ctx, sks[i].scalar).pk == sks[i].pk);
+  }
+  items[5].proof.s[31] ^= 1;
+  items[77].pub.encoded[0] = 0x04;                       // not a compressed-point tag
+  items[300].output = items[301].output;
+  const auto res = ietf::verify_batch(ctx, items, Bytes{7, 7});
+  for (size_t i = 0; i < n; ++i) {
+    if (i == 5 || i == 300) CHECK(res[i] == Error::VerificationFailure);
+    else if (i == 77) CHECK(res[i] == Error::InvalidData);
+    else CHECK(!res[i].has_value());
+  }
+  std::vector<pedersen::Item<P>> pitems;
+  for (size_t i = 0; i < 40; ++i) {
+    const auto in_i = Input<P>::new_(ctx, msgs[i]);
+    const auto out_i = sks[i].output(ctx, *in_i);
+    pitems.push_back({*in_i, out_i, pedersen::prove(ctx, sks[i], *in_i, out_i, Bytes{9}).first});
+    CHECK(!pedersen::verify(ctx, *in_i, out_i, Bytes{9}, pitems.back().proof).has_value());
+  }
+  pitems[11].proof.sb[30] ^= 2;
+  bool fast = true;
+  const auto pres = pedersen::verify_batch(ctx, pitems, Bytes{9}, &fast);
+  CHECK(!fast);
+  for (size_t i = 0; i < pitems.size(); ++i) CHECK(i == 11 ? pres[i] == Error::VerificationFailure : !pres[i].has_value());
+  std::printf("mirror_test p256 ok: RFC 9381 B.1, %zu IETF proofs, %zu Pedersen proofs\n", n, pitems.size());
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc != 17) { std::printf("usage: mirror_test <16 hex fields>\n"); return 2; }
+  if (argc != 17 && argc != 23) { std::printf("usage: mirror_test <16 hex fields> [<6 secp256r1 fields>]\n"); return 2; }
+  if (argc == 23 && p256_section(argv + 17)) return 1;
   const std::string seed = argv[1], alpha = argv[2], ad = argv[3], pk = argv[4], h = argv[5], gamma = argv[6],
                     beta = argv[7], c = argv[8], s = argv[9], ped_ad = argv[10], blinding = argv[11], pk_com = argv[12],
                     pr = argv[13], pok = argv[14], ps = argv[15], psb = argv[16];
@@ -84,11 +160,11 @@ int main(int argc, char** argv) {
   items[7].proof.s[0] ^= 1;
   items[1234].output = items[1235].output;
   for (auto& b : items[1999].proof.c) b = 0xff;         // c >= r: decoded mod r, as `Proof::c` upstream -> a wrong challenge
-  for (auto& b : items[2000].proof.s) b = 0xff;         // s >= r: strict -> InvalidData
+  for (auto& b : items[1998].proof.s) b = 0xff;         // s >= r: strict -> InvalidData
   const auto res = ietf::verify_batch(ctx, items, unhex(ad));
   for (size_t i = 0; i < n; ++i) {
     if (i == 7 || i == 1234 || i == 1999) CHECK(res[i] == Error::VerificationFailure);
-    else if (i == 2000) CHECK(res[i] == Error::InvalidData);
+    else if (i == 1998) CHECK(res[i] == Error::InvalidData);
     else CHECK(!res[i].has_value());
   }
   // several contexts from one process (one per GPU; here three on the same device): slices tile the batch

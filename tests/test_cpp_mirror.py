@@ -29,7 +29,11 @@ def test_cpp_mirror_kat_and_batches(kat):
     assert p["seed"] == v["seed"] and p["alpha"] == v["alpha"]
     args = [v["seed"], v["alpha"], v["ad"], v["pk"], v["h"], v["gamma"], v["beta"], v["c"], v["s"],
             p["ad"], p["blinding"], p["pk_com"], p["r"], p["ok"], p["s"], p["sb"]]
+    # suites::secp256r1 through the same templates: RFC 9381 B.1 example 10 (tests/golden/rfc9381_p256_sha256_tai.json)
+    import json
+    w = json.load(open(os.path.join(os.path.dirname(HERE), "golden", "rfc9381_p256_sha256_tai.json")))["vectors"][0]
+    args += [w["sk"], w["pk"], w["alpha"], w["h"], w["pi"], w["beta"]]
     # empty hex fields (e.g. ad = "") must survive the command line
     r = subprocess.run([EXE] + args, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "mirror_test ok" in r.stdout
+    assert "mirror_test ok" in r.stdout and "mirror_test p256 ok" in r.stdout
