@@ -36,6 +36,7 @@ SYMBOLS = [
     "vrfhip_output_hash_batch", "vrfhip_output_hash_batch_dev",
     "vrfhip_secret_from_seed_batch", "vrfhip_secret_from_seed_batch_dev",
     "vrfhip_point_validate_batch", "vrfhip_point_validate_batch_dev",
+    "vrfhip_te_sw_map_batch", "vrfhip_te_sw_map_batch_dev",
     "vrfhip_fq_mul_batch", "vrfhip_test_pairing_quad_ops", "vrfhip_debug_proofs_per_lane",
     "vrfhip_ietf_verify_batch_multi", "vrfhip_ietf_prove_batch_multi",
     "vrfhip_pedersen_prove_batch_multi", "vrfhip_pedersen_verify_batch_multi",
@@ -58,7 +59,7 @@ class SuiteDescStruct(ctypes.Structure):
 _lib = None
 
 
-ABI_VERSION = 140      # vrfhip_abi_version() of the library this binding was written against
+ABI_VERSION = 141      # vrfhip_abi_version() of the library this binding was written against
 
 
 def load() -> ctypes.CDLL:
@@ -152,6 +153,8 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_secret_from_seed_batch_dev.argtypes = [c_void_p, c_size_t, P, c_uint32, P, P, c_void_p]
     lib.vrfhip_point_validate_batch.argtypes = [c_void_p, c_size_t, P, P, P]
     lib.vrfhip_point_validate_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, c_void_p]
+    lib.vrfhip_te_sw_map_batch.argtypes = [c_void_p, c_size_t, c_int32, P, P, P]
+    lib.vrfhip_te_sw_map_batch_dev.argtypes = [c_void_p, c_size_t, c_int32, P, P, P, c_void_p]
     lib.vrfhip_fq_mul_batch.argtypes = [c_void_p, c_size_t, P, P, P]
     lib.vrfhip_test_pairing_quad_ops.argtypes = [c_void_p, c_size_t, P, P]
     lib.vrfhip_debug_proofs_per_lane.argtypes = [c_size_t]

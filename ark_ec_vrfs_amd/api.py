@@ -588,6 +588,17 @@ class Context:
                    "vrfhip_point_validate_batch")
         return (st, xy) if want_xy else st
 
+    def te_sw_map_batch(self, points_xy, to_te: bool = False):
+        """`utils::te_sw_map::te_to_sw` (to_te=False) / `sw_to_te` (to_te=True) on n x 64 B affine x || y points of the
+        context's twisted-Edwards curve / its short-Weierstrass form.  Returns (out_xy, status): status 2 = upstream's None
+        (or a coordinate not below the modulus), the row is then zero."""
+        p = np.ascontiguousarray(points_xy, dtype=np.uint8).reshape(-1, 64)
+        n = p.shape[0]
+        out, st = np.empty((n, 64), np.uint8), np.empty(n, np.uint8)
+        _lib.check(self._lib.vrfhip_te_sw_map_batch(self._h, n, 1 if to_te else 0, _ptr(p), _ptr(out), _ptr(st)),
+                   "vrfhip_te_sw_map_batch")
+        return out, st
+
     def fq_mul_batch(self, a, b) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1, 32)
         b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, 32)

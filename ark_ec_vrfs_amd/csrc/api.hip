@@ -24,11 +24,16 @@ namespace vrf {
 void launch_pairing_row_selftest(size_t n, const uint8_t* in, uint8_t* status, hipStream_t st);
 // The kernel objects of the other base fields (field.h): this file is compiled for field 0 (kernels.h declared its
 // launchers in vrf::f_bls381fr) and reaches the 2^255 - 19 and BN254 Fr builds through the same declarations.
+inline namespace f_bls381fr {
+#include "te_sw_map.inc"
+}
 namespace f_25519 {
 #include "launchers.inc"
+#include "te_sw_map.inc"
 }
 namespace f_bn254fr {
 #include "launchers.inc"
+#include "te_sw_map.inc"
 }
 }  // namespace vrf
 using namespace vrf;
@@ -306,7 +311,7 @@ size_t blob_bytes(size_t n, const uint32_t* off, uint32_t len, bool shared) {
 
 extern "C" {
 
-int32_t vrfhip_abi_version(void) { return 140; }
+int32_t vrfhip_abi_version(void) { return 141; }
 
 const char* vrfhip_last_error(void) { return g_last_error.c_str(); }
 
@@ -1777,6 +1782,45 @@ int32_t vrfhip_point_validate_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* po
   int32_t rc = vrfhip_point_validate_batch_dev(ctx, n, d_in, xy_out ? d_xy : nullptr, d_st, ctx->stream);
   if (rc) return rc;
   if (xy_out) HIP_TRY(hipMemcpyAsync(xy_out, d_xy, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_te_sw_map_batch_dev(vrfhip_ctx* ctx, size_t n, int32_t to_te, const uint8_t* d_in_xy, uint8_t* d_out_xy,
+                                   uint8_t* d_status, void* stream) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "te_sw_map: the context's curve is not twisted Edwards");
+  if (to_te != 0 && to_te != 1) return fail(VRFHIP_ERR_BAD_ARG, "to_te must be 0 (TE -> SW) or 1 (SW -> TE)");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!d_in_xy || !d_out_xy || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  FIELD_CALL(ctx, launch_te_sw_map((int)ctx->suite, n, to_te, ctx->coords_mont256() ? 1 : 0, d_in_xy, d_out_xy, d_status,
+                                   static_cast<hipStream_t>(stream)));
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_te_sw_map_batch(vrfhip_ctx* ctx, size_t n, int32_t to_te, const uint8_t* in_xy, uint8_t* out_xy,
+                               uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "te_sw_map: the context's curve is not twisted Edwards");
+  if (to_te != 0 && to_te != 1) return fail(VRFHIP_ERR_BAD_ARG, "to_te must be 0 (TE -> SW) or 1 (SW -> TE)");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!in_xy || !out_xy || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_stage(ctx, 2 * Stage::pad(n * 64) + Stage::pad(n));
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t* d_in = sg.take(n * 64);
+  uint8_t* d_out = sg.take(n * 64);
+  uint8_t* d_st = sg.take(n);
+  HIP_TRY(hipMemcpyAsync(d_in, in_xy, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  rc = vrfhip_te_sw_map_batch_dev(ctx, n, to_te, d_in, d_out, d_st, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out_xy, d_out, n * 64, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return VRFHIP_SUCCESS;

@@ -1,7 +1,9 @@
 // k_misc.hip -- table construction and the small building-block kernels.
 #include "kernels.h"
+#include "te_sw_map.cuh"
 
 VRF_NS_BEGIN
+#include "te_sw_map.inc"
 
 // ---- one-time table construction (context creation) ----
 // gb_xy: the descriptor's generator and Pedersen blinding base, x || y as 32-byte little-endian canonical
@@ -152,6 +154,34 @@ __global__ void __launch_bounds__(BLOCK) k_point_validate(size_t n, const uint8_
 void launch_point_validate(int suite, size_t n, const uint8_t* pts, uint8_t* xy, uint8_t* status,
                            uint32_t* tabs, DevTables T, hipStream_t st) {
   if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_point_validate<S>, grid_for(n), dim3(BLOCK), 0, st, n, pts, xy, status, tabs, T));
+}
+
+// ---- `utils::te_sw_map`: twisted-Edwards <-> short-Weierstrass, x || y in, x || y out (te_sw_map.cuh) ----
+template <class S>
+__global__ void __launch_bounds__(BLOCK) k_te_sw_map(size_t n, int to_te, int mont256, const uint8_t* in_xy, uint8_t* out_xy,
+                                                      uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(in_xy + i * 64);
+  uint32_t xin[8], yin[8], cw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { xin[j] = p[j]; yin[j] = p[8 + j]; }
+  bool ok = !u256_ge(xin, vrfk::Q32) && !u256_ge(yin, vrfk::Q32);
+  const FeN x = fe_from_abi(cw, xin, mont256 != 0), y = fe_from_abi(cw, yin, mont256 != 0);
+  FeN ox, oy;
+  if (to_te) ok = sw_to_te<S>(ox, oy, x, y) && ok;          // wave-uniform
+  else ok = te_to_sw<S>(ox, oy, x, y) && ok;
+  uint32_t xw[8], yw[8];
+  if (mont256) { fe_to_mont256(xw, ox); fe_to_mont256(yw, oy); }
+  else { fe_to_u256(xw, ox); fe_to_u256(yw, oy); }
+  uint32_t* o = reinterpret_cast<uint32_t*>(out_xy + i * 64);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { o[j] = ok ? xw[j] : 0u; o[8 + j] = ok ? yw[j] : 0u; }
+  status[i] = ok ? ST_OK : ST_INVALID_DATA;
+}
+void launch_te_sw_map(int suite, size_t n, int to_te, int mont256, const uint8_t* in_xy, uint8_t* out_xy, uint8_t* status,
+                      hipStream_t st) {
+  if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_te_sw_map<S>, grid_for(n), dim3(BLOCK), 0, st, n, to_te, mont256, in_xy, out_xy, status));
 }
 
 // ---- key sets (keyed verification): validated keys and their fixed-base combs, context resident ----

@@ -472,6 +472,19 @@ int32_t vrfhip_point_validate_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* po
 int32_t vrfhip_point_validate_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_points,
                                         uint8_t* d_xy_out, uint8_t* d_status, void* stream);
 
+/* `utils::te_sw_map::{te_to_sw, sw_to_te}` (src/lib.rs:14 `utils`): the point map between the context's twisted-Edwards
+ * curve and the short-Weierstrass form of its Montgomery model (B v^2 = u^3 + A u^2 + u with A = 2(a+d)/(a-d),
+ * B = 4/(a-d), arkworks' MontCurveConfig; SW point ((u + A/3)/B, v/B)) -- what `suites::bandersnatch_sw` values and the
+ * ring plumbing are converted with.  to_te = 0: in_xy are TE points, out_xy their SW images; to_te = 1: the inverse.
+ * Points are n x 64 B affine x || y, 32-byte little-endian canonical integers (arkworks' in-memory limbs with
+ * VRFHIP_FLAG_COORDS_MONT256).  status[i] = 0, or 2 where upstream returns None -- TE x = 0 or y = 1 (the identity and the
+ * point of order 2 have no affine image), SW y = 0 or B x - A/3 = -1 -- or a coordinate is not below the modulus; out_xy[i]
+ * is then all zero.  As upstream (`new_unchecked`), no curve-membership test.  Twisted-Edwards suites only. */
+int32_t vrfhip_te_sw_map_batch(vrfhip_ctx* ctx, size_t n, int32_t to_te, const uint8_t* in_xy, uint8_t* out_xy,
+                               uint8_t* status);
+int32_t vrfhip_te_sw_map_batch_dev(vrfhip_ctx* ctx, size_t n, int32_t to_te, const uint8_t* d_in_xy, uint8_t* d_out_xy,
+                                   uint8_t* d_status, void* stream);
+
 /* Test-only primitive: the quad-distributed Fp12 operations of the pairing kernel (one item per DPP quad)
  * against the one-lane tower operations on the same operands.  fp12_pairs: n x 2 x 12 field elements of
  * 48 bytes, little-endian (reduced mod p by the loader).  status[i] = bit mask of differing operations

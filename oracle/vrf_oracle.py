@@ -449,6 +449,64 @@ def pedersen_verify(S: SuiteParams, H: Point, gamma: Point, ad: bytes, proof) ->
 # JubJub descriptor (unpinned, see note above)
 # --------------------------------------------------------------------------------------
 
+# ------------------------------------------------------------------ TE <-> SW map
+# [ref src/lib.rs:14 `utils`: te_sw_map::{te_to_sw, sw_to_te}]  The point map between a twisted-Edwards curve and the
+# short-Weierstrass form of its Montgomery model (what the `bandersnatch_sw` suite and the ring plumbing sit on).
+# Montgomery model  B v^2 = u^3 + A u^2 + u  with  A = 2(a + d)/(a - d),  B = 4/(a - d)  (arkworks' MontCurveConfig);
+#   TE -> Mont: (u, v) = ((1 + y)/(1 - y), (1 + y)/((1 - y) x));  Mont -> SW: ((u + A/3)/B, v/B);
+#   SW: y^2 = x^3 + a' x + b',  a' = (3 - A^2)/(3 B^2),  b' = (2 A^3 - 9 A)/(27 B^3).
+# Pinned as far as this environment allows: for Bandersnatch these formulas give exactly the four coefficients of
+# ark-ed-on-bls12-381-bandersnatch (MontCurveConfig COEFF_A / COEFF_B, SWConfig COEFF_A / COEFF_B) as recalled digit for
+# digit -- tests/test_te_sw_map.py -- which fixes the scaling of the map (the only freedom left is y -> -y, and upstream
+# takes v/B with the sign above).  None where upstream's `inverse()?` returns None: x = 0 or y = 1 (TE -> SW: the identity
+# and the point of order 2 have no affine image), y = 0 or B x - A/3 = -1 (SW -> TE).
+def te_sw_constants(S: SuiteParams):
+    """(A, B, a', b') of the Montgomery and short-Weierstrass models of S's curve."""
+    q = S.q
+    A = 2 * (S.a + S.d) * finv(S.a - S.d, q) % q
+    B = 4 * finv(S.a - S.d, q) % q
+    return (A, B, (3 - A * A) * finv(3 * B * B, q) % q, (2 * A ** 3 - 9 * A) * finv(27 * B ** 3, q) % q)
+
+
+def te_to_sw(S: SuiteParams, P: Point) -> Optional[Point]:
+    q = S.q
+    x, y = P
+    A, B, _, _ = te_sw_constants(S)
+    if (1 - y) % q == 0 or (x - x * y) % q == 0:
+        return None
+    u = (1 + y) * finv(1 - y, q) % q
+    v = (1 + y) * finv(x - x * y, q) % q
+    return ((u + A * finv(3, q)) * finv(B, q) % q, v * finv(B, q) % q)
+
+
+def sw_to_te(S: SuiteParams, P: Point) -> Optional[Point]:
+    q = S.q
+    x, y = P
+    A, B, _, _ = te_sw_constants(S)
+    mx, my = (B * x - A * finv(3, q)) % q, B * y % q
+    if my == 0 or (mx + 1) % q == 0:
+        return None
+    return (mx * finv(my, q) % q, (mx - 1) * finv(mx + 1, q) % q)
+
+
+def sw_add(S: SuiteParams, P: Optional[Point], Q: Optional[Point]) -> Optional[Point]:
+    """The chord-and-tangent law on the short-Weierstrass form (None = infinity): the tests check the map against it."""
+    q = S.q
+    _, _, a2, _ = te_sw_constants(S)
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    if P[0] == Q[0]:
+        if (P[1] + Q[1]) % q == 0:
+            return None
+        lam = (3 * P[0] * P[0] + a2) * finv(2 * P[1], q) % q
+    else:
+        lam = (Q[1] - P[1]) * finv(Q[0] - P[0], q) % q
+    x = (lam * lam - P[0] - Q[0]) % q
+    return (x, (lam * (P[0] - x) - P[1]) % q)
+
+
 def jubjub_params() -> SuiteParams:
     base = SuiteParams(
         name="jubjub_sha512_tai", suite_id=b"JubJub_SHA-512_TAI", q=Q, a=Q - 1, d=_JUBJUB_D,

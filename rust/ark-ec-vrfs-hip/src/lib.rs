@@ -332,6 +332,53 @@ impl<S: GpuSuite> GpuBatch<S> {
     }
 }
 
+impl<S: GpuSuite> GpuBatch<S> {
+    /// `utils::te_sw_map::te_to_sw` for every point: the coordinates of its image on the short-Weierstrass form of the
+    /// curve (the caller wraps them: `WeierstrassAffine::new_unchecked(x, y)`), or `None` where upstream's map is `None`
+    /// (the identity and the point of order 2).  One launch on the first device.
+    pub fn te_to_sw(&self, points: &[AffinePoint<S>]) -> Result<Vec<Option<(BaseField<S>, BaseField<S>)>>, GpuError> {
+        let n = points.len();
+        let mut inp = vec![0u8; n * 64];
+        for (i, p) in points.iter().enumerate() {
+            let mut xy = [0u8; 64];
+            affine_xy::<S>(p, &mut xy);
+            inp[i * 64..(i + 1) * 64].copy_from_slice(&xy);
+        }
+        let (out, status) = self.te_sw_map(n, 0, &inp)?;
+        Ok((0..n)
+            .map(|i| {
+                (status[i] == 0).then(|| {
+                    let x = BaseField::<S>::deserialize_uncompressed_unchecked(&out[i * 64..i * 64 + 32]).expect("canonical x");
+                    let y = BaseField::<S>::deserialize_uncompressed_unchecked(&out[i * 64 + 32..i * 64 + 64]).expect("canonical y");
+                    (x, y)
+                })
+            })
+            .collect())
+    }
+
+    /// `utils::te_sw_map::sw_to_te`: short-Weierstrass coordinates back to points of `S`'s twisted-Edwards curve (no
+    /// curve-membership test, as upstream's `new_unchecked`).
+    pub fn sw_to_te(&self, points: &[(BaseField<S>, BaseField<S>)]) -> Result<Vec<Option<AffinePoint<S>>>, GpuError> {
+        let n = points.len();
+        let mut inp = vec![0u8; n * 64];
+        for (i, (x, y)) in points.iter().enumerate() {
+            x.serialize_uncompressed(&mut inp[i * 64..i * 64 + 32]).expect("32-byte base field");
+            y.serialize_uncompressed(&mut inp[i * 64 + 32..i * 64 + 64]).expect("32-byte base field");
+        }
+        let (out, status) = self.te_sw_map(n, 1, &inp)?;
+        Ok((0..n).map(|i| (status[i] == 0).then(|| point_from_xy::<S>(&out[i * 64..(i + 1) * 64]))).collect())
+    }
+
+    fn te_sw_map(&self, n: usize, to_te: i32, inp: &[u8]) -> Result<(Vec<u8>, Vec<u8>), GpuError> {
+        let mut out = vec![0u8; n * 64];
+        let mut status = vec![0u8; n];
+        check(unsafe {
+            ffi::vrfhip_te_sw_map_batch(self.ctxs[0], n, to_te, inp.as_ptr(), out.as_mut_ptr(), status.as_mut_ptr())
+        })?;
+        Ok((out, status))
+    }
+}
+
 impl<S: GpuSuite> Drop for GpuBatch<S> {
     fn drop(&mut self) {
         for &c in &self.ctxs {

@@ -26,9 +26,24 @@ def test_header_symbols_are_exported():
     assert sorted(_lib.SYMBOLS) == decl
 
 
+def test_every_entry_point_has_a_declared_signature():
+    """A call through ctypes without argtypes passes a size_t as a 32-bit int: every symbol that takes arguments has them
+    declared, with the arity of its C declaration."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "vrfhip.h")).read()
+    lib = _lib.load()
+    for name in _lib.SYMBOLS:
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, hdr, re.S)
+        assert m, name
+        params = m.group(1).strip()
+        arity = 0 if params == "void" else params.count(",") + 1
+        at = getattr(lib, name).argtypes
+        assert (at is None and arity == 0) or (at is not None and len(at) == arity), (name, arity, at)
+
+
 def test_abi_version_and_no_cpu_fallback():
     lib = _lib.load()
-    assert lib.vrfhip_abi_version() == _lib.ABI_VERSION == 140
+    assert lib.vrfhip_abi_version() == _lib.ABI_VERSION == 141
     import torch
     if not torch.cuda.is_available():
         from ark_ec_vrfs_amd import Context, VrfHipError
