@@ -17,6 +17,7 @@
 //   ietf::Verifier::verify(&public, input, output, ad, &p) ietf::verify(ctx, public, input, output, ad, p) -> Result
 //   pedersen::Prover::prove(..) -> (Proof, blinding)       pedersen::prove(..) -> std::pair<Proof, Scalar>
 //   pedersen::Verifier::verify(input, output, ad, &p)      pedersen::verify(ctx, input, output, ad, p) -> Result
+//   utils::te_sw_map::{te_to_sw, sw_to_te}(point)          utils::te_to_sw(ctx, points) / utils::sw_to_te(ctx, points)
 //   Error::{VerificationFailure, InvalidData}              enum class Error; Result = std::optional<Error> (nullopt = Ok(()))
 // Suites: the four twisted-Edwards ones (32-byte ArkworksCodec points, SHA-512) and `suites::secp256r1` (33-byte Sec1
 // points, big-endian scalars, SHA-256) through the same templates: Point<S> / Hash<S> carry the widths.
@@ -413,6 +414,30 @@ std::vector<Result> verify_batch(const Context<S>& ctx, const std::vector<Item<S
   return res;
 }
 }  // namespace pedersen
+
+// -------------------------------------------------------------------------------- `utils::te_sw_map` (src/lib.rs:14)
+namespace utils {
+using XY = std::array<uint8_t, 64>;           // an affine point as x || y, 32-byte little-endian canonical integers
+namespace detail {
+template <class S>
+std::vector<std::optional<XY>> te_sw_map(const Context<S>& ctx, const std::vector<XY>& pts, int32_t to_te) {
+  static_assert(S::EDWARDS, "te_sw_map: the suite's curve is not twisted Edwards");
+  const size_t n = pts.size();
+  Bytes in = ark_vrf_hip::detail::column(pts, [](const XY& t) -> const XY& { return t; }), out(64 * n + 1), st(n + 1);
+  check(vrfhip_te_sw_map_batch(ctx.handle(), n, to_te, in.data(), out.data(), st.data()), "vrfhip_te_sw_map_batch");
+  std::vector<std::optional<XY>> r(n);
+  for (size_t i = 0; i < n; ++i)
+    if (st[i] == VRFHIP_ST_OK) { r[i].emplace(); ark_vrf_hip::detail::take(*r[i], out, i); }
+  return r;
+}
+}  // namespace detail
+// `te_to_sw`: points of S's twisted-Edwards curve -> the short-Weierstrass form of its Montgomery model; nullopt = None
+template <class S>
+std::vector<std::optional<XY>> te_to_sw(const Context<S>& ctx, const std::vector<XY>& pts) { return detail::te_sw_map(ctx, pts, 0); }
+// `sw_to_te`: the inverse map
+template <class S>
+std::vector<std::optional<XY>> sw_to_te(const Context<S>& ctx, const std::vector<XY>& pts) { return detail::te_sw_map(ctx, pts, 1); }
+}  // namespace utils
 
 }  // namespace ark_vrf_hip
 #endif  // VRFHIP_HPP

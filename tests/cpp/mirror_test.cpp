@@ -220,6 +220,15 @@ int main(int argc, char** argv) {
   {
     vrfhip_suite_desc d = Context<S>::default_descriptor();
     CHECK(d.curve == VRFHIP_CURVE_BANDERSNATCH && d.suite_id_len == 25 && d.challenge_len == 32);
+    // utils::te_sw_map: the generator and the blinding base go to the Weierstrass form and come back; the identity has no image
+    utils::XY g, bb, id{};
+    std::copy(d.generator, d.generator + 64, g.begin());
+    std::copy(d.blinding_base, d.blinding_base + 64, bb.begin());
+    id[32] = 1;                                                            // (0, 1)
+    const auto sw = utils::te_to_sw(ctx, {g, bb, id});
+    CHECK(sw.size() == 3 && sw[0].has_value() && sw[1].has_value() && !sw[2].has_value() && !(*sw[0] == g));
+    const auto te = utils::sw_to_te(ctx, {*sw[0], *sw[1]});
+    CHECK(te[0].has_value() && *te[0] == g && te[1].has_value() && *te[1] == bb);
     Context<S> from_desc(d, 0);
     const auto a = ietf::prove_batch(ctx, {sks[0], sks[1]}, {msgs[0], msgs[1]}, unhex(ad));
     const auto b = ietf::prove_batch(from_desc, {sks[0], sks[1]}, {msgs[0], msgs[1]}, unhex(ad));
