@@ -22,6 +22,7 @@ SYMBOLS = [
     "vrfhip_ctx_set_flags", "vrfhip_ctx_get_flags", "vrfhip_ctx_point_bytes", "vrfhip_ctx_hash_bytes",
     "vrfhip_ietf_verify_batch", "vrfhip_ietf_verify_batch_dev",
     "vrfhip_ietf_verify_batch_affine", "vrfhip_ietf_verify_batch_affine_dev",
+    "vrfhip_ietf_verify_batch_alpha", "vrfhip_ietf_verify_batch_alpha_dev",
     "vrfhip_keyset_create", "vrfhip_keyset_destroy", "vrfhip_keyset_bytes",
     "vrfhip_ietf_verify_batch_keyed", "vrfhip_ietf_verify_batch_keyed_dev",
     "vrfhip_ietf_prove_batch", "vrfhip_ietf_prove_batch_dev",
@@ -59,7 +60,7 @@ class SuiteDescStruct(ctypes.Structure):
 _lib = None
 
 
-ABI_VERSION = 141      # vrfhip_abi_version() of the library this binding was written against
+ABI_VERSION = 142      # vrfhip_abi_version() of the library this binding was written against
 
 
 def load() -> ctypes.CDLL:
@@ -110,6 +111,8 @@ def load() -> ctypes.CDLL:
     P = c_void_p  # raw addresses (host buffers or device pointers)
     lib.vrfhip_ietf_verify_batch.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P]
     lib.vrfhip_ietf_verify_batch_dev.argtypes = [c_void_p, c_size_t, P, P, P, P, P, P, P, c_uint32, P, c_void_p]
+    lib.vrfhip_ietf_verify_batch_alpha.argtypes = [c_void_p, c_size_t, P, P, P, c_uint32, P, P, P, P, P, c_uint32, P]
+    lib.vrfhip_ietf_verify_batch_alpha_dev.argtypes = [c_void_p, c_size_t, P, P, P, c_uint32, P, P, P, P, P, c_uint32, P, c_void_p]
     lib.vrfhip_ietf_verify_batch_affine.argtypes = lib.vrfhip_ietf_verify_batch.argtypes
     lib.vrfhip_ietf_verify_batch_affine_dev.argtypes = lib.vrfhip_ietf_verify_batch_dev.argtypes
     lib.vrfhip_keyset_create.argtypes = [c_void_p, c_size_t, P, P, POINTER(c_void_p)]

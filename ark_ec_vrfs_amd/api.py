@@ -280,6 +280,21 @@ class Context:
             _ptr(status)), "vrfhip_ietf_verify_batch")
         return status
 
+    def ietf_verify_batch_alpha(self, pk, msgs, out, c, s, ad=b"") -> np.ndarray:
+        """`Input::new(alpha)` + `ietf::Verifier::verify` in one call (vrfhip_ietf_verify_batch_alpha): msgs is a sequence of
+        byte strings or an (n, L) uint8 array; H is hashed to the curve on the device and stays there as affine coordinates."""
+        pk, out, c, s = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (pk, out, c, s))
+        n = pk.shape[0]
+        if not all(x.shape[0] == n for x in (out, c, s)):
+            raise ValueError("ragged batch")
+        msg_blob, msg_off, msg_len, _ = self._msg_args(n, msgs, None)
+        status = np.empty(n, dtype=np.uint8)
+        blob, off, ad_len = self._ad_args(ad, n)
+        _lib.check(self._lib.vrfhip_ietf_verify_batch_alpha(
+            self._h, n, _ptr(pk), _ptr(msg_blob), _ptr(msg_off), msg_len, _ptr(out), _ptr(c), _ptr(s), _ptr(blob), _ptr(off),
+            ad_len, _ptr(status)), "vrfhip_ietf_verify_batch_alpha")
+        return status
+
     # ---- keyed verification: public keys with context-resident fixed-base tables --------------
     def keyset_create(self, pks):
         """`Public` keys -> KeySet (validated points + one 881 KB comb each, resident in HBM).  Returns
@@ -663,6 +678,15 @@ class Context:
             self._h, n, pk.data_ptr(), inp.data_ptr(), out.data_ptr(), c.data_ptr(), s.data_ptr(),
             None if ad is None else ad.data_ptr(), None if ad_off is None else ad_off.data_ptr(), ad_len,
             status.data_ptr(), st), "vrfhip_ietf_verify_batch_dev")
+
+    def ietf_verify_batch_alpha_dev(self, pk, msg, msg_len, out, c, s, status, msg_off=None, ad=None, ad_off=None, ad_len=0,
+                                    stream=None):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        dp = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self._lib.vrfhip_ietf_verify_batch_alpha_dev(
+            self._h, pk.shape[0], pk.data_ptr(), dp(msg), dp(msg_off), msg_len, out.data_ptr(), c.data_ptr(), s.data_ptr(),
+            dp(ad), dp(ad_off), ad_len, status.data_ptr(), st), "vrfhip_ietf_verify_batch_alpha_dev")
 
     def ietf_prove_batch_dev(self, sk, msg, msg_len, out, c, s, pk_out=None, input_out=None, status=None,
                              msg_off=None, inputs=None, ad=None, ad_off=None, ad_len=0, stream=None):

@@ -311,7 +311,7 @@ size_t blob_bytes(size_t n, const uint32_t* off, uint32_t len, bool shared) {
 
 extern "C" {
 
-int32_t vrfhip_abi_version(void) { return 141; }
+int32_t vrfhip_abi_version(void) { return 142; }
 
 const char* vrfhip_last_error(void) { return g_last_error.c_str(); }
 
@@ -676,6 +676,7 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
     a.n = m;
     a.pk = ks ? d_pk : d_pk + base * pw; a.h = d_input + base * pw; a.gamma = d_output + base * pw;
     a.affine_in = affine ? (ctx->coords_mont256() ? 2 : 1) : 0;
+    a.h_in_tabs = 0;
     a.check_mask = ctx->check_mask();
     a.key_index = ks ? d_key_index + base : nullptr;
     a.key_combs = ks ? ks->d_combs : nullptr;
@@ -762,6 +763,88 @@ int32_t vrfhip_ietf_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d
   return verify_dev_impl(ctx, n, false, d_pk, d_input, d_output, d_c, d_s, d_ad, d_ad_off, ad_len, d_status,
                          stream);
 }
+// `Input::new(alpha)` + `ietf::Verifier::verify` in one launch group: H never leaves the device and is never compressed,
+// decompressed or subgroup-tested (k_verify.hip k_verify_input_from_alpha).  Per chunk of the workspace: hash-to-curve writes
+// enc(H) into the (otherwise idle) aux region and H's tables into slot 1, the decode stage handles pk and Gamma.
+int32_t vrfhip_ietf_verify_batch_alpha_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_pk, const uint8_t* d_msg,
+                                           const uint32_t* d_msg_off, uint32_t msg_len, const uint8_t* d_output,
+                                           const uint8_t* d_c, const uint8_t* d_s, const uint8_t* d_ad,
+                                           const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_status, void* stream) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "verify from alpha: twisted-Edwards suites (secp256r1: vrfhip_hash_to_curve_batch, then verify)");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!d_pk || !d_output || !d_c || !d_s || !d_status || (!d_msg && (msg_len || d_msg_off)))
+    return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if ((ad_len || d_ad_off) && !d_ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_workspace(ctx, n);
+  if (rc) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (size_t base = 0; base < n; base += ctx->ws_cap) {
+    const size_t m = std::min(ctx->ws_cap, n - base);
+    uint8_t* d_henc = reinterpret_cast<uint8_t*>(ctx->ws.aux);              // [m][32]: AUX_WORDS * 4 >= 32 bytes per item
+    BytesView mv = d_msg_off ? make_view(d_msg, d_msg_off + base, msg_len, false)
+                             : make_view(d_msg ? d_msg + base * (size_t)msg_len : d_msg, nullptr, msg_len, false);
+    FIELD_CALL(ctx, launch_verify_input_from_alpha((int)ctx->suite, m, mv, d_henc, ctx->ws.tabs, ctx->T, st, ctx->ws.flags,
+                                                   ctx->d_queue));
+    VerifyArgs a;
+    a.suite = (int)ctx->suite;
+    a.k_lane = lanes_k(m, VERIFY_K_POLICY);
+    a.n = m;
+    a.pk = d_pk + base * 32; a.h = d_henc; a.gamma = d_output + base * 32;
+    a.affine_in = 0;
+    a.h_in_tabs = 1;
+    a.check_mask = ctx->check_mask() & ~2u;             // CHK_INPUT: H is a cofactor multiple by construction
+    a.key_index = nullptr; a.key_combs = nullptr; a.key_valid = nullptr; a.n_keys = 0;
+    a.c = d_c + base * 32; a.s = d_s + base * 32;
+    a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
+    a.status = d_status + base;
+    a.ws = ctx->ws;
+    a.T = ctx->T;
+    FIELD_CALL(ctx, launch_ietf_verify(a, st, prof_events(ctx)));
+  }
+  HIP_TRY(hipGetLastError());
+  return VRFHIP_SUCCESS;
+}
+
+int32_t vrfhip_ietf_verify_batch_alpha(vrfhip_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* msg,
+                                       const uint32_t* msg_off, uint32_t msg_len, const uint8_t* output, const uint8_t* c,
+                                       const uint8_t* s, const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
+                                       uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "verify from alpha: twisted-Edwards suites (secp256r1: vrfhip_hash_to_curve_batch, then verify)");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!pk || !output || !c || !s || !status || (!msg && (msg_len || msg_off))) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  const size_t msgb = blob_bytes(n, msg_off, msg_len, false), adb = blob_bytes(n, ad_off, ad_len, true);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_stage(ctx, 4 * Stage::pad(n * 32) + Stage::pad(msgb + 1) + Stage::pad(adb + 1) + 2 * Stage::pad((n + 1) * 4) +
+                                     Stage::pad(n));
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t *d_pk = sg.take(n * 32), *d_g = sg.take(n * 32), *d_c = sg.take(n * 32), *d_s = sg.take(n * 32);
+  uint8_t *d_msg = sg.take(msgb + 1), *d_ad = sg.take(adb + 1);
+  uint32_t* d_moff = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+  uint32_t* d_aoff = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
+  uint8_t* d_st = sg.take(n);
+  HIP_TRY(hipMemcpyAsync(d_pk, pk, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_g, output, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_c, c, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_s, s, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (msgb) HIP_TRY(hipMemcpyAsync(d_msg, msg, msgb, hipMemcpyHostToDevice, ctx->stream));
+  if (adb) HIP_TRY(hipMemcpyAsync(d_ad, ad, adb, hipMemcpyHostToDevice, ctx->stream));
+  if (msg_off) HIP_TRY(hipMemcpyAsync(d_moff, msg_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (ad_off) HIP_TRY(hipMemcpyAsync(d_aoff, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  rc = vrfhip_ietf_verify_batch_alpha_dev(ctx, n, d_pk, d_msg, msg_off ? d_moff : nullptr, msg_len, d_g, d_c, d_s, d_ad,
+                                          ad_off ? d_aoff : nullptr, ad_len, d_st, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
 int32_t vrfhip_ietf_verify_batch_affine_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_pk_xy,
                                             const uint8_t* d_input_xy, const uint8_t* d_output_xy,
                                             const uint8_t* d_c, const uint8_t* d_s, const uint8_t* d_ad,
@@ -1619,10 +1702,24 @@ int32_t vrfhip_hash_to_curve_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
   if (!d_points || (!d_msg && (msg_len || d_msg_off))) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  if (ctx->sw) p256::launch_hash_to_curve(n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T.sq.str, static_cast<hipStream_t>(stream));
-  else
-  FIELD_CALL(ctx, launch_hash_to_curve((int)ctx->suite, n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T,
-                       static_cast<hipStream_t>(stream)));
+  if (ctx->sw) {
+    p256::launch_hash_to_curve(n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T.sq.str, static_cast<hipStream_t>(stream));
+  } else if (ctx->suite == VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2) {
+    FIELD_CALL(ctx, launch_hash_to_curve((int)ctx->suite, n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T,
+                                         static_cast<hipStream_t>(stream)));
+  } else {
+    // try-and-increment suites: the counters are found by the provers' work-queue search first (one flag byte per item of
+    // the workspace holds them), chunk by chunk of the workspace
+    int32_t rc = ensure_workspace(ctx, n);
+    if (rc) return rc;
+    for (size_t base = 0; base < n; base += ctx->ws_cap) {
+      const size_t m = std::min(ctx->ws_cap, n - base);
+      BytesView mv = d_msg_off ? make_view(d_msg, d_msg_off + base, msg_len, false)
+                               : make_view(d_msg ? d_msg + base * (size_t)msg_len : d_msg, nullptr, msg_len, false);
+      FIELD_CALL(ctx, launch_hash_to_curve((int)ctx->suite, m, mv, d_points + base * 32, ctx->T, static_cast<hipStream_t>(stream),
+                                           ctx->ws.flags, ctx->d_queue));
+    }
+  }
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
 }

@@ -1,6 +1,7 @@
 // k_misc.hip -- table construction and the small building-block kernels.
 #include "kernels.h"
 #include "te_sw_map.cuh"
+#include "tai_find.cuh"
 
 VRF_NS_BEGIN
 #include "te_sw_map.inc"
@@ -60,20 +61,31 @@ void launch_init_tables(int suite, uint32_t* g_win, uint32_t* g_comb, uint32_t* 
 
 // ---- Input::new ----
 template <class S>
-__global__ void __launch_bounds__(BLOCK, 2) k_hash_to_curve(size_t n, BytesView msg, uint8_t* points, DevTables T) {
+__global__ void __launch_bounds__(BLOCK, 2) k_hash_to_curve(size_t n, BytesView msg, uint8_t* points, DevTables T,
+                                                             const uint8_t* tai_ctr) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint8_t* m; uint32_t len;
   bytes_get(msg, i, m, len);
-  PtE h = data_to_point<S>(m, len, T.sq);
+  PtE h = data_to_point<S>(m, len, T.sq, tai_ctr ? tai_ctr[i] : 0u);      // try-and-increment: k_tai_find's counter
   FeN x, y;
   te_to_affine(x, y, h);
   uint32_t e[8];
   te_encode_affine(e, x, y, T.sq.str.flags);
   store32(points, i, e);
 }
-void launch_hash_to_curve(int suite, size_t n, BytesView msg, uint8_t* points, DevTables T, hipStream_t st) {
-  if (n) VRF_DISPATCH_SUITE(suite, hipLaunchKernelGGL(k_hash_to_curve<S>, grid_for(n), dim3(BLOCK), 0, st, n, msg, points, T));
+// tai_ctr ([n] bytes) + queue: scratch for the try-and-increment suites' counter search (tai_find.cuh); without them every
+// lane loops until its own item succeeds and a wave pays for its unluckiest lane
+void launch_hash_to_curve(int suite, size_t n, BytesView msg, uint8_t* points, DevTables T, hipStream_t st, uint8_t* tai_ctr,
+                          unsigned long long* queue) {
+  if (!n) return;
+  VRF_DISPATCH_SUITE(suite, {
+    const uint8_t* ctr = nullptr;
+    if constexpr (!S::H2C_ELL2) {
+      if (tai_ctr && queue) { launch_tai_find_t<S>(n, msg, tai_ctr, T.sq, queue, st); ctr = tai_ctr; }
+    }
+    hipLaunchKernelGGL(k_hash_to_curve<S>, grid_for(n), dim3(BLOCK), 0, st, n, msg, points, T, ctr);
+  });
 }
 
 // ---- Output::hash ----

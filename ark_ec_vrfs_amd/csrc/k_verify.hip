@@ -1,6 +1,7 @@
 // k_verify.hip -- IETF ECVRF batch verification kernels.
 // Replaces the body of `ietf::Verifier::verify` (/root/reference src/lib.rs:14).
 #include "kernels.h"
+#include "tai_find.cuh"
 
 VRF_NS_BEGIN
 
@@ -22,6 +23,34 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_verify_decode(VerifyArgs a) {
   size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
   if (first >= a.n) return;
   verify_decode_multi<S>(a.k_lane, a.T, first, a.n, a.pk, a.h, a.gamma, a.ws.tabs, a.ws.pts, a.ws.flags, a.check_mask);
+}
+
+// Verification from alpha (`Input::new(alpha)` inside the call, as a deployed verifier holds pk, alpha and the proof):
+// H leaves hash-to-curve as affine x, y -- its encoding goes where the finish stage reads it (`enc`, 32 B per item), its
+// GLV table pair straight into slot 1 of the item's tables.  No compression, second square root or subgroup test for H:
+// it is a cofactor multiple by construction.
+template <class S>
+__global__ void __launch_bounds__(BLOCK, 2) k_verify_input_from_alpha(size_t n, BytesView msg, uint8_t* enc, uint32_t* tabs,
+                                                                      DevTables T, const uint8_t* tai_ctr) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* m; uint32_t len;
+  bytes_get(msg, i, m, len);
+  PtE h = data_to_point<S>(m, len, T.sq, tai_ctr ? tai_ctr[i] : 0u);
+  FeN x, y;
+  te_to_affine(x, y, h);
+  uint32_t e[8];
+  te_encode_affine(e, x, y, T.sq.str.flags);
+  store32(enc, i, e);
+  build_glv_tables<S>(tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS) + 2 * WIN_TABLE_WORDS, x, y);
+}
+// stage 1 after it: pk and Gamma only
+template <class S, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_verify_decode_skip_h(VerifyArgs a) {
+  size_t first = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * a.k_lane;
+  if (first >= a.n) return;
+  verify_decode_multi<S, 2, true>(a.k_lane, a.T, first, a.n, a.pk, nullptr, a.gamma, a.ws.tabs, a.ws.pts, a.ws.flags,
+                                  a.check_mask);
 }
 
 // stage 1, keyed: only H and Gamma are decompressed; validity also requires a valid, existing key
@@ -119,6 +148,7 @@ static void launch_verify_t(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev)
   const dim3 gk = grid_for(lanes_k_);
   if (ev) (void)hipEventRecord(ev[0], st);
   if (a.key_index) VRF_LAUNCH_MINW(k_verify_decode_keyed, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
+  else if (a.h_in_tabs) VRF_LAUNCH_MINW(k_verify_decode_skip_h, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
   else if (a.affine_in) hipLaunchKernelGGL(k_verify_decode_affine<S>, grid_for(a.n), dim3(BLOCK), 0, st, a);
   else VRF_LAUNCH_MINW(k_verify_decode, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
   if (!ev && !a.key_index && a.n <= STRAUS_FUSE_MAX_ITEMS) {
@@ -136,6 +166,18 @@ static void launch_verify_t(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev)
   if (ev) (void)hipEventRecord(ev[3], st);
   VRF_LAUNCH_MINW(k_verify_finish, S, lanes_k_, gk, spread_lds_bytes(gk.x), st, a);
   if (ev) (void)hipEventRecord(ev[4], st);
+}
+// tai_ctr / queue: as launch_hash_to_curve (the decode stage that follows overwrites the flag bytes the counters sit in)
+void launch_verify_input_from_alpha(int suite, size_t n, BytesView msg, uint8_t* enc, uint32_t* tabs, DevTables T,
+                                    hipStream_t st, uint8_t* tai_ctr, unsigned long long* queue) {
+  if (!n) return;
+  VRF_DISPATCH_SUITE(suite, {
+    const uint8_t* ctr = nullptr;
+    if constexpr (!S::H2C_ELL2) {
+      if (tai_ctr && queue) { launch_tai_find_t<S>(n, msg, tai_ctr, T.sq, queue, st); ctr = tai_ctr; }
+    }
+    hipLaunchKernelGGL(k_verify_input_from_alpha<S>, grid_for(n), dim3(BLOCK), 0, st, n, msg, enc, tabs, T, ctr);
+  });
 }
 void launch_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (a.n == 0) return;

@@ -1,0 +1,80 @@
+// tai_find.cuh -- the work-queue counter search of try-and-increment hash-to-curve (`Input::new` on the TAI suites,
+// /root/reference src/lib.rs:15-16): shared by the provers (k_prove.hip), `vrfhip_hash_to_curve_batch` (k_misc.hip) and
+// verification from alpha (k_verify.hip).  Each translation unit instantiates the kernel for its own suites.
+#pragma once
+#include "kernels.h"
+#include <algorithm>
+
+VRF_NS_BEGIN
+
+// stage 0 for try-and-increment suites: find every item's first counter whose candidate decodes.  A lane that
+// loops until ITS item succeeds makes the wave pay the maximum over 64 geometric trials (about 7 attempts for
+// an expected 2).  Here the lanes of a persistent wave draw items from a global queue: a lane whose attempt
+// succeeded records the counter and takes the next item at once, so a wave performs about two attempts per
+// item and the only idle lanes are those of the last few iterations of the whole grid.
+// An attempt has a cheap half (hash the counter, y < q, denominator non-zero) and an expensive one (the Jacobi symbol,
+// four times the hash).  Where the cheap half rejects often -- Baby-JubJub: q = 0.378 * 2^255, five hashes per point --
+// a wave that ran both halves every trip would run the symbol for the one lane in three that needs it; so a lane that
+// passed the cheap half WAITS (ready), the others keep hashing, and the wave runs the symbol once three quarters of its
+// lanes are ready (or nobody is left to hash).  Suites whose candidates rarely fail the cheap half (JubJub 0.91,
+// Ed25519 1.0) take the symbol every trip, as before.
+template <class S>
+__global__ void __launch_bounds__(64, 2) k_tai_find(size_t n, BytesView msg, uint8_t* ctr_out, SqrtTables T,
+                                                 unsigned long long* queue) {
+  constexpr size_t NONE = ~size_t(0);
+  const int lane = threadIdx.x;
+  size_t item = NONE;
+  uint32_t ctr = 0;
+  bool ready = false;                                      // this lane holds a candidate that awaits its Jacobi symbol
+  FeN w = fe_zero();
+  bool drained = false;                                    // the queue has no items left (wave-uniform)
+  while (true) {
+    const bool need = item == NONE && !drained;
+    const unsigned long long mask = __ballot(need);
+    if (mask) {
+      const uint32_t cnt = (uint32_t)__popcll(mask);
+      const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(queue, (unsigned long long)cnt);
+      base = __shfl(base, 0, 64);
+      if (need && base + rank < n) { item = (size_t)(base + rank); ctr = 0; ready = false; }
+      if (base + cnt >= n) drained = true;
+    }
+    if (!__any(item != NONE)) break;                       // every lane idle and nothing left to draw
+    if (item != NONE && !ready) {                          // the cheap half
+      const uint8_t* m; uint32_t len;
+      bytes_get(msg, item, m, len);
+      if (tai_attempt_candidate<S>(w, m, len, ctr, T)) {
+        ready = true;
+      } else if (ctr == 255) {
+        ctr_out[item] = 255;                               // hash_to_curve_tai reports the failure
+        item = NONE;
+      } else {
+        ++ctr;
+      }
+    }
+    const unsigned long long rmask = __ballot(ready), hmask = __ballot(item != NONE && !ready);
+    if (__popcll(rmask) >= 48 || (rmask && !hmask)) {      // the expensive half, for the lanes that wait for it
+      if (ready) {
+        ready = false;
+        if (fe_is_square_or_zero(w, T) || ctr == 255) {
+          ctr_out[item] = (uint8_t)ctr;
+          item = NONE;
+        } else {
+          ++ctr;
+        }
+      }
+    }
+  }
+}
+
+// the launch: the queue counter is reset on the stream first; persistent waves, 4 per SIMD at most
+template <class S>
+inline void launch_tai_find_t(size_t n, BytesView msg, uint8_t* ctr_out, const SqrtTables& T, unsigned long long* queue,
+                              hipStream_t st) {
+  (void)hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
+  const size_t waves = std::min<size_t>((n + 63) / 64, 4096);
+  hipLaunchKernelGGL(k_tai_find<S>, dim3((unsigned)waves), dim3(64), 0, st, n, msg, ctr_out, T, queue);
+}
+
+VRF_NS_END

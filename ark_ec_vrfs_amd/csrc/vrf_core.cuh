@@ -760,8 +760,9 @@ constexpr int DEC_SLOT = 4 * NL;            // per point: y | num | den | prefix
 // points: base pointers of the pk / H / Gamma arrays; items [first, first + K) ∩ [0, n).
 // tabs_base / scratch_base / flags: workspace arrays indexed by item.
 // NP = 3: pk, H, Gamma (table slots 0, 1, 2); NP = 2 (keyed verification: the key's tables are context
-// resident): H, Gamma (pk is not read, slots 1, 2).
-template <class S, int NP = 3>
+// resident): H, Gamma (pk is not read, slots 1, 2); NP = 2 with SKIP_H (verification from alpha: H came out of
+// hash-to-curve in this call and its tables are already in slot 1): pk, Gamma (slots 0, 2).
+template <class S, int NP = 3, bool SKIP_H = false>
 VRF_HD void verify_decode_multi(int K, const DevTables& T, size_t first, size_t n, const uint8_t* pk,
                                 const uint8_t* hh, const uint8_t* gamma, uint32_t* tabs_base,
                                 uint32_t* scratch_base, uint8_t* flags, uint32_t check_mask = 0) {
@@ -772,7 +773,7 @@ VRF_HD void verify_decode_multi(int K, const DevTables& T, size_t first, size_t 
 #pragma unroll 1
   for (int j = 0; j < NP * K; ++j) {
     const size_t item = first + j / NP;
-    const int p = j % NP + (3 - NP);
+    const int p = SKIP_H ? (j % NP) * 2 : j % NP + (3 - NP);
     if (item < n) {
       const uint8_t* src = p == 0 ? pk : (p == 1 ? hh : gamma);
       uint32_t enc[8];
@@ -794,7 +795,7 @@ VRF_HD void verify_decode_multi(int K, const DevTables& T, size_t first, size_t 
 #pragma unroll 1
   for (int j = NP * K - 1; j >= 0; --j) {
     const size_t item = first + j / NP;
-    const int p = j % NP + (3 - NP);
+    const int p = SKIP_H ? (j % NP) * 2 : j % NP + (3 - NP);
     if (item < n) {
       const uint32_t* slot = scr + j * DEC_SLOT;
       DecodeA a;

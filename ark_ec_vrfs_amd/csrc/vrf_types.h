@@ -80,6 +80,7 @@ struct VerifyArgs {
   size_t n;
   const uint8_t *pk, *h, *gamma, *c, *s;   // affine_in != 0: pk, h, gamma are 64-byte x || y
   int affine_in;
+  int h_in_tabs;                           // verification from alpha: h = the encodings hash-to-curve wrote, H's tables are built
   uint32_t check_mask;                     // CHK_* bits: which decoded points get the subgroup test
   BytesView ad;
   uint8_t* status;

@@ -501,6 +501,15 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
         cx.set_prevalidated(False)
         res["ietf_verify_" + tag]["prevalidated"] = {"value": D.world * n * max(2, args.config_steps) / el_p, "unit": "verifies/s",
                                                      "ms_per_step": el_p / max(2, args.config_steps) * 1e3}
+        if not sw:
+            # as a deployed verifier runs it: from (pk, alpha, proof), H hashed inside the call and kept affine (cfg_from_alpha)
+            fn_a = lambda: cx.ietf_verify_batch_alpha_dev(pk, msg, 32, g, c, s_, st)
+            st.fill_(255)
+            fn_a(); torch.cuda.synchronize()
+            assert int(st.sum()) == 0
+            el_a, _ = timed(D, fn_a, max(2, args.config_steps), 1)
+            res["ietf_verify_" + tag]["from_alpha"] = {"value": D.world * n * max(2, args.config_steps) / el_a, "unit": "verifies/s",
+                                                       "ms_per_step": el_a / max(2, args.config_steps) * 1e3}
         if sw:
             # the same verification from typed values: pk, input, output as x || y (no decompression)
             from ark_ec_vrfs_amd import _lib as _l
@@ -591,6 +600,43 @@ def cfg_shard_sizes(D, args, ctx, pk, hh, gamma, c, s):
                         % (lg, 1 << (20 - lg)),
             "value": D.world * m * steps / el, "unit": "verifies/s", "ms_per_step": el / steps * 1e3}
     return out
+
+
+def cfg_from_alpha(D, args, ctx, lib, pk, msg, hh, gamma, c, s):
+    """Verification as a deployed verifier runs it: it holds pk, alpha and the proof, H is not on the wire.  Two forms on the
+    headline batch: `vrfhip_hash_to_curve_batch_dev` then verify with the input declared validated (a cofactor multiple needs
+    no subgroup test), and the fused `vrfhip_ietf_verify_batch_alpha_dev`, which keeps H on the device as affine coordinates
+    (no compression, second square root or test).  145 B per verify cross the boundary (pk, a 32-byte alpha, Gamma, c, s)."""
+    from ark_ec_vrfs_amd import _lib
+    torch = D.torch
+    n = pk.shape[0]
+    st = torch.empty(n, dtype=torch.uint8, device=D.dev)
+    h2 = torch.empty_like(hh)
+    stream = torch.cuda.current_stream().cuda_stream
+    steps = max(3, args.config_steps)
+
+    def two_calls():
+        _lib.check(lib.vrfhip_hash_to_curve_batch_dev(ctx.handle, n, msg.data_ptr(), None, msg.shape[1], h2.data_ptr(), stream), "h2c")
+        ctx.ietf_verify_batch_dev(pk, h2, gamma, c, s, st)
+
+    fused = lambda: ctx.ietf_verify_batch_alpha_dev(pk, msg, msg.shape[1], gamma, c, s, st)
+    flags0 = ctx.get_flags() if hasattr(ctx, "get_flags") else 0
+    ctx.set_flags(flags0 | ctx.PREVALIDATED_INPUT)
+    two_calls(); torch.cuda.synchronize()
+    assert int(st.sum()) == 0 and bool((h2 == hh).all())
+    el2, _ = timed(D, two_calls, steps, 1)
+    ctx.set_flags(flags0)
+    st.fill_(255)
+    fused(); torch.cuda.synchronize()
+    assert int(st.sum()) == 0
+    el1, _ = timed(D, fused, steps, 1)
+    return {"ietf_verify_from_alpha": {
+        "workload": "IETF ECVRF verify from (pk, alpha, proof), Bandersnatch, batch 2^%d per GPU: Input::new(alpha) inside the "
+                    "call, H kept on the device as affine coordinates; pk and Gamma checked as in the headline"
+                    % (n.bit_length() - 1),
+        "value": D.world * n * steps / el1, "unit": "verifies/s", "ms_per_step": el1 / steps * 1e3, "bytes_per_unit": 145,
+        "two_calls": {"workload": "vrfhip_hash_to_curve_batch_dev, then verify with VRFHIP_FLAG_PREVALIDATED_INPUT",
+                      "value": D.world * n * steps / el2, "unit": "verifies/s", "ms_per_step": el2 / steps * 1e3}}}
 
 
 def cfg_pairing(D, args, ctx, want_cpu):
@@ -809,6 +855,7 @@ def run_rank(args):
         from ark_ec_vrfs_amd import BabyJubJubSha512Tai, Ed25519Sha512Tai, Secp256r1Sha256Tai
         legs = (("ietf_prove", lambda: {"ietf_prove": cfg_ietf_prove(D, args, ctx, sk, msg, want_cpu and rank == 0)}),
                 ("shard_sizes", lambda: cfg_shard_sizes(D, args, ctx, pk, hh, gamma, c, s)),
+                ("from_alpha", lambda: cfg_from_alpha(D, args, ctx, lib, pk, msg, hh, gamma, c, s)),
                 ("ietf_verify_keyed", lambda: {"ietf_verify_keyed": cfg_ietf_keyed(D, args, ctx, msg, lo)}),
                 ("pedersen_jubjub", lambda: cfg_pedersen_jubjub(D, args, msg, lo, want_cpu and rank == 0)),
                 ("ed25519", lambda: cfg_suite_ietf(D, args, "ed25519", Ed25519Sha512Tai, 3, "Ed25519_SHA-512_TAI", lo,

@@ -242,6 +242,22 @@ int32_t vrfhip_ietf_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d
  * (the form `Public`, `Input`, `Output` wrap): pk_xy, input_xy, output_xy are n x 64 B, x || y as
  * 32-byte little-endian canonical integers.  No square roots are needed; InvalidData = coordinate
  * >= q or point off the curve. */
+/* `Input::new(alpha)` + `ietf::Verifier::verify` (src/lib.rs:14-16) in one call: what a deployed verifier holds is the
+ * public key, the message alpha and the proof -- H is not on the wire, the verifier hashes alpha to the curve itself.  msg /
+ * msg_off / msg_len name the messages as in vrfhip_ietf_prove_batch (n+1 offsets into msg, or msg_off = NULL and msg_len
+ * bytes each).  Statuses are those of vrfhip_hash_to_curve_batch followed by vrfhip_ietf_verify_batch; H stays on the device
+ * as affine coordinates, so its compression, second square root and subgroup test (a cofactor multiple needs none) are not
+ * paid.  Twisted-Edwards suites (secp256r1: VRFHIP_ERR_UNSUPPORTED; use the two calls). */
+int32_t vrfhip_ietf_verify_batch_alpha(vrfhip_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* msg,
+                                       const uint32_t* msg_off, uint32_t msg_len, const uint8_t* output,
+                                       const uint8_t* c, const uint8_t* s, const uint8_t* ad,
+                                       const uint32_t* ad_off, uint32_t ad_len, uint8_t* status);
+int32_t vrfhip_ietf_verify_batch_alpha_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_pk, const uint8_t* d_msg,
+                                           const uint32_t* d_msg_off, uint32_t msg_len, const uint8_t* d_output,
+                                           const uint8_t* d_c, const uint8_t* d_s, const uint8_t* d_ad,
+                                           const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_status,
+                                           void* stream);
+
 int32_t vrfhip_ietf_verify_batch_affine(vrfhip_ctx* ctx, size_t n, const uint8_t* pk_xy,
                                         const uint8_t* input_xy, const uint8_t* output_xy,
                                         const uint8_t* c, const uint8_t* s, const uint8_t* ad,

@@ -255,6 +255,29 @@ std::vector<Result> verify_batch(const Context<S>& ctx, const std::vector<Item<S
   for (size_t i = 0; i < n; ++i) r[i] = result_of(st[i]);
   return r;
 }
+// n x (Input::new(alpha) + verify): what a verifier holding public keys, messages and proofs runs; the inputs are hashed
+// to the curve on the GPU and stay there (items[i].input is not read).  Twisted-Edwards suites.
+template <class S>
+std::vector<Result> verify_batch_from_alpha(const Context<S>& ctx, const std::vector<Item<S>>& items,
+                                            const std::vector<Bytes>& alphas, const Bytes& ad) {
+  static_assert(S::EDWARDS, "verify_batch_from_alpha: twisted-Edwards suites");
+  const size_t n = items.size();
+  if (alphas.size() != n) throw std::invalid_argument("verify_batch_from_alpha: ragged batch");
+  Bytes pk = detail::column(items, [](const Item<S>& t) -> const auto& { return t.pub.encoded; });
+  Bytes g = detail::column(items, [](const Item<S>& t) -> const auto& { return t.output.encoded; });
+  Bytes c = detail::column(items, [](const Item<S>& t) -> const auto& { return t.proof.c; });
+  Bytes s = detail::column(items, [](const Item<S>& t) -> const auto& { return t.proof.s; });
+  Bytes blob, st(n + 1);
+  std::vector<uint32_t> off(n + 1, 0);
+  for (size_t i = 0; i < n; ++i) { blob.insert(blob.end(), alphas[i].begin(), alphas[i].end()); off[i + 1] = (uint32_t)blob.size(); }
+  blob.push_back(0);
+  check(vrfhip_ietf_verify_batch_alpha(ctx.handle(), n, pk.data(), blob.data(), off.data(), 0, g.data(), c.data(), s.data(),
+                                       detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), st.data()),
+        "vrfhip_ietf_verify_batch_alpha");
+  std::vector<Result> r(n);
+  for (size_t i = 0; i < n; ++i) r[i] = result_of(st[i]);
+  return r;
+}
 // n x verify over several contexts (one per GPU): context g verifies items [g*n/G, (g+1)*n/G) on its own host
 // thread; items are independent, so the only merge is the concatenation of the results.
 template <class S>

@@ -254,6 +254,50 @@ impl<S: GpuSuite> GpuBatch<S> {
         Ok(status.into_iter().map(status_to_result).collect())
     }
 
+    /// `Input::new(alpha)` followed by `ietf::Verifier::verify` for every item -- what a verifier that holds public keys,
+    /// messages and proofs runs.  The inputs are hashed to the curve on the GPU and never leave it
+    /// (`vrfhip_ietf_verify_batch_alpha`); one launch group on the first device.
+    pub fn ietf_verify_from_alpha(
+        &self,
+        publics: &[Public<S>],
+        alphas: &[&[u8]],
+        outputs: &[Output<S>],
+        ad: &[u8],
+        proofs: &[ietf::Proof<S>],
+    ) -> Result<Vec<Result<(), Error>>, GpuError> {
+        let n = publics.len();
+        assert!(n == alphas.len() && n == outputs.len() && n == proofs.len());
+        let mut buf = vec![0u8; 4 * n * 32];
+        {
+            let (pk, rest) = buf.split_at_mut(n * 32);
+            let (g, rest) = rest.split_at_mut(n * 32);
+            let (c, s) = rest.split_at_mut(n * 32);
+            for i in 0..n {
+                let r = i * 32..(i + 1) * 32;
+                point32::<S>(&publics[i].0, &mut pk[r.clone()]);
+                point32::<S>(&outputs[i].0, &mut g[r.clone()]);
+                scalar32::<S>(&proofs[i].c, &mut c[r.clone()]);
+                scalar32::<S>(&proofs[i].s, &mut s[r]);
+            }
+        }
+        let mut msg = Vec::new();
+        let mut off = vec![0u32; n + 1];
+        for (i, a) in alphas.iter().enumerate() {
+            msg.extend_from_slice(a);
+            off[i + 1] = msg.len() as u32;
+        }
+        msg.push(0);
+        let mut status = vec![0u8; n];
+        let p = buf.as_ptr();
+        check(unsafe {
+            ffi::vrfhip_ietf_verify_batch_alpha(
+                self.ctxs[0], n, p, msg.as_ptr(), off.as_ptr(), 0, p.add(n * 32), p.add(2 * n * 32), p.add(3 * n * 32),
+                ad.as_ptr(), core::ptr::null(), ad.len() as u32, status.as_mut_ptr(),
+            )
+        })?;
+        Ok(status.into_iter().map(status_to_result).collect())
+    }
+
     /// `pedersen::Prover::prove`: (output, proof, blinding factor) per item, or the item's `Error`.
     pub fn pedersen_prove(
         &self,

@@ -167,6 +167,14 @@ int main(int argc, char** argv) {
     else if (i == 1998) CHECK(res[i] == Error::InvalidData);
     else CHECK(!res[i].has_value());
   }
+  // the same verdicts from (pk, alpha, proof): Input::new inside the call; another message is another H
+  {
+    auto alphas = msgs;
+    alphas[55].push_back(0x21);
+    const auto ares = ietf::verify_batch_from_alpha(ctx, items, alphas, unhex(ad));
+    CHECK(ares.size() == n);
+    for (size_t i = 0; i < n; ++i) CHECK(i == 55 ? ares[i] == Error::VerificationFailure : ares[i] == res[i]);
+  }
   // several contexts from one process (one per GPU; here three on the same device): slices tile the batch
   {
     Context<S> c1(0), c2(0);

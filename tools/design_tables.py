@@ -17,6 +17,9 @@ row("configs[2] **IETF verify 2^20, Bandersnatch, wire format, checked** (headli
 row("… points declared pre-validated", d["prevalidated"], "verifies/s")
 for lg in (19, 18, 17):
     row("… on a 2^%d shard (per-GPU share of a 2^20 batch at N = %d)" % (lg, 1 << (20 - lg)), c["ietf_verify_shard_2^%d" % lg], "verifies/s")
+if "ietf_verify_from_alpha" in c:
+    row("… from (pk, alpha, proof): hash-to-curve inside the call, H kept affine (`vrfhip_ietf_verify_batch_alpha`)", c["ietf_verify_from_alpha"], "verifies/s")
+    row("… … the two-call form (hash_to_curve_batch, verify with the input pre-validated)", c["ietf_verify_from_alpha"]["two_calls"], "verifies/s")
 row("… keyed (`vrfhip_keyset_create`, 1024 resident keys)", c["ietf_verify_keyed"], "verifies/s", ["decode", "straus_v", "comb_u", "finish"])
 row("configs[1] IETF prove 2^16", c["ietf_prove"], "proofs/s", ["prepare", "mul", "finish"])
 rows.append("| … prove 2^20 (produces the headline's inputs) | %.2fe7 proofs/s | %.1f ms | | |" % (d["proofs_per_sec"] / 1e7, (1 << 20) / d["proofs_per_sec"] * 1e3))
@@ -26,9 +29,13 @@ row("… batched (digest + one MSM)", c["pedersen_verify_batched_jubjub"], "veri
 row("f4 IETF prove 2^20, Ed25519", c["ietf_prove_ed25519"], "proofs/s", ["tai_find+prepare", "mul", "finish"])
 row("f4 IETF verify 2^20, Ed25519, checked", c["ietf_verify_ed25519"], "verifies/s", ["decode", "straus_v", "straus_u", "finish"])
 row("… pre-validated", c["ietf_verify_ed25519"]["prevalidated"], "verifies/s")
+if "from_alpha" in c["ietf_verify_ed25519"]:
+    row("… from (pk, alpha, proof), checked", c["ietf_verify_ed25519"]["from_alpha"], "verifies/s")
 row("f4 IETF prove 2^20, Baby-JubJub", c["ietf_prove_babyjubjub"], "proofs/s", ["tai_find+prepare", "mul", "finish"])
 row("f4 IETF verify 2^20, Baby-JubJub, checked", c["ietf_verify_babyjubjub"], "verifies/s", ["decode", "straus_v", "straus_u", "finish"])
 row("… pre-validated", c["ietf_verify_babyjubjub"]["prevalidated"], "verifies/s")
+if "from_alpha" in c["ietf_verify_babyjubjub"]:
+    row("… from (pk, alpha, proof), checked", c["ietf_verify_babyjubjub"]["from_alpha"], "verifies/s")
 row("f4 IETF prove 2^20, secp256r1 (RFC 9381 P256-SHA256-TAI)", c["ietf_prove_secp256r1"], "proofs/s", ["tai_find+prepare", "mul", "finish"])
 row("f4 IETF verify 2^20, secp256r1, Sec1 wire format", c["ietf_verify_secp256r1"], "verifies/s", ["decode", "straus_v", "straus_u", "finish"])
 if "affine_inputs" in c["ietf_verify_secp256r1"]:
@@ -47,6 +54,7 @@ def find(name, grid):
         if v["kernel"] == name and v["grid"] == grid:
             return v
 want = [("vrf::k_verify_decode<vrf::SuiteBS, 2>", 524288, " (checked and pre-validated launches averaged)"), ("vrf::k_verify_straus<vrf::SuiteBS, 1>", 1048576, ""), ("vrf::k_verify_straus<vrf::SuiteBS, 0>", 1048576, ""), ("vrf::k_verify_finish<vrf::SuiteBS, 2>", 524288, ""),
+        ("vrf::k_verify_input_from_alpha<vrf::SuiteBS>", 1048576, " (hash-to-curve + H's tables)"), ("vrf::k_verify_decode_skip_h<vrf::SuiteBS, 2>", 524288, " (pk, Γ)"),
         ("vrf::k_verify_decode_keyed<vrf::SuiteBS, 2>", 524288, ""), ("vrf::k_verify_comb_u<vrf::SuiteBS>", 1048576, ""),
         ("vrf::k_prove_mul<vrf::SuiteBS>", 131072, " (2^16)"), ("vrf::k_prove_prepare_multi<vrf::SuiteBS, 2>", 131072, " (2^20)"), ("vrf::k_prove_mul<vrf::SuiteBS>", 2097152, " (2^20)"),
         ("vrf::k_prove_finish<vrf::SuiteBS, 2>", 131072, " (2^20)"),
