@@ -283,7 +283,9 @@ class Context:
     def ietf_verify_batch_alpha(self, pk, msgs, out, c, s, ad=b"") -> np.ndarray:
         """`Input::new(alpha)` + `ietf::Verifier::verify` in one call (vrfhip_ietf_verify_batch_alpha): msgs is a sequence of
         byte strings or an (n, L) uint8 array; H is hashed to the curve on the device and stays there as affine coordinates."""
-        pk, out, c, s = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (pk, out, c, s))
+        pw = self.point_bytes()
+        pk, out = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, pw) for x in (pk, out))
+        c, s = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (c, s))
         n = pk.shape[0]
         if not all(x.shape[0] == n for x in (out, c, s)):
             raise ValueError("ragged batch")

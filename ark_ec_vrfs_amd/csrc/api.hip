@@ -771,7 +771,6 @@ int32_t vrfhip_ietf_verify_batch_alpha_dev(vrfhip_ctx* ctx, size_t n, const uint
                                            const uint8_t* d_c, const uint8_t* d_s, const uint8_t* d_ad,
                                            const uint32_t* d_ad_off, uint32_t ad_len, uint8_t* d_status, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "verify from alpha: twisted-Edwards suites (secp256r1: vrfhip_hash_to_curve_batch, then verify)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!d_pk || !d_output || !d_c || !d_s || !d_status || (!d_msg && (msg_len || d_msg_off)))
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
@@ -781,6 +780,30 @@ int32_t vrfhip_ietf_verify_batch_alpha_dev(vrfhip_ctx* ctx, size_t n, const uint
   int32_t rc = ensure_workspace(ctx, n);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (ctx->sw) {
+    // secp256r1: the two stages as they are (cofactor 1: there is no subgroup test to skip), H's Sec1 string parked in the
+    // projective-results region, which nothing writes before the decode stage has read it
+    for (size_t base = 0; base < n; base += ctx->ws_cap) {
+      const size_t m = std::min(ctx->ws_cap, n - base);
+      uint8_t* d_henc = reinterpret_cast<uint8_t*>(ctx->p256_ws.pts);
+      BytesView mv = d_msg_off ? make_view(d_msg, d_msg_off + base, msg_len, false)
+                               : make_view(d_msg ? d_msg + base * (size_t)msg_len : d_msg, nullptr, msg_len, false);
+      p256::launch_hash_to_curve(m, mv, d_henc, ctx->T.sq.str, st, ctx->p256_ws.flags, ctx->d_queue);
+      p256::VerifyArgs a;
+      a.n = m;
+      a.pk = d_pk + base * 33; a.h = d_henc; a.gamma = d_output + base * 33;
+      a.affine_in = 0;
+      a.c = d_c + base * 32; a.s = d_s + base * 32;
+      a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
+      a.status = d_status + base;
+      a.ws = ctx->p256_ws;
+      a.comb = ctx->d_p256_comb;
+      a.str = ctx->T.sq.str;
+      p256::launch_verify(a, st, prof_events(ctx));
+    }
+    HIP_TRY(hipGetLastError());
+    return VRFHIP_SUCCESS;
+  }
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     const size_t m = std::min(ctx->ws_cap, n - base);
     uint8_t* d_henc = reinterpret_cast<uint8_t*>(ctx->ws.aux);              // [m][32]: AUX_WORDS * 4 >= 32 bytes per item
@@ -813,24 +836,24 @@ int32_t vrfhip_ietf_verify_batch_alpha(vrfhip_ctx* ctx, size_t n, const uint8_t*
                                        const uint8_t* s, const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
                                        uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "verify from alpha: twisted-Edwards suites (secp256r1: vrfhip_hash_to_curve_batch, then verify)");
   if (n == 0) return VRFHIP_SUCCESS;
   if (!pk || !output || !c || !s || !status || (!msg && (msg_len || msg_off))) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
   const size_t msgb = blob_bytes(n, msg_off, msg_len, false), adb = blob_bytes(n, ad_off, ad_len, true);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  int32_t rc = ensure_stage(ctx, 4 * Stage::pad(n * 32) + Stage::pad(msgb + 1) + Stage::pad(adb + 1) + 2 * Stage::pad((n + 1) * 4) +
-                                     Stage::pad(n));
+  const size_t pw = ctx->pt_bytes();
+  int32_t rc = ensure_stage(ctx, 2 * Stage::pad(n * pw) + 2 * Stage::pad(n * 32) + Stage::pad(msgb + 1) + Stage::pad(adb + 1) +
+                                     2 * Stage::pad((n + 1) * 4) + Stage::pad(n));
   if (rc) return rc;
   Stage sg(ctx->d_stage);
-  uint8_t *d_pk = sg.take(n * 32), *d_g = sg.take(n * 32), *d_c = sg.take(n * 32), *d_s = sg.take(n * 32);
+  uint8_t *d_pk = sg.take(n * pw), *d_g = sg.take(n * pw), *d_c = sg.take(n * 32), *d_s = sg.take(n * 32);
   uint8_t *d_msg = sg.take(msgb + 1), *d_ad = sg.take(adb + 1);
   uint32_t* d_moff = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
   uint32_t* d_aoff = reinterpret_cast<uint32_t*>(sg.take((n + 1) * 4));
   uint8_t* d_st = sg.take(n);
-  HIP_TRY(hipMemcpyAsync(d_pk, pk, n * 32, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(d_g, output, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_pk, pk, n * pw, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_g, output, n * pw, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(d_c, c, n * 32, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(d_s, s, n * 32, hipMemcpyHostToDevice, ctx->stream));
   if (msgb) HIP_TRY(hipMemcpyAsync(d_msg, msg, msgb, hipMemcpyHostToDevice, ctx->stream));
@@ -1703,7 +1726,15 @@ int32_t vrfhip_hash_to_curve_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   if (ctx->sw) {
-    p256::launch_hash_to_curve(n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T.sq.str, static_cast<hipStream_t>(stream));
+    int32_t rc = ensure_workspace(ctx, n);
+    if (rc) return rc;
+    for (size_t base = 0; base < n; base += ctx->ws_cap) {
+      const size_t m = std::min(ctx->ws_cap, n - base);
+      BytesView mv = d_msg_off ? make_view(d_msg, d_msg_off + base, msg_len, false)
+                               : make_view(d_msg ? d_msg + base * (size_t)msg_len : d_msg, nullptr, msg_len, false);
+      p256::launch_hash_to_curve(m, mv, d_points + base * 33, ctx->T.sq.str, static_cast<hipStream_t>(stream), ctx->p256_ws.flags,
+                                 ctx->d_queue);
+    }
   } else if (ctx->suite == VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2) {
     FIELD_CALL(ctx, launch_hash_to_curve((int)ctx->suite, n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T,
                                          static_cast<hipStream_t>(stream)));

@@ -380,7 +380,8 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_ped_verify_finish(p256::Ped
 }
 
 // ------------------------------------------------------------------------------------------------ building blocks
-__global__ void __launch_bounds__(P256_BLOCK) k_p256_hash_to_curve(size_t n, BytesViewLite msg, uint8_t* out, SuiteStr str) {
+__global__ void __launch_bounds__(P256_BLOCK) k_p256_hash_to_curve(size_t n, BytesViewLite msg, uint8_t* out, SuiteStr str,
+                                                                    const uint8_t* tai_ctr) {
   const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint8_t* m;
@@ -388,7 +389,7 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_hash_to_curve(size_t n, Byt
   bytes_lite_get(msg, i, m, len);
   FeN x, y;
   uint32_t xw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool ok = p256_hash_to_curve(x, y, xw, m, len, str);
+  const bool ok = p256_hash_to_curve(x, y, xw, m, len, str, tai_ctr ? tai_ctr[i] : 0u);     // k_p256_tai_find's counter
   sec1_store(out + i * SEC1_LEN, ok ? 2u : 0u, xw);       // 256 failed attempts (2^-256): an all-zero string
 }
 
@@ -496,8 +497,19 @@ void launch_pedersen_verify(const PedVerifyArgs& a, hipStream_t st, hipEvent_t* 
   if (ev) (void)hipEventRecord(ev[4], st);
 }
 
-void launch_hash_to_curve(size_t n, BytesViewLite msg, uint8_t* points33, const SuiteStr& str, hipStream_t st) {
-  hipLaunchKernelGGL(k_p256_hash_to_curve, dim3(blocks_for(n)), dim3(P256_BLOCK), 0, st, n, msg, points33, str);
+// tai_ctr ([n] bytes) + queue: scratch for the work-queue counter search the prover uses; without them every lane loops until
+// its own item succeeds
+void launch_hash_to_curve(size_t n, BytesViewLite msg, uint8_t* points33, const SuiteStr& str, hipStream_t st, uint8_t* tai_ctr,
+                          unsigned long long* queue) {
+  if (!n) return;
+  if (tai_ctr && queue) {
+    (void)hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
+    const size_t waves = std::min<size_t>((n + 63) / 64, 4096);
+    hipLaunchKernelGGL(k_p256_tai_find, dim3((unsigned)waves), dim3(64), 0, st, n, msg, tai_ctr, str, queue);
+  } else {
+    tai_ctr = nullptr;
+  }
+  hipLaunchKernelGGL(k_p256_hash_to_curve, dim3(blocks_for(n)), dim3(P256_BLOCK), 0, st, n, msg, points33, str, tai_ctr);
 }
 void launch_output_hash(size_t n, const uint8_t* gamma33, uint8_t* hash32, const SuiteStr& str, hipStream_t st) {
   hipLaunchKernelGGL(k_p256_output_hash, dim3(blocks_for(n)), dim3(P256_BLOCK), 0, st, n, gamma33, hash32, str);

@@ -89,7 +89,8 @@ void default_blinding_base(uint8_t xy[64]);
 void launch_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev);    // ev: nullptr or 5 events (stage boundaries)
 void launch_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev);      // IETF, or Pedersen when a.pedersen
 void launch_pedersen_verify(const PedVerifyArgs& a, hipStream_t st, hipEvent_t* ev);
-void launch_hash_to_curve(size_t n, BytesViewLite msg, uint8_t* points33, const SuiteStr& str, hipStream_t st);
+void launch_hash_to_curve(size_t n, BytesViewLite msg, uint8_t* points33, const SuiteStr& str, hipStream_t st,
+                          uint8_t* tai_ctr = nullptr, unsigned long long* queue = nullptr);
 void launch_output_hash(size_t n, const uint8_t* gamma33, uint8_t* hash32, const SuiteStr& str, hipStream_t st);
 void launch_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk32, uint8_t* pk33,
                              const uint32_t* comb, hipStream_t st);

@@ -247,7 +247,7 @@ int32_t vrfhip_ietf_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d
  * msg_off / msg_len name the messages as in vrfhip_ietf_prove_batch (n+1 offsets into msg, or msg_off = NULL and msg_len
  * bytes each).  Statuses are those of vrfhip_hash_to_curve_batch followed by vrfhip_ietf_verify_batch; H stays on the device
  * as affine coordinates, so its compression, second square root and subgroup test (a cofactor multiple needs none) are not
- * paid.  Twisted-Edwards suites (secp256r1: VRFHIP_ERR_UNSUPPORTED; use the two calls). */
+ * paid.  (secp256r1: the two stages run as they are inside the one call -- cofactor 1, nothing to skip.) */
 int32_t vrfhip_ietf_verify_batch_alpha(vrfhip_ctx* ctx, size_t n, const uint8_t* pk, const uint8_t* msg,
                                        const uint32_t* msg_off, uint32_t msg_len, const uint8_t* output,
                                        const uint8_t* c, const uint8_t* s, const uint8_t* ad,

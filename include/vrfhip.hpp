@@ -256,11 +256,10 @@ std::vector<Result> verify_batch(const Context<S>& ctx, const std::vector<Item<S
   return r;
 }
 // n x (Input::new(alpha) + verify): what a verifier holding public keys, messages and proofs runs; the inputs are hashed
-// to the curve on the GPU and stay there (items[i].input is not read).  Twisted-Edwards suites.
+// to the curve on the GPU and stay there (items[i].input is not read).
 template <class S>
 std::vector<Result> verify_batch_from_alpha(const Context<S>& ctx, const std::vector<Item<S>>& items,
                                             const std::vector<Bytes>& alphas, const Bytes& ad) {
-  static_assert(S::EDWARDS, "verify_batch_from_alpha: twisted-Edwards suites");
   const size_t n = items.size();
   if (alphas.size() != n) throw std::invalid_argument("verify_batch_from_alpha: ragged batch");
   Bytes pk = detail::column(items, [](const Item<S>& t) -> const auto& { return t.pub.encoded; });

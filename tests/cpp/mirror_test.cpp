@@ -88,6 +88,12 @@ static int p256_section(char** a) {
     else if (i == 77) CHECK(res[i] == Error::InvalidData);
     else CHECK(!res[i].has_value());
   }
+  {
+    auto alphas = msgs;
+    alphas[9][0] ^= 1;
+    const auto ares = ietf::verify_batch_from_alpha(ctx, items, alphas, Bytes{7, 7});
+    for (size_t i = 0; i < n; ++i) CHECK(i == 9 ? ares[i] == Error::VerificationFailure : ares[i] == res[i]);
+  }
   std::vector<pedersen::Item<P>> pitems;
   for (size_t i = 0; i < 40; ++i) {
     const auto in_i = Input<P>::new_(ctx, msgs[i]);

@@ -2,7 +2,7 @@
 as one call, `vrfhip_ietf_verify_batch_alpha`: H is hashed to the curve on the device and is never compressed, decompressed
 or subgroup-tested.  GPU tier: statuses equal (a) the C oracle's verify on the oracle's own H and (b) the library's two-call
 form (hash_to_curve_batch, then ietf_verify_batch), on every twisted-Edwards suite, with every kind of defect including a
-wrong message; ragged messages with per-item ad; launch groups of several sizes; the refusal on secp256r1."""
+wrong message; ragged messages with per-item ad; launch groups of several sizes; secp256r1 (the two stages inside one call)."""
 import os
 
 import numpy as np
@@ -68,7 +68,7 @@ def test_gpu_verify_from_alpha_equals_oracle_and_two_call_form(name):
 
 
 @pytest.mark.gpu
-def test_gpu_verify_from_alpha_on_device_pointers_and_refusal():
+def test_gpu_verify_from_alpha_on_device_pointers():
     import torch
     import ark_ec_vrfs_amd as pkg
     ctx = pkg.Context(0)
@@ -98,8 +98,35 @@ def test_gpu_verify_from_alpha_on_device_pointers_and_refusal():
     torch.cuda.synchronize()
     assert bool((st == st2).all()) and int((st == 1).sum()) == len(range(0, n, 997)) + len(range(5, n, 1009))
     ctx.close()
-    p = pkg.Context(0, pkg.Secp256r1Sha256Tai)
-    with pytest.raises(Exception):
-        p.ietf_verify_batch_alpha(np.zeros((2, 32), np.uint8), [b"a", b"b"], np.zeros((2, 32), np.uint8), np.zeros((2, 32), np.uint8),
-                                  np.zeros((2, 32), np.uint8))
-    p.close()
+
+
+@pytest.mark.gpu
+def test_gpu_verify_from_alpha_secp256r1_equals_the_oracle():
+    """secp256r1 (cofactor 1: nothing to skip): hash-to-curve and verify inside the one call; statuses equal the C oracle's
+    on its own H, and hash_to_curve_batch (now through the work-queue counter search) equals the oracle's H."""
+    import ark_ec_vrfs_amd as pkg
+    ctx = pkg.Context(0, pkg.Secp256r1Sha256Tai)
+    rng = np.random.default_rng(256)
+    n = 2500
+    seeds = np.arange(n, dtype=np.uint64).view(np.uint8).reshape(n, 8)
+    sk, _ = ctx.secret_from_seed_batch(seeds)
+    msg = rng.integers(0, 256, (n, 37), dtype=np.uint8)
+    ref = co.p256_ietf_prove_batch(sk, msgs=msg, ad=b"p", threads=NCPU)
+    assert (ctx.hash_to_curve_batch(msg) == ref["input"]).all()
+    assert (ctx.ietf_verify_batch_alpha(ref["pk"], msg, ref["output"], ref["c"], ref["s"], ad=b"p") == 0).all()
+    pk, out, c, s, m2 = (x.copy() for x in (ref["pk"], ref["output"], ref["c"], ref["s"], msg))
+    m2[::11, 3] ^= 1
+    s[3::13, 30] ^= 2
+    c[5::17, 31] ^= 1
+    s[7::101] = 0xFF
+    pk[2::23, 0] = 5
+    out[4::29, 9] ^= 4
+    h2 = ctx.hash_to_curve_batch(m2)
+    assert (h2[1::11] == ref["input"][1::11]).all()
+    want = co.p256_ietf_verify_batch(pk, h2, out, c, s, ad=b"p", threads=NCPU)
+    got = ctx.ietf_verify_batch_alpha(pk, m2, out, c, s, ad=b"p")
+    assert (got == want).all() and set(np.unique(want)) == {0, 1, 2}
+    msgs = [bytes(rng.integers(0, 256, int(rng.integers(0, 70)), dtype=np.uint8)) for _ in range(130)]
+    pr = ctx.ietf_prove_batch(sk[:130], msgs=msgs, ad=b"")
+    assert (ctx.ietf_verify_batch_alpha(pr["pk"], msgs, pr["output"], pr["c"], pr["s"]) == 0).all()
+    ctx.close()

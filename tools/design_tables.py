@@ -38,6 +38,8 @@ if "from_alpha" in c["ietf_verify_babyjubjub"]:
     row("… from (pk, alpha, proof), checked", c["ietf_verify_babyjubjub"]["from_alpha"], "verifies/s")
 row("f4 IETF prove 2^20, secp256r1 (RFC 9381 P256-SHA256-TAI)", c["ietf_prove_secp256r1"], "proofs/s", ["tai_find+prepare", "mul", "finish"])
 row("f4 IETF verify 2^20, secp256r1, Sec1 wire format", c["ietf_verify_secp256r1"], "verifies/s", ["decode", "straus_v", "straus_u", "finish"])
+if "from_alpha" in c["ietf_verify_secp256r1"]:
+    row("… from (pk, alpha, proof)", c["ietf_verify_secp256r1"]["from_alpha"], "verifies/s")
 if "affine_inputs" in c["ietf_verify_secp256r1"]:
     row("… pk, input, output as x ‖ y (typed callers)", c["ietf_verify_secp256r1"]["affine_inputs"], "verifies/s")
 row("… Pedersen prove 2^20, secp256r1 (unpinned; built-in blinding base)", c["pedersen_prove_secp256r1"], "proofs/s", ["tai_find+prepare", "mul", "finish"])
