@@ -537,6 +537,41 @@ impl GpuBatchSec1 {
         })?;
         Ok(status.into_iter().map(status_to_result).collect())
     }
+
+    /// `Input::new(alpha)` followed by `ietf::Verifier::verify` for every item (`vrfhip_ietf_verify_batch_alpha`): the
+    /// inputs are hashed to the curve on the GPU; one launch group on the first device.
+    pub fn ietf_verify_from_alpha(
+        &self,
+        publics: &[Public<P256>],
+        alphas: &[&[u8]],
+        outputs: &[Output<P256>],
+        ad: &[u8],
+        proofs: &[ietf::Proof<P256>],
+    ) -> Result<Vec<Result<(), Error>>, GpuError> {
+        let n = publics.len();
+        assert!(n == alphas.len() && n == outputs.len() && n == proofs.len());
+        let (mut pk, mut g) = (vec![0u8; n * SEC1], vec![0u8; n * SEC1]);
+        let (mut c, mut s) = (vec![0u8; n * 32], vec![0u8; n * 32]);
+        let mut msg = Vec::new();
+        let mut off = vec![0u32; n + 1];
+        for i in 0..n {
+            Self::put_point(&publics[i].0, &mut pk[i * SEC1..(i + 1) * SEC1]);
+            Self::put_point(&outputs[i].0, &mut g[i * SEC1..(i + 1) * SEC1]);
+            Self::put_scalar(&proofs[i].c, &mut c[i * 32..(i + 1) * 32]);
+            Self::put_scalar(&proofs[i].s, &mut s[i * 32..(i + 1) * 32]);
+            msg.extend_from_slice(alphas[i]);
+            off[i + 1] = msg.len() as u32;
+        }
+        msg.push(0);
+        let mut status = vec![0u8; n];
+        check(unsafe {
+            ffi::vrfhip_ietf_verify_batch_alpha(
+                self.ctxs[0], n, pk.as_ptr(), msg.as_ptr(), off.as_ptr(), 0, g.as_ptr(), c.as_ptr(), s.as_ptr(), ad.as_ptr(),
+                core::ptr::null(), ad.len() as u32, status.as_mut_ptr(),
+            )
+        })?;
+        Ok(status.into_iter().map(status_to_result).collect())
+    }
 }
 
 impl GpuBatchSec1 {
