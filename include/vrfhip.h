@@ -73,7 +73,7 @@ typedef enum vrfhip_suite {
    * 16 significant bytes), `Output::hash` is 32 bytes (vrfhip_ctx_point_bytes / vrfhip_ctx_hash_bytes tell).  As in the
    * other suites a secret key and the proof's `s` must be canonical (< n, else InvalidData: RFC 9381 5.4.4) while `c` is taken
    * mod n; a point needs tag 0x02 / 0x03, x < p and to lie on the curve (cofactor 1: no subgroup test).  Entry points:
-   * vrfhip_ietf_prove_batch / _verify_batch (+ _dev, _multi), vrfhip_hash_to_curve_batch, vrfhip_output_hash_batch,
+   * vrfhip_ietf_prove_batch / _verify_batch (+ _dev, _multi), vrfhip_ietf_verify_batch_alpha, vrfhip_hash_to_curve_batch, vrfhip_output_hash_batch,
    * vrfhip_secret_from_seed_batch, vrfhip_point_validate_batch (+ _dev), and the Pedersen scheme per proof:
    * vrfhip_pedersen_prove_batch / vrfhip_pedersen_verify_batch (+ _dev, _multi) when the descriptor carries a blinding base
    * (the built-in one is a nothing-up-my-sleeve point: upstream's `BLINDING_BASE` for this suite is not known here; a
