@@ -94,6 +94,72 @@ def slim_results(res):
     return {k: ({"error": v["error"]} if "error" in v else {"value": v["value"], "ms_per_step": v["ms_per_step"]})
             for k, v in res.items()}
 
+FINAL_LINE_MAX = 4096             # the driver keeps an 8 KB stdout tail: the last line must fit it whole, with margin
+
+
+def _round_floats(x, sig=6):
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    if isinstance(x, dict):
+        return {k: _round_floats(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round_floats(v, sig) for v in x]
+    return x
+
+
+def assemble_final_line(out, configs_file=None):
+    """The ONE line the driver parses: headline metric + roofline + valu + cpu_baseline, <= FINAL_LINE_MAX bytes whatever
+    the number of secondary legs.  `out` is the full record (with "configs"); the legs themselves go to an earlier stdout
+    line and to `configs_file`.  Pure: no I/O, so tests/test_bench_launch.py can size-check it on CPU."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "scaling_modes",
+            "vs_baseline", "dtype", "data", "config", "roofline", "valu", "stage_ms_per_step", "proofs_per_sec", "cpu_baseline")
+    line = {k: out[k] for k in keep if k in out}
+    if "prevalidated" in out:
+        line["prevalidated"] = {k: out["prevalidated"][k] for k in ("value", "ms_per_step") if k in out["prevalidated"]}
+    if line.get("cpu_baseline"):
+        cb = dict(line["cpu_baseline"])
+        for k in ("sample", "note"):
+            if k in cb and len(cb[k]) > 160:
+                cb[k] = cb[k][:157] + "..."
+        line["cpu_baseline"] = cb
+    line["configs_file"] = configs_file
+    line = _round_floats(line)
+    if line.get("roofline") and line["roofline"].get("peak"):          # frac stays exactly achieved / peak after rounding
+        line["roofline"]["frac"] = line["roofline"]["achieved"] / line["roofline"]["peak"]
+    cfgs = out.get("configs") or {}
+    # one number per secondary leg, as many as fit (full records: configs_file and the earlier stdout line)
+    summary = {}
+    for k, v in cfgs.items():
+        summary[k] = "error" if "error" in v else [float("%.4g" % v["value"]), float("%.4g" % v["ms_per_step"])]
+    line["configs_summary"] = summary
+    while summary and len(json.dumps(line)) > FINAL_LINE_MAX:
+        summary.pop(next(reversed(summary)))
+    if cfgs and len(summary) < len(cfgs):
+        line["configs_summary_truncated"] = len(cfgs) - len(summary)
+    if len(json.dumps(line)) > FINAL_LINE_MAX:      # cannot happen with the fields above; never print an unparseable tail
+        for k in ("configs_summary", "prevalidated", "stage_ms_per_step", "scaling_modes"):
+            line.pop(k, None)
+            if len(json.dumps(line)) <= FINAL_LINE_MAX:
+                break
+    return line
+
+
+def print_result(out, configs, world):
+    """Secondary legs: full records on an EARLIER stdout line and in a file; the LAST line is the headline alone and stays
+    under FINAL_LINE_MAX bytes (a 25 KB line overflowed the driver's stdout tail)."""
+    configs_file = None
+    if configs:
+        configs_file = os.environ.get("VRFHIP_BENCH_CONFIGS_FILE") or os.path.join(ROOT, "bench_configs_n%d.json" % world)
+        try:
+            with open(configs_file, "w") as f:
+                json.dump({"headline": {k: v for k, v in out.items() if k != "configs"}, "configs": configs}, f, indent=1)
+            if configs_file.startswith(ROOT + os.sep):
+                configs_file = os.path.relpath(configs_file, ROOT)
+        except OSError as e:
+            configs_file = "not written: %r" % (e,)
+        print(json.dumps({"bench_configs": configs}), flush=True)
+    print(json.dumps(assemble_final_line(out, configs_file)), flush=True)
+
 
 def merge_rank_results(own, allr):
     """own: this rank's full results of a leg; allr: slim_results of every rank.  A config's rate is set by its slowest
@@ -739,8 +805,10 @@ def cfg_pairing(D, args, ctx, want_cpu):
         leg = cpu_leg(leg_c, 4 * cpu_cores(), args.cpu_seconds, k, "checks/s", "verdicts equal the GPU's")
         leg["note"] = ("CPU restatement in C (oracle/c/oracle_bls.c: 6 x 64-bit Montgomery limbs, Karatsuba tower, plain "
                        "square-and-multiply final exponentiation), not arkworks: no Rust toolchain on this box")
+        res["pairing_check"]["cpu_baseline"] = leg          # one record; the other pairing legs point at it
         for k in res:
-            res[k]["cpu_baseline"] = leg
+            if k != "pairing_check":
+                res[k]["cpu_baseline_ref"] = "pairing_check"
     return res
 
 
@@ -908,7 +976,7 @@ def run_rank(args):
             out["cpu_baseline"] = headline_cpu_baseline(args, pk, hh, gamma, c, s, status)
         if configs:
             out["configs"] = configs
-        print(json.dumps(out), flush=True)
+        print_result(out, configs, world)
     D.close()
     ctx.close()
 

@@ -91,3 +91,67 @@ def test_secondary_leg_results_merge_across_ranks():
     assert m["a"] == {"value": 8.0, "ms_per_step": 1.25, "unit": "x/s"}
     assert m["b"] == {"error": "boom"} and "error" in m["c"] and m["d"] == {"error": "leg failed early"}
     assert b.merge_rank_results(r0, [b.slim_results(r0)] * 3)["b"]["value"] == 5.0
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_final_line_stays_under_4_kb_with_every_leg_present():
+    """round 3's 25.7 KB line overflowed the driver's 8 KB stdout tail and the headline went unparsed.
+    assemble_final_line must bring ANY full record (here: round 3's, 30 legs with cpu_baseline notes, and a doubled copy of
+    it) under 4096 bytes with the headline's roofline, valu and cpu_baseline intact."""
+    b = _load_bench()
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r03", "bench_n1_default.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000 and len(full["configs"]) >= 20
+    fat = dict(full, configs=dict(full["configs"], **{k + "_again": v for k, v in full["configs"].items()}))
+    fat["cpu_baseline"] = dict(full["cpu_baseline"], note=full["cpu_baseline"]["note"] * 8)
+    for rec in (full, fat):
+        line = b.assemble_final_line(rec, "bench_configs_n1.json")
+        text = json.dumps(line)
+        assert len(text) <= b.FINAL_LINE_MAX == 4096, len(text)
+        back = json.loads(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "scaling_modes", "vs_baseline", "dtype", "data", "config", "roofline", "valu", "stage_ms_per_step",
+                  "cpu_baseline", "configs_file"):
+            assert k in back, k
+        assert "configs" not in back
+        assert abs(back["roofline"]["frac"] / full["roofline"]["frac"] - 1) < 1e-5
+        assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-12
+        assert abs(back["cpu_baseline"]["value"] / full["cpu_baseline"]["value"] - 1) < 1e-5
+        assert abs(back["value"] / full["value"] - 1) < 1e-5 and back["config"]["workload"] == full["config"]["workload"]
+    # with round 3's real leg count every leg also has its one-number summary in the line
+    line = b.assemble_final_line(full, "x")
+    assert set(line["configs_summary"]) == set(full["configs"]) and "configs_summary_truncated" not in line
+
+
+def test_last_stdout_line_of_a_run_is_the_short_headline(tmp_path):
+    """What the driver does: take the LAST stdout line and parse it.  run_rank's printing, replayed on a recorded full
+    record (no GPU here): the legs go out on an earlier line and into the configs file, the last line parses and carries
+    roofline.frac and cpu_baseline.value."""
+    code = (
+        "import json, sys, os\n"
+        "sys.argv = ['bench.py']\n"
+        "import importlib.util\n"
+        "spec = importlib.util.spec_from_file_location('bench_mod', %r)\n"
+        "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "full = json.loads(open(%r).read().strip().splitlines()[-1])\n"
+        "b.print_result(full, full.get('configs'), 1)\n"
+    ) % (os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "profiles", "r03", "bench_n1_default.json"))
+    cf = str(tmp_path / "cfg.json")
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VRFHIP_BENCH_CONFIGS_FILE=cf),
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 2 and len(lines[-1]) <= 4096 and "bench_configs" in json.loads(lines[0])
+    d = json.loads(lines[-1])
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    saved = json.load(open(cf))
+    assert saved["configs"]["pairing_check"]["value"] > 0 and saved["headline"]["value"] == json.loads(
+        open(os.path.join(ROOT, "profiles", "r03", "bench_n1_default.json")).read().strip().splitlines()[-1])["value"]
+    # the driver's 8 KB tail always contains the whole last line
+    assert len(lines[-1].encode()) + 1 < 8192

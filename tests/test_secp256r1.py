@@ -464,7 +464,26 @@ def test_gpu_batch_round_trip_across_launch_groups(gpu):
         rm = ietf_prove_batch_multi([gpu, other], sk[:m], [x.tobytes() for x in msg[:m]], ad=b"batch")
         assert all((rm[k] == r[k][:m]).all() for k in ("output", "c", "s", "pk", "input"))
         stm = ietf_verify_batch_multi([gpu, other], rm["pk"], rm["input"], rm["output"], rm["c"], s2[:m], ad=b"batch")
-        assert (stm == st[:m]).all() if False else (stm[::3] == 1).all()
+        assert (stm == st[:m]).all() and (stm[::3] == 1).all() and (np.delete(stm, np.s_[::3]) == 0).all()
+        # the Pedersen scheme through two contexts: proof bytes equal the single context's, and a mixed batch (tampered s,
+        # tampered sb, an undecodable R, another item's Ok) gets the single context's statuses item for item
+        from ark_ec_vrfs_amd import pedersen_prove_batch_multi, pedersen_verify_batch_multi
+        msgs_m = [x.tobytes() for x in msg[:m]]
+        p1 = gpu.pedersen_prove_batch(sk[:m], msgs=msg[:m], ad=b"batch")
+        pm = pedersen_prove_batch_multi([gpu, other], sk[:m], msgs_m, ad=b"batch")
+        names = ("output", "pk_com", "r", "ok", "s", "sb", "input")
+        assert all((pm[k] == p1[k]).all() for k in names)
+        bad = {k: pm[k].copy() for k in names}
+        bad["s"][::5, 9] ^= 0x10
+        bad["sb"][1::5, 30] ^= 0x01
+        bad["r"][2::7, 0] = 0x05                      # not a Sec1 tag: InvalidData
+        bad["ok"][3::11] = np.roll(pm["ok"], 1, axis=0)[3::11]
+        args = [bad[k] for k in ("input", "output", "pk_com", "r", "ok", "s", "sb")]
+        st1 = gpu.pedersen_verify_batch(*args, ad=b"batch")
+        stp = pedersen_verify_batch_multi([gpu, other], *args, ad=b"batch")
+        assert (stp == st1).all() and (st1[::5] != 0).all() and (st1[2::7] == 2).all()
+        clean = np.ones(m, bool); clean[::5] = clean[1::5] = clean[2::7] = clean[3::11] = False
+        assert (st1[clean] == 0).all() and clean.sum() > m // 3
     finally:
         other.close()
         gpu.reserve(1 << 20)
