@@ -234,6 +234,23 @@ class Context:
     def get_flags(self) -> int:
         return int(self._lib.vrfhip_ctx_get_flags(self._h))
 
+    # test / tuning knobs (vrfhip_debug_set): the library never reads the environment
+    PAIRING_LAYOUTS = {"auto": 0, "lane": 1, "quad": 2, "row": 3, "tri": 4, "oct": 5, "noprep": 0x100}
+
+    def debug_set(self, key: int, value: int) -> None:
+        _lib.check(self._lib.vrfhip_debug_set(self._h, int(key), int(value)), "vrfhip_debug_set")
+
+    def debug_pairing_layout(self, *names: str) -> None:
+        """Force a pairing-check layout (tests): any of PAIRING_LAYOUTS, OR-ed; no name = back to the default."""
+        v = 0
+        for nm in names:
+            v |= self.PAIRING_LAYOUTS[nm]
+        self.debug_set(1, v)
+
+    def debug_pipeline(self, first_log2: int = 17, chunk_log2: int = 18) -> None:
+        self.debug_set(2, first_log2)
+        self.debug_set(3, chunk_log2)
+
     def set_prevalidated(self, on: bool = True) -> None:
         """All points declared validated by the caller (on) / everything checked as arkworks' deserialisation does (off)."""
         self.set_flags(self.PREVALIDATED_ALL if on else 0)

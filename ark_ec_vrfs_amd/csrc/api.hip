@@ -100,6 +100,9 @@ struct vrfhip_ctx {
   uint32_t* d_pair_prep = nullptr;         // Miller-loop lines of shared G2 points (pairing check, SRS case)
   int cus = 256;
   uint32_t flags = 0;                      // VRFHIP_FLAG_PREVALIDATED_* (vrfhip_ctx_set_flags)
+  // test / tuning knobs (vrfhip_debug_set; nothing in the product reads the environment)
+  int dbg_pairing_layout = 0;              // kernels.h PAIRING_*: 0 = by batch size
+  int pipe_first_log2 = 17, pipe_chunk_log2 = 18;   // host-pointer pipeline: first chunk, later chunks (items, log2)
   uint32_t check_mask() const { return ~flags & (uint32_t)VRFHIP_FLAG_PREVALIDATED_ALL; }
   // secp256r1 (`suites::secp256r1`): short-Weierstrass law, Sec1 wire format (33-byte points, big-endian scalars), SHA-256.
   // Its kernels (k_p256.hip) have their own tables and workspace; the entry points below branch on `sw` where the
@@ -311,7 +314,7 @@ size_t blob_bytes(size_t n, const uint32_t* off, uint32_t len, bool shared) {
 
 extern "C" {
 
-int32_t vrfhip_abi_version(void) { return 142; }
+int32_t vrfhip_abi_version(void) { return 143; }
 
 const char* vrfhip_last_error(void) { return g_last_error.c_str(); }
 
@@ -601,6 +604,24 @@ size_t vrfhip_ctx_hash_bytes(const vrfhip_ctx* ctx) { return ctx ? ctx->hash_byt
 
 int32_t vrfhip_debug_proofs_per_lane(size_t n) { return lanes_k(n, VERIFY_K_POLICY); }
 
+int32_t vrfhip_debug_set(vrfhip_ctx* ctx, int32_t key, int32_t value) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  switch (key) {
+    case VRFHIP_DEBUG_PAIRING_LAYOUT:
+      if ((value & 0xff) > PAIRING_OCT || (value & ~0x1ff)) return fail(VRFHIP_ERR_BAD_ARG, "unknown pairing layout");
+      ctx->dbg_pairing_layout = value;
+      return VRFHIP_SUCCESS;
+    case VRFHIP_DEBUG_PIPE_FIRST_LOG2:
+    case VRFHIP_DEBUG_PIPE_CHUNK_LOG2:
+      if (value < 12 || value > 18) return fail(VRFHIP_ERR_BAD_ARG, "pipeline chunk log2 must lie in 12..18");
+      (key == VRFHIP_DEBUG_PIPE_FIRST_LOG2 ? ctx->pipe_first_log2 : ctx->pipe_chunk_log2) = value;
+      return VRFHIP_SUCCESS;
+    default:
+      return fail(VRFHIP_ERR_BAD_ARG, "unknown debug key");
+  }
+}
+
 int32_t vrfhip_ctx_profile(vrfhip_ctx* ctx, int32_t enable) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -734,10 +755,8 @@ int32_t verify_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* 
     rc = pipe_prepare(ctx, std::max<size_t>(slot_bytes, 256));
     if (rc) return rc;
     int slot = 0;
-    // the first chunk's copy is the only one nothing hides: it is a smaller chunk (tuning hooks: VRFHIP_PIPE_FIRST_LOG2,
-    // VRFHIP_PIPE_CHUNK_LOG2 <= 18)
-    static const size_t first_chunk = [] { const char* e = getenv("VRFHIP_PIPE_FIRST_LOG2"); int v = e ? atoi(e) : 17; return size_t(1) << std::min(std::max(v, 12), 18); }();
-    static const size_t chunk = [] { const char* e = getenv("VRFHIP_PIPE_CHUNK_LOG2"); int v = e ? atoi(e) : 18; return size_t(1) << std::min(std::max(v, 12), 18); }();
+    // the first chunk's copy is the only one nothing hides: it is a smaller chunk (tuning: vrfhip_debug_set keys 2, 3)
+    const size_t first_chunk = size_t(1) << ctx->pipe_first_log2, chunk = size_t(1) << ctx->pipe_chunk_log2;
     for (size_t base = 0, m = 0; base < n; base += m, slot ^= 1) {
       m = std::min(base == 0 ? first_chunk : chunk, n - base);
       rc = pipe_send(ctx, arrs, pinned, 5, base, m, slot);
@@ -1546,7 +1565,7 @@ int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   launch_pairing_check2(n, d_g1, d_g2, g2_shared ? 0 : 384, d_status, static_cast<hipStream_t>(stream),
-                        g2_shared ? ctx->d_pair_prep : nullptr);
+                        g2_shared ? ctx->d_pair_prep : nullptr, ctx->dbg_pairing_layout);
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
 }
@@ -1653,7 +1672,7 @@ int32_t vrfhip_pairing_check_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint
   launch_batch_digest(ds, n, 0, d_digest_ws, d_root, st);   // the weights depend on every byte of the batch
   launch_g1_rlc(L, d_g1, seed, d_root, 0, d_status, st, ev ? ev + 1 : nullptr);
   // one pairing check for the whole batch: (sum z A, sum z B) against the shared pair (prepared lines)
-  launch_pairing_check2(1, L.sums, d_g2_shared, 0, d_verdict, st, ctx->d_pair_prep);
+  launch_pairing_check2(1, L.sums, d_g2_shared, 0, d_verdict, st, ctx->d_pair_prep, ctx->dbg_pairing_layout);
   if (ev) (void)hipEventRecord(ev[4], st);
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
@@ -1686,7 +1705,7 @@ int32_t vrfhip_pairing_check_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t*
   if (verdict != 0) {
     // some item is false (or the shared pair is invalid): the per-item kernel names it
     if (batch_ok) *batch_ok = 0;
-    launch_pairing_check2(n, d_g1, d_g2, 0, d_st, ctx->stream, ctx->d_pair_prep);
+    launch_pairing_check2(n, d_g1, d_g2, 0, d_st, ctx->stream, ctx->d_pair_prep, ctx->dbg_pairing_layout);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1710,6 +1729,27 @@ int32_t vrfhip_test_pairing_quad_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* f
   HIP_TRY(hipMemcpyAsync(d_in, fp12_pairs, n * 1152, hipMemcpyHostToDevice, ctx->stream));
   launch_pairing_quad_selftest(n, d_in, d_st, ctx->stream);
   launch_pairing_row_selftest(n, d_in, d_st, ctx->stream);        // bits 64 / 128: the row-distributed tower
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return VRFHIP_SUCCESS;
+}
+
+// Test-only: the 8-lanes-per-item Fp12 tower (bls12_oct.cuh) and its cross-lane moves against the one-lane operations
+int32_t vrfhip_test_pairing_oct_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp12_pairs, uint8_t* status) {
+  if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
+  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (n == 0) return VRFHIP_SUCCESS;
+  if (!fp12_pairs || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+  DeviceGuard guard(ctx->device);
+  int32_t rc = ensure_stage(ctx, Stage::pad(n * 1152) + Stage::pad(n));
+  if (rc) return rc;
+  Stage sg(ctx->d_stage);
+  uint8_t* d_in = sg.take(n * 1152);
+  uint8_t* d_st = sg.take(n);
+  HIP_TRY(hipMemcpyAsync(d_in, fp12_pairs, n * 1152, hipMemcpyHostToDevice, ctx->stream));
+  launch_pairing_oct_selftest(n, d_in, d_st, ctx->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(status, d_st, n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -3,12 +3,11 @@
 // (/root/reference src/lib.rs:14 `ring`).
 //   k_pairing_check2_quad (k_pairing_quad.hip): one item per DPP quad, tower arithmetic in registers -- the
 //                           path vrfhip_pairing_check_batch runs.
-//   k_pairing_check2      : one item per lane (bls12.cuh); kept as the cross-check of the quad arithmetic
-//                           and selectable with VRFHIP_PAIRING=lane.
+//   k_pairing_check2_oct  (k_pairing_oct.hip): one item per 8 lanes, Fp2 split over lane pairs -- the throughput path.
+//   k_pairing_check2      : one item per lane (bls12.cuh); kept as the cross-check of the distributed arithmetic
+//                           (layout PAIRING_LANE, reachable through vrfhip_debug_set only).
 #include "kernels.h"
 #include "bls12.cuh"
-#include <cstdlib>
-#include <cstring>
 
 namespace vrf {
 
@@ -50,27 +49,35 @@ size_t pairing_prep_bytes() { return (size_t)(bls::G2_PREP_WORDS + 96 + 1) * siz
 void launch_pairing_check2_quad(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status,
                                 hipStream_t st);
 void launch_pairing_check2_quad_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st);
-void launch_pairing_check2_row_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st);
-// Up to this many checks against a prepared pair run one item per 16-lane ROW (three quads share the tower: half the
-// latency, 4/3 the lanes and some exchange traffic); beyond it throughput matters and a quad per item is better.
-constexpr size_t PAIRING_ROW_MAX_ITEMS = 4096;   // measured: rows 5.8-6.1 ms up to 2^12 items, 12 ms at 2^13; quads 9.5 ms throughout
+void launch_pairing_check2_row_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st, int tri);
+void launch_pairing_check2_oct(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status, hipStream_t st);
+void launch_pairing_check2_oct_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st);
+// Up to this many checks against a prepared pair run one item per 16-lane ROW or per WAVE (latency: half the chain of a
+// quad, more lanes per item); beyond it throughput matters and the 8-lane layout (k_pairing_oct.hip) takes over.
+constexpr size_t PAIRING_ROW_MAX_ITEMS = 4096;   // measured (round 3): rows 5.8-6.1 ms up to 2^12 items, 12 ms at 2^13
+// Unprepared (per-item G2 points): quads below this many items (one wave per SIMD has the shorter chain), 8 lanes per
+// item from here on (two waves per SIMD resident).
+constexpr size_t PAIRING_OCT_MIN_ITEMS = 2048;
 
 void launch_pairing_check2(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status,
-                           hipStream_t st, uint32_t* prep) {
+                           hipStream_t st, uint32_t* prep, int layout) {
   if (!n) return;
-  const char* mode = getenv("VRFHIP_PAIRING");
-  if (mode && !strcmp(mode, "lane")) {
+  const int mode = layout & 0xff;
+  if (mode == PAIRING_LANE) {
     hipLaunchKernelGGL(k_pairing_check2, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, g1, g2, g2_stride, status);
     return;
   }
-  if (g2_stride == 0 && prep && !(mode && !strcmp(mode, "noprep"))) {
+  if (g2_stride == 0 && prep && !(layout & PAIRING_NOPREP)) {
     hipLaunchKernelGGL(k_pairing_prepare_g2, dim3(1), dim3(64), 0, st, g2, prep);
-    const bool force_row = mode && !strcmp(mode, "row");
-    if ((n <= PAIRING_ROW_MAX_ITEMS && !(mode && !strcmp(mode, "quad"))) || force_row) launch_pairing_check2_row_prepared(n, g1, prep, status, st);
-    else launch_pairing_check2_quad_prepared(n, g1, prep, status, st);
+    if (mode == PAIRING_ROW || mode == PAIRING_TRI) launch_pairing_check2_row_prepared(n, g1, prep, status, st, mode == PAIRING_TRI);
+    else if (mode == PAIRING_QUAD) launch_pairing_check2_quad_prepared(n, g1, prep, status, st);
+    else if (mode == PAIRING_OCT) launch_pairing_check2_oct_prepared(n, g1, prep, status, st);
+    else if (n <= PAIRING_ROW_MAX_ITEMS) launch_pairing_check2_row_prepared(n, g1, prep, status, st, -1);
+    else launch_pairing_check2_oct_prepared(n, g1, prep, status, st);
     return;
   }
-  launch_pairing_check2_quad(n, g1, g2, g2_stride, status, st);
+  if (mode == PAIRING_QUAD || (mode != PAIRING_OCT && n < PAIRING_OCT_MIN_ITEMS)) launch_pairing_check2_quad(n, g1, g2, g2_stride, status, st);
+  else launch_pairing_check2_oct(n, g1, g2, g2_stride, status, st);
 }
 
 }  // namespace vrf

@@ -2,8 +2,6 @@
 // form of k_pairing_check2_quad_prepared for the handful of checks that decide a batch (vrfhip_pairing_check_batch_rlc).
 // SURVEY.md section 8 rows a11 / f3, `ring::Verifier::verify` tail (/root/reference src/lib.rs:14 `ring`).
 #include "kernels.h"
-#include <cstdlib>
-#include <cstring>
 #include "bls12.cuh"
 #include "bls12_row.cuh"
 
@@ -79,10 +77,10 @@ __global__ void __launch_bounds__(ROW_BLOCK) k_pairing_row_selftest(size_t n, co
 
 // Up to this many checks run one item per WAVE (three rows: Fp2 products split over the rows too); then one item per row.
 constexpr size_t PAIRING_TRI_MAX_ITEMS = 1024;   // measured: 4.1-4.3 ms up to 1024 items (one wave each), 8.6 ms at 2048; rows 5.3 ms
-void launch_pairing_check2_row_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st) {
+// want_tri: 1 one item per wave, 0 one item per row, -1 by batch size
+void launch_pairing_check2_row_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st, int want_tri) {
   if (!n) return;
-  const char* mode = getenv("VRFHIP_PAIRING_ROW");
-  const bool tri = mode ? !strcmp(mode, "tri") : n <= PAIRING_TRI_MAX_ITEMS;
+  const bool tri = want_tri >= 0 ? want_tri != 0 : n <= PAIRING_TRI_MAX_ITEMS;
   if (tri) {
     hipLaunchKernelGGL(k_pairing_check2_row_prepared<true>, dim3((unsigned)n), dim3(ROW_BLOCK), 0, st, n, g1, prep, status);
     return;

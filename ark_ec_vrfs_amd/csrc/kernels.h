@@ -10,9 +10,14 @@ namespace vrf {
 // g2_stride == 0: every item uses the same two G2 points; prep (pairing_prep_bytes() of device memory, nullable)
 // then receives their Miller-loop lines, computed once
 size_t pairing_prep_bytes();
+// layout: 0 = chosen by batch size; otherwise a test asks for one (vrfhip_debug_set, VRFHIP_DEBUG_PAIRING_LAYOUT):
+// 1 one item per lane, 2 per DPP quad, 3 per 16-lane row, 4 per wave, 5 per 8 lanes; | 0x100: no prepared lines
+enum : int { PAIRING_AUTO = 0, PAIRING_LANE = 1, PAIRING_QUAD = 2, PAIRING_ROW = 3, PAIRING_TRI = 4, PAIRING_OCT = 5,
+             PAIRING_NOPREP = 0x100 };
 void launch_pairing_check2(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status,
-                           hipStream_t st, uint32_t* prep = nullptr);
+                           hipStream_t st, uint32_t* prep = nullptr, int layout = PAIRING_AUTO);
 void launch_pairing_quad_selftest(size_t n, const uint8_t* in, uint8_t* status, hipStream_t st);
+void launch_pairing_oct_selftest(size_t n, const uint8_t* in, uint8_t* status, hipStream_t st);
 }  // namespace vrf
 
 VRF_NS_BEGIN

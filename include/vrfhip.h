@@ -506,6 +506,21 @@ int32_t vrfhip_te_sw_map_batch_dev(vrfhip_ctx* ctx, size_t n, int32_t to_te, con
  * 48 bytes, little-endian (reduced mod p by the loader).  status[i] = bit mask of differing operations
  * (1 mul, 2 sqr, 4 cyclotomic sqr, 8 mul_by_014, 16 frobenius, 32 conj / gather-scatter); 0 = all equal. */
 int32_t vrfhip_test_pairing_quad_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp12_pairs, uint8_t* status);
+/* The same for the 8-lanes-per-item layout (an Fp2 split over a lane pair; the throughput path from 2^11 items on) and its
+ * cross-lane moves.  status[i]: 1 mul, 2 sqr, 4 cyclotomic sqr (of x^((p^6-1)(p^2+1))), 8 mul_by_014, 16 frobenius,
+ * 32 inverse, 64 conj / scatter / easy part, 128 a cross-lane move; 0 = all equal. */
+int32_t vrfhip_test_pairing_oct_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp12_pairs, uint8_t* status);
+
+/* Test / tuning knobs of a context.  The library never reads the environment; what rounds 1-3 steered with VRFHIP_PAIRING,
+ * VRFHIP_PAIRING_ROW and VRFHIP_PIPE_*_LOG2 is set here, by tests and tuning scripts only.  Not part of the reference's
+ * API (/root/reference src/lib.rs:13-17 has no counterpart); defaults are what production runs. */
+enum {
+  VRFHIP_DEBUG_PAIRING_LAYOUT = 1,  /* 0 by batch size (default); 1 one item per lane, 2 per DPP quad, 3 per 16-lane row,
+                                       4 per wave, 5 per 8 lanes; | 0x100: do not prepare the lines of a shared G2 pair */
+  VRFHIP_DEBUG_PIPE_FIRST_LOG2 = 2, /* host-pointer verify pipeline: log2 items of the first chunk (12..18, default 17) */
+  VRFHIP_DEBUG_PIPE_CHUNK_LOG2 = 3  /* ... of the following chunks (12..18, default 18) */
+};
+int32_t vrfhip_debug_set(vrfhip_ctx* ctx, int32_t key, int32_t value);
 
 /* One call, several devices ------------------------------------------------------------ */
 

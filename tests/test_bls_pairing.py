@@ -247,25 +247,24 @@ def test_gpu_pairing_shared_g2_prepared_lines(ctx):
     # the verdicts also agree with the path that does not prepare lines, and -- small batches run one item per
     # 16-lane row (bls12_row.cuh), large ones one item per quad -- with the quad kernel forced on this small batch
     # and with the row / quad switch crossed by a tiled batch
-    import os
-    for mode in ("noprep", "quad"):
-        os.environ["VRFHIP_PAIRING"] = mode
+    for mode in ("noprep", "quad", "oct"):
+        ctx.debug_pairing_layout(mode)
         try:
             assert list(ctx.pairing_check_batch(g1, sh, g2_shared=True)) == want, mode
             a = ctx.pairing_check_batch(g1, sh_inf, g2_shared=True)
             assert list(a) == list(bb), mode
         finally:
-            del os.environ["VRFHIP_PAIRING"]
-    for reps in (25, 26, 102, 103):        # 1000 items: one per wave (three rows); 1040, 4080: one per row; 4120: one per quad
+            ctx.debug_pairing_layout()
+    for reps in (25, 26, 102, 103):        # 1000 items: one per wave (three rows); 1040, 4080: one per row; 4120: 8 lanes per item
         big = np.tile(g1, (reps, 1))
         assert list(ctx.pairing_check_batch(big, sh, g2_shared=True)) == want * reps
     for rowmode in ("tri", "row"):                              # both row layouts forced on the small batch
-        os.environ["VRFHIP_PAIRING_ROW"] = rowmode
+        ctx.debug_pairing_layout(rowmode)
         try:
             assert list(ctx.pairing_check_batch(g1, sh, g2_shared=True)) == want, rowmode
             assert list(ctx.pairing_check_batch(g1, sh_inf, g2_shared=True)) == list(bb), rowmode
         finally:
-            del os.environ["VRFHIP_PAIRING_ROW"]
+            ctx.debug_pairing_layout()
 
 
 @pytest.mark.gpu
@@ -309,6 +308,67 @@ def test_gpu_quad_tower_ops_match_one_lane_ops(ctx):
     st = np.full(n, 255, np.uint8)
     _lib.check(lib.vrfhip_test_pairing_quad_ops(ctx.handle, n, raw.ctypes.data, st.ctypes.data), "quad selftest")
     assert (st == 0).all(), {int(i): int(v) for i, v in enumerate(st) if v}
+
+
+@pytest.mark.gpu
+def test_gpu_oct_tower_equals_lane_tower(ctx):
+    """The throughput pairing kernel spreads one item over 8 lanes with every Fp2 split over a lane pair
+    (bls12_oct.cuh).  Its cross-lane moves (quad_perm, row_shl:4 / row_shr:4 with bank masks, the ballot) and its Fp12
+    operations -- product, squaring, cyclotomic squaring, sparse product, Frobenius, inversion, the easy part -- must equal
+    the one-lane operations of bls12.cuh on random operands, in every item slot of a wave and with edge values."""
+    from ark_ec_vrfs_amd import _lib
+    lib = _lib.load()
+    rnd = np.random.default_rng(4)
+    n = 300
+    raw = rnd.integers(0, 256, (n, 2, 12, 48), dtype=np.uint8)
+    raw[..., 47] &= 0x0f                                   # < 2^380 < p: canonical inputs
+    raw[1, :, :, :] = 0; raw[1, :, 0, 0] = 1               # x = y = 1
+    pm1 = np.frombuffer(int(P - 1).to_bytes(48, "little"), np.uint8)
+    raw[2, :, :, :] = pm1
+    st = np.full(n, 255, np.uint8)
+    _lib.check(lib.vrfhip_test_pairing_oct_ops(ctx.handle, n, raw.ctypes.data, st.ctypes.data), "oct selftest")
+    assert (st == 0).all(), {int(i): int(v) for i, v in enumerate(st) if v}
+
+
+@pytest.fixture(scope="module")
+def ho():
+    so = os.path.join(HERE, "libhostsim_bls_oct.so")
+    subprocess.run(["make", "-C", HERE, "libhostsim_bls_oct.so"], check=True, stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(so)
+    for f in (lib.hb_oct_moves, lib.hb_oct_selftest, lib.hb_oct_pairing_check2, lib.hb_oct_pairing_check2_prepared):
+        f.restype = ctypes.c_uint32
+    return lib
+
+
+def test_hostsim_oct_layout_tower_and_checks(hb, ho):
+    """bls12_oct.cuh on the CPU: the 8 lanes of an item are 8 threads that meet at a barrier in every cross-lane move.
+    Tower operations against the one-lane tower (itself held against the Python oracle above), then whole pairing checks --
+    valid, wrong, invalid, infinity on either side -- against pairing_check2_item, with per-item and with prepared lines."""
+    assert ho.hb_oct_moves() == 0
+    rnd = random.Random(11)
+    rf2 = lambda: b.Fp2(rnd.randrange(P), rnd.randrange(P))
+    rf12 = lambda: b.Fp12(b.Fp6(rf2(), rf2(), rf2()), b.Fp6(rf2(), rf2(), rf2()))
+    edge = b.Fp12(b.Fp6(b.Fp2(P - 1, P - 1), b.Fp2(1, 0), b.Fp2(0, P - 1)), b.Fp6(b.Fp2(P - 2, 1), b.Fp2(0, 0), b.Fp2(P - 1, 0)))
+    for it in range(24):
+        x, y = (edge, rf12()) if it == 0 else (rf12(), edge) if it == 1 else (rf12(), rf12())
+        c0, c1, c4 = rf2(), rf2(), rf2()
+        cc = b"".join(w(v) for v in (c0.a, c0.b, c1.a, c1.b, c4.a, c4.b))
+        assert ho.hb_oct_selftest(_enc12(x), _enc12(y), cc) == 0, it
+    cases = []
+    for (p0, q0), (p1, q1) in kzg_like_items(2, seed=8):
+        g1, g2 = enc_g1(p0) + enc_g1(p1), enc_g2(q0) + enc_g2(q1)
+        bad1 = bytearray(g1); bad1[100] ^= 1
+        bad2 = bytearray(g2); bad2[200] ^= 1
+        cases += [(g1, g2), (enc_g1(p0) + enc_g1(b.g1_add(p1, b.G1)), g2), (enc_g1(p0) + bytes(96), g2), (bytes(192), g2),
+                  (g1, enc_g2(q0) + bytes(192)), (g1, bytes(384)), (bytes(bad1), g2), (g1, bytes(bad2)),
+                  (g1, enc_g2(q0) + w(P) + bytes(144))]
+    seen = set()
+    for g1, g2 in cases:
+        want = hb.hb_pairing_check2(g1, g2)
+        assert ho.hb_oct_pairing_check2(g1, g2) == want
+        assert ho.hb_oct_pairing_check2_prepared(g1, g2) == want
+        seen.add(want)
+    assert seen == {0, 1, 2}
 
 
 # ------------------------------------------------------------------------------------------ G1 MSM, batched check
@@ -577,12 +637,14 @@ def test_gpu_pairing_soak_distinct_items_every_path(ctx):
     ref = co.pairing_check_batch(g1, g2, threads=ncpu)
     assert (ref == want).all(), [(k, int(a), int(c)) for k, a, c in zip(kinds, ref, want) if a != c][:5]
     assert len({bytes(r) for r in g1}) > n - n // 20 and len({bytes(r) for r in g2}) > n - n // 20     # distinct (but for the zeroed ones)
-    assert (ctx.pairing_check_batch(g1, g2) == want).all()
-    os.environ["VRFHIP_PAIRING"] = "lane"
-    try:
-        assert (ctx.pairing_check_batch(g1, g2) == want).all()
-    finally:
-        del os.environ["VRFHIP_PAIRING"]
+    assert (ctx.pairing_check_batch(g1, g2) == want).all()               # 2^12 items: 8 lanes per item
+    for mode in ("lane", "quad", "oct"):
+        ctx.debug_pairing_layout(mode)
+        try:
+            assert (ctx.pairing_check_batch(g1, g2) == want).all(), mode
+        finally:
+            ctx.debug_pairing_layout()
+    assert (ctx.pairing_check_batch(g1[:1500], g2[:1500]) == want[:1500]).all()    # below the switch: one item per quad
     # one shared pair (Q0, tau Q0): the KZG verifier's shape
     tau = 0x1D3A5F7C9B2E4F6A8C0E1B3D5F7A9C0E2B4D6F8A1C3E5A7C9E0B2D4F6A8C1E3
     q0 = co.g2_mul(0xC0FFEE1234567, enc_g2(b.G2))
@@ -592,14 +654,19 @@ def test_gpu_pairing_soak_distinct_items_every_path(ctx):
     sref = co.pairing_check_batch(s1, sg2, shared=True, threads=ncpu)
     assert (sref == swant).all(), [(k, int(a), int(c)) for k, a, c in zip(skinds, sref, swant) if a != c][:5]
     assert set(np.unique(swant)) == {0, 1, 2}
-    for cnt in (1000, 4096, m):                                        # one item per wave | per row | per quad
+    for cnt in (1000, 4096, m):                                        # one item per wave | per row | per 8 lanes
         assert (ctx.pairing_check_batch(s1[:cnt], sg2, g2_shared=True) == swant[:cnt]).all(), cnt
-    for mode in ("noprep", "quad", "row"):
-        os.environ["VRFHIP_PAIRING"] = mode
+    for mode in ("noprep", "quad", "row", "oct"):
+        ctx.debug_pairing_layout(mode)
         try:
             assert (ctx.pairing_check_batch(s1[:1500], sg2, g2_shared=True) == swant[:1500]).all(), mode
         finally:
-            del os.environ["VRFHIP_PAIRING"]
+            ctx.debug_pairing_layout()
+    ctx.debug_pairing_layout("noprep", "oct")                            # shared pair through the unprepared 8-lane kernel
+    try:
+        assert (ctx.pairing_check_batch(s1[:700], sg2, g2_shared=True) == swant[:700]).all()
+    finally:
+        ctx.debug_pairing_layout()
     assert (ctx.pairing_check_batch(s1, np.tile(sg2, (m, 1))) == swant).all()       # the same items through the per-item kernel
     # batched: a batch with false items fails as a whole and falls back to the per-item verdicts ...
     st, batch_ok = ctx.pairing_check_batch_rlc(s1, sg2, seed=bytes(range(32)))
