@@ -38,7 +38,7 @@ SYMBOLS = [
     "vrfhip_secret_from_seed_batch", "vrfhip_secret_from_seed_batch_dev",
     "vrfhip_point_validate_batch", "vrfhip_point_validate_batch_dev",
     "vrfhip_te_sw_map_batch", "vrfhip_te_sw_map_batch_dev",
-    "vrfhip_fq_mul_batch", "vrfhip_test_pairing_quad_ops", "vrfhip_test_pairing_oct_ops", "vrfhip_debug_set",
+    "vrfhip_fq_mul_batch", "vrfhip_test_pairing_quad_ops", "vrfhip_test_pairing_oct_ops", "vrfhip_debug_set", "vrfhip_test_blinding_base",
     "vrfhip_debug_proofs_per_lane",
     "vrfhip_ietf_verify_batch_multi", "vrfhip_ietf_prove_batch_multi",
     "vrfhip_pedersen_prove_batch_multi", "vrfhip_pedersen_verify_batch_multi",
@@ -163,6 +163,7 @@ def load() -> ctypes.CDLL:
     lib.vrfhip_test_pairing_quad_ops.argtypes = [c_void_p, c_size_t, P, P]
     lib.vrfhip_test_pairing_oct_ops.argtypes = [c_void_p, c_size_t, P, P]
     lib.vrfhip_debug_set.argtypes = [c_void_p, c_int32, c_int32]
+    lib.vrfhip_test_blinding_base.argtypes = [c_int32, P]
     lib.vrfhip_debug_proofs_per_lane.argtypes = [c_size_t]
     CP = POINTER(c_void_p)   # vrfhip_ctx* const*
     lib.vrfhip_ietf_verify_batch_multi.argtypes = [CP, c_int32, c_size_t, P, P, P, P, P, P, P, c_uint32, P]

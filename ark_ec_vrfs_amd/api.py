@@ -75,7 +75,9 @@ class BabyJubJubSha512Tai(Suite):
 
 class Secp256r1Sha256Tai(Suite):
     """`suites::secp256r1` = RFC 9381 ECVRF-P256-SHA256-TAI (suite_string 0x01).  Own wire format: points are 33-byte SEC1
-    compressed strings, scalars 32-byte BIG-endian integers, `Output::hash` is 32 bytes (SHA-256); IETF scheme only."""
+    compressed strings, scalars 32-byte BIG-endian integers, `Output::hash` is 32 bytes (SHA-256).  Both schemes; the
+    Pedersen scheme needs the caller's `PedersenSuite::BLINDING_BASE` in the descriptor (upstream's constant is not pinned
+    here: the default descriptor leaves it zero and pedersen_* then raise)."""
     SUITE_ID = b"\x01"
     CHALLENGE_LEN = 16
     SUITE_ENUM = 5
@@ -104,6 +106,20 @@ class SuiteDesc:
         d = _lib.SuiteDescStruct()
         _lib.check(_lib.load().vrfhip_suite_desc_default(suite.SUITE_ENUM, ctypes.byref(d)), "vrfhip_suite_desc_default")
         return SuiteDesc._from_struct(d)
+
+    @staticmethod
+    def test_blinding_base(suite: type) -> bytes:
+        """vrfhip_test_blinding_base: a nothing-up-my-sleeve subgroup point (x || y) -- NOT upstream's constant; for tests
+        and bench legs of suites whose `PedersenSuite::BLINDING_BASE` is unpinned."""
+        out = (ctypes.c_uint8 * 64)()
+        _lib.check(_lib.load().vrfhip_test_blinding_base(suite.SUITE_ENUM, out), "vrfhip_test_blinding_base")
+        return bytes(out)
+
+    @staticmethod
+    def with_test_blinding_base(suite: type) -> "SuiteDesc":
+        d = SuiteDesc.default(suite)
+        d.blinding_base = SuiteDesc.test_blinding_base(suite)
+        return d
 
     @staticmethod
     def _from_struct(d) -> "SuiteDesc":
@@ -173,11 +189,16 @@ def _pack_var(items: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
 class Context:
     """One GPU + one suite: owns the device tables and HBM workspace (vrfhip_ctx)."""
 
-    def __init__(self, device: int = 0, suite: type = BandersnatchSha512Ell2, desc: Optional[SuiteDesc] = None):
+    def __init__(self, device: int = 0, suite: type = BandersnatchSha512Ell2, desc: Optional[SuiteDesc] = None,
+                 test_blinding_base: bool = False):
         """suite: a built-in suite class; desc: a suite descriptor (overrides `suite`), e.g. the upstream JubJub
-        constants filled in by the caller."""
+        constants filled in by the caller.  test_blinding_base: tests / bench only -- the built-in descriptor with the
+        placeholder blinding base of vrfhip_test_blinding_base (the default descriptor of every suite but Bandersnatch has
+        none, and no Pedersen scheme)."""
         self._lib = _lib.load()
         self.suite = suite
+        if desc is None and test_blinding_base:
+            desc = SuiteDesc.with_test_blinding_base(suite)
         h = ctypes.c_void_p()
         if desc is not None:
             d = desc._to_struct()

@@ -100,6 +100,8 @@ struct vrfhip_ctx {
   uint32_t* d_pair_prep = nullptr;         // Miller-loop lines of shared G2 points (pairing check, SRS case)
   int cus = 256;
   uint32_t flags = 0;                      // VRFHIP_FLAG_PREVALIDATED_* (vrfhip_ctx_set_flags)
+  bool have_blinding = true;               // false: the descriptor's blinding base is all-zero -- a suite without the Pedersen scheme
+  bool has_pedersen() const { return sw ? d_p256_comb_b != nullptr : have_blinding; }
   // test / tuning knobs (vrfhip_debug_set; nothing in the product reads the environment)
   int dbg_pairing_layout = 0;              // kernels.h PAIRING_*: 0 = by batch size
   int pipe_first_log2 = 17, pipe_chunk_log2 = 18;   // host-pointer pipeline: first chunk, later chunks (items, log2)
@@ -318,6 +320,26 @@ int32_t vrfhip_abi_version(void) { return 143; }
 
 const char* vrfhip_last_error(void) { return g_last_error.c_str(); }
 
+static const char NO_BLINDING_MSG[] =
+    "the suite descriptor carries no Pedersen blinding base (PedersenSuite::BLINDING_BASE): only Bandersnatch's is pinned by an "
+    "upstream vector; supply the suite's constant in vrfhip_suite_desc.blinding_base";
+
+// The nothing-up-my-sleeve points rounds 1-3 shipped as default blinding bases (tools/gen_constants.py: try-and-increment on
+// "vrfhip-<suite>-blinding-base").  They are NOT upstream's constants: proofs made with them do not verify under ark-vrf.
+// Tests and bench legs that want the Pedersen scheme on a suite whose constant is unpinned ask for them by name.
+int32_t vrfhip_test_blinding_base(vrfhip_suite suite, uint8_t out_xy[64]) {
+  if (!out_xy) return fail(VRFHIP_ERR_BAD_ARG, "out is NULL");
+  uint8_t g[64];
+  bool have = false;
+  if (suite == VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2) have = vrf::f_bls381fr::field_default_points(SUITE_BS, g, out_xy);
+  else if (suite == VRFHIP_SUITE_JUBJUB_SHA512_TAI) have = vrf::f_bls381fr::field_default_points(SUITE_JJ, g, out_xy);
+  else if (suite == VRFHIP_SUITE_ED25519_SHA512_TAI) have = vrf::f_25519::field_default_points(SUITE_ED, g, out_xy);
+  else if (suite == VRFHIP_SUITE_BABY_JUBJUB_SHA512_TAI) have = vrf::f_bn254fr::field_default_points(SUITE_BJ, g, out_xy);
+  else if (suite == VRFHIP_SUITE_SECP256R1_SHA256_TAI) { p256::default_blinding_base(out_xy); have = true; }
+  if (!have) return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported suite");
+  return VRFHIP_SUCCESS;
+}
+
 int32_t vrfhip_suite_desc_default(vrfhip_suite suite, vrfhip_suite_desc* out) {
   if (!out) return fail(VRFHIP_ERR_BAD_ARG, "out is NULL");
   std::memset(out, 0, sizeof *out);
@@ -337,15 +359,18 @@ int32_t vrfhip_suite_desc_default(vrfhip_suite suite, vrfhip_suite_desc* out) {
     out->curve = VRFHIP_CURVE_JUBJUB;
     put(out->suite_id, out->suite_id_len, "JubJub_SHA-512_TAI");
     have = vrf::f_bls381fr::field_default_points(SUITE_JJ, out->generator, out->blinding_base);
+    std::memset(out->blinding_base, 0, 64);          // upstream's constant is not pinned here: no Pedersen scheme by default
   } else if (suite == VRFHIP_SUITE_ED25519_SHA512_TAI) {
     out->curve = VRFHIP_CURVE_ED25519;
     out->challenge_len = 16;                         // upstream: `CHALLENGE_LEN = 16` (RFC 9381 cLen of the edwards25519 suites)
     put(out->suite_id, out->suite_id_len, "Ed25519_SHA-512_TAI");
     have = vrf::f_25519::field_default_points(SUITE_ED, out->generator, out->blinding_base);
+    std::memset(out->blinding_base, 0, 64);
   } else if (suite == VRFHIP_SUITE_BABY_JUBJUB_SHA512_TAI) {
     out->curve = VRFHIP_CURVE_BABY_JUBJUB;
     put(out->suite_id, out->suite_id_len, "BabyJubJub_SHA-512_TAI");
     have = vrf::f_bn254fr::field_default_points(SUITE_BJ, out->generator, out->blinding_base);
+    std::memset(out->blinding_base, 0, 64);
   }
   else if (suite == VRFHIP_SUITE_SECP256R1_SHA256_TAI) {
     out->curve = VRFHIP_CURVE_SECP256R1;
@@ -353,7 +378,7 @@ int32_t vrfhip_suite_desc_default(vrfhip_suite suite, vrfhip_suite_desc* out) {
     out->suite_id[0] = 0x01;                         // RFC 9381 suite_string
     out->suite_id_len = 1;
     p256::default_generator(out->generator);
-    p256::default_blinding_base(out->blinding_base); // nothing-up-my-sleeve: upstream's constant is not known here
+    // blinding_base stays all-zero: upstream's constant is not known here (vrfhip_test_blinding_base has a placeholder)
     have = true;
   }
   if (!have) return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported suite");
@@ -502,6 +527,12 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
   uint8_t gb[128];
   std::memcpy(gb, desc->generator, 64);
   std::memcpy(gb + 64, desc->blinding_base, 64);
+  {
+    bool have_b = false;
+    for (size_t i = 0; i < 64; ++i) have_b = have_b || desc->blinding_base[i] != 0;
+    ctx->have_blinding = have_b;
+    if (!have_b) std::memcpy(gb + 64, desc->generator, 64);   // the table kernel wants a valid point; the scheme stays off
+  }
   HIP_TRY_C(hipMalloc(&d_init, 512));
   HIP_TRY_C(hipMalloc(&d_prefix, prefix_bytes));
   auto free_tmp = [&]() { (void)hipFree(d_prefix); (void)hipFree(d_init); };
@@ -1040,7 +1071,7 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
   if (pedersen ? (!o.pk || !o.r || !o.ok || !o.sb) : !o.c) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if (!d_input && !d_msg && (msg_len || d_msg_off)) return fail(VRFHIP_ERR_BAD_ARG, "msg is NULL");
   if ((ad_len || d_ad_off) && !d_ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
-  if (ctx->sw && pedersen && !ctx->d_p256_comb_b) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the descriptor carries no Pedersen blinding base");
+  if (pedersen && !ctx->has_pedersen()) return fail(VRFHIP_ERR_UNSUPPORTED, NO_BLINDING_MSG);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   int32_t rc = ensure_workspace(ctx, n);
@@ -1241,7 +1272,7 @@ int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_
   if (!d_input || !d_output || !d_pk_com || !d_r || !d_ok || !d_s || !d_sb || !d_status)
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if ((ad_len || d_ad_off) && !d_ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
-  if (ctx->sw && !ctx->d_p256_comb_b) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the descriptor carries no Pedersen blinding base");
+  if (!ctx->has_pedersen()) return fail(VRFHIP_ERR_UNSUPPORTED, NO_BLINDING_MSG);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   int32_t rc = ensure_workspace(ctx, n);
@@ -1336,6 +1367,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
   if (n && (!d_input || !d_output || !d_pk_com || !d_r || !d_ok || !d_s || !d_sb || !d_status))
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if ((ad_len || d_ad_off) && !d_ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");
+  if (!ctx->has_pedersen()) return fail(VRFHIP_ERR_UNSUPPORTED, NO_BLINDING_MSG);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   hipStream_t st = static_cast<hipStream_t>(stream);

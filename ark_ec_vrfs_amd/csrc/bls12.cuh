@@ -188,6 +188,47 @@ VRF_HD Fp<1, mul2_v(V1, V2, V3, V4)> fp_mul2(const Fp<L1, V1>& a, const Fp<L2, V
   r.v[NLB - 1] = (int32_t)acc;
   return r;
 }
+// u1 c1 + w1 d1 + u2 c2 + w2 d2 + u3 c3 + w3 d3 with ONE Montgomery reduction: a component of a sum of three Fp2
+// products (a column of a sparse Fp12 product).  Six products and the m p row fill the 64-bit column accumulators exactly
+// as far as one product of limb bounds 2 x 4 does (fp_mul), so every operand must have normalised limbs.
+constexpr int mul6_v(int va, int vb, int vc, int vy) { return 1 + (2 * vy * (va + vb + vc) + 2499) / 2500; }
+template <int VA, int VB, int VC, int VY>
+VRF_HD Fp<1, mul6_v(VA, VB, VC, VY)> fp_mul6(const Fp<1, VA>& u1, const Fp<1, VA>& w1, const Fp<1, VB>& u2, const Fp<1, VB>& w2,
+                                             const Fp<1, VC>& u3, const Fp<1, VC>& w3, const Fp<1, VY>& c1, const Fp<1, VY>& d1,
+                                             const Fp<1, VY>& c2, const Fp<1, VY>& d2, const Fp<1, VY>& c3, const Fp<1, VY>& d3) {
+  Fp<1, mul6_v(VA, VB, VC, VY)> r;
+  int32_t m[NLB];
+  int64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < NLB; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) {
+      acc = smad(u1.v[i], c1.v[k - i], acc); acc = smad(w1.v[i], d1.v[k - i], acc);
+      acc = smad(u2.v[i], c2.v[k - i], acc); acc = smad(w2.v[i], d2.v[k - i], acc);
+      acc = smad(u3.v[i], c3.v[k - i], acc); acc = smad(w3.v[i], d3.v[k - i], acc);
+    }
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc = smad(m[i], (int32_t)vrfk::BLS_P28[k - i], acc);
+    m[k] = (int32_t)(((uint32_t)acc * vrfk::BLS_PINV28) & MASKB);
+    acc = smad(m[k], (int32_t)vrfk::BLS_P28[0], acc);
+    acc >>= LWB;
+  }
+#pragma unroll
+  for (int k = NLB; k < 2 * NLB - 1; ++k) {
+#pragma unroll
+    for (int i = k - NLB + 1; i < NLB; ++i) {
+      acc = smad(u1.v[i], c1.v[k - i], acc); acc = smad(w1.v[i], d1.v[k - i], acc);
+      acc = smad(u2.v[i], c2.v[k - i], acc); acc = smad(w2.v[i], d2.v[k - i], acc);
+      acc = smad(u3.v[i], c3.v[k - i], acc); acc = smad(w3.v[i], d3.v[k - i], acc);
+    }
+#pragma unroll
+    for (int i = k - NLB + 1; i < NLB; ++i) acc = smad(m[i], (int32_t)vrfk::BLS_P28[k - i], acc);
+    r.v[k - NLB] = (int32_t)((uint32_t)acc & MASKB);
+    acc >>= LWB;
+  }
+  r.v[NLB - 1] = (int32_t)acc;
+  return r;
+}
 template <int L, int V>
 VRF_HD Fp<1, mul_v(V, V)> fp_sqr(const Fp<L, V>& a) {
   static_assert(L * L <= 8, "");

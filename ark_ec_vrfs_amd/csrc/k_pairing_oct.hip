@@ -79,7 +79,8 @@ __global__ void __launch_bounds__(OCT_BLOCK) k_pairing_oct_selftest(size_t n, co
   fp12_mul_by_014(&ref, &y.c0.c0, &y.c0.c1, &y.c1.c2);
   {
     const FpS l0 = ln.h ? y.c0.c0.b : y.c0.c0.a, l1 = ln.h ? y.c0.c1.b : y.c0.c1.a, l4 = ln.h ? y.c1.c2.b : y.c1.c2.a;
-    if (!o12_same(o12_mul_by_014(xo, l0, l1, l4, ln), &ref, ln)) bad |= 8;
+    if (!o12_same(o12_mul_by_014<true>(xo, l0, l1, l4, ln), &ref, ln)) bad |= 8;
+    if (!o12_same(o12_mul_by_014<false>(xo, l0, l1, l4, ln), &ref, ln)) bad |= 8;
   }
   fp12_frob(&ref, &x);
   if (!o12_same(o12_frob(xo, ln), &ref, ln)) bad |= 16;

@@ -419,7 +419,7 @@ def cfg_pedersen_jubjub(D, args, msg, lo, want_cpu):
     from ark_ec_vrfs_amd import Context, JubJubSha512Tai, _lib
     lib = _lib.load()
     n = msg.shape[0]
-    cj = Context(D.local, suite=JubJubSha512Tai)
+    cj = Context(D.local, suite=JubJubSha512Tai, test_blinding_base=True)
     stream = torch.cuda.current_stream().cuda_stream
     mk = lambda: torch.empty((n, 32), dtype=torch.uint8, device=D.dev)
     seeds = (torch.arange(n, dtype=torch.int64, device=D.dev) + lo).view(torch.uint8).reshape(n, 8)
@@ -512,7 +512,7 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
     from ark_ec_vrfs_amd import Context, _lib
     lib = _lib.load()
     n = 1 << args.log2_batch
-    cx = Context(D.local, suite=suite_cls)
+    cx = Context(D.local, suite=suite_cls, test_blinding_base=True)
     res = {}
     try:
         stream = torch.cuda.current_stream().cuda_stream

@@ -158,8 +158,16 @@ const char* vrfhip_last_error(void);
 int32_t vrfhip_ctx_create(vrfhip_suite suite, int32_t device, vrfhip_ctx** out);
 void vrfhip_ctx_destroy(vrfhip_ctx* ctx);
 
-/* The built-in descriptor of `suite` (what vrfhip_ctx_create uses); a caller edits the fields it wants to replace. */
+/* The built-in descriptor of `suite` (what vrfhip_ctx_create uses); a caller edits the fields it wants to replace.
+ * `blinding_base` (`PedersenSuite::BLINDING_BASE`) is filled in for Bandersnatch only, where upstream's Pedersen vector
+ * pins it.  For JubJub, Ed25519, Baby-JubJub and secp256r1 upstream's constant is not authenticated here, so the default
+ * descriptor leaves it ALL ZERO: the context then has no Pedersen scheme (vrfhip_pedersen_* return
+ * VRFHIP_ERR_UNSUPPORTED) until the caller writes the suite's constant into the descriptor -- the Rust crate does, from the
+ * `PedersenSuite` trait.  (Rounds 1-3 shipped an invented point there: proofs made with it never verify upstream.) */
 int32_t vrfhip_suite_desc_default(vrfhip_suite suite, vrfhip_suite_desc* out);
+/* Test / bench only: a nothing-up-my-sleeve point of the suite's prime-order subgroup (x || y, 32-byte little-endian) to use
+ * as blinding base where upstream's is unknown.  NOT upstream's constant; Bandersnatch returns its pinned one. */
+int32_t vrfhip_test_blinding_base(vrfhip_suite suite, uint8_t out_xy[64]);
 /* Create a context from a descriptor.  VRFHIP_ERR_BAD_ARG if a length is out of range or the generator / blinding
  * base is not a non-identity point of the curve's prime-order subgroup (checked on the device);
  * VRFHIP_ERR_UNSUPPORTED for an unknown curve or challenge length. */

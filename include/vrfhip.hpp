@@ -112,6 +112,13 @@ class Context {
     check(vrfhip_suite_desc_default(S::ID, &d), "vrfhip_suite_desc_default");
     return d;
   }
+  // tests only: the default descriptor with the placeholder blinding base of vrfhip_test_blinding_base (upstream's
+  // `PedersenSuite::BLINDING_BASE` is pinned for Bandersnatch alone; the other default descriptors carry none)
+  static vrfhip_suite_desc test_descriptor() {
+    vrfhip_suite_desc d = default_descriptor();
+    check(vrfhip_test_blinding_base(S::ID, d.blinding_base), "vrfhip_test_blinding_base");
+    return d;
+  }
   // point classes whose subgroup membership the caller vouches for (typed, already validated values):
   // VRFHIP_FLAG_PREVALIDATED_*; default 0 = arkworks' checked deserialisation inside every verify
   void set_flags(uint32_t flags) { check(vrfhip_ctx_set_flags(h_, flags), "vrfhip_ctx_set_flags"); }

@@ -86,7 +86,8 @@ uint32_t hb_oct_selftest(const uint8_t* xb, const uint8_t* yb, const uint8_t* cb
     if (!o12_same(o12_mul(xo, yo, ln), &r_mul, ln)) bad |= 1;
     if (!o12_same(o12_sqr(xo, ln), &r_sqr, ln)) bad |= 2;
     if (!o12_same(o12_cyclotomic_sqr(xco, ln), &r_cyc, ln)) bad |= 4;
-    if (!o12_same(o12_mul_by_014(xo, l0, l1, l4, ln), &r_014, ln)) bad |= 8;
+    if (!o12_same(o12_mul_by_014<true>(xo, l0, l1, l4, ln), &r_014, ln)) bad |= 8;
+    if (!o12_same(o12_mul_by_014<false>(xo, l0, l1, l4, ln), &r_014, ln)) bad |= 8;
     if (!o12_same(o12_frob(xo, ln), &r_frob, ln)) bad |= 16;
     if (!o12_same(o12_inv(xo, ln), &r_inv, ln)) bad |= 32;
     if (!o12_same(o12_conj(xo), &r_conj, ln) || !o12_same(xo, &x, ln)) bad |= 64;

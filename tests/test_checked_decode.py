@@ -204,7 +204,7 @@ def test_pedersen_verify_and_batched_verify_on_shifted_points_jubjub(checked_ora
     tors = [o.te_mul(J, j, T8) for j in (1, 2, 4)]          # orders 8, 4, 2
     assert tors[2] == (0, J.q - 1)
     co.set_suite(2)
-    cj = Context(0, suite=JubJubSha512Tai)
+    cj = Context(0, suite=JubJubSha512Tai, test_blinding_base=True)
     try:
         _pedersen_case(J, co, cj, rnd, tors)
     finally:

@@ -507,7 +507,7 @@ def test_msm_group_boundaries(ctx, n):
 
 def test_msm_jubjub_matches_naive_oracle():
     from ark_ec_vrfs_amd import Context, JubJubSha512Tai
-    cj = Context(0, suite=JubJubSha512Tai)
+    cj = Context(0, suite=JubJubSha512Tai, test_blinding_base=True)
     co.set_suite(2)
     try:
         n = 3000

@@ -119,7 +119,7 @@ def test_pedersen_jubjub_soak_lane_variants(n):
     from ark_ec_vrfs_amd import Context, JubJubSha512Tai, _lib
     lib = _lib.load()
     dev = torch.device("cuda:0")
-    cj = Context(0, suite=JubJubSha512Tai)
+    cj = Context(0, suite=JubJubSha512Tai, test_blinding_base=True)
     co.set_suite(2)
     try:
         sk = _seeded_sk(torch, lib, _lib, cj, n, dev)

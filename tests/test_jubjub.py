@@ -145,7 +145,7 @@ def test_tai_counter_hint_is_exact(hj, J):
 @pytest.fixture(scope="module")
 def ctx_jj():
     from ark_ec_vrfs_amd import Context, JubJubSha512Tai
-    c = Context(0, suite=JubJubSha512Tai)
+    c = Context(0, suite=JubJubSha512Tai, test_blinding_base=True)
     yield c
     c.close()
 

@@ -126,7 +126,7 @@ def test_keyed_jubjub(synth):
     """The other suite: keys are validated by r*P = O (no 2-descent on a cofactor-8 curve), same statuses as the
     plain verifier."""
     from ark_ec_vrfs_amd import Context, JubJubSha512Tai
-    cj = Context(0, suite=JubJubSha512Tai)
+    cj = Context(0, suite=JubJubSha512Tai, test_blinding_base=True)
     co.set_suite(2)
     try:
         n, nk = 500, 9

@@ -348,7 +348,7 @@ def _suite_class(name):
 def gpu(request):
     from ark_ec_vrfs_amd import Context
     S, _, sid = SUITES[request.param]
-    ctx = Context(0, suite=_suite_class(request.param))
+    ctx = Context(0, suite=_suite_class(request.param), test_blinding_base=True)
     co.set_suite(sid)
     yield ctx, S, sid
     co.set_suite(1)
@@ -645,7 +645,7 @@ def test_gpu_every_other_entry_point_on_the_new_suites(gpu):
     finally:
         ks.close()
     # three contexts, one call
-    extra = [Context(0, suite=ctx.suite), Context(0, suite=ctx.suite)]
+    extra = [Context(0, suite=ctx.suite, test_blinding_base=True), Context(0, suite=ctx.suite, test_blinding_base=True)]
     ctxs = [ctx] + extra
     try:
         many = ietf_prove_batch_multi(ctxs, sk, msgs, ad=ads)
@@ -675,7 +675,7 @@ def test_gpu_every_other_entry_point_on_the_new_suites(gpu):
             x, y = int.from_bytes(row[:32].tobytes(), "little"), int.from_bytes(row[32:].tobytes(), "little")
             out[i] = np.frombuffer(le(x * R256 % Q) + le(y * R256 % Q), np.uint8)
         return out
-    c2 = Context(0, suite=ctx.suite)
+    c2 = Context(0, suite=ctx.suite, test_blinding_base=True)
     try:
         m = 64
         ref = c2.ietf_prove_batch(sk[:m], msgs=msgs[:m], ad=b"m")

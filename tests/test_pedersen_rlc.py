@@ -203,7 +203,7 @@ def test_gpu_rlc_affine_inputs(ctx, synth):
 @pytest.mark.gpu
 def test_gpu_rlc_jubjub(synth):
     from ark_ec_vrfs_amd import Context, JubJubSha512Tai
-    cj = Context(0, suite=JubJubSha512Tai)
+    cj = Context(0, suite=JubJubSha512Tai, test_blinding_base=True)
     co.set_suite(2)
     try:
         n = 700

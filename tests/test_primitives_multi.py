@@ -62,7 +62,7 @@ def test_point_add_and_scalar_mul_jubjub():
     from ark_ec_vrfs_amd import Context, JubJubSha512Tai
     J = o.jubjub_params()
     rnd = random.Random(42)
-    cj = Context(0, suite=JubJubSha512Tai)
+    cj = Context(0, suite=JubJubSha512Tai, test_blinding_base=True)
     try:
         a, b = _law_cases(J, rnd, 12)
         out, st = cj.test_point_add(np.stack([enc(J, P) for P in a]), np.stack([enc(J, P) for P in b]))
@@ -175,7 +175,7 @@ def test_gpu_prove_points_affine_equal_the_decoded_compressed_outputs(suite_name
     if jj:
         co.set_suite(2)
     try:
-        ctxs = [Context(0, suite=suite) for _ in range(3)]
+        ctxs = [Context(0, suite=suite, test_blinding_base=True) for _ in range(3)]
         c0 = ctxs[0]
         n = 300
         sk = np.stack([np.frombuffer(co.secret_from_seed(o.synth_seed(4000 + i)), np.uint8) for i in range(n)])

@@ -343,7 +343,7 @@ def _on_curve_x(x):
 @pytest.fixture(scope="module")
 def gpu():
     from ark_ec_vrfs_amd import Context, Secp256r1Sha256Tai
-    ctx = Context(0, Secp256r1Sha256Tai)
+    ctx = Context(0, Secp256r1Sha256Tai, test_blinding_base=True)
     yield ctx
     ctx.close()
 
@@ -458,7 +458,7 @@ def test_gpu_batch_round_trip_across_launch_groups(gpu):
         H, _ = sw.hash_to_curve_tai(msg[i].tobytes())
         gamma, c, s = sw.ietf_prove(k, H, b"batch")
         assert r["output"][i].tobytes() == sw.point_encode(gamma) and r["c"][i].tobytes() == be(c) and r["s"][i].tobytes() == be(s)
-    other = Context(0, Secp256r1Sha256Tai)
+    other = Context(0, Secp256r1Sha256Tai, test_blinding_base=True)
     try:
         m = 4099
         rm = ietf_prove_batch_multi([gpu, other], sk[:m], [x.tobytes() for x in msg[:m]], ad=b"batch")
@@ -611,7 +611,7 @@ def test_gpu_pedersen_equals_the_c_oracle(gpu):
         assert (got == want).all(), np.nonzero(got != want)[0][:10]
         assert set(np.unique(want)) == {0, 1, 2} and (want[kind >= 8] == 0).all()
         assert (gpu.pedersen_verify_batch(*[r[k] for k in ("input", "output", "pk_com", "r", "ok", "s", "sb")], ad=b"pee") == 1).all()
-        other = Context(0, gpu.suite)
+        other = Context(0, gpu.suite, test_blinding_base=True)
         try:
             m = 1001
             rm = pedersen_prove_batch_multi([gpu, other], sk[6:6 + m], [x.tobytes() for x in msg[6:6 + m]], ad=b"ped")

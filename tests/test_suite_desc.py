@@ -185,7 +185,7 @@ def test_custom_jubjub_descriptor_equals_oracle():
     co.set_suite(2)
     sk, msg = _items(8, 31000)              # the same secrets (reduced mod JubJub's r) as inside _gpu_vs_oracle
     co.set_suite(1)
-    cj = Context(0, suite=JubJubSha512Tai)
+    cj = Context(0, suite=JubJubSha512Tai, test_blinding_base=True)
     try:
         b = cj.pedersen_prove_batch(sk, msgs=msg, ad=b"desc")
         assert not (b["pk_com"] == pref["pk_com"][:8]).all(axis=1).any()       # another blinding base
@@ -210,3 +210,45 @@ def test_invalid_descriptors_are_refused():
         with pytest.raises(VrfHipError):
             Context(0, desc=d).close()
     Context(0, desc=good).close()
+
+
+@pytest.mark.gpu
+def test_default_descriptors_carry_only_the_pinned_blinding_base():
+    """ADVICE r3 (medium): `PedersenSuite::BLINDING_BASE` is pinned by an upstream vector for Bandersnatch only.  The default
+    descriptor of every other suite leaves it all-zero, such a context has the IETF scheme and every building block but
+    refuses the Pedersen entry points (UNSUPPORTED) -- no proof is ever made with an invented base by default -- and the
+    placeholder point is available by name (vrfhip_test_blinding_base) for tests and bench legs."""
+    import numpy as np
+    from ark_ec_vrfs_amd import (BabyJubJubSha512Tai, BandersnatchSha512Ell2, Context, Ed25519Sha512Tai, JubJubSha512Tai,
+                                 Secp256r1Sha256Tai, SuiteDesc, VrfHipError)
+    assert SuiteDesc.default(BandersnatchSha512Ell2).blinding_base == xy((S.bx, S.by)) != bytes(64)
+    assert SuiteDesc.test_blinding_base(BandersnatchSha512Ell2) == xy((S.bx, S.by))
+    for suite in (JubJubSha512Tai, Ed25519Sha512Tai, BabyJubJubSha512Tai, Secp256r1Sha256Tai):
+        d = SuiteDesc.default(suite)
+        assert d.blinding_base == bytes(64), suite.__name__
+        tb = SuiteDesc.test_blinding_base(suite)
+        assert tb != bytes(64) and SuiteDesc.with_test_blinding_base(suite).blinding_base == tb
+        c = Context(0, suite=suite)
+        try:
+            assert c.desc().blinding_base == bytes(64)
+            sk = np.arange(1, 1 + 4 * 32, dtype=np.uint8).reshape(4, 32) % 200
+            msgs = [b"m%d" % i for i in range(4)]
+            pr = c.ietf_prove_batch(sk, msgs=msgs, ad=b"x")                     # the IETF scheme is there
+            assert not c.ietf_verify_batch(pr["pk"], pr["input"], pr["output"], pr["c"], pr["s"], ad=b"x").any()
+            with pytest.raises(VrfHipError, match="blinding base"):
+                c.pedersen_prove_batch(sk, msgs=msgs, ad=b"x")
+            pw = c.point_bytes()
+            zp, zs = np.zeros((4, pw), np.uint8), np.zeros((4, 32), np.uint8)
+            with pytest.raises(VrfHipError, match="blinding base"):
+                c.pedersen_verify_batch(pr["input"], pr["output"], zp, zp, zp, zs, zs, ad=b"x")
+            if suite is not Secp256r1Sha256Tai:
+                with pytest.raises(VrfHipError, match="blinding base"):
+                    c.pedersen_verify_batch_rlc(pr["input"], pr["output"], zp, zp, zp, zs, zs, ad=b"x")
+        finally:
+            c.close()
+        c2 = Context(0, suite=suite, test_blinding_base=True)                    # opting in brings the scheme back
+        try:
+            p2 = c2.pedersen_prove_batch(sk, msgs=msgs, ad=b"x")
+            assert not c2.pedersen_verify_batch(p2["input"], p2["output"], p2["pk_com"], p2["r"], p2["ok"], p2["s"], p2["sb"], ad=b"x").any()
+        finally:
+            c2.close()

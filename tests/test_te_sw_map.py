@@ -83,7 +83,7 @@ def test_gpu_te_sw_map_equals_the_restatement(name):
     import ark_ec_vrfs_amd as pkg
     S = SUITES[name]
     q = S.q
-    ctx = pkg.Context(0, getattr(pkg, GPU_SUITES[name]))
+    ctx = pkg.Context(0, getattr(pkg, GPU_SUITES[name]), test_blinding_base=True)
     rnd = random.Random("gpu" + name)
     G = (S.gx, S.gy)
     pts = [o.te_mul(S, rnd.randrange(1, S.r), G) for _ in range(300)]
@@ -134,7 +134,7 @@ def test_gpu_te_sw_map_equals_the_restatement(name):
     assert e.shape == (0, 64) and es.shape == (0,)
     ctx.close()
     if name == "bandersnatch":
-        p = pkg.Context(0, pkg.Secp256r1Sha256Tai)
+        p = pkg.Context(0, pkg.Secp256r1Sha256Tai, test_blinding_base=True)
         with pytest.raises(Exception):
             p.te_sw_map_batch(te[:2])
         p.close()

@@ -20,7 +20,7 @@ SUITES = {"bandersnatch": ("BandersnatchSha512Ell2", 1), "jubjub": ("JubJubSha51
 def test_gpu_verify_from_alpha_equals_oracle_and_two_call_form(name):
     import ark_ec_vrfs_amd as pkg
     cls, sid = SUITES[name]
-    ctx = pkg.Context(0, getattr(pkg, cls))
+    ctx = pkg.Context(0, getattr(pkg, cls), test_blinding_base=True)
     co.set_suite(sid)
     try:
         rng = np.random.default_rng(sid)
@@ -105,7 +105,7 @@ def test_gpu_verify_from_alpha_secp256r1_equals_the_oracle():
     """secp256r1 (cofactor 1: nothing to skip): hash-to-curve and verify inside the one call; statuses equal the C oracle's
     on its own H, and hash_to_curve_batch (now through the work-queue counter search) equals the oracle's H."""
     import ark_ec_vrfs_amd as pkg
-    ctx = pkg.Context(0, pkg.Secp256r1Sha256Tai)
+    ctx = pkg.Context(0, pkg.Secp256r1Sha256Tai, test_blinding_base=True)
     rng = np.random.default_rng(256)
     n = 2500
     seeds = np.arange(n, dtype=np.uint64).view(np.uint8).reshape(n, 8)

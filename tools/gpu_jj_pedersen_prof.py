@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ark_ec_vrfs_amd import Context, JubJubSha512Tai, _lib
-ctx = Context(0, suite=JubJubSha512Tai); dev = torch.device('cuda:0'); lib = _lib.load()
+ctx = Context(0, suite=JubJubSha512Tai, test_blinding_base=True); dev = torch.device('cuda:0'); lib = _lib.load()
 n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 20)
 seeds = torch.arange(n, dtype=torch.int64, device=dev).view(torch.uint8).reshape(n, 8)
 sk = torch.empty((n, 32), dtype=torch.uint8, device=dev)

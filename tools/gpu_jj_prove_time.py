@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ark_ec_vrfs_amd import Context, JubJubSha512Tai, _lib
-ctx = Context(0, suite=JubJubSha512Tai); dev = torch.device('cuda:0'); lib = _lib.load()
+ctx = Context(0, suite=JubJubSha512Tai, test_blinding_base=True); dev = torch.device('cuda:0'); lib = _lib.load()
 for logn in (16, 20):
     n = 1 << logn
     seeds = torch.arange(n, dtype=torch.int64, device=dev).view(torch.uint8).reshape(n, 8)

@@ -46,7 +46,7 @@ def mutate(fields, orders, big_endian):
 
 
 def run(name, suite, sid, order, big_endian, p256):
-    ctx = Context(0, suite)
+    ctx = Context(0, suite, test_blinding_base=True)
     seeds = np.arange(N, dtype=np.uint64).view(np.uint8).reshape(N, 8)
     msg = rng.integers(0, 256, (N, 32), dtype=np.uint8)
     sk, _ = ctx.secret_from_seed_batch(seeds)

@@ -8,7 +8,7 @@ from ark_ec_vrfs_amd import Context, Secp256r1Sha256Tai
 from oracle import c_oracle as co, sw_oracle as sw
 n = 1 << 16
 rng = np.random.default_rng(2026)
-ctx = Context(0, Secp256r1Sha256Tai)
+ctx = Context(0, Secp256r1Sha256Tai, test_blinding_base=True)
 co.p256_set_blinding_base(sw.default_blinding_base())
 pts = [rng.integers(0, 256, (n, 33), dtype=np.uint8) for _ in range(5)]
 for p in pts:

@@ -31,7 +31,7 @@ def secrets(order, big_endian):
 
 
 def run(name, suite, sid, order, big_endian, p256):
-    ctx = Context(0, suite)
+    ctx = Context(0, suite, test_blinding_base=True)
     if p256:
         co.p256_set_blinding_base(sw.default_blinding_base())
         ip, pp = co.p256_ietf_prove_batch, co.p256_pedersen_prove_batch

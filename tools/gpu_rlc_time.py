@@ -6,7 +6,7 @@ from ark_ec_vrfs_amd import Context, JubJubSha512Tai, BandersnatchSha512Ell2, _l
 dev = torch.device('cuda:0'); lib = _lib.load()
 logs = [int(x) for x in sys.argv[1:]] or [16, 18, 20]
 for suite in (BandersnatchSha512Ell2, JubJubSha512Tai):
-    ctx = Context(0, suite=suite)
+    ctx = Context(0, suite=suite, test_blinding_base=True)
     st0 = torch.cuda.current_stream().cuda_stream
     for logn in logs:
         n = 1 << logn

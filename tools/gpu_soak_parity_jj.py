@@ -7,7 +7,7 @@ from ark_ec_vrfs_amd import Context, JubJubSha512Tai
 from oracle import c_oracle as co
 n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 18)
 th = min(os.cpu_count() or 8, 64)
-ctx = Context(0, suite=JubJubSha512Tai)
+ctx = Context(0, suite=JubJubSha512Tai, test_blinding_base=True)
 co.set_suite(2)
 seeds = np.arange(n, dtype=np.uint64).view(np.uint8).reshape(n, 8)
 sk, pk = ctx.secret_from_seed_batch(seeds)

@@ -5,7 +5,7 @@ import torch
 from ark_ec_vrfs_amd import Context, JubJubSha512Tai, BandersnatchSha512Ell2, _lib
 dev = torch.device('cuda:0'); lib = _lib.load()
 for suite in (BandersnatchSha512Ell2, JubJubSha512Tai):
-    ctx = Context(0, suite=suite); st0 = torch.cuda.current_stream().cuda_stream
+    ctx = Context(0, suite=suite, test_blinding_base=True); st0 = torch.cuda.current_stream().cuda_stream
     n = 1 << 20
     seeds = torch.arange(n, dtype=torch.int64, device=dev).view(torch.uint8).reshape(n, 8)
     sk = torch.empty((n, 32), dtype=torch.uint8, device=dev); pk = torch.empty((n, 32), dtype=torch.uint8, device=dev)
