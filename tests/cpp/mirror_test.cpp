@@ -40,7 +40,11 @@ static int p256_section(char** a) {
     // the default descriptor of this suite has no Pedersen blinding base (upstream's is not pinned): the scheme is refused
     Context<P> plain(0);
     bool refused = false;
-    try { const auto in0 = Input<P>::new_(plain, Bytes{1}); (void)pedersen::prove(plain, Scalar{1}, *in0, Output<P>{in0->encoded}, Bytes{}); }
+    try {
+      const auto sec0 = Secret<P>::from_seed(plain, Bytes{1});
+      const auto in0 = Input<P>::new_(plain, Bytes{1});
+      (void)pedersen::prove(plain, sec0, *in0, sec0.output(plain, *in0), Bytes{});
+    }
     catch (const ApiError& e) { refused = e.code == VRFHIP_ERR_UNSUPPORTED; }
     CHECK(refused);
   }
