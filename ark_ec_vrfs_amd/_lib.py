@@ -61,6 +61,21 @@ class SuiteDescStruct(ctypes.Structure):
 _lib = None
 
 
+def source_stamp() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.cuh, *.h, *.inc, Makefile, sorted by name).  A profile summary
+    (profiles/pmc_kernels.json) carries the stamp of the sources it was measured on; bench.py attaches its counters to a
+    fresh number only when the stamp still matches (a stale profile must not decorate a new kernel)."""
+    import glob
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.cuh")) + glob.glob(os.path.join(d, "*.h")) +
+                    glob.glob(os.path.join(d, "*.inc")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 ABI_VERSION = 143      # vrfhip_abi_version() of the library this binding was written against
 
 

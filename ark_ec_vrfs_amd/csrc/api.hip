@@ -100,6 +100,8 @@ struct vrfhip_ctx {
   uint32_t* d_pair_prep = nullptr;         // Miller-loop lines of shared G2 points (pairing check, SRS case)
   int cus = 256;
   uint32_t flags = 0;                      // VRFHIP_FLAG_PREVALIDATED_* (vrfhip_ctx_set_flags)
+  uint8_t* d_h2c_ctr = nullptr;            // try-and-increment counters of vrfhip_hash_to_curve_batch: one byte per item of a chunk
+  size_t h2c_cap = 0;
   bool have_blinding = true;               // false: the descriptor's blinding base is all-zero -- a suite without the Pedersen scheme
   bool has_pedersen() const { return sw ? d_p256_comb_b != nullptr : have_blinding; }
   // test / tuning knobs (vrfhip_debug_set; nothing in the product reads the environment)
@@ -587,6 +589,7 @@ void vrfhip_ctx_destroy(vrfhip_ctx* ctx) {
     if (ctx->d_pair_prep) (void)hipFree(ctx->d_pair_prep);
     if (ctx->d_p256_comb) (void)hipFree(ctx->d_p256_comb);
     if (ctx->d_p256_comb_b) (void)hipFree(ctx->d_p256_comb_b);
+    if (ctx->d_h2c_ctr) (void)hipFree(ctx->d_h2c_ctr);
     if (ctx->h_pin) {
       std::memset(ctx->h_pin, 0, 2 * ctx->pin_slot_bytes);     // may have staged caller data
       (void)hipHostFree(ctx->h_pin);
@@ -1797,30 +1800,35 @@ int32_t vrfhip_hash_to_curve_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
   if (!d_points || (!d_msg && (msg_len || d_msg_off))) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
+  // The try-and-increment suites find their counters with the provers' work-queue search, which wants one byte per item: a
+  // buffer of its own (n bytes, at most 2^20 per chunk) -- not the prove / verify workspace (7 KiB per item), which this
+  // entry point neither needs nor should resize.
+  const size_t chunk = std::min<size_t>(n, size_t(1) << 20);
+  if (ctx->sw || ctx->suite != VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2) {
+    if (ctx->h2c_cap < chunk) {
+      if (ctx->d_h2c_ctr) { (void)hipStreamSynchronize(static_cast<hipStream_t>(stream)); (void)hipFree(ctx->d_h2c_ctr); ctx->d_h2c_ctr = nullptr; ctx->h2c_cap = 0; }
+      if (hipMalloc(&ctx->d_h2c_ctr, chunk) != hipSuccess) return fail(VRFHIP_ERR_OOM, "hipMalloc(hash-to-curve counters) failed");
+      ctx->h2c_cap = chunk;
+    }
+  }
   if (ctx->sw) {
-    int32_t rc = ensure_workspace(ctx, n);
-    if (rc) return rc;
-    for (size_t base = 0; base < n; base += ctx->ws_cap) {
-      const size_t m = std::min(ctx->ws_cap, n - base);
+    for (size_t base = 0; base < n; base += chunk) {
+      const size_t m = std::min(chunk, n - base);
       BytesView mv = d_msg_off ? make_view(d_msg, d_msg_off + base, msg_len, false)
                                : make_view(d_msg ? d_msg + base * (size_t)msg_len : d_msg, nullptr, msg_len, false);
-      p256::launch_hash_to_curve(m, mv, d_points + base * 33, ctx->T.sq.str, static_cast<hipStream_t>(stream), ctx->p256_ws.flags,
+      p256::launch_hash_to_curve(m, mv, d_points + base * 33, ctx->T.sq.str, static_cast<hipStream_t>(stream), ctx->d_h2c_ctr,
                                  ctx->d_queue);
     }
   } else if (ctx->suite == VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2) {
     FIELD_CALL(ctx, launch_hash_to_curve((int)ctx->suite, n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T,
                                          static_cast<hipStream_t>(stream)));
   } else {
-    // try-and-increment suites: the counters are found by the provers' work-queue search first (one flag byte per item of
-    // the workspace holds them), chunk by chunk of the workspace
-    int32_t rc = ensure_workspace(ctx, n);
-    if (rc) return rc;
-    for (size_t base = 0; base < n; base += ctx->ws_cap) {
-      const size_t m = std::min(ctx->ws_cap, n - base);
+    for (size_t base = 0; base < n; base += chunk) {
+      const size_t m = std::min(chunk, n - base);
       BytesView mv = d_msg_off ? make_view(d_msg, d_msg_off + base, msg_len, false)
                                : make_view(d_msg ? d_msg + base * (size_t)msg_len : d_msg, nullptr, msg_len, false);
       FIELD_CALL(ctx, launch_hash_to_curve((int)ctx->suite, m, mv, d_points + base * 32, ctx->T, static_cast<hipStream_t>(stream),
-                                           ctx->ws.flags, ctx->d_queue));
+                                           ctx->d_h2c_ctr, ctx->d_queue));
     }
   }
   HIP_TRY(hipGetLastError());

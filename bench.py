@@ -112,7 +112,8 @@ def assemble_final_line(out, configs_file=None):
     the number of secondary legs.  `out` is the full record (with "configs"); the legs themselves go to an earlier stdout
     line and to `configs_file`.  Pure: no I/O, so tests/test_bench_launch.py can size-check it on CPU."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "scaling_modes",
-            "vs_baseline", "dtype", "data", "config", "roofline", "valu", "stage_ms_per_step", "proofs_per_sec", "cpu_baseline")
+            "vs_baseline", "dtype", "data", "config", "roofline", "valu", "pmc_stale", "stage_ms_per_step", "proofs_per_sec",
+            "cpu_baseline")
     line = {k: out[k] for k in keep if k in out}
     if "prevalidated" in out:
         line["prevalidated"] = {k: out["prevalidated"][k] for k in ("value", "ms_per_step") if k in out["prevalidated"]}
@@ -279,14 +280,36 @@ def timed(D, fn, steps, warmup, gather_t=None, n_per_rank=0, n_global=None):
     return D.max_elapsed(time.perf_counter() - t0), out
 
 
+_PMC = None
+
+
+def pmc_table():
+    """profiles/pmc_kernels.json if it was measured on THESE kernel sources, else {} (and why).  The file carries the
+    sha256 of csrc/ at profiling time ("_stamp": tools/summarize_profiles3.py); a bench run on edited kernels reports
+    `valu` / `roofline.traffic` as null instead of replaying counters of other code."""
+    global _PMC
+    if _PMC is None:
+        path = os.environ.get("VRFHIP_BENCH_PMC_FILE") or os.path.join(ROOT, "profiles", "pmc_kernels.json")
+        tab, why = {}, "no profiles/pmc_kernels.json"
+        if os.path.exists(path):
+            from ark_ec_vrfs_amd._lib import source_stamp
+            raw = json.load(open(path))
+            st = raw.get("_stamp") or {}
+            if st.get("source_sha256") == source_stamp():
+                tab, why = raw, None
+            else:
+                why = "profiles/pmc_kernels.json was measured on other kernel sources (stamp %s..., now %s...): re-profile" % (
+                    str(st.get("source_sha256"))[:12], source_stamp()[:12])
+        _PMC = (tab, why)
+    return _PMC
+
+
 def pmc_for(name, log2_batch):
     """HBM traffic and executed vector instructions per launch of a config's dominant kernel, measured with
-    rocprofv3 --pmc on the same command line (profiles/pmc_kernels.json; tools/summarize_profiles2.py)."""
-    path = os.path.join(ROOT, "profiles", "pmc_kernels.json")
-    if os.path.exists(path):
-        e = json.load(open(path)).get(name)
-        if e and e.get("log2_batch") == log2_batch:
-            return e
+    rocprofv3 --pmc on the same command line (profiles/pmc_kernels.json; tools/summarize_profiles3.py)."""
+    e = pmc_table()[0].get(name)
+    if e and e.get("log2_batch") == log2_batch:
+        return e
     return None
 
 
@@ -736,14 +759,14 @@ def cfg_pairing(D, args, ctx, want_cpu):
                      "ms_per_step": el / args.config_steps * 1e3, "bytes_per_unit": bytes_per, "roofline": rf, "valu": v}
 
     run("pairing_check", lambda: ctx.pairing_check_batch_dev(d1, d2, pstat), B_PAIRING,
-        "k_pairing_check2_quad (one item per DPP quad: 2-pair Miller loop + final exponentiation)",
+        "k_pairing_check2_oct (one item per 8 lanes, Fp2 split over lane pairs: 2-pair Miller loop + final exponentiation)",
         "BLS12-381 pairing check, 2 (G1, G2) pairs per item, batch 2^14 per GPU (BASELINE.json configs[4]); "
         "8 fixture items tiled (the kernel has no data-dependent shortcuts)", "pairing_check")
     s1 = np.stack([hx(h) for h in fx["shared"]])
     ds1 = torch.from_numpy(np.tile(s1, (k // s1.shape[0], 1)).copy()).to(D.dev)
     dsh = torch.from_numpy(hx(fx["shared_g2"]).copy()).to(D.dev)
     run("pairing_check_shared_g2", lambda: ctx.pairing_check_batch_dev(ds1, dsh, pstat, g2_shared=True), B_PAIRING_SHARED,
-        "k_pairing_check2_quad_prepared (lines of the shared G2 pair prepared once per context)",
+        "k_pairing_check2_oct_prepared (lines of the shared G2 pair prepared once per context)",
         "the same check against ONE shared G2 pair (a KZG verifier's SRS), batch 2^14 per GPU", "pairing_check_shared")
     # the same shared-G2 checks as ONE batch: two G1 multi-scalar multiplications + one pairing (random linear
     # combination).  At 2^14 the single pairing's latency (one quad) is the whole cost; the amortised rate shows at 2^18.
@@ -965,7 +988,7 @@ def run_rank(args):
                                       "deserialisation" if checked else "inputs declared pre-validated (no subgroup check)"),
                        "global_batch": main_global, "parallelism": "items sharded x%d, result gather only" % world,
                        "subgroup_check": checked},
-            "roofline": r, "valu": v,
+            "roofline": r, "valu": v, "pmc_stale": pmc_table()[1],
             "stage_ms_per_step": {"decode": stage_ms[0], "straus_v": stage_ms[1], "straus_u": stage_ms[2],
                                   "finish": stage_ms[3]},
             "proofs_per_sec": n / prove_s,

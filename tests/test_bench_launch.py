@@ -155,3 +155,33 @@ def test_last_stdout_line_of_a_run_is_the_short_headline(tmp_path):
         open(os.path.join(ROOT, "profiles", "r03", "bench_n1_default.json")).read().strip().splitlines()[-1])["value"]
     # the driver's 8 KB tail always contains the whole last line
     assert len(lines[-1].encode()) + 1 < 8192
+
+
+def test_stale_profile_counters_are_not_attached(tmp_path):
+    """`valu` and `roofline.traffic` are replayed from profiles/pmc_kernels.json.  The file carries the
+    sha256 of the kernel sources it was measured on; a stamp that does not match the tree (or no stamp) gives no counters
+    and a reason, a matching stamp gives them."""
+    from ark_ec_vrfs_amd._lib import source_stamp
+    b = _load_bench()
+    entry = {"ietf_verify": {"log2_batch": 20, "hbm_bytes_per_launch": 1.0, "valu_lane_instructions_per_launch": 2.0}}
+    f = tmp_path / "pmc.json"
+    for stamp, live in (({"source_sha256": source_stamp()}, True), ({"source_sha256": "0" * 64}, False), (None, False)):
+        d = dict(entry)
+        if stamp is not None:
+            d["_stamp"] = stamp
+        f.write_text(json.dumps(d))
+        os.environ["VRFHIP_BENCH_PMC_FILE"] = str(f)
+        try:
+            b._PMC = None
+            tab, why = b.pmc_table()
+            assert (b.pmc_for("ietf_verify", 20) is not None) == live and (why is None) == live
+            assert b.pmc_for("ietf_verify", 19) is None
+            r, v = b.roofline("k", 161, 1 << 20, 14.5, 20, b.pmc_for("ietf_verify", 20))
+            assert (r["traffic"] is not None) == live and (v is not None) == live
+        finally:
+            del os.environ["VRFHIP_BENCH_PMC_FILE"]
+            b._PMC = None
+    # the committed summary either matches the committed sources or is ignored -- never silently replayed
+    tab, why = b.pmc_table()
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_kernels.json")))
+    assert bool(tab) == ((committed.get("_stamp") or {}).get("source_sha256") == source_stamp()) and bool(tab) == (why is None)

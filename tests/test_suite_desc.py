@@ -231,9 +231,10 @@ def test_default_descriptors_carry_only_the_pinned_blinding_base():
         c = Context(0, suite=suite)
         try:
             assert c.desc().blinding_base == bytes(64)
-            sk = np.arange(1, 1 + 4 * 32, dtype=np.uint8).reshape(4, 32) % 200
+            sk, _ = c.secret_from_seed_batch(np.arange(4 * 8, dtype=np.uint8).reshape(4, 8))
             msgs = [b"m%d" % i for i in range(4)]
             pr = c.ietf_prove_batch(sk, msgs=msgs, ad=b"x")                     # the IETF scheme is there
+            assert not pr["status"].any()
             assert not c.ietf_verify_batch(pr["pk"], pr["input"], pr["output"], pr["c"], pr["s"], ad=b"x").any()
             with pytest.raises(VrfHipError, match="blinding base"):
                 c.pedersen_prove_batch(sk, msgs=msgs, ad=b"x")

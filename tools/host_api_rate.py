@@ -42,12 +42,23 @@ def three_contexts():
         t.join()
 
 
+from ark_ec_vrfs_amd import ietf_verify_batch_multi  # noqa: E402
+extra8 = [Context(0) for _ in range(5)]         # 8 contexts in ONE process: what the Rust crate's _multi call does on an 8-GPU node
+ctx8 = [ctx] + others + extra8
+
+
+def eight_contexts_multi():
+    st8 = ietf_verify_batch_multi(ctx8, *host, ad=b"")
+    assert not st8.any()
+
+
 for name, fn in (("device pointers", lambda: (ctx.ietf_verify_batch_dev(pk, hh, g, c, s, status), torch.cuda.synchronize())),
                  ("host pointers (pageable numpy)", lambda: ctx.ietf_verify_batch(*host, ad=b"")),
                  ("host pointers (vrfhip_host_alloc)", lambda: ctx.ietf_verify_batch(*pinned, ad=b"")),
-                 ("3 contexts x 1/3 batch, pageable", three_contexts)):
+                 ("3 contexts x 1/3 batch, pageable", three_contexts),
+                 ("vrfhip_ietf_verify_batch_multi, 8 contexts (one device), pageable", eight_contexts_multi)):
     fn()
     best = 1e9
     for _ in range(5):
         t0 = time.perf_counter(); r = fn(); best = min(best, time.perf_counter() - t0)
-    print("%-32s %.2f ms per 2^20 verifies = %.3e verifies/s" % (name, best * 1e3, n / best), flush=True)
+    print("%-66s %.2f ms per 2^20 verifies = %.3e verifies/s" % (name, best * 1e3, n / best), flush=True)

@@ -18,7 +18,14 @@ usage: python tools/summarize_profiles3.py gpurun_out/r03prof profiles/r03"""
 import collections, csv, glob, json, os, re, shutil, sys
 
 src, dst = sys.argv[1], sys.argv[2]
+ROUND = sys.argv[3] if len(sys.argv) > 3 else "r03"
 os.makedirs(dst, exist_ok=True)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ark_ec_vrfs_amd._lib import source_stamp, LIB_PATH  # noqa: E402  (what the counters were measured on)
+import hashlib  # noqa: E402
+STAMP = {"source_sha256": source_stamp(), "lib_sha256": hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest(),
+         "round": ROUND, "note": "sha256 of ark_ec_vrfs_amd/csrc sources (ark_ec_vrfs_amd._lib.source_stamp) and of libvrfhip.so "
+                                 "at profiling time; bench.py attaches these counters only while the source stamp matches"}
 VALU_PEAK = 256 * 4 * 16 * 2.4e9
 
 
@@ -87,7 +94,7 @@ json.dump({"command": "rocprofv3 {--kernel-trace --stats | --pmc <one group per 
            "note": "averages per launch; valu_frac_of_peak = SQ_INSTS_VALU x 64 / duration / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz); "
                    "clock_ghz_observed = GRBM_GUI_ACTIVE / 8 / duration; issue_slot_frac = SQ_INSTS_VALU x 4 / (cycles x 1024 SIMDs); "
                    "issue_cycle_frac prices non-INT64 instructions at 2 cycles",
-           "kernels": rows}, open(os.path.join(dst, "rocprofv3_kernels_by_grid.json"), "w"), indent=1)
+           "_stamp": STAMP, "kernels": rows}, open(os.path.join(dst, "rocprofv3_kernels_by_grid.json"), "w"), indent=1)
 
 # config -> (kernel substring, grid) of its dominant kernel
 N20, N16, N14 = 1 << 20, 1 << 16, 1 << 14
@@ -99,12 +106,12 @@ CONFIGS = [("ietf_verify", "k_verify_straus<vrf::SuiteBS, 1>", N20, 20), ("ietf_
            ("pedersen_prove_jubjub", "k_prove_mul<vrf::SuiteJJ>", 2 * N20, 20),
            ("pedersen_verify_jubjub", "k_ped_verify_straus<vrf::SuiteJJ, 0>", N20, 20),
            ("pedersen_rlc_jubjub", "k_rlc_decode<vrf::SuiteJJ, 2>", None, 20),
-           ("pairing_check", "k_pairing_check2_quad(", 4 * N14, 14), ("pairing_check_shared", "k_pairing_check2_quad_prepared", 4 * N14, 14)]
+           ("pairing_check", "k_pairing_check2_oct(", 8 * N14, 14), ("pairing_check_shared", "k_pairing_check2_oct_prepared", 8 * N14, 14)]
 out = collections.OrderedDict()
 for cfg, pat, grid, lg in CONFIGS:
     pat = pat.rstrip("(")
     cand = [e for e in rows if (e["kernel"].endswith(pat) or pat in e["kernel"]) and (grid is None or abs(e["grid"] - grid) <= 256)
-            and not (pat.endswith("quad") and "prepared" in e["kernel"])]
+            and not (pat.endswith(("quad", "oct")) and "prepared" in e["kernel"])]
     if not cand:
         continue
     e = max(cand, key=lambda x: x.get("launches", 0))
@@ -114,7 +121,8 @@ for cfg, pat, grid, lg in CONFIGS:
                 "clock_ghz_observed": e.get("clock_ghz_observed"), "issue_slot_frac": e.get("issue_slot_frac"),
                 "issue_cycle_frac": e.get("issue_cycle_frac"),
                 "scratch_bytes_per_lane": (e.get("dispatch") or {}).get("Scratch_Size"),
-                "source": "profiles/r03/rocprofv3_kernels_by_grid.json (tools/profile_round3.sh)"}
+                "source": "profiles/%s/rocprofv3_kernels_by_grid.json (tools/profile_round4.sh)" % ROUND}
+out["_stamp"] = STAMP
 json.dump(out, open(os.path.join(dst, "pmc_kernels.json"), "w"), indent=1)
 for e in rows[:60]:
     print("%-62s grid %-9d x%-3d %9.3f ms  hbm %.3g B  %.2f GHz  slot %.2f  cyc %.2f  scratch %s" % (
