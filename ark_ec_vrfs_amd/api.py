@@ -234,6 +234,7 @@ class Context:
     # VRFHIP_FLAG_PREVALIDATED_* (include/vrfhip.h)
     PREVALIDATED_PUBLIC, PREVALIDATED_INPUT, PREVALIDATED_OUTPUT, PREVALIDATED_PROOF, PREVALIDATED_ALL = 1, 2, 4, 8, 15
     PROVE_POINTS_AFFINE = 16        # VRFHIP_FLAG_PROVE_POINTS_AFFINE: the provers write points as x || y (64 B)
+    CT_TABLES = 64                  # VRFHIP_FLAG_CT_TABLES: the provers' per-proof table lookups read all eight entries
     COORDS_MONT256 = 32             # VRFHIP_FLAG_COORDS_MONT256: x || y pairs are arkworks' in-memory Montgomery limbs
 
     def point_bytes(self) -> int:
@@ -256,7 +257,7 @@ class Context:
         return int(self._lib.vrfhip_ctx_get_flags(self._h))
 
     # test / tuning knobs (vrfhip_debug_set): the library never reads the environment
-    PAIRING_LAYOUTS = {"auto": 0, "lane": 1, "quad": 2, "row": 3, "tri": 4, "oct": 5, "noprep": 0x100}
+    PAIRING_LAYOUTS = {"auto": 0, "lane": 1, "quad": 2, "row": 3, "tri": 4, "oct": 5, "oct1": 6, "noprep": 0x100}
 
     def debug_set(self, key: int, value: int) -> None:
         _lib.check(self._lib.vrfhip_debug_set(self._h, int(key), int(value)), "vrfhip_debug_set")
@@ -339,7 +340,7 @@ class Context:
     def keyset_create(self, pks):
         """`Public` keys -> KeySet (validated points + one 881 KB comb each, resident in HBM).  Returns
         (keyset, status): status[i] = 0, or 2 if key i is not a point of the prime-order subgroup."""
-        k = np.ascontiguousarray(pks, dtype=np.uint8).reshape(-1, 32)
+        k = np.ascontiguousarray(pks, dtype=np.uint8).reshape(-1, self.point_bytes())
         st = np.empty(k.shape[0], dtype=np.uint8)
         h = ctypes.c_void_p()
         _lib.check(self._lib.vrfhip_keyset_create(self._h, k.shape[0], _ptr(k), _ptr(st), ctypes.byref(h)),
@@ -481,7 +482,7 @@ class Context:
         seed: 32 secret random bytes (default os.urandom).  affine: the five point arrays are (n, 64)
         x || y little-endian (arkworks `Affine`) instead of compressed encodings."""
         import os
-        pw = 64 if affine else 32
+        pw = 64 if affine else self.point_bytes()
         arrs = [np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, pw) for x in (inp, out, pk_com, r, ok)]
         arrs += [np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (s, sb)]
         n = arrs[0].shape[0]
@@ -531,12 +532,13 @@ class Context:
 
     def msm(self, bases_xy, scalars):
         """`VariableBaseMSM::msm`: sum_i scalars[i] * bases[i].  bases_xy: (n, 64) affine x||y LE;
-        scalars: (n, 32) LE.  Returns (point32, xy64); raises InvalidData on bad inputs."""
+        scalars: (n, 32) in the suite's scalar encoding (LE; big-endian on secp256r1).  Returns (point, xy64) with the
+        point in the suite's encoding (32 bytes; 33-byte Sec1 on secp256r1); raises InvalidData on bad inputs."""
         b = np.ascontiguousarray(bases_xy, dtype=np.uint8).reshape(-1, 64)
         k = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
         if b.shape[0] != k.shape[0]:
             raise ValueError("ragged batch")
-        out, xy, st = np.empty(32, np.uint8), np.empty(64, np.uint8), np.empty(1, np.uint8)
+        out, xy, st = np.empty(self.point_bytes(), np.uint8), np.empty(64, np.uint8), np.empty(1, np.uint8)
         _lib.check(self._lib.vrfhip_msm(self._h, b.shape[0], _ptr(b) if b.size else None, _ptr(k) if k.size else None,
                                         _ptr(out), _ptr(xy), _ptr(st)), "vrfhip_msm")
         if st[0] != ST_OK:

@@ -20,6 +20,12 @@
 #include "p256.h"
 
 namespace vrf {
+// k_pairing_oct.hip: per-item G2 points as two kernels (lines -> HBM -> Miller loop + final exponentiation)
+size_t pairing_oct_lines_bytes(size_t items);
+void launch_pairing_check2_oct_split(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status, void* ws,
+                                     size_t chunk, hipStream_t st);
+constexpr size_t PAIRING_OCT_SPLIT_MIN_ITEMS = 2048;      // below: one item per quad (k_pairing_quad.hip), the shorter chain
+constexpr size_t PAIRING_OCT_SPLIT_CHUNK = size_t(1) << 15;   // items per pass: 45.7 KB of lines each, 1.5 GB of workspace
 // k_pairing_row.hip: the selftest operands through the row-distributed tower (bls12_row.cuh); ORs 64 / 128 into status[i]
 void launch_pairing_row_selftest(size_t n, const uint8_t* in, uint8_t* status, hipStream_t st);
 // The kernel objects of the other base fields (field.h): this file is compiled for field 0 (kernels.h declared its
@@ -626,7 +632,7 @@ void vrfhip_host_free(void* p) {
 
 int32_t vrfhip_ctx_set_flags(vrfhip_ctx* ctx, uint32_t flags) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (flags & ~(uint32_t)(VRFHIP_FLAG_PREVALIDATED_ALL | VRFHIP_FLAG_PROVE_POINTS_AFFINE | VRFHIP_FLAG_COORDS_MONT256))
+  if (flags & ~(uint32_t)(VRFHIP_FLAG_PREVALIDATED_ALL | VRFHIP_FLAG_PROVE_POINTS_AFFINE | VRFHIP_FLAG_COORDS_MONT256 | VRFHIP_FLAG_CT_TABLES))
     return fail(VRFHIP_ERR_BAD_ARG, "unknown flag bits");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   ctx->flags = flags;
@@ -643,7 +649,7 @@ int32_t vrfhip_debug_set(vrfhip_ctx* ctx, int32_t key, int32_t value) {
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   switch (key) {
     case VRFHIP_DEBUG_PAIRING_LAYOUT:
-      if ((value & 0xff) > PAIRING_OCT || (value & ~0x1ff)) return fail(VRFHIP_ERR_BAD_ARG, "unknown pairing layout");
+      if ((value & 0xff) > 6 || (value & ~0x1ff)) return fail(VRFHIP_ERR_BAD_ARG, "unknown pairing layout");
       ctx->dbg_pairing_layout = value;
       return VRFHIP_SUCCESS;
     case VRFHIP_DEBUG_PIPE_FIRST_LOG2:
@@ -1096,6 +1102,7 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
       a.gamma = at(o.output, base, ptw); a.c = at(o.c, base, 32); a.s = at(o.s, base, 32);
       a.pk_out = at(o.pk, base, ptw); a.h_out = at(o.input, base, 33); a.status = at(o.status, base, 1);
       a.pedersen = pedersen ? 1 : 0;
+      a.ct_tables = (ctx->flags & VRFHIP_FLAG_CT_TABLES) ? 1 : 0;
       a.r_out = at(o.r, base, ptw); a.ok_out = at(o.ok, base, ptw); a.sb_out = at(o.sb, base, 32);
       a.blinding_out = at(o.blinding, base, 32);
       a.comb_b = ctx->d_p256_comb_b;
@@ -1129,7 +1136,7 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
     a.h_out = at(o.input, base, 32);
     a.status = at(o.status, base, 1);
     a.pedersen = pedersen ? 1 : 0;
-    a.check_mask = ctx->check_mask();
+    a.check_mask = ctx->check_mask() | ((ctx->flags & VRFHIP_FLAG_CT_TABLES) ? (uint32_t)CHK_CT_TABLES : 0u);
     a.r_out = at(o.r, base, ptw); a.ok_out = at(o.ok, base, ptw); a.sb_out = at(o.sb, base, 32);
     a.blinding_out = at(o.blinding, base, 32);
     a.ws = ctx->ws;
@@ -1365,7 +1372,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
                      const uint8_t seed[32], uint8_t* d_status,
                      uint8_t* d_fail_flag, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the batched Pedersen verifier takes Sec1 points (the x || y form is not built)");
   if (!d_fail_flag || !seed) return fail(VRFHIP_ERR_BAD_ARG, "NULL fail flag or seed");
   if (n && (!d_input || !d_output || !d_pk_com || !d_r || !d_ok || !d_s || !d_sb || !d_status))
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
@@ -1376,6 +1383,42 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
   hipStream_t st = static_cast<hipStream_t>(stream);
   HIP_TRY(hipMemsetAsync(d_fail_flag, 0, 1, st));
   if (n == 0) return VRFHIP_SUCCESS;
+  if (ctx->sw) {
+    // secp256r1: launch groups of at most 2^20 proofs, each ONE MSM over 5 m + 2 points; no per-proof workspace at all
+    const size_t cap = std::min<size_t>(n, size_t(1) << 20);
+    const size_t Ncap = 5 * cap + 2;
+    const int groups_cap = p256::msm_groups(Ncap, ctx->cus);
+    const size_t msm_b = Stage::pad(p256::msm_workspace_bytes(Ncap, groups_cap));
+    int32_t rc2 = ensure_msm_workspace(ctx, msm_b + Stage::pad(digest_ws_bytes(cap)) + 256);
+    if (rc2) return rc2;
+    uint8_t* d_dws = static_cast<uint8_t*>(ctx->d_msm_ws) + msm_b;
+    uint8_t* d_rt = d_dws + Stage::pad(digest_ws_bytes(cap));
+    for (size_t base = 0; base < n; base += cap) {
+      const size_t m = std::min(cap, n - base), N = 5 * m + 2;
+      p256::RlcArgs a{};
+      a.n = m;
+      a.index0 = base;
+      a.h = d_input + base * 33; a.gamma = d_output + base * 33; a.pk_com = d_pk_com + base * 33;
+      a.r = d_r + base * 33; a.ok = d_ok + base * 33; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
+      a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
+      a.status = d_status + base;
+      a.L = p256::msm_layout(N, p256::msm_groups(N, ctx->cus), ctx->d_msm_ws);
+      std::memcpy(a.seed, seed, 32);
+      std::memcpy(a.gen_xy, ctx->desc.generator, 64);
+      std::memcpy(a.b_xy, ctx->desc.blinding_base, 64);
+      a.str = ctx->T.sq.str;
+      DigestSrc ds{};
+      const uint8_t* arr[7] = {a.h, a.gamma, a.pk_com, a.r, a.ok, a.s, a.sb};
+      for (int j = 0; j < 7; ++j) { ds.p[j] = arr[j]; ds.w[j] = j < 5 ? 33u : 32u; }
+      ds.n_arr = 7;
+      ds.ad = a.ad;
+      launch_batch_digest(ds, m, base, d_dws, d_rt, st);
+      a.root = d_rt;
+      p256::launch_pedersen_rlc(a, d_fail_flag, st, prof_events(ctx));
+    }
+    HIP_TRY(hipGetLastError());
+    return VRFHIP_SUCCESS;
+  }
   int32_t rc = ensure_workspace(ctx, n);
   if (rc) return rc;
   size_t msm_bytes;
@@ -1427,7 +1470,7 @@ int32_t rlc_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* inp
                       const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
                       const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->sw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the batched Pedersen verifier takes Sec1 points (the x || y form is not built)");
   if (!seed) return fail(VRFHIP_ERR_BAD_ARG, "seed is NULL");
   if (batch_ok) *batch_ok = 1;
   if (n == 0) return VRFHIP_SUCCESS;
@@ -1437,7 +1480,7 @@ int32_t rlc_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* inp
   size_t adb = blob_bytes(n, ad_off, ad_len, true);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  const size_t pw = affine ? 64 : 32;
+  const size_t pw = affine ? 64 : ctx->pt_bytes();
   size_t need = 5 * Stage::pad(n * pw) + (affine ? 5 : 0) * Stage::pad(n * 32) + 2 * Stage::pad(n * 32) +
                 Stage::pad(adb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n) + 256;
   int32_t rc = ensure_stage(ctx, need);
@@ -1533,12 +1576,20 @@ int32_t vrfhip_pedersen_verify_batch_rlc_affine(vrfhip_ctx* ctx, size_t n, const
 int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, const uint8_t* d_scalars,
                        uint8_t* d_out_point, uint8_t* d_out_xy, uint8_t* d_status, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (!d_out_point || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!d_bases_xy || !d_scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (ctx->sw) {
+    // secp256r1: big-endian scalars, the sum as a 33-byte Sec1 string (0x00 + zeros = the point at infinity)
+    const int groups = p256::msm_groups(n ? n : 1, ctx->cus);
+    int32_t rc = ensure_msm_workspace(ctx, p256::msm_workspace_bytes(n ? n : 1, groups));
+    if (rc) return rc;
+    p256::launch_msm(n, d_bases_xy, ctx->coords_mont256() ? 1 : 0, d_scalars, d_out_point, d_out_xy, d_status, ctx->d_msm_ws, groups, st);
+    HIP_TRY(hipGetLastError());
+    return VRFHIP_SUCCESS;
+  }
   if (n == 0) {                       // empty sum: the identity (0, 1)
     uint8_t id[64] = {0};
     id[32] = 1;
@@ -1563,7 +1614,6 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
 int32_t vrfhip_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases_xy, const uint8_t* scalars,
                    uint8_t* out_point, uint8_t* out_xy, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (!out_point || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!bases_xy || !scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1573,7 +1623,7 @@ int32_t vrfhip_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases_xy, const uin
   Stage sg(ctx->d_stage);
   uint8_t* d_xy = sg.take(n * 64 + 1);
   uint8_t* d_k = sg.take(n * 32 + 1);
-  uint8_t* d_out = sg.take(32);
+  uint8_t* d_out = sg.take(64);             // 32 (Edwards) or 33 (Sec1) bytes are used
   uint8_t* d_oxy = sg.take(64);
   uint8_t* d_st = sg.take(1);
   if (n) {
@@ -1582,7 +1632,7 @@ int32_t vrfhip_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases_xy, const uin
   }
   rc = vrfhip_msm_dev(ctx, n, d_xy, d_k, d_out, d_oxy, d_st, ctx->stream);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(out_point, d_out, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(out_point, d_out, ctx->pt_bytes(), hipMemcpyDeviceToHost, ctx->stream));
   if (out_xy) HIP_TRY(hipMemcpyAsync(out_xy, d_oxy, 64, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipMemcpyAsync(status, d_st, 1, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1599,8 +1649,23 @@ int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
   if (!d_g1 || !d_g2 || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  launch_pairing_check2(n, d_g1, d_g2, g2_shared ? 0 : 384, d_status, static_cast<hipStream_t>(stream),
-                        g2_shared ? ctx->d_pair_prep : nullptr, ctx->dbg_pairing_layout);
+  {
+    // Per-item G2 points from 2^11 items on (and whenever a test asks for the 8-lane layout): the G2 walk and the Miller
+    // loop as two kernels with the lines parked in HBM between them (k_pairing_oct.hip); layout 6 = the same work as ONE
+    // kernel, kept for comparison.
+    const int lay = ctx->dbg_pairing_layout, mode = lay & 0xff;
+    const bool unprepared = !g2_shared || (lay & PAIRING_NOPREP) != 0;
+    if (unprepared && (mode == PAIRING_OCT || (mode == PAIRING_AUTO && n >= PAIRING_OCT_SPLIT_MIN_ITEMS))) {
+      const size_t chunk = std::min<size_t>(n, PAIRING_OCT_SPLIT_CHUNK);
+      int32_t rc = ensure_msm_workspace(ctx, pairing_oct_lines_bytes(chunk));
+      if (rc) return rc;
+      launch_pairing_check2_oct_split(n, d_g1, d_g2, g2_shared ? 0 : 384, d_status, ctx->d_msm_ws, chunk, static_cast<hipStream_t>(stream));
+      HIP_TRY(hipGetLastError());
+      return VRFHIP_SUCCESS;
+    }
+    launch_pairing_check2(n, d_g1, d_g2, g2_shared ? 0 : 384, d_status, static_cast<hipStream_t>(stream),
+                          g2_shared ? ctx->d_pair_prep : nullptr, mode == 6 ? ((lay & ~0xff) | PAIRING_OCT) : lay);
+  }
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
 }

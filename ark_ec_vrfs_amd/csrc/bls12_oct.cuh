@@ -594,6 +594,99 @@ uint32_t pairing_check2_oct(const uint32_t* g1, const uint32_t* g2, Ln ln) {
   }
 }
 
+// ---- per-item G2 points in two kernels: the lines first, then the prepared-lines Miller loop ----
+// With the G2 steps, the squaring and two sparse products in ONE loop the loop body outgrows the instruction cache (the
+// fused sparse product made the single kernel slower, 8.97 -> 9.27 ms per 2^14 checks, while it made the prepared-lines
+// kernel faster).  So the per-item path runs the G2 walk on its own -- all eight lanes busy, four per (P, Q) pair -- and
+// leaves the 68 lines of each pair, already scaled by (x_P, y_P), in HBM: 45.7 KB per item, written and read once, item
+// index fastest so that the eight items of a wave touch consecutive words.  The second kernel is the prepared-lines loop
+// with per-item lines.  word(k, pair, coef, h, limb) of item i sits at lines[((((k * 2 + pair) * 3 + coef) * 2 + h) * 14 + limb) * n + i].
+constexpr int OCT_LINE_WORDS = 2 * 3 * 2 * NLB;            // one Miller step of one item: two pairs x (c0, c1, c4) x two components
+constexpr size_t oct_lines_words_per_item() { return (size_t)G2_LINES * OCT_LINE_WORDS; }
+VRF_HD size_t oct_line_off(int k, int pair, int coef, int h) { return ((((size_t)k * 2 + pair) * 3 + coef) * 2 + h) * NLB; }
+
+// item_flags: 4 words per item: ok0, skip0, ok1, skip1 (ok: both points of the pair decoded and lie on their curves;
+// skip: one of them is the point at infinity -- the pair contributes 1)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline))
+#else
+inline
+#endif
+void pairing_lines_oct(const uint32_t* g1, const uint32_t* g2, uint32_t* lines, uint32_t* item_flags, size_t n, size_t item, Ln ln) {
+  const int pi = ln.j >> 1, sl = ln.j & 1;
+  G1A P;
+  G2A Q;
+  bool i1, i2;
+  G1Aff P1;
+  const bool ok1 = g1_load(P1, i1, g1 + 24 * pi);
+  P.x = P1.x; P.y = P1.y;
+  const bool ok2 = g2_load_o(Q, i2, g2 + 48 * pi, ln);
+  if (sl == 0 && ln.h == 0) {
+    item_flags[4 * item + 2 * pi] = (ok1 && ok2) ? 1u : 0u;
+    item_flags[4 * item + 2 * pi + 1] = (i1 || i2) ? 1u : 0u;
+  }
+  G2T T;
+  T.X = Q.x; T.Y = Q.y; T.Z = o2_one(ln);
+  auto store = [&](int k, const G2L& L) {
+    // the two lanes of a pair that share a component split the three coefficients: s = 0 writes c0 and c1, s = 1 writes c4
+    uint32_t* base = lines + item;
+    if (sl == 0) {
+      const size_t o0 = oct_line_off(k, pi, 0, ln.h), o1 = oct_line_off(k, pi, 1, ln.h);
+#pragma unroll
+      for (int i = 0; i < NLB; ++i) { base[(o0 + i) * n] = (uint32_t)L.c0.v[i]; base[(o1 + i) * n] = (uint32_t)L.c1.v[i]; }
+    } else {
+      const size_t o4 = oct_line_off(k, pi, 2, ln.h);
+#pragma unroll
+      for (int i = 0; i < NLB; ++i) base[(o4 + i) * n] = (uint32_t)L.c4.v[i];
+    }
+  };
+  int k = 0;
+#pragma unroll 1
+  for (int bit = 62; bit >= 0; --bit) {
+    store(k++, g2_double_o(T, P, ln));
+    if ((X_ABS >> bit) & 1) store(k++, g2_add_o(T, Q, P, ln));
+  }
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline))
+#else
+inline
+#endif
+uint32_t pairing_check2_oct_lines(const uint32_t* lines, const uint32_t* item_flags, size_t n, size_t item, Ln ln) {
+  const bool all_ok = item_flags[4 * item] != 0 && item_flags[4 * item + 2] != 0;
+  const bool skip0 = item_flags[4 * item + 1] != 0, skip1 = item_flags[4 * item + 3] != 0;
+  const uint32_t* base = lines + item;
+  auto load = [&](int k, int pair, int coef) {
+    FpS x;
+    const size_t o = oct_line_off(k, pair, coef, ln.h);
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) x.v[i] = (int32_t)base[(o + i) * n];
+    return x;
+  };
+  O12 f = o12_one(ln);
+  int k = 0;
+#pragma unroll 1
+  for (int bit = 62; bit >= 0; --bit) {
+    f = o12_sqr(f, ln);
+    const int nsteps = ((X_ABS >> bit) & 1) ? 2 : 1;
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step, ++k) {
+#pragma unroll 1
+      for (int i = 0; i < 2; ++i) {
+        const FpS l0 = load(k, i, 0), l1 = load(k, i, 1), l4 = load(k, i, 2);
+        const bool skip = i == 0 ? skip0 : skip1;
+        if (!skip) f = o12_mul_by_014<true>(f, l0, l1, l4, ln);
+      }
+    }
+  }
+  f = o12_conj(f);
+  const O12 e = final_exponentiation_o(f, ln);
+  const bool one = o12_is_one(e, ln);
+  if (!all_ok) return PST_INVALID;
+  return one ? PST_OK : PST_FAIL;
+}
+
 // One item per 8 lanes against prepared G2 lines (pairing_prepare_g2_pair).  g1: 2 x 24 words.  Lane pair (column j) of
 // pair j >> 1 scales c1 by x_P (j even) or c4 by y_P (j odd), component-wise.
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -22,7 +22,7 @@ constexpr int DIGEST_MAX_ARRAYS = 8;
 
 struct DigestSrc {
   const uint8_t* p[DIGEST_MAX_ARRAYS];
-  uint32_t w[DIGEST_MAX_ARRAYS];       // bytes per item (multiples of 4; the arrays are 4-byte aligned)
+  uint32_t w[DIGEST_MAX_ARRAYS];       // bytes per item (a multiple of 4 needs a 4-byte aligned array; other widths are read bytewise)
   int n_arr;
   BytesViewLite ad;                    // blob == nullptr: no per-item string
 };
@@ -49,8 +49,12 @@ VRF_HD void digest_leaf(uint8_t* out, const DigestSrc& s, size_t i, uint64_t ind
 #pragma unroll
   for (int j = 0; j < 8; ++j) sha512_put_byte(h, (uint8_t)(index >> (8 * j)));
 #pragma unroll 1
-  for (int a = 0; a < s.n_arr; ++a)
-    sha512_put_mem32(h, reinterpret_cast<const uint32_t*>(s.p[a] + i * (size_t)s.w[a]), s.w[a] / 4);
+  for (int a = 0; a < s.n_arr; ++a) {
+    // 4-byte multiples (the Edwards suites' 32 / 64-byte fields) go in as words, anything else (secp256r1's 33-byte Sec1
+    // points) byte by byte: the same byte string either way
+    if ((s.w[a] & 3u) == 0) sha512_put_mem32(h, reinterpret_cast<const uint32_t*>(s.p[a] + i * (size_t)s.w[a]), s.w[a] / 4);
+    else sha512_put_bytes(h, s.p[a] + i * (size_t)s.w[a], s.w[a]);
+  }
   uint32_t ad_len = 0;
   if (s.ad.blob) {
     const uint8_t* ad;

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(128) k_g1_prep_rlc(G1MsmLayout L, const uint8_
   for (int j = 0; j < 4; ++j) { z[j] = sha512_word_mem(h, j); z[4 + j] = 0; }
 #pragma unroll 1
   for (int s = 0; s < 2; ++s) {
-    g1_store_affine(L.pts + ((size_t)s * L.n + i) * G1_AFF_WORDS, s == 0 ? P[0] : P[1]);
+    g1_store_affine(L.pts + ((size_t)s * L.n + i) * G1_AFF_STRIDE, s == 0 ? P[0] : P[1]);
     g1_write_digits(L.digits + (size_t)s * L.windows * L.n, L.n, i, L.windows, z, !ok || (s == 0 ? inf[0] : inf[1]));
   }
   status[i] = ok ? 0 : 2;
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(128) k_g1_prep_msm(G1MsmLayout L, const uint8_
     if (!decided && k[j] != vrfk::Q32[j]) { lt = k[j] < vrfk::Q32[j]; decided = true; }
   ok = ok && lt;
   if (!ok) L.flags[0] = 2;                    // InvalidData (copied into the caller's status byte)
-  g1_store_affine(L.pts + i * G1_AFF_WORDS, P);
+  g1_store_affine(L.pts + i * G1_AFF_STRIDE, P);
   g1_write_digits(L.digits, L.n, i, L.windows, k, !ok || inf);
 }
 
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(G1_BLOCK) k_g1_buckets(G1MsmLayout L) {
   const size_t hi = lo + L.per_group < L.n ? lo + L.per_group : L.n;
   const uint32_t cnt_all = lo < hi ? (uint32_t)(hi - lo) : 0u;
   const int16_t* dig = L.digits + ((size_t)set * L.windows + w) * L.n + lo;
-  const uint32_t* P = L.pts + ((size_t)set * L.n + lo) * G1_AFF_WORDS;
+  const uint32_t* P = L.pts + ((size_t)set * L.n + lo) * G1_AFF_STRIDE;
   uint32_t* list = L.lists + (size_t)wg * L.list_cap;
   uint32_t* heads = L.heads + (size_t)wg * G1_BLOCK * G1_PT_WORDS;
   g1p_store(bucket + t * G1_PT_WORDS, g1_identity());
@@ -193,14 +193,25 @@ __global__ void __launch_bounds__(G1_BLOCK) k_g1_buckets(G1MsmLayout L) {
     uint32_t cur = G1_NONE;
     bool first_run = true;
     uint32_t* myhead = heads + (size_t)t * G1_PT_WORDS;
+    // the list entry names the point: entries are fetched two trips ahead, points one trip ahead (k_msm.hip)
+    auto load_xy = [&](FpS& x, FpS& y, uint32_t e) {
+      const uint32_t* src = P + (size_t)(e & G1_IDX_MASK) * G1_AFF_STRIDE;
+#pragma unroll
+      for (int j = 0; j < NLB; ++j) { x.v[j] = (int32_t)src[j]; y.v[j] = (int32_t)src[NLB + j]; }
+    };
+    uint32_t ent_n = 0, ent_nn = 0;
+    FpS x_n = FpS(fp_zero()), y_n = FpS(fp_zero());
+    if (cnt > 0) ent_n = list[t];
+    if (cnt > 1) ent_nn = list[(size_t)G1_BLOCK + t];
+    if (cnt > 0) load_xy(x_n, y_n, ent_n);
 #pragma unroll 1
     for (uint32_t i = 0; i < chunk; ++i) {
       if (i < cnt) {
-        const uint32_t ent = list[(size_t)i * G1_BLOCK + t];
-        const uint32_t* src = P + (size_t)(ent & G1_IDX_MASK) * G1_AFF_WORDS;
-        FpS x, y;
-#pragma unroll
-        for (int j = 0; j < NLB; ++j) { x.v[j] = (int32_t)src[j]; y.v[j] = (int32_t)src[NLB + j]; }
+        const uint32_t ent = ent_n;
+        const FpS x = x_n, y = y_n;
+        ent_n = ent_nn;
+        if (i + 2 < cnt) ent_nn = list[(size_t)(i + 2) * G1_BLOCK + t];
+        if (i + 1 < cnt) load_xy(x_n, y_n, ent_n);
         const uint32_t b = (ent >> G1_IDX_BITS) & (G1_BUCKETS - 1);
         if (b != cur) {
           if (cur != G1_NONE) {
@@ -339,7 +350,7 @@ int g1_msm_groups(size_t n, int sets, int windows, int cus) {
 }
 size_t g1_msm_workspace_bytes(size_t n, int sets, int windows, int groups) {
   const size_t per_group = (n + groups - 1) / groups, list_cap = per_group + G1_BLOCK, wgs = (size_t)sets * windows * groups;
-  return pad256((size_t)sets * n * G1_AFF_WORDS * 4) + pad256((size_t)sets * windows * n * 2) + pad256(wgs * list_cap * 4) +
+  return pad256((size_t)sets * n * G1_AFF_STRIDE * 4) + pad256((size_t)sets * windows * n * 2) + pad256(wgs * list_cap * 4) +
          pad256(wgs * G1_BLOCK * G1_PT_WORDS * 4) + pad256(wgs * G1_PT_WORDS * 4) + 256 + 256;
 }
 G1MsmLayout g1_msm_layout(size_t n, int sets, int windows, int groups, void* ws) {
@@ -349,7 +360,7 @@ G1MsmLayout g1_msm_layout(size_t n, int sets, int windows, int groups, void* ws)
   L.list_cap = L.per_group + G1_BLOCK;
   const size_t wgs = (size_t)sets * windows * groups;
   uint8_t* p = static_cast<uint8_t*>(ws);
-  L.pts = reinterpret_cast<uint32_t*>(p); p += pad256((size_t)sets * n * G1_AFF_WORDS * 4);
+  L.pts = reinterpret_cast<uint32_t*>(p); p += pad256((size_t)sets * n * G1_AFF_STRIDE * 4);
   L.digits = reinterpret_cast<int16_t*>(p); p += pad256((size_t)sets * windows * n * 2);
   L.lists = reinterpret_cast<uint32_t*>(p); p += pad256(wgs * L.list_cap * 4);
   L.heads = reinterpret_cast<uint32_t*>(p); p += pad256(wgs * G1_BLOCK * G1_PT_WORDS * 4);

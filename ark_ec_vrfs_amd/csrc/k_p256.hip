@@ -90,9 +90,9 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_verify_decode(p256::VerifyA
   uint32_t c[8], s[8];
   const bool ok = a.affine_in
                       ? p256_verify_decode_affine_item(x, y, enc, c, s, a.pk + i * 64, a.h + i * 64, a.gamma + i * 64, a.c + i * 32,
-                                                       a.s + i * 32, a.affine_in == 2)
+                                                       a.s + i * 32, a.affine_in == 2, a.str.challenge_len)
                       : p256_verify_decode_item(x, y, enc, c, s, a.pk + i * SEC1_LEN, a.h + i * SEC1_LEN, a.gamma + i * SEC1_LEN,
-                                                a.c + i * 32, a.s + i * 32);
+                                                a.c + i * 32, a.s + i * 32, a.str.challenge_len);
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     ws_store_fe(a.ws.aff, cap, i, j * 18, x[j]);
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(P256_BLOCK) __attribute__((amdgpu_waves_per_eu
   ws_load8(k, a.ws.sc, cap, i, (job & 2) ? 8 : 0);
   PtW r;
   if (job & 1) {
-    r = sw_quad_mul(ws_quad_tab(a.ws.tabs, i), 1, k);
+    r = sw_quad_mul(ws_quad_tab(a.ws.tabs, i), 1, k, a.ct_tables != 0);
   } else {
     r = sw_comb_mul(a.comb, k);
     if constexpr (PED != 0) {

@@ -34,6 +34,28 @@ k_pairing_check2_oct_prepared(size_t n, const uint8_t* g1, const uint32_t* prep,
   if ((lane & 7) == 0) status[item] = (uint8_t)st;
 }
 
+// The per-item path in two kernels (bls12_oct.cuh): lines of both pairs -> HBM, then the prepared-lines Miller loop over them
+__global__ void __launch_bounds__(OCT_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_pairing_lines_oct(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint32_t* lines, uint32_t* item_flags) {
+  const size_t lane = (size_t)blockIdx.x * OCT_BLOCK + threadIdx.x;
+  const size_t item = lane >> 3;
+  if (item >= n) return;
+  bls::oct::Ln ln;
+  bls::oct::lanes_of(ln, (int)(threadIdx.x & 63));
+  bls::oct::pairing_lines_oct(reinterpret_cast<const uint32_t*>(g1 + item * 192), reinterpret_cast<const uint32_t*>(g2 + item * g2_stride),
+                              lines, item_flags, n, item, ln);
+}
+__global__ void __launch_bounds__(OCT_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_pairing_check2_oct_lines(size_t n, const uint32_t* lines, const uint32_t* item_flags, uint8_t* status) {
+  const size_t lane = (size_t)blockIdx.x * OCT_BLOCK + threadIdx.x;
+  const size_t item = lane >> 3;
+  if (item >= n) return;
+  bls::oct::Ln ln;
+  bls::oct::lanes_of(ln, (int)(threadIdx.x & 63));
+  const uint32_t st = bls::oct::pairing_check2_oct_lines(lines, item_flags, n, item, ln);
+  if ((lane & 7) == 0) status[item] = (uint8_t)st;
+}
+
 // Test-only: the oct tower operations against the one-lane operations of bls12.cuh on the same operands, and the
 // cross-lane moves themselves.  in: n x 2 x 12 field elements of 48 bytes (little-endian, reduced mod p by the loader);
 // status[i] = bit mask of what differs (0 = all equal): 1 mul, 2 sqr, 4 cyclotomic sqr (of x^((p^6-1)(p^2+1))),
@@ -111,6 +133,22 @@ void launch_pairing_check2_oct(size_t n, const uint8_t* g1, const uint8_t* g2, s
   const size_t lanes = 8 * n;
   hipLaunchKernelGGL(k_pairing_check2_oct, dim3((unsigned)((lanes + OCT_BLOCK - 1) / OCT_BLOCK)), dim3(OCT_BLOCK), 0, st, n, g1, g2,
                      g2_stride, status);
+}
+
+// per-item G2 points through the two kernels above; ws: pairing_oct_lines_bytes(chunk) of device memory, chunk = the number
+// of items one pass may hold (the batch is walked in chunks of that size)
+size_t pairing_oct_lines_bytes(size_t items) { return items * (bls::oct::oct_lines_words_per_item() + 4) * sizeof(uint32_t); }
+void launch_pairing_check2_oct_split(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status, void* ws,
+                                     size_t chunk, hipStream_t st) {
+  for (size_t base = 0; base < n; base += chunk) {
+    const size_t m = n - base < chunk ? n - base : chunk;
+    uint32_t* lines = static_cast<uint32_t*>(ws);
+    uint32_t* flags = lines + m * bls::oct::oct_lines_words_per_item();
+    const unsigned blocks = (unsigned)((8 * m + OCT_BLOCK - 1) / OCT_BLOCK);
+    hipLaunchKernelGGL(k_pairing_lines_oct, dim3(blocks), dim3(OCT_BLOCK), 0, st, m, g1 + base * 192, g2 + base * g2_stride, g2_stride,
+                       lines, flags);
+    hipLaunchKernelGGL(k_pairing_check2_oct_lines, dim3(blocks), dim3(OCT_BLOCK), 0, st, m, lines, flags, status + base);
+  }
 }
 
 void launch_pairing_check2_oct_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st) {

@@ -110,7 +110,7 @@ void PROVE_STAGE(launch_prove_stage1)(const ProveArgs& a, hipStream_t st) {
 
 #if VRF_PROVE_PART == 2
 // stage 2: two lanes per proof: lane 0 -> (sk*H, sk*G), lane 1 -> (k*H, k*G)
-template <class S>
+template <class S, bool CT>
 __global__ void __launch_bounds__(BLOCK) k_prove_mul(ProveArgs a) {
   size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   size_t i = t >> 1;
@@ -128,13 +128,15 @@ __global__ void __launch_bounds__(BLOCK) k_prove_mul(ProveArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) sc[j] = 0;
   }
-  prove_mul_item<S>(a.ws.pts + i * PROVE_PTS_WORDS + half * 2 * UV_WORDS, a.T,
+  prove_mul_item<S, CT>(a.ws.pts + i * PROVE_PTS_WORDS + half * 2 * UV_WORDS, a.T,
                           a.ws.tabs + i * ProveLayout<S>::TAB_WORDS, sc,
                           a.pedersen ? a.ws.aux + i * AUX_WORDS + 16 + half * 8 : nullptr);
 }
 
 void PROVE_STAGE(launch_prove_stage2)(const ProveArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_prove_mul<ProveSuite>, grid_for(2 * a.n), dim3(BLOCK), 0, st, a);
+  // CHK_CT_TABLES (VRFHIP_FLAG_CT_TABLES): the instantiation whose window lookups read all eight entries
+  if (a.check_mask & CHK_CT_TABLES) hipLaunchKernelGGL((k_prove_mul<ProveSuite, true>), grid_for(2 * a.n), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL((k_prove_mul<ProveSuite, false>), grid_for(2 * a.n), dim3(BLOCK), 0, st, a);
 }
 #endif  // part 2
 

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_rlc_decode(RlcArgs a) {
         if (!ok) valid_mask &= ~(1u << (j / 5));
         pa.y = d.y;
         pa.dt = fe_mul(fe_mul(pa.x, pa.y), S::d());
-        pta_store(a.L.pts + rlc_index(p, n, item) * PTA_WORDS, pa);
+        pta_store(a.L.pts + rlc_index(p, n, item) * MSM_PTA_STRIDE, pa);
       }
     }
     // ---- challenge, weights, scalars, digits ----
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(BLOCK, MINW) k_rlc_prep_affine(RlcArgs a) {
       valid = fe_eq(lhs, fe_mul(pa.dt, xyv)) && valid;
       if (a.check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF))
         valid = in_prime_subgroup<S>(pa.x, pa.y, a.T.sq) && valid;
-      pta_store(a.L.pts + rlc_index(p, n, item) * PTA_WORDS, pa);
+      pta_store(a.L.pts + rlc_index(p, n, item) * MSM_PTA_STRIDE, pa);
       // compressed encoding for the challenge: y, sign bit = (x > q - x); slot order pk_com, H, Gamma, R, Ok
       uint32_t e[8];
 #pragma unroll
@@ -218,7 +218,7 @@ __global__ void k_rlc_fixed(RlcArgs a) {
     uint32_t k[8];
     fr_reduce512<S>(k, wide);
     const uint32_t* src = f == 0 ? a.T.g_comb : a.T.b_comb;
-    uint32_t* dst = a.L.pts + (3 * a.n + f) * PTA_WORDS;
+    uint32_t* dst = a.L.pts + (3 * a.n + f) * MSM_PTA_STRIDE;
     for (int j = 0; j < PTA_WORDS; ++j) dst[j] = src[j];
     msm_write_digits<S>(a.L.digits, N, 3 * a.n + f, k, false, false);
   }

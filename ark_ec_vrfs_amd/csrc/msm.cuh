@@ -15,6 +15,9 @@ constexpr int MSM_W = 23;                         // windows: 11*23 = 253 bits
 constexpr int MSM_BUCKETS = 1 << (MSM_C - 1);     // 1024 signed buckets per window
 constexpr int MSM_BLOCK = 512;                    // lanes per workgroup
 constexpr int MSM_PT_WORDS = 4 * NL;              // extended point staged in LDS / HBM: X, Y, Z, T
+constexpr int MSM_PTA_STRIDE = 32;                // words between the affine-cached points of L.pts: 108 B of point in a
+                                                  // 128-B slot, so that a bucket gather touches ONE cache line (27-word
+                                                  // records straddled two: 26.7 GB of traffic per 2^20-proof batch)
 constexpr int MSM_IDX_BITS = 21;                  // list entry: point index inside its group
 constexpr uint32_t MSM_IDX_MASK = (1u << MSM_IDX_BITS) - 1;
 constexpr size_t MSM_MAX_PER_GROUP = size_t(1) << MSM_IDX_BITS;

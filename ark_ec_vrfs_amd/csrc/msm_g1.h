@@ -13,6 +13,7 @@ constexpr int G1_W_FULL = 26;                  // windows of a 255-bit scalar (2
 constexpr int G1_W_SHORT = 13;                 // windows of a 128-bit weight (130 bits)
 constexpr int G1_PT_WORDS = 42;                // projective (X, Y, Z), 14 limbs each
 constexpr int G1_AFF_WORDS = 28;               // Montgomery affine (x, y)
+constexpr int G1_AFF_STRIDE = 32;              // words between the points of L.pts: 112 B in a 128-B slot (one cache line per gather)
 constexpr int G1_IDX_BITS = 21;
 constexpr size_t G1_MAX_PER_GROUP = size_t(1) << G1_IDX_BITS;
 
@@ -22,7 +23,7 @@ struct G1MsmLayout {
   size_t n;
   int sets, windows, groups;
   size_t per_group, list_cap;
-  uint32_t* pts;      // [sets][n][G1_AFF_WORDS]   Montgomery affine coordinates
+  uint32_t* pts;      // [sets][n][G1_AFF_STRIDE]  Montgomery affine coordinates
   int16_t* digits;    // [sets][windows][n]        signed digits in [-511, 512]; 0 = the point takes no part
   uint32_t* lists;    // [sets*windows*groups][list_cap] bucket-sorted entries, lane-transposed
   uint32_t* heads;    // [sets*windows*groups][G1_BLOCK][G1_PT_WORDS] first-run partial sums

@@ -58,6 +58,7 @@ struct ProveArgs {
   int out_affine;                    // != 0: gamma, pk_out, r_out, ok_out are n x 64 B x || y (2: arkworks Montgomery limbs)
   // Pedersen (pedersen != 0): c is unused, pk_out receives pk_com, and the outputs below are written
   int pedersen;
+  int ct_tables;                     // != 0: window-table lookups by secret digits read all eight entries (VRFHIP_FLAG_CT_TABLES)
   uint8_t *r_out, *ok_out, *sb_out;  // n x 33, n x 33, n x 32
   uint8_t* blinding_out;             // nullable: n x 32
   const uint32_t* comb_b;            // fixed-base comb of the blinding base
@@ -77,6 +78,48 @@ struct PedVerifyArgs {
   const uint32_t *comb, *comb_b;
   SuiteStr str;
 };
+
+// ---- multi-scalar multiplication and the batched Pedersen verifier (k_p256_msm.hip) ----
+constexpr int MSM_C = 10;                   // signed window bits: 512 buckets x 108 B = 54 KiB of LDS
+constexpr int MSM_W = 26;                   // windows of a folded 256-bit scalar (260 bits)
+constexpr int MSM_AFF_STRIDE = 32;          // words per affine point slot (x, y: 18 words) -- one 128-B line per gather
+struct MsmL {
+  size_t n;
+  int groups;
+  size_t per_group, list_cap;
+  uint32_t* pts;             // [n][MSM_AFF_STRIDE]  Montgomery affine (x, y)
+  int16_t* digits;           // [MSM_W][n]           signed digits in [-512, 512]; 0 = the point takes no part
+  uint32_t* lists;           // [MSM_W*groups][list_cap] bucket-sorted entries, lane-transposed
+  uint32_t* heads;           // [MSM_W*groups][512][27] first-run partial sums
+  uint32_t* part;            // [MSM_W][groups][27]  per-workgroup window sums
+  uint8_t* flags;            // [256] flags[0] != 0: an input of the plain MSM was invalid
+  unsigned long long* cols;  // [2][8] limb columns of sum z'_i s_i and sum z'_i sb_i (batched verifier)
+};
+int msm_groups(size_t n, int cus);
+size_t msm_workspace_bytes(size_t n, int groups);
+MsmL msm_layout(size_t n, int groups, void* ws);
+// `VariableBaseMSM::msm`: bases n x 64 B x || y (little-endian canonical; mont256: arkworks Montgomery limbs; all-zero = the
+// point at infinity), scalars n x 32 B big-endian (< n).  out33: Sec1 (0x00 + zeros for the point at infinity), out_xy:
+// x || y (all-zero for it); status1[0] = 0 / 2 (a coordinate >= p, a point off the curve, a scalar >= n: outputs zeroed).
+void launch_msm(size_t n, const uint8_t* xy, int mont256, const uint8_t* scalars_be, uint8_t* out33, uint8_t* out_xy, uint8_t* status1,
+                void* ws, int groups, hipStream_t st);
+struct RlcArgs {
+  size_t n;                                     // proofs in this launch group
+  unsigned long long index0;                    // index of the first one in the caller's batch (the weights depend on it)
+  const uint8_t *h, *gamma, *pk_com, *r, *ok;   // n x 33 B Sec1
+  const uint8_t *s, *sb;                        // n x 32 B big-endian
+  BytesViewLite ad;
+  uint8_t* status;                              // [n] 0 = part of the batch sum, 2 = InvalidData (left out of it)
+  MsmL L;                                       // over 5n + 2 points
+  unsigned long long* fixed_cols;               // = L.cols (set by the launcher)
+  uint8_t seed[32];
+  const uint8_t* root;                          // [32] device memory: batch digest of this launch group (digest.cuh)
+  uint8_t gen_xy[64], b_xy[64];                 // the descriptor's generator and blinding base
+  SuiteStr str;
+};
+// fail_flag[0] = 1 unless sum_i z_i (s_i H_i - c_i Gamma_i - Ok_i) + z'_i (s_i G + sb_i B - c_i pk_com_i - R_i) = O over the
+// decodable proofs.  ev: nullptr or 5 events (start, after decode, after buckets, after final, end).
+void launch_pedersen_rlc(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev);
 
 size_t comb_bytes();
 // comb of the point gen_xy (x || y, 32-byte little-endian canonical integers, as vrfhip_suite_desc carries it);

@@ -321,7 +321,16 @@ VRF_HD bool sw_scalar_fold(uint32_t out[8], const uint32_t k[8]) {
   for (int i = 0; i < 8; ++i) out[i] = lt ? nk[i] : k[i];
   return lt;
 }
-VRF_HD PtW sw_quad_mul(const uint32_t* tabs, size_t stride, const uint32_t k[8]) {
+// sw_lookup with an access pattern that does not depend on the digit: all eight entries are read, the wanted one kept by
+// masks (the prover's tables are indexed by digits of sk and of the nonce: VRFHIP_FLAG_CT_TABLES)
+VRF_HD PtW sw_lookup_ct(const uint32_t* tab, size_t stride, int digit) {
+  const int mag = digit < 0 ? -digit : digit;
+  PtW e = sw_identity();
+#pragma unroll 1
+  for (int j = 0; j < SW_WIN; ++j) e = sw_select(mag == j + 1, ptw_load(tab + (size_t)j * SW_ENTRY_WORDS * stride, stride), e);
+  return sw_cneg(digit < 0, e);
+}
+VRF_HD PtW sw_quad_mul(const uint32_t* tabs, size_t stride, const uint32_t k[8], bool ct = false) {
   uint32_t mag[8], rec[8];
   const bool neg = sw_scalar_fold(mag, k);
   const uint32_t top = sw_recode(rec, mag);
@@ -333,7 +342,8 @@ VRF_HD PtW sw_quad_mul(const uint32_t* tabs, size_t stride, const uint32_t k[8])
     for (int j = 0; j < SW_QUAD_TABLES; ++j) {
       int d = scalar_digit4(rec, 16 * j + i);
       if (top && j == 3 && i == 15) d = 8;               // (digit 64, digit 63) = (1, -8)  ->  digit 63 = +8
-      acc = sw_add(acc, sw_lookup(tabs + (size_t)j * SW_TABLE_WORDS * stride, stride, neg ? -d : d));
+      const uint32_t* tj = tabs + (size_t)j * SW_TABLE_WORDS * stride;
+      acc = sw_add(acc, ct ? sw_lookup_ct(tj, stride, neg ? -d : d) : sw_lookup(tj, stride, neg ? -d : d));
     }
   }
   return acc;
@@ -459,9 +469,16 @@ VRF_HD bool p256_scalar_decode(uint32_t out[8], const uint8_t* be) {
 
 // ---- IETF verify, per item [ref src/lib.rs:14 `ietf::Verifier::verify`, RFC 9381 5.3] ----
 // stage 1: decode pk, H, Gamma (33-byte Sec1) and the proof scalars; false = InvalidData
+// The c field: a scalar (mod n) when CHALLENGE_LEN = 32; with a shorter challenge a field holding more than CHALLENGE_LEN
+// bytes is no proof string -- it is kept as it stands and never equals a recomputed challenge (vrf_core.cuh
+// proof_challenge_decode)
+VRF_HD void p256_challenge_decode(uint32_t c[8], const uint8_t* cb, uint32_t challenge_len) {
+  if (challenge_len < 32u) load_be256(c, cb);
+  else (void)p256_scalar_decode(c, cb);
+}
 VRF_HD bool p256_verify_decode_item(FeN (&x)[3], FeN (&y)[3], Sec1W (&enc)[3], uint32_t c[8], uint32_t s[8],
                                     const uint8_t* pk, const uint8_t* h, const uint8_t* gamma, const uint8_t* cb,
-                                    const uint8_t* sb) {
+                                    const uint8_t* sb, uint32_t challenge_len) {
   bool ok = true;
 #pragma unroll 1
   for (int j = 0; j < 3; ++j) {
@@ -475,7 +492,7 @@ VRF_HD bool p256_verify_decode_item(FeN (&x)[3], FeN (&y)[3], Sec1W (&enc)[3], u
     for (int k = 0; k < 3; ++k)
       if (j == k) { x[k] = xx; y[k] = yy; enc[k] = w; }
   }
-  (void)p256_scalar_decode(c, cb);
+  p256_challenge_decode(c, cb, challenge_len);
   return p256_scalar_decode(s, sb) && ok;
 }
 // stage 1 for callers that hold the points as arkworks `Affine { x, y }`: pk, H, Gamma as 64-byte x || y (little-endian
@@ -483,7 +500,7 @@ VRF_HD bool p256_verify_decode_item(FeN (&x)[3], FeN (&y)[3], Sec1W (&enc)[3], u
 // curve is InvalidData; the encodings the challenge hashes are rebuilt from (x, parity of y).
 VRF_HD bool p256_verify_decode_affine_item(FeN (&x)[3], FeN (&y)[3], Sec1W (&enc)[3], uint32_t c[8], uint32_t s[8],
                                            const uint8_t* pk_xy, const uint8_t* h_xy, const uint8_t* gamma_xy, const uint8_t* cb,
-                                           const uint8_t* sb, bool mont256) {
+                                           const uint8_t* sb, bool mont256, uint32_t challenge_len) {
   bool ok = true;
 #pragma unroll 1
   for (int j = 0; j < 3; ++j) {
@@ -501,7 +518,7 @@ VRF_HD bool p256_verify_decode_affine_item(FeN (&x)[3], FeN (&y)[3], Sec1W (&enc
     for (int k = 0; k < 3; ++k)
       if (j == k) { x[k] = xx; y[k] = yy; enc[k] = w; }
   }
-  (void)p256_scalar_decode(c, cb);
+  p256_challenge_decode(c, cb, challenge_len);
   return p256_scalar_decode(s, sb) && ok;
 }
 // stage 3: c' = challenge(pk, H, Gamma, U, V, ad) == c.  1 = the proof does not verify

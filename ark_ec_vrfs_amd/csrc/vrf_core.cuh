@@ -167,7 +167,8 @@ VRF_HD bool subgroup_by_2descent(const FeN& y, const SqrtTables& T) {
 
 // check_mask bits (= the complement of include/vrfhip.h VRFHIP_FLAG_PREVALIDATED_*): which point classes get
 // the prime-order-subgroup test when they are decoded
-enum : uint32_t { CHK_PUBLIC = 1, CHK_INPUT = 2, CHK_OUTPUT = 4, CHK_PROOF = 8 };
+enum : uint32_t { CHK_PUBLIC = 1, CHK_INPUT = 2, CHK_OUTPUT = 4, CHK_PROOF = 8,
+                  CHK_CT_TABLES = 0x100 };      // provers: window-table lookups read all 8 entries (VRFHIP_FLAG_CT_TABLES)
 
 // ------------------------------------------------------------------------ window tables
 // multiples 1..8 of an affine point, cached form, written to `tab` (WIN_TABLE_WORDS words).
@@ -225,6 +226,29 @@ VRF_HD PtC win_lookup(const uint32_t* tab, int digit) {   // |digit| in 0..8
   return e;
 }
 
+// The same lookup with a memory access pattern that does not depend on the digit: all eight entries are read and the
+// wanted one is kept by masks.  For the provers' per-proof tables, whose digits are digits of sk or of the nonce k
+// (VRFHIP_FLAG_CT_TABLES; arkworks' own mul_bigint is not constant-time either -- this is hardening).
+template <bool CT>
+VRF_HD PtC win_lookup_t(const uint32_t* tab, int digit) {
+  if constexpr (!CT) {
+    return win_lookup(tab, digit);
+  } else {
+    const int mag = digit < 0 ? -digit : digit;
+    PtC e = te_identity_cached();
+#pragma unroll 1
+    for (int j = 0; j < WIN_ENTRIES; ++j) {
+      const PtC t = ptc_load(tab + j * PTC_WORDS);
+      const bool hit = mag == j + 1;
+      e.X = fe_select(hit, t.X, e.X);
+      e.Y = fe_select(hit, t.Y, e.Y);
+      e.Z = fe_select(hit, t.Z, e.Z);
+      e.dT = fe_select(hit, t.dT, e.dT);
+    }
+    return e;
+  }
+}
+
 VRF_HD void sel8(uint32_t out[8], bool c, const uint32_t a[8], const uint32_t b[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) out[i] = c ? a[i] : b[i];
@@ -271,7 +295,7 @@ struct Straus4 {
   uint32_t rec[4][4];
   bool neg[4];
 };
-template <class C, int NT = 4>
+template <class C, int NT = 4, bool CT = false>
 VRF_HD PtE straus4(const Straus4& q) {
   PtE acc = te_identity();
 #pragma unroll 1
@@ -289,14 +313,14 @@ VRF_HD PtE straus4(const Straus4& q) {
       const uint32_t* tab = t == 0 ? q.tab[0] : t == 1 ? q.tab[1] : t == 2 ? q.tab[2] : q.tab[3];
       bool neg = t == 0 ? q.neg[0] : t == 1 ? q.neg[1] : t == 2 ? q.neg[2] : q.neg[3];
       int d = scalar_digit4_128(rec, w);
-      acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != neg, t != NT - 1 || w == 0);   // doublings follow
+      acc = te_add_cached<C>(acc, win_lookup_t<CT>(tab, d), (d < 0) != neg, t != NT - 1 || w == 0);   // doublings follow
     }
   }
   return acc;
 }
 
 // k*P for one window table (prove: Gamma = sk*H, kH)
-template <class C>
+template <class C, bool CT = false>
 VRF_HD PtE win_mul(const uint32_t* tab, const uint32_t rec[8], bool negate = false, int top = 63) {
   PtE acc = te_identity();
 #pragma unroll 1
@@ -306,7 +330,7 @@ VRF_HD PtE win_mul(const uint32_t* tab, const uint32_t rec[8], bool negate = fal
       for (int j = 0; j < 4; ++j) acc = te_dbl<C>(acc, j == 3);
     }
     int d = scalar_digit4(rec, w);
-    acc = te_add_cached<C>(acc, win_lookup(tab, d), (d < 0) != negate, w == 0);
+    acc = te_add_cached<C>(acc, win_lookup_t<CT>(tab, d), (d < 0) != negate, w == 0);
   }
   return acc;
 }
@@ -713,6 +737,20 @@ VRF_HD void challenge5(uint32_t c_out[8], const uint32_t (&pts)[5][8], const uin
   fr_reduce256<S>(c_out, be);
 }
 
+// The c field of a proof.  With CHALLENGE_LEN = 32 it is a scalar, decoded mod r as upstream's scalar_decode does (s stays
+// strict).  With a shorter challenge upstream's wire format has CHALLENGE_LEN bytes for it, so a 32-byte field holding more
+// cannot be a proof string: it is compared as it stands and never equals a recomputed challenge (< 2^(8 len)) -- c + r no
+// longer verifies (malleability of the 16-byte-challenge suites at this ABI).
+template <class S>
+VRF_HD void proof_challenge_decode(uint32_t out[8], const uint32_t c[8], const SuiteStr& ss) {
+  if (ss.challenge_len < 32u) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = c[j];
+  } else {
+    fr_reduce256<S>(out, c);
+  }
+}
+
 // ------------------------------------------------------------------------ IETF verify
 // [ref src/lib.rs:14 `ietf::Verifier::verify`]  U = s*G - c*Y, V = s*H - c*Gamma, accept iff
 // challenge(Y, H, Gamma, U, V, ad) == c.  Three stages (three kernels):
@@ -883,7 +921,7 @@ VRF_HD void verify_finish_multi(int K, size_t first, size_t n, uint32_t* pts_bas
         bytes_lite_get(ad, item, adp, adl);
         uint32_t c2[8], cr[8];
         challenge5<S>(c2, pts, adp, adl, ss);
-        fr_reduce256<S>(cr, c);                  // `Proof::c` is decoded mod r upstream (scalar_decode), s strictly
+        proof_challenge_decode<S>(cr, c, ss);
         uint32_t diff = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) diff |= c2[k] ^ cr[k];
@@ -996,7 +1034,7 @@ VRF_HD uint32_t verify_finish_item(const uint32_t* uv, const uint32_t pk[8], con
                                    uint32_t ad_len, const SuiteStr& ss) {
   valid = valid && fr_is_canonical<S>(s);
   uint32_t cr[8];
-  fr_reduce256<S>(cr, c);                        // `Proof::c` is decoded mod r upstream, s strictly
+  proof_challenge_decode<S>(cr, c, ss);
   FeP zin[2] = {fe_load<1, 5>(uv + 2 * NL), fe_load<1, 5>(uv + UV_WORDS + 2 * NL)};
   FeN zi[2];
   fe_batch_inv(zi, zin);
@@ -1308,11 +1346,11 @@ VRF_HD void build_prove_tables(uint32_t* tab, const FeP& x, const FeP& y) {
 }
 // scalar * H from the tables of build_prove_tables: stream t reads digits DIGITS * t + w of a 64-digit signed radix-16
 // string (GLV: k1's 32 digits then k2's 32 digits; else the 253-bit scalar) and adds from table t
-template <class S>
+template <class S, bool CT = false>
 VRF_HD PtE var_base_mul(const uint32_t* tab, const uint32_t scalar[8]);
-template <class S>
+template <class S, bool CT = false>
 VRF_HD PtE prove_var_mul(const uint32_t* tab, const uint32_t scalar[8]) {
-  if constexpr (S::HAS_GLV) return var_base_mul<S>(tab, scalar);     // two-table GLV Straus over {H, psi H}
+  if constexpr (S::HAS_GLV) return var_base_mul<S, CT>(tab, scalar);     // two-table GLV Straus over {H, psi H}
   constexpr int NT = ProveLayout<S>::TABS, ND = ProveLayout<S>::DIGITS;
   uint32_t rec[8];
   const bool neg_lo = false, neg_hi = false;
@@ -1328,7 +1366,7 @@ VRF_HD PtE prove_var_mul(const uint32_t* tab, const uint32_t scalar[8]) {
     for (int t = 0; t < NT; ++t) {
       const int d = scalar_digit4(rec, ND * t + w);
       const bool neg = 2 * t < NT ? neg_lo : neg_hi;
-      acc = te_add_cached<S>(acc, win_lookup(tab + t * WIN_TABLE_WORDS, d), (d < 0) != neg, t != NT - 1 || w == 0);
+      acc = te_add_cached<S>(acc, win_lookup_t<CT>(tab + t * WIN_TABLE_WORDS, d), (d < 0) != neg, t != NT - 1 || w == 0);
     }
   }
   return acc;
@@ -1477,7 +1515,7 @@ VRF_HD void prove_prepare_multi(int K, const DevTables& T, size_t first, size_t 
 #endif
 
 // scalar * P from the GLV table pair {P, psi P} (or the single 253-bit table of a suite without endomorphism)
-template <class S>
+template <class S, bool CT>
 VRF_HD PtE var_base_mul(const uint32_t* tab, const uint32_t scalar[8]) {
   PtE w;
   if constexpr (S::HAS_GLV) {
@@ -1493,19 +1531,19 @@ VRF_HD PtE var_base_mul(const uint32_t* tab, const uint32_t scalar[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { q.rec[2][i] = 0; q.rec[3][i] = 0; }
     q.neg[2] = false; q.neg[3] = false;
-    w = straus4<S, 2>(q);
+    w = straus4<S, 2, CT>(q);
   } else {
     uint32_t rec[8];
     scalar_recode_signed4(rec, scalar);
-    w = win_mul<S>(tab, rec);
+    w = win_mul<S, CT>(tab, rec);
   }
   return w;
 }
 
-template <class S>
+template <class S, bool CT = false>
 VRF_HD void prove_mul_item(uint32_t* out /*2*UV_WORDS*/, const DevTables& T, const uint32_t* tab,
                            const uint32_t scalar[8], const uint32_t* scalar2) {
-  const PtE w = prove_var_mul<S>(tab, scalar);
+  const PtE w = prove_var_mul<S, CT>(tab, scalar);
   fe_store(out, w.X); fe_store(out + NL, w.Y); fe_store(out + 2 * NL, w.Z);
   PtE c;
   if (scalar2) {

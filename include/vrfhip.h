@@ -199,6 +199,13 @@ int32_t vrfhip_ctx_get_desc(const vrfhip_ctx* ctx, vrfhip_suite_desc* out);
  * copies memory instead of converting field elements (into_bigint / from_bigint are a Montgomery product each).  Compressed
  * points, scalars, the suite descriptor and vrfhip_fq_mul_batch are unaffected.  An all-zero pair (failed item) stays all-zero. */
 #define VRFHIP_FLAG_COORDS_MONT256 32u
+/* Hardening of the provers (not a parity matter: arkworks' mul_bigint is not constant-time either, `Secret` only zeroizes).
+ * The provers multiply H by the secret key and by the nonce through per-proof window tables of 8 entries, and a lookup reads
+ * the entry a secret digit names.  With this flag every such lookup reads ALL eight entries and keeps one by masks, so the
+ * addresses the prover touches in its per-proof tables no longer follow the secret (cost: INTEGRATION.md section 4).  The
+ * fixed-base combs of G and of the blinding base stay indexed by secret digits: they are shared read-only tables resident
+ * in L2 / MALL, whose access pattern the flag does not change.  Proof bytes are identical with and without it. */
+#define VRFHIP_FLAG_CT_TABLES 64u
 int32_t vrfhip_ctx_set_flags(vrfhip_ctx* ctx, uint32_t flags);
 uint32_t vrfhip_ctx_get_flags(const vrfhip_ctx* ctx);
 
@@ -524,7 +531,8 @@ int32_t vrfhip_test_pairing_oct_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp
  * API (/root/reference src/lib.rs:13-17 has no counterpart); defaults are what production runs. */
 enum {
   VRFHIP_DEBUG_PAIRING_LAYOUT = 1,  /* 0 by batch size (default); 1 one item per lane, 2 per DPP quad, 3 per 16-lane row,
-                                       4 per wave, 5 per 8 lanes; | 0x100: do not prepare the lines of a shared G2 pair */
+                                       4 per wave, 5 per 8 lanes (per-item G2: lines kernel + Miller kernel), 6 per 8 lanes in
+                                       one kernel; | 0x100: do not prepare the lines of a shared G2 pair */
   VRFHIP_DEBUG_PIPE_FIRST_LOG2 = 2, /* host-pointer verify pipeline: log2 items of the first chunk (12..18, default 17) */
   VRFHIP_DEBUG_PIPE_CHUNK_LOG2 = 3  /* ... of the following chunks (12..18, default 18) */
 };

@@ -359,7 +359,8 @@ int p256_ietf_verify(const uint8_t pk[33], const uint8_t h[33], const uint8_t ga
   size_t lens[5] = {33, 33, 33, sec1_encode(uenc, &U), sec1_encode(venc, &V)};
   const uint8_t* encs[5] = {pk, h, gamma, uenc, venc};
   challenge(cc, encs, lens, ad, ad_len);
-  return cmp4(cc, c) == 0 ? 0 : 1;
+  load_be(t, c_be);                              /* CHALLENGE_LEN = 16: the field as it stands (oracle_vrf.c oracle_ietf_verify) */
+  return cmp4(cc, t) == 0 ? 0 : 1;
 }
 
 /* ---- Pedersen VRF (oracle/sw_oracle.py pedersen_*; unpinned on this suite) ---- */
@@ -437,6 +438,55 @@ int p256_pedersen_verify(const uint8_t h[33], const uint8_t gamma[33], const uin
   jac_mul(&t1, &G, s); jac_mul(&t2, &BB_, sb); jac_add(&rhs, &t1, &t2);
   l1 = sec1_encode(e1, &lhs); l2 = sec1_encode(e2, &rhs);
   return (l1 == l2 && !memcmp(e1, e2, l1)) ? 0 : 1;
+}
+
+/* `VariableBaseMSM::msm` restated the plain way: sum_i k_i P_i by one double-and-add per term (arkworks' msm is a bucket method;
+ * the sum is the same group element).  bases: n x 64 B affine x || y, 32-byte LITTLE-endian integers (all-zero = the point at
+ * infinity), scalars: n x 32 B big-endian (< n).  out33: Sec1 (0x00 + 32 zero bytes for the point at infinity), out_xy: x || y
+ * little-endian (all-zero for it).  Returns 0, or 2 on a coordinate >= p, a point off the curve or a scalar >= n (outputs
+ * zeroed) -- the statuses of vrfhip_msm on the secp256r1 suite.  [ref /root/reference src/lib.rs:14 `reexports`; BASELINE.json] */
+int p256_msm(size_t n, const uint8_t* bases_xy, const uint8_t* scalars_be, uint8_t out33[33], uint8_t out_xy[64]) {
+  ensure_init();
+  jac acc;
+  jac_inf(&acc);
+  int bad = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const uint8_t* b = bases_xy + 64 * i;
+    uint64_t xw[4], yw[4], k[4];
+    for (int j = 0; j < 4; ++j) {
+      xw[j] = 0; yw[j] = 0;
+      for (int t = 7; t >= 0; --t) { xw[j] = (xw[j] << 8) | b[8 * j + t]; yw[j] = (yw[j] << 8) | b[32 + 8 * j + t]; }
+    }
+    load_be(k, scalars_be + 32 * i);
+    if (cmp4(k, N_M) >= 0 || cmp4(xw, P_M) >= 0 || cmp4(yw, P_M) >= 0) { bad = 1; continue; }
+    if (is_zero4(xw) && is_zero4(yw)) continue;                  /* infinity: adds nothing */
+    fe x, y, l, r, t;
+    to_mont(&FP, x.v, xw); to_mont(&FP, y.v, yw);
+    qmul(&l, &y, &y);
+    qmul(&t, &x, &x); qmul(&r, &t, &x);
+    qsub(&r, &r, &x); qsub(&r, &r, &x); qsub(&r, &r, &x);
+    qadd(&r, &r, &B_M);
+    if (memcmp(l.v, r.v, 32) != 0) { bad = 1; continue; }
+    jac p, kp;
+    jac_from_affine(&p, &x, &y);
+    jac_mul(&kp, &p, k);
+    jac_add(&acc, &acc, &kp);
+  }
+  memset(out33, 0, 33);
+  if (out_xy) memset(out_xy, 0, 64);
+  if (bad) return 2;
+  if (jac_is_inf(&acc)) return 0;
+  sec1_encode(out33, &acc);
+  if (out_xy) {
+    /* affine x, y from the Sec1 string and the parity of y */
+    jac q;
+    sec1_decode(&q, out33);
+    uint64_t xa[4], ya[4];
+    from_mont(&FP, xa, q.X.v); from_mont(&FP, ya, q.Y.v);
+    for (int j = 0; j < 4; ++j)
+      for (int t = 0; t < 8; ++t) { out_xy[8 * j + t] = (uint8_t)(xa[j] >> (8 * t)); out_xy[32 + 8 * j + t] = (uint8_t)(ya[j] >> (8 * t)); }
+  }
+  return 0;
 }
 
 /* ---- batch drivers ---- */

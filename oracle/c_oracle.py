@@ -68,6 +68,8 @@ def load() -> ctypes.CDLL:
         lib.p256_hash_to_curve.argtypes = [P, c_size_t, P]
         lib.p256_output_hash.argtypes = [P, P]
         lib.p256_point_decode.argtypes = [P]
+        lib.p256_msm.argtypes = [c_size_t, P, P, P, P]
+        lib.p256_msm.restype = c_int
         lib.oracle_g1_mul.argtypes = [P, P, P]
         lib.oracle_g1_mul.restype = c_int
         lib.oracle_g2_mul.argtypes = [P, P, P]
@@ -375,6 +377,16 @@ def p256_output_hash(gamma33: bytes) -> bytes:
 
 def p256_point_decode(enc33: bytes) -> int:
     return load().p256_point_decode(bytes(enc33))
+
+
+def p256_msm(bases_xy, scalars_be):
+    """sum_i k_i P_i on secp256r1 (oracle_p256.c p256_msm): bases (n, 64) x || y little-endian, scalars (n, 32) big-endian.
+    Returns (status, sec1 33 bytes, xy 64 bytes)."""
+    b = np.ascontiguousarray(bases_xy, dtype=np.uint8).reshape(-1, 64)
+    k = np.ascontiguousarray(scalars_be, dtype=np.uint8).reshape(-1, 32)
+    o33, oxy = ctypes.create_string_buffer(33), ctypes.create_string_buffer(64)
+    st = load().p256_msm(b.shape[0], b.ctypes.data if b.size else None, k.ctypes.data if k.size else None, o33, oxy)
+    return st, o33.raw, oxy.raw
 
 
 def p256_set_blinding_base(pt) -> None:

@@ -155,7 +155,8 @@ def ietf_verify(pk: Point, h: Point, gamma: Point, ad: bytes, c: int, s: int, su
     """[ref src/lib.rs:14 `ietf::Verifier::verify`]"""
     u = add(mul(s, gen), neg(mul(c, pk)))
     v = add(mul(s, h), neg(mul(c, gamma)))
-    return challenge([pk, h, gamma, u, v], ad, suite_id, challenge_len) == c % N
+    # a c field holding more than CHALLENGE_LEN bytes is no proof string (vrf_oracle.ietf_verify)
+    return challenge([pk, h, gamma, u, v], ad, suite_id, challenge_len) == (c if challenge_len < 32 else c % N)
 
 
 # ---- Pedersen VRF  [ref src/lib.rs:14 `pedersen`]  (SURVEY.md Appendix A.5, with this suite's codec and hash) ----

@@ -406,7 +406,9 @@ def ietf_verify(S: SuiteParams, pk: Point, H: Point, gamma: Point, ad: bytes, c:
     G = (S.gx, S.gy)
     U = te_add(S, te_mul(S, s, G), te_neg(S, te_mul(S, c, pk)))
     V = te_add(S, te_mul(S, s, H), te_neg(S, te_mul(S, c, gamma)))
-    return challenge_rfc9381(S, [pk, H, gamma, U, V], ad) == c % S.r      # `Proof::c` is a field element: mod r
+    # `Proof::c` is a field element (mod r) when CHALLENGE_LEN = 32; upstream writes a shorter challenge with CHALLENGE_LEN
+    # bytes, so a 32-byte field holding more is no proof string: compared as it stands, it never matches
+    return challenge_rfc9381(S, [pk, H, gamma, U, V], ad) == (c if S.challenge_len < 32 else c % S.r)
 
 
 # --------------------------------------------------------------------------------------

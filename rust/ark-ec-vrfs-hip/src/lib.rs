@@ -577,7 +577,8 @@ impl GpuBatchSec1 {
 impl GpuBatchSec1 {
     /// `pedersen::Prover::prove` per (secret, input) pair: (output, proof, blinding factor) or the item's `Error`.  The
     /// contexts must have been made from a descriptor that carries upstream's `BLINDING_BASE` for the suite
-    /// ([`GpuBatchSec1::with_blinding_base`]); the library's built-in base is a placeholder.
+    /// ([`GpuBatchSec1::with_blinding_base`]): the library's default descriptor of this suite carries none, and these calls
+    /// then answer `VRFHIP_ERR_UNSUPPORTED` instead of proving with an invented point.
     pub fn pedersen_prove(
         &self,
         secrets: &[Secret<P256>],
@@ -652,7 +653,8 @@ impl GpuBatchSec1 {
     }
 
     /// Contexts whose descriptor carries the suite's own `PedersenSuite::BLINDING_BASE` (x || y, little-endian, as the
-    /// descriptor states every point) instead of the library's placeholder.
+    /// descriptor states every point).  The default descriptor leaves the field all-zero (no Pedersen scheme): upstream's
+    /// constant is pinned by a vector for Bandersnatch only, so every other suite gets it from the trait, here.
     pub fn with_blinding_base(devices: &[i32]) -> Result<Self, GpuError> {
         let mut desc: ffi::vrfhip_suite_desc = unsafe { core::mem::zeroed() };
         check(unsafe { ffi::vrfhip_suite_desc_default(ffi::VRFHIP_SUITE_SECP256R1_SHA256_TAI, &mut desc) })?;

@@ -102,6 +102,13 @@ uint32_t hb_oct_pairing_check2(const uint8_t* g1x2, const uint8_t* g2x2) {
   uint32_t w1[48], w2[96]; memcpy(w1, g1x2, 192); memcpy(w2, g2x2, 384);
   return agree(run8([&](const Ln& ln) -> uint32_t { return pairing_check2_oct(w1, w2, ln); }));
 }
+// the per-item path in two passes: the lines of both pairs into a buffer, then the Miller loop over them
+uint32_t hb_oct_pairing_check2_split(const uint8_t* g1x2, const uint8_t* g2x2) {
+  uint32_t w1[48], w2[96]; memcpy(w1, g1x2, 192); memcpy(w2, g2x2, 384);
+  std::vector<uint32_t> lines(oct_lines_words_per_item()), flags(4, 0xdeadu);
+  run8([&](const Ln& ln) -> uint32_t { pairing_lines_oct(w1, w2, lines.data(), flags.data(), 1, 0, ln); return 0; });
+  return agree(run8([&](const Ln& ln) -> uint32_t { return pairing_check2_oct_lines(lines.data(), flags.data(), 1, 0, ln); }));
+}
 uint32_t hb_oct_pairing_check2_prepared(const uint8_t* g1x2, const uint8_t* g2x2) {
   uint32_t w1[48], w2[96]; memcpy(w1, g1x2, 192); memcpy(w2, g2x2, 384);
   std::vector<uint32_t> prep(G2_PREP_WORDS);

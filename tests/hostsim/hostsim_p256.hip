@@ -134,7 +134,7 @@ int hp_prove(const uint8_t* sk_be, const uint8_t* msg, uint32_t msg_len, const u
 // 0 = ok, 1 = does not verify, 2 = invalid data
 int hp_verify(const uint8_t* pk, const uint8_t* h, const uint8_t* gamma, const uint8_t* c_be, const uint8_t* s_be, const uint8_t* ad, uint32_t ad_len) {
   FeN x[3], y[3]; Sec1W enc[3]; uint32_t c[8], s[8];
-  if (!p256_verify_decode_item(x, y, enc, c, s, pk, h, gamma, c_be, s_be)) return 2;
+  if (!p256_verify_decode_item(x, y, enc, c, s, pk, h, gamma, c_be, s_be, g_str.challenge_len)) return 2;
   std::vector<uint32_t> ty(SW_TABLE_WORDS), th(SW_TABLE_WORDS), tg(SW_TABLE_WORDS);
   sw_build_table(ty.data(), 1, sw_from_affine(x[0], y[0]));
   sw_build_table(th.data(), 1, sw_from_affine(x[1], y[1]));

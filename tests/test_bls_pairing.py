@@ -335,7 +335,8 @@ def ho():
     so = os.path.join(HERE, "libhostsim_bls_oct.so")
     subprocess.run(["make", "-C", HERE, "libhostsim_bls_oct.so"], check=True, stdout=subprocess.DEVNULL)
     lib = ctypes.CDLL(so)
-    for f in (lib.hb_oct_moves, lib.hb_oct_selftest, lib.hb_oct_pairing_check2, lib.hb_oct_pairing_check2_prepared):
+    for f in (lib.hb_oct_moves, lib.hb_oct_selftest, lib.hb_oct_pairing_check2, lib.hb_oct_pairing_check2_prepared,
+              lib.hb_oct_pairing_check2_split):
         f.restype = ctypes.c_uint32
     return lib
 
@@ -366,6 +367,7 @@ def test_hostsim_oct_layout_tower_and_checks(hb, ho):
     for g1, g2 in cases:
         want = hb.hb_pairing_check2(g1, g2)
         assert ho.hb_oct_pairing_check2(g1, g2) == want
+        assert ho.hb_oct_pairing_check2_split(g1, g2) == want                  # lines kernel + Miller kernel
         assert ho.hb_oct_pairing_check2_prepared(g1, g2) == want
         seen.add(want)
     assert seen == {0, 1, 2}
@@ -638,7 +640,7 @@ def test_gpu_pairing_soak_distinct_items_every_path(ctx):
     assert (ref == want).all(), [(k, int(a), int(c)) for k, a, c in zip(kinds, ref, want) if a != c][:5]
     assert len({bytes(r) for r in g1}) > n - n // 20 and len({bytes(r) for r in g2}) > n - n // 20     # distinct (but for the zeroed ones)
     assert (ctx.pairing_check_batch(g1, g2) == want).all()               # 2^12 items: 8 lanes per item
-    for mode in ("lane", "quad", "oct"):
+    for mode in ("lane", "quad", "oct", "oct1"):
         ctx.debug_pairing_layout(mode)
         try:
             assert (ctx.pairing_check_batch(g1, g2) == want).all(), mode

@@ -398,6 +398,12 @@ def test_gpu_prove_verify_pedersen_equal_the_c_oracle(gpu, ad):
     st = ctx.ietf_verify_batch(pkv, inp, outp, c, s, ad=ad)
     assert (st == want).all() and set(np.unique(want)) == {0, 1, 2}
     assert (ctx.ietf_verify_batch(ref["pk"], ref["input"], ref["output"], ref["c"], ref["s"], ad=ad) == 0).all()
+    # c + r alone: the same scalar under another string.  A 32-byte challenge is a scalar (decoded mod r, as upstream); a
+    # shorter one has CHALLENGE_LEN bytes on upstream's wire, so the larger field is no proof string and fails
+    cr = np.frombuffer(b"".join(le(int.from_bytes(ref["c"][i].tobytes(), "little") + S.r) for i in range(16)), np.uint8).reshape(16, 32)
+    st_cr = ctx.ietf_verify_batch(ref["pk"][:16], ref["input"][:16], ref["output"][:16], cr, ref["s"][:16], ad=ad)
+    assert (st_cr == (1 if S.challenge_len < 32 else 0)).all()
+    assert (co.ietf_verify_batch(ref["pk"][:16], ref["input"][:16], ref["output"][:16], cr, ref["s"][:16], ad, threads=NCPU) == st_cr).all()
     assert (ctx.ietf_verify_batch(ref["pk"], ref["input"], ref["output"], ref["c"], ref["s"], ad=ad + b"!") == 1).all()
     # Pedersen
     pref = co.pedersen_prove_batch(sk, msgs=msg, ad=ad, threads=NCPU)

@@ -286,7 +286,8 @@ def test_host_build_prove_and_verify_equal_the_oracle(hp):
         assert hp.hp_verify(pk, h, g, be(c), be((s + 1) % N), ad, len(ad)) == 1
         if s + N < (1 << 256):
             assert hp.hp_verify(pk, h, g, be(c), be(s + N), ad, len(ad)) == 2                                 # s >= n: RFC 9381 5.4.4
-        assert hp.hp_verify(pk, h, g, be(c + N) if c + N < (1 << 256) else be(c), be(s), ad, len(ad)) == 0   # c mod n, as upstream
+        if c + N < (1 << 256):
+            assert hp.hp_verify(pk, h, g, be(c + N), be(s), ad, len(ad)) == 1                                # a c field above 16 bytes is no proof string
         assert hp.hp_verify(pk, h, g, be(c + (1 << 128)), be(s), ad, len(ad)) == 1                           # c is 16 bytes
         other = sw.point_encode(sw.mul(rnd.randrange(1, N), G))
         assert hp.hp_verify(other, h, g, be(c), be(s), ad, len(ad)) == 1
@@ -407,13 +408,14 @@ def test_gpu_prove_and_verify_equal_the_oracle(gpu):
         want[i] = [0, 1, 1, 1, 2, 2, 1, 2][kind]
     got = gpu.ietf_verify_batch(pkt, ht, gt, ct, st_, ad=ads)
     assert (got == want).all(), (got, want)
-    # a non-canonical s is InvalidData (RFC 9381 5.4.4; upstream deserialises s strictly), c is taken mod n
+    # a non-canonical s is InvalidData (RFC 9381 5.4.4; upstream deserialises s strictly); a c field holding more than the
+    # suite's 16 challenge bytes (here c + n: the same scalar) is no proof string and fails
     s0, c0 = int.from_bytes(r["s"][0].tobytes(), "big"), int.from_bytes(r["c"][0].tobytes(), "big")
     if s0 + N < (1 << 256):
         s2 = r["s"].copy(); s2[0] = np.frombuffer(be(s0 + N), np.uint8)
         assert gpu.ietf_verify_batch(pk, r["input"], r["output"], r["c"], s2, ad=ads)[0] == 2
     c2 = r["c"].copy(); c2[0] = np.frombuffer(be(c0 + N), np.uint8)
-    assert gpu.ietf_verify_batch(pk, r["input"], r["output"], c2, r["s"], ad=ads)[0] == 0
+    assert gpu.ietf_verify_batch(pk, r["input"], r["output"], c2, r["s"], ad=ads)[0] == 1
     # corners of the group law built from valid bytes: c = 1, s = sk makes U = s G - c Y the point at infinity (hashed as
     # the single byte 0x00, as Sec1Codec encodes it); pk = H = Gamma makes both ladders add a point to itself
     k0 = sw.secret_from_seed(seeds[0].tobytes())
@@ -680,12 +682,149 @@ def test_gpu_xy_forms_for_typed_callers(gpu):
 
 @pytest.mark.gpu
 def test_gpu_entry_points_outside_the_suite_are_refused(gpu):
+    """What the suite still lacks answers UNSUPPORTED before any byte is read: the x || y form of the batched Pedersen verifier
+    and resident key sets.  (Round 4 built the MSM and the batched verifier: tests below.)"""
     from ark_ec_vrfs_amd import VrfHipError
-    z32, z33 = np.zeros((2, 32), np.uint8), np.zeros((2, 33), np.uint8)
+    z32, z33, z64 = np.zeros((2, 32), np.uint8), np.zeros((2, 33), np.uint8), np.zeros((2, 64), np.uint8)
     with pytest.raises(VrfHipError):
-        gpu.pedersen_verify_batch_rlc(z32, z32, z32, z32, z32, z32, z32, seed=bytes(32))    # refused before any byte is read
+        gpu.pedersen_verify_batch_rlc(z64, z64, z64, z64, z64, z32, z32, seed=bytes(32), affine=True)
     with pytest.raises(VrfHipError):
-        gpu.msm(np.zeros((2, 64), np.uint8), z32)
+        gpu.keyset_create(z33)
     gpu.set_prevalidated(True)                      # cofactor 1: nothing to skip, accepted and without effect
     assert gpu.ietf_verify_batch(z33, z33, z33, z32, z32)[0] == 2
     gpu.set_prevalidated(False)
+
+
+def test_oracle_msm_against_discrete_logs():
+    """oracle_p256.c p256_msm (one double-and-add per term) against sum k_i a_i * G from the discrete logs, with P and -P,
+    a repeated point, the point at infinity, zero and extreme scalars, and the invalid inputs."""
+    rnd = random.Random(70)
+    le = lambda v: int(v).to_bytes(32, "little")
+    a = [rnd.randrange(1, N) for _ in range(10)]
+    pts = [sw.mul(x, sw.G) for x in a]
+    rows = [le(p_[0]) + le(p_[1]) for p_ in pts]
+    neg0 = sw.neg(pts[0])
+    bases = rows + [rows[1], le(neg0[0]) + le(neg0[1]), bytes(64)]
+    logs = a + [a[1], N - a[0], 0]
+    ks = [rnd.randrange(N) for _ in range(10)] + [N - 1, 0, 12345]
+    ks[2], ks[3] = 0, 1
+    st, o33, oxy = co.p256_msm(_u8(bases), _u8(be(k) for k in ks))
+    want = sw.mul(sum(x * y for x, y in zip(logs, ks)) % N, sw.G)
+    assert st == 0 and o33 == sw.point_encode(want) and oxy == le(want[0]) + le(want[1])
+    st, o33, oxy = co.p256_msm(_u8([rows[0], le(neg0[0]) + le(neg0[1])]), _u8([be(7), be(7)]))
+    assert st == 0 and o33 == bytes(33) and oxy == bytes(64)                      # the point at infinity
+    bad = bytearray(rows[4]); bad[1] ^= 2
+    assert co.p256_msm(_u8([rows[0], bytes(bad)]), _u8([be(1), be(1)]))[0] == 2    # off the curve
+    assert co.p256_msm(_u8([rows[0]]), _u8([be(N)]))[0] == 2                       # scalar not below n
+    assert co.p256_msm(_u8([le(P) + le(1)]), _u8([be(1)]))[0] == 2                 # coordinate not below p
+
+
+@pytest.mark.gpu
+def test_gpu_msm_equals_the_oracle(gpu):
+    """`VariableBaseMSM::msm` on secp256r1 (k_p256_msm.hip: Pippenger, 512 LDS buckets per window, the complete addition
+    law) against oracle_p256.c and against discrete-log sums: sizes that cross the group boundaries, many equal points (one
+    bucket meeting P, P again and -P), infinity, extreme scalars, the Montgomery-limb coordinate format, invalid inputs."""
+    from ark_ec_vrfs_amd import InvalidData
+    rnd = random.Random(71)
+    le = lambda v: int(v).to_bytes(32, "little")
+    a = [rnd.randrange(1, N) for _ in range(40)]
+    pool = [sw.mul(x, sw.G) for x in a]
+    enc = [le(p_[0]) + le(p_[1]) for p_ in pool]
+    for n in (0, 1, 2, 63, 700, 5000, 40000):
+        idx = [rnd.randrange(40) for _ in range(n)]
+        ks = [rnd.randrange(N) for _ in range(n)]
+        for j in range(0, n, 97):
+            ks[j] = rnd.choice([0, 1, N - 1, (N - 1) // 2, (N + 1) // 2, 1 << 255, (1 << 128) - 1])
+        bases = _u8(enc[i] for i in idx) if n else np.zeros((0, 64), np.uint8)
+        sc = _u8(be(k) for k in ks) if n else np.zeros((0, 32), np.uint8)
+        want = sw.mul(sum(a[i] * k for i, k in zip(idx, ks)) % N, sw.G) if n else None
+        pt, xy = gpu.msm(bases, sc)
+        if n == 0:
+            assert pt == bytes(33) and xy == bytes(64)
+        else:
+            assert pt == sw.point_encode(want) and xy == le(want[0]) + le(want[1]), n
+        if 0 < n <= 5000:
+            st, o33, oxy = co.p256_msm(bases, sc)
+            assert st == 0 and o33 == pt and oxy == xy
+    # one bucket meets P twice and -P once; the point at infinity among the bases; everything cancels
+    P0, nP0 = enc[0], le(sw.neg(pool[0])[0]) + le(sw.neg(pool[0])[1])
+    pt, xy = gpu.msm(_u8([P0, P0, nP0, bytes(64)]), _u8([be(9), be(9), be(18), be(5)]))
+    assert pt == bytes(33) and xy == bytes(64)
+    pt, _ = gpu.msm(_u8([P0, P0, nP0]), _u8([be(9), be(9), be(9)]))
+    assert pt == sw.point_encode(sw.mul(9 * a[0] % N, sw.G))
+    # arkworks' in-memory coordinates
+    gpu.set_flags(gpu.COORDS_MONT256)
+    try:
+        xym = lambda p_: le(p_[0] * (1 << 256) % P) + le(p_[1] * (1 << 256) % P)
+        pt, xy = gpu.msm(_u8(xym(pool[i]) for i in range(5)), _u8(be(k + 3) for k in range(5)))
+        want = sw.mul(sum(a[i] * (i + 3) for i in range(5)) % N, sw.G)
+        assert pt == sw.point_encode(want) and xy == xym(want)
+    finally:
+        gpu.set_flags(0)
+    bad = bytearray(enc[4]); bad[1] ^= 2
+    for bases, sc in ((_u8([enc[0], bytes(bad)]), _u8([be(1), be(1)])), (_u8([enc[0]]), _u8([be(N)])),
+                      (_u8([le(P) + le(1)]), _u8([be(1)]))):
+        with pytest.raises(InvalidData):
+            gpu.msm(bases, sc)
+
+
+@pytest.mark.gpu
+def test_gpu_batched_pedersen_verifier(gpu):
+    """`pedersen::Verifier::verify` for a whole batch as ONE MSM over 5 n + 2 points (random linear combination, weights from
+    a digest of every input byte).  Statuses always equal the per-proof verifier's (oracle_p256.c); the single-MSM verdict
+    accepts a valid batch, rejects every kind of single defect, and is not fooled by two defects that cancel without
+    weights (Ok_0 += D, Ok_1 -= D); undecodable proofs are left out of the sum and flagged."""
+    import torch
+    B = sw.default_blinding_base()
+    co.p256_set_blinding_base(B)
+    n = 2500
+    rng = np.random.default_rng(44)
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8); sk[:, 0] &= 0x7f
+    msg = rng.integers(0, 256, (n, 20), dtype=np.uint8)
+    pr = gpu.pedersen_prove_batch(sk, msgs=msg, ad=b"rlc")
+    assert not pr["status"].any()
+    F = ("input", "output", "pk_com", "r", "ok", "s", "sb")
+    args = lambda d: [d[k] for k in F]
+    seed = bytes(range(32))
+    st, ok = gpu.pedersen_verify_batch_rlc(*args(pr), ad=b"rlc", seed=seed)
+    assert ok and not st.any()
+    st, ok = gpu.pedersen_verify_batch_rlc(*args(pr), ad=b"other", seed=seed)            # every challenge changes
+    assert not ok and (st == 1).all()
+    for field, row, col in (("s", 7, 31), ("sb", 8, 0), ("output", 9, 5), ("pk_com", 10, 20), ("r", 11, 32), ("ok", 12, 1), ("input", 13, 9)):
+        b = {k: v.copy() for k, v in pr.items()}
+        if field in ("s", "sb"):
+            b[field][row, col] ^= 4
+        else:
+            b[field][row] = pr[field][row + 1]                                             # another proof's (valid) point
+        st, ok = gpu.pedersen_verify_batch_rlc(*args(b), ad=b"rlc", seed=seed)
+        want = co.p256_pedersen_verify_batch(*args(b), b"rlc", threads=8)
+        assert not ok and (st == want).all() and st[row] == 1 and st.sum() == 1, field
+    # two defects that cancel in an unweighted sum
+    D = sw.mul(123456789, sw.G)
+    b = {k: v.copy() for k, v in pr.items()}
+    ok0, ok1 = sw.point_decode(pr["ok"][0].tobytes()), sw.point_decode(pr["ok"][1].tobytes())
+    b["ok"][0] = np.frombuffer(sw.point_encode(sw.add(ok0, D)), np.uint8)
+    b["ok"][1] = np.frombuffer(sw.point_encode(sw.add(ok1, sw.neg(D))), np.uint8)
+    st, ok = gpu.pedersen_verify_batch_rlc(*args(b), ad=b"rlc", seed=seed)
+    assert not ok and st[0] == 1 and st[1] == 1 and st.sum() == 2
+    # undecodable proofs: InvalidData, left out; the rest still passes as one MSM
+    b = {k: v.copy() for k, v in pr.items()}
+    b["s"][3] = np.frombuffer(be(N), np.uint8)
+    b["r"][4, 0] = 5
+    b["output"][5, 1:] = np.frombuffer(be(P), np.uint8)
+    st, ok = gpu.pedersen_verify_batch_rlc(*args(b), ad=b"rlc", seed=seed)
+    want = co.p256_pedersen_verify_batch(*args(b), b"rlc", threads=8)
+    assert ok and (st == want).all() and list(np.flatnonzero(st)) == [3, 4, 5] and (st[3:6] == 2).all()
+    # the device entry point: verdict flag only, per-item ad
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(pr[k].copy()).to(dev) for k in F}
+    status = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+    flag = torch.full((1,), 9, dtype=torch.uint8, device=dev)
+    ad = torch.from_numpy(np.frombuffer(b"rlc", np.uint8).copy()).to(dev)
+    gpu.pedersen_verify_batch_rlc_dev(*[t[k] for k in F], status, flag, seed, ad=ad, ad_len=3)
+    torch.cuda.synchronize()
+    assert int(flag[0]) == 0 and int(status.sum()) == 0
+    t["sb"][77, 3] ^= 1
+    gpu.pedersen_verify_batch_rlc_dev(*[t[k] for k in F], status, flag, seed, ad=ad, ad_len=3)
+    torch.cuda.synchronize()
+    assert int(flag[0]) == 1 and int(status.sum()) == 0           # the batch stage names no culprit: that is the fallback's job

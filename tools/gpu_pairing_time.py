@@ -27,7 +27,7 @@ for logn in logs:
     d1 = torch.from_numpy(np.tile(g1, (n // 8, 1)).copy()).to(dev)
     d2 = torch.from_numpy(np.tile(g2, (n // 8, 1)).copy()).to(dev)
     st = torch.full((n,), 9, dtype=torch.uint8, device=dev)
-    for mode in ("quad", "oct"):
+    for mode in ("quad", "oct1", "oct"):
         ctx.debug_pairing_layout(mode)
         t = best(lambda: ctx.pairing_check_batch_dev(d1, d2, st))
         assert int(st.sum()) == 0
