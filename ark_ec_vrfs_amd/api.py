@@ -350,7 +350,8 @@ class Context:
     def ietf_verify_batch_keyed(self, keyset, key_index, inp, out, c, s, ad=b"") -> np.ndarray:
         """`ietf::Verifier::verify` against keys of a KeySet; key_index[i] names the key of proof i."""
         idx = np.ascontiguousarray(key_index, dtype=np.uint32).reshape(-1)
-        inp, out, c, s = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (inp, out, c, s))
+        inp, out = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, self.point_bytes()) for x in (inp, out))
+        c, s = (np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32) for x in (c, s))
         n = idx.shape[0]
         if not all(x.shape[0] == n for x in (inp, out, c, s)):
             raise ValueError("ragged batch")

@@ -144,7 +144,9 @@ struct vrfhip_keyset {
   size_t n_keys = 0;
   uint8_t* d_enc = nullptr;       // [n_keys][32] encodings (hashed by the challenge)
   uint8_t* d_valid = nullptr;     // [n_keys]
-  uint32_t* d_combs = nullptr;    // [n_keys][32][255][27]
+  uint32_t* d_combs = nullptr;    // [n_keys][32][255][27]   (secp256r1: [n_keys][rows][128][28])
+  uint32_t* d_aff = nullptr;      // secp256r1 only: [n_keys][18] Montgomery affine coordinates
+  int rows = 0;                   // secp256r1 only: comb rows per key = challenge_len + 1
   size_t bytes = 0;
 };
 
@@ -698,7 +700,6 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
                         const vrfhip_keyset* ks = nullptr, const uint32_t* d_key_index = nullptr) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ks && (ks->ctx != ctx || !d_key_index)) return fail(VRFHIP_ERR_BAD_ARG, "key set of another context, or NULL key index");
-  if (ctx->sw && ks) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: no key sets");
   if (n == 0) return VRFHIP_SUCCESS;
   if (ks) d_pk = ks->d_enc;
   if (!d_pk || !d_input || !d_output || !d_c || !d_s || !d_status)
@@ -712,7 +713,7 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
   if (ctx->sw) {
     for (size_t base = 0; base < n; base += ctx->ws_cap) {
       const size_t m = std::min(ctx->ws_cap, n - base);
-      p256::VerifyArgs a;
+      p256::VerifyArgs a{};
       a.n = m;
       const size_t pw = affine ? 64 : 33;
       a.pk = d_pk + base * pw; a.h = d_input + base * pw; a.gamma = d_output + base * pw;
@@ -723,6 +724,11 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
       a.ws = ctx->p256_ws;
       a.comb = ctx->d_p256_comb;
       a.str = ctx->T.sq.str;
+      if (ks) {
+        a.pk = nullptr;
+        a.key_index = d_key_index + base; a.n_keys = ks->n_keys; a.key_enc = ks->d_enc; a.key_aff = ks->d_aff;
+        a.key_valid = ks->d_valid; a.key_combs = ks->d_combs; a.key_rows = ks->rows;
+      }
       p256::launch_verify(a, st, prof_events(ctx));
     }
     HIP_TRY(hipGetLastError());
@@ -848,7 +854,7 @@ int32_t vrfhip_ietf_verify_batch_alpha_dev(vrfhip_ctx* ctx, size_t n, const uint
       BytesView mv = d_msg_off ? make_view(d_msg, d_msg_off + base, msg_len, false)
                                : make_view(d_msg ? d_msg + base * (size_t)msg_len : d_msg, nullptr, msg_len, false);
       p256::launch_hash_to_curve(m, mv, d_henc, ctx->T.sq.str, st, ctx->p256_ws.flags, ctx->d_queue);
-      p256::VerifyArgs a;
+      p256::VerifyArgs a{};
       a.n = m;
       a.pk = d_pk + base * 33; a.h = d_henc; a.gamma = d_output + base * 33;
       a.affine_in = 0;
@@ -954,7 +960,6 @@ int32_t vrfhip_keyset_create(vrfhip_ctx* ctx, size_t n_keys, const uint8_t* pks,
   if (!out) return fail(VRFHIP_ERR_BAD_ARG, "out is NULL");
   *out = nullptr;
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
   if (n_keys == 0 || !pks) return fail(VRFHIP_ERR_BAD_ARG, "no keys");
   if (n_keys > (size_t(1) << 24)) return fail(VRFHIP_ERR_BAD_ARG, "too many keys");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -962,6 +967,31 @@ int32_t vrfhip_keyset_create(vrfhip_ctx* ctx, size_t n_keys, const uint8_t* pks,
   vrfhip_keyset* ks = new vrfhip_keyset();
   ks->ctx = ctx;
   ks->n_keys = n_keys;
+  if (ctx->sw) {
+    // secp256r1: 33-byte Sec1 keys; per key the comb rows a challenge can reach (challenge_len + 1 rows of 128 entries)
+    ks->rows = (int)ctx->desc.challenge_len + 1;
+    const size_t cb = n_keys * p256::key_comb_bytes(ks->rows);
+    auto bail_sw = [&](hipError_t e, const char* what) {
+      vrfhip_keyset_destroy(ks);
+      return fail(e == hipErrorOutOfMemory ? VRFHIP_ERR_OOM : VRFHIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&ks->d_enc, n_keys * 33 + 3)) != hipSuccess) return bail_sw(e, "hipMalloc(keys)");
+    if ((e = hipMalloc(&ks->d_valid, (n_keys + 255) & ~size_t(255))) != hipSuccess) return bail_sw(e, "hipMalloc(valid)");
+    if ((e = hipMalloc(&ks->d_aff, n_keys * 18 * sizeof(uint32_t))) != hipSuccess) return bail_sw(e, "hipMalloc(affine)");
+    if ((e = hipMalloc(&ks->d_combs, cb)) != hipSuccess) return bail_sw(e, "hipMalloc(combs)");
+    ks->bytes = n_keys * (33 + 1 + 72) + cb;
+    if ((e = hipMemcpyAsync(ks->d_enc, pks, n_keys * 33, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return bail_sw(e, "copy keys");
+    p256::launch_keyset_build(n_keys, ks->d_enc, ks->d_aff, ks->d_valid, ks->d_combs, ks->rows, ctx->stream);
+    if ((e = hipGetLastError()) != hipSuccess) return bail_sw(e, "launch");
+    std::vector<uint8_t> valid(n_keys);
+    if ((e = hipMemcpyAsync(valid.data(), ks->d_valid, n_keys, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return bail_sw(e, "copy back");
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return bail_sw(e, "synchronize");
+    if (status)
+      for (size_t i = 0; i < n_keys; ++i) status[i] = valid[i] ? VRFHIP_ST_OK : VRFHIP_ST_INVALID_DATA;
+    *out = ks;
+    return VRFHIP_SUCCESS;
+  }
   const size_t comb_bytes = n_keys * COMB_WORDS * sizeof(uint32_t);
   const size_t prefix_bytes = n_keys * COMB_ROWS * (size_t)COMB_COLS * NL * sizeof(uint32_t);
   uint32_t *d_xy = nullptr, *d_prefix = nullptr;
@@ -1009,6 +1039,7 @@ void vrfhip_keyset_destroy(vrfhip_keyset* ks) {
     if (ks->d_enc) (void)hipFree(ks->d_enc);
     if (ks->d_valid) (void)hipFree(ks->d_valid);
     if (ks->d_combs) (void)hipFree(ks->d_combs);
+    if (ks->d_aff) (void)hipFree(ks->d_aff);
   }
   delete ks;
 }
@@ -1037,15 +1068,17 @@ int32_t vrfhip_ietf_verify_batch_keyed(vrfhip_ctx* ctx, const vrfhip_keyset* key
   size_t adb = blob_bytes(n, ad_off, ad_len, true);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
-  size_t need = 4 * Stage::pad(n * 32) + Stage::pad(n * 4) + Stage::pad(adb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n);
+  const size_t pw = ctx->pt_bytes();           // input / output: 32-byte points, 33-byte Sec1 strings on secp256r1
+  size_t need = 2 * Stage::pad(n * pw) + 2 * Stage::pad(n * 32) + Stage::pad(n * 4) + Stage::pad(adb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n);
   int32_t rc = ensure_stage(ctx, need);
   if (rc) return rc;
   Stage sg(ctx->d_stage);
   const uint8_t* src[4] = {input, output, c, s};
   uint8_t* d[4];
   for (int i = 0; i < 4; ++i) {
-    d[i] = sg.take(n * 32);
-    HIP_TRY(hipMemcpyAsync(d[i], src[i], n * 32, hipMemcpyHostToDevice, ctx->stream));
+    const size_t w = i < 2 ? pw : 32;
+    d[i] = sg.take(n * w);
+    HIP_TRY(hipMemcpyAsync(d[i], src[i], n * w, hipMemcpyHostToDevice, ctx->stream));
   }
   uint32_t* d_idx = reinterpret_cast<uint32_t*>(sg.take(n * 4));
   uint8_t* d_ad = sg.take(adb + 1);

@@ -80,6 +80,28 @@ __global__ void k_p256_init_comb(uint32_t* comb, const uint8_t* gen_xy, uint8_t*
   p256_comb_build_row(comb, w, x, y);
 }
 
+// ------------------------------------------------------------------------------------------------ key sets
+// `Public` keys a verifier meets again and again: each is decoded once and gets the rows of a radix-256 comb that a
+// challenge can reach (challenge_len + 1 rows of 128 entries: 244 KB for the suite's 16-byte challenges), so that
+// -c * Y in U = s G - c Y is 17 additions and no doubling, with no table to build per proof.  One lane per (key, row).
+__global__ void __launch_bounds__(64) k_p256_keyset_build(size_t n_keys, const uint8_t* pks33, uint32_t* aff, uint8_t* valid,
+                                                          uint32_t* combs, int rows) {
+  const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (t >= n_keys * (size_t)rows) return;
+  const size_t key = t / rows;
+  const int w = (int)(t % rows);
+  FeN x, y;
+  const bool ok = sec1_decode(x, y, pks33 + key * SEC1_LEN);
+  if (w == 0) {
+    valid[key] = ok ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { aff[key * 18 + j] = x.v[j]; aff[key * 18 + NL + j] = y.v[j]; }
+  }
+  // an undecodable key still gets a (never used) row of some point: the generator's place holder keeps the lanes uniform
+  const FeN gx = fe_select(ok, x, fe_one()), gy = fe_select(ok, y, fe_one());
+  p256_comb_build_row(combs + key * (size_t)rows * P256_COMB_ROW_WORDS, w, gx, gy);
+}
+
 // ------------------------------------------------------------------------------------------------ IETF verify
 __global__ void __launch_bounds__(P256_BLOCK) k_p256_verify_decode(p256::VerifyArgs a) {
   const size_t i = (size_t)blockIdx.x * P256_BLOCK + threadIdx.x;
@@ -88,6 +110,38 @@ __global__ void __launch_bounds__(P256_BLOCK) k_p256_verify_decode(p256::VerifyA
   FeN x[3], y[3];
   Sec1W enc[3];
   uint32_t c[8], s[8];
+  if (a.key_index) {
+    // keyed: Y comes from the key set (decoded when the set was made); H and Gamma are wire data as ever
+    const size_t k = a.key_index[i] < a.n_keys ? a.key_index[i] : 0;
+    bool ok = a.key_index[i] < a.n_keys && a.key_valid[k] != 0;
+    const uint8_t* ke = a.key_enc + k * SEC1_LEN;
+    enc[0].tag = ke[0];
+    load_be256(enc[0].xw, ke + 1);
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { x[0].v[j] = a.key_aff[k * 18 + j]; y[0].v[j] = a.key_aff[k * 18 + NL + j]; }
+#pragma unroll 1
+    for (int j = 1; j < 3; ++j) {
+      const uint8_t* e = (j == 1 ? a.h : a.gamma) + i * SEC1_LEN;
+      FeN xx, yy;
+      ok = sec1_decode(xx, yy, e) && ok;
+      Sec1W w;
+      w.tag = e[0];
+      load_be256(w.xw, e + 1);
+      if (j == 1) { x[1] = xx; y[1] = yy; enc[1] = w; } else { x[2] = xx; y[2] = yy; enc[2] = w; }
+    }
+    p256_challenge_decode(c, a.c + i * 32, a.str.challenge_len);
+    ok = p256_scalar_decode(s, a.s + i * 32) && ok;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      ws_store_fe(a.ws.aff, cap, i, j * 18, x[j]);
+      ws_store_fe(a.ws.aff, cap, i, j * 18 + 9, y[j]);
+      ws_store_enc(a.ws.enc, cap, i, j, enc[j]);
+    }
+    ws_store8(a.ws.sc, cap, i, 0, c);
+    ws_store8(a.ws.sc, cap, i, 8, s);
+    a.ws.flags[i] = ok ? 1 : 0;
+    return;
+  }
   const bool ok = a.affine_in
                       ? p256_verify_decode_affine_item(x, y, enc, c, s, a.pk + i * 64, a.h + i * 64, a.gamma + i * 64, a.c + i * 32,
                                                        a.s + i * 32, a.affine_in == 2, a.str.challenge_len)
@@ -118,6 +172,13 @@ __global__ void __launch_bounds__(P256_BLOCK) __attribute__((amdgpu_waves_per_eu
   ws_load8(c, a.ws.sc, cap, i, 0);
   ws_load8(s, a.ws.sc, cap, i, 8);
   if constexpr (WHICH == 0) {
+    if (a.key_index) {
+      // keyed: U = s G - c Y from two combs: 33 + key_rows additions, no doubling, no table (wave-uniform branch)
+      const size_t k = a.key_index[i] < a.n_keys ? a.key_index[i] : 0;
+      const PtW cy = sw_comb_mul(a.key_combs + k * (size_t)a.key_rows * P256_COMB_ROW_WORDS, c, a.key_rows);
+      ptw_store(ws_pt(a.ws.pts, cap, i, 0), cap, sw_add(sw_comb_mul(a.comb, s), sw_cneg(true, cy)));
+      return;
+    }
     uint32_t* ty = ws_tab(a.ws.tabs, cap, i, 0);
     sw_build_table(ty, 1, sw_from_affine(ws_load_fe(a.ws.aff, cap, i, 0), ws_load_fe(a.ws.aff, cap, i, 9)));
     ptw_store(ws_pt(a.ws.pts, cap, i, 0), cap, sw_comb_minus_win(a.comb, ty, 1, s, c, sw_challenge_windows(a.str)));
@@ -451,6 +512,12 @@ void launch_init_comb(uint32_t* comb, const uint8_t* d_gen_xy, uint8_t* d_ok, hi
   hipLaunchKernelGGL(k_p256_init_comb, dim3(1), dim3(64), 0, st, comb, d_gen_xy, d_ok);
 }
 
+size_t key_comb_bytes(int rows) { return (size_t)rows * P256_COMB_ROW_WORDS * sizeof(uint32_t); }
+void launch_keyset_build(size_t n_keys, const uint8_t* pks33, uint32_t* aff, uint8_t* valid, uint32_t* combs, int rows, hipStream_t st) {
+  if (!n_keys) return;
+  const size_t lanes = n_keys * (size_t)rows;
+  hipLaunchKernelGGL(k_p256_keyset_build, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, n_keys, pks33, aff, valid, combs, rows);
+}
 void launch_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
   const unsigned g = blocks_for(a.n);
   if (ev) (void)hipEventRecord(ev[0], st);

@@ -46,6 +46,14 @@ struct VerifyArgs {
   Ws ws;
   const uint32_t* comb;              // fixed-base comb of the generator
   SuiteStr str;
+  // keyed verification (key_index != nullptr): pk is ignored; item i is verified under key key_index[i] of a key set
+  const uint32_t* key_index;         // [n]
+  size_t n_keys;
+  const uint8_t* key_enc;            // [n_keys][33] Sec1 strings (hashed by the challenge)
+  const uint32_t* key_aff;           // [n_keys][18] Montgomery affine coordinates
+  const uint8_t* key_valid;          // [n_keys]
+  const uint32_t* key_combs;         // [n_keys][key_rows][128][28] radix-256 comb rows 0 .. key_rows - 1 of every key
+  int key_rows;                      // challenge_len + 1: the rows a challenge can reach
 };
 struct ProveArgs {
   size_t n;
@@ -122,6 +130,9 @@ struct RlcArgs {
 void launch_pedersen_rlc(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev);
 
 size_t comb_bytes();
+// `Public` keys with resident combs (vrfhip_keyset_create on this suite): rows = challenge_len + 1 rows of 128 entries each
+size_t key_comb_bytes(int rows);
+void launch_keyset_build(size_t n_keys, const uint8_t* pks33, uint32_t* aff, uint8_t* valid, uint32_t* combs, int rows, hipStream_t st);
 // comb of the point gen_xy (x || y, 32-byte little-endian canonical integers, as vrfhip_suite_desc carries it);
 // ok[0] = 1 if it is a point of the curve other than the point at infinity
 void launch_init_comb(uint32_t* comb, const uint8_t* d_gen_xy, uint8_t* d_ok, hipStream_t st);

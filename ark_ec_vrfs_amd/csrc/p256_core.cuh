@@ -380,12 +380,13 @@ VRF_HD uint32_t sw_recode8(uint32_t rec[8], const uint32_t k[8]) {
   }
   return c;
 }
-VRF_HD PtW sw_comb_mul(const uint32_t* comb, const uint32_t k[8]) {
+// rows: how many rows of the comb the scalar can reach (a challenge of L bytes: L + 1; default: all 33)
+VRF_HD PtW sw_comb_mul(const uint32_t* comb, const uint32_t k[8], int rows = P256_COMB_ROWS) {
   uint32_t rec[8];
   const uint32_t top = sw_recode8(rec, k);
   PtW acc = sw_identity();
 #pragma unroll 1
-  for (int w = 0; w < P256_COMB_ROWS; ++w) {
+  for (int w = 0; w < rows; ++w) {
     uint32_t word = rec[0];
 #pragma unroll
     for (int i = 1; i < 8; ++i)

@@ -465,7 +465,8 @@ def cfg_pedersen_jubjub(D, args, msg, lo, want_cpu):
     rf, v = roofline("k_prove_mul (253-bit Straus: JubJub has no endomorphism)", B_PED_PROVE, n, ms[1], groups,
                      pmc_for("pedersen_prove_jubjub", lg))
     res["pedersen_prove_jubjub"] = {
-        "workload": "Pedersen VRF prove, JubJub_SHA-512_TAI, batch 2^%d per GPU (BASELINE.json configs[3], prove half)" % lg,
+        "workload": "Pedersen VRF prove, JubJub_SHA-512_TAI, batch 2^%d per GPU (BASELINE.json configs[3], prove half); non-upstream "
+                    "blinding base (vrfhip_test_blinding_base: upstream's JubJub constant is not pinned)" % lg,
         "value": D.world * n * args.config_steps / el, "unit": "proofs/s", "ms_per_step": el / args.config_steps * 1e3,
         "bytes_per_unit": B_PED_PROVE, "roofline": rf, "valu": v,
         "stage_ms_per_step": {"tai_find+prepare": ms[0], "mul": ms[1], "finish": ms[3]}}
@@ -622,7 +623,7 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
             ms, groups = stage_avg(cx)
             assert int(st.sum()) == 0
             res["pedersen_prove_" + tag] = {
-                "workload": "Pedersen VRF prove, %s, batch 2^%d per GPU" % (title, lg),
+                "workload": "Pedersen VRF prove, %s, batch 2^%d per GPU; non-upstream blinding base (vrfhip_test_blinding_base)" % (title, lg),
                 "value": D.world * n * args.config_steps / el, "unit": "proofs/s", "ms_per_step": el / args.config_steps * 1e3,
                 "stage_ms_per_step": {"tai_find+prepare": ms[0], "mul": ms[1], "finish": ms[3]}}
             fn = lambda: cx.pedersen_verify_batch_dev(hh, g, pc, rr, okp, s_, sbb, st)
@@ -633,9 +634,24 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
             ms, groups = stage_avg(cx)
             assert int(st.sum()) == 0
             res["pedersen_verify_" + tag] = {
-                "workload": "Pedersen VRF verify, %s, batch 2^%d per GPU, per proof, Sec1 wire format" % (title, lg),
+                "workload": "Pedersen VRF verify, %s, batch 2^%d per GPU, per proof, Sec1 wire format; non-upstream blinding base" % (title, lg),
                 "value": D.world * n * args.config_steps / el, "unit": "verifies/s", "ms_per_step": el / args.config_steps * 1e3,
                 "stage_ms_per_step": {"decode": ms[0], "eq_h": ms[1], "eq_g": ms[2], "finish": ms[3]}}
+            # ... and the whole batch through ONE MSM over 5 n + 2 points (k_p256_msm.hip)
+            flag = torch.empty(1, dtype=torch.uint8, device=D.dev)
+            seed = os.urandom(32)
+            fn = lambda: cx.pedersen_verify_batch_rlc_dev(hh, g, pc, rr, okp, s_, sbb, st, flag, seed)
+            fn(); torch.cuda.synchronize()
+            cx.profile(True)
+            el, _ = timed(D, fn, args.config_steps, 1)
+            cx.profile(False)
+            ms, groups = stage_avg(cx)
+            assert int(flag[0]) == 0 and int(st.sum()) == 0
+            res["pedersen_verify_batched_" + tag] = {
+                "workload": "Pedersen VRF verify, %s, whole batch by one Pippenger MSM (random linear combination), 2^%d per GPU" % (title, lg),
+                "value": D.world * n * args.config_steps / el, "unit": "verifies/s", "ms_per_step": el / args.config_steps * 1e3,
+                "stage_ms_per_step": {"decode": ms[0], "msm_buckets": ms[1], "msm_final": ms[2] + ms[3]},
+                "note": "non-upstream blinding base (vrfhip_test_blinding_base)"}
             fn = lambda: cx.ietf_prove_batch_dev(sk, msg, 32, g, c, s_, pk, hh, st)        # the IETF proofs back for the CPU leg
             fn(); torch.cuda.synchronize()
         if want_cpu:

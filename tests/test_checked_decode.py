@@ -91,8 +91,11 @@ def test_flags_roundtrip_and_default_is_checked(ctx):
     ctx.set_flags(ctx.COORDS_MONT256)
     assert ctx.get_flags() == 32
     ctx.set_flags(0)
+    ctx.set_flags(ctx.CT_TABLES)                    # prover hardening (tests/test_new_suites.py: same proof bytes)
+    assert ctx.get_flags() == 64
+    ctx.set_flags(0)
     with pytest.raises(Exception):
-        ctx.set_flags(64)
+        ctx.set_flags(128)
 
 
 @pytest.mark.gpu

@@ -292,3 +292,33 @@ def test_gpu_coords_mont256_equal_the_canonical_format(ctx):
             assert (gp[key] == to_mont(pxy[idx])).all(), key
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_ct_table_lookups_give_the_same_proofs():
+    """VRFHIP_FLAG_CT_TABLES: the provers' per-proof window-table lookups read all eight entries and keep
+    one by masks.  Proof bytes must not change -- every suite, both schemes, against the same context without the flag (which
+    the parity tests hold against the oracles)."""
+    import numpy as np
+    from ark_ec_vrfs_amd import (BabyJubJubSha512Tai, BandersnatchSha512Ell2, Context, Ed25519Sha512Tai, JubJubSha512Tai,
+                                 Secp256r1Sha256Tai)
+    n = 3000
+    for suite in (BandersnatchSha512Ell2, JubJubSha512Tai, Ed25519Sha512Tai, BabyJubJubSha512Tai, Secp256r1Sha256Tai):
+        c = Context(0, suite=suite, test_blinding_base=True)
+        try:
+            sk, _ = c.secret_from_seed_batch(np.arange(n * 8, dtype=np.uint8).reshape(n, 8))
+            sk[7] = 255                                   # not canonical: InvalidData either way
+            msgs = np.random.default_rng(5).integers(0, 256, (n, 19), dtype=np.uint8)
+            a = c.ietf_prove_batch(sk, msgs=msgs, ad=b"ct")
+            p = c.pedersen_prove_batch(sk, msgs=msgs, ad=b"ct")
+            c.set_flags(c.CT_TABLES)
+            a2 = c.ietf_prove_batch(sk, msgs=msgs, ad=b"ct")
+            p2 = c.pedersen_prove_batch(sk, msgs=msgs, ad=b"ct")
+            c.set_flags(0)
+            assert a["status"][7] == 2 and a["status"].sum() == 2
+            for k in a:
+                assert (a[k] == a2[k]).all(), (suite.__name__, k)
+            for k in p:
+                assert (p[k] == p2[k]).all(), (suite.__name__, k)
+        finally:
+            c.close()

@@ -682,14 +682,12 @@ def test_gpu_xy_forms_for_typed_callers(gpu):
 
 @pytest.mark.gpu
 def test_gpu_entry_points_outside_the_suite_are_refused(gpu):
-    """What the suite still lacks answers UNSUPPORTED before any byte is read: the x || y form of the batched Pedersen verifier
-    and resident key sets.  (Round 4 built the MSM and the batched verifier: tests below.)"""
+    """What the suite still lacks answers UNSUPPORTED before any byte is read: the x || y form of the batched Pedersen
+    verifier.  (Round 4 built the MSM, the batched verifier and key sets: tests below.)"""
     from ark_ec_vrfs_amd import VrfHipError
     z32, z33, z64 = np.zeros((2, 32), np.uint8), np.zeros((2, 33), np.uint8), np.zeros((2, 64), np.uint8)
     with pytest.raises(VrfHipError):
         gpu.pedersen_verify_batch_rlc(z64, z64, z64, z64, z64, z32, z32, seed=bytes(32), affine=True)
-    with pytest.raises(VrfHipError):
-        gpu.keyset_create(z33)
     gpu.set_prevalidated(True)                      # cofactor 1: nothing to skip, accepted and without effect
     assert gpu.ietf_verify_batch(z33, z33, z33, z32, z32)[0] == 2
     gpu.set_prevalidated(False)
@@ -828,3 +826,42 @@ def test_gpu_batched_pedersen_verifier(gpu):
     gpu.pedersen_verify_batch_rlc_dev(*[t[k] for k in F], status, flag, seed, ad=ad, ad_len=3)
     torch.cuda.synchronize()
     assert int(flag[0]) == 1 and int(status.sum()) == 0           # the batch stage names no culprit: that is the fallback's job
+
+
+@pytest.mark.gpu
+def test_gpu_keyed_verification(gpu):
+    """`ietf::Verifier::verify` against a resident key set (vrfhip_keyset_create on this suite: every key decoded once, the 17
+    comb rows a 16-byte challenge can reach kept in HBM; U = s G - c Y from two combs).  Statuses equal the plain verifier's
+    and the C oracle's on a batch with every kind of defect; an undecodable key and a key index out of range are InvalidData."""
+    rng = np.random.default_rng(55)
+    nk, n = 37, 5000
+    ksk = rng.integers(0, 256, (nk, 32), dtype=np.uint8); ksk[:, 0] &= 0x7f
+    kp = gpu.ietf_prove_batch(ksk, msgs=[b"k"] * nk, ad=b"")
+    keys = kp["pk"].copy()
+    keys[5] = 0; keys[5, 0] = 7                                       # not a Sec1 string
+    ks, kst = gpu.keyset_create(keys)
+    try:
+        assert list(np.flatnonzero(kst)) == [5] and kst[5] == 2 and ks.bytes() > nk * 17 * 128 * 112
+        idx = rng.integers(0, nk, n).astype(np.uint32)
+        idx[idx == 5] = 6
+        msg = rng.integers(0, 256, (n, 17), dtype=np.uint8)
+        pr = gpu.ietf_prove_batch(ksk[idx], msgs=msg, ad=b"keyed")
+        assert not pr["status"].any() and (pr["pk"] == keys[idx]).all()
+        inp, out, c, s = (pr[k].copy() for k in ("input", "output", "c", "s"))
+        s[::7, 30] ^= 1
+        c[3::31, 31] ^= 1
+        c[4::37, 2] ^= 1                                              # a c above 16 bytes
+        out[11::67] = pr["output"][12::67][: len(out[11::67])]
+        inp[13::71, 0] = 9                                             # undecodable H
+        s[5::61] = np.frombuffer(be(N), np.uint8)
+        idx2 = idx.copy(); idx2[17::97] = (idx2[17::97] + 1) % nk       # another signer's key
+        idx2[idx2 == 5] = 4
+        want = co.p256_ietf_verify_batch(keys[idx2], inp, out, c, s, b"keyed", threads=8)
+        plain = gpu.ietf_verify_batch(keys[idx2], inp, out, c, s, ad=b"keyed")
+        got = gpu.ietf_verify_batch_keyed(ks, idx2, inp, out, c, s, ad=b"keyed")
+        assert (plain == want).all() and (got == want).all() and set(np.unique(want)) == {0, 1, 2}
+        idx3 = idx[:64].copy(); idx3[1] = 5; idx3[2] = nk; idx3[3] = 0xffffffff
+        got = gpu.ietf_verify_batch_keyed(ks, idx3, pr["input"][:64], pr["output"][:64], pr["c"][:64], pr["s"][:64], ad=b"keyed")
+        assert list(got[1:4]) == [2, 2, 2] and not got[4:].any() and got[0] == 0
+    finally:
+        ks.close()
