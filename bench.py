@@ -775,7 +775,7 @@ def cfg_pairing(D, args, ctx, want_cpu):
                      "ms_per_step": el / args.config_steps * 1e3, "bytes_per_unit": bytes_per, "roofline": rf, "valu": v}
 
     run("pairing_check", lambda: ctx.pairing_check_batch_dev(d1, d2, pstat), B_PAIRING,
-        "k_pairing_check2_oct (one item per 8 lanes, Fp2 split over lane pairs: 2-pair Miller loop + final exponentiation)",
+        "k_pairing_lines_oct + k_pairing_check2_oct_lines (one item per 8 lanes, Fp2 split over lane pairs: G2 lines -> HBM, then 2-pair Miller loop + final exponentiation)",
         "BLS12-381 pairing check, 2 (G1, G2) pairs per item, batch 2^14 per GPU (BASELINE.json configs[4]); "
         "8 fixture items tiled (the kernel has no data-dependent shortcuts)", "pairing_check")
     s1 = np.stack([hx(h) for h in fx["shared"]])

@@ -98,15 +98,15 @@ json.dump({"command": "rocprofv3 {--kernel-trace --stats | --pmc <one group per 
 
 # config -> (kernel substring, grid) of its dominant kernel
 N20, N16, N14 = 1 << 20, 1 << 16, 1 << 14
-CONFIGS = [("ietf_verify", "k_verify_straus<vrf::SuiteBS, 1>", N20, 20), ("ietf_prove", "k_prove_mul<vrf::SuiteBS>", 2 * N16, 16),
-           ("ietf_prove_ed25519", "k_prove_mul<vrf::SuiteED>", 2 * N20, 20), ("ietf_verify_ed25519", "k_verify_decode<vrf::SuiteED, 2>", None, 20),
-           ("ietf_prove_babyjubjub", "k_prove_mul<vrf::SuiteBJ>", 2 * N20, 20),
+CONFIGS = [("ietf_verify", "k_verify_straus<vrf::SuiteBS, 1>", N20, 20), ("ietf_prove", "k_prove_mul<vrf::SuiteBS, false>", 2 * N16, 16),
+           ("ietf_prove_ed25519", "k_prove_mul<vrf::SuiteED, false>", 2 * N20, 20), ("ietf_verify_ed25519", "k_verify_decode<vrf::SuiteED, 2>", None, 20),
+           ("ietf_prove_babyjubjub", "k_prove_mul<vrf::SuiteBJ, false>", 2 * N20, 20),
            ("ietf_verify_babyjubjub", "k_verify_straus<vrf::SuiteBJ, 1>", N20, 20),
            ("ietf_prove_secp256r1", "k_p256_prove_mul<0>", 4 * N20, 20), ("ietf_verify_secp256r1", "k_p256_verify_mul<1>", N20, 20),
-           ("pedersen_prove_jubjub", "k_prove_mul<vrf::SuiteJJ>", 2 * N20, 20),
+           ("pedersen_prove_jubjub", "k_prove_mul<vrf::SuiteJJ, false>", 2 * N20, 20),
            ("pedersen_verify_jubjub", "k_ped_verify_straus<vrf::SuiteJJ, 0>", N20, 20),
            ("pedersen_rlc_jubjub", "k_rlc_decode<vrf::SuiteJJ, 2>", None, 20),
-           ("pairing_check", "k_pairing_check2_oct(", 8 * N14, 14), ("pairing_check_shared", "k_pairing_check2_oct_prepared", 8 * N14, 14)]
+           ("pairing_check", "k_pairing_check2_oct_lines", 8 * N14, 14), ("pairing_check_shared", "k_pairing_check2_oct_prepared", 8 * N14, 14)]
 out = collections.OrderedDict()
 for cfg, pat, grid, lg in CONFIGS:
     pat = pat.rstrip("(")
