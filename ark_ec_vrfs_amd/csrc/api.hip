@@ -1420,7 +1420,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
     // secp256r1: launch groups of at most 2^20 proofs, each ONE MSM over 5 m + 2 points; no per-proof workspace at all
     const size_t cap = std::min<size_t>(n, size_t(1) << 20);
     const size_t Ncap = 5 * cap + 2;
-    const int groups_cap = p256::msm_groups(Ncap, ctx->cus);
+    const int groups_cap = p256::msm_groups(Ncap, 3 * cap + 2, ctx->cus);
     const size_t msm_b = Stage::pad(p256::msm_workspace_bytes(Ncap, groups_cap));
     int32_t rc2 = ensure_msm_workspace(ctx, msm_b + Stage::pad(digest_ws_bytes(cap)) + 256);
     if (rc2) return rc2;
@@ -1435,7 +1435,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
       a.r = d_r + base * 33; a.ok = d_ok + base * 33; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
       a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
       a.status = d_status + base;
-      a.L = p256::msm_layout(N, p256::msm_groups(N, ctx->cus), ctx->d_msm_ws);
+      a.L = p256::msm_layout(N, 3 * m + 2, p256::msm_groups(N, 3 * m + 2, ctx->cus), ctx->d_msm_ws);
       std::memcpy(a.seed, seed, 32);
       std::memcpy(a.gen_xy, ctx->desc.generator, 64);
       std::memcpy(a.b_xy, ctx->desc.blinding_base, 64);
@@ -1616,7 +1616,7 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (ctx->sw) {
     // secp256r1: big-endian scalars, the sum as a 33-byte Sec1 string (0x00 + zeros = the point at infinity)
-    const int groups = p256::msm_groups(n ? n : 1, ctx->cus);
+    const int groups = p256::msm_groups(n ? n : 1, n ? n : 1, ctx->cus);
     int32_t rc = ensure_msm_workspace(ctx, p256::msm_workspace_bytes(n ? n : 1, groups));
     if (rc) return rc;
     p256::launch_msm(n, d_bases_xy, ctx->coords_mont256() ? 1 : 0, d_scalars, d_out_point, d_out_xy, d_status, ctx->d_msm_ws, groups, st);

@@ -3,9 +3,10 @@
 // (named in BASELINE.json north_star; reached from /root/reference through `reexports`,
 // src/lib.rs:14).
 //
-// Pippenger with signed 11-bit windows (msm.cuh).
+// Pippenger with signed 10-bit windows (msm.cuh).
 //   k_msm_prep    : bases -> Montgomery affine-cached (x, y, d*x*y); scalars -> signed digits
-//   k_msm_buckets : one workgroup per (window, point-group); the 1024 buckets of the window live in LDS.
+//   k_msm_buckets : one workgroup per (window, point-group); the 512 buckets of the window live in LDS (72 KB: two
+//                   workgroups per CU).
 //                   The workgroup counting-sorts its points by bucket (LDS atomics + wave-shuffle block
 //                   scan), then the sorted list is cut into 512 EQUAL chunks, one per lane: every lane
 //                   performs the same number of mixed additions whatever the digit distribution.  A
@@ -66,7 +67,7 @@ constexpr uint32_t MSM_NONE = 0xffffffffu;
 template <class S>
 __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
   extern __shared__ uint32_t lds[];
-  uint32_t* bucket = lds;                                   // [1024][36] bucket accumulators (147,456 B)
+  uint32_t* bucket = lds;                                   // [MSM_BUCKETS][36] bucket accumulators (73,728 B)
   uint32_t* counts = lds + MSM_BUCKETS * MSM_PT_WORDS;      // [1024] bucket sizes
   uint32_t* cursor = counts + MSM_BUCKETS;                  // [1024] scatter cursors, later head bucket ids
   uint32_t* wsum = cursor + MSM_BUCKETS;                    // [8] per-wave totals for the block scan
@@ -87,11 +88,12 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
   uint32_t* heads = L.heads + (size_t)wg * MSM_BLOCK * MSM_PT_WORDS;
   {
     PtE id = te_identity();
-    lds_store_pt(bucket + (2 * t) * MSM_PT_WORDS, id);
-    lds_store_pt(bucket + (2 * t + 1) * MSM_PT_WORDS, id);
+#pragma unroll
+    for (int u = 0; u < MSM_BPL; ++u) lds_store_pt(bucket + (MSM_BPL * t + u) * MSM_PT_WORDS, id);
   }
   // 1. histogram of the group's digits
-  counts[t] = 0; counts[t + MSM_BLOCK] = 0;
+#pragma unroll
+  for (int u = 0; u < MSM_BPL; ++u) counts[t + u * MSM_BLOCK] = 0;
   __syncthreads();
   // four independent digit loads per trip keep the memory pipe busy (a lane's trip is latency-bound)
   for (uint32_t j0 = t; j0 < cnt_all; j0 += 4 * MSM_BLOCK) {
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
   // 2. exclusive scan over 1024 counts: lane t scans its pair, waves scan by shuffles
   uint32_t m;
   {
-    uint32_t c0 = counts[2 * t], c1 = counts[2 * t + 1];
+    uint32_t c0 = counts[MSM_BPL * t], c1 = MSM_BPL == 2 ? counts[MSM_BPL * t + MSM_BPL - 1] : 0u;
     uint32_t v = c0 + c1, incl = v;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
@@ -126,7 +128,8 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
     }
     m = total;
     uint32_t excl = wbase + incl - v;
-    cursor[2 * t] = excl; cursor[2 * t + 1] = excl + c0;
+    cursor[MSM_BPL * t] = excl;
+    if (MSM_BPL == 2) cursor[MSM_BPL * t + MSM_BPL - 1] = excl + c0;
   }
   __syncthreads();
   // 3. scatter into bucket order, transposed so that entry i of lane l sits at list[i*512 + l]
@@ -206,18 +209,21 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
     lds_store_pt(slot, te_add<S>(lds_load_pt(slot), h));
   }
   __syncthreads();
-  // ---- bucket reduction: R = sum_j j*B_j over j = 1..1024, lane t holds B_{2t+1}, B_{2t+2} ----
-  // S_t = B_{2t+1} + B_{2t+2};  L_t = S_t + B_{2t+2};  R = sum_t L_t + 2 sum_{t>=1} Suf_t,
-  // Suf_t = sum_{u>=t} S_u.  The staging area re-uses the bucket storage, one slot per lane.
+  // ---- bucket reduction: R = sum_j j*B_j.  One bucket per lane (10-bit windows): lane t holds B_{t+1}; a suffix scan gives
+  // S_t = sum_{u >= t} B_{u+1} and R = sum_t S_t.  Two per lane (11-bit): S_t = B_{2t+1} + B_{2t+2}, L_t = S_t + B_{2t+2},
+  // R = sum_t L_t + 2 sum_{t >= 1} Suf_t with Suf the suffix sums of S.  The staging area re-uses the bucket storage. ----
   PtE Ssum, V;
-  {
+  if (MSM_BPL == 2) {
     PtE b1 = lds_load_pt(bucket + (2 * t + 1) * MSM_PT_WORDS);
     Ssum = te_add<S>(lds_load_pt(bucket + (2 * t) * MSM_PT_WORDS), b1);
     V = te_add<S>(Ssum, b1);                      // L_t
+  } else {
+    Ssum = lds_load_pt(bucket + t * MSM_PT_WORDS);
+    V = te_identity();
   }
   __syncthreads();
   uint32_t* stage = lds;                          // [512][36]
-  // pass 0: suffix scan of S (Hillis-Steele);  pass 1: tree reduction of V = L + 2*Suf
+  // pass 0: suffix scan of S (Hillis-Steele);  pass 1: tree reduction
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     PtE cur = pass == 0 ? Ssum : V;
@@ -231,7 +237,11 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
       if (active) cur = te_add<S>(cur, lds_load_pt(stage + (t + s) * MSM_PT_WORDS));
     }
     if (pass == 0) {
-      if (t >= 1) V = te_add<S>(V, te_dbl<S>(cur, true));
+      if (MSM_BPL == 2) {
+        if (t >= 1) V = te_add<S>(V, te_dbl<S>(cur, true));
+      } else {
+        V = cur;                                  // S_t: the tree below sums them
+      }
     } else {
       V = cur;
     }
@@ -313,7 +323,7 @@ VRF_HD PtE te_dbl_quad(const PtE& p, int q) {
   return r;
 }
 
-constexpr int MSM_FINAL_BLOCK = 128;     // 23 windows x 4 lanes = 92 active lanes in two waves
+constexpr int MSM_FINAL_BLOCK = 128;     // 26 windows x 4 lanes = 104 active lanes in two waves
 
 template <class S>
 __global__ void __launch_bounds__(MSM_FINAL_BLOCK) k_msm_final(const uint32_t* part, int groups, int groups_hi,
@@ -405,14 +415,15 @@ static int msm_groups_hi(size_t n, size_t n_long, int groups) {
 }
 
 int msm_groups(size_t n, size_t n_long, int cus) {
-  // Workgroups = 12*g + 11*g_hi, each with the whole CU's LDS: aim at one full round of the chip for
-  // mid-sized inputs and two for large ones (the dispatcher evens out the tails), at least 16 points per
+  // Workgroups = MSM_W_SHORT g + (MSM_W - MSM_W_SHORT) g_hi, two of them per CU (72 KB of LDS each): aim at one full round
+  // of the chip for mid-sized inputs and two for large ones (the dispatcher evens out the tails), at least 16 points per
   // lane and group, never more than 2^21 points per group.
+  const int slots = 2 * cus;
   const int rounds = n >= (size_t(1) << 22) ? 2 : 1;
   const double share = n ? (double)n_long / (double)n : 1.0;
-  int g = (int)(rounds * cus / (MSM_W_SHORT + (MSM_W - MSM_W_SHORT) * share));
+  int g = (int)(rounds * slots / (MSM_W_SHORT + (MSM_W - MSM_W_SHORT) * share));
   if (g < 1) g = 1;
-  while (g > 1 && MSM_W_SHORT * g + (MSM_W - MSM_W_SHORT) * msm_groups_hi(n, n_long, g) > rounds * cus) --g;
+  while (g > 1 && MSM_W_SHORT * g + (MSM_W - MSM_W_SHORT) * msm_groups_hi(n, n_long, g) > rounds * slots) --g;
   size_t max_g = (n + 8191) / 8192;
   if ((size_t)g > max_g) g = (int)max_g;
   if (g < 1) g = 1;
@@ -459,7 +470,7 @@ MsmLayout msm_layout(size_t n, size_t n_long, int groups, void* ws) {
 template <class S>
 static void launch_msm_core_t(const MsmLayout& L, uint8_t* out_enc, uint8_t* out_xy, uint8_t* status,
                               uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev) {
-  const size_t lds_bytes = ((size_t)MSM_BUCKETS * MSM_PT_WORDS + 2 * MSM_BUCKETS + 16) * 4;   // 155,712 B of 160 KiB
+  const size_t lds_bytes = ((size_t)MSM_BUCKETS * MSM_PT_WORDS + 2 * MSM_BUCKETS + 16) * 4;   // 77,888 B: two workgroups per CU
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_buckets<S>),

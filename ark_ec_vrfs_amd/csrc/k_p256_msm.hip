@@ -113,9 +113,16 @@ __global__ void __launch_bounds__(PM_BLOCK) k_pm_buckets(MsmL L) {
   const int t = threadIdx.x;
   const int wg = blockIdx.x;
   const int w = wg / L.groups, g = wg % L.groups;
-  const size_t lo = (size_t)g * L.per_group;
-  const size_t hi = lo + L.per_group < L.n ? lo + L.per_group : L.n;
-  const uint32_t cnt_all = lo < hi ? (uint32_t)(hi - lo) : 0u;
+  // windows a bare weight cannot reach hold the full-size scalars only: fewer, equally sized groups
+  const bool high = w >= p256::MSM_W_SHORT;
+  const size_t span = high ? L.per_group_hi : L.per_group, end = high ? L.n_long : L.n;
+  const size_t lo = (size_t)g * span;
+  const size_t hi = lo + span < end ? lo + span : end;
+  const uint32_t cnt_all = (!(high && g >= L.groups_hi) && lo < hi) ? (uint32_t)(hi - lo) : 0u;
+  if (cnt_all == 0) {                          // wave-uniform: an idle workgroup of a high window (or an empty tail group)
+    if (t == 0) pm_store(L.part + ((size_t)w * L.groups + g) * PM_PT, sw_identity());
+    return;
+  }
   const int16_t* dig = L.digits + (size_t)w * L.n + lo;
   const uint32_t* P = L.pts + lo * PM_AFF;
   uint32_t* list = L.lists + (size_t)wg * L.list_cap;
@@ -395,8 +402,11 @@ VRF_NS_END
 namespace vrf {
 namespace p256 {
 
-int msm_groups(size_t n, int cus) {
-  int g = 2 * cus / MSM_W;                         // two workgroups of 54 KiB LDS fit a CU: about one round of the chip
+int msm_groups(size_t n, size_t n_long, int cus) {
+  // two workgroups of 54 KiB LDS fit a CU; the active workgroups -- MSM_W_SHORT g in the low windows, (MSM_W - MSM_W_SHORT)
+  // g n_long / n in the high ones -- should fill about one round of the chip
+  const double share = n ? (double)(n_long < n ? n_long : n) / (double)n : 1.0;
+  int g = (int)(2.0 * cus / (MSM_W_SHORT + (MSM_W - MSM_W_SHORT) * share));
   if (g < 1) g = 1;
   const size_t max_g = (n + 4095) / 4096;          // at least 8 points per lane and group
   if ((size_t)g > max_g) g = (int)max_g;
@@ -410,10 +420,17 @@ size_t msm_workspace_bytes(size_t n, int groups) {
   return pad256(n * PM_AFF * 4) + pad256((size_t)MSM_W * n * 2) + pad256(wgs * list_cap * 4) + pad256(wgs * PM_BLOCK * PM_PT * 4) +
          pad256(wgs * PM_PT * 4) + 256 + 256;
 }
-MsmL msm_layout(size_t n, int groups, void* ws) {
+MsmL msm_layout(size_t n, size_t n_long, int groups, void* ws) {
   MsmL L;
   L.n = n; L.groups = groups;
+  L.n_long = n_long < n ? n_long : n;
   L.per_group = (n + groups - 1) / groups;
+  int gh = (int)(((double)L.n_long / (double)(n ? n : 1)) * groups + 0.999);
+  if (gh < 1) gh = 1;
+  if (gh > groups) gh = groups;
+  L.groups_hi = gh;
+  L.per_group_hi = (L.n_long + gh - 1) / gh;
+  if (L.per_group_hi > L.per_group) { L.groups_hi = groups; L.per_group_hi = (L.n_long + groups - 1) / groups; }
   L.list_cap = L.per_group + PM_BLOCK;
   const size_t wgs = (size_t)MSM_W * groups;
   uint8_t* p = static_cast<uint8_t*>(ws);
@@ -429,8 +446,8 @@ MsmL msm_layout(size_t n, int groups, void* ws) {
 
 void launch_msm(size_t n, const uint8_t* xy, int mont256, const uint8_t* scalars_be, uint8_t* out33, uint8_t* out_xy, uint8_t* status1,
                 void* ws, int groups, hipStream_t st) {
-  MsmL L = msm_layout(n ? n : 1, groups, ws);
-  L.n = n;
+  MsmL L = msm_layout(n ? n : 1, n ? n : 1, groups, ws);
+  L.n = n; L.n_long = n;
   (void)hipMemsetAsync(L.flags, 0, 256, st);
   if (n == 0) {                                    // the empty sum: the point at infinity
     if (out33) (void)hipMemsetAsync(out33, 0, 33, st);

@@ -91,10 +91,15 @@ struct PedVerifyArgs {
 constexpr int MSM_C = 10;                   // signed window bits: 512 buckets x 108 B = 54 KiB of LDS
 constexpr int MSM_W = 26;                   // windows of a folded 256-bit scalar (260 bits)
 constexpr int MSM_AFF_STRIDE = 32;          // words per affine point slot (x, y: 18 words) -- one 128-B line per gather
+constexpr int MSM_W_SHORT = 13;             // windows a 128-bit weight can reach (130 bits)
 struct MsmL {
   size_t n;
-  int groups;
-  size_t per_group, list_cap;
+  // Points [0, n_long) carry full-size scalars, points [n_long, n) bare 128-bit weights whose digits in the windows >=
+  // MSM_W_SHORT are zero: those windows partition [0, n_long) only, into groups_hi <= groups groups of about the same size
+  // as a low window's (the workgroups g >= groups_hi of a high window have nothing to do).
+  size_t n_long;
+  int groups, groups_hi;
+  size_t per_group, per_group_hi, list_cap;
   uint32_t* pts;             // [n][MSM_AFF_STRIDE]  Montgomery affine (x, y)
   int16_t* digits;           // [MSM_W][n]           signed digits in [-512, 512]; 0 = the point takes no part
   uint32_t* lists;           // [MSM_W*groups][list_cap] bucket-sorted entries, lane-transposed
@@ -103,9 +108,9 @@ struct MsmL {
   uint8_t* flags;            // [256] flags[0] != 0: an input of the plain MSM was invalid
   unsigned long long* cols;  // [2][8] limb columns of sum z'_i s_i and sum z'_i sb_i (batched verifier)
 };
-int msm_groups(size_t n, int cus);
+int msm_groups(size_t n, size_t n_long, int cus);
 size_t msm_workspace_bytes(size_t n, int groups);
-MsmL msm_layout(size_t n, int groups, void* ws);
+MsmL msm_layout(size_t n, size_t n_long, int groups, void* ws);
 // `VariableBaseMSM::msm`: bases n x 64 B x || y (little-endian canonical; mont256: arkworks Montgomery limbs; all-zero = the
 // point at infinity), scalars n x 32 B big-endian (< n).  out33: Sec1 (0x00 + zeros for the point at infinity), out_xy:
 // x || y (all-zero for it); status1[0] = 0 / 2 (a coordinate >= p, a point off the curve, a scalar >= n: outputs zeroed).
