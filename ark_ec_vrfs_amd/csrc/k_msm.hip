@@ -3,10 +3,9 @@
 // (named in BASELINE.json north_star; reached from /root/reference through `reexports`,
 // src/lib.rs:14).
 //
-// Pippenger with signed 10-bit windows (msm.cuh).
+// Pippenger with signed 11-bit windows (msm.cuh).
 //   k_msm_prep    : bases -> Montgomery affine-cached (x, y, d*x*y); scalars -> signed digits
-//   k_msm_buckets : one workgroup per (window, point-group); the 512 buckets of the window live in LDS (72 KB: two
-//                   workgroups per CU).
+//   k_msm_buckets : one workgroup per (window, point-group); the 1024 buckets of the window live in LDS.
 //                   The workgroup counting-sorts its points by bucket (LDS atomics + wave-shuffle block
 //                   scan), then the sorted list is cut into 512 EQUAL chunks, one per lane: every lane
 //                   performs the same number of mixed additions whatever the digit distribution.  A
@@ -67,17 +66,21 @@ constexpr uint32_t MSM_NONE = 0xffffffffu;
 template <class S>
 __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
   extern __shared__ uint32_t lds[];
-  uint32_t* bucket = lds;                                   // [MSM_BUCKETS][36] bucket accumulators (73,728 B)
+  uint32_t* bucket = lds;                                   // [MSM_BUCKETS][36] bucket accumulators (147,456 B)
   uint32_t* counts = lds + MSM_BUCKETS * MSM_PT_WORDS;      // [1024] bucket sizes
   uint32_t* cursor = counts + MSM_BUCKETS;                  // [1024] scatter cursors, later head bucket ids
   uint32_t* wsum = cursor + MSM_BUCKETS;                    // [8] per-wave totals for the block scan
   const int t = threadIdx.x;
   // low windows (all points) first, then the high windows (only the points with full-size scalars)
+  // GROUP-major: consecutive workgroups are the windows of ONE point group, so the workgroups that run at the same time
+  // gather from the same few slices of the point array and find each other's lines in the Infinity Cache / L2 (window-major
+  // order streamed the whole array from HBM once per window: 16.6 GB per batched-Pedersen launch, 2.2 TB/s of random 128-B
+  // reads -- the bound behind the 0.72 of the issue slots)
   const int wg = blockIdx.x;
   const int n_lo_wgs = MSM_W_SHORT * L.groups;
   const bool low = wg < n_lo_wgs;
-  const int w = low ? wg / L.groups : MSM_W_SHORT + (wg - n_lo_wgs) / L.groups_hi;
-  const int g = low ? wg % L.groups : (wg - n_lo_wgs) % L.groups_hi;
+  const int w = low ? wg % MSM_W_SHORT : MSM_W_SHORT + (wg - n_lo_wgs) % (MSM_W - MSM_W_SHORT);
+  const int g = low ? wg / MSM_W_SHORT : (wg - n_lo_wgs) / (MSM_W - MSM_W_SHORT);
   const size_t span = low ? L.per_group : L.per_group_hi, end = low ? L.n : L.n_long;
   const size_t lo = (size_t)g * span;
   const size_t hi = lo + span < end ? lo + span : end;
@@ -222,13 +225,13 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_buckets(MsmLayout L) {
     V = te_identity();
   }
   __syncthreads();
-  uint32_t* stage = lds;                          // [512][36]
+  uint32_t* stage = lds;                          // [MSM_BLOCK][36]
   // pass 0: suffix scan of S (Hillis-Steele);  pass 1: tree reduction
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     PtE cur = pass == 0 ? Ssum : V;
 #pragma unroll 1
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < MSM_LOG2_BLOCK; ++k) {
       const int s = pass == 0 ? (1 << k) : (MSM_BLOCK >> (k + 1));
       __syncthreads();
       lds_store_pt(stage + t * MSM_PT_WORDS, cur);
@@ -323,7 +326,7 @@ VRF_HD PtE te_dbl_quad(const PtE& p, int q) {
   return r;
 }
 
-constexpr int MSM_FINAL_BLOCK = 128;     // 26 windows x 4 lanes = 104 active lanes in two waves
+constexpr int MSM_FINAL_BLOCK = 128;     // 23 windows x 4 lanes = 92 active lanes in two waves
 
 template <class S>
 __global__ void __launch_bounds__(MSM_FINAL_BLOCK) k_msm_final(const uint32_t* part, int groups, int groups_hi,
@@ -415,10 +418,10 @@ static int msm_groups_hi(size_t n, size_t n_long, int groups) {
 }
 
 int msm_groups(size_t n, size_t n_long, int cus) {
-  // Workgroups = MSM_W_SHORT g + (MSM_W - MSM_W_SHORT) g_hi, two of them per CU (72 KB of LDS each): aim at one full round
-  // of the chip for mid-sized inputs and two for large ones (the dispatcher evens out the tails), at least 16 points per
-  // lane and group, never more than 2^21 points per group.
-  const int slots = 2 * cus;
+  // Workgroups = MSM_W_SHORT g + (MSM_W - MSM_W_SHORT) g_hi, as many per CU as their LDS allows (one with 1024 buckets):
+  // aim at one full round of the chip for mid-sized inputs and two for large ones (the dispatcher evens out the tails), at
+  // least 16 points per lane and group, never more than 2^21 points per group.
+  const int slots = cus;                          // 1024 buckets x 144 B: one workgroup per CU
   const int rounds = n >= (size_t(1) << 22) ? 2 : 1;
   const double share = n ? (double)n_long / (double)n : 1.0;
   int g = (int)(rounds * slots / (MSM_W_SHORT + (MSM_W - MSM_W_SHORT) * share));
@@ -470,7 +473,7 @@ MsmLayout msm_layout(size_t n, size_t n_long, int groups, void* ws) {
 template <class S>
 static void launch_msm_core_t(const MsmLayout& L, uint8_t* out_enc, uint8_t* out_xy, uint8_t* status,
                               uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev) {
-  const size_t lds_bytes = ((size_t)MSM_BUCKETS * MSM_PT_WORDS + 2 * MSM_BUCKETS + 16) * 4;   // 77,888 B: two workgroups per CU
+  const size_t lds_bytes = ((size_t)MSM_BUCKETS * MSM_PT_WORDS + 2 * MSM_BUCKETS + 16) * 4;   // 155,712 B of 160 KiB
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_buckets<S>),

@@ -2,7 +2,7 @@
 // digits themselves (k_rlc.hip: batched Pedersen verification by random linear combination).
 //
 // Replaces ark_ec::scalar_mul::VariableBaseMSM::msm (named in BASELINE.json north_star; reached from
-// /root/reference through `reexports`, src/lib.rs:14).  Signed 10-bit windows: 26 windows x 512
+// /root/reference through `reexports`, src/lib.rs:14).  Signed 11-bit windows: 23 windows x 1024
 // buckets.  Scalars k > r/2 are replaced by r - k with the point's sign flipped, so k < 2^252 and the
 // top window never carries out.
 #pragma once
@@ -10,15 +10,23 @@
 
 VRF_NS_BEGIN
 
-// Round 4: 10-bit windows.  1024 buckets x 144 B filled a CU's LDS, so ONE workgroup of 8 waves ran per CU -- two waves per
-// SIMD under a loop whose additions are dependency chains and whose operands are gathered from HBM: 0.70-0.72 of the
-// issue slots (profiles/r03, r04).  512 buckets (72 KB) let two workgroups share a CU, four waves per SIMD, for three more
-// windows (26 instead of 23).
-constexpr int MSM_C = 10;                         // window bits
-constexpr int MSM_W = 26;                         // windows: 10*26 = 260 bits >= 253
-constexpr int MSM_BUCKETS = 1 << (MSM_C - 1);     // 512 signed buckets per window
+// 11-bit windows: 1024 buckets x 144 B fill a CU's LDS, ONE workgroup of 8 waves per CU.  Round 4 tried 10-bit windows
+// (512 buckets, 72 KB: two workgroups per CU, four waves per SIMD, 26 windows instead of 23) on the hypothesis that the
+// 0.72 of the issue slots was an occupancy limit: the batched Pedersen verifier's bucket stage went 7.5 -> 11.4 ms and the
+// plain MSM of 2^20 points 2.8 -> 4.8 ms -- the extra windows and the halved chunk per lane (the sort, the head merge and
+// the 18-step bucket reduction are per workgroup) cost far more than the occupancy returned.  The code keeps both shapes
+// (MSM_BPL buckets per lane); 11 bits is what ships.
+constexpr int MSM_C = 11;                         // window bits
+constexpr int MSM_W = 23;                         // windows: 11*23 = 253 bits
+constexpr int MSM_BUCKETS = 1 << (MSM_C - 1);     // 1024 signed buckets per window
+// 512 lanes per workgroup.  Round 4 also tried 1024 (the LDS footprint is the buckets' whatever the lane count, so the one
+// workgroup per CU holds 16 waves instead of 8): the bucket stage of the batched Pedersen verifier went 7.6 -> 8.7 ms, the
+// plain MSM of 2^20 points 2.86 -> 3.19 ms.  With the 10-bit experiment above and the group-major launch order (no change)
+// that makes three measured answers to "why 0.72 of the issue slots": not occupancy, not HBM re-reads.
 constexpr int MSM_BLOCK = 512;                    // lanes per workgroup
-constexpr int MSM_BPL = MSM_BUCKETS / MSM_BLOCK;  // buckets per lane in the scan and the reduction (1; 2 with 11-bit windows)
+constexpr int MSM_LOG2_BLOCK = 9;
+constexpr int MSM_BPL = MSM_BUCKETS / MSM_BLOCK;  // buckets per lane in the scan and the reduction (2; the code also runs with 1)
+static_assert((1 << MSM_LOG2_BLOCK) == MSM_BLOCK && MSM_BPL >= 1 && MSM_BPL <= 2, "workgroup shape");
 constexpr int MSM_PT_WORDS = 4 * NL;              // extended point staged in LDS / HBM: X, Y, Z, T
 constexpr int MSM_PTA_STRIDE = 32;                // words between the affine-cached points of L.pts: 108 B of point in a
                                                   // 128-B slot, so that a bucket gather touches ONE cache line (27-word
@@ -28,7 +36,7 @@ constexpr uint32_t MSM_IDX_MASK = (1u << MSM_IDX_BITS) - 1;
 constexpr size_t MSM_MAX_PER_GROUP = size_t(1) << MSM_IDX_BITS;
 
 // Device-side layout of one MSM over n points (all regions inside one workspace allocation).
-constexpr int MSM_W_SHORT = 13;                   // windows a scalar < 2^128 can reach (10*13 = 130 bits)
+constexpr int MSM_W_SHORT = 12;                   // windows a scalar < 2^128 can reach (11*12 = 132 bits)
 
 // MsmLayout (device-side layout of one MSM over n points): vrf_types.h
 

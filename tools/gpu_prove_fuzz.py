@@ -30,8 +30,13 @@ def secrets(order, big_endian):
     return sk
 
 
+CT = "--ct" in sys.argv        # VRFHIP_FLAG_CT_TABLES: the provers' window lookups read all eight table entries
+
+
 def run(name, suite, sid, order, big_endian, p256):
     ctx = Context(0, suite, test_blinding_base=True)
+    if CT:
+        ctx.set_flags(ctx.CT_TABLES)
     if p256:
         co.p256_set_blinding_base(sw.default_blinding_base())
         ip, pp = co.p256_ietf_prove_batch, co.p256_pedersen_prove_batch
