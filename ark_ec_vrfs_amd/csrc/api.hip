@@ -24,7 +24,7 @@ namespace vrf {
 size_t pairing_oct_lines_bytes(size_t items);
 void launch_pairing_check2_oct_split(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status, void* ws,
                                      size_t chunk, hipStream_t st);
-constexpr size_t PAIRING_OCT_SPLIT_MIN_ITEMS = 2048;      // below: one item per quad (k_pairing_quad.hip), the shorter chain
+constexpr size_t PAIRING_OCT_SPLIT_MIN_ITEMS = 1;         // every size: 4.6-4.7 ms for 8 .. 4096 items against 10.9 per quad
 constexpr size_t PAIRING_OCT_SPLIT_CHUNK = size_t(1) << 15;   // items per pass: 45.7 KB of lines each, 1.5 GB of workspace
 // k_pairing_row.hip: the selftest operands through the row-distributed tower (bls12_row.cuh); ORs 64 / 128 into status[i]
 void launch_pairing_row_selftest(size_t n, const uint8_t* in, uint8_t* status, hipStream_t st);
@@ -1683,7 +1683,7 @@ int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   {
-    // Per-item G2 points from 2^11 items on (and whenever a test asks for the 8-lane layout): the G2 walk and the Miller
+    // Per-item G2 points: the G2 walk and the Miller
     // loop as two kernels with the lines parked in HBM between them (k_pairing_oct.hip); layout 6 = the same work as ONE
     // kernel, kept for comparison.
     const int lay = ctx->dbg_pairing_layout, mode = lay & 0xff;

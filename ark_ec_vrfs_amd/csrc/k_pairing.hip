@@ -52,13 +52,11 @@ void launch_pairing_check2_quad_prepared(size_t n, const uint8_t* g1, const uint
 void launch_pairing_check2_row_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st, int tri);
 void launch_pairing_check2_oct(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status, hipStream_t st);
 void launch_pairing_check2_oct_prepared(size_t n, const uint8_t* g1, const uint32_t* prep, uint8_t* status, hipStream_t st);
-// Up to this many checks against a prepared pair run one item per 16-lane ROW or per WAVE (latency: half the chain of a
-// quad, more lanes per item); beyond it throughput matters and the 8-lane layout (k_pairing_oct.hip) takes over.
-constexpr size_t PAIRING_ROW_MAX_ITEMS = 4096;   // measured (round 3): rows 5.8-6.1 ms up to 2^12 items, 12 ms at 2^13
-// Unprepared (per-item G2 points): quads below this many items (one wave per SIMD has the shorter chain), 8 lanes per
-// item from here on (two waves per SIMD resident).
-constexpr size_t PAIRING_OCT_MIN_ITEMS = 2048;
-
+// Layout by default: ONE ITEM PER 8 LANES at every batch size.  Measured (profiles/r04/pairing_layouts_time_small.log):
+// prepared lines, 8 .. 4096 items: 3.6 ms per launch against 3.9-4.1 (one item per wave), 5.3-5.5 (per row), 9.1 (per quad);
+// per-item G2 points, 8 .. 4096 items: 4.6-4.7 ms (lines kernel + Miller kernel) against 10.9 (per quad).  A single wave of
+// the 8-lane kernels is a shorter chain than any of the older layouts, so the row / wave / quad kernels (rounds 1-3) are
+// no longer chosen by size; they stay selectable (vrfhip_debug_set) as independent formulations for the tests.
 void launch_pairing_check2(size_t n, const uint8_t* g1, const uint8_t* g2, size_t g2_stride, uint8_t* status,
                            hipStream_t st, uint32_t* prep, int layout) {
   if (!n) return;
@@ -71,12 +69,11 @@ void launch_pairing_check2(size_t n, const uint8_t* g1, const uint8_t* g2, size_
     hipLaunchKernelGGL(k_pairing_prepare_g2, dim3(1), dim3(64), 0, st, g2, prep);
     if (mode == PAIRING_ROW || mode == PAIRING_TRI) launch_pairing_check2_row_prepared(n, g1, prep, status, st, mode == PAIRING_TRI);
     else if (mode == PAIRING_QUAD) launch_pairing_check2_quad_prepared(n, g1, prep, status, st);
-    else if (mode == PAIRING_OCT) launch_pairing_check2_oct_prepared(n, g1, prep, status, st);
-    else if (n <= PAIRING_ROW_MAX_ITEMS) launch_pairing_check2_row_prepared(n, g1, prep, status, st, -1);
     else launch_pairing_check2_oct_prepared(n, g1, prep, status, st);
     return;
   }
-  if (mode == PAIRING_QUAD || (mode != PAIRING_OCT && n < PAIRING_OCT_MIN_ITEMS)) launch_pairing_check2_quad(n, g1, g2, g2_stride, status, st);
+  // per-item G2 points reach this function only for the one-kernel forms (api.hip runs the default two-kernel path itself)
+  if (mode == PAIRING_QUAD) launch_pairing_check2_quad(n, g1, g2, g2_stride, status, st);
   else launch_pairing_check2_oct(n, g1, g2, g2_stride, status, st);
 }
 

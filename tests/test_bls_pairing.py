@@ -255,7 +255,7 @@ def test_gpu_pairing_shared_g2_prepared_lines(ctx):
             assert list(a) == list(bb), mode
         finally:
             ctx.debug_pairing_layout()
-    for reps in (25, 26, 102, 103):        # 1000 items: one per wave (three rows); 1040, 4080: one per row; 4120: 8 lanes per item
+    for reps in (25, 26, 102, 103):        # 1000 .. 4120 items, all through the default (8 lanes per item); rounds 1-3 switched layouts here
         big = np.tile(g1, (reps, 1))
         assert list(ctx.pairing_check_batch(big, sh, g2_shared=True)) == want * reps
     for rowmode in ("tri", "row"):                              # both row layouts forced on the small batch
@@ -656,7 +656,7 @@ def test_gpu_pairing_soak_distinct_items_every_path(ctx):
     sref = co.pairing_check_batch(s1, sg2, shared=True, threads=ncpu)
     assert (sref == swant).all(), [(k, int(a), int(c)) for k, a, c in zip(skinds, sref, swant) if a != c][:5]
     assert set(np.unique(swant)) == {0, 1, 2}
-    for cnt in (1000, 4096, m):                                        # one item per wave | per row | per 8 lanes
+    for cnt in (1, 7, 1000, 4096, m):                                  # the default layout (8 lanes per item) at every size
         assert (ctx.pairing_check_batch(s1[:cnt], sg2, g2_shared=True) == swant[:cnt]).all(), cnt
     for mode in ("noprep", "quad", "row", "oct"):
         ctx.debug_pairing_layout(mode)

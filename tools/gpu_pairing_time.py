@@ -43,7 +43,7 @@ for logn in logs:
     n = 1 << logn
     d1 = torch.from_numpy(np.tile(s1, (n // 8, 1)).copy()).to(dev)
     st = torch.full((n,), 9, dtype=torch.uint8, device=dev)
-    for mode in ("quad", "oct", "row", "tri") if logn <= 13 else ("quad", "oct"):
+    for mode in ("quad", "oct", "row", "tri") if logn <= 12 else ("quad", "oct"):
         ctx.debug_pairing_layout(mode)
         t = best(lambda: ctx.pairing_check_batch_dev(d1, dsh, st, g2_shared=True))
         assert int(st.sum()) == 0
