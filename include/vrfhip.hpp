@@ -424,18 +424,14 @@ std::vector<Result> verify_batch(const Context<S>& ctx, const std::vector<Item<S
   Bytes sb = detail::column(items, [](const Item<S>& t) -> const auto& { return t.proof.sb; });
   Bytes st(n + 1);
   int32_t fast = 1;
-  if constexpr (S::EDWARDS) {
+  {
+    // every suite has the single-MSM verifier (secp256r1 since round 4)
     std::array<uint8_t, 32> seed;
     std::random_device rd;                                 // must be unpredictable to the provers
     for (auto& b : seed) b = (uint8_t)rd();
     check(vrfhip_pedersen_verify_batch_rlc(ctx.handle(), n, h.data(), g.data(), pc.data(), r.data(), ok.data(), s.data(),
                                            sb.data(), detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), seed.data(), st.data(),
                                            &fast), "vrfhip_pedersen_verify_batch_rlc");
-  } else {
-    fast = 0;
-    check(vrfhip_pedersen_verify_batch(ctx.handle(), n, h.data(), g.data(), pc.data(), r.data(), ok.data(), s.data(),
-                                       sb.data(), detail::ad_ptr(ad), nullptr, (uint32_t)ad.size(), st.data()),
-          "vrfhip_pedersen_verify_batch");
   }
   if (fast_path) *fast_path = fast != 0;
   std::vector<Result> res(n);
