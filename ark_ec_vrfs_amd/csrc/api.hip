@@ -113,6 +113,8 @@ struct vrfhip_ctx {
   // test / tuning knobs (vrfhip_debug_set; nothing in the product reads the environment)
   int dbg_pairing_layout = 0;              // kernels.h PAIRING_*: 0 = by batch size
   int pipe_first_log2 = 17, pipe_chunk_log2 = 18;   // host-pointer pipeline: first chunk, later chunks (items, log2)
+  int dbg_prove_k = 0;                     // > 0: proofs per lane in the provers' prepare / finish stages (default: lanes_k)
+  int dbg_p256_msm_groups = 0;             // > 0: point groups per window of the secp256r1 MSM (default: p256::msm_groups)
   uint32_t check_mask() const { return ~flags & (uint32_t)VRFHIP_FLAG_PREVALIDATED_ALL; }
   // secp256r1 (`suites::secp256r1`): short-Weierstrass law, Sec1 wire format (33-byte points, big-endian scalars), SHA-256.
   // Its kernels (k_p256.hip) have their own tables and workspace; the entry points below branch on `sw` where the
@@ -659,6 +661,14 @@ int32_t vrfhip_debug_set(vrfhip_ctx* ctx, int32_t key, int32_t value) {
       if (value < 12 || value > 18) return fail(VRFHIP_ERR_BAD_ARG, "pipeline chunk log2 must lie in 12..18");
       (key == VRFHIP_DEBUG_PIPE_FIRST_LOG2 ? ctx->pipe_first_log2 : ctx->pipe_chunk_log2) = value;
       return VRFHIP_SUCCESS;
+    case VRFHIP_DEBUG_PROVE_K:
+      if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(VRFHIP_ERR_BAD_ARG, "proofs per lane: 0 (default), 1, 2, 4 or 8");
+      ctx->dbg_prove_k = value;
+      return VRFHIP_SUCCESS;
+    case VRFHIP_DEBUG_P256_MSM_GROUPS:
+      if (value < 0 || value > 4096) return fail(VRFHIP_ERR_BAD_ARG, "groups out of range");
+      ctx->dbg_p256_msm_groups = value;
+      return VRFHIP_SUCCESS;
     default:
       return fail(VRFHIP_ERR_BAD_ARG, "unknown debug key");
   }
@@ -1154,7 +1164,7 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
     size_t m = std::min(ctx->ws_cap, n - base);
     ProveArgs a;
     a.suite = (int)ctx->suite;
-    a.k_lane = lanes_k(m, PROVE_K);
+    a.k_lane = ctx->dbg_prove_k > 0 ? ctx->dbg_prove_k : lanes_k(m, PROVE_K);
     a.n = m;
     a.sk = d_sk + base * 32;
     if (d_msg_off) a.msg = make_view(d_msg, d_msg_off + base, 0, false);
@@ -1420,7 +1430,12 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
     // secp256r1: launch groups of at most 2^20 proofs, each ONE MSM over 5 m + 2 points; no per-proof workspace at all
     const size_t cap = std::min<size_t>(n, size_t(1) << 20);
     const size_t Ncap = 5 * cap + 2;
-    const int groups_cap = p256::msm_groups(Ncap, 3 * cap + 2, ctx->cus);
+    auto p256_groups = [&](size_t N_, size_t long_) {
+      int g = ctx->dbg_p256_msm_groups > 0 ? ctx->dbg_p256_msm_groups : p256::msm_groups(N_, long_, ctx->cus);
+      const size_t min_g = (N_ + (size_t(1) << 21) - 1) >> 21;
+      return (size_t)g < min_g ? (int)min_g : g;
+    };
+    const int groups_cap = p256_groups(Ncap, 3 * cap + 2);
     const size_t msm_b = Stage::pad(p256::msm_workspace_bytes(Ncap, groups_cap));
     int32_t rc2 = ensure_msm_workspace(ctx, msm_b + Stage::pad(digest_ws_bytes(cap)) + 256);
     if (rc2) return rc2;
@@ -1435,7 +1450,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
       a.r = d_r + base * 33; a.ok = d_ok + base * 33; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
       a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
       a.status = d_status + base;
-      a.L = p256::msm_layout(N, 3 * m + 2, p256::msm_groups(N, 3 * m + 2, ctx->cus), ctx->d_msm_ws);
+      a.L = p256::msm_layout(N, 3 * m + 2, p256_groups(N, 3 * m + 2), ctx->d_msm_ws);
       std::memcpy(a.seed, seed, 32);
       std::memcpy(a.gen_xy, ctx->desc.generator, 64);
       std::memcpy(a.b_xy, ctx->desc.blinding_base, 64);

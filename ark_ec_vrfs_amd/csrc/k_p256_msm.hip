@@ -112,17 +112,16 @@ __global__ void __launch_bounds__(PM_BLOCK) k_pm_buckets(MsmL L) {
   uint32_t* wsum = cursor + PM_BUCKETS;                     // [8]
   const int t = threadIdx.x;
   const int wg = blockIdx.x;
-  const int w = wg / L.groups, g = wg % L.groups;
-  // windows a bare weight cannot reach hold the full-size scalars only: fewer, equally sized groups
-  const bool high = w >= p256::MSM_W_SHORT;
+  // the grid holds the low windows' workgroups (MSM_W_SHORT x groups) and then the high windows' (x groups_hi): the windows a
+  // bare 128-bit weight cannot reach hold the full-size scalars only, in fewer groups of about the same size
+  const int n_lo = p256::MSM_W_SHORT * L.groups;
+  const bool high = wg >= n_lo;
+  const int w = high ? p256::MSM_W_SHORT + (wg - n_lo) / L.groups_hi : wg / L.groups;
+  const int g = high ? (wg - n_lo) % L.groups_hi : wg % L.groups;
   const size_t span = high ? L.per_group_hi : L.per_group, end = high ? L.n_long : L.n;
   const size_t lo = (size_t)g * span;
   const size_t hi = lo + span < end ? lo + span : end;
-  const uint32_t cnt_all = (!(high && g >= L.groups_hi) && lo < hi) ? (uint32_t)(hi - lo) : 0u;
-  if (cnt_all == 0) {                          // wave-uniform: an idle workgroup of a high window (or an empty tail group)
-    if (t == 0) pm_store(L.part + ((size_t)w * L.groups + g) * PM_PT, sw_identity());
-    return;
-  }
+  const uint32_t cnt_all = lo < hi ? (uint32_t)(hi - lo) : 0u;
   const int16_t* dig = L.digits + (size_t)w * L.n + lo;
   const uint32_t* P = L.pts + lo * PM_AFF;
   uint32_t* list = L.lists + (size_t)wg * L.list_cap;
@@ -259,8 +258,10 @@ __global__ void __launch_bounds__(64) k_pm_final(MsmL L, uint8_t* out33, uint8_t
   __shared__ uint32_t stage[32 * PM_PT];
   const int t = threadIdx.x;
   PtW acc = sw_identity();
-  if (t < PM_W)
-    for (int g = 0; g < L.groups; ++g) acc = sw_add(acc, pm_load(L.part + ((size_t)t * L.groups + g) * PM_PT));
+  if (t < PM_W) {
+    const int ng = t < p256::MSM_W_SHORT ? L.groups : L.groups_hi;
+    for (int g = 0; g < ng; ++g) acc = sw_add(acc, pm_load(L.part + ((size_t)t * L.groups + g) * PM_PT));
+  }
   {
     PtJ j = sw_to_jac(acc);
     const int nd = t < PM_W ? PM_C * t : 0;
@@ -390,7 +391,8 @@ size_t pad256(size_t x) { return (x + 255) & ~size_t(255); }
 void launch_core(const MsmL& L, uint8_t* out33, uint8_t* out_xy, int xy_mont256, uint8_t* status1, uint8_t* fail_flag, hipStream_t st,
                  hipEvent_t* ev) {
   const size_t lds_bytes = ((size_t)PM_BUCKETS * PM_PT + 2 * PM_BUCKETS + 16) * 4;
-  hipLaunchKernelGGL(k_pm_buckets, dim3((unsigned)(PM_W * L.groups)), dim3(PM_BLOCK), lds_bytes, st, L);
+  const unsigned wgs = (unsigned)(p256::MSM_W_SHORT * L.groups + (PM_W - p256::MSM_W_SHORT) * L.groups_hi);
+  hipLaunchKernelGGL(k_pm_buckets, dim3(wgs), dim3(PM_BLOCK), lds_bytes, st, L);
   if (ev) (void)hipEventRecord(ev[2], st);
   hipLaunchKernelGGL(k_pm_final, dim3(1), dim3(64), 0, st, L, out33, out_xy, xy_mont256, status1, fail_flag);
   if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
@@ -403,11 +405,15 @@ namespace vrf {
 namespace p256 {
 
 int msm_groups(size_t n, size_t n_long, int cus) {
-  // two workgroups of 54 KiB LDS fit a CU; the active workgroups -- MSM_W_SHORT g in the low windows, (MSM_W - MSM_W_SHORT)
-  // g n_long / n in the high ones -- should fill about one round of the chip
+  // The bucket kernel holds 176 registers: two waves per SIMD, so ONE 512-lane workgroup per CU whatever its LDS (measured:
+  // 208 workgroups ran as one round, 260 as two -- profiles/r04/knob_sweep.log).  Workgroups = MSM_W_SHORT g in the low windows
+  // + (MSM_W - MSM_W_SHORT) g n_long / n in the high ones: one round of the chip for mid-sized inputs, two for large ones.
+  const int rounds = n >= (size_t(1) << 22) ? 2 : 1;
   const double share = n ? (double)(n_long < n ? n_long : n) / (double)n : 1.0;
-  int g = (int)(2.0 * cus / (MSM_W_SHORT + (MSM_W - MSM_W_SHORT) * share));
+  int g = (int)(rounds * cus / (MSM_W_SHORT + (MSM_W - MSM_W_SHORT) * share));
   if (g < 1) g = 1;
+  auto wgs = [&](int gg) { return MSM_W_SHORT * gg + (MSM_W - MSM_W_SHORT) * (int)(share * gg + 0.999); };
+  while (g > 1 && wgs(g) > rounds * cus) --g;
   const size_t max_g = (n + 4095) / 4096;          // at least 8 points per lane and group
   if ((size_t)g > max_g) g = (int)max_g;
   if (g < 1) g = 1;

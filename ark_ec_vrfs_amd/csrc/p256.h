@@ -96,7 +96,7 @@ struct MsmL {
   size_t n;
   // Points [0, n_long) carry full-size scalars, points [n_long, n) bare 128-bit weights whose digits in the windows >=
   // MSM_W_SHORT are zero: those windows partition [0, n_long) only, into groups_hi <= groups groups of about the same size
-  // as a low window's (the workgroups g >= groups_hi of a high window have nothing to do).
+  // as a low window's (the grid is MSM_W_SHORT groups + (MSM_W - MSM_W_SHORT) groups_hi workgroups).
   size_t n_long;
   int groups, groups_hi;
   size_t per_group, per_group_hi, list_cap;

@@ -534,7 +534,9 @@ enum {
                                        4 per wave, 5 per 8 lanes (per-item G2: lines kernel + Miller kernel), 6 per 8 lanes in
                                        one kernel; | 0x100: do not prepare the lines of a shared G2 pair */
   VRFHIP_DEBUG_PIPE_FIRST_LOG2 = 2, /* host-pointer verify pipeline: log2 items of the first chunk (12..18, default 17) */
-  VRFHIP_DEBUG_PIPE_CHUNK_LOG2 = 3  /* ... of the following chunks (12..18, default 18) */
+  VRFHIP_DEBUG_PIPE_CHUNK_LOG2 = 3, /* ... of the following chunks (12..18, default 18) */
+  VRFHIP_DEBUG_PROVE_K = 4,         /* proofs per lane in the provers' prepare / finish stages: 0 = by batch size, 1, 2, 4, 8 */
+  VRFHIP_DEBUG_P256_MSM_GROUPS = 5  /* point groups per window of the secp256r1 MSM: 0 = by batch size */
 };
 int32_t vrfhip_debug_set(vrfhip_ctx* ctx, int32_t key, int32_t value);
 
