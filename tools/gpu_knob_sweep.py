@@ -1,5 +1,5 @@
 """Sweeps of two launch-shape knobs (vrfhip_debug_set): proofs per lane in the provers' prepare / finish stages, and point
-groups per window of the secp256r1 MSM inside the batched Pedersen verifier.  usage (GPU box): python tools/gpu_knob_sweep.py"""
+groups per window of the secp256r1 MSM inside the batched Pedersen verifier.  usage (GPU box): python tools/gpu_knob_sweep.py [p256]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,7 +24,7 @@ def batch(ctx, suite):
     return sk, msg
 
 
-for suite in (BandersnatchSha512Ell2, JubJubSha512Tai):
+for suite in (() if "p256" in sys.argv[1:] else (BandersnatchSha512Ell2, JubJubSha512Tai)):
     ctx = Context(0, suite=suite, test_blinding_base=True)
     sk, msg = batch(ctx, suite)
     mk = lambda: torch.empty((n, 32), dtype=torch.uint8, device=dev)
@@ -48,7 +48,7 @@ cp.pedersen_prove_batch_dev(sk, msg, 32, g, pc, rr, okp, s_, sbb, None, hh, st)
 torch.cuda.synchronize()
 assert int(st.sum()) == 0
 seed = os.urandom(32)
-for groups in (0, 8, 10, 12, 14, 16, 19, 24, 32):
+for groups in (0, 8, 10, 11, 12, 16, 20, 22, 24, 26, 32, 36, 48):
     cp.debug_set(5, groups)
     fn = lambda: cp.pedersen_verify_batch_rlc_dev(hh, g, pc, rr, okp, s_, sbb, st, flag, seed)
     fn(); torch.cuda.synchronize()
