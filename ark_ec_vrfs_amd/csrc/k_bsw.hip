@@ -1,0 +1,383 @@
+// k_bsw.hip -- kernels of `suites::bandersnatch_sw` (/root/reference src/lib.rs:14): the codec-bound stages of the IETF and
+// Pedersen schemes on the short-Weierstrass presentation of Bandersnatch (bsw_core.cuh).  The stages between them are the
+// twisted-Edwards suite's: the provers' multiplication stage IS launch_prove_stage2_bs (k_prove.hip), and the verifiers'
+// Straus stages wrap the same per-item functions (verify_straus_item, pedersen_verify_straus_item) -- so the workspace
+// (window tables, projective intermediates, aux words, flag bytes) has the layout k_prove.hip / k_verify.hip /
+// k_pedersen.hip give it, and the launch arguments are theirs (vrf_types.h), with 33-byte point rows.
+#include "kernels.h"
+#include "bsw_core.cuh"
+#include "tai_find.cuh"
+
+VRF_NS_BEGIN
+
+void launch_prove_stage2_bs(const ProveArgs& a, hipStream_t st);      // k_prove.hip (suite 1, stage 2)
+
+namespace {
+
+// flag byte of an item in the workspace: bit 0 = inputs valid; bits 6-7 = flag byte of enc(H) (its x words sit in aux[0..8))
+VRF_HD Enc33 aux_h_enc(const uint32_t* aux, uint8_t flag) {
+  Enc33 e;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e.w[j] = aux[j];
+  e.fl = flag & 0xC0u;
+  return e;
+}
+
+// ---- Secret::from_seed / Secret::public ----
+__global__ void __launch_bounds__(BLOCK, 2) k_bsw_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len,
+                                                                   uint8_t* sk_out, uint8_t* pk_out, DevTables T) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t sk[8];
+  secret_from_seed_item<BswS>(sk, seeds + i * (size_t)seed_len, seed_len);
+  store32(sk_out, i, sk);
+  if (pk_out) store33(pk_out, i, bsw_encode<BswS, true>(gcomb_mul<BswS>(T.g_comb, sk)));
+}
+
+// ---- Input::new ----
+__global__ void __launch_bounds__(BLOCK, 2) k_bsw_hash_to_curve(size_t n, BytesView msg, uint8_t* points, DevTables T,
+                                                                const uint8_t* tai_ctr) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* m; uint32_t len;
+  bytes_get(msg, i, m, len);
+  store33(points, i, bsw_encode<BswS>(bsw_hash_to_curve_tai(m, len, T.sq, tai_ctr ? tai_ctr[i] : 0u)));
+}
+
+// ---- Output::hash ----
+__global__ void __launch_bounds__(BLOCK) k_bsw_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash, SqrtTables T) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t o[16];
+  bsw_output_hash(o, enc33_canonical(load33(gamma, i)), T.str);      // `Output::hash` encodes the typed point
+  uint32_t* p = reinterpret_cast<uint32_t*>(hash + i * 64);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) p[j] = o[j];
+}
+
+// ---- codec: checked point decoding; xy (nullable) receives the Weierstrass x || y ----
+__global__ void __launch_bounds__(BLOCK) k_bsw_point_validate(size_t n, const uint8_t* pts, uint8_t* xy, uint8_t* status,
+                                                              DevTables T) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  FeN tx, ty, sx, sy;
+  bool inf;
+  bool ok = bsw_decode<BswS>(tx, ty, sx, sy, inf, load33(pts, i), T.sq);
+  ok = ok && in_prime_subgroup<BswS>(tx, ty, T.sq);
+  status[i] = ok ? ST_OK : ST_INVALID_DATA;
+  if (xy) {
+    uint32_t xw[8], yw[8];
+    fe_to_u256(xw, sx);
+    fe_to_u256(yw, sy);
+    uint32_t* p = reinterpret_cast<uint32_t*>(xy + i * 64);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { p[j] = ok && !inf ? xw[j] : 0u; p[8 + j] = ok && !inf ? yw[j] : 0u; }
+  }
+}
+
+// ---- provers, stage 1: H (given, or hashed from the message), enc(H), nonce(s), blinding, window tables of H ----
+__global__ void __launch_bounds__(BLOCK, 2) k_bsw_prove_prepare(ProveArgs a) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  uint32_t sk[8], k[8];
+  load32(sk, a.sk, i);
+  bool valid = fr_is_canonical<BswS>(sk);
+  FeN x, y;
+  Enc33 h_enc;
+  if (a.h_given) {
+    const Enc33 e = load33(a.h_given, i);
+    valid = bsw_decode<BswS>(x, y, e, a.T.sq) && valid;
+    if (a.check_mask & CHK_INPUT) valid = in_prime_subgroup<BswS>(x, y, a.T.sq) && valid;     // a given H is wire data
+    h_enc = enc33_canonical(e);
+  } else {
+    const uint8_t* msg; uint32_t msg_len;
+    bytes_get(a.msg, i, msg, msg_len);
+    const PtE hp = bsw_hash_to_curve_tai(msg, msg_len, a.T.sq, a.ws.flags[i]);     // k_tai_find left the first candidate's counter
+    const SwFrac f = bsw_frac<BswS>(hp.X, hp.Y, hp.Z);
+    const FeN dens[2] = {fe_full(hp.Z), f.den};
+    FeN inv[2];
+    fe_batch_inv(inv, dens);
+    x = fe_mul(hp.X, inv[0]);
+    y = fe_mul(hp.Y, inv[0]);
+    h_enc = bsw_encode_frac(f, inv[1]);
+  }
+  bsw_nonce(k, sk, h_enc);
+  build_prove_tables<BswS>(a.ws.tabs + i * ProveLayout<BswS>::TAB_WORDS, x, y);
+  uint32_t* aux = a.ws.aux + i * AUX_WORDS;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { aux[j] = h_enc.w[j]; aux[8 + j] = k[j]; }
+  if (a.pedersen) {
+    const uint8_t* ad; uint32_t ad_len;
+    bytes_get(a.ad, i, ad, ad_len);
+    uint32_t b[8], kb[8];
+    bsw_blinding(b, sk, h_enc, ad, ad_len, a.T.sq.str);
+    bsw_nonce(kb, b, h_enc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { aux[16 + j] = b[j]; aux[24 + j] = kb[j]; }
+  }
+  a.ws.flags[i] = (uint8_t)((valid ? 1u : 0u) | (h_enc.fl & 0xC0u));
+}
+
+// ---- provers, stage 3: the four products [sk*H, sk*G (+ b*B), k*H, k*G (+ kb*B)] -> encodings, challenge, responses ----
+__global__ void __launch_bounds__(BLOCK, 2) k_bsw_prove_finish(ProveArgs a) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  const uint32_t* pts = a.ws.pts + i * PROVE_PTS_WORDS;
+  SwFrac f[4];
+  FeN dens[4], inv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[j] = bsw_frac<BswS>(fe_load<1, 5>(pts + j * UV_WORDS), fe_load<1, 5>(pts + j * UV_WORDS + NL),
+                          fe_load<1, 5>(pts + j * UV_WORDS + 2 * NL));
+    dens[j] = f[j].den;
+  }
+  fe_batch_inv<true>(inv, dens);                 // secret-dependent values: fixed-shape inversion
+  Enc33 e[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) e[j] = bsw_encode_frac(f[j], inv[j]);
+  const uint32_t* aux = a.ws.aux + i * AUX_WORDS;
+  const uint8_t flag = a.ws.flags[i];
+  const bool ok = (flag & 1u) != 0;
+  const Enc33 h_enc = aux_h_enc(aux, flag);
+  uint32_t sk[8], k[8], c[8], cs[8], s[8];
+  load32(sk, a.sk, i);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) k[j] = aux[8 + j];
+  const uint8_t* ad; uint32_t ad_len;
+  bytes_get(a.ad, i, ad, ad_len);
+  const Enc33 cp[5] = {e[1], h_enc, e[0], e[3], e[2]};        // pk (or pk_com), H, Gamma, k*G (+ kb*B), k*H
+  bsw_challenge5(c, cp, ad, ad_len, a.T.sq.str);
+  fr_mul<BswS>(cs, c, sk);
+  fr_add<BswS>(s, cs, k);
+  if (a.pedersen) {
+    uint32_t b[8], kb[8], cb[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { b[j] = aux[16 + j]; kb[j] = aux[24 + j]; }
+    fr_mul<BswS>(cb, c, b);
+    fr_add<BswS>(sb, cb, kb);
+    if (!ok) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sb[j] = 0; b[j] = 0; }
+    }
+    store33(a.r_out, i, e[3], ok);
+    store33(a.ok_out, i, e[2], ok);
+    store32(a.sb_out, i, sb);
+    if (a.blinding_out) store32(a.blinding_out, i, b);
+  }
+  if (!ok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { c[j] = 0; s[j] = 0; }
+  }
+  store32(a.s, i, s);
+  if (a.c) store32(a.c, i, c);
+  store33(a.gamma, i, e[0], ok);
+  if (a.pk_out) store33(a.pk_out, i, e[1], ok);
+  if (a.h_out) store33(a.h_out, i, h_enc);
+  if (a.status) a.status[i] = ok ? ST_OK : ST_INVALID_DATA;
+}
+
+// ---- IETF verify, stage 1: decode pk, H, Gamma; GLV window tables; canonical encodings for the challenge ----
+// aux: 3 x 8 words of x, then one word holding the three flag bytes
+__global__ void __launch_bounds__(BLOCK, 2) k_bsw_verify_decode(VerifyArgs a) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  uint32_t* aux = a.ws.aux + i * AUX_WORDS;
+  uint32_t* tabs = a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS);
+  bool valid = true;
+  uint32_t fls = 0;
+#pragma unroll 1
+  for (int p = 0; p < 3; ++p) {
+    const Enc33 e = load33(p == 0 ? a.pk : p == 1 ? a.h : a.gamma, i);
+    FeN x, y;
+    valid = bsw_decode<BswS>(x, y, e, a.T.sq) && valid;
+    if ((a.check_mask >> p) & 1u) valid = in_prime_subgroup<BswS>(x, y, a.T.sq) && valid;       // bit p: pk, H, Gamma
+    build_glv_tables<BswS>(tabs + p * 2 * WIN_TABLE_WORDS, x, y);
+    const Enc33 ce = enc33_canonical(e);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aux[8 * p + j] = ce.w[j];
+    fls |= ce.fl << (8 * p);
+  }
+  aux[24] = fls;
+  a.ws.flags[i] = valid ? 1 : 0;
+}
+
+// the proof's scalars for the Straus stages: c mod r, s as is (a non-canonical s is reported by the finish stage)
+VRF_HD void bsw_load_cs(uint32_t c[8], uint32_t s[8], const uint8_t* c_arr, const uint8_t* s_arr, size_t i) {
+  uint32_t cw[8];
+  load32(cw, c_arr, i); load32(s, s_arr, i);
+  fr_reduce256<BswS>(c, cw);
+  const bool s_ok = fr_is_canonical<BswS>(s);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { c[j] = s_ok ? c[j] : 0u; s[j] = s_ok ? s[j] : 0u; }
+}
+
+// stage 2: HALF 1: V = s*H - c*Gamma; HALF 0: U = s*G - c*pk (separate launches: every wave runs one shape)
+template <int HALF>
+__global__ void __launch_bounds__(BLOCK) k_bsw_verify_straus(VerifyArgs a) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  uint32_t c[8], s[8];
+  bsw_load_cs(c, s, a.c, a.s, i);
+  verify_straus_item<BswS, HALF>(a.ws.pts + i * PROVE_PTS_WORDS + HALF * UV_WORDS, a.T,
+                                 a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), c, s);
+}
+
+// stage 3: encode U, V (one inversion); challenge; compare
+__global__ void __launch_bounds__(BLOCK, 2) k_bsw_verify_finish(VerifyArgs a) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  const uint32_t* pts = a.ws.pts + i * PROVE_PTS_WORDS;
+  SwFrac f[2];
+  FeN dens[2], inv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    f[j] = bsw_frac<BswS>(fe_load<1, 5>(pts + j * UV_WORDS), fe_load<1, 5>(pts + j * UV_WORDS + NL),
+                          fe_load<1, 5>(pts + j * UV_WORDS + 2 * NL));
+    dens[j] = f[j].den;
+  }
+  fe_batch_inv(inv, dens);
+  const uint32_t* aux = a.ws.aux + i * AUX_WORDS;
+  Enc33 cp[5];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cp[p].w[j] = aux[8 * p + j];
+    cp[p].fl = (aux[24] >> (8 * p)) & 0xffu;
+  }
+  cp[3] = bsw_encode_frac(f[0], inv[0]);
+  cp[4] = bsw_encode_frac(f[1], inv[1]);
+  const uint8_t* ad; uint32_t ad_len;
+  bytes_lite_get(a.ad, i, ad, ad_len);
+  uint32_t c[8], sc[8], c2[8], cr[8];
+  load32(c, a.c, i); load32(sc, a.s, i);
+  bsw_challenge5(c2, cp, ad, ad_len, a.T.sq.str);
+  proof_challenge_decode<BswS>(cr, c, a.T.sq.str);
+  uint32_t diff = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) diff |= c2[j] ^ cr[j];
+  const bool valid = a.ws.flags[i] != 0 && fr_is_canonical<BswS>(sc);
+  a.status[i] = (uint8_t)(!valid ? ST_INVALID_DATA : (diff == 0 ? ST_OK : ST_VERIFICATION_FAILURE));
+}
+
+// ---- Pedersen verify, stage 1: decode H, Gamma, pk_com, R, Ok; tables of the first three; affine R, Ok; challenge ----
+__global__ void __launch_bounds__(BLOCK, 2) k_bsw_ped_verify_decode(PedersenVerifyArgs a) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  uint32_t* tabs = a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS);
+  uint32_t* pts = a.ws.pts + i * PROVE_PTS_WORDS;
+  Enc33 enc[5];
+  bool valid = true;
+#pragma unroll 1
+  for (int p = 0; p < 5; ++p) {
+    const Enc33 e = load33(p == 0 ? a.h : p == 1 ? a.gamma : p == 2 ? a.pk_com : p == 3 ? a.r : a.ok, i);
+    FeN x, y;
+    valid = bsw_decode<BswS>(x, y, e, a.T.sq) && valid;
+    // check_mask: H is an input, Gamma an output, pk_com / R / Ok proof points
+    if (a.check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF)) valid = in_prime_subgroup<BswS>(x, y, a.T.sq) && valid;
+    if (p < 3) {
+      build_glv_tables<BswS>(tabs + p * 2 * WIN_TABLE_WORDS, x, y);
+    } else {
+      uint32_t* dst = pts + (p == 3 ? PED_R_OFF : PED_OK_OFF);
+      fe_store(dst, x);
+      fe_store(dst + NL, y);
+    }
+    const Enc33 ce = enc33_canonical(e);
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      if (q == p) enc[q] = ce;
+  }
+  const uint8_t* ad; uint32_t ad_len;
+  bytes_get(a.ad, i, ad, ad_len);
+  const Enc33 cp[5] = {enc[2], enc[0], enc[1], enc[3], enc[4]};      // pk_com, H, Gamma, R, Ok
+  uint32_t c[8];
+  bsw_challenge5(c, cp, ad, ad_len, a.T.sq.str);
+  uint32_t* aux = a.ws.aux + i * AUX_WORDS;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) aux[j] = c[j];
+  a.ws.flags[i] = valid ? 1 : 0;
+}
+
+// HALF 0: s*H - c*Gamma ; HALF 1: s*G - c*pk_com + sb*B
+template <int HALF>
+__global__ void __launch_bounds__(BLOCK) k_bsw_ped_verify_straus(PedersenVerifyArgs a) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  uint32_t c[8], s[8], sb[8];
+  load32(s, a.s, i); load32(sb, a.sb, i);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c[j] = a.ws.aux[i * AUX_WORDS + j];
+  if (!fr_is_canonical<BswS>(s) || !fr_is_canonical<BswS>(sb)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0; sb[j] = 0; }
+  }
+  pedersen_verify_straus_item<BswS, HALF>(a.ws.pts + i * PROVE_PTS_WORDS + HALF * UV_WORDS, a.T,
+                                          a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), c, s, sb);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_bsw_ped_verify_finish(PedersenVerifyArgs a) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  uint32_t s[8], sb[8];
+  load32(s, a.s, i); load32(sb, a.sb, i);
+  a.status[i] = (uint8_t)pedersen_verify_finish_item<BswS>(a.ws.pts + i * PROVE_PTS_WORDS, s, sb, a.ws.flags[i] != 0);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------- launchers
+void launch_bsw_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len, uint8_t* sk, uint8_t* pk, DevTables T,
+                                 hipStream_t st) {
+  if (n) hipLaunchKernelGGL(k_bsw_secret_from_seed, grid_for(n), dim3(BLOCK), 0, st, n, seeds, seed_len, sk, pk, T);
+}
+// tai_ctr ([n] bytes) + queue: scratch of the counter search (tai_find.cuh); without them each lane loops on its own item
+void launch_bsw_hash_to_curve(size_t n, BytesView msg, uint8_t* points, DevTables T, hipStream_t st, uint8_t* tai_ctr,
+                              unsigned long long* queue) {
+  if (!n) return;
+  const uint8_t* ctr = nullptr;
+  if (tai_ctr && queue) { launch_tai_find_t<SuiteBW>(n, msg, tai_ctr, T.sq, queue, st); ctr = tai_ctr; }
+  hipLaunchKernelGGL(k_bsw_hash_to_curve, grid_for(n), dim3(BLOCK), 0, st, n, msg, points, T, ctr);
+}
+void launch_bsw_output_hash(size_t n, const uint8_t* gamma, uint8_t* hash, DevTables T, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(k_bsw_output_hash, grid_for(n), dim3(BLOCK), 0, st, n, gamma, hash, T.sq);
+}
+void launch_bsw_point_validate(size_t n, const uint8_t* pts, uint8_t* xy, uint8_t* status, DevTables T, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(k_bsw_point_validate, grid_for(n), dim3(BLOCK), 0, st, n, pts, xy, status, T);
+}
+// IETF and (a.pedersen) Pedersen proving.  ev: as launch_ietf_prove
+void launch_bsw_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev) {
+  if (a.n == 0) return;
+  if (ev) (void)hipEventRecord(ev[0], st);
+  if (!a.h_given) launch_tai_find_t<SuiteBW>(a.n, a.msg, a.ws.flags, a.T.sq, a.tai_queue, st);
+  hipLaunchKernelGGL(k_bsw_prove_prepare, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  launch_prove_stage2_bs(a, st);
+  if (ev) { (void)hipEventRecord(ev[2], st); (void)hipEventRecord(ev[3], st); }
+  hipLaunchKernelGGL(k_bsw_prove_finish, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[4], st);
+}
+void launch_bsw_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
+  if (a.n == 0) return;
+  if (ev) (void)hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(k_bsw_verify_decode, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  hipLaunchKernelGGL(k_bsw_verify_straus<1>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[2], st);
+  hipLaunchKernelGGL(k_bsw_verify_straus<0>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[3], st);
+  hipLaunchKernelGGL(k_bsw_verify_finish, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[4], st);
+}
+void launch_bsw_pedersen_verify(const PedersenVerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
+  if (a.n == 0) return;
+  if (ev) (void)hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(k_bsw_ped_verify_decode, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  hipLaunchKernelGGL(k_bsw_ped_verify_straus<0>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[2], st);
+  hipLaunchKernelGGL(k_bsw_ped_verify_straus<1>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[3], st);
+  hipLaunchKernelGGL(k_bsw_ped_verify_finish, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[4], st);
+}
+
+VRF_NS_END
