@@ -76,7 +76,7 @@ def source_stamp() -> str:
     return h.hexdigest()
 
 
-ABI_VERSION = 143      # vrfhip_abi_version() of the library this binding was written against
+ABI_VERSION = 144      # vrfhip_abi_version() of the library this binding was written against
 
 
 def load() -> ctypes.CDLL:

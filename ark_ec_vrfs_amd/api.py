@@ -83,7 +83,17 @@ class Secp256r1Sha256Tai(Suite):
     SUITE_ENUM = 5
 
 
-CURVE_BANDERSNATCH, CURVE_JUBJUB, CURVE_ED25519, CURVE_BABY_JUBJUB, CURVE_SECP256R1 = 1, 2, 3, 4, 5
+class BandersnatchSwSha512Tai(Suite):
+    """`suites::bandersnatch_sw`: the Bandersnatch group on its short-Weierstrass model, try-and-increment.  Own wire format:
+    points are arkworks' 33-byte compressed short-Weierstrass strings (x little-endian, then a flag byte); scalars and the
+    output hash as for the twisted-Edwards suite.  Parity unpinned (include/vrfhip.h); the Pedersen scheme needs a blinding
+    base in the descriptor."""
+    SUITE_ID = b"Bandersnatch_SW_SHA-512_TAI"
+    CHALLENGE_LEN = 32
+    SUITE_ENUM = 6
+
+
+CURVE_BANDERSNATCH, CURVE_JUBJUB, CURVE_ED25519, CURVE_BABY_JUBJUB, CURVE_SECP256R1, CURVE_BANDERSNATCH_SW = 1, 2, 3, 4, 5, 6
 # vrfhip_suite_desc.flags (VRFHIP_SUITE_FLAG_*): what separates RFC 9381's edwards suites from upstream's built-in ones
 SUITE_FLAG_SIGN_PARITY, SUITE_FLAG_CHALLENGE_LE, SUITE_FLAG_HASH_COFACTOR = 1, 2, 4
 

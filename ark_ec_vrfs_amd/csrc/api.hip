@@ -18,6 +18,8 @@
 #include "msm.cuh"
 #include "msm_g1.h"
 #include "p256.h"
+#include "bsw.h"
+#include "constants_bsw.gen.h"
 
 namespace vrf {
 // k_pairing_oct.hip: per-item G2 points as two kernels (lines -> HBM -> Miller loop + final exponentiation)
@@ -76,6 +78,9 @@ int32_t fail(int32_t code, const std::string& msg) {
   } while (0)
 
 constexpr size_t DEFAULT_CHUNK = size_t(1) << 20;
+const char BSW_UNSUPPORTED_MSG[] =
+    "not available for the bandersnatch_sw suite (secret keys, hash-to-curve, output hash, point validation, the IETF scheme incl. "
+    "verification from alpha, and the Pedersen scheme per proof are)";
 
 }  // namespace
 
@@ -123,7 +128,10 @@ struct vrfhip_ctx {
   uint32_t* d_p256_comb = nullptr;
   uint32_t* d_p256_comb_b = nullptr;       // comb of the Pedersen blinding base (nullptr: the descriptor's base is all-zero)
   p256::Ws p256_ws{};
-  size_t pt_bytes() const { return sw ? 33 : 32; }        // one compressed point on the wire
+  // `suites::bandersnatch_sw`: a Bandersnatch (twisted-Edwards) context whose codec is arkworks' short-Weierstrass one --
+  // 33-byte points on the wire; tables, workspace and the arithmetic stages are the Edwards suite's (bsw.h, k_bsw.hip)
+  bool bsw = false;
+  size_t pt_bytes() const { return (sw || bsw) ? 33 : 32; }        // one compressed point on the wire
   size_t hash_bytes() const { return sw ? 32 : 64; }      // `Output::hash`: the suite hasher's output
   size_t prove_point_bytes() const { return (flags & VRFHIP_FLAG_PROVE_POINTS_AFFINE) ? 64 : pt_bytes(); }
   bool coords_mont256() const { return (flags & VRFHIP_FLAG_COORDS_MONT256) != 0; }
@@ -328,7 +336,7 @@ size_t blob_bytes(size_t n, const uint32_t* off, uint32_t len, bool shared) {
 
 extern "C" {
 
-int32_t vrfhip_abi_version(void) { return 143; }
+int32_t vrfhip_abi_version(void) { return 144; }
 
 const char* vrfhip_last_error(void) { return g_last_error.c_str(); }
 
@@ -348,6 +356,7 @@ int32_t vrfhip_test_blinding_base(vrfhip_suite suite, uint8_t out_xy[64]) {
   else if (suite == VRFHIP_SUITE_ED25519_SHA512_TAI) have = vrf::f_25519::field_default_points(SUITE_ED, g, out_xy);
   else if (suite == VRFHIP_SUITE_BABY_JUBJUB_SHA512_TAI) have = vrf::f_bn254fr::field_default_points(SUITE_BJ, g, out_xy);
   else if (suite == VRFHIP_SUITE_SECP256R1_SHA256_TAI) { p256::default_blinding_base(out_xy); have = true; }
+  else if (suite == VRFHIP_SUITE_BANDERSNATCH_SW_SHA512_TAI) { std::memcpy(out_xy, vrfk_bsw::BB_XY, 64); have = true; }
   if (!have) return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported suite");
   return VRFHIP_SUCCESS;
 }
@@ -393,6 +402,14 @@ int32_t vrfhip_suite_desc_default(vrfhip_suite suite, vrfhip_suite_desc* out) {
     // blinding_base stays all-zero: upstream's constant is not known here (vrfhip_test_blinding_base has a placeholder)
     have = true;
   }
+  else if (suite == VRFHIP_SUITE_BANDERSNATCH_SW_SHA512_TAI) {
+    out->curve = VRFHIP_CURVE_BANDERSNATCH_SW;
+    put(out->suite_id, out->suite_id_len, "Bandersnatch_SW_SHA-512_TAI");
+    std::memcpy(out->generator, vrfk_bsw::G_XY, 64);          // te_sw_map image of the twisted-Edwards suite's generator
+    // blinding_base stays all-zero: upstream's constant is not pinned here (vrfhip_test_blinding_base: the image of the
+    // twisted-Edwards suite's)
+    have = true;
+  }
   if (!have) return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported suite");
   return VRFHIP_SUCCESS;
 }
@@ -417,9 +434,11 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
   *out = nullptr;
   if (!desc) return fail(VRFHIP_ERR_BAD_ARG, "desc is NULL");
   if (desc->struct_size != sizeof(vrfhip_suite_desc)) return fail(VRFHIP_ERR_BAD_ARG, "desc.struct_size mismatch");
-  if (desc->curve < VRFHIP_CURVE_BANDERSNATCH || desc->curve > VRFHIP_CURVE_SECP256R1)
+  if (desc->curve < VRFHIP_CURVE_BANDERSNATCH || desc->curve > VRFHIP_CURVE_BANDERSNATCH_SW)
     return fail(VRFHIP_ERR_UNSUPPORTED, "unsupported curve");
   if (desc->curve == VRFHIP_CURVE_SECP256R1 && desc->flags) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1 takes no suite flags");
+  const bool bsw = desc->curve == VRFHIP_CURVE_BANDERSNATCH_SW;
+  if (bsw && desc->flags) return fail(VRFHIP_ERR_UNSUPPORTED, "bandersnatch_sw takes no suite flags");
   if (desc->challenge_len == 0 || desc->challenge_len > 32) return fail(VRFHIP_ERR_UNSUPPORTED, "challenge_len must be 1..32");
   if (desc->flags & ~(uint32_t)VRFHIP_SUITE_FLAG_ALL) return fail(VRFHIP_ERR_UNSUPPORTED, "unknown suite flag bits");
   if (desc->suite_id_len == 0 || desc->suite_id_len > sizeof desc->suite_id)
@@ -428,7 +447,8 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
   if (ell2 && (desc->h2c_dst_len == 0 || desc->h2c_dst_len > sizeof desc->h2c_dst))
     return fail(VRFHIP_ERR_BAD_ARG, "h2c_dst_len out of range");
   // one built-in suite per curve: its id names the compiled arithmetic (SUITE_* in vrf_types.h follow vrfhip_suite)
-  const vrfhip_suite suite = (vrfhip_suite)desc->curve;
+  // (the short-Weierstrass presentation of Bandersnatch runs the twisted-Edwards suite's arithmetic: bsw_core.cuh)
+  const vrfhip_suite suite = bsw ? VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2 : (vrfhip_suite)desc->curve;
   static_assert((int)VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2 == SUITE_BS && (int)VRFHIP_SUITE_JUBJUB_SHA512_TAI == SUITE_JJ &&
                 (int)VRFHIP_SUITE_ED25519_SHA512_TAI == SUITE_ED && (int)VRFHIP_SUITE_BABY_JUBJUB_SHA512_TAI == SUITE_BJ &&
                 (int)VRFHIP_CURVE_ED25519 == SUITE_ED && (int)VRFHIP_CURVE_BABY_JUBJUB == SUITE_BJ, "suite / curve ids");
@@ -442,6 +462,7 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
   ctx->device = device;
   ctx->suite = suite;
   ctx->field = suite_field((int)suite);
+  ctx->bsw = bsw;
   ctx->desc = *desc;
   auto cleanup = [&](int32_t rc) {
     vrfhip_ctx_destroy(ctx);
@@ -557,6 +578,23 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
   }
   uint32_t* d_mont = reinterpret_cast<uint32_t*>(d_init + 128);
   uint8_t* d_flags = d_init + 128 + 4 * NL * sizeof(uint32_t);
+  if (bsw) {
+    // the descriptor holds the short-Weierstrass coordinates (`Suite::generator()` of the SW suite): tables are built from
+    // their te_sw_map images.  A point without one (infinity, y = 0) is no generator.
+    uint8_t map_st[2] = {1, 1};
+    vrf::f_bls381fr::launch_te_sw_map(SUITE_BS, 2, 1, 0, d_init, d_init + 288, d_init + 420, ctx->stream);
+    hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
+    hipError_t e3 = hipMemcpy(map_st, d_init + 420, 2, hipMemcpyDeviceToHost);
+    hipError_t e4 = hipMemcpy(d_init, d_init + 288, 128, hipMemcpyDeviceToDevice);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+      free_tmp();
+      HIP_TRY_C(e1); HIP_TRY_C(e2); HIP_TRY_C(e3); HIP_TRY_C(e4);
+    }
+    if (map_st[0] || map_st[1]) {
+      free_tmp();
+      return cleanup(fail(VRFHIP_ERR_BAD_ARG, map_st[0] ? "desc.generator has no twisted-Edwards image" : "desc.blinding_base has no twisted-Edwards image"));
+    }
+  }
   FIELD_CALL(ctx, launch_init_tables((int)suite, ctx->d_g_win, ctx->d_g_comb, ctx->d_b_comb, d_prefix, d_init, d_mont, d_flags, ctx->T.sq,
                      ctx->stream));
   uint8_t base_ok[2] = {0, 0};
@@ -744,7 +782,8 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
     HIP_TRY(hipGetLastError());
     return VRFHIP_SUCCESS;
   }
-  const size_t pw = affine ? 64 : 32;
+  if (ctx->bsw && (affine || ks)) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
+  const size_t pw = affine ? 64 : ctx->pt_bytes();
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     size_t m = std::min(ctx->ws_cap, n - base);
     VerifyArgs a;
@@ -764,7 +803,8 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
     a.status = d_status + base;
     a.ws = ctx->ws;
     a.T = ctx->T;
-    FIELD_CALL(ctx, launch_ietf_verify(a, st, prof_events(ctx)));
+    if (ctx->bsw) launch_bsw_ietf_verify(a, st, prof_events(ctx));
+    else FIELD_CALL(ctx, launch_ietf_verify(a, st, prof_events(ctx)));
   }
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
@@ -879,6 +919,31 @@ int32_t vrfhip_ietf_verify_batch_alpha_dev(vrfhip_ctx* ctx, size_t n, const uint
     HIP_TRY(hipGetLastError());
     return VRFHIP_SUCCESS;
   }
+  if (ctx->bsw) {
+    // the two stages as they are: H's 33-byte string parked in the projective-results region, which nothing writes before the
+    // decode stage has read it; H is a cofactor multiple by construction, so its subgroup test is skipped
+    for (size_t base = 0; base < n; base += ctx->ws_cap) {
+      const size_t m = std::min(ctx->ws_cap, n - base);
+      uint8_t* d_henc = reinterpret_cast<uint8_t*>(ctx->ws.pts);
+      BytesView mv = d_msg_off ? make_view(d_msg, d_msg_off + base, msg_len, false)
+                               : make_view(d_msg ? d_msg + base * (size_t)msg_len : d_msg, nullptr, msg_len, false);
+      launch_bsw_hash_to_curve(m, mv, d_henc, ctx->T, st, ctx->ws.flags, ctx->d_queue);
+      VerifyArgs a{};
+      a.suite = (int)ctx->suite;
+      a.k_lane = 1;
+      a.n = m;
+      a.pk = d_pk + base * 33; a.h = d_henc; a.gamma = d_output + base * 33;
+      a.check_mask = ctx->check_mask() & ~2u;
+      a.c = d_c + base * 32; a.s = d_s + base * 32;
+      a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
+      a.status = d_status + base;
+      a.ws = ctx->ws;
+      a.T = ctx->T;
+      launch_bsw_ietf_verify(a, st, prof_events(ctx));
+    }
+    HIP_TRY(hipGetLastError());
+    return VRFHIP_SUCCESS;
+  }
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     const size_t m = std::min(ctx->ws_cap, n - base);
     uint8_t* d_henc = reinterpret_cast<uint8_t*>(ctx->ws.aux);              // [m][32]: AUX_WORDS * 4 >= 32 bytes per item
@@ -972,6 +1037,7 @@ int32_t vrfhip_keyset_create(vrfhip_ctx* ctx, size_t n_keys, const uint8_t* pks,
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (n_keys == 0 || !pks) return fail(VRFHIP_ERR_BAD_ARG, "no keys");
   if (n_keys > (size_t(1) << 24)) return fail(VRFHIP_ERR_BAD_ARG, "too many keys");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   vrfhip_keyset* ks = new vrfhip_keyset();
@@ -1160,6 +1226,8 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
     HIP_TRY(hipGetLastError());
     return VRFHIP_SUCCESS;
   }
+  if (ctx->bsw && (ctx->flags & VRFHIP_FLAG_PROVE_POINTS_AFFINE)) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
+  const size_t ipw = ctx->pt_bytes();                    // input points and enc(H) out: always compressed
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     size_t m = std::min(ctx->ws_cap, n - base);
     ProveArgs a;
@@ -1169,14 +1237,14 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
     a.sk = d_sk + base * 32;
     if (d_msg_off) a.msg = make_view(d_msg, d_msg_off + base, 0, false);
     else a.msg = make_view(d_msg ? d_msg + base * (size_t)msg_len : nullptr, nullptr, msg_len, false);
-    a.h_given = d_input ? d_input + base * 32 : nullptr;
+    a.h_given = d_input ? d_input + base * ipw : nullptr;
     a.tai_queue = ctx->d_queue;
     a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
     const size_t ptw = ctx->prove_point_bytes();        // 32: compressed, 64: x || y (VRFHIP_FLAG_PROVE_POINTS_AFFINE)
     a.out_affine = ptw == 64 ? 1 : 0;
     a.gamma = at(o.output, base, ptw); a.c = at(o.c, base, 32); a.s = at(o.s, base, 32);
     a.pk_out = at(o.pk, base, ptw);
-    a.h_out = at(o.input, base, 32);
+    a.h_out = at(o.input, base, ipw);
     a.status = at(o.status, base, 1);
     a.pedersen = pedersen ? 1 : 0;
     a.check_mask = ctx->check_mask() | ((ctx->flags & VRFHIP_FLAG_CT_TABLES) ? (uint32_t)CHK_CT_TABLES : 0u);
@@ -1184,7 +1252,8 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
     a.blinding_out = at(o.blinding, base, 32);
     a.ws = ctx->ws;
     a.T = ctx->T;
-    FIELD_CALL(ctx, launch_ietf_prove(a, st, prof_events(ctx)));
+    if (ctx->bsw) launch_bsw_prove(a, st, prof_events(ctx));
+    else FIELD_CALL(ctx, launch_ietf_prove(a, st, prof_events(ctx)));
     if (a.out_affine && ctx->coords_mont256()) {       // x || y outputs in arkworks' in-memory form
       FIELD_CALL(ctx, launch_xy_to_mont256(m, a.gamma, st));
       FIELD_CALL(ctx, launch_xy_to_mont256(m, a.pk_out, st));
@@ -1353,14 +1422,16 @@ int32_t vrfhip_pedersen_verify_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_
     PedersenVerifyArgs a;
     a.suite = (int)ctx->suite;
     a.n = m;
-    a.h = d_input + base * 32; a.gamma = d_output + base * 32; a.pk_com = d_pk_com + base * 32;
-    a.r = d_r + base * 32; a.ok = d_ok + base * 32; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
+    const size_t pw = ctx->pt_bytes();
+    a.h = d_input + base * pw; a.gamma = d_output + base * pw; a.pk_com = d_pk_com + base * pw;
+    a.r = d_r + base * pw; a.ok = d_ok + base * pw; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
     a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
     a.check_mask = ctx->check_mask();
     a.status = d_status + base;
     a.ws = ctx->ws;
     a.T = ctx->T;
-    FIELD_CALL(ctx, launch_pedersen_verify(a, st, prof_events(ctx)));
+    if (ctx->bsw) launch_bsw_pedersen_verify(a, st, prof_events(ctx));
+    else FIELD_CALL(ctx, launch_pedersen_verify(a, st, prof_events(ctx)));
   }
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
@@ -1416,6 +1487,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
                      uint8_t* d_fail_flag, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the batched Pedersen verifier takes Sec1 points (the x || y form is not built)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!d_fail_flag || !seed) return fail(VRFHIP_ERR_BAD_ARG, "NULL fail flag or seed");
   if (n && (!d_input || !d_output || !d_pk_com || !d_r || !d_ok || !d_s || !d_sb || !d_status))
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
@@ -1519,6 +1591,7 @@ int32_t rlc_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* inp
                       const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the batched Pedersen verifier takes Sec1 points (the x || y form is not built)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!seed) return fail(VRFHIP_ERR_BAD_ARG, "seed is NULL");
   if (batch_ok) *batch_ok = 1;
   if (n == 0) return VRFHIP_SUCCESS;
@@ -1626,6 +1699,7 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (!d_out_point || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!d_bases_xy || !d_scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1693,6 +1767,7 @@ int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
                                        void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (n == 0) return VRFHIP_SUCCESS;
   if (!d_g1 || !d_g2 || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1722,6 +1797,7 @@ int32_t vrfhip_pairing_check_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* g1,
                                    int32_t g2_shared, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (n == 0) return VRFHIP_SUCCESS;
   if (!g1 || !g2 || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1747,6 +1823,7 @@ int32_t vrfhip_g1_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases, con
                           uint8_t* d_status, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!d_out || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!d_bases || !d_scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if (n > (size_t(1) << 28)) return fail(VRFHIP_ERR_BAD_ARG, "batch too large");
@@ -1767,6 +1844,7 @@ int32_t vrfhip_g1_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases, const uin
                       uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!out || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!bases || !scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1795,6 +1873,7 @@ int32_t vrfhip_pairing_check_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint
                                            const uint8_t seed[32], uint8_t* d_status, uint8_t* d_verdict, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!d_verdict || !seed) return fail(VRFHIP_ERR_BAD_ARG, "NULL verdict or seed");
   if (n && (!d_g1 || !d_g2_shared || !d_status)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if (n > (size_t(1) << 28)) return fail(VRFHIP_ERR_BAD_ARG, "batch too large");
@@ -1830,6 +1909,7 @@ int32_t vrfhip_pairing_check_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t*
                                        const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!seed) return fail(VRFHIP_ERR_BAD_ARG, "seed is NULL");
   if (batch_ok) *batch_ok = 1;
   if (n == 0) return VRFHIP_SUCCESS;
@@ -1865,6 +1945,7 @@ int32_t vrfhip_pairing_check_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t*
 int32_t vrfhip_test_pairing_quad_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp12_pairs, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (n == 0) return VRFHIP_SUCCESS;
   if (!fp12_pairs || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1887,6 +1968,7 @@ int32_t vrfhip_test_pairing_quad_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* f
 int32_t vrfhip_test_pairing_oct_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp12_pairs, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (n == 0) return VRFHIP_SUCCESS;
   if (!fp12_pairs || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1917,7 +1999,7 @@ int32_t vrfhip_hash_to_curve_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
   // buffer of its own (n bytes, at most 2^20 per chunk) -- not the prove / verify workspace (7 KiB per item), which this
   // entry point neither needs nor should resize.
   const size_t chunk = std::min<size_t>(n, size_t(1) << 20);
-  if (ctx->sw || ctx->suite != VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2) {
+  if (ctx->sw || ctx->bsw || ctx->suite != VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2) {
     if (ctx->h2c_cap < chunk) {
       if (ctx->d_h2c_ctr) { (void)hipStreamSynchronize(static_cast<hipStream_t>(stream)); (void)hipFree(ctx->d_h2c_ctr); ctx->d_h2c_ctr = nullptr; ctx->h2c_cap = 0; }
       if (hipMalloc(&ctx->d_h2c_ctr, chunk) != hipSuccess) return fail(VRFHIP_ERR_OOM, "hipMalloc(hash-to-curve counters) failed");
@@ -1931,6 +2013,13 @@ int32_t vrfhip_hash_to_curve_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
                                : make_view(d_msg ? d_msg + base * (size_t)msg_len : d_msg, nullptr, msg_len, false);
       p256::launch_hash_to_curve(m, mv, d_points + base * 33, ctx->T.sq.str, static_cast<hipStream_t>(stream), ctx->d_h2c_ctr,
                                  ctx->d_queue);
+    }
+  } else if (ctx->bsw) {
+    for (size_t base = 0; base < n; base += chunk) {
+      const size_t m = std::min(chunk, n - base);
+      BytesView mv = d_msg_off ? make_view(d_msg, d_msg_off + base, msg_len, false)
+                               : make_view(d_msg ? d_msg + base * (size_t)msg_len : d_msg, nullptr, msg_len, false);
+      launch_bsw_hash_to_curve(m, mv, d_points + base * 33, ctx->T, static_cast<hipStream_t>(stream), ctx->d_h2c_ctr, ctx->d_queue);
     }
   } else if (ctx->suite == VRFHIP_SUITE_BANDERSNATCH_SHA512_ELL2) {
     FIELD_CALL(ctx, launch_hash_to_curve((int)ctx->suite, n, make_view(d_msg, d_msg_off, msg_len, false), d_points, ctx->T,
@@ -1984,6 +2073,7 @@ int32_t vrfhip_output_hash_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   if (ctx->sw) p256::launch_output_hash(n, d_output, d_hash, ctx->T.sq.str, static_cast<hipStream_t>(stream));
+  else if (ctx->bsw) launch_bsw_output_hash(n, d_output, d_hash, ctx->T, static_cast<hipStream_t>(stream));
   else
   FIELD_CALL(ctx, launch_output_hash((int)ctx->suite, n, d_output, d_hash, ctx->T, static_cast<hipStream_t>(stream)));
   HIP_TRY(hipGetLastError());
@@ -2021,6 +2111,7 @@ int32_t vrfhip_secret_from_seed_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   if (ctx->sw) p256::launch_secret_from_seed(n, d_seeds, seed_len, d_sk_out, d_pk_out, ctx->d_p256_comb, static_cast<hipStream_t>(stream));
+  else if (ctx->bsw) launch_bsw_secret_from_seed(n, d_seeds, seed_len, d_sk_out, d_pk_out, ctx->T, static_cast<hipStream_t>(stream));
   else
   FIELD_CALL(ctx, launch_secret_from_seed((int)ctx->suite, n, d_seeds, seed_len, d_sk_out, d_pk_out, ctx->T,
                           static_cast<hipStream_t>(stream)));
@@ -2066,6 +2157,12 @@ int32_t vrfhip_point_validate_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t
   DeviceGuard guard(ctx->device);
   if (ctx->sw) {
     p256::launch_point_validate(n, d_points, d_xy_out, ctx->coords_mont256() ? 1 : 0, d_status, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return VRFHIP_SUCCESS;
+  }
+  if (ctx->bsw) {                  // x || y out: the short-Weierstrass coordinates
+    launch_bsw_point_validate(n, d_points, d_xy_out, d_status, ctx->T, static_cast<hipStream_t>(stream));
+    if (d_xy_out && ctx->coords_mont256()) FIELD_CALL(ctx, launch_xy_to_mont256(n, d_xy_out, static_cast<hipStream_t>(stream)));
     HIP_TRY(hipGetLastError());
     return VRFHIP_SUCCESS;
   }
@@ -2151,6 +2248,7 @@ int32_t vrfhip_fq_mul_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const u
                             uint8_t* r) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (n == 0) return VRFHIP_SUCCESS;
   if (!a || !b || !r) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -2176,6 +2274,7 @@ int32_t vrfhip_test_point_add(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const
                               uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (n == 0) return VRFHIP_SUCCESS;
   if (!a || !b || !out || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -2198,6 +2297,7 @@ int32_t vrfhip_test_scalar_mul(vrfhip_ctx* ctx, size_t n, const uint8_t* scalars
                                uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (n == 0) return VRFHIP_SUCCESS;
   if (!scalars || !points || !out || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -2229,6 +2329,7 @@ int32_t test_hash_impl(vrfhip_ctx* ctx, size_t n, const uint8_t* msg, const uint
                        uint8_t* out, int which) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (n == 0) return VRFHIP_SUCCESS;
   if (!out || (!msg && (msg_len || msg_off))) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   const size_t ob = which ? 96 : 64;
@@ -2335,6 +2436,7 @@ int32_t vrfhip_test_batch_digest(vrfhip_ctx* ctx, size_t n, int32_t n_arr, const
                                  uint64_t index0, uint8_t root[32]) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
+  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!root || !arrays || !widths || n == 0) return fail(VRFHIP_ERR_BAD_ARG, "NULL argument or empty batch");
   if (n_arr < 1 || n_arr > DIGEST_MAX_ARRAYS) return fail(VRFHIP_ERR_BAD_ARG, "1..8 arrays");
   if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");

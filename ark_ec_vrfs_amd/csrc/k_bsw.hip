@@ -4,7 +4,7 @@
 // Straus stages wrap the same per-item functions (verify_straus_item, pedersen_verify_straus_item) -- so the workspace
 // (window tables, projective intermediates, aux words, flag bytes) has the layout k_prove.hip / k_verify.hip /
 // k_pedersen.hip give it, and the launch arguments are theirs (vrf_types.h), with 33-byte point rows.
-#include "kernels.h"
+#include "bsw.h"
 #include "bsw_core.cuh"
 #include "tai_find.cuh"
 

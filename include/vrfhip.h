@@ -84,7 +84,24 @@ typedef enum vrfhip_suite {
    * tests run: tests/golden/rfc9381_p256_sha256_tai.json (the RFC's use: message = PK_string || alpha).  As upstream, the
    * RFC 6979 nonce takes h1 unreduced and the first HMAC_DRBG candidate mod n (each differs from the RFC text with
    * probability 2^-32). */
-  VRFHIP_SUITE_SECP256R1_SHA256_TAI = 5
+  VRFHIP_SUITE_SECP256R1_SHA256_TAI = 5,
+  /* `suites::bandersnatch_sw` ("Bandersnatch_SW_SHA-512_TAI"): the Bandersnatch group on its short-Weierstrass model
+   * (ark-ed-on-bls12-381-bandersnatch SWAffine: y^2 = x^3 + a' x + b', the Weierstrass form of the curve's Montgomery model),
+   * SHA-512, ArkworksCodec, `nonce_rfc_8032`, try-and-increment, `CHALLENGE_LEN = 32`.  WIRE FORMAT: points are arkworks'
+   * 33-byte compressed short-Weierstrass strings -- x as a 32-byte little-endian integer, then one flag byte (0x80: y is the
+   * larger of {y, q - y}; 0x40: the point at infinity, written with x = 0; both = error; the six low bits are not looked at) --
+   * scalars 32-byte little-endian, `Output::hash` 64 bytes.  The arithmetic is the twisted-Edwards suite's (same group:
+   * points cross `utils::te_sw_map` at the codec, csrc/bsw_core.cuh), so speed and the checked-decode rules are that suite's.
+   * Entry points: vrfhip_secret_from_seed_batch, vrfhip_hash_to_curve_batch, vrfhip_output_hash_batch,
+   * vrfhip_point_validate_batch (x || y out = Weierstrass coordinates), vrfhip_ietf_prove_batch / _verify_batch (+ _dev,
+   * _multi), vrfhip_ietf_verify_batch_alpha, vrfhip_pedersen_prove_batch / _verify_batch (+ _dev, _multi; needs a blinding
+   * base in the descriptor), vrfhip_te_sw_map_batch.  Everything else returns VRFHIP_ERR_UNSUPPORTED (x || y forms of the
+   * schemes, key sets, MSM, the batched Pedersen verifier).  PARITY UNPINNED: no vector of this suite is on this machine;
+   * the suite string, the generator (= te_sw_map image of the twisted-Edwards suite's) and the flag convention are
+   * recollections; what is checked is consistency with the vector-pinned twisted-Edwards suite through the map
+   * (tests/test_bandersnatch_sw.py).  With the subgroup test switched off (VRFHIP_FLAG_PREVALIDATED_*) a point with y = 0 is
+   * InvalidData here (it has no Edwards image) where upstream would compute with it. */
+  VRFHIP_SUITE_BANDERSNATCH_SW_SHA512_TAI = 6
 } vrfhip_suite;
 
 /* Suite descriptor: what a `Suite` / `PedersenSuite` impl states as DATA (src/lib.rs:16 `Suite`, :14 `suites`):
@@ -98,10 +115,14 @@ typedef enum vrfhip_curve {
   VRFHIP_CURVE_JUBJUB = 2,       /* ark-ed-on-bls12-381 (JubJub): a = -1, cofactor 8; try-and-increment (RFC 9381) */
   VRFHIP_CURVE_ED25519 = 3,      /* ark-ed25519: q = 2^255 - 19, a = -1, cofactor 8; try-and-increment */
   VRFHIP_CURVE_BABY_JUBJUB = 4,  /* ark-ed-on-bn254: q = BN254 Fr, a = 1, cofactor 8; try-and-increment */
-  VRFHIP_CURVE_SECP256R1 = 5     /* ark-secp256r1: y^2 = x^3 - 3x + b over the NIST P-256 prime, cofactor 1; try-and-increment,
+  VRFHIP_CURVE_SECP256R1 = 5,    /* ark-secp256r1: y^2 = x^3 - 3x + b over the NIST P-256 prime, cofactor 1; try-and-increment,
                                     SHA-256, Sec1 wire format.  Descriptor: suite_id, challenge_len, generator and
                                     blinding_base are read (points still x || y little-endian; an all-zero blinding_base =
                                     no Pedersen scheme); flags must be 0 */
+  VRFHIP_CURVE_BANDERSNATCH_SW = 6 /* ark-ed-on-bls12-381-bandersnatch SWAffine: Bandersnatch's short-Weierstrass model,
+                                    cofactor 4; try-and-increment, 33-byte arkworks SW wire format.  Descriptor: suite_id,
+                                    challenge_len, generator and blinding_base (x || y of the WEIERSTRASS points, little-endian;
+                                    an all-zero blinding_base = no Pedersen scheme) are read; flags must be 0 */
 } vrfhip_curve;
 
 /* What a `Suite` impl may override besides its constants (`Suite::Codec`, `Suite::challenge`, `Suite::point_to_hash`):

@@ -43,7 +43,7 @@ def test_every_entry_point_has_a_declared_signature():
 
 def test_abi_version_and_no_cpu_fallback():
     lib = _lib.load()
-    assert lib.vrfhip_abi_version() == _lib.ABI_VERSION == 143
+    assert lib.vrfhip_abi_version() == _lib.ABI_VERSION == 144
     import torch
     if not torch.cuda.is_available():
         from ark_ec_vrfs_amd import Context, VrfHipError

@@ -1,0 +1,337 @@
+"""`suites::bandersnatch_sw` ("Bandersnatch_SW_SHA-512_TAI"): the Bandersnatch group on its short-Weierstrass model
+(SURVEY.md section 2.2 suite list; section 8 row f4).
+
+PARITY UNPINNED: no vector of this suite is on this machine.  What the tiers check:
+  CPU: the oracle (oracle/bsw_oracle.py, chord-and-tangent ON the Weierstrass curve) against the vector-pinned
+       twisted-Edwards oracle through `utils::te_sw_map` -- same secret, same input point: Gamma, the public key, the Pedersen
+       commitment are each other's images; a proof made on one model verifies there; the codec's rules.
+  GPU (-m gpu): the HIP path (which runs the group law on the EDWARDS model and crosses the map at the codec,
+       csrc/bsw_core.cuh) against the oracle through the C ABI: prove bytes, verify statuses on tampered / undecodable /
+       small-order / non-canonical inputs, Pedersen, verification from alpha, and the same consistency with the device's own
+       twisted-Edwards suite at 2^13 items."""
+import numpy as np
+import pytest
+
+from oracle import bsw_oracle as bo
+from oracle import vrf_oracle as vo
+
+TE = vo.BANDERSNATCH
+Q, R = bo.Q, bo.R
+
+
+def le(x):
+    return int(x).to_bytes(32, "little")
+
+
+def xy(p):
+    return le(p[0]) + le(p[1])
+
+
+def _u8(rows):
+    return np.stack([np.frombuffer(bytes(r), np.uint8) for r in rows])
+
+
+def _torsion2():
+    """The three points of order 2: (x, 0) with x a root of x^3 + a' x + b'.  One is the image's partner of the Edwards
+    point (0, -1); the other two have no affine Edwards image."""
+    # E[2] is rational (Z2 x Z2 x Zr): u in {0, roots of u^2 + A u + 1} on the Montgomery model; x = (u + A/3) / B
+    A, B, _, _ = vo.te_sw_constants(TE)
+    roots = []
+    third = A * vo.finv(3, Q) % Q
+    disc = vo.fsqrt((A * A - 4) % Q, Q)
+    us = [0] + ([] if disc is None else [(-A + disc) * vo.finv(2, Q) % Q, (-A - disc) * vo.finv(2, Q) % Q])
+    for u in us:
+        x = (u + third) * vo.finv(B, Q) % Q
+        assert (x ** 3 + bo.A * x + bo.B) % Q == 0
+        roots.append((x, 0))
+    return roots
+
+
+# ------------------------------------------------------------------------------------------------------ CPU tier
+def test_curve_and_constants():
+    assert bo.is_on_curve(bo.G) and bo.is_on_curve(bo.BLINDING_BASE)
+    assert bo.in_prime_subgroup(bo.G) and bo.in_prime_subgroup(bo.BLINDING_BASE)
+    assert bo.mul(R, bo.G) is None and bo.mul(R - 1, bo.G) == bo.neg(bo.G)
+    assert vo.sw_to_te(TE, bo.G) == (TE.gx, TE.gy)
+    # group order 4 r: cofactor clearing lands in the subgroup; the 2-torsion is rational and full
+    t2 = _torsion2()
+    assert len(t2) == 3 and all(bo.mul(2, t) is None for t in t2)
+    assert bo.add(t2[0], t2[1]) == t2[2]
+    # the generated device constants are these numbers
+    import re
+    src = open(__import__("os").path.join(__import__("os").path.dirname(__file__), "..", "ark_ec_vrfs_amd", "csrc",
+                                          "constants_bsw.gen.h")).read()
+    g = bytes(int(v) for v in re.search(r"G_XY\[64\] = \{([^}]*)\}", src).group(1).split(","))
+    b = bytes(int(v) for v in re.search(r"BB_XY\[64\] = \{([^}]*)\}", src).group(1).split(","))
+    assert g == xy(bo.G) and b == xy(bo.BLINDING_BASE)
+
+
+def test_oracle_group_law_is_the_map_image_of_the_edwards_law():
+    import random
+    rnd = random.Random(5)
+    P = bo.G
+    for _ in range(40):
+        k1, k2 = rnd.randrange(1, R), rnd.randrange(1, R)
+        a, b = bo.mul(k1, P), bo.mul(k2, P)
+        ta, tb = vo.te_mul(TE, k1, (TE.gx, TE.gy)), vo.te_mul(TE, k2, (TE.gx, TE.gy))
+        assert vo.te_to_sw(TE, ta) == a and vo.sw_to_te(TE, b) == tb
+        assert vo.te_to_sw(TE, vo.te_add(TE, ta, tb)) == bo.add(a, b)
+        assert bo.add(a, a) == bo.mul(2, a) and bo.add(a, bo.neg(a)) is None and bo.add(a, None) == a
+
+
+def test_codec_rules():
+    p = bo.mul(7, bo.G)
+    e = bo.point_encode(p)
+    assert len(e) == 33 and e[:32] == le(p[0]) and e[32] == (0x80 if p[1] > Q - p[1] else 0)
+    assert bo.point_decode(e) == (True, p)
+    assert bo.point_decode(bo.point_encode(bo.neg(p))) == (True, bo.neg(p)) and bo.point_encode(bo.neg(p))[32] == e[32] ^ 0x80
+    assert bo.point_encode(None) == bytes(32) + b"\x40" and bo.point_decode(bytes(32) + b"\x40") == (True, None)
+    assert bo.point_decode(e[:32] + bytes([e[32] | 0x40]))[0] == (e[32] == 0)           # both flags: an error
+    assert bo.point_decode(e[:32] + bytes([e[32] | 0x2a])) == (True, p)                 # low flag-byte bits are not looked at
+    assert bo.point_decode(le(123) + b"\x40") == (True, None)                           # infinity: x is not looked at...
+    assert bo.point_decode(le(Q) + b"\x40")[0] is False                                 # ...beyond being a field element
+    assert bo.point_decode(le(Q + p[0]) + e[32:])[0] is False
+    x = next(x for x in range(2, 100) if vo.legendre((x ** 3 + bo.A * x + bo.B) % Q, Q) == -1)
+    assert bo.point_decode(le(x) + b"\x00")[0] is False
+    t = _torsion2()[0]
+    assert bo.point_decode(le(t[0]) + b"\x80") == (True, t) and bo.point_encode(t)[32] == 0     # y = 0: either flag
+    assert bo.point_decode_checked(le(t[0]) + b"\x00")[0] is False
+    assert bo.point_decode_checked(bo.point_encode(bo.add(p, t)))[0] is False           # outside the prime-order subgroup
+
+
+def test_oracle_schemes_against_the_pinned_edwards_oracle():
+    """Same secret, same input point on both models: Gamma, pk and pk_com are each other's images (the nonce and the challenge
+    hash the encodings, so they differ by design); proofs verify on their own model and not after tampering."""
+    for i in range(6):
+        sk = bo.secret_from_seed(b"seed %d" % i)
+        assert sk == vo.secret_from_seed(TE, b"seed %d" % i)
+        h = bo.hash_to_curve_tai(b"input %d" % i)
+        assert bo.in_prime_subgroup(h)
+        ht = vo.sw_to_te(TE, h)
+        ad = b"ad" * i
+        gamma, c, s = bo.ietf_prove(sk, h, ad)
+        gt, _, _ = vo.ietf_prove(TE, sk, ht, ad)
+        pk = bo.public_from_secret(sk)
+        assert vo.te_to_sw(TE, gt) == gamma and vo.te_to_sw(TE, vo.public_from_secret(TE, sk)) == pk
+        assert bo.ietf_verify(pk, h, gamma, ad, c, s) and bo.ietf_verify(pk, h, gamma, ad, c + R, s)
+        assert not bo.ietf_verify(pk, h, gamma, ad + b"x", c, s) and not bo.ietf_verify(pk, h, gamma, ad, c, (s + 1) % R)
+        assert not bo.ietf_verify(pk, h, bo.add(gamma, bo.G), ad, c, s)
+        enc = [bo.point_encode(p) for p in (pk, h, gamma)]
+        assert bo.ietf_verify_bytes(*enc, ad, le(c), le(s)) == 0 and bo.ietf_verify_bytes(*enc, ad, le(c), le(s + R)) == 2
+        g2, proof, b = bo.pedersen_prove(sk, h, ad)
+        assert g2 == gamma and bo.pedersen_verify(h, gamma, ad, proof)
+        # the commitment with the Edwards oracle's arithmetic and THIS suite's blinding factor
+        te_com = vo.te_add(TE, vo.te_mul(TE, sk, (TE.gx, TE.gy)), vo.te_mul(TE, b, (TE.bx, TE.by)))
+        assert vo.te_to_sw(TE, te_com) == proof[0]
+        bad = (proof[0], proof[1], proof[2], proof[3], (proof[4] + 1) % R)
+        assert not bo.pedersen_verify(h, gamma, ad, bad)
+        assert len(bo.output_hash(gamma)) == 64
+
+
+# ------------------------------------------------------------------------------------------------------ GPU tier
+@pytest.fixture(scope="module")
+def gpu():
+    from ark_ec_vrfs_amd import BandersnatchSwSha512Tai, Context
+    ctx = Context(0, BandersnatchSwSha512Tai, test_blinding_base=True)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_descriptor_keys_and_hash_to_curve(gpu):
+    from ark_ec_vrfs_amd import BandersnatchSwSha512Tai, Context, SuiteDesc
+    assert gpu.point_bytes() == 33 and gpu.hash_bytes() == 64
+    d = gpu.desc()
+    assert d.curve == 6 and d.suite_id == bo.SUITE_ID and d.challenge_len == 32 and d.flags == 0
+    assert d.generator == xy(bo.G) and d.blinding_base == xy(bo.BLINDING_BASE)
+    plain = Context(0, BandersnatchSwSha512Tai)                       # the built-in descriptor: no blinding base, no Pedersen scheme
+    assert plain.desc().blinding_base == bytes(64) and plain.desc().generator == xy(bo.G)
+    sk0 = np.zeros((1, 32), np.uint8); sk0[0, 0] = 3
+    with pytest.raises(Exception):
+        plain.pedersen_prove_batch(sk0, msgs=[b"m"], ad=b"")
+    assert plain.ietf_prove_batch(sk0, msgs=[b"m"], ad=b"")["pk"][0].tobytes() == bo.point_encode(bo.mul(3, bo.G))
+    plain.close()
+    bad = SuiteDesc.with_test_blinding_base(BandersnatchSwSha512Tai)
+    bad.generator = xy((bo.G[0], (bo.G[1] + 1) % Q))
+    with pytest.raises(Exception):
+        Context(0, desc=bad)
+    n = 200
+    seeds = _u8(b"seed-%05d" % i + bytes(i % 7) + bytes(22 - i % 7) for i in range(n))
+    sk, pk = gpu.secret_from_seed_batch(seeds)
+    for i in range(0, n, 9):
+        k = bo.secret_from_seed(seeds[i].tobytes())
+        assert sk[i].tobytes() == le(k) and pk[i].tobytes() == bo.point_encode(bo.mul(k, bo.G))
+    msgs = [b"m%d" % i * (i % 6) for i in range(n)]
+    hs = gpu.hash_to_curve_batch(msgs)
+    for i in range(n):
+        assert hs[i].tobytes() == bo.point_encode(bo.hash_to_curve_tai(msgs[i])), i
+    fixed = np.frombuffer(b"".join(b"%032d" % i for i in range(64)), np.uint8).reshape(64, 32)
+    hf = gpu.hash_to_curve_batch(fixed)
+    assert all(hf[i].tobytes() == bo.point_encode(bo.hash_to_curve_tai(fixed[i].tobytes())) for i in range(64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("given", [False, True])
+def test_gpu_prove_bytes_and_verify_statuses_equal_the_oracle(gpu, given):
+    n = 96
+    seeds = _u8(b"k%07d" % i for i in range(n))
+    sk, pk = gpu.secret_from_seed_batch(seeds)
+    msgs = [b"alpha %d" % i * (1 + i % 4) for i in range(n)]
+    ads = [b"ad" * (i % 5) for i in range(n)]
+    H = [bo.hash_to_curve_tai(m) for m in msgs]
+    if given:
+        r = gpu.ietf_prove_batch(sk, inputs=_u8(bo.point_encode(h) for h in H), ad=ads)
+    else:
+        r = gpu.ietf_prove_batch(sk, msgs=msgs, ad=ads)
+    assert (r["status"] == 0).all() and (r["pk"] == pk).all()
+    proofs = []
+    for i in range(n):
+        k = int.from_bytes(sk[i].tobytes(), "little")
+        gamma, c, s = bo.ietf_prove(k, H[i], ads[i])
+        proofs.append((gamma, c, s))
+        assert r["input"][i].tobytes() == bo.point_encode(H[i]) and r["output"][i].tobytes() == bo.point_encode(gamma), i
+        assert r["c"][i].tobytes() == le(c) and r["s"][i].tobytes() == le(s), i
+    assert (gpu.ietf_verify_batch(pk, r["input"], r["output"], r["c"], r["s"], ad=ads) == 0).all()
+    beta = gpu.output_hash_batch(r["output"])
+    assert all(beta[i].tobytes() == bo.output_hash(proofs[i][0]) for i in range(n))
+    # every kind of defect; the oracle decides
+    pkt, ht, gt, ct, st_ = (x.copy() for x in (pk, r["input"], r["output"], r["c"], r["s"]))
+    t2 = _torsion2()
+    offx = next(x for x in range(2, 100) if vo.legendre((x ** 3 + bo.A * x + bo.B) % Q, Q) == -1)
+    for i in range(n):
+        kind = i % 16
+        if kind == 1: st_[i, 3] ^= 1
+        elif kind == 2: ct[i, 30] ^= 1
+        elif kind == 3: gt[i] = r["output"][(i + 1) % n]
+        elif kind == 4: pkt[i] = np.frombuffer(le(offx) + b"\x00", np.uint8)                    # not on the curve
+        elif kind == 5: ht[i, 32] |= 0xC0                                                        # both flags
+        elif kind == 6: ct[i] = np.frombuffer(le(proofs[i][1] + R), np.uint8)                   # c + r: the same scalar mod r
+        elif kind == 7: gt[i] = np.frombuffer(le(Q + 5) + b"\x00", np.uint8)                    # x >= q
+        elif kind == 8: st_[i] = np.frombuffer(le(proofs[i][2] + R), np.uint8)                  # s not canonical
+        elif kind == 9: pkt[i, 32] |= 0x15                                                       # junk in the flag byte's low bits: ignored
+        elif kind == 10: gt[i] = np.frombuffer(bo.point_encode(bo.add(proofs[i][0], t2[i % 3])), np.uint8)    # + a point of order 2
+        elif kind == 11: pkt[i] = np.frombuffer(le(t2[i % 3][0]) + b"\x00", np.uint8)           # a point of order 2 itself
+        elif kind == 12: ht[i] = np.frombuffer(le(77) + b"\x40", np.uint8)                      # infinity (x not looked at)
+        elif kind == 13: gt[i, 32] ^= 0x80                                                       # -Gamma
+        elif kind == 14: pkt[i] = np.frombuffer(bytes(32) + b"\x40", np.uint8)                  # pk = infinity
+    want = np.array([bo.ietf_verify_bytes(pkt[i].tobytes(), ht[i].tobytes(), gt[i].tobytes(), ads[i], ct[i].tobytes(),
+                                          st_[i].tobytes()) for i in range(n)], np.uint8)
+    got = gpu.ietf_verify_batch(pkt, ht, gt, ct, st_, ad=ads)
+    assert (got == want).all(), (got, want)
+    assert set(want) == {0, 1, 2} and want[9] == 0 and want[6] == 0 and want[10] == 2 and want[12] in (1, 2)
+    # verification from alpha
+    assert (gpu.ietf_verify_batch_alpha(pk, msgs, r["output"], r["c"], r["s"], ad=ads) == 0).all()
+    got = gpu.ietf_verify_batch_alpha(pkt, msgs, gt, ct, st_, ad=ads)
+    want_a = np.array([bo.ietf_verify_bytes(pkt[i].tobytes(), r["input"][i].tobytes(), gt[i].tobytes(), ads[i], ct[i].tobytes(),
+                                            st_[i].tobytes()) for i in range(n)], np.uint8)
+    assert (got == want_a).all()
+    # point validation, x || y out
+    pts = _u8([bo.point_encode(bo.mul(7, bo.G)), le(offx) + b"\x00", bytes(32) + b"\x40", bo.point_encode(bo.add(bo.G, t2[0])),
+               le(bo.G[0]) + b"\xc0", bo.point_encode(bo.neg(bo.G))])
+    stv, xyv = gpu.point_validate_batch(pts, want_xy=True)
+    assert list(stv) == [0, 2, 0, 2, 2, 0]
+    assert xyv[0].tobytes() == xy(bo.mul(7, bo.G)) and xyv[5].tobytes() == xy(bo.neg(bo.G)) and xyv[2].tobytes() == bytes(64)
+
+
+@pytest.mark.gpu
+def test_gpu_pedersen_equals_the_oracle(gpu):
+    n = 64
+    seeds = _u8(b"p%07d" % i for i in range(n))
+    sk, _ = gpu.secret_from_seed_batch(seeds)
+    msgs = [b"in %d" % i for i in range(n)]
+    ads = [b"x" * (i % 3) for i in range(n)]
+    r = gpu.pedersen_prove_batch(sk, msgs=msgs, ad=ads)
+    assert (r["status"] == 0).all()
+    for i in range(n):
+        k = int.from_bytes(sk[i].tobytes(), "little")
+        h = bo.hash_to_curve_tai(msgs[i])
+        gamma, (pk_com, rr, ok, s, sb), b = bo.pedersen_prove(k, h, ads[i])
+        for key, val in (("input", h), ("output", gamma), ("pk_com", pk_com), ("r", rr), ("ok", ok)):
+            assert r[key][i].tobytes() == bo.point_encode(val), (i, key)
+        assert r["s"][i].tobytes() == le(s) and r["sb"][i].tobytes() == le(sb) and r["blinding"][i].tobytes() == le(b)
+    args = [r[k_] for k_ in ("input", "output", "pk_com", "r", "ok", "s", "sb")]
+    assert (gpu.pedersen_verify_batch(*args, ad=ads) == 0).all()
+    t = [a.copy() for a in args]
+    t2 = _torsion2()
+    for i in range(n):
+        kind = i % 8
+        if kind == 1: t[5][i, 0] ^= 1
+        elif kind == 2: t[6][i, 0] ^= 1
+        elif kind == 3: t[2][i] = args[2][(i + 1) % n]
+        elif kind == 4: t[3][i, 32] |= 0xC0
+        elif kind == 5: t[4][i] = np.frombuffer(bo.point_encode(bo.add(bo.point_decode(args[4][i].tobytes())[1], t2[0])), np.uint8)
+        elif kind == 6: t[6][i] = np.frombuffer(le(int.from_bytes(args[6][i].tobytes(), "little") + R), np.uint8)
+        elif kind == 7: t[1][i, 32] |= 0x03
+    want = np.array([bo.pedersen_verify_bytes(*(t[j][i].tobytes() for j in range(7)), ads[i]) for i in range(n)], np.uint8)
+    got = gpu.pedersen_verify_batch(*t, ad=ads)
+    assert (got == want).all() and set(want) == {0, 1, 2}, (got, want)
+    with pytest.raises(Exception):
+        gpu.pedersen_verify_batch_rlc(*args, ad=ads)                 # the batched verifier is not built for this suite
+
+
+@pytest.mark.gpu
+def test_gpu_consistency_with_the_edwards_suite_at_scale(gpu):
+    """2^13 proofs: every Gamma / pk of this suite is the te_sw_map image of what the device's own (vector-pinned)
+    twisted-Edwards suite computes from the same secret and the mapped input point; everything verifies; a tampered stripe
+    does not."""
+    from ark_ec_vrfs_amd import BandersnatchSha512Ell2, Context
+    n = 1 << 13
+    rng = np.random.default_rng(11)
+    seeds = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    sk, pk = gpu.secret_from_seed_batch(seeds)
+    msgs = rng.integers(0, 256, (n, 24), dtype=np.uint8)
+    r = gpu.ietf_prove_batch(sk, msgs=msgs, ad=b"scale")
+    assert (r["status"] == 0).all() and (r["pk"] == pk).all()
+    assert (gpu.ietf_verify_batch(pk, r["input"], r["output"], r["c"], r["s"], ad=b"scale") == 0).all()
+    assert (gpu.ietf_verify_batch_alpha(pk, msgs, r["output"], r["c"], r["s"], ad=b"scale") == 0).all()
+    s2 = r["s"].copy(); s2[::5, 1] ^= 4
+    st = gpu.ietf_verify_batch(pk, r["input"], r["output"], r["c"], s2, ad=b"scale")
+    assert (st[::5] != 0).all() and (np.delete(st, np.arange(0, n, 5)) == 0).all()
+    # the Weierstrass coordinates of H, Gamma, pk -> Edwards coordinates -> the Edwards suite's compressed form
+    te = Context(0, BandersnatchSha512Ell2)
+    def sw_xy(enc):
+        stv, xyv = gpu.point_validate_batch(enc, want_xy=True)
+        assert (stv == 0).all()
+        return xyv
+    def te_enc(xy_te):
+        out = xy_te[:, 32:].copy()
+        x = xy_te[:, :32]
+        # arkworks' flag: x > q - x  <=>  x > (q - 1) / 2, compared as big-endian byte strings
+        half = np.frombuffer(((Q - 1) // 2).to_bytes(32, "big"), np.uint8)
+        xb = x[:, ::-1]
+        diff = xb.astype(np.int16) - half.astype(np.int16)
+        first = np.argmax(diff != 0, axis=1)
+        gt = diff[np.arange(len(x)), first] > 0
+        out[gt, 31] |= 0x80
+        return out
+    h_te, st_h = te.te_sw_map_batch(sw_xy(r["input"]), to_te=True)
+    g_te, st_g = te.te_sw_map_batch(sw_xy(r["output"]), to_te=True)
+    p_te, st_p = te.te_sw_map_batch(sw_xy(pk), to_te=True)
+    assert (st_h == 0).all() and (st_g == 0).all() and (st_p == 0).all()
+    rt = te.ietf_prove_batch(sk, inputs=te_enc(h_te), ad=b"scale")
+    assert (rt["status"] == 0).all()
+    assert (rt["output"] == te_enc(g_te)).all() and (rt["pk"] == te_enc(p_te)).all()
+    te.close()
+
+
+@pytest.mark.gpu
+def test_gpu_multi_context_and_refused_entry_points(gpu):
+    from ark_ec_vrfs_amd import BandersnatchSwSha512Tai, Context, ietf_prove_batch_multi, ietf_verify_batch_multi
+    n = 700
+    seeds = _u8(b"m%07d" % i for i in range(n))
+    sk, pk = gpu.secret_from_seed_batch(seeds)
+    msgs = np.frombuffer(b"".join(b"%016d" % i for i in range(n)), np.uint8).reshape(n, 16)
+    r = gpu.ietf_prove_batch(sk, msgs=msgs, ad=b"")
+    c2 = Context(0, BandersnatchSwSha512Tai)
+    rm = ietf_prove_batch_multi([gpu, c2], sk, msgs=msgs, ad=b"")
+    assert all((rm[k] == r[k]).all() for k in ("output", "c", "s", "pk", "input"))
+    s2 = r["s"].copy(); s2[3::11, 0] ^= 1
+    st = gpu.ietf_verify_batch(pk, r["input"], r["output"], r["c"], s2, ad=b"")
+    stm = ietf_verify_batch_multi([gpu, c2], pk, r["input"], r["output"], r["c"], s2, ad=b"")
+    assert (stm == st).all() and (st[3::11] == 1).all() and st.sum() == len(st[3::11])
+    c2.close()
+    with pytest.raises(Exception):
+        gpu.msm(np.zeros((4, 64), np.uint8), np.zeros((4, 32), np.uint8))
+    with pytest.raises(Exception):
+        gpu.ietf_verify_batch_affine(np.zeros((2, 64), np.uint8), np.zeros((2, 64), np.uint8), np.zeros((2, 64), np.uint8),
+                                     np.zeros((2, 32), np.uint8), np.zeros((2, 32), np.uint8))
