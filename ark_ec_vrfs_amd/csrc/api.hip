@@ -80,7 +80,7 @@ int32_t fail(int32_t code, const std::string& msg) {
 constexpr size_t DEFAULT_CHUNK = size_t(1) << 20;
 const char BSW_UNSUPPORTED_MSG[] =
     "not available for the bandersnatch_sw suite (secret keys, hash-to-curve, output hash, point validation, the IETF scheme incl. "
-    "verification from alpha, and the Pedersen scheme per proof are)";
+    "verification from alpha, and the Pedersen scheme per proof and batched are; the x || y forms, key sets and MSM are not)";
 
 }  // namespace
 
@@ -1487,7 +1487,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
                      uint8_t* d_fail_flag, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the batched Pedersen verifier takes Sec1 points (the x || y form is not built)");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
+  if (ctx->bsw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!d_fail_flag || !seed) return fail(VRFHIP_ERR_BAD_ARG, "NULL fail flag or seed");
   if (n && (!d_input || !d_output || !d_pk_com || !d_r || !d_ok || !d_s || !d_sb || !d_status))
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
@@ -1557,7 +1557,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
     a.k_lane = lanes_k(m, VERIFY_K_POLICY);
     a.n = m;
     a.index0 = base;
-    const size_t pw = affine ? 64 : 32;
+    const size_t pw = affine ? 64 : ctx->pt_bytes();
     a.h = d_input + base * pw; a.gamma = d_output + base * pw; a.pk_com = d_pk_com + base * pw;
     a.r = d_r + base * pw; a.ok = d_ok + base * pw; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
     a.affine_in = affine ? (ctx->coords_mont256() ? 2 : 1) : 0;
@@ -1578,7 +1578,8 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
     ds.ad = a.ad;
     launch_batch_digest(ds, m, base, d_digest_ws, d_root, st);
     a.root = d_root;
-    FIELD_CALL(ctx, launch_pedersen_rlc(a, d_fail_flag, st, prof_events(ctx)));
+    if (ctx->bsw) launch_bsw_pedersen_rlc(a, d_fail_flag, st, prof_events(ctx));
+    else FIELD_CALL(ctx, launch_pedersen_rlc(a, d_fail_flag, st, prof_events(ctx)));
   }
   HIP_TRY(hipGetLastError());
   return VRFHIP_SUCCESS;
@@ -1591,7 +1592,7 @@ int32_t rlc_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* inp
                       const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the batched Pedersen verifier takes Sec1 points (the x || y form is not built)");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
+  if (ctx->bsw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!seed) return fail(VRFHIP_ERR_BAD_ARG, "seed is NULL");
   if (batch_ok) *batch_ok = 1;
   if (n == 0) return VRFHIP_SUCCESS;

@@ -1,7 +1,7 @@
 // bsw.h -- launch interface of `suites::bandersnatch_sw` (/root/reference src/lib.rs:14) between the C ABI (api.hip) and
 // k_bsw.hip.  The suite runs on a Bandersnatch (base field 0) context: same tables, same workspace, same launch arguments
 // (vrf_types.h) as the twisted-Edwards suite, with 33-byte compressed short-Weierstrass points in every point array
-// (bsw_core.cuh).  Not built for this suite: x || y inputs / outputs of the schemes, key sets, MSM, the batched Pedersen verifier.
+// (bsw_core.cuh).  Not built for this suite: x || y inputs / outputs of the schemes, key sets, MSM over caller-supplied bases.
 #pragma once
 #include "kernels.h"
 
@@ -20,5 +20,7 @@ void launch_bsw_prove(const ProveArgs& a, hipStream_t st, hipEvent_t* ev = nullp
 // a.affine_in, a.h_in_tabs, a.key_index must be 0 / NULL; a.k_lane is not read
 void launch_bsw_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
 void launch_bsw_pedersen_verify(const PedersenVerifyArgs& a, hipStream_t st, hipEvent_t* ev = nullptr);
+// the batched Pedersen verifier (launch_pedersen_rlc's contract, msm.cuh layout); a.affine_in must be 0
+void launch_bsw_pedersen_rlc(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev = nullptr);
 
 VRF_NS_END

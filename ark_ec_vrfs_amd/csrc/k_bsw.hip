@@ -6,6 +6,7 @@
 // k_pedersen.hip give it, and the launch arguments are theirs (vrf_types.h), with 33-byte point rows.
 #include "bsw.h"
 #include "bsw_core.cuh"
+#include "msm.cuh"
 #include "tai_find.cuh"
 
 VRF_NS_BEGIN
@@ -322,6 +323,95 @@ __global__ void __launch_bounds__(BLOCK) k_bsw_ped_verify_finish(PedersenVerifyA
   a.status[i] = (uint8_t)pedersen_verify_finish_item<BswS>(a.ws.pts + i * PROVE_PTS_WORDS, s, sb, a.ws.flags[i] != 0);
 }
 
+// ---- batched Pedersen verification (random linear combination, k_rlc.hip's scheme): the decode stage for this codec ----
+// One lane per proof: five decodes into the MSM layout (Montgomery affine-cached Edwards points), the challenge over the
+// canonical 33-byte encodings, weights, scalars and window digits; the two fixed-base scalars as 64-bit limb columns.  The
+// weights are k_rlc.hip's (rlc_weights: seed, digest of the launch group's wire bytes, index).
+__global__ void __launch_bounds__(BLOCK, 2) k_bsw_rlc_decode(RlcArgs a) {
+  const size_t item = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  const size_t n = a.n, N = a.L.n;
+  uint64_t cols[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) cols[j] = 0;
+  if (item < n) {
+    Enc33 enc[5];
+    bool valid = true;
+#pragma unroll 1
+    for (int p = 0; p < 5; ++p) {
+      const Enc33 e = load33(p == 0 ? a.h : p == 1 ? a.gamma : p == 2 ? a.pk_com : p == 3 ? a.r : a.ok, item);
+      PtA pa;
+      bool ok = bsw_decode<BswS>(pa.x, pa.y, e, a.T.sq);
+      if (a.check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF)) ok = in_prime_subgroup<BswS>(pa.x, pa.y, a.T.sq) && ok;
+      valid = valid && ok;
+      pa.dt = fe_mul(fe_mul(pa.x, pa.y), BswS::d());
+      pta_store(a.L.pts + rlc_index(p, n, item) * MSM_PTA_STRIDE, pa);
+      const Enc33 ce = enc33_canonical(e);
+#pragma unroll
+      for (int q = 0; q < 5; ++q)
+        if (q == p) enc[q] = ce;
+    }
+    uint32_t s[8], sb[8];
+    load32(s, a.s, item); load32(sb, a.sb, item);
+    valid = valid && fr_is_canonical<BswS>(s) && fr_is_canonical<BswS>(sb);
+    if (!valid) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] = 0; sb[j] = 0; }
+    }
+    const uint8_t* adp; uint32_t adl;
+    bytes_get(a.ad, item, adp, adl);
+    const Enc33 cp[5] = {enc[2], enc[0], enc[1], enc[3], enc[4]};      // pk_com, H, Gamma, R, Ok
+    uint32_t c[8], z[8], zp[8], t[8];
+    bsw_challenge5(c, cp, adp, adl, a.T.sq.str);
+    rlc_weights<BswS>(z, zp, a.seed, a.root, a.index0 + item);
+    fr_mul<BswS>(t, z, s);
+    msm_write_digits<BswS>(a.L.digits, N, rlc_index(0, n, item), t, false, !valid);     // + (z s) H
+    fr_mul<BswS>(t, z, c);
+    msm_write_digits<BswS>(a.L.digits, N, rlc_index(1, n, item), t, true, !valid);      // - (z c) Gamma
+    fr_mul<BswS>(t, zp, c);
+    msm_write_digits<BswS>(a.L.digits, N, rlc_index(2, n, item), t, true, !valid);      // - (z' c) pk_com
+    msm_write_digits<BswS>(a.L.digits, N, rlc_index(3, n, item), zp, true, !valid);     // - z' R   (128 bits)
+    msm_write_digits<BswS>(a.L.digits, N, rlc_index(4, n, item), z, true, !valid);      // - z Ok   (128 bits)
+    fr_mul<BswS>(t, zp, s);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cols[j] += t[j];
+    fr_mul<BswS>(t, zp, sb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cols[8 + j] += t[j];
+    a.status[item] = (uint8_t)(valid ? ST_OK : ST_INVALID_DATA);
+  }
+  // wave reduction of the fixed-base limb columns, one atomic per column and wave
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    uint64_t v = cols[j];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_down(v, sft, 64);
+    if ((threadIdx.x & 63) == 0 && v != 0)
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.fixed_cols) + j, (unsigned long long)v);
+  }
+}
+// one lane: columns -> scalars mod r; G and B (entry 1 * 256^0 of the fixed-base combs) become points 3n, 3n + 1
+__global__ void k_bsw_rlc_fixed(RlcArgs a) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const size_t N = a.L.n;
+#pragma unroll 1
+  for (int f = 0; f < 2; ++f) {
+    uint32_t wide[16];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      uint64_t acc = (j < 8 ? a.fixed_cols[f * 8 + j] : 0) + carry;   // columns < 2^52, carry < 2^32
+      wide[j] = (uint32_t)acc;
+      carry = acc >> 32;
+    }
+    uint32_t k[8];
+    fr_reduce512<BswS>(k, wide);
+    const uint32_t* src = f == 0 ? a.T.g_comb : a.T.b_comb;
+    uint32_t* dst = a.L.pts + (3 * a.n + f) * MSM_PTA_STRIDE;
+    for (int j = 0; j < PTA_WORDS; ++j) dst[j] = src[j];
+    msm_write_digits<BswS>(a.L.digits, N, 3 * a.n + f, k, false, false);
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------- launchers
@@ -378,6 +468,18 @@ void launch_bsw_pedersen_verify(const PedersenVerifyArgs& a, hipStream_t st, hip
   if (ev) (void)hipEventRecord(ev[3], st);
   hipLaunchKernelGGL(k_bsw_ped_verify_finish, grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[4], st);
+}
+// enqueues decode + MSM (k_msm.hip's bucket and final kernels); fail_flag[0] becomes 1 if the batch equation does not hold.
+// a.affine_in must be 0; a.k_lane and a.scratch are not read.  ev (nullable, 5 events): start | decode | buckets | final | final
+void launch_bsw_pedersen_rlc(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev) {
+  if (a.n == 0) return;
+  (void)hipMemsetAsync(a.L.flags, 0, 256, st);
+  (void)hipMemsetAsync(a.fixed_cols, 0, 16 * sizeof(uint64_t), st);
+  if (ev) (void)hipEventRecord(ev[0], st);
+  hipLaunchKernelGGL(k_bsw_rlc_decode, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  hipLaunchKernelGGL(k_bsw_rlc_fixed, dim3(1), dim3(64), 0, st, a);
+  if (ev) (void)hipEventRecord(ev[1], st);
+  launch_msm_core(SUITE_BS, a.L, nullptr, nullptr, nullptr, fail_flag, st, ev ? ev + 2 : nullptr);
 }
 
 VRF_NS_END

@@ -346,9 +346,10 @@ def cpu_cores():
     return min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0)))
 
 
-def cpu_leg(fn, probe, budget_s, cap, unit, what, src="oracle/c/oracle_vrf.c"):
+def cpu_leg(fn, probe, budget_s, cap, unit, what, src="oracle/c/oracle_vrf.c", cores=None):
     """fn(m) runs the oracle on the first m items.  Probe, then one bounded run of about budget_s seconds."""
-    cores = cpu_cores()
+    python_port = cores is not None                 # a single-threaded pure-Python oracle (named in src)
+    cores = cores or cpu_cores()
     t0 = time.perf_counter()
     fn(probe)
     rate = probe / (time.perf_counter() - t0)
@@ -358,7 +359,8 @@ def cpu_leg(fn, probe, budget_s, cap, unit, what, src="oracle/c/oracle_vrf.c"):
     dt = time.perf_counter() - t0
     return {"value": m / dt, "unit": unit, "cores": cores, "kind": "port",
             "sample": "first %d items of the same batch, %.1f s wall on %d threads; %s" % (m, dt, cores, what),
-            "note": "CPU restatement in C (%s), not arkworks: no Rust toolchain on this box" % src}
+            "note": ("CPU restatement (%s), not arkworks: no Rust toolchain on this box" if python_port else
+                     "CPU restatement in C (%s), not arkworks: no Rust toolchain on this box") % src}
 
 
 BLS_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
@@ -584,6 +586,7 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
         st = torch.empty(n, dtype=torch.uint8, device=D.dev)
         lg = args.log2_batch
         sw = tag == "secp256r1"
+        bsw = tag == "bandersnatch_sw"           # the Edwards arithmetic behind arkworks' 33-byte short-Weierstrass codec
         b_prove, b_verify = B_PROVE + (pw - 32), B_VERIFY + 3 * (pw - 32)      # one / three points of pw bytes instead of 32
         fn = lambda: cx.ietf_prove_batch_dev(sk, msg, 32, g, c, s_, pk, hh, st)
         fn(); torch.cuda.synchronize()
@@ -593,6 +596,7 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
         ms, groups = stage_avg(cx)
         assert int(st.sum()) == 0
         rf, v = roofline("k_p256_prove_mul (sk*G, sk*H, k*G, k*H: 4 lanes per proof, grid.y = 4)" if sw else
+                         "k_prove_mul (sk*H, sk*G, k*H, k*G: 2 lanes per proof; the twisted-Edwards suite's kernel)" if bsw else
                          "k_prove_mul (sk*H, sk*G, k*H, k*G: 2 lanes per proof)", b_prove, n, ms[1], groups, pmc_for("ietf_prove_" + tag, lg))
         res["ietf_prove_" + tag] = {
             "workload": "IETF ECVRF prove, %s, batch 2^%d per GPU (SURVEY.md section 8 f4)" % (title, lg),
@@ -609,6 +613,9 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
         heavy = max(range(4), key=lambda k: ms[k])
         kname = ("k_verify_decode (3 decompressions + subgroup tests + tables)", "k_verify_straus<1> (V = s*H - c*Gamma)",
                  "k_verify_straus<0> (U = s*G - c*Y)", "k_verify_finish")[heavy]
+        if bsw:
+            kname = ("k_bsw_verify_decode (3 decompressions + te_sw_map + subgroup tests + tables)", "k_bsw_verify_straus<1> (V = s*H - c*Gamma)",
+                     "k_bsw_verify_straus<0> (U = s*G - c*Y)", "k_bsw_verify_finish")[heavy]
         if sw:
             kname = ("k_p256_verify_decode", "k_p256_verify_mul<1> (V = s*H - c*Gamma)", "k_p256_verify_mul<0> (U = s*G - c*Y)",
                      "k_p256_verify_finish")[heavy]
@@ -645,7 +652,8 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
             assert int(st.sum()) == 0
             res["ietf_verify_" + tag]["affine_inputs"] = {"value": D.world * n * max(2, args.config_steps) / el_xy, "unit": "verifies/s",
                                                           "ms_per_step": el_xy / max(2, args.config_steps) * 1e3}
-            # the Pedersen scheme on this suite (built-in nothing-up-my-sleeve blinding base), per proof
+        if sw or bsw:
+            # the Pedersen scheme on this suite (placeholder blinding base), per proof
             pc, rr, okp, sbb = mkp(), mkp(), mkp(), mk()
             fn = lambda: cx.pedersen_prove_batch_dev(sk, msg, 32, g, pc, rr, okp, s_, sbb, None, hh, st)
             fn(); torch.cuda.synchronize()
@@ -666,10 +674,11 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
             ms, groups = stage_avg(cx)
             assert int(st.sum()) == 0
             res["pedersen_verify_" + tag] = {
-                "workload": "Pedersen VRF verify, %s, batch 2^%d per GPU, per proof, Sec1 wire format; non-upstream blinding base" % (title, lg),
+                "workload": "Pedersen VRF verify, %s, batch 2^%d per GPU, per proof, %d-byte points; non-upstream blinding base" % (title, lg, pw),
                 "value": D.world * n * args.config_steps / el, "unit": "verifies/s", "ms_per_step": el / args.config_steps * 1e3,
                 "stage_ms_per_step": {"decode": ms[0], "eq_h": ms[1], "eq_g": ms[2], "finish": ms[3]}}
-            # ... and the whole batch through ONE MSM over 5 n + 2 points (k_p256_msm.hip)
+        if sw or bsw:
+            # ... and the whole batch through ONE MSM over 5 n + 2 points (k_p256_msm.hip; bandersnatch_sw: k_msm.hip behind k_bsw_rlc_decode)
             flag = torch.empty(1, dtype=torch.uint8, device=D.dev)
             seed = os.urandom(32)
             fn = lambda: cx.pedersen_verify_batch_rlc_dev(hh, g, pc, rr, okp, s_, sbb, st, flag, seed)
@@ -684,9 +693,33 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
                 "value": D.world * n * args.config_steps / el, "unit": "verifies/s", "ms_per_step": el / args.config_steps * 1e3,
                 "stage_ms_per_step": {"decode": ms[0], "msm_buckets": ms[1], "msm_final": ms[2] + ms[3]},
                 "note": "non-upstream blinding base (vrfhip_test_blinding_base)"}
+        if sw or bsw:
             fn = lambda: cx.ietf_prove_batch_dev(sk, msg, 32, g, c, s_, pk, hh, st)        # the IETF proofs back for the CPU leg
             fn(); torch.cuda.synchronize()
-        if want_cpu:
+        if want_cpu and bsw:
+            # the only CPU restatement of this suite is the pure-Python oracle (oracle/bsw_oracle.py): a parity check and a
+            # scalar-interpreter rate, on a sample sized for it
+            from oracle import bsw_oracle as bo
+            cap = 256
+            host = lambda t: t[:cap].cpu().numpy()
+            skh, msgh, gh, ch, sh, pkh, hhh = (host(t) for t in (sk, msg, g, c, s_, pk, hh))
+
+            def leg_p(k):
+                for i in range(k):
+                    h = bo.hash_to_curve_tai(msgh[i].tobytes())
+                    gamma, cc, ss = bo.ietf_prove(int.from_bytes(skh[i].tobytes(), "little"), h, b"")
+                    assert bo.point_encode(gamma) == gh[i].tobytes() and cc.to_bytes(32, "little") == ch[i].tobytes() and \
+                        ss.to_bytes(32, "little") == sh[i].tobytes(), "GPU proofs differ from the CPU oracle on the sample"
+            res["ietf_prove_" + tag]["cpu_baseline"] = cpu_leg(leg_p, 32, args.cpu_seconds / 4, cap, "proofs/s",
+                                                               "proof bytes equal the GPU's", "oracle/bsw_oracle.py (pure Python)", cores=1)
+
+            def leg_v(k):
+                for i in range(k):
+                    assert bo.ietf_verify_bytes(pkh[i].tobytes(), hhh[i].tobytes(), gh[i].tobytes(), b"", ch[i].tobytes(),
+                                                sh[i].tobytes()) == 0, "CPU oracle rejects GPU-made proofs"
+            res["ietf_verify_" + tag]["cpu_baseline"] = cpu_leg(leg_v, 32, args.cpu_seconds / 4, cap, "verifies/s",
+                                                                "statuses equal the GPU's", "oracle/bsw_oracle.py (pure Python)", cores=1)
+        elif want_cpu:
             from oracle import c_oracle as co
             cap = 1 << 15
             host = lambda t: t[:cap].cpu().numpy()
@@ -998,7 +1031,7 @@ def run_rank(args):
     want_cpu = (not args.no_cpu_baseline) and world == 1
     configs = {}
     if not args.no_configs:
-        from ark_ec_vrfs_amd import BabyJubJubSha512Tai, Ed25519Sha512Tai, Secp256r1Sha256Tai
+        from ark_ec_vrfs_amd import BabyJubJubSha512Tai, BandersnatchSwSha512Tai, Ed25519Sha512Tai, Secp256r1Sha256Tai
         legs = (("ietf_prove", lambda: {"ietf_prove": cfg_ietf_prove(D, args, ctx, sk, msg, want_cpu and rank == 0)}),
                 ("shard_sizes", lambda: cfg_shard_sizes(D, args, ctx, pk, hh, gamma, c, s)),
                 ("from_alpha", lambda: cfg_from_alpha(D, args, ctx, lib, pk, msg, hh, gamma, c, s)),
@@ -1010,6 +1043,8 @@ def run_rank(args):
                                                       want_cpu and rank == 0)),
                 ("secp256r1", lambda: cfg_suite_ietf(D, args, "secp256r1", Secp256r1Sha256Tai, 5, "P256_SHA256_TAI (RFC 9381 suite 0x01)", lo,
                                                      want_cpu and rank == 0)),
+                ("bandersnatch_sw", lambda: cfg_suite_ietf(D, args, "bandersnatch_sw", BandersnatchSwSha512Tai, 1,
+                                                           "Bandersnatch_SW_SHA-512_TAI (33-byte arkworks SW points)", lo, want_cpu and rank == 0)),
                 ("pairing", lambda: cfg_pairing(D, args, ctx, want_cpu and rank == 0)))
         only = [x for x in args.only.split(",") if x]
         D.local_legs = world > 1

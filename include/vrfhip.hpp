@@ -19,7 +19,8 @@
 //   pedersen::Verifier::verify(input, output, ad, &p)      pedersen::verify(ctx, input, output, ad, p) -> Result
 //   utils::te_sw_map::{te_to_sw, sw_to_te}(point)          utils::te_to_sw(ctx, points) / utils::sw_to_te(ctx, points)
 //   Error::{VerificationFailure, InvalidData}              enum class Error; Result = std::optional<Error> (nullopt = Ok(()))
-// Suites: the four twisted-Edwards ones (32-byte ArkworksCodec points, SHA-512) and `suites::secp256r1` (33-byte Sec1
+// Suites: the four twisted-Edwards ones (32-byte ArkworksCodec points, SHA-512), `suites::bandersnatch_sw` (33-byte
+// ArkworksCodec short-Weierstrass points) and `suites::secp256r1` (33-byte Sec1
 // points, big-endian scalars, SHA-256) through the same templates: Point<S> / Hash<S> carry the widths.
 // Several GPUs from one process: ietf::verify_batch_sharded over one Context per device (contiguous slices, one
 // host thread per context, no exchange) -- the single-process form of `bench.py --gpus N`.
@@ -86,6 +87,15 @@ struct Secp256r1Sha256Tai {
   static constexpr vrfhip_suite ID = VRFHIP_SUITE_SECP256R1_SHA256_TAI;
   static constexpr const char* SUITE_ID = "\x01";
   static constexpr size_t POINT_LEN = 33, HASH_LEN = 32;
+  static constexpr bool EDWARDS = false;
+};
+// `suites::bandersnatch_sw` (upstream "Bandersnatch_SW_SHA-512_TAI"): the Bandersnatch group on its short-Weierstrass model;
+// ArkworksCodec over SWAffine -- 33-byte compressed points (x little-endian, then a flag byte), little-endian scalars, SHA-512.
+// No key sets and no x || y forms on this suite (include/vrfhip.h).
+struct BandersnatchSwSha512Tai {
+  static constexpr vrfhip_suite ID = VRFHIP_SUITE_BANDERSNATCH_SW_SHA512_TAI;
+  static constexpr const char* SUITE_ID = "Bandersnatch_SW_SHA-512_TAI";
+  static constexpr size_t POINT_LEN = 33, HASH_LEN = 64;
   static constexpr bool EDWARDS = false;
 };
 template <class S> using Point = std::array<uint8_t, S::POINT_LEN>;     // an encoded point of suite S

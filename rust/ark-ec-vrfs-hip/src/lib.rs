@@ -679,3 +679,128 @@ impl Drop for GpuBatchSec1 {
         }
     }
 }
+
+/// `suites::bandersnatch_sw` ("Bandersnatch_SW_SHA-512_TAI"): Bandersnatch on its short-Weierstrass model, ArkworksCodec over
+/// `SWAffine` -- 33-byte compressed points.  libvrfhip runs the group law on the twisted-Edwards model and crosses
+/// `utils::te_sw_map` at the codec (csrc/bsw_core.cuh), so this suite has the twisted-Edwards suite's speed; it has no x || y
+/// forms, which is why it does not go through `GpuBatch<S>`: points travel as `codec::point_encode` strings both ways (an
+/// output costs the caller one `codec::point_decode`).  The suite's constants -- suite string, generator, blinding base --
+/// are taken from the `Suite` impl through the descriptor, as for every suite.
+pub struct GpuBatchSw {
+    ctxs: Vec<*mut ffi::vrfhip_ctx>,
+}
+
+unsafe impl Send for GpuBatchSw {}
+unsafe impl Sync for GpuBatchSw {}
+
+type BSw = suites::bandersnatch_sw::BandersnatchSha512Tai;
+const SWPT: usize = 33;
+
+impl GpuBatchSw {
+    pub fn new(devices: &[i32]) -> Result<Self, GpuError> {
+        let mut desc = ffi::vrfhip_suite_desc {
+            struct_size: core::mem::size_of::<ffi::vrfhip_suite_desc>() as u32,
+            curve: ffi::VRFHIP_CURVE_BANDERSNATCH_SW,
+            suite_id_len: BSw::SUITE_ID.len() as u32,
+            suite_id: [0u8; 64],
+            h2c_dst_len: 0,
+            h2c_dst: [0u8; 128],
+            generator: [0u8; 64],
+            blinding_base: [0u8; 64],
+            challenge_len: BSw::CHALLENGE_LEN as u32,
+            flags: 0,
+        };
+        desc.suite_id[..BSw::SUITE_ID.len()].copy_from_slice(BSw::SUITE_ID);
+        affine_xy::<BSw>(&BSw::generator(), &mut desc.generator); // the Weierstrass coordinates
+        affine_xy::<BSw>(&<BSw as PedersenSuite>::BLINDING_BASE, &mut desc.blinding_base);
+        let mut this = GpuBatchSw { ctxs: Vec::new() };
+        for &dev in devices {
+            let mut ctx: *mut ffi::vrfhip_ctx = core::ptr::null_mut();
+            check(unsafe { ffi::vrfhip_ctx_create_desc(&desc, dev, &mut ctx) })?;
+            debug_assert_eq!(unsafe { ffi::vrfhip_ctx_point_bytes(ctx) }, SWPT);
+            this.ctxs.push(ctx);
+        }
+        Ok(this)
+    }
+
+    fn put_point(p: &AffinePoint<BSw>, out: &mut [u8]) {
+        let mut v = Vec::with_capacity(SWPT);
+        codec::point_encode_into::<BSw>(p, &mut v);
+        out.copy_from_slice(&v);
+    }
+
+    /// `Secret::output` + `ietf::Prover::prove` per (secret, input) pair.
+    pub fn ietf_prove(
+        &self,
+        secrets: &[Secret<BSw>],
+        inputs: &[Input<BSw>],
+        ad: &[u8],
+    ) -> Result<Vec<Result<(Output<BSw>, ietf::Proof<BSw>), Error>>, GpuError> {
+        let n = secrets.len();
+        assert_eq!(n, inputs.len());
+        let (mut sk, mut h) = (vec![0u8; n * 32], vec![0u8; n * SWPT]);
+        for i in 0..n {
+            scalar32::<BSw>(&secrets[i].scalar, &mut sk[i * 32..(i + 1) * 32]);
+            Self::put_point(&inputs[i].0, &mut h[i * SWPT..(i + 1) * SWPT]);
+        }
+        let (mut gamma, mut c, mut s) = (vec![0u8; n * SWPT], vec![0u8; n * 32], vec![0u8; n * 32]);
+        let mut status = vec![0u8; n];
+        check(unsafe {
+            ffi::vrfhip_ietf_prove_batch_multi(
+                self.ctxs.as_ptr(), self.ctxs.len() as i32, n, sk.as_ptr(), core::ptr::null(), core::ptr::null(), 0,
+                h.as_ptr(), ad.as_ptr(), core::ptr::null(), ad.len() as u32, gamma.as_mut_ptr(), c.as_mut_ptr(),
+                s.as_mut_ptr(), core::ptr::null_mut(), core::ptr::null_mut(), status.as_mut_ptr(),
+            )
+        })?;
+        sk.iter_mut().for_each(|b| *b = 0);
+        Ok((0..n)
+            .map(|i| {
+                status_to_result(status[i])?;
+                let out = Output::<BSw>::from(codec::point_decode::<BSw>(&gamma[i * SWPT..(i + 1) * SWPT])?);
+                let proof = ietf::Proof::<BSw> {
+                    c: codec::scalar_decode::<BSw>(&c[i * 32..(i + 1) * 32]),
+                    s: codec::scalar_decode::<BSw>(&s[i * 32..(i + 1) * 32]),
+                };
+                Ok((out, proof))
+            })
+            .collect())
+    }
+
+    /// `ietf::Verifier::verify` per item.
+    pub fn ietf_verify(
+        &self,
+        publics: &[Public<BSw>],
+        inputs: &[Input<BSw>],
+        outputs: &[Output<BSw>],
+        ad: &[u8],
+        proofs: &[ietf::Proof<BSw>],
+    ) -> Result<Vec<Result<(), Error>>, GpuError> {
+        let n = publics.len();
+        assert!(n == inputs.len() && n == outputs.len() && n == proofs.len());
+        let (mut pk, mut h, mut g) = (vec![0u8; n * SWPT], vec![0u8; n * SWPT], vec![0u8; n * SWPT]);
+        let (mut c, mut s) = (vec![0u8; n * 32], vec![0u8; n * 32]);
+        for i in 0..n {
+            Self::put_point(&publics[i].0, &mut pk[i * SWPT..(i + 1) * SWPT]);
+            Self::put_point(&inputs[i].0, &mut h[i * SWPT..(i + 1) * SWPT]);
+            Self::put_point(&outputs[i].0, &mut g[i * SWPT..(i + 1) * SWPT]);
+            scalar32::<BSw>(&proofs[i].c, &mut c[i * 32..(i + 1) * 32]);
+            scalar32::<BSw>(&proofs[i].s, &mut s[i * 32..(i + 1) * 32]);
+        }
+        let mut status = vec![0u8; n];
+        check(unsafe {
+            ffi::vrfhip_ietf_verify_batch_multi(
+                self.ctxs.as_ptr(), self.ctxs.len() as i32, n, pk.as_ptr(), h.as_ptr(), g.as_ptr(), c.as_ptr(), s.as_ptr(),
+                ad.as_ptr(), core::ptr::null(), ad.len() as u32, status.as_mut_ptr(),
+            )
+        })?;
+        Ok(status.into_iter().map(status_to_result).collect())
+    }
+}
+
+impl Drop for GpuBatchSw {
+    fn drop(&mut self) {
+        for &c in &self.ctxs {
+            unsafe { ffi::vrfhip_ctx_destroy(c) };
+        }
+    }
+}

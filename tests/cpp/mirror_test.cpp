@@ -128,9 +128,66 @@ static int p256_section(char** a) {
   return 0;
 }
 
+// `suites::bandersnatch_sw` through the same templates: 33-byte arkworks short-Weierstrass points.  No vector of this suite
+// exists here (tests/test_bandersnatch_sw.py holds the library against its oracle); this is the API shape: round trips,
+// tampering, the batched paths.
+static int bsw_section() {
+  using W = BandersnatchSwSha512Tai;
+  Context<W> ctx(Context<W>::test_descriptor(), 0);
+  const size_t n = 300;
+  std::vector<Secret<W>> sks;
+  std::vector<Bytes> msgs;
+  for (size_t i = 0; i < n; ++i) {
+    Bytes sd(8);
+    for (int k = 0; k < 8; ++k) sd[k] = (uint8_t)(i >> (8 * k));
+    sks.push_back(Secret<W>::from_seed(ctx, sd));
+    msgs.push_back(Bytes(1 + i % 50, (uint8_t)(i * 5)));
+  }
+  CHECK(sks[0].pk.size() == 33 && (sks[0].pk[32] & 0x3f) == 0);
+  auto items = ietf::prove_batch(ctx, sks, msgs, Bytes{1, 2});
+  for (size_t i = 0; i < n; i += 37) {
+    const auto in_i = Input<W>::new_(ctx, msgs[i]);
+    CHECK(in_i->encoded == items[i].input.encoded && sks[i].pk == items[i].pub.encoded);
+    const auto out_i = sks[i].output(ctx, *in_i);
+    CHECK(out_i.encoded == items[i].output.encoded && out_i.hash(ctx).size() == 64);
+    const auto p_i = ietf::prove(ctx, sks[i], *in_i, out_i, Bytes{1, 2});
+    CHECK(p_i.c == items[i].proof.c && p_i.s == items[i].proof.s);
+    CHECK(!ietf::verify(ctx, sks[i].public_key(), *in_i, out_i, Bytes{1, 2}, p_i).has_value());
+  }
+  items[4].proof.c[0] ^= 1;
+  items[50].pub.encoded[32] = 0xC0;                      // both flags
+  items[51].output.encoded[32] |= 0x07;                  // junk below the flags: not looked at
+  items[200].output = items[201].output;
+  const auto res = ietf::verify_batch(ctx, items, Bytes{1, 2});
+  for (size_t i = 0; i < n; ++i) {
+    if (i == 4 || i == 200) CHECK(res[i] == Error::VerificationFailure);
+    else if (i == 50) CHECK(res[i] == Error::InvalidData);
+    else CHECK(!res[i].has_value());
+  }
+  const auto ares = ietf::verify_batch_from_alpha(ctx, items, msgs, Bytes{1, 2});
+  for (size_t i = 0; i < n; ++i) CHECK(ares[i] == res[i]);
+  std::vector<pedersen::Item<W>> pitems;
+  for (size_t i = 0; i < 48; ++i) {
+    const auto in_i = Input<W>::new_(ctx, msgs[i]);
+    const auto out_i = sks[i].output(ctx, *in_i);
+    pitems.push_back({*in_i, out_i, pedersen::prove(ctx, sks[i], *in_i, out_i, Bytes{9}).first});
+    CHECK(!pedersen::verify(ctx, *in_i, out_i, Bytes{9}, pitems.back().proof).has_value());
+  }
+  bool fast = false;
+  for (const auto& r2 : pedersen::verify_batch(ctx, pitems, Bytes{9}, &fast)) CHECK(!r2.has_value());
+  CHECK(fast);
+  pitems[7].proof.s[3] ^= 8;
+  const auto pres = pedersen::verify_batch(ctx, pitems, Bytes{9}, &fast);
+  CHECK(!fast);
+  for (size_t i = 0; i < pitems.size(); ++i) CHECK(i == 7 ? pres[i] == Error::VerificationFailure : !pres[i].has_value());
+  std::printf("mirror_test bandersnatch_sw ok: %zu IETF proofs, %zu Pedersen proofs\n", n, pitems.size());
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc != 17 && argc != 23) { std::printf("usage: mirror_test <16 hex fields> [<6 secp256r1 fields>]\n"); return 2; }
   if (argc == 23 && p256_section(argv + 17)) return 1;
+  if (bsw_section()) return 1;
   const std::string seed = argv[1], alpha = argv[2], ad = argv[3], pk = argv[4], h = argv[5], gamma = argv[6],
                     beta = argv[7], c = argv[8], s = argv[9], ped_ad = argv[10], blinding = argv[11], pk_com = argv[12],
                     pr = argv[13], pok = argv[14], ps = argv[15], psb = argv[16];

@@ -265,8 +265,20 @@ def test_gpu_pedersen_equals_the_oracle(gpu):
     want = np.array([bo.pedersen_verify_bytes(*(t[j][i].tobytes() for j in range(7)), ads[i]) for i in range(n)], np.uint8)
     got = gpu.pedersen_verify_batch(*t, ad=ads)
     assert (got == want).all() and set(want) == {0, 1, 2}, (got, want)
+    # the whole batch through ONE multi-scalar multiplication: same statuses; the valid batch takes the fast path
+    st_b, fast = gpu.pedersen_verify_batch_rlc(*args, ad=ads, seed=bytes(range(32)))
+    assert fast and (st_b == 0).all()
+    st_b, fast = gpu.pedersen_verify_batch_rlc(*t, ad=ads, seed=bytes(range(32)))
+    assert not fast and (st_b == want).all()
+    # defects that cancel in an unweighted sum: sb_i + d, sb_j - d
+    u = [a.copy() for a in args]
+    d = 12345
+    for i, sign in ((3, 1), (9, -1)):
+        u[6][i] = np.frombuffer(le((int.from_bytes(args[6][i].tobytes(), "little") + sign * d) % R), np.uint8)
+    st_b, fast = gpu.pedersen_verify_batch_rlc(*u, ad=ads)
+    assert not fast and list(np.nonzero(st_b)[0]) == [3, 9]
     with pytest.raises(Exception):
-        gpu.pedersen_verify_batch_rlc(*args, ad=ads)                 # the batched verifier is not built for this suite
+        gpu.pedersen_verify_batch_rlc(*[np.zeros((2, 64), np.uint8)] * 5, np.zeros((2, 32), np.uint8), np.zeros((2, 32), np.uint8), affine=True)
 
 
 @pytest.mark.gpu
