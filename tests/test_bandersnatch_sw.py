@@ -4,11 +4,18 @@
 PARITY UNPINNED: no vector of this suite is on this machine.  What the tiers check:
   CPU: the oracle (oracle/bsw_oracle.py, chord-and-tangent ON the Weierstrass curve) against the vector-pinned
        twisted-Edwards oracle through `utils::te_sw_map` -- same secret, same input point: Gamma, the public key, the Pedersen
-       commitment are each other's images; a proof made on one model verifies there; the codec's rules.
+       commitment are each other's images; a proof made on one model verifies there; the codec's rules.  And the device
+       header of the suite compiled for the host (tests/hostsim/hostsim_bsw.hip: decode with the map and the subgroup test,
+       projective encode, the transcript hashes, try-and-increment) against the oracle.
   GPU (-m gpu): the HIP path (which runs the group law on the EDWARDS model and crosses the map at the codec,
        csrc/bsw_core.cuh) against the oracle through the C ABI: prove bytes, verify statuses on tampered / undecodable /
        small-order / non-canonical inputs, Pedersen, verification from alpha, and the same consistency with the device's own
        twisted-Edwards suite at 2^13 items."""
+import ctypes
+import os
+import random
+import subprocess
+
 import numpy as np
 import pytest
 
@@ -126,6 +133,87 @@ def test_oracle_schemes_against_the_pinned_edwards_oracle():
         bad = (proof[0], proof[1], proof[2], proof[3], (proof[4] + 1) % R)
         assert not bo.pedersen_verify(h, gamma, ad, bad)
         assert len(bo.output_hash(gamma)) == 64
+
+
+# ------------------------------------------------------------------------- the device header on the host (CPU tier)
+@pytest.fixture(scope="module")
+def hb():
+    hs = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+    subprocess.run(["make", "-C", hs, "libhostsim_bsw.so"], check=True, stdout=subprocess.DEVNULL)
+    return ctypes.CDLL(os.path.join(hs, "libhostsim_bsw.so"))
+
+
+def _hb_decode(hb, enc):
+    te, sw = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+    fl = hb.hb_decode(bytes(enc), te, sw)
+    return fl, te.raw, sw.raw
+
+
+def _hb_encode(hb, te_pt, z):
+    o = ctypes.create_string_buffer(33)
+    hb.hb_encode(xy(te_pt), le(z), o)
+    return o.raw
+
+
+def test_host_build_codec_equals_the_oracle(hb):
+    rnd = random.Random(17)
+    t2 = _torsion2()
+    pts = [bo.mul(rnd.randrange(1, R), bo.G) for _ in range(24)]
+    pts += [bo.neg(pts[0]), bo.add(pts[1], t2[0]), bo.add(pts[2], t2[1]), bo.add(pts[3], t2[2])]
+    for p in pts:
+        e = bo.point_encode(p)
+        fl, te, sw = _hb_decode(hb, e)
+        assert fl & 1 and not fl & 2 and bool(fl & 4) == bo.in_prime_subgroup(p)
+        assert sw == xy(p) and te == xy(vo.sw_to_te(TE, p))
+        junk = e[:32] + bytes([e[32] | rnd.randrange(64)])                       # low flag-byte bits are not looked at
+        assert _hb_decode(hb, junk)[1:] == (te, sw)
+        o = ctypes.create_string_buffer(33); hb.hb_canonical(junk, o)
+        assert o.raw == e
+        for z in (1, 2, rnd.randrange(1, Q)):                                      # projective representatives
+            assert _hb_encode(hb, vo.sw_to_te(TE, p), z) == e
+    # infinity <-> (0, 1); the Edwards point of order 2 (0, -1) <-> (x0, 0)
+    fl, te, _ = _hb_decode(hb, le(99) + b"\x40")
+    assert fl == 7 and te == xy((0, 1))
+    assert _hb_encode(hb, (0, 1), 5) == bytes(32) + b"\x40"
+    enc_t = _hb_encode(hb, (0, Q - 1), 3)
+    ok, t = bo.point_decode(enc_t)
+    assert ok and t[1] == 0 and t in t2 and enc_t[32] == 0
+    # rejected: both flags, x >= q, not on the curve, and y = 0 (no Edwards image: see csrc/bsw_core.cuh)
+    e = bo.point_encode(pts[0])
+    offx = next(x for x in range(2, 100) if vo.legendre((x ** 3 + bo.A * x + bo.B) % Q, Q) == -1)
+    for bad in (e[:32] + bytes([e[32] | 0xC0]), le(Q + 3) + b"\x00", le(offx) + b"\x00", le(Q) + b"\x40", le(t2[0][0]) + b"\x00"):
+        assert _hb_decode(hb, bad)[0] & 1 == 0
+
+
+def test_host_build_hashes_and_try_and_increment_equal_the_oracle(hb):
+    rnd = random.Random(23)
+    for i in range(12):
+        P5 = [bo.mul(rnd.randrange(1, R), bo.G) for _ in range(5)]
+        if i == 3:
+            P5[2] = None
+        ad = bytes(rnd.randrange(256) for _ in range(rnd.choice((0, 1, 7, 64, 111, 200))))
+        c = ctypes.create_string_buffer(32)
+        hb.hb_challenge(b"".join(bo.point_encode(p) for p in P5), ad, len(ad), c)
+        assert c.raw == le(bo.challenge(P5, ad))
+        sk = rnd.randrange(1, R)
+        k = ctypes.create_string_buffer(32); hb.hb_nonce(le(sk), bo.point_encode(P5[0]), k)
+        assert k.raw == le(bo.nonce_rfc8032(sk, P5[0]))
+        b = ctypes.create_string_buffer(32); hb.hb_blinding(le(sk), bo.point_encode(P5[1]), ad, len(ad), b)
+        assert b.raw == le(bo.pedersen_blinding(sk, P5[1], ad))
+        o = ctypes.create_string_buffer(64); hb.hb_output_hash(bo.point_encode(P5[4]), o)
+        assert o.raw == bo.output_hash(P5[4])
+    for i in range(40):
+        msg = bytes(rnd.randrange(256) for _ in range(rnd.choice((0, 3, 32, 100))))
+        e, hint = ctypes.create_string_buffer(33), ctypes.c_uint32(0)
+        hb.hb_hash_to_curve(msg, len(msg), 0, e, ctypes.byref(hint))
+        want = bo.point_encode(bo.hash_to_curve_tai(msg))
+        assert e.raw == want
+        # the counter k_tai_find hands the kernels: the first candidate that is a finite curve point; starting there changes nothing
+        first = next(c for c in range(256) if (lambda okp: okp[0] and okp[1] is not None)(
+            bo.point_decode(bo.sha512(bo.SUITE_ID + b"\x01" + msg + bytes([c]) + b"\x00")[:33])))
+        assert hint.value == first
+        e2 = ctypes.create_string_buffer(33); hb.hb_hash_to_curve(msg, len(msg), hint.value, e2, None)
+        assert e2.raw == want
 
 
 # ------------------------------------------------------------------------------------------------------ GPU tier

@@ -46,6 +46,14 @@ row("… Pedersen prove 2^20, secp256r1 (unpinned; placeholder blinding base)", 
 row("… Pedersen verify 2^20, secp256r1, per proof", c["pedersen_verify_secp256r1"], "verifies/s", ["decode", "eq_h", "eq_g", "finish"])
 if "pedersen_verify_batched_secp256r1" in c:
     row("… batched (digest + one MSM over 5n + 2 points)", c["pedersen_verify_batched_secp256r1"], "verifies/s", ["decode", "msm_buckets", "msm_final"])
+if "ietf_prove_bandersnatch_sw" in c:
+    row("f4 IETF prove 2^20, bandersnatch_sw (33-byte SW points; Edwards arithmetic behind the codec)", c["ietf_prove_bandersnatch_sw"], "proofs/s", ["tai_find+prepare", "mul", "finish"])
+    row("f4 IETF verify 2^20, bandersnatch_sw, checked", c["ietf_verify_bandersnatch_sw"], "verifies/s", ["decode", "straus_v", "straus_u", "finish"])
+    if "from_alpha" in c["ietf_verify_bandersnatch_sw"]:
+        row("… from (pk, alpha, proof)", c["ietf_verify_bandersnatch_sw"]["from_alpha"], "verifies/s")
+    row("… Pedersen prove 2^20, bandersnatch_sw (placeholder blinding base)", c["pedersen_prove_bandersnatch_sw"], "proofs/s", ["tai_find+prepare", "mul", "finish"])
+    row("… Pedersen verify 2^20, bandersnatch_sw, per proof", c["pedersen_verify_bandersnatch_sw"], "verifies/s", ["decode", "eq_h", "eq_g", "finish"])
+    row("… batched (digest + one MSM over 5n + 2 points)", c["pedersen_verify_batched_bandersnatch_sw"], "verifies/s", ["decode", "msm_buckets", "msm_final"])
 row("configs[4] pairing check 2^14, per item", c["pairing_check"], "checks/s", None, 1e6, "e6")
 row("… shared G2 pair (prepared lines)", c["pairing_check_shared_g2"], "checks/s", None, 1e6, "e6")
 row("… shared G2 pair, ONE batch (two G1 MSMs + one pairing), 2^14", c["pairing_check_batched_shared_g2_2^14"], "checks/s", ["prep", "msm_buckets", "msm_final", "pairing"], 1e6, "e6")

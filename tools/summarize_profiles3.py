@@ -106,6 +106,8 @@ CONFIGS = [("ietf_verify", "k_verify_straus<vrf::SuiteBS, 1>", N20, 20), ("ietf_
            ("pedersen_prove_jubjub", "k_prove_mul<vrf::SuiteJJ, false>", 2 * N20, 20),
            ("pedersen_verify_jubjub", "k_ped_verify_straus<vrf::SuiteJJ, 0>", N20, 20),
            ("pedersen_rlc_jubjub", "k_rlc_decode<vrf::SuiteJJ, 2>", None, 20),
+           ("ietf_prove_bandersnatch_sw", "k_prove_mul<vrf::SuiteBS, false>", 2 * N20, 20),
+           ("ietf_verify_bandersnatch_sw", "k_bsw_verify_decode", None, 20),
            ("pairing_check", "k_pairing_check2_oct_lines", 8 * N14, 14), ("pairing_check_shared", "k_pairing_check2_oct_prepared", 8 * N14, 14)]
 out = collections.OrderedDict()
 for cfg, pat, grid, lg in CONFIGS:
