@@ -4,13 +4,21 @@
 
 namespace vrf {
 
-__global__ void __launch_bounds__(BLOCK) k_digest_leaves(DigestSrc src, size_t n, uint64_t index0, uint8_t* leaves) {
+// Minimum waves per SIMD the compiler must leave room for.  1 = no register cap: the leaf kernel then takes 310 registers (one
+// wave per SIMD) and is the fastest of the three builds measured at 2^20 items (the part of a batched Pedersen verification
+// outside its stage events: 0.94 ms uncapped, 1.18 ms capped at 256 registers, 4.08 ms at 128 -- the SHA-512 message schedule
+// spills; profiles/r04/digest_ab.log, tools/gpu_digest_ab.py).
+#ifndef DIGEST_MINW
+#define DIGEST_MINW 1
+#endif
+
+__global__ void __launch_bounds__(BLOCK, DIGEST_MINW) k_digest_leaves(DigestSrc src, size_t n, uint64_t index0, uint8_t* leaves) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   digest_leaf(leaves + i * 32, src, i, index0 + i);
 }
 
-__global__ void __launch_bounds__(64) k_digest_nodes(const uint8_t* children, size_t n_children, uint8_t* nodes) {
+__global__ void __launch_bounds__(64, DIGEST_MINW) k_digest_nodes(const uint8_t* children, size_t n_children, uint8_t* nodes) {
   size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
   size_t first = t * DIGEST_FAN;
   if (first >= n_children) return;
