@@ -346,10 +346,9 @@ def cpu_cores():
     return min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0)))
 
 
-def cpu_leg(fn, probe, budget_s, cap, unit, what, src="oracle/c/oracle_vrf.c", cores=None):
+def cpu_leg(fn, probe, budget_s, cap, unit, what, src="oracle/c/oracle_vrf.c"):
     """fn(m) runs the oracle on the first m items.  Probe, then one bounded run of about budget_s seconds."""
-    python_port = cores is not None                 # a single-threaded pure-Python oracle (named in src)
-    cores = cores or cpu_cores()
+    cores = cpu_cores()
     t0 = time.perf_counter()
     fn(probe)
     rate = probe / (time.perf_counter() - t0)
@@ -359,8 +358,7 @@ def cpu_leg(fn, probe, budget_s, cap, unit, what, src="oracle/c/oracle_vrf.c", c
     dt = time.perf_counter() - t0
     return {"value": m / dt, "unit": unit, "cores": cores, "kind": "port",
             "sample": "first %d items of the same batch, %.1f s wall on %d threads; %s" % (m, dt, cores, what),
-            "note": ("CPU restatement (%s), not arkworks: no Rust toolchain on this box" if python_port else
-                     "CPU restatement in C (%s), not arkworks: no Rust toolchain on this box") % src}
+            "note": "CPU restatement in C (%s), not arkworks: no Rust toolchain on this box" % src}
 
 
 BLS_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
@@ -697,28 +695,24 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
             fn = lambda: cx.ietf_prove_batch_dev(sk, msg, 32, g, c, s_, pk, hh, st)        # the IETF proofs back for the CPU leg
             fn(); torch.cuda.synchronize()
         if want_cpu and bsw:
-            # the only CPU restatement of this suite is the pure-Python oracle (oracle/bsw_oracle.py): a parity check and a
-            # scalar-interpreter rate, on a sample sized for it
-            from oracle import bsw_oracle as bo
-            cap = 256
+            # oracle/c/oracle_bsw.c: the suite on the Weierstrass curve itself (Jacobian double-and-add), 16 threads
+            from oracle import c_oracle as co
+            cap = 1 << 15
             host = lambda t: t[:cap].cpu().numpy()
             skh, msgh, gh, ch, sh, pkh, hhh = (host(t) for t in (sk, msg, g, c, s_, pk, hh))
 
             def leg_p(k):
-                for i in range(k):
-                    h = bo.hash_to_curve_tai(msgh[i].tobytes())
-                    gamma, cc, ss = bo.ietf_prove(int.from_bytes(skh[i].tobytes(), "little"), h, b"")
-                    assert bo.point_encode(gamma) == gh[i].tobytes() and cc.to_bytes(32, "little") == ch[i].tobytes() and \
-                        ss.to_bytes(32, "little") == sh[i].tobytes(), "GPU proofs differ from the CPU oracle on the sample"
-            res["ietf_prove_" + tag]["cpu_baseline"] = cpu_leg(leg_p, 32, args.cpu_seconds / 4, cap, "proofs/s",
-                                                               "proof bytes equal the GPU's", "oracle/bsw_oracle.py (pure Python)", cores=1)
+                ref = co.bsw_ietf_prove_batch(skh[:k], msgs=msgh[:k], ad=b"", threads=cpu_cores())
+                assert (ref["output"] == gh[:k]).all() and (ref["c"] == ch[:k]).all() and (ref["s"] == sh[:k]).all(), \
+                    "GPU proofs differ from the CPU oracle on the sample"
+            res["ietf_prove_" + tag]["cpu_baseline"] = cpu_leg(leg_p, 16 * cpu_cores(), args.cpu_seconds / 2, cap, "proofs/s",
+                                                               "proof bytes equal the GPU's", "oracle/c/oracle_bsw.c")
 
             def leg_v(k):
-                for i in range(k):
-                    assert bo.ietf_verify_bytes(pkh[i].tobytes(), hhh[i].tobytes(), gh[i].tobytes(), b"", ch[i].tobytes(),
-                                                sh[i].tobytes()) == 0, "CPU oracle rejects GPU-made proofs"
-            res["ietf_verify_" + tag]["cpu_baseline"] = cpu_leg(leg_v, 32, args.cpu_seconds / 4, cap, "verifies/s",
-                                                                "statuses equal the GPU's", "oracle/bsw_oracle.py (pure Python)", cores=1)
+                stv = co.bsw_ietf_verify_batch(pkh[:k], hhh[:k], gh[:k], ch[:k], sh[:k], b"", threads=cpu_cores())
+                assert not stv.any(), "CPU oracle rejects GPU-made proofs"
+            res["ietf_verify_" + tag]["cpu_baseline"] = cpu_leg(leg_v, 16 * cpu_cores(), args.cpu_seconds / 2, cap, "verifies/s",
+                                                                "statuses equal the GPU's", "oracle/c/oracle_bsw.c")
         elif want_cpu:
             from oracle import c_oracle as co
             cap = 1 << 15

@@ -927,3 +927,6 @@ void oracle_fq_mul(const uint8_t a[32], const uint8_t b[32], uint8_t r[32]) {
 void oracle_sha512(const uint8_t* m, size_t n, uint8_t out[64]) {
   sha512_ctx c; sha512_init(&c); sha512_update(&c, m, n); sha512_final(&c, out);
 }
+
+/* `suites::bandersnatch_sw` on its own curve model: shares this file's field, hash and thread helpers */
+#include "oracle_bsw.c"

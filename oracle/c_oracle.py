@@ -424,3 +424,125 @@ def p256_pedersen_verify_batch(h, gamma, pk_com, r, ok, s, sb, ad: bytes = b"", 
     adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
     load().p256_pedersen_verify_batch(n, *[x.ctypes.data for x in pts + sc], adb.ctypes.data, len(ad), st.ctypes.data, threads)
     return st
+
+
+# ------------------------------------------------------------------ `suites::bandersnatch_sw` (oracle/c/oracle_bsw.c)
+# 33-byte arkworks short-Weierstrass points, little-endian scalars; arithmetic on the Weierstrass curve itself.
+def _bsw():
+    lib = load()
+    if not getattr(lib, "_bsw_typed", False):
+        P = c_void_p
+        lib.oracle_bsw_ietf_verify_batch.argtypes = [c_size_t, P, P, P, P, P, P, c_size_t, P, c_int]
+        lib.oracle_bsw_ietf_verify_batch.restype = None
+        lib.oracle_bsw_ietf_prove_batch.argtypes = [c_size_t, P, P, c_size_t, P, P, c_size_t, P, P, P, P, P, P, c_int]
+        lib.oracle_bsw_ietf_prove_batch.restype = None
+        lib.oracle_bsw_pedersen_verify_batch.argtypes = [c_size_t, P, P, P, P, c_size_t, P, c_int]
+        lib.oracle_bsw_pedersen_verify_batch.restype = None
+        lib.oracle_bsw_pedersen_prove_batch.argtypes = [c_size_t, P, P, c_size_t, P, P, c_size_t, P, P, P, P, P, c_int]
+        lib.oracle_bsw_pedersen_prove_batch.restype = None
+        lib.oracle_bsw_secret_public.argtypes = [P, c_size_t, P, P]
+        lib.oracle_bsw_hash_to_curve.argtypes = [P, c_size_t, P]
+        lib.oracle_bsw_hash_to_curve.restype = c_int
+        lib.oracle_bsw_output_hash.argtypes = [P, P]
+        lib.oracle_bsw_point_decode.argtypes = [P, c_int, P]
+        lib.oracle_bsw_point_decode.restype = c_int
+        lib.oracle_bsw_constants.argtypes = [P, P, P]
+        lib._bsw_typed = True
+    return lib
+
+
+def bsw_constants():
+    """(a', b'), generator, blinding base as the C oracle derives them: three 64-byte x || y strings."""
+    ab, g, bb = (ctypes.create_string_buffer(64) for _ in range(3))
+    _bsw().oracle_bsw_constants(ab, g, bb)
+    return ab.raw, g.raw, bb.raw
+
+
+def bsw_secret_public(seed: bytes):
+    sk, pk = ctypes.create_string_buffer(32), ctypes.create_string_buffer(33)
+    _bsw().oracle_bsw_secret_public(bytes(seed), len(seed), sk, pk)
+    return sk.raw, pk.raw
+
+
+def bsw_hash_to_curve(msg: bytes) -> bytes:
+    out = ctypes.create_string_buffer(33)
+    _bsw().oracle_bsw_hash_to_curve(bytes(msg), len(msg), out)
+    return out.raw
+
+
+def bsw_output_hash(gamma: bytes) -> bytes:
+    out = ctypes.create_string_buffer(64)
+    _bsw().oracle_bsw_output_hash(bytes(gamma), out)
+    return out.raw
+
+
+def bsw_point_decode(enc: bytes, subgroup: bool = True):
+    """x || y (64 bytes; zeros for the point at infinity) or None."""
+    xy = ctypes.create_string_buffer(64)
+    return xy.raw if _bsw().oracle_bsw_point_decode(bytes(enc), 1 if subgroup else 0, xy) == 0 else None
+
+
+def bsw_ietf_prove_batch(sk, msgs: np.ndarray = None, inputs=None, ad: bytes = b"", threads: int = 1):
+    sk = _a(sk).reshape(-1, 32)
+    n = sk.shape[0]
+    res = {k: np.empty((n, 32 if k in ("c", "s") else 33), dtype=np.uint8) for k in ("output", "c", "s", "pk", "input")}
+    st = np.empty(n, dtype=np.uint8)
+    adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
+    mp, ml, ip = None, 0, None
+    if inputs is not None:
+        inputs = _a(inputs).reshape(n, 33)
+        ip = inputs.ctypes.data
+    else:
+        msgs = _a(msgs).reshape(n, -1)
+        ml = msgs.shape[1]
+        msgs = np.concatenate([msgs.reshape(-1), np.zeros(1, np.uint8)])
+        mp = msgs.ctypes.data
+    _bsw().oracle_bsw_ietf_prove_batch(n, sk.ctypes.data, mp, ml, ip, adb.ctypes.data, len(ad), res["output"].ctypes.data,
+                                       res["c"].ctypes.data, res["s"].ctypes.data, res["pk"].ctypes.data, res["input"].ctypes.data,
+                                       st.ctypes.data, threads)
+    res["status"] = st
+    return res
+
+
+def bsw_ietf_verify_batch(pk, h, gamma, c, s, ad: bytes = b"", threads: int = 1) -> np.ndarray:
+    pts = [_a(x).reshape(-1, 33) for x in (pk, h, gamma)]
+    sc = [_a(x).reshape(-1, 32) for x in (c, s)]
+    n = pts[0].shape[0]
+    st = np.empty(n, dtype=np.uint8)
+    adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
+    _bsw().oracle_bsw_ietf_verify_batch(n, *[x.ctypes.data for x in pts + sc], adb.ctypes.data, len(ad), st.ctypes.data, threads)
+    return st
+
+
+def bsw_pedersen_prove_batch(sk, msgs: np.ndarray = None, inputs=None, ad: bytes = b"", threads: int = 1):
+    """dict(output, pk_com, r, ok (n x 33), s, sb, blinding (n x 32), input, status)."""
+    sk = _a(sk).reshape(-1, 32)
+    n = sk.shape[0]
+    gamma, proof = np.empty((n, 33), np.uint8), np.empty((n, 163), np.uint8)
+    blind, hh, st = np.empty((n, 32), np.uint8), np.empty((n, 33), np.uint8), np.empty(n, np.uint8)
+    adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
+    mp, ml, ip = None, 0, None
+    if inputs is not None:
+        inputs = _a(inputs).reshape(n, 33)
+        ip = inputs.ctypes.data
+    else:
+        msgs = _a(msgs).reshape(n, -1)
+        ml = msgs.shape[1]
+        msgs = np.concatenate([msgs.reshape(-1), np.zeros(1, np.uint8)])
+        mp = msgs.ctypes.data
+    _bsw().oracle_bsw_pedersen_prove_batch(n, sk.ctypes.data, mp, ml, ip, adb.ctypes.data, len(ad), gamma.ctypes.data, proof.ctypes.data,
+                                           blind.ctypes.data, hh.ctypes.data, st.ctypes.data, threads)
+    return {"output": gamma, "pk_com": proof[:, :33].copy(), "r": proof[:, 33:66].copy(), "ok": proof[:, 66:99].copy(),
+            "s": proof[:, 99:131].copy(), "sb": proof[:, 131:163].copy(), "blinding": blind, "input": hh, "status": st}
+
+
+def bsw_pedersen_verify_batch(h, gamma, pk_com, r, ok, s, sb, ad: bytes = b"", threads: int = 1) -> np.ndarray:
+    h, gamma = _a(h).reshape(-1, 33), _a(gamma).reshape(-1, 33)
+    n = h.shape[0]
+    proof = np.ascontiguousarray(np.concatenate([_a(x).reshape(n, -1) for x in (pk_com, r, ok, s, sb)], axis=1))
+    assert proof.shape[1] == 163
+    st = np.empty(n, dtype=np.uint8)
+    adb = np.frombuffer(bytes(ad) + b"\0", dtype=np.uint8)
+    _bsw().oracle_bsw_pedersen_verify_batch(n, h.ctypes.data, gamma.ctypes.data, proof.ctypes.data, adb.ctypes.data, len(ad),
+                                            st.ctypes.data, threads)
+    return st

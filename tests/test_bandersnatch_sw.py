@@ -20,6 +20,7 @@ import numpy as np
 import pytest
 
 from oracle import bsw_oracle as bo
+from oracle import c_oracle as co
 from oracle import vrf_oracle as vo
 
 TE = vo.BANDERSNATCH
@@ -133,6 +134,80 @@ def test_oracle_schemes_against_the_pinned_edwards_oracle():
         bad = (proof[0], proof[1], proof[2], proof[3], (proof[4] + 1) % R)
         assert not bo.pedersen_verify(h, gamma, ad, bad)
         assert len(bo.output_hash(gamma)) == 64
+
+
+def _defects(rnd, n, pk, h, g, c, s, proofs):
+    """Every kind of defect on copies of a valid batch (proofs[i] = (Gamma, c, s) as the oracle's values)."""
+    pkt, ht, gt, ct, st_ = (x.copy() for x in (pk, h, g, c, s))
+    t2 = _torsion2()
+    offx = next(x for x in range(2, 100) if vo.legendre((x ** 3 + bo.A * x + bo.B) % Q, Q) == -1)
+    for i in range(n):
+        kind = i % 16
+        if kind == 1: st_[i, 3] ^= 1
+        elif kind == 2: ct[i, 30] ^= 1
+        elif kind == 3: gt[i] = g[(i + 1) % n]
+        elif kind == 4: pkt[i] = np.frombuffer(le(offx) + b"\x00", np.uint8)                    # not on the curve
+        elif kind == 5: ht[i, 32] |= 0xC0                                                        # both flags
+        elif kind == 6: ct[i] = np.frombuffer(le(proofs[i][1] + R), np.uint8)                   # c + r: the same scalar mod r
+        elif kind == 7: gt[i] = np.frombuffer(le(Q + 5) + b"\x00", np.uint8)                    # x >= q
+        elif kind == 8: st_[i] = np.frombuffer(le(proofs[i][2] + R), np.uint8)                  # s not canonical
+        elif kind == 9: pkt[i, 32] |= rnd.randrange(1, 64)                                       # junk in the flag byte's low bits: ignored
+        elif kind == 10: gt[i] = np.frombuffer(bo.point_encode(bo.add(proofs[i][0], t2[i % 3])), np.uint8)    # + a point of order 2
+        elif kind == 11: pkt[i] = np.frombuffer(le(t2[i % 3][0]) + b"\x00", np.uint8)           # a point of order 2 itself
+        elif kind == 12: ht[i] = np.frombuffer(le(77) + b"\x40", np.uint8)                      # infinity (x not looked at)
+        elif kind == 13: gt[i, 32] ^= 0x80                                                       # -Gamma
+        elif kind == 14: pkt[i] = np.frombuffer(bytes(32) + b"\x40", np.uint8)                  # pk = infinity
+    return pkt, ht, gt, ct, st_
+
+
+def test_c_oracle_equals_the_python_oracle():
+    """oracle/c/oracle_bsw.c (the batch-size checker and CPU baseline) against oracle/bsw_oracle.py: constants, keys,
+    hash-to-curve, both schemes byte for byte, statuses on every kind of defect."""
+    rnd = random.Random(31)
+    ab, g, bb = co.bsw_constants()
+    assert ab == le(bo.A) + le(bo.B) and g == xy(bo.G) and bb == xy(bo.BLINDING_BASE)
+    n = 48
+    seeds = [b"seed-%d" % i for i in range(n)]
+    sk = _u8(co.bsw_secret_public(sd)[0] for sd in seeds)
+    for i in range(0, n, 5):
+        k = bo.secret_from_seed(seeds[i])
+        assert co.bsw_secret_public(seeds[i]) == (le(k), bo.point_encode(bo.mul(k, bo.G)))
+    msgs = np.frombuffer(b"".join(b"%020d" % i for i in range(n)), np.uint8).reshape(n, 20)
+    ad = b"additional"
+    r = co.bsw_ietf_prove_batch(sk, msgs=msgs, ad=ad, threads=4)
+    proofs = []
+    for i in range(n):
+        k = int.from_bytes(sk[i].tobytes(), "little")
+        h = bo.hash_to_curve_tai(msgs[i].tobytes())
+        gamma, c, s = bo.ietf_prove(k, h, ad)
+        proofs.append((gamma, c, s))
+        assert co.bsw_hash_to_curve(msgs[i].tobytes()) == bo.point_encode(h) == r["input"][i].tobytes()
+        assert r["output"][i].tobytes() == bo.point_encode(gamma) and r["c"][i].tobytes() == le(c) and r["s"][i].tobytes() == le(s)
+        assert r["pk"][i].tobytes() == bo.point_encode(bo.mul(k, bo.G))
+        assert co.bsw_output_hash(r["output"][i].tobytes()) == bo.output_hash(gamma)
+    r2 = co.bsw_ietf_prove_batch(sk, inputs=r["input"], ad=ad, threads=2)
+    assert all((r2[k_] == r[k_]).all() for k_ in ("output", "c", "s", "pk", "input"))
+    t = _defects(rnd, n, r["pk"], r["input"], r["output"], r["c"], r["s"], proofs)
+    got = co.bsw_ietf_verify_batch(*t, ad=ad, threads=4)
+    want = np.array([bo.ietf_verify_bytes(t[0][i].tobytes(), t[1][i].tobytes(), t[2][i].tobytes(), ad, t[3][i].tobytes(),
+                                          t[4][i].tobytes()) for i in range(n)], np.uint8)
+    assert (got == want).all() and set(want) == {0, 1, 2}
+    p = co.bsw_pedersen_prove_batch(sk, msgs=msgs, ad=ad, threads=4)
+    for i in range(0, n, 3):
+        k = int.from_bytes(sk[i].tobytes(), "little")
+        gamma, (pc, rr, ok, s, sb), b = bo.pedersen_prove(k, bo.hash_to_curve_tai(msgs[i].tobytes()), ad)
+        assert [p[k_][i].tobytes() for k_ in ("output", "pk_com", "r", "ok")] == [bo.point_encode(v) for v in (gamma, pc, rr, ok)]
+        assert p["s"][i].tobytes() == le(s) and p["sb"][i].tobytes() == le(sb) and p["blinding"][i].tobytes() == le(b)
+    args = [p[k_].copy() for k_ in ("input", "output", "pk_com", "r", "ok", "s", "sb")]
+    args[5][1, 0] ^= 1; args[6][2, 0] ^= 1; args[3][3, 32] |= 0xC0; args[2][4] = args[2][5]
+    got = co.bsw_pedersen_verify_batch(*args, ad=ad, threads=4)
+    want = np.array([bo.pedersen_verify_bytes(*(args[j][i].tobytes() for j in range(7)), ad) for i in range(n)], np.uint8)
+    assert (got == want).all() and list(want[:6]) == [0, 1, 1, 2, 1, 0]
+    for enc in (bo.point_encode(bo.mul(5, bo.G)), bytes(32) + b"\x40", le(_torsion2()[1][0]) + b"\x00"):
+        ok_, pt = bo.point_decode_checked(enc)
+        assert (co.bsw_point_decode(enc) is not None) == ok_
+        if ok_:
+            assert co.bsw_point_decode(enc) == (bytes(64) if pt is None else xy(pt))
 
 
 # ------------------------------------------------------------------------- the device header on the host (CPU tier)
@@ -367,6 +442,47 @@ def test_gpu_pedersen_equals_the_oracle(gpu):
     assert not fast and list(np.nonzero(st_b)[0]) == [3, 9]
     with pytest.raises(Exception):
         gpu.pedersen_verify_batch_rlc(*[np.zeros((2, 64), np.uint8)] * 5, np.zeros((2, 32), np.uint8), np.zeros((2, 32), np.uint8), affine=True)
+
+
+@pytest.mark.gpu
+def test_gpu_whole_batch_equals_the_c_oracle(gpu):
+    """2^13 items against the C oracle (which works on the Weierstrass curve): every proof byte, every status of a batch
+    with all defect kinds, both schemes."""
+    import multiprocessing
+    nt = min(16, multiprocessing.cpu_count())
+    rnd = random.Random(41)
+    n = 1 << 13
+    rng = np.random.default_rng(5)
+    seeds = rng.integers(0, 256, (n, 12), dtype=np.uint8)
+    sk, pk = gpu.secret_from_seed_batch(seeds)
+    for i in range(0, n, 997):
+        assert (sk[i].tobytes(), pk[i].tobytes()) == co.bsw_secret_public(seeds[i].tobytes())
+    msgs = rng.integers(0, 256, (n, 28), dtype=np.uint8)
+    ad = b"whole batch"
+    r = gpu.ietf_prove_batch(sk, msgs=msgs, ad=ad)
+    ref = co.bsw_ietf_prove_batch(sk, msgs=msgs, ad=ad, threads=nt)
+    for k_ in ("output", "c", "s", "pk", "input"):
+        assert (r[k_] == ref[k_]).all(), k_
+    proofs = [(None, int.from_bytes(ref["c"][i].tobytes(), "little"), int.from_bytes(ref["s"][i].tobytes(), "little")) for i in range(n)]
+    for i in range(10, n, 16):                                   # the defect that needs the typed Gamma
+        proofs[i] = (bo.point_decode(ref["output"][i].tobytes())[1],) + proofs[i][1:]
+    t = _defects(rnd, n, ref["pk"], ref["input"], ref["output"], ref["c"], ref["s"], proofs)
+    want = co.bsw_ietf_verify_batch(*t, ad=ad, threads=nt)
+    got = gpu.ietf_verify_batch(*t, ad=ad)
+    assert (got == want).all() and set(np.unique(want)) == {0, 1, 2}
+    assert (np.bincount(want, minlength=3) > n // 16).all()
+    p = gpu.pedersen_prove_batch(sk, msgs=msgs, ad=ad)
+    pref = co.bsw_pedersen_prove_batch(sk, msgs=msgs, ad=ad, threads=nt)
+    for k_ in ("output", "pk_com", "r", "ok", "s", "sb", "blinding", "input"):
+        assert (p[k_] == pref[k_]).all(), k_
+    args = [pref[k_].copy() for k_ in ("input", "output", "pk_com", "r", "ok", "s", "sb")]
+    args[5][::7, 2] ^= 1; args[6][3::11, 0] ^= 1; args[3][5::13, 32] |= 0xC0; args[2][6::17] = args[2][7::17][: len(args[2][6::17])]
+    args[4][8::19, 32] ^= 0x80
+    want = co.bsw_pedersen_verify_batch(*args, ad=ad, threads=nt)
+    got = gpu.pedersen_verify_batch(*args, ad=ad)
+    assert (got == want).all() and set(np.unique(want)) == {0, 1, 2}
+    got_b, fast = gpu.pedersen_verify_batch_rlc(*args, ad=ad)
+    assert not fast and (got_b == want).all()
 
 
 @pytest.mark.gpu
