@@ -9,8 +9,8 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ark_ec_vrfs_amd import (BabyJubJubSha512Tai, BandersnatchSha512Ell2, Context, Ed25519Sha512Tai, JubJubSha512Tai,
-                             Secp256r1Sha256Tai)
+from ark_ec_vrfs_amd import (BabyJubJubSha512Tai, BandersnatchSha512Ell2, BandersnatchSwSha512Tai, Context, Ed25519Sha512Tai,
+                             JubJubSha512Tai, Secp256r1Sha256Tai)
 from oracle import c_oracle as co, sw_oracle as sw
 
 ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 12
@@ -45,7 +45,7 @@ def mutate(fields, orders, big_endian):
     return out
 
 
-def run(name, suite, sid, order, big_endian, p256):
+def run(name, suite, sid, order, big_endian, p256, bsw=False):
     ctx = Context(0, suite, test_blinding_base=True)
     seeds = np.arange(N, dtype=np.uint64).view(np.uint8).reshape(N, 8)
     msg = rng.integers(0, 256, (N, 32), dtype=np.uint8)
@@ -53,6 +53,8 @@ def run(name, suite, sid, order, big_endian, p256):
     if p256:
         co.p256_set_blinding_base(sw.default_blinding_base())
         iv, pv = co.p256_ietf_verify_batch, co.p256_pedersen_verify_batch
+    elif bsw:
+        iv, pv = co.bsw_ietf_verify_batch, co.bsw_pedersen_verify_batch
     else:
         co.set_suite(sid)
         iv, pv = co.ietf_verify_batch, co.pedersen_verify_batch
@@ -66,7 +68,7 @@ def run(name, suite, sid, order, big_endian, p256):
         got, want = ctx.ietf_verify_batch(*m, ad=b"mf"), iv(*m, ad=b"mf", threads=THREADS)
         bad += int((got != want).sum())
         hist += np.bincount(want, minlength=3)
-    print("%-12s ietf     %8d mutated proofs, differences %d, oracle statuses %s" % (name, ROUNDS * N, bad, hist.tolist()), flush=True)
+    print("%-15s ietf     %8d mutated proofs, differences %d, oracle statuses %s" % (name, ROUNDS * N, bad, hist.tolist()), flush=True)
     if not p256:
         # the same through verification from (pk, alpha, proof): the message takes the input's place among the mutated fields
         # (its H for the oracle comes from the library's hash-to-curve, itself held against the oracle by the tests)
@@ -79,7 +81,7 @@ def run(name, suite, sid, order, big_endian, p256):
             want = iv(m[0], ctx.hash_to_curve_batch(m[1]), m[2], m[3], m[4], ad=b"mf", threads=THREADS)
             bad_a += int((got != want).sum())
             hist += np.bincount(want, minlength=3)
-        print("%-12s alpha    %8d mutated proofs, differences %d, oracle statuses %s" % (name, ROUNDS * N, bad_a, hist.tolist()), flush=True)
+        print("%-15s alpha    %8d mutated proofs, differences %d, oracle statuses %s" % (name, ROUNDS * N, bad_a, hist.tolist()), flush=True)
         bad += bad_a
     r = ctx.pedersen_prove_batch(sk, msgs=msg, ad=b"mf")
     base = [r[k] for k in ("input", "output", "pk_com", "r", "ok", "s", "sb")]
@@ -91,7 +93,7 @@ def run(name, suite, sid, order, big_endian, p256):
         got, want = ctx.pedersen_verify_batch(*m, ad=b"mf"), pv(*m, ad=b"mf", threads=THREADS)
         badp += int((got != want).sum())
         hist += np.bincount(want, minlength=3)
-    print("%-12s pedersen %8d mutated proofs, differences %d, oracle statuses %s" % (name, ROUNDS * N, badp, hist.tolist()), flush=True)
+    print("%-15s pedersen %8d mutated proofs, differences %d, oracle statuses %s" % (name, ROUNDS * N, badp, hist.tolist()), flush=True)
     ctx.close()
     return bad + badp
 
@@ -106,6 +108,7 @@ total += run("jubjub", JubJubSha512Tai, 2, R_JJ, False, False)
 total += run("ed25519", Ed25519Sha512Tai, 3, R_ED, False, False)
 total += run("babyjubjub", BabyJubJubSha512Tai, 4, R_BJ, False, False)
 total += run("secp256r1", Secp256r1Sha256Tai, 5, sw.N, True, True)
+total += run("bandersnatch_sw", BandersnatchSwSha512Tai, 6, R_BS, False, False, bsw=True)
 co.set_suite(1)
 print("TOTAL differences", total)
 sys.exit(1 if total else 0)

@@ -9,8 +9,8 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ark_ec_vrfs_amd import (BabyJubJubSha512Tai, BandersnatchSha512Ell2, Context, Ed25519Sha512Tai, JubJubSha512Tai,
-                             Secp256r1Sha256Tai)
+from ark_ec_vrfs_amd import (BabyJubJubSha512Tai, BandersnatchSha512Ell2, BandersnatchSwSha512Tai, Context, Ed25519Sha512Tai,
+                             JubJubSha512Tai, Secp256r1Sha256Tai)
 from oracle import c_oracle as co, sw_oracle as sw
 
 N = 1024
@@ -33,13 +33,15 @@ def secrets(order, big_endian):
 CT = "--ct" in sys.argv        # VRFHIP_FLAG_CT_TABLES: the provers' window lookups read all eight table entries
 
 
-def run(name, suite, sid, order, big_endian, p256):
+def run(name, suite, sid, order, big_endian, p256, bsw=False):
     ctx = Context(0, suite, test_blinding_base=True)
     if CT:
         ctx.set_flags(ctx.CT_TABLES)
     if p256:
         co.p256_set_blinding_base(sw.default_blinding_base())
         ip, pp = co.p256_ietf_prove_batch, co.p256_pedersen_prove_batch
+    elif bsw:
+        ip, pp = co.bsw_ietf_prove_batch, co.bsw_pedersen_prove_batch
     else:
         co.set_suite(sid)
         ip, pp = co.ietf_prove_batch, co.pedersen_prove_batch
@@ -57,7 +59,7 @@ def run(name, suite, sid, order, big_endian, p256):
         for k in ("output", "pk_com", "r", "ok", "s", "sb", "blinding"):
             bad += int((pgot[k] != pref[k]).any(axis=1).sum())
         proofs += 2 * N
-    print("%-12s %7d proofs (IETF + Pedersen) over %d message / ad length pairs, differing fields %d" % (name, proofs, len(MSG_LENS), bad), flush=True)
+    print("%-15s %7d proofs (IETF + Pedersen) over %d message / ad length pairs, differing fields %d" % (name, proofs, len(MSG_LENS), bad), flush=True)
     ctx.close()
     return bad
 
@@ -72,6 +74,7 @@ total += run("jubjub", JubJubSha512Tai, 2, R_JJ, False, False)
 total += run("ed25519", Ed25519Sha512Tai, 3, R_ED, False, False)
 total += run("babyjubjub", BabyJubJubSha512Tai, 4, R_BJ, False, False)
 total += run("secp256r1", Secp256r1Sha256Tai, 5, sw.N, True, True)
+total += run("bandersnatch_sw", BandersnatchSwSha512Tai, 6, R_BS, False, False, bsw=True)
 co.set_suite(1)
 print("TOTAL differing fields", total)
 sys.exit(1 if total else 0)
