@@ -585,7 +585,9 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
     vrf::f_bls381fr::launch_te_sw_map(SUITE_BS, 2, 1, 0, d_init, d_init + 288, d_init + 420, ctx->stream);
     hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
     hipError_t e3 = hipMemcpy(map_st, d_init + 420, 2, hipMemcpyDeviceToHost);
-    hipError_t e4 = hipMemcpy(d_init, d_init + 288, 128, hipMemcpyDeviceToDevice);
+    // on the context's stream, in front of the table kernels: a device-to-device hipMemcpy on the null stream need not have
+    // finished when it returns, and the (non-blocking) stream would not wait for it
+    hipError_t e4 = hipMemcpyAsync(d_init, d_init + 288, 128, hipMemcpyDeviceToDevice, ctx->stream);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
       free_tmp();
       HIP_TRY_C(e1); HIP_TRY_C(e2); HIP_TRY_C(e3); HIP_TRY_C(e4);

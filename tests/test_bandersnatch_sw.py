@@ -314,6 +314,12 @@ def test_gpu_descriptor_keys_and_hash_to_curve(gpu):
         plain.pedersen_prove_batch(sk0, msgs=[b"m"], ad=b"")
     assert plain.ietf_prove_batch(sk0, msgs=[b"m"], ad=b"")["pk"][0].tobytes() == bo.point_encode(bo.mul(3, bo.G))
     plain.close()
+    # context creation maps the descriptor's points to the Edwards model in front of the table kernels (same stream): repeated
+    # creations, back to back, each give the right tables (a null-stream copy there once raced with them under the profiler)
+    for _ in range(6):
+        cx = Context(0, BandersnatchSwSha512Tai)
+        assert cx.secret_from_seed_batch(np.zeros((1, 4), np.uint8))[1][0].tobytes() == co.bsw_secret_public(bytes(4))[1]
+        cx.close()
     bad = SuiteDesc.with_test_blinding_base(BandersnatchSwSha512Tai)
     bad.generator = xy((bo.G[0], (bo.G[1] + 1) % Q))
     with pytest.raises(Exception):
