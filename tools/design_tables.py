@@ -86,6 +86,10 @@ want = [("vrf::k_verify_decode<vrf::SuiteBS, 2>", 524288, " (checked and pre-val
         ("vrf::k_p256_ped_verify_decode", 1048576, ""), ("vrf::k_p256_ped_verify_mul<0>", 1048576, " (sH − cΓ − Ok = O)"),
         ("vrf::k_p256_ped_verify_mul<1>", 1048576, " (sG + sbB − c·pk_com − R = O)"),
         ("vrf::k_pm_rlc_decode", 1048576, " (secp256r1: five decompressions, challenge, weights, digits)"), ("vrf::k_pm_buckets", None, " (secp256r1, 5·2^20 + 2 points)"),
+        ("vrf::k_tai_find<vrf::SuiteBW>", 262144, " (bandersnatch_sw: 8.8 expected attempts per input)"), ("vrf::k_bsw_prove_prepare", 1048576, ""),
+        ("vrf::k_bsw_prove_finish", 1048576, ""), ("vrf::k_bsw_verify_decode", 1048576, " (3 x: sqrt, te_sw_map, 2-descent, GLV tables)"),
+        ("vrf::k_bsw_verify_straus<1>", 1048576, " (= verify_straus_item<BS, 1>)"), ("vrf::k_bsw_verify_straus<0>", 1048576, ""), ("vrf::k_bsw_verify_finish", 1048576, ""),
+        ("vrf::k_bsw_ped_verify_decode", 1048576, ""), ("vrf::k_bsw_rlc_decode", 1048576, " (in front of k_msm_buckets<BS>)"),
         ("vrf::k_pairing_lines_oct", 131072, " (2^14 items x 8 lanes: G2 walk, lines -> HBM)"), ("vrf::k_pairing_check2_oct_lines", 131072, " (Miller loop over them + final exponentiation)"),
         ("vrf::k_pairing_check2_oct_prepared", 131072, " (shared G2 pair)"), ("vrf::k_pairing_check2_row_prepared<true>", 64, " (ONE item: 48 lanes)"),
         ("vrf::k_g1_buckets", 119808, " (2^18 × 2 sets)"), ("vrf::k_g1_final", 256, " (2 sets × 128 lanes)")]
