@@ -493,7 +493,7 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
     HIP_TRY_C(hipMalloc(&ctx->d_queue, 256));
     HIP_TRY_C(hipMalloc(&d_gen, 256));
     uint8_t gen_ok = 0;
-    hipError_t e0 = hipMemcpy(d_gen, desc->generator, 64, hipMemcpyHostToDevice);
+    hipError_t e0 = hipMemcpyAsync(d_gen, desc->generator, 64, hipMemcpyHostToDevice, ctx->stream);   // ordered with the kernel below
     p256::launch_init_comb(ctx->d_p256_comb, d_gen, d_gen + 128, ctx->stream);
     hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(ctx->stream);
     hipError_t e3 = hipMemcpy(&gen_ok, d_gen + 128, 1, hipMemcpyDeviceToHost);
@@ -507,7 +507,7 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
       HIP_TRY_C(hipMalloc(&ctx->d_p256_comb_b, p256::comb_bytes()));
       HIP_TRY_C(hipMalloc(&d_b, 256));
       uint8_t b_ok = 0;
-      hipError_t f0 = hipMemcpy(d_b, desc->blinding_base, 64, hipMemcpyHostToDevice);
+      hipError_t f0 = hipMemcpyAsync(d_b, desc->blinding_base, 64, hipMemcpyHostToDevice, ctx->stream);
       p256::launch_init_comb(ctx->d_p256_comb_b, d_b, d_b + 128, ctx->stream);
       hipError_t f1 = hipGetLastError(), f2 = hipStreamSynchronize(ctx->stream);
       hipError_t f3 = hipMemcpy(&b_ok, d_b + 128, 1, hipMemcpyDeviceToHost);
@@ -573,7 +573,8 @@ int32_t vrfhip_ctx_create_desc(const vrfhip_suite_desc* desc, int32_t device, vr
   ctx->T.sq.lut = ctx->d_sqrt_lut;
   ctx->T.sq.str = hs;
   {
-    hipError_t e1 = hipMemcpy(d_init, gb, sizeof gb, hipMemcpyHostToDevice);
+    // on the context's stream: ordered in front of the table kernels by construction (gb outlives the synchronisation below)
+    hipError_t e1 = hipMemcpyAsync(d_init, gb, sizeof gb, hipMemcpyHostToDevice, ctx->stream);
     if (e1 != hipSuccess) { free_tmp(); HIP_TRY_C(e1); }
   }
   uint32_t* d_mont = reinterpret_cast<uint32_t*>(d_init + 128);
