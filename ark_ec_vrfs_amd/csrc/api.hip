@@ -80,7 +80,8 @@ int32_t fail(int32_t code, const std::string& msg) {
 constexpr size_t DEFAULT_CHUNK = size_t(1) << 20;
 const char BSW_UNSUPPORTED_MSG[] =
     "not available for the bandersnatch_sw suite (secret keys, hash-to-curve, output hash, point validation, the IETF scheme incl. "
-    "verification from alpha, and the Pedersen scheme per proof and batched are; the x || y forms, key sets and MSM are not)";
+    "verification from alpha, the x || y forms, key sets, the Pedersen scheme per proof and batched, MSM, and the pairing / G1 "
+    "entry points are; the x || y form of the batched Pedersen verifier and the twisted-Edwards test primitives are not)";
 
 }  // namespace
 
@@ -785,7 +786,6 @@ int32_t verify_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d
     HIP_TRY(hipGetLastError());
     return VRFHIP_SUCCESS;
   }
-  if (ctx->bsw && (affine || ks)) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   const size_t pw = affine ? 64 : ctx->pt_bytes();
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     size_t m = std::min(ctx->ws_cap, n - base);
@@ -1040,7 +1040,6 @@ int32_t vrfhip_keyset_create(vrfhip_ctx* ctx, size_t n_keys, const uint8_t* pks,
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (n_keys == 0 || !pks) return fail(VRFHIP_ERR_BAD_ARG, "no keys");
   if (n_keys > (size_t(1) << 24)) return fail(VRFHIP_ERR_BAD_ARG, "too many keys");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   vrfhip_keyset* ks = new vrfhip_keyset();
@@ -1087,14 +1086,16 @@ int32_t vrfhip_keyset_create(vrfhip_ctx* ctx, size_t n_keys, const uint8_t* pks,
       return bail(fail(e__ == hipErrorOutOfMemory ? VRFHIP_ERR_OOM : VRFHIP_ERR_HIP,               \
                        std::string(#expr) + ": " + hipGetErrorString(e__)));                       \
   } while (0)
-  HIP_TRY_K(hipMalloc(&ks->d_enc, n_keys * 32));
+  const size_t kw = ctx->pt_bytes();                 // 32; 33 for bandersnatch_sw
+  HIP_TRY_K(hipMalloc(&ks->d_enc, n_keys * kw + 3));
   HIP_TRY_K(hipMalloc(&ks->d_valid, (n_keys + 255) & ~size_t(255)));
   HIP_TRY_K(hipMalloc(&ks->d_combs, comb_bytes));
   HIP_TRY_K(hipMalloc(&d_xy, n_keys * 2 * NL * sizeof(uint32_t)));
   HIP_TRY_K(hipMalloc(&d_prefix, prefix_bytes));
-  ks->bytes = n_keys * 32 + n_keys + comb_bytes;
-  HIP_TRY_K(hipMemcpyAsync(ks->d_enc, pks, n_keys * 32, hipMemcpyHostToDevice, ctx->stream));
-  FIELD_CALL(ctx, launch_keyset_build((int)ctx->suite, n_keys, ks->d_enc, d_xy, ks->d_valid, ks->d_combs, d_prefix, ctx->T, ctx->stream));
+  ks->bytes = n_keys * kw + n_keys + comb_bytes;
+  HIP_TRY_K(hipMemcpyAsync(ks->d_enc, pks, n_keys * kw, hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->bsw) launch_bsw_keyset_build(n_keys, ks->d_enc, d_xy, ks->d_valid, ks->d_combs, d_prefix, ctx->T, ctx->stream);
+  else FIELD_CALL(ctx, launch_keyset_build((int)ctx->suite, n_keys, ks->d_enc, d_xy, ks->d_valid, ks->d_combs, d_prefix, ctx->T, ctx->stream));
   HIP_TRY_K(hipGetLastError());
   if (status) {
     std::vector<uint8_t> valid(n_keys);
@@ -1229,7 +1230,6 @@ int32_t prove_dev_impl(vrfhip_ctx* ctx, size_t n, bool pedersen, const uint8_t* 
     HIP_TRY(hipGetLastError());
     return VRFHIP_SUCCESS;
   }
-  if (ctx->bsw && (ctx->flags & VRFHIP_FLAG_PROVE_POINTS_AFFINE)) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   const size_t ipw = ctx->pt_bytes();                    // input points and enc(H) out: always compressed
   for (size_t base = 0; base < n; base += ctx->ws_cap) {
     size_t m = std::min(ctx->ws_cap, n - base);
@@ -1703,10 +1703,37 @@ int32_t vrfhip_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases_xy, con
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (!d_out_point || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!d_bases_xy || !d_scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (ctx->bsw) {
+    // bandersnatch_sw: the bases are Weierstrass x || y.  They cross te_sw_map into the MSM workspace, the Edwards kernels add
+    // them up, and the sum goes back: a 33-byte encoding (infinity for the empty sum) and Weierstrass x || y
+    const size_t m = n ? n : 1;
+    const int groups = msm_groups(m, m, ctx->cus);
+    const size_t core = msm_workspace_bytes(m, groups);
+    int32_t rc = ensure_msm_workspace(ctx, core + Stage::pad(m * 64) + Stage::pad(m) + 256);
+    if (rc) return rc;
+    uint8_t* d_map = static_cast<uint8_t*>(ctx->d_msm_ws) + core;
+    uint8_t* d_mst = d_map + Stage::pad(m * 64);
+    uint8_t* d_sum = d_mst + Stage::pad(m);             // 64 B Edwards x || y, then 32 B of its (unused) compressed form
+    if (n == 0) {
+      uint8_t inf[33] = {0};
+      inf[32] = 0x40;
+      HIP_TRY(hipMemcpyAsync(d_out_point, inf, 33, hipMemcpyHostToDevice, st));
+      if (d_out_xy) HIP_TRY(hipMemsetAsync(d_out_xy, 0, 64, st));
+      HIP_TRY(hipMemsetAsync(d_status, 0, 1, st));
+      HIP_TRY(hipStreamSynchronize(st));     // the source above is a stack buffer
+      return VRFHIP_SUCCESS;
+    }
+    const int m256 = ctx->coords_mont256() ? 1 : 0;
+    vrf::f_bls381fr::launch_te_sw_map(SUITE_BS, n, 1, m256, d_bases_xy, d_map, d_mst, st);
+    vrf::f_bls381fr::launch_msm_coords(SUITE_BS, n, d_map, d_scalars, d_sum + 64, d_sum, d_status, ctx->d_msm_ws, groups, m256, 0u, st);
+    launch_bsw_msm_out(d_sum, d_out_point, d_out_xy, d_status, st);
+    if (d_out_xy && m256) vrf::f_bls381fr::launch_xy_to_mont256(1, d_out_xy, st);
+    HIP_TRY(hipGetLastError());
+    return VRFHIP_SUCCESS;
+  }
   if (ctx->sw) {
     // secp256r1: big-endian scalars, the sum as a 33-byte Sec1 string (0x00 + zeros = the point at infinity)
     const int groups = p256::msm_groups(n ? n : 1, n ? n : 1, ctx->cus);
@@ -1771,7 +1798,6 @@ int32_t vrfhip_pairing_check_batch_dev(vrfhip_ctx* ctx, size_t n, const uint8_t*
                                        void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (n == 0) return VRFHIP_SUCCESS;
   if (!d_g1 || !d_g2 || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1801,7 +1827,6 @@ int32_t vrfhip_pairing_check_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* g1,
                                    int32_t g2_shared, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (n == 0) return VRFHIP_SUCCESS;
   if (!g1 || !g2 || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1827,7 +1852,6 @@ int32_t vrfhip_g1_msm_dev(vrfhip_ctx* ctx, size_t n, const uint8_t* d_bases, con
                           uint8_t* d_status, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!d_out || !d_status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!d_bases || !d_scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if (n > (size_t(1) << 28)) return fail(VRFHIP_ERR_BAD_ARG, "batch too large");
@@ -1848,7 +1872,6 @@ int32_t vrfhip_g1_msm(vrfhip_ctx* ctx, size_t n, const uint8_t* bases, const uin
                       uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!out || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL output");
   if (n && (!bases || !scalars)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1877,7 +1900,6 @@ int32_t vrfhip_pairing_check_batch_rlc_dev(vrfhip_ctx* ctx, size_t n, const uint
                                            const uint8_t seed[32], uint8_t* d_status, uint8_t* d_verdict, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!d_verdict || !seed) return fail(VRFHIP_ERR_BAD_ARG, "NULL verdict or seed");
   if (n && (!d_g1 || !d_g2_shared || !d_status)) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   if (n > (size_t(1) << 28)) return fail(VRFHIP_ERR_BAD_ARG, "batch too large");
@@ -1913,7 +1935,6 @@ int32_t vrfhip_pairing_check_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t*
                                        const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!seed) return fail(VRFHIP_ERR_BAD_ARG, "seed is NULL");
   if (batch_ok) *batch_ok = 1;
   if (n == 0) return VRFHIP_SUCCESS;
@@ -1949,7 +1970,6 @@ int32_t vrfhip_pairing_check_batch_rlc(vrfhip_ctx* ctx, size_t n, const uint8_t*
 int32_t vrfhip_test_pairing_quad_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp12_pairs, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (n == 0) return VRFHIP_SUCCESS;
   if (!fp12_pairs || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1972,7 +1992,6 @@ int32_t vrfhip_test_pairing_quad_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* f
 int32_t vrfhip_test_pairing_oct_ops(vrfhip_ctx* ctx, size_t n, const uint8_t* fp12_pairs, uint8_t* status) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (n == 0) return VRFHIP_SUCCESS;
   if (!fp12_pairs || !status) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -2252,7 +2271,6 @@ int32_t vrfhip_fq_mul_batch(vrfhip_ctx* ctx, size_t n, const uint8_t* a, const u
                             uint8_t* r) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (n == 0) return VRFHIP_SUCCESS;
   if (!a || !b || !r) return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -2440,7 +2458,6 @@ int32_t vrfhip_test_batch_digest(vrfhip_ctx* ctx, size_t n, int32_t n_arr, const
                                  uint64_t index0, uint8_t root[32]) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
   if (ctx->sw) return fail(VRFHIP_ERR_UNSUPPORTED, "not available for the secp256r1 suite (the IETF and Pedersen schemes per proof, hash-to-curve, output hash, keys and point validation are)");
-  if (ctx->bsw) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!root || !arrays || !widths || n == 0) return fail(VRFHIP_ERR_BAD_ARG, "NULL argument or empty batch");
   if (n_arr < 1 || n_arr > DIGEST_MAX_ARRAYS) return fail(VRFHIP_ERR_BAD_ARG, "1..8 arrays");
   if ((ad_len || ad_off) && !ad) return fail(VRFHIP_ERR_BAD_ARG, "ad is NULL");

@@ -24,6 +24,14 @@ VRF_HD Enc33 aux_h_enc(const uint32_t* aux, uint8_t flag) {
   return e;
 }
 
+// x || y (64 bytes, canonical little-endian) of an encoded finite point; zeros for infinity or an invalid item
+VRF_HD void store_xy64(uint8_t* base, size_t i, const Enc33& e, const uint32_t yw[8], bool ok) {
+  uint32_t* p = reinterpret_cast<uint32_t*>(base + i * 64);
+  const bool fin = ok && (e.fl & BSW_INF) == 0u;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { p[k] = fin ? e.w[k] : 0u; p[8 + k] = fin ? yw[k] : 0u; }
+}
+
 // ---- Secret::from_seed / Secret::public ----
 __global__ void __launch_bounds__(BLOCK, 2) k_bsw_secret_from_seed(size_t n, const uint8_t* seeds, uint32_t seed_len,
                                                                    uint8_t* sk_out, uint8_t* pk_out, DevTables T) {
@@ -134,8 +142,9 @@ __global__ void __launch_bounds__(BLOCK, 2) k_bsw_prove_finish(ProveArgs a) {
   }
   fe_batch_inv<true>(inv, dens);                 // secret-dependent values: fixed-shape inversion
   Enc33 e[4];
+  uint32_t syw[4][8];                              // canonical y words (x || y outputs)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) e[j] = bsw_encode_frac(f[j], inv[j]);
+  for (int j = 0; j < 4; ++j) e[j] = bsw_encode_frac(f[j], inv[j], syw[j]);
   const uint32_t* aux = a.ws.aux + i * AUX_WORDS;
   const uint8_t flag = a.ws.flags[i];
   const bool ok = (flag & 1u) != 0;
@@ -160,8 +169,8 @@ __global__ void __launch_bounds__(BLOCK, 2) k_bsw_prove_finish(ProveArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { sb[j] = 0; b[j] = 0; }
     }
-    store33(a.r_out, i, e[3], ok);
-    store33(a.ok_out, i, e[2], ok);
+    if (a.out_affine) { store_xy64(a.r_out, i, e[3], syw[3], ok); store_xy64(a.ok_out, i, e[2], syw[2], ok); }
+    else { store33(a.r_out, i, e[3], ok); store33(a.ok_out, i, e[2], ok); }
     store32(a.sb_out, i, sb);
     if (a.blinding_out) store32(a.blinding_out, i, b);
   }
@@ -171,14 +180,23 @@ __global__ void __launch_bounds__(BLOCK, 2) k_bsw_prove_finish(ProveArgs a) {
   }
   store32(a.s, i, s);
   if (a.c) store32(a.c, i, c);
-  store33(a.gamma, i, e[0], ok);
-  if (a.pk_out) store33(a.pk_out, i, e[1], ok);
+  if (a.out_affine) {
+    // x || y of the Weierstrass points instead of the encodings: the caller builds typed values without a square root
+    store_xy64(a.gamma, i, e[0], syw[0], ok);
+    if (a.pk_out) store_xy64(a.pk_out, i, e[1], syw[1], ok);
+  } else {
+    store33(a.gamma, i, e[0], ok);
+    if (a.pk_out) store33(a.pk_out, i, e[1], ok);
+  }
   if (a.h_out) store33(a.h_out, i, h_enc);
   if (a.status) a.status[i] = ok ? ST_OK : ST_INVALID_DATA;
 }
 
 // ---- IETF verify, stage 1: decode pk, H, Gamma; GLV window tables; canonical encodings for the challenge ----
-// aux: 3 x 8 words of x, then one word holding the three flag bytes
+// aux: 3 x 8 words of x, then one word holding the three flag bytes.
+// a.affine_in (1: canonical, 2: Montgomery-256): the three points come as Weierstrass x || y (64 bytes): range and curve
+// checks instead of the square root.  a.key_index (keyed verification): pk is not read -- the key set holds its canonical
+// encoding, its validity and its comb (the U half runs k_bsw_verify_comb_u).
 __global__ void __launch_bounds__(BLOCK, 2) k_bsw_verify_decode(VerifyArgs a) {
   size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= a.n) return;
@@ -187,16 +205,39 @@ __global__ void __launch_bounds__(BLOCK, 2) k_bsw_verify_decode(VerifyArgs a) {
   bool valid = true;
   uint32_t fls = 0;
 #pragma unroll 1
-  for (int p = 0; p < 3; ++p) {
-    const Enc33 e = load33(p == 0 ? a.pk : p == 1 ? a.h : a.gamma, i);
+  for (int p = a.key_index ? 1 : 0; p < 3; ++p) {
+    const uint8_t* src = p == 0 ? a.pk : p == 1 ? a.h : a.gamma;
     FeN x, y;
-    valid = bsw_decode<BswS>(x, y, e, a.T.sq) && valid;
+    Enc33 ce;
+    if (a.affine_in) {
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(src + i * 64);
+      uint32_t xin[8], yin[8], yw[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { xin[j] = w[j]; yin[j] = w[8 + j]; }
+      valid = valid && !u256_ge(xin, vrfk::Q32) && !u256_ge(yin, vrfk::Q32);
+      const FeN sx = fe_from_abi(ce.w, xin, a.affine_in == 2), sy = fe_from_abi(yw, yin, a.affine_in == 2);   // ce.w, yw: canonical words
+      valid = fe_eq(fe_sqr(sy), bsw_rhs(sx)) && valid;
+      valid = sw_to_te<BswS>(x, y, sx, sy) && valid;
+      ce.fl = u256_gt(yw, vrfk::QM1H32) ? BSW_NEG : 0u;
+    } else {
+      const Enc33 e = load33(src, i);
+      valid = bsw_decode<BswS>(x, y, e, a.T.sq) && valid;
+      ce = enc33_canonical(e);
+    }
     if ((a.check_mask >> p) & 1u) valid = in_prime_subgroup<BswS>(x, y, a.T.sq) && valid;       // bit p: pk, H, Gamma
     build_glv_tables<BswS>(tabs + p * 2 * WIN_TABLE_WORDS, x, y);
-    const Enc33 ce = enc33_canonical(e);
 #pragma unroll
     for (int j = 0; j < 8; ++j) aux[8 * p + j] = ce.w[j];
     fls |= ce.fl << (8 * p);
+  }
+  if (a.key_index) {
+    const uint32_t key = a.key_index[i];
+    const bool key_ok = key < a.n_keys && a.key_valid[key] != 0;
+    valid = valid && key_ok;
+    const Enc33 ke = load33(a.pk, key_ok ? key : 0);          // a.pk: the key set's canonical encodings
+#pragma unroll
+    for (int j = 0; j < 8; ++j) aux[j] = ke.w[j];
+    fls |= ke.fl & 0xC0u;
   }
   aux[24] = fls;
   a.ws.flags[i] = valid ? 1 : 0;
@@ -221,6 +262,62 @@ __global__ void __launch_bounds__(BLOCK) k_bsw_verify_straus(VerifyArgs a) {
   bsw_load_cs(c, s, a.c, a.s, i);
   verify_straus_item<BswS, HALF>(a.ws.pts + i * PROVE_PTS_WORDS + HALF * UV_WORDS, a.T,
                                  a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS), c, s);
+}
+
+// stage 2, keyed U half: U = s*G - c*Y from two fixed-base combs (k_verify_comb_u's arithmetic)
+__global__ void __launch_bounds__(BLOCK) k_bsw_verify_comb_u(VerifyArgs a) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= a.n) return;
+  uint32_t c[8], s[8];
+  bsw_load_cs(c, s, a.c, a.s, i);
+  const uint32_t key = a.key_index[i] < a.n_keys ? a.key_index[i] : 0;
+  PtE r = gcomb_mul<BswS>(a.T.g_comb, s);
+  r = comb_add<BswS>(r, a.key_combs + (size_t)key * COMB_WORDS, c, true);
+  uint32_t* out = a.ws.pts + i * PROVE_PTS_WORDS;
+  fe_store(out, r.X); fe_store(out + NL, r.Y); fe_store(out + 2 * NL, r.Z);
+}
+
+// ---- key sets: validated keys (encodings canonicalised in place), their Edwards coordinates for the comb build ----
+__global__ void __launch_bounds__(BLOCK) k_bsw_keyset_decode(size_t n, uint8_t* pks, uint32_t* xy, uint8_t* valid, DevTables T) {
+  size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const Enc33 e = load33(pks, i);
+  FeN x, y;
+  bool ok = bsw_decode<BswS>(x, y, e, T.sq);
+  ok = ok && in_prime_subgroup<BswS>(x, y, T.sq);
+  // an invalid key gets the identity's tables: every proof that names it is reported InvalidData anyway
+  fe_store(xy + i * 2 * NL, fe_select(ok, x, fe_zero()));
+  fe_store(xy + i * 2 * NL + NL, fe_select(ok, y, fe_one()));
+  valid[i] = ok ? 1 : 0;
+  store33(pks, i, enc33_canonical(e));
+}
+__global__ void __launch_bounds__(64, 2) k_bsw_keyset_comb(size_t n_keys, const uint32_t* xy, uint32_t* combs, uint32_t* prefix) {
+  size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;           // one lane per (key, row)
+  if (t >= n_keys * COMB_ROWS) return;
+  const size_t key = t / COMB_ROWS;
+  const int w = (int)(t % COMB_ROWS);
+  const FeN x = fe_load<1, 2>(xy + key * 2 * NL), y = fe_load<1, 2>(xy + key * 2 * NL + NL);
+  comb_build_row<BswS>(combs + key * COMB_WORDS + (size_t)w * COMB_COLS * PTA_WORDS, prefix + t * COMB_COLS * NL, x, y, w);
+}
+
+// ---- MSM over caller-supplied Weierstrass bases: the Edwards sum (x || y, canonical) -> 33-byte encoding + Weierstrass x || y ----
+// (a base without an Edwards image -- y = 0, a coordinate >= q -- left te_sw_map as the row (0, 0), which the Edwards MSM
+// reports: it is not on that curve)
+__global__ void k_bsw_msm_out(const uint8_t* te_xy, uint8_t* out33, uint8_t* out_xy, uint8_t* status) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const uint8_t bad = status[0];
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(te_xy);
+  uint32_t xw[8], yw[8], cw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { xw[j] = w[j]; yw[j] = w[8 + j]; }
+  PtE p = te_from_affine(fe_from_abi(cw, xw, false), fe_from_abi(cw, yw, false));
+  const SwFrac f = bsw_frac<BswS>(p.X, p.Y, p.Z);
+  uint32_t syw[8];
+  const Enc33 e = bsw_encode_frac(f, fe_inv(f.den), syw);
+  const bool ok = bad == 0;
+  store33(out33, 0, ok ? e : enc33_infinity());
+  if (out_xy) store_xy64(out_xy, 0, e, syw, ok);
+  status[0] = ok ? ST_OK : ST_INVALID_DATA;
 }
 
 // stage 3: encode U, V (one inversion); challenge; compare
@@ -452,10 +549,22 @@ void launch_bsw_ietf_verify(const VerifyArgs& a, hipStream_t st, hipEvent_t* ev)
   if (ev) (void)hipEventRecord(ev[1], st);
   hipLaunchKernelGGL(k_bsw_verify_straus<1>, grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[2], st);
-  hipLaunchKernelGGL(k_bsw_verify_straus<0>, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  if (a.key_index) hipLaunchKernelGGL(k_bsw_verify_comb_u, grid_for(a.n), dim3(BLOCK), 0, st, a);
+  else hipLaunchKernelGGL(k_bsw_verify_straus<0>, grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[3], st);
   hipLaunchKernelGGL(k_bsw_verify_finish, grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[4], st);
+}
+// pks: [n_keys][33] device memory, canonicalised in place; xy: [n_keys][18] words, prefix: [n_keys * 32][255][9] words of scratch
+void launch_bsw_keyset_build(size_t n_keys, uint8_t* pks, uint32_t* xy, uint8_t* valid, uint32_t* combs, uint32_t* prefix, DevTables T,
+                             hipStream_t st) {
+  if (!n_keys) return;
+  hipLaunchKernelGGL(k_bsw_keyset_decode, grid_for(n_keys), dim3(BLOCK), 0, st, n_keys, pks, xy, valid, T);
+  hipLaunchKernelGGL(k_bsw_keyset_comb, dim3((unsigned)((n_keys * COMB_ROWS + 63) / 64)), dim3(64), 0, st, n_keys, xy, combs, prefix);
+}
+// after launch_te_sw_map (bases -> Edwards) and launch_msm_coords (the Edwards sum te_xy, status[0])
+void launch_bsw_msm_out(const uint8_t* te_xy, uint8_t* out33, uint8_t* out_xy, uint8_t* status, hipStream_t st) {
+  hipLaunchKernelGGL(k_bsw_msm_out, dim3(1), dim3(64), 0, st, te_xy, out33, out_xy, status);
 }
 void launch_bsw_pedersen_verify(const PedersenVerifyArgs& a, hipStream_t st, hipEvent_t* ev) {
   if (a.n == 0) return;

@@ -537,7 +537,7 @@ def test_gpu_consistency_with_the_edwards_suite_at_scale(gpu):
 
 
 @pytest.mark.gpu
-def test_gpu_multi_context_and_refused_entry_points(gpu):
+def test_gpu_multi_context(gpu):
     from ark_ec_vrfs_amd import BandersnatchSwSha512Tai, Context, ietf_prove_batch_multi, ietf_verify_batch_multi
     n = 700
     seeds = _u8(b"m%07d" % i for i in range(n))
@@ -552,8 +552,108 @@ def test_gpu_multi_context_and_refused_entry_points(gpu):
     stm = ietf_verify_batch_multi([gpu, c2], pk, r["input"], r["output"], r["c"], s2, ad=b"")
     assert (stm == st).all() and (st[3::11] == 1).all() and st.sum() == len(st[3::11])
     c2.close()
+@pytest.mark.gpu
+def test_gpu_xy_forms_key_sets_and_msm(gpu):
+    """The remaining entry points of the suite: x || y inputs (no square root) and outputs, verification against a resident
+    key set, MSM over Weierstrass bases -- each against the compressed path or the oracle."""
+    from ark_ec_vrfs_amd import BandersnatchSha512Ell2, Context
+    rnd = random.Random(77)
+    n = 512
+    seeds = _u8(b"x%07d" % (i % 16) for i in range(n))                  # 16 distinct keys
+    sk, pk = gpu.secret_from_seed_batch(seeds)
+    msgs = np.frombuffer(b"".join(b"%024d" % i for i in range(n)), np.uint8).reshape(n, 24)
+    ad = b"xy"
+    r = gpu.ietf_prove_batch(sk, msgs=msgs, ad=ad)
+    t2 = _torsion2()
+    # ---- x || y inputs ----
+    def sw_xy(enc):
+        stv, xyv = gpu.point_validate_batch(enc, want_xy=True)
+        assert (stv == 0).all()
+        return xyv
+    xs = [sw_xy(a) for a in (pk, r["input"], r["output"])]
+    assert xs[2][5].tobytes() == xy(bo.point_decode(r["output"][5].tobytes())[1])
+    assert (gpu.ietf_verify_batch_affine(*xs, r["c"], r["s"], ad=ad) == 0).all()
+    bad = [a.copy() for a in xs]
+    cc, ss = r["c"].copy(), r["s"].copy()
+    want = np.zeros(n, np.uint8)
+    for i in range(0, n, 7):
+        kind = (i // 7) % 6
+        if kind == 0: ss[i, 1] ^= 2; want[i] = 1
+        elif kind == 1: bad[2][i, 40] ^= 1; want[i] = 2                                            # y off the curve
+        elif kind == 2: bad[0][i, :32] = np.frombuffer(le(Q + 1), np.uint8); want[i] = 2           # x >= q
+        elif kind == 3:                                                                             # on the curve, outside the subgroup
+            bad[1][i] = np.frombuffer(xy(bo.add(bo.point_decode(r["input"][i].tobytes())[1], t2[i % 3])), np.uint8); want[i] = 2
+        elif kind == 4: bad[2][i] = xs[2][(i + 1) % n]; want[i] = 1
+        elif kind == 5: bad[0][i] = np.frombuffer(xy(t2[0]), np.uint8); want[i] = 2                # y = 0
+    got = gpu.ietf_verify_batch_affine(*bad, cc, ss, ad=ad)
+    assert (got == want).all(), (got[::7], want[::7])
+    # ---- x || y outputs, canonical and in arkworks' in-memory Montgomery form; they feed the x || y verifier ----
+    for flags in (gpu.PROVE_POINTS_AFFINE, gpu.PROVE_POINTS_AFFINE | gpu.COORDS_MONT256):
+        gpu.set_flags(flags)
+        ra = gpu.ietf_prove_batch(sk, msgs=msgs, ad=ad)
+        pa = gpu.pedersen_prove_batch(sk[:64], msgs=msgs[:64], ad=ad)
+        assert ra["output"].shape == (n, 64) and (ra["c"] == r["c"]).all() and (ra["s"] == r["s"]).all()
+        if flags == gpu.PROVE_POINTS_AFFINE:
+            assert (ra["output"] == xs[2]).all() and (ra["pk"] == xs[0]).all()
+        else:
+            R256 = (1 << 256) % Q
+            g5 = bo.point_decode(r["output"][5].tobytes())[1]
+            assert ra["output"][5].tobytes() == le(g5[0] * R256 % Q) + le(g5[1] * R256 % Q)
+        h_xy = sw_xy(r["input"]) if flags == gpu.PROVE_POINTS_AFFINE else None
+        if h_xy is not None:
+            assert (gpu.ietf_verify_batch_affine(ra["pk"], h_xy, ra["output"], ra["c"], ra["s"], ad=ad) == 0).all()
+        else:
+            stv, hm = gpu.point_validate_batch(r["input"], want_xy=True)            # x || y out follows the flag too
+            assert (gpu.ietf_verify_batch_affine(ra["pk"], hm, ra["output"], ra["c"], ra["s"], ad=ad) == 0).all()
+        gpu.set_flags(0)
+        pc = gpu.pedersen_prove_batch(sk[:64], msgs=msgs[:64], ad=ad)
+        assert (pa["s"] == pc["s"]).all() and (pa["sb"] == pc["sb"]).all()
+        if flags == gpu.PROVE_POINTS_AFFINE:
+            for k_ in ("output", "pk_com", "r", "ok"):
+                assert (pa[k_] == sw_xy(pc[k_])).all(), k_
+    # ---- key sets ----
+    keys = pk[:16].copy()
+    keys[3, 32] |= 0x2a                                                      # junk under the flags: accepted, hashed canonically
+    keys[7] = np.frombuffer(bo.point_encode(bo.add(bo.point_decode(pk[7].tobytes())[1], t2[1])), np.uint8)     # outside the subgroup
+    ks, kst = gpu.keyset_create(keys)
+    assert list(kst) == [0] * 7 + [2] + [0] * 8
+    idx = (np.arange(n) % 16).astype(np.uint32)
+    idx[11] = 99                                                             # no such key
+    s2 = r["s"].copy(); s2[5::16, 0] ^= 1
+    got = gpu.ietf_verify_batch_keyed(ks, idx, r["input"], r["output"], r["c"], s2, ad=ad)
+    want = gpu.ietf_verify_batch(pk, r["input"], r["output"], r["c"], s2, ad=ad)
+    want[idx == 7] = 2
+    want[11] = 2
+    assert (got == want).all() and (want[5::16] == 1).all()
+    ks.close()
+    # ---- MSM over Weierstrass bases ----
+    m = 200
+    ks_ = [rnd.randrange(1, R) for _ in range(m)]
+    pts = [bo.mul(rnd.randrange(1, R), bo.G) for _ in range(m)]
+    acc = None
+    for k_, p_ in zip(ks_, pts):
+        acc = bo.add(acc, bo.mul(k_, p_))
+    enc, sxy = gpu.msm(_u8(xy(p_) for p_ in pts), _u8(le(k_) for k_ in ks_))
+    assert enc == bo.point_encode(acc) and sxy == xy(acc)
+    enc, sxy = gpu.msm(_u8([xy(pts[0]), xy(bo.neg(pts[0]))]), _u8([le(5), le(5)]))
+    assert enc == bytes(32) + b"\x40" and sxy == bytes(64)
+    enc, sxy = gpu.msm(np.zeros((0, 64), np.uint8), np.zeros((0, 32), np.uint8))
+    assert enc == bytes(32) + b"\x40"
+    for bad_base in (xy(t2[0]), le(Q) + le(1), xy((pts[0][0], (pts[0][1] + 1) % Q))):
+        with pytest.raises(Exception):
+            gpu.msm(_u8([xy(pts[0]), bad_base]), _u8([le(1), le(1)]))
+    # 2^14 bases: equal to the Edwards suite's MSM over the mapped bases, mapped back
+    te = Context(0, BandersnatchSha512Ell2)
+    big = 1 << 14
+    bsk, bpk = gpu.secret_from_seed_batch(np.arange(big, dtype=np.uint64).view(np.uint8).reshape(big, 8))
+    bases = sw_xy(bpk)
+    scal = bsk[::-1].copy()
+    enc, sxy = gpu.msm(bases, scal)
+    te_bases, stt = te.te_sw_map_batch(bases, to_te=True)
+    assert (stt == 0).all()
+    _, te_sum = te.msm(te_bases, scal)
+    back, stb = te.te_sw_map_batch(np.frombuffer(te_sum, np.uint8).reshape(1, 64), to_te=False)
+    assert stb[0] == 0 and back[0].tobytes() == sxy and enc[:32] == sxy[:32]
+    te.close()
     with pytest.raises(Exception):
-        gpu.msm(np.zeros((4, 64), np.uint8), np.zeros((4, 32), np.uint8))
-    with pytest.raises(Exception):
-        gpu.ietf_verify_batch_affine(np.zeros((2, 64), np.uint8), np.zeros((2, 64), np.uint8), np.zeros((2, 64), np.uint8),
-                                     np.zeros((2, 32), np.uint8), np.zeros((2, 32), np.uint8))
+        gpu.pedersen_verify_batch_rlc(*[np.zeros((2, 64), np.uint8)] * 5, np.zeros((2, 32), np.uint8), np.zeros((2, 32), np.uint8), affine=True)
