@@ -92,11 +92,13 @@ typedef enum vrfhip_suite {
    * larger of {y, q - y}; 0x40: the point at infinity, written with x = 0; both = error; the six low bits are not looked at) --
    * scalars 32-byte little-endian, `Output::hash` 64 bytes.  The arithmetic is the twisted-Edwards suite's (same group:
    * points cross `utils::te_sw_map` at the codec, csrc/bsw_core.cuh), so speed and the checked-decode rules are that suite's.
-   * Entry points: vrfhip_secret_from_seed_batch, vrfhip_hash_to_curve_batch, vrfhip_output_hash_batch,
-   * vrfhip_point_validate_batch (x || y out = Weierstrass coordinates), vrfhip_ietf_prove_batch / _verify_batch (+ _dev,
-   * _multi), vrfhip_ietf_verify_batch_alpha, vrfhip_pedersen_prove_batch / _verify_batch (+ _dev, _multi; needs a blinding
-   * base in the descriptor), vrfhip_te_sw_map_batch.  Everything else returns VRFHIP_ERR_UNSUPPORTED (x || y forms of the
-   * schemes, key sets, MSM, the batched Pedersen verifier).  PARITY UNPINNED: no vector of this suite is on this machine;
+   * Entry points: every one the twisted-Edwards suites have -- keys, hash-to-curve, output hash, point validation, the IETF
+   * scheme (vrfhip_ietf_prove_batch / _verify_batch + _dev, _multi, _alpha, _affine, _keyed with vrfhip_keyset_create over
+   * 33-byte keys), the Pedersen scheme (per proof and vrfhip_pedersen_verify_batch_rlc; needs a blinding base in the
+   * descriptor), vrfhip_msm (bases and out_xy: WEIERSTRASS x || y; the sum as a 33-byte string), vrfhip_te_sw_map_batch, the
+   * pairing / G1 entry points -- except the x || y form of the batched Pedersen verifier (vrfhip_pedersen_verify_batch_rlc_affine:
+   * VRFHIP_ERR_UNSUPPORTED).  Every x || y this suite reads or writes (VRFHIP_FLAG_PROVE_POINTS_AFFINE, the _affine verifier,
+   * vrfhip_point_validate_batch) is in Weierstrass coordinates, little-endian, Montgomery-256 under VRFHIP_FLAG_COORDS_MONT256.  PARITY UNPINNED: no vector of this suite is on this machine;
    * the suite string, the generator (= te_sw_map image of the twisted-Edwards suite's) and the flag convention are
    * recollections; what is checked is consistency with the vector-pinned twisted-Edwards suite through the map
    * (tests/test_bandersnatch_sw.py).  With the subgroup test switched off (VRFHIP_FLAG_PREVALIDATED_*) a point with y = 0 is

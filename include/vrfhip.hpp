@@ -91,7 +91,7 @@ struct Secp256r1Sha256Tai {
 };
 // `suites::bandersnatch_sw` (upstream "Bandersnatch_SW_SHA-512_TAI"): the Bandersnatch group on its short-Weierstrass model;
 // ArkworksCodec over SWAffine -- 33-byte compressed points (x little-endian, then a flag byte), little-endian scalars, SHA-512.
-// No key sets and no x || y forms on this suite (include/vrfhip.h).
+// (The x || y form of the batched Pedersen verifier is the one entry point this suite lacks: include/vrfhip.h.)
 struct BandersnatchSwSha512Tai {
   static constexpr vrfhip_suite ID = VRFHIP_SUITE_BANDERSNATCH_SW_SHA512_TAI;
   static constexpr const char* SUITE_ID = "Bandersnatch_SW_SHA-512_TAI";
@@ -149,10 +149,10 @@ template <class S> struct Public { Point<S> encoded; };    // `Public`: compress
 template <class S>
 class KeySet {
  public:
-  static_assert(S::EDWARDS, "key sets exist for the twisted-Edwards suites");
   KeySet(const Context<S>& ctx, const std::vector<Public<S>>& keys) : valid_(keys.size()) {
-    Bytes flat(keys.size() * 32), st(keys.size());
-    for (size_t i = 0; i < keys.size(); ++i) std::memcpy(flat.data() + 32 * i, keys[i].encoded.data(), 32);
+    constexpr size_t W = S::POINT_LEN;                    // every suite has key sets (secp256r1, bandersnatch_sw: round 4)
+    Bytes flat(keys.size() * W), st(keys.size());
+    for (size_t i = 0; i < keys.size(); ++i) std::memcpy(flat.data() + W * i, keys[i].encoded.data(), W);
     check(vrfhip_keyset_create(ctx.handle(), keys.size(), flat.data(), st.data(), &h_), "vrfhip_keyset_create");
     for (size_t i = 0; i < keys.size(); ++i) valid_[i] = st[i] == VRFHIP_ST_OK;
   }
@@ -456,7 +456,7 @@ using XY = std::array<uint8_t, 64>;           // an affine point as x || y, 32-b
 namespace detail {
 template <class S>
 std::vector<std::optional<XY>> te_sw_map(const Context<S>& ctx, const std::vector<XY>& pts, int32_t to_te) {
-  static_assert(S::EDWARDS, "te_sw_map: the suite's curve is not twisted Edwards");
+  static_assert(S::EDWARDS || S::ID == VRFHIP_SUITE_BANDERSNATCH_SW_SHA512_TAI, "te_sw_map: the suite's curve has no twisted-Edwards model");
   const size_t n = pts.size();
   Bytes in = ark_vrf_hip::detail::column(pts, [](const XY& t) -> const XY& { return t; }), out(64 * n + 1), st(n + 1);
   check(vrfhip_te_sw_map_batch(ctx.handle(), n, to_te, in.data(), out.data(), st.data()), "vrfhip_te_sw_map_batch");

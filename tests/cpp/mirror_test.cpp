@@ -180,6 +180,20 @@ static int bsw_section() {
   const auto pres = pedersen::verify_batch(ctx, pitems, Bytes{9}, &fast);
   CHECK(!fast);
   for (size_t i = 0; i < pitems.size(); ++i) CHECK(i == 7 ? pres[i] == Error::VerificationFailure : !pres[i].has_value());
+  {
+    // key sets on this suite too: the items' keys, named by index
+    std::vector<Public<W>> keys;
+    for (size_t i = 0; i < 8; ++i) keys.push_back(sks[i].public_key());
+    KeySet<W> ks(ctx, keys);
+    std::vector<Secret<W>> who;
+    std::vector<Bytes> what;
+    std::vector<uint32_t> idx;
+    for (size_t i = 0; i < 64; ++i) { idx.push_back((uint32_t)(i % 8)); who.push_back(sks[i % 8]); what.push_back(msgs[i]); }
+    auto kitems = ietf::prove_batch(ctx, who, what, Bytes{3});
+    kitems[9].proof.s[0] ^= 1;
+    const auto kres = ietf::verify_batch_keyed(ctx, ks, idx, kitems, Bytes{3});
+    for (size_t i = 0; i < kitems.size(); ++i) CHECK(i == 9 ? kres[i] == Error::VerificationFailure : !kres[i].has_value());
+  }
   std::printf("mirror_test bandersnatch_sw ok: %zu IETF proofs, %zu Pedersen proofs\n", n, pitems.size());
   return 0;
 }
