@@ -638,7 +638,7 @@ def cfg_suite_ietf(D, args, tag, suite_cls, oracle_suite, title, lo, want_cpu):
             el_a, _ = timed(D, fn_a, max(2, args.config_steps), 1)
             res["ietf_verify_" + tag]["from_alpha"] = {"value": D.world * n * max(2, args.config_steps) / el_a, "unit": "verifies/s",
                                                        "ms_per_step": el_a / max(2, args.config_steps) * 1e3}
-        if sw:
+        if sw or bsw:
             # the same verification from typed values: pk, input, output as x || y (no decompression)
             from ark_ec_vrfs_amd import _lib as _l
             xy = [torch.empty((n, 64), dtype=torch.uint8, device=D.dev) for _ in range(3)]

@@ -51,6 +51,8 @@ if "ietf_prove_bandersnatch_sw" in c:
     row("f4 IETF verify 2^20, bandersnatch_sw, checked", c["ietf_verify_bandersnatch_sw"], "verifies/s", ["decode", "straus_v", "straus_u", "finish"])
     if "from_alpha" in c["ietf_verify_bandersnatch_sw"]:
         row("… from (pk, alpha, proof)", c["ietf_verify_bandersnatch_sw"]["from_alpha"], "verifies/s")
+    if "affine_inputs" in c["ietf_verify_bandersnatch_sw"]:
+        row("… pk, input, output as Weierstrass x ‖ y (typed callers)", c["ietf_verify_bandersnatch_sw"]["affine_inputs"], "verifies/s")
     row("… Pedersen prove 2^20, bandersnatch_sw (placeholder blinding base)", c["pedersen_prove_bandersnatch_sw"], "proofs/s", ["tai_find+prepare", "mul", "finish"])
     row("… Pedersen verify 2^20, bandersnatch_sw, per proof", c["pedersen_verify_bandersnatch_sw"], "verifies/s", ["decode", "eq_h", "eq_g", "finish"])
     row("… batched (digest + one MSM over 5n + 2 points)", c["pedersen_verify_batched_bandersnatch_sw"], "verifies/s", ["decode", "msm_buckets", "msm_final"])
