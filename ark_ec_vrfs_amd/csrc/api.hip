@@ -81,7 +81,7 @@ constexpr size_t DEFAULT_CHUNK = size_t(1) << 20;
 const char BSW_UNSUPPORTED_MSG[] =
     "not available for the bandersnatch_sw suite (secret keys, hash-to-curve, output hash, point validation, the IETF scheme incl. "
     "verification from alpha, the x || y forms, key sets, the Pedersen scheme per proof and batched, MSM, and the pairing / G1 "
-    "entry points are; the x || y form of the batched Pedersen verifier and the twisted-Edwards test primitives are not)";
+    "entry points are; the twisted-Edwards test primitives are not)";
 
 }  // namespace
 
@@ -1489,8 +1489,6 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
                      const uint8_t seed[32], uint8_t* d_status,
                      uint8_t* d_fail_flag, void* stream) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the batched Pedersen verifier takes Sec1 points (the x || y form is not built)");
-  if (ctx->bsw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!d_fail_flag || !seed) return fail(VRFHIP_ERR_BAD_ARG, "NULL fail flag or seed");
   if (n && (!d_input || !d_output || !d_pk_com || !d_r || !d_ok || !d_s || !d_sb || !d_status))
     return fail(VRFHIP_ERR_BAD_ARG, "NULL array");
@@ -1521,8 +1519,10 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
       p256::RlcArgs a{};
       a.n = m;
       a.index0 = base;
-      a.h = d_input + base * 33; a.gamma = d_output + base * 33; a.pk_com = d_pk_com + base * 33;
-      a.r = d_r + base * 33; a.ok = d_ok + base * 33; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
+      const size_t pw = affine ? 64 : 33;
+      a.h = d_input + base * pw; a.gamma = d_output + base * pw; a.pk_com = d_pk_com + base * pw;
+      a.r = d_r + base * pw; a.ok = d_ok + base * pw; a.s = d_s + base * 32; a.sb = d_sb + base * 32;
+      a.affine_in = affine ? (ctx->coords_mont256() ? 2 : 1) : 0;
       a.ad = make_view(d_ad, d_ad_off ? d_ad_off + base : nullptr, ad_len, true);
       a.status = d_status + base;
       a.L = p256::msm_layout(N, 3 * m + 2, p256_groups(N, 3 * m + 2), ctx->d_msm_ws);
@@ -1532,7 +1532,7 @@ int32_t rlc_dev_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* d_in
       a.str = ctx->T.sq.str;
       DigestSrc ds{};
       const uint8_t* arr[7] = {a.h, a.gamma, a.pk_com, a.r, a.ok, a.s, a.sb};
-      for (int j = 0; j < 7; ++j) { ds.p[j] = arr[j]; ds.w[j] = j < 5 ? 33u : 32u; }
+      for (int j = 0; j < 7; ++j) { ds.p[j] = arr[j]; ds.w[j] = j < 5 ? (uint32_t)pw : 32u; }
       ds.n_arr = 7;
       ds.ad = a.ad;
       launch_batch_digest(ds, m, base, d_dws, d_rt, st);
@@ -1594,8 +1594,6 @@ int32_t rlc_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* inp
                       const uint8_t* ad, const uint32_t* ad_off, uint32_t ad_len,
                       const uint8_t seed[32], uint8_t* status, int32_t* batch_ok) {
   if (!ctx) return fail(VRFHIP_ERR_BAD_ARG, "ctx is NULL");
-  if (ctx->sw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, "secp256r1: the batched Pedersen verifier takes Sec1 points (the x || y form is not built)");
-  if (ctx->bsw && affine) return fail(VRFHIP_ERR_UNSUPPORTED, BSW_UNSUPPORTED_MSG);
   if (!seed) return fail(VRFHIP_ERR_BAD_ARG, "seed is NULL");
   if (batch_ok) *batch_ok = 1;
   if (n == 0) return VRFHIP_SUCCESS;
@@ -1606,7 +1604,7 @@ int32_t rlc_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* inp
   std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   DeviceGuard guard(ctx->device);
   const size_t pw = affine ? 64 : ctx->pt_bytes();
-  size_t need = 5 * Stage::pad(n * pw) + (affine ? 5 : 0) * Stage::pad(n * 32) + 2 * Stage::pad(n * 32) +
+  size_t need = 5 * Stage::pad(n * pw) + (affine ? 5 : 0) * Stage::pad(n * ctx->pt_bytes()) + 2 * Stage::pad(n * 32) +
                 Stage::pad(adb + 1) + Stage::pad((n + 1) * 4) + Stage::pad(n) + 256;
   int32_t rc = ensure_stage(ctx, need);
   if (rc) return rc;
@@ -1637,10 +1635,16 @@ int32_t rlc_host_impl(vrfhip_ctx* ctx, size_t n, bool affine, const uint8_t* inp
     // rejected as InvalidData keep that status (an off-curve affine point has no compressed form).
     if (batch_ok) *batch_ok = 0;
     if (affine) {
+      const size_t ew = ctx->pt_bytes();
       for (int i = 0; i < 5; ++i) {
-        uint8_t* enc = sg.take(n * 32);
-        if (ctx->coords_mont256()) FIELD_CALL(ctx, launch_xy_from_mont256(n, d[i], ctx->stream));      // the staged copy, in place
-        FIELD_CALL(ctx, launch_affine_compress(n, d[i], enc, ctx->T.sq.str.flags, ctx->stream));
+        uint8_t* enc = sg.take(n * ew);
+        const int m256 = ctx->coords_mont256() ? 1 : 0;
+        if (ctx->sw) p256::launch_affine_compress(n, d[i], m256, enc, ctx->stream);
+        else if (ctx->bsw) launch_bsw_affine_compress(n, d[i], m256, enc, ctx->stream);
+        else {
+          if (m256) FIELD_CALL(ctx, launch_xy_from_mont256(n, d[i], ctx->stream));      // the staged copy, in place
+          FIELD_CALL(ctx, launch_affine_compress(n, d[i], enc, ctx->T.sq.str.flags, ctx->stream));
+        }
         d[i] = enc;
       }
     }

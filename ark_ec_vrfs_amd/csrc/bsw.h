@@ -1,7 +1,7 @@
 // bsw.h -- launch interface of `suites::bandersnatch_sw` (/root/reference src/lib.rs:14) between the C ABI (api.hip) and
 // k_bsw.hip.  The suite runs on a Bandersnatch (base field 0) context: same tables, same workspace, same launch arguments
 // (vrf_types.h) as the twisted-Edwards suite, with 33-byte compressed short-Weierstrass points in every point array
-// (bsw_core.cuh).  Not built for this suite: the x || y form of the batched Pedersen verifier.
+// (bsw_core.cuh).
 #pragma once
 #include "kernels.h"
 
@@ -26,7 +26,9 @@ void launch_bsw_keyset_build(size_t n_keys, uint8_t* pks, uint32_t* xy, uint8_t*
                              hipStream_t st);
 // the Edwards MSM's sum (te_xy: x || y canonical; status[0] its verdict) -> 33-byte encoding, Weierstrass x || y (nullable)
 void launch_bsw_msm_out(const uint8_t* te_xy, uint8_t* out33, uint8_t* out_xy, uint8_t* status, hipStream_t st);
-// the batched Pedersen verifier (launch_pedersen_rlc's contract, msm.cuh layout); a.affine_in must be 0
+// the batched Pedersen verifier (launch_pedersen_rlc's contract, msm.cuh layout); a.affine_in: Weierstrass x || y points
+// (and n x 64 B x || y -> n x 33 B encodings, for the per-proof fallback of a failed x || y batch; mont256: the form of xy)
+void launch_bsw_affine_compress(size_t n, const uint8_t* xy, int mont256, uint8_t* enc33, hipStream_t st);
 void launch_bsw_pedersen_rlc(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev = nullptr);
 
 VRF_NS_END

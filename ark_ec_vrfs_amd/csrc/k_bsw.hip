@@ -192,6 +192,21 @@ __global__ void __launch_bounds__(BLOCK, 2) k_bsw_prove_finish(ProveArgs a) {
   if (a.status) a.status[i] = ok ? ST_OK : ST_INVALID_DATA;
 }
 
+// A point handed over as Weierstrass x || y (64 bytes; mont256: arkworks' in-memory Montgomery limbs): range and curve checks
+// instead of the square root, then the same map.  ce: the encoding `point_encode` gives it.
+VRF_HD bool bsw_from_xy(FeN& tx, FeN& ty, Enc33& ce, const uint8_t* src, size_t i, bool mont256) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(src + i * 64);
+  uint32_t xin[8], yin[8], yw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { xin[j] = w[j]; yin[j] = w[8 + j]; }
+  bool ok = !u256_ge(xin, vrfk::Q32) && !u256_ge(yin, vrfk::Q32);
+  const FeN sx = fe_from_abi(ce.w, xin, mont256), sy = fe_from_abi(yw, yin, mont256);      // ce.w, yw: canonical words
+  ok = fe_eq(fe_sqr(sy), bsw_rhs(sx)) && ok;
+  ok = sw_to_te<BswS>(tx, ty, sx, sy) && ok;
+  ce.fl = u256_gt(yw, vrfk::QM1H32) ? BSW_NEG : 0u;
+  return ok;
+}
+
 // ---- IETF verify, stage 1: decode pk, H, Gamma; GLV window tables; canonical encodings for the challenge ----
 // aux: 3 x 8 words of x, then one word holding the three flag bytes.
 // a.affine_in (1: canonical, 2: Montgomery-256): the three points come as Weierstrass x || y (64 bytes): range and curve
@@ -210,15 +225,7 @@ __global__ void __launch_bounds__(BLOCK, 2) k_bsw_verify_decode(VerifyArgs a) {
     FeN x, y;
     Enc33 ce;
     if (a.affine_in) {
-      const uint32_t* w = reinterpret_cast<const uint32_t*>(src + i * 64);
-      uint32_t xin[8], yin[8], yw[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { xin[j] = w[j]; yin[j] = w[8 + j]; }
-      valid = valid && !u256_ge(xin, vrfk::Q32) && !u256_ge(yin, vrfk::Q32);
-      const FeN sx = fe_from_abi(ce.w, xin, a.affine_in == 2), sy = fe_from_abi(yw, yin, a.affine_in == 2);   // ce.w, yw: canonical words
-      valid = fe_eq(fe_sqr(sy), bsw_rhs(sx)) && valid;
-      valid = sw_to_te<BswS>(x, y, sx, sy) && valid;
-      ce.fl = u256_gt(yw, vrfk::QM1H32) ? BSW_NEG : 0u;
+      valid = bsw_from_xy(x, y, ce, src, i, a.affine_in == 2) && valid;
     } else {
       const Enc33 e = load33(src, i);
       valid = bsw_decode<BswS>(x, y, e, a.T.sq) && valid;
@@ -435,9 +442,16 @@ __global__ void __launch_bounds__(BLOCK, 2) k_bsw_rlc_decode(RlcArgs a) {
     bool valid = true;
 #pragma unroll 1
     for (int p = 0; p < 5; ++p) {
-      const Enc33 e = load33(p == 0 ? a.h : p == 1 ? a.gamma : p == 2 ? a.pk_com : p == 3 ? a.r : a.ok, item);
+      const uint8_t* src = p == 0 ? a.h : p == 1 ? a.gamma : p == 2 ? a.pk_com : p == 3 ? a.r : a.ok;
       PtA pa;
-      bool ok = bsw_decode<BswS>(pa.x, pa.y, e, a.T.sq);
+      Enc33 e;
+      bool ok;
+      if (a.affine_in) {                          // Weierstrass x || y: e comes out canonical
+        ok = bsw_from_xy(pa.x, pa.y, e, src, item, a.affine_in == 2);
+      } else {
+        e = load33(src, item);
+        ok = bsw_decode<BswS>(pa.x, pa.y, e, a.T.sq);
+      }
       if (a.check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF)) ok = in_prime_subgroup<BswS>(pa.x, pa.y, a.T.sq) && ok;
       valid = valid && ok;
       pa.dt = fe_mul(fe_mul(pa.x, pa.y), BswS::d());
@@ -578,8 +592,27 @@ void launch_bsw_pedersen_verify(const PedersenVerifyArgs& a, hipStream_t st, hip
   hipLaunchKernelGGL(k_bsw_ped_verify_finish, grid_for(a.n), dim3(BLOCK), 0, st, a);
   if (ev) (void)hipEventRecord(ev[4], st);
 }
+// n x 64 B Weierstrass x || y -> n x 33 B encodings (a failed x || y batch falls back to the per-proof kernels); a coordinate
+// >= q gives an undecodable string (both flags)
+__global__ void __launch_bounds__(BLOCK) k_bsw_affine_compress(size_t n, const uint8_t* xy, uint8_t* enc, int mont256) {
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(xy + i * 64);
+  Enc33 e;
+  uint32_t xin[8], yin[8], yw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { xin[j] = w[j]; yin[j] = w[8 + j]; }
+  const bool bad = u256_ge(xin, vrfk::Q32) || u256_ge(yin, vrfk::Q32);
+  (void)fe_from_abi(e.w, xin, mont256 != 0);         // e.w, yw: the canonical words
+  (void)fe_from_abi(yw, yin, mont256 != 0);
+  e.fl = bad ? 0xC0u : (u256_gt(yw, vrfk::QM1H32) ? BSW_NEG : 0u);
+  store33(enc, i, e);
+}
+void launch_bsw_affine_compress(size_t n, const uint8_t* xy, int mont256, uint8_t* enc, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(k_bsw_affine_compress, grid_for(n), dim3(BLOCK), 0, st, n, xy, enc, mont256);
+}
 // enqueues decode + MSM (k_msm.hip's bucket and final kernels); fail_flag[0] becomes 1 if the batch equation does not hold.
-// a.affine_in must be 0; a.k_lane and a.scratch are not read.  ev (nullable, 5 events): start | decode | buckets | final | final
+// a.affine_in: the five point arrays are Weierstrass x || y; a.k_lane and a.scratch are not read.  ev (nullable, 5 events): start | decode | buckets | final | final
 void launch_bsw_pedersen_rlc(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev) {
   if (a.n == 0) return;
   (void)hipMemsetAsync(a.L.flags, 0, 256, st);

@@ -309,8 +309,37 @@ __global__ void __launch_bounds__(128) k_pm_rlc_decode(p256::RlcArgs a) {
   bytes_lite_get(a.ad, i, ad, ad_len);
   FeN x[5], y[5];
   uint32_t c[8], s[8], sb[8];
-  const bool ok = p256_ped_verify_decode_item(x, y, c, s, sb, a.h + i * SEC1_LEN, a.gamma + i * SEC1_LEN, a.pk_com + i * SEC1_LEN,
-                                              a.r + i * SEC1_LEN, a.ok + i * SEC1_LEN, a.s + i * 32, a.sb + i * 32, ad, ad_len, a.str);
+  bool ok;
+  if (a.affine_in) {
+    // typed callers: the five points as x || y (no square root); the Sec1 strings the challenge hashes are rebuilt from
+    // (x, parity of y); a coordinate >= p or a point off the curve is InvalidData
+    ok = true;
+    Sec1W enc[5];
+#pragma unroll 1
+    for (int j = 0; j < 5; ++j) {
+      const uint8_t* src = j == 0 ? a.h : j == 1 ? a.gamma : j == 2 ? a.pk_com : j == 3 ? a.r : a.ok;
+      const uint32_t* e = reinterpret_cast<const uint32_t*>(src + i * 64);
+      uint32_t xin[8], yin[8], xc[8], yc[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { xin[k] = e[k]; yin[k] = e[8 + k]; }
+      const FeN xx = fe_from_abi(xc, xin, a.affine_in == 2), yy = fe_from_abi(yc, yin, a.affine_in == 2);
+      ok = !u256_ge_q(xin) && !u256_ge_q(yin) && sw_on_curve(xx, yy) && ok;
+      Sec1W w;
+      w.tag = 2u + (yc[0] & 1u);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w.xw[k] = xc[k];
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+        if (j == k) { x[k] = xx; y[k] = yy; enc[k] = w; }
+    }
+    const Sec1W pts[5] = {enc[2], enc[0], enc[1], enc[3], enc[4]};
+    p256_challenge(c, pts, ad, ad_len, a.str);
+    const bool s_ok = p256_scalar_decode(s, a.s + i * 32), sb_ok = p256_scalar_decode(sb, a.sb + i * 32);
+    ok = ok && s_ok && sb_ok;
+  } else {
+    ok = p256_ped_verify_decode_item(x, y, c, s, sb, a.h + i * SEC1_LEN, a.gamma + i * SEC1_LEN, a.pk_com + i * SEC1_LEN,
+                                     a.r + i * SEC1_LEN, a.ok + i * SEC1_LEN, a.s + i * 32, a.sb + i * 32, ad, ad_len, a.str);
+  }
   a.status[i] = ok ? 0 : 2;
   // z, z' = the two halves of SHA-256("vrfhip-p256-rlc-v1" || seed || batch digest || u64_le(index)), forced odd (non-zero)
   Sha256 hh;
@@ -398,6 +427,18 @@ void launch_core(const MsmL& L, uint8_t* out33, uint8_t* out_xy, int xy_mont256,
   if (ev) { (void)hipEventRecord(ev[3], st); (void)hipEventRecord(ev[4], st); }
 }
 
+__global__ void __launch_bounds__(128) k_pm_affine_compress(size_t n, const uint8_t* xy, uint8_t* enc, int mont256) {
+  const size_t i = (size_t)blockIdx.x * 128 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(xy + i * 64);
+  uint32_t xin[8], yin[8], xw[8], yw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { xin[j] = w[j]; yin[j] = w[8 + j]; }
+  const bool bad = u256_ge_q(xin) || u256_ge_q(yin);
+  (void)fe_from_abi(xw, xin, mont256 != 0);         // xw, yw: the canonical words
+  (void)fe_from_abi(yw, yin, mont256 != 0);
+  sec1_store(enc + i * SEC1_LEN, bad ? 0xffu : 2u + (yw[0] & 1u), xw);
+}
 }  // namespace
 VRF_NS_END
 
@@ -475,6 +516,10 @@ void launch_pedersen_rlc(const RlcArgs& a_in, uint8_t* fail_flag, hipStream_t st
   hipLaunchKernelGGL(k_pm_rlc_fixed, dim3(1), dim3(64), 0, st, a);
   if (ev) (void)hipEventRecord(ev[1], st);
   launch_core(a.L, nullptr, nullptr, 0, nullptr, fail_flag, st, ev);
+}
+
+void launch_affine_compress(size_t n, const uint8_t* xy, int mont256, uint8_t* enc33, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(k_pm_affine_compress, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, n, xy, enc33, mont256);
 }
 
 }  // namespace p256

@@ -119,7 +119,8 @@ void launch_msm(size_t n, const uint8_t* xy, int mont256, const uint8_t* scalars
 struct RlcArgs {
   size_t n;                                     // proofs in this launch group
   unsigned long long index0;                    // index of the first one in the caller's batch (the weights depend on it)
-  const uint8_t *h, *gamma, *pk_com, *r, *ok;   // n x 33 B Sec1
+  const uint8_t *h, *gamma, *pk_com, *r, *ok;   // n x 33 B Sec1; affine_in: n x 64 B x || y (little-endian)
+  int affine_in;                                // 0: Sec1 strings, 1: x || y canonical, 2: x || y Montgomery-256
   const uint8_t *s, *sb;                        // n x 32 B big-endian
   BytesViewLite ad;
   uint8_t* status;                              // [n] 0 = part of the batch sum, 2 = InvalidData (left out of it)
@@ -133,6 +134,9 @@ struct RlcArgs {
 // fail_flag[0] = 1 unless sum_i z_i (s_i H_i - c_i Gamma_i - Ok_i) + z'_i (s_i G + sb_i B - c_i pk_com_i - R_i) = O over the
 // decodable proofs.  ev: nullptr or 5 events (start, after decode, after buckets, after final, end).
 void launch_pedersen_rlc(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev);
+// n x 64 B x || y (little-endian; mont256: arkworks Montgomery limbs) -> n x 33 B Sec1 strings (a failed x || y batch falls back
+// to the per-proof kernels); a coordinate >= p gives an undecodable string (tag 0xff)
+void launch_affine_compress(size_t n, const uint8_t* xy, int mont256, uint8_t* enc33, hipStream_t st);
 
 size_t comb_bytes();
 // `Public` keys with resident combs (vrfhip_keyset_create on this suite): rows = challenge_len + 1 rows of 128 entries each

@@ -446,8 +446,24 @@ def test_gpu_pedersen_equals_the_oracle(gpu):
         u[6][i] = np.frombuffer(le((int.from_bytes(args[6][i].tobytes(), "little") + sign * d) % R), np.uint8)
     st_b, fast = gpu.pedersen_verify_batch_rlc(*u, ad=ads)
     assert not fast and list(np.nonzero(st_b)[0]) == [3, 9]
-    with pytest.raises(Exception):
-        gpu.pedersen_verify_batch_rlc(*[np.zeros((2, 64), np.uint8)] * 5, np.zeros((2, 32), np.uint8), np.zeros((2, 32), np.uint8), affine=True)
+    # ... and from Weierstrass x || y (typed callers), canonical and Montgomery-256; a failed batch falls back per proof
+    for flags in (0, gpu.COORDS_MONT256):
+        gpu.set_flags(flags)
+        xy5 = []
+        for a in args[:5]:
+            stv, xyv = gpu.point_validate_batch(a, want_xy=True)
+            assert not stv.any()
+            xy5.append(xyv)
+        st_b, fast = gpu.pedersen_verify_batch_rlc(*xy5, args[5], args[6], ad=ads, affine=True)
+        assert fast and not st_b.any()
+        badxy = [a.copy() for a in xy5]
+        sb2 = args[6].copy()
+        sb2[2, 0] ^= 1
+        badxy[4][5, 33] ^= 1                                                   # Ok off the curve
+        badxy[1][7] = xy5[1][8]
+        st_b, fast = gpu.pedersen_verify_batch_rlc(*badxy, args[5], sb2, ad=ads, affine=True)
+        assert not fast and st_b[2] == 1 and st_b[5] == 2 and st_b[7] == 1 and st_b.sum() == 4
+    gpu.set_flags(0)
 
 
 @pytest.mark.gpu
@@ -655,5 +671,3 @@ def test_gpu_xy_forms_key_sets_and_msm(gpu):
     back, stb = te.te_sw_map_batch(np.frombuffer(te_sum, np.uint8).reshape(1, 64), to_te=False)
     assert stb[0] == 0 and back[0].tobytes() == sxy and enc[:32] == sxy[:32]
     te.close()
-    with pytest.raises(Exception):
-        gpu.pedersen_verify_batch_rlc(*[np.zeros((2, 64), np.uint8)] * 5, np.zeros((2, 32), np.uint8), np.zeros((2, 32), np.uint8), affine=True)

@@ -681,16 +681,46 @@ def test_gpu_xy_forms_for_typed_callers(gpu):
 
 
 @pytest.mark.gpu
-def test_gpu_entry_points_outside_the_suite_are_refused(gpu):
-    """What the suite still lacks answers UNSUPPORTED before any byte is read: the x || y form of the batched Pedersen
-    verifier.  (Round 4 built the MSM, the batched verifier and key sets: tests below.)"""
-    from ark_ec_vrfs_amd import VrfHipError
-    z32, z33, z64 = np.zeros((2, 32), np.uint8), np.zeros((2, 33), np.uint8), np.zeros((2, 64), np.uint8)
-    with pytest.raises(VrfHipError):
-        gpu.pedersen_verify_batch_rlc(z64, z64, z64, z64, z64, z32, z32, seed=bytes(32), affine=True)
-    gpu.set_prevalidated(True)                      # cofactor 1: nothing to skip, accepted and without effect
+def test_gpu_prevalidated_flags_are_accepted_without_effect(gpu):
+    """Cofactor 1: there is no subgroup test to skip.  (Nothing is refused on this suite any more: round 4 built the MSM, the
+    batched verifier in both forms and key sets -- tests below.)"""
+    z32, z33 = np.zeros((2, 32), np.uint8), np.zeros((2, 33), np.uint8)
+    gpu.set_prevalidated(True)
     assert gpu.ietf_verify_batch(z33, z33, z33, z32, z32)[0] == 2
     gpu.set_prevalidated(False)
+
+
+@pytest.mark.gpu
+def test_gpu_batched_pedersen_verifier_from_xy(gpu):
+    """The batched verifier from typed values: the five points of every proof as x || y (canonical, and arkworks' in-memory
+    Montgomery limbs): same statuses and verdicts as the Sec1 form; a failed batch falls back to the per-proof kernels through
+    the compressed strings rebuilt from the coordinates."""
+    B = sw.default_blinding_base()
+    co.p256_set_blinding_base(B)
+    n = 700
+    rng = np.random.default_rng(45)
+    sk = rng.integers(0, 256, (n, 32), dtype=np.uint8); sk[:, 0] &= 0x7f
+    msg = rng.integers(0, 256, (n, 20), dtype=np.uint8)
+    pr = gpu.pedersen_prove_batch(sk, msgs=msg, ad=b"xy")
+    F = ("input", "output", "pk_com", "r", "ok")
+    seed = bytes(range(32))
+    for flags in (0, gpu.COORDS_MONT256):
+        gpu.set_flags(flags)
+        xy5 = []
+        for k in F:
+            stv, xyv = gpu.point_validate_batch(pr[k], want_xy=True)           # follows COORDS_MONT256
+            assert not stv.any()
+            xy5.append(xyv)
+        st, ok = gpu.pedersen_verify_batch_rlc(*xy5, pr["s"], pr["sb"], ad=b"xy", seed=seed, affine=True)
+        assert ok and not st.any()
+        bad = [a.copy() for a in xy5]
+        sb2 = pr["sb"].copy()
+        sb2[9, 31] ^= 1                                                        # wrong response
+        bad[1][20] = xy5[1][21]                                                # another proof's output
+        bad[3][30, 40] ^= 1                                                    # R off the curve (or a coordinate >= p)
+        st, ok = gpu.pedersen_verify_batch_rlc(*bad, pr["s"], sb2, ad=b"xy", seed=seed, affine=True)
+        assert not ok and st[9] == 1 and st[20] == 1 and st[30] == 2 and st.sum() == 4
+    gpu.set_flags(0)
 
 
 def test_oracle_msm_against_discrete_logs():
