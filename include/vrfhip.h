@@ -79,8 +79,8 @@ typedef enum vrfhip_suite {
    * (the built-in one is a nothing-up-my-sleeve point: upstream's `BLINDING_BASE` for this suite is not known here; a
    * descriptor with an all-zero base makes a context without the scheme).  The x || y forms work as for the other suites
    * (vrfhip_ietf_verify_batch_affine; VRFHIP_FLAG_PROVE_POINTS_AFFINE for the provers' Gamma / pk / pk_com / R / Ok;
-   * VRFHIP_FLAG_COORDS_MONT256; always little-endian, as arkworks holds coordinates in memory).  Everything else returns
-   * VRFHIP_ERR_UNSUPPORTED (the batched Pedersen verifier, MSM and key sets are not built for it).  Pinned by RFC 9381 Appendix B.1, which upstream's own
+   * VRFHIP_FLAG_COORDS_MONT256; always little-endian, as arkworks holds coordinates in memory).  Since round 4 also vrfhip_msm, the batched
+   * Pedersen verifier (vrfhip_pedersen_verify_batch_rlc, both forms) and key sets: every entry point exists on this suite.  Pinned by RFC 9381 Appendix B.1, which upstream's own
    * tests run: tests/golden/rfc9381_p256_sha256_tai.json (the RFC's use: message = PK_string || alpha).  As upstream, the
    * RFC 6979 nonce takes h1 unreduced and the first HMAC_DRBG candidate mod n (each differs from the RFC text with
    * probability 2^-32). */
@@ -96,8 +96,7 @@ typedef enum vrfhip_suite {
    * scheme (vrfhip_ietf_prove_batch / _verify_batch + _dev, _multi, _alpha, _affine, _keyed with vrfhip_keyset_create over
    * 33-byte keys), the Pedersen scheme (per proof and vrfhip_pedersen_verify_batch_rlc; needs a blinding base in the
    * descriptor), vrfhip_msm (bases and out_xy: WEIERSTRASS x || y; the sum as a 33-byte string), vrfhip_te_sw_map_batch, the
-   * pairing / G1 entry points -- except the x || y form of the batched Pedersen verifier (vrfhip_pedersen_verify_batch_rlc_affine:
-   * VRFHIP_ERR_UNSUPPORTED).  Every x || y this suite reads or writes (VRFHIP_FLAG_PROVE_POINTS_AFFINE, the _affine verifier,
+   * pairing / G1 entry points.  Every x || y this suite reads or writes (VRFHIP_FLAG_PROVE_POINTS_AFFINE, the _affine verifier,
    * vrfhip_point_validate_batch) is in Weierstrass coordinates, little-endian, Montgomery-256 under VRFHIP_FLAG_COORDS_MONT256.  PARITY UNPINNED: no vector of this suite is on this machine;
    * the suite string, the generator (= te_sw_map image of the twisted-Edwards suite's) and the flag convention are
    * recollections; what is checked is consistency with the vector-pinned twisted-Edwards suite through the map

@@ -91,7 +91,6 @@ struct Secp256r1Sha256Tai {
 };
 // `suites::bandersnatch_sw` (upstream "Bandersnatch_SW_SHA-512_TAI"): the Bandersnatch group on its short-Weierstrass model;
 // ArkworksCodec over SWAffine -- 33-byte compressed points (x little-endian, then a flag byte), little-endian scalars, SHA-512.
-// (The x || y form of the batched Pedersen verifier is the one entry point this suite lacks: include/vrfhip.h.)
 struct BandersnatchSwSha512Tai {
   static constexpr vrfhip_suite ID = VRFHIP_SUITE_BANDERSNATCH_SW_SHA512_TAI;
   static constexpr const char* SUITE_ID = "Bandersnatch_SW_SHA-512_TAI";
