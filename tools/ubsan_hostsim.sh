@@ -17,6 +17,7 @@ done
 /opt/rocm/bin/hipcc $FLAGS -DVRF_FIELD=1 -c "$HS/hostsim_suite.hip" -o "$OUT/hostsim_suite_f1.o" 2>/dev/null &
 /opt/rocm/bin/hipcc $FLAGS -DVRF_FIELD=2 -c "$HS/hostsim_suite.hip" -o "$OUT/hostsim_suite_f2.o" 2>/dev/null &
 /opt/rocm/bin/hipcc $FLAGS -DVRF_FIELD=3 -c "$HS/hostsim_p256.hip" -o "$OUT/hostsim_p256.o" 2>/dev/null &
+/opt/rocm/bin/hipcc $FLAGS -DVRF_FIELD=0 -c "$HS/hostsim_bsw.hip" -o "$OUT/hostsim_bsw.o" 2>/dev/null &      # bandersnatch_sw codec
 wait
 link "$OUT/libhostsim.so" "$OUT/hostsim_fe.o" "$OUT/hostsim_verify.o" "$OUT/hostsim_prove.o"
 link "$OUT/libhostsim_bls.so" "$OUT/hostsim_bls.o"
@@ -24,7 +25,8 @@ link "$OUT/libhostsim_jj.so" "$OUT/hostsim_jj.o"
 link "$OUT/libhostsim_f1.so" "$OUT/hostsim_suite_f1.o"
 link "$OUT/libhostsim_f2.so" "$OUT/hostsim_suite_f2.o"
 link "$OUT/libhostsim_p256.so" "$OUT/hostsim_p256.o"
-LIBS="libhostsim.so libhostsim_bls.so libhostsim_jj.so libhostsim_f1.so libhostsim_f2.so libhostsim_p256.so"
+link "$OUT/libhostsim_bsw.so" "$OUT/hostsim_bsw.o"
+LIBS="libhostsim.so libhostsim_bls.so libhostsim_jj.so libhostsim_f1.so libhostsim_f2.so libhostsim_p256.so libhostsim_bsw.so"
 # the test fixtures run `make` on the library they load: bring the regular build up to date first, so that make finds
 # nothing to do and leaves the sanitizer builds in place
 make -C "$HS" -j8 all > /dev/null
@@ -33,4 +35,4 @@ for l in $LIBS; do cp -p "$HS/$l" "$OUT/orig/$l"; cp "$OUT/$l" "$HS/$l"; done
 restore() { for l in $LIBS; do cp -p "$OUT/orig/$l" "$HS/$l"; touch "$HS/$l"; done; }
 trap restore EXIT
 cd "$ROOT"
-UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 python -m pytest tests/test_hostsim.py tests/test_bls_pairing.py tests/test_jubjub.py tests/test_new_suites.py tests/test_secp256r1.py -x -q -m "not gpu"
+UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 python -m pytest tests/test_hostsim.py tests/test_bls_pairing.py tests/test_jubjub.py tests/test_new_suites.py tests/test_secp256r1.py tests/test_bandersnatch_sw.py -x -q -m "not gpu"
