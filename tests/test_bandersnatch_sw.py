@@ -568,6 +568,14 @@ def test_gpu_multi_context(gpu):
     stm = ietf_verify_batch_multi([gpu, c2], pk, r["input"], r["output"], r["c"], s2, ad=b"")
     assert (stm == st).all() and (st[3::11] == 1).all() and st.sum() == len(st[3::11])
     c2.close()
+    # the curve-independent entry points run on this suite's contexts too: the pairing check of the ring verifier's tail
+    import json
+    import os as _os
+    fx = json.load(open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "pairing_items.json")))
+    hx = lambda h: np.frombuffer(bytes.fromhex(h), np.uint8)
+    g2 = hx(fx["shared_g2"])
+    items = np.stack([hx(h) for h in fx["shared"][:4]] + [hx(h) for h in fx["shared_bad"][:2]])
+    assert list(gpu.pairing_check_batch(items, g2, g2_shared=True)) == [0, 0, 0, 0, 1, 1]
 @pytest.mark.gpu
 def test_gpu_xy_forms_key_sets_and_msm(gpu):
     """The remaining entry points of the suite: x || y inputs (no square root) and outputs, verification against a resident
