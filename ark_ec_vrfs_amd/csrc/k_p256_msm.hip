@@ -103,6 +103,33 @@ __global__ void __launch_bounds__(128) k_pm_prep(MsmL L, const uint8_t* xy, cons
   pm_write_digits(L.digits, L.n, i, k, false, !ok || inf);
 }
 
+// P + (x2, y2) for any P (the point at infinity included) and an AFFINE second operand (RCB 2016 algorithm 5, a = -3):
+// 11 products + 2 by b -- sw_add with Z2 = 1 spelt out, which drops the Z1 Z2 product and turns the two Karatsuba-shaped
+// cross terms into one product each.  The bucket loop adds nothing but affine input points.
+VRF_HD PtW sw_madd(const PtW& p, const FeN& x2, const FeN& y2) {
+  const FeN b = CurveP256::b();
+  const FeN t0 = fe_mul(p.X, x2), t1 = fe_mul(p.Y, y2);
+  const FeN t2 = p.Z;
+  const auto t3 = fe_sub(fe_mul(fe_add(p.X, p.Y), fe_add(x2, y2)), fe_add(t0, t1));      // X1 Y2 + X2 Y1
+  const auto t4 = fe_add(fe_mul(y2, p.Z), p.Y);                                           // Y1 + Y2 Z1
+  const auto y3 = fe_add(fe_mul(x2, p.Z), p.X);                                           // X1 + X2 Z1
+  const FeN a1 = fe_wred(fe_sub(y3, fe_mul(t2, b)));
+  const auto a3 = fe_add(fe_dbl(a1), a1);
+  const auto z3 = fe_norm(fe_sub(t1, fe_norm(a3)));
+  const auto x3 = fe_norm(fe_add(t1, a3));
+  const auto t2x3 = fe_norm(fe_add(fe_dbl(t2), t2));
+  const FeN bb = fe_wred(fe_sub(fe_sub(fe_mul(y3, b), t2x3), t0));
+  const auto y3b = fe_add(fe_dbl(bb), bb);
+  const auto t0b = fe_norm(fe_sub(fe_add(fe_dbl(t0), t0), t2x3));
+  const auto t1b = fe_mul(fe_norm(t4), y3b);
+  const auto t2b = fe_mul(t0b, fe_norm(y3b));
+  PtW r;
+  r.Y = fe_wred(fe_add(fe_mul(x3, z3), t2b));
+  r.X = fe_wred(fe_sub(fe_mul(fe_norm(t3), x3), t1b));
+  r.Z = fe_wred(fe_add(fe_mul(fe_norm(t4), z3), fe_mul(fe_norm(t3), t0b)));
+  return r;
+}
+
 // ------------------------------------------------------------------------------- buckets
 __global__ void __launch_bounds__(PM_BLOCK) k_pm_buckets(MsmL L) {
   extern __shared__ uint32_t lds[];
@@ -213,7 +240,7 @@ __global__ void __launch_bounds__(PM_BLOCK) k_pm_buckets(MsmL L) {
           cur = b;
           acc = sw_identity();
         }
-        acc = sw_add(acc, sw_cneg((ent >> 31) != 0, sw_from_affine(x, y)));
+        acc = sw_madd(acc, x, fe_select((ent >> 31) != 0, fe_wred(fe_neg(y)), y));
       }
     }
     if (cnt > 0) {

@@ -48,7 +48,7 @@ cp.pedersen_prove_batch_dev(sk, msg, 32, g, pc, rr, okp, s_, sbb, None, hh, st)
 torch.cuda.synchronize()
 assert int(st.sum()) == 0
 seed = os.urandom(32)
-for groups in (0, 8, 10, 11, 12, 16, 20, 22, 24, 26, 32, 36, 48):
+for groups in (0, 11, 12, 16, 20, 24, 25, 26, 32, 40, 48, 50, 52, 64, 72):
     cp.debug_set(5, groups)
     fn = lambda: cp.pedersen_verify_batch_rlc_dev(hh, g, pc, rr, okp, s_, sbb, st, flag, seed)
     fn(); torch.cuda.synchronize()
