@@ -68,12 +68,21 @@ __global__ void __launch_bounds__(64, 2) k_tai_find(size_t n, BytesView msg, uin
   }
 }
 
-// the launch: the queue counter is reset on the stream first; persistent waves, 4 per SIMD at most
+// the launch: the queue counter is reset on the stream first; persistent waves, as many as are RESIDENT at once (the kernel
+// holds 256 registers: two waves per SIMD) -- later waves of a larger grid would find the queue empty.  Measured: 44 of 64
+// lanes active per vector instruction on JubJub, 28 on bandersnatch_sw (profiles/r04/lane_utilisation_bench.log): a wave's
+// last trips run with ever fewer lanes, each lane's last item ending on its own attempt.
 template <class S>
 inline void launch_tai_find_t(size_t n, BytesView msg, uint8_t* ctr_out, const SqrtTables& T, unsigned long long* queue,
                               hipStream_t st) {
   (void)hipMemsetAsync(queue, 0, sizeof(unsigned long long), st);
-  const size_t waves = std::min<size_t>((n + 63) / 64, 4096);
+  static const size_t resident = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    return (size_t)cus * 4 * 2;
+  }();
+  const size_t waves = std::min<size_t>((n + 63) / 64, resident);
   hipLaunchKernelGGL(k_tai_find<S>, dim3((unsigned)waves), dim3(64), 0, st, n, msg, ctr_out, T, queue);
 }
 
