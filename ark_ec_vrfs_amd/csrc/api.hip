@@ -923,11 +923,15 @@ int32_t vrfhip_ietf_verify_batch_alpha_dev(vrfhip_ctx* ctx, size_t n, const uint
     return VRFHIP_SUCCESS;
   }
   if (ctx->bsw) {
-    // the two stages as they are: H's 33-byte string parked in the projective-results region, which nothing writes before the
-    // decode stage has read it; H is a cofactor multiple by construction, so its subgroup test is skipped
+    // the two stages as they are: H's 33-byte strings parked in the (otherwise idle) MSM workspace -- every region of the
+    // verify workspace is written by the decode stage; H is a cofactor multiple by construction, so its subgroup test is skipped
+    {
+      const int32_t rc2 = ensure_msm_workspace(ctx, std::min(ctx->ws_cap, n) * 33 + 256);
+      if (rc2) return rc2;
+    }
     for (size_t base = 0; base < n; base += ctx->ws_cap) {
       const size_t m = std::min(ctx->ws_cap, n - base);
-      uint8_t* d_henc = reinterpret_cast<uint8_t*>(ctx->ws.pts);
+      uint8_t* d_henc = static_cast<uint8_t*>(ctx->d_msm_ws);
       BytesView mv = d_msg_off ? make_view(d_msg, d_msg_off + base, msg_len, false)
                                : make_view(d_msg ? d_msg + base * (size_t)msg_len : d_msg, nullptr, msg_len, false);
       launch_bsw_hash_to_curve(m, mv, d_henc, ctx->T, st, ctx->ws.flags, ctx->d_queue);

@@ -116,6 +116,56 @@ VRF_HD bool bsw_decode(FeN& tx, FeN& ty, const Enc33& e, const SqrtTables& T) {
   return bsw_decode<C>(tx, ty, sx, sy, inf, e, T);
 }
 
+// ---- the way in, split so that several points share ONE inversion (Montgomery's trick across their map denominators) ----
+// Phase A leaves sx | sy | den | prefix (the product of the denominators in front of this point) in a 36-word slot of the
+// caller's scratch and multiplies the running product; phase B, called in REVERSE order with inv = 1 / (product of all the
+// denominators so far), gives the point's Edwards coordinates and strips its denominator from inv.
+constexpr int BSW_SLOT = 4 * NL;
+constexpr uint32_t BSW_A_OK = 1u, BSW_A_INF = 2u;
+VRF_HD uint32_t bsw_in_a_store(uint32_t* slot, FeN& run, const FeN& sx, const FeN& sy, bool ok, bool inf) {
+  const FeN a = te_coeff_a<BswS>(), d = BswS::d();
+  const FeN x12 = fe_full(fe_dbl(fe_dbl(fe_times3(sx))));
+  const FeN den_w = fe_full(fe_sub(fe_full(fe_add(x12, a)), fe_full(fe_mul5(d))));           // 12 X + a - 5 d
+  const FeN den = fe_mul(fe_full(fe_dbl(fe_times3(sy))), den_w);                                // 6 Y (12 X + a - 5 d)
+  const bool some = !fe_is_zero(den);
+  const FeN dd = fe_select(some && !inf, den, fe_one());
+  fe_store(slot, sx); fe_store(slot + NL, sy); fe_store(slot + 2 * NL, dd); fe_store(slot + 3 * NL, run);
+  run = fe_mul(run, dd);
+  return ((ok && (inf || some)) ? BSW_A_OK : 0u) | (inf ? BSW_A_INF : 0u);
+}
+// from the wire
+VRF_HD uint32_t bsw_in_a(uint32_t* slot, FeN& run, const Enc33& e, const SqrtTables& T) {
+  const uint32_t fl = e.fl & 0xC0u;
+  bool ok = fl != 0xC0u && !u256_ge(e.w, vrfk::Q32);
+  const bool inf = fl == BSW_INF;
+  const FeN sx = fe_from_u256(e.w);
+  FeN root;
+  bool sq = fe_sqrt_or_zsqrt(root, bsw_rhs(sx), T);
+  uint32_t yw[8];
+  fe_to_u256(yw, root);
+  uint32_t nz = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) nz |= yw[i];
+  sq = sq || nz == 0;
+  const bool larger = u256_gt(yw, vrfk::QM1H32);
+  const FeN sy = fe_full(fe_cneg(larger != (fl == BSW_NEG), root));
+  return bsw_in_a_store(slot, run, sx, sy, ok && (inf || sq), inf);
+}
+VRF_HD void bsw_in_b(FeN& tx, FeN& ty, FeN& inv, const uint32_t* slot, bool inf) {
+  const FeN sx = fe_load<1, 2>(slot), sy = fe_load<1, 2>(slot + NL), den = fe_load<1, 2>(slot + 2 * NL);
+  const FeN prefix = fe_load<1, 2>(slot + 3 * NL);
+  const FeN i = fe_mul(inv, prefix);
+  inv = fe_mul(inv, den);
+  const FeN a = te_coeff_a<BswS>(), d = BswS::d();
+  const FeN x6 = fe_full(fe_dbl(fe_times3(sx))), y6 = fe_full(fe_dbl(fe_times3(sy)));
+  const FeN x12 = fe_full(fe_dbl(x6));
+  const FeN num_v = fe_full(fe_sub(x6, fe_full(fe_add(a, d))));                                // 6 X - (a + d)
+  const FeN num_w = fe_full(fe_add(fe_sub(x12, fe_full(fe_mul5(a))), d));                       // 12 X - 5 a + d
+  const FeN den_w = fe_full(fe_sub(fe_full(fe_add(x12, a)), fe_full(fe_mul5(d))));            // 12 X + a - 5 d
+  tx = fe_select(inf, fe_zero(), fe_mul(fe_mul(num_v, den_w), i));
+  ty = fe_select(inf, fe_one(), fe_mul(fe_mul(num_w, y6), i));
+}
+
 // ---- encode: Edwards projective -> wire ----
 // the Weierstrass image of (X : Y : Z) as two numerators over one denominator (den = 1 where the image has none: the
 // neutral element, and the point of order 2 on the Edwards y axis whose image is (nx / den, 0))

@@ -192,9 +192,9 @@ __global__ void __launch_bounds__(BLOCK, 2) k_bsw_prove_finish(ProveArgs a) {
   if (a.status) a.status[i] = ok ? ST_OK : ST_INVALID_DATA;
 }
 
-// A point handed over as Weierstrass x || y (64 bytes; mont256: arkworks' in-memory Montgomery limbs): range and curve checks
-// instead of the square root, then the same map.  ce: the encoding `point_encode` gives it.
-VRF_HD bool bsw_from_xy(FeN& tx, FeN& ty, Enc33& ce, const uint8_t* src, size_t i, bool mont256) {
+// Phase A (bsw_core.cuh) of a point handed over as Weierstrass x || y (64 bytes; mont256: arkworks' in-memory Montgomery
+// limbs): range and curve checks instead of the square root.  ce: the encoding `point_encode` gives it.
+VRF_HD uint32_t bsw_in_a_xy(uint32_t* slot, FeN& run, Enc33& ce, const uint8_t* src, size_t i, bool mont256) {
   const uint32_t* w = reinterpret_cast<const uint32_t*>(src + i * 64);
   uint32_t xin[8], yin[8], yw[8];
 #pragma unroll
@@ -202,9 +202,8 @@ VRF_HD bool bsw_from_xy(FeN& tx, FeN& ty, Enc33& ce, const uint8_t* src, size_t 
   bool ok = !u256_ge(xin, vrfk::Q32) && !u256_ge(yin, vrfk::Q32);
   const FeN sx = fe_from_abi(ce.w, xin, mont256), sy = fe_from_abi(yw, yin, mont256);      // ce.w, yw: canonical words
   ok = fe_eq(fe_sqr(sy), bsw_rhs(sx)) && ok;
-  ok = sw_to_te<BswS>(tx, ty, sx, sy) && ok;
   ce.fl = u256_gt(yw, vrfk::QM1H32) ? BSW_NEG : 0u;
-  return ok;
+  return bsw_in_a_store(slot, run, sx, sy, ok, false);
 }
 
 // ---- IETF verify, stage 1: decode pk, H, Gamma; GLV window tables; canonical encodings for the challenge ----
@@ -217,25 +216,40 @@ __global__ void __launch_bounds__(BLOCK, 2) k_bsw_verify_decode(VerifyArgs a) {
   if (i >= a.n) return;
   uint32_t* aux = a.ws.aux + i * AUX_WORDS;
   uint32_t* tabs = a.ws.tabs + i * (VERIFY_TABS * WIN_TABLE_WORDS);
-  bool valid = true;
-  uint32_t fls = 0;
+  uint32_t* scr = a.ws.pts + i * PROVE_PTS_WORDS;       // 3 slots of 36 words: the item's own slice, idle until the Straus stage
+  static_assert(PROVE_PTS_WORDS >= 3 * BSW_SLOT, "decode scratch");
+  const int p0 = a.key_index ? 1 : 0;
+  // phase A: square roots (or range / curve checks of x || y), map denominators, their running product
+  FeN run = fe_one();
+  uint32_t bits = 0, fls = 0;
 #pragma unroll 1
-  for (int p = a.key_index ? 1 : 0; p < 3; ++p) {
+  for (int p = p0; p < 3; ++p) {
     const uint8_t* src = p == 0 ? a.pk : p == 1 ? a.h : a.gamma;
-    FeN x, y;
     Enc33 ce;
+    uint32_t st;
     if (a.affine_in) {
-      valid = bsw_from_xy(x, y, ce, src, i, a.affine_in == 2) && valid;
+      st = bsw_in_a_xy(scr + p * BSW_SLOT, run, ce, src, i, a.affine_in == 2);
     } else {
       const Enc33 e = load33(src, i);
-      valid = bsw_decode<BswS>(x, y, e, a.T.sq) && valid;
+      st = bsw_in_a(scr + p * BSW_SLOT, run, e, a.T.sq);
       ce = enc33_canonical(e);
     }
-    if ((a.check_mask >> p) & 1u) valid = in_prime_subgroup<BswS>(x, y, a.T.sq) && valid;       // bit p: pk, H, Gamma
-    build_glv_tables<BswS>(tabs + p * 2 * WIN_TABLE_WORDS, x, y);
+    bits |= st << (2 * p);
 #pragma unroll
     for (int j = 0; j < 8; ++j) aux[8 * p + j] = ce.w[j];
     fls |= ce.fl << (8 * p);
+  }
+  // phase B: ONE inversion for the item's points; Edwards coordinates, subgroup test, tables
+  FeN inv = fe_inv(run);
+  bool valid = true;
+#pragma unroll 1
+  for (int p = 2; p >= p0; --p) {
+    const uint32_t st = (bits >> (2 * p)) & 3u;
+    FeN x, y;
+    bsw_in_b(x, y, inv, scr + p * BSW_SLOT, (st & BSW_A_INF) != 0);
+    valid = valid && (st & BSW_A_OK) != 0;
+    if ((a.check_mask >> p) & 1u) valid = in_prime_subgroup<BswS>(x, y, a.T.sq) && valid;       // bit p: pk, H, Gamma
+    build_glv_tables<BswS>(tabs + p * 2 * WIN_TABLE_WORDS, x, y);
   }
   if (a.key_index) {
     const uint32_t key = a.key_index[i];
@@ -440,26 +454,37 @@ __global__ void __launch_bounds__(BLOCK, 2) k_bsw_rlc_decode(RlcArgs a) {
   if (item < n) {
     Enc33 enc[5];
     bool valid = true;
+    uint32_t* scr = a.scratch + item * (size_t)a.scratch_stride;        // 5 slots of 36 words (bsw_core.cuh)
+    FeN run = fe_one();
+    uint32_t bits = 0;
 #pragma unroll 1
     for (int p = 0; p < 5; ++p) {
       const uint8_t* src = p == 0 ? a.h : p == 1 ? a.gamma : p == 2 ? a.pk_com : p == 3 ? a.r : a.ok;
-      PtA pa;
-      Enc33 e;
-      bool ok;
-      if (a.affine_in) {                          // Weierstrass x || y: e comes out canonical
-        ok = bsw_from_xy(pa.x, pa.y, e, src, item, a.affine_in == 2);
+      Enc33 ce;
+      uint32_t st;
+      if (a.affine_in) {                          // Weierstrass x || y: the encoding comes out canonical
+        st = bsw_in_a_xy(scr + p * BSW_SLOT, run, ce, src, item, a.affine_in == 2);
       } else {
-        e = load33(src, item);
-        ok = bsw_decode<BswS>(pa.x, pa.y, e, a.T.sq);
+        const Enc33 e = load33(src, item);
+        st = bsw_in_a(scr + p * BSW_SLOT, run, e, a.T.sq);
+        ce = enc33_canonical(e);
       }
+      bits |= st << (2 * p);
+#pragma unroll
+      for (int q = 0; q < 5; ++q)
+        if (q == p) enc[q] = ce;
+    }
+    FeN inv = fe_inv(run);                        // one inversion for the proof's five points
+#pragma unroll 1
+    for (int p = 4; p >= 0; --p) {
+      const uint32_t st = (bits >> (2 * p)) & 3u;
+      PtA pa;
+      bsw_in_b(pa.x, pa.y, inv, scr + p * BSW_SLOT, (st & BSW_A_INF) != 0);
+      bool ok = (st & BSW_A_OK) != 0;
       if (a.check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF)) ok = in_prime_subgroup<BswS>(pa.x, pa.y, a.T.sq) && ok;
       valid = valid && ok;
       pa.dt = fe_mul(fe_mul(pa.x, pa.y), BswS::d());
       pta_store(a.L.pts + rlc_index(p, n, item) * MSM_PTA_STRIDE, pa);
-      const Enc33 ce = enc33_canonical(e);
-#pragma unroll
-      for (int q = 0; q < 5; ++q)
-        if (q == p) enc[q] = ce;
     }
     uint32_t s[8], sb[8];
     load32(s, a.s, item); load32(sb, a.sb, item);
@@ -612,7 +637,7 @@ void launch_bsw_affine_compress(size_t n, const uint8_t* xy, int mont256, uint8_
   if (n) hipLaunchKernelGGL(k_bsw_affine_compress, grid_for(n), dim3(BLOCK), 0, st, n, xy, enc, mont256);
 }
 // enqueues decode + MSM (k_msm.hip's bucket and final kernels); fail_flag[0] becomes 1 if the batch equation does not hold.
-// a.affine_in: the five point arrays are Weierstrass x || y; a.k_lane and a.scratch are not read.  ev (nullable, 5 events): start | decode | buckets | final | final
+// a.affine_in: the five point arrays are Weierstrass x || y; a.scratch: >= 180 words per proof; a.k_lane is not read.  ev (nullable, 5 events): start | decode | buckets | final | final
 void launch_bsw_pedersen_rlc(const RlcArgs& a, uint8_t* fail_flag, hipStream_t st, hipEvent_t* ev) {
   if (a.n == 0) return;
   (void)hipMemsetAsync(a.L.flags, 0, 256, st);
