@@ -39,6 +39,22 @@ void hb_encode(const uint8_t* te_xy, const uint8_t* z_, uint8_t* enc) {
   p.X = fe_mul(x, z); p.Y = fe_mul(y, z); p.Z = z; p.T = fe_mul(fe_mul(x, y), z);
   store33(enc, 0, bsw_encode<BswS>(p));
 }
+// n <= 8 points through the two-phase way in (ONE inversion for all of them, as k_bsw_verify_decode / k_bsw_rlc_decode run it):
+// flags[i] as hb_decode bits 0 and 1, te_xy[i] the Edwards coordinates
+void hb_decode_shared(const uint8_t* encs, int n, uint8_t* te_xy, uint8_t* flags) {
+  const SqrtTables T = tables();
+  uint32_t scr[8 * BSW_SLOT];
+  uint32_t st[8];
+  FeN run = fe_one();
+  for (int p = 0; p < n; ++p) st[p] = bsw_in_a(scr + p * BSW_SLOT, run, load33(encs, p), T);
+  FeN inv = fe_inv(run);
+  for (int p = n - 1; p >= 0; --p) {
+    FeN x, y;
+    bsw_in_b(x, y, inv, scr + p * BSW_SLOT, (st[p] & BSW_A_INF) != 0);
+    out(te_xy + 64 * p, x); out(te_xy + 64 * p + 32, y);
+    flags[p] = (uint8_t)(((st[p] & BSW_A_OK) ? 1 : 0) | ((st[p] & BSW_A_INF) ? 2 : 0));
+  }
+}
 void hb_canonical(const uint8_t* enc, uint8_t* o) { store33(o, 0, enc33_canonical(load33(enc, 0))); }
 void hb_challenge(const uint8_t* pts, const uint8_t* ad, uint32_t ad_len, uint8_t* c) {
   Enc33 e[5];

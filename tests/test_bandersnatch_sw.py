@@ -260,6 +260,28 @@ def test_host_build_codec_equals_the_oracle(hb):
         assert _hb_decode(hb, bad)[0] & 1 == 0
 
 
+def test_host_build_shared_inversion_equals_the_point_by_point_decode(hb):
+    """The way in as the verify kernels run it: the points of an item share one te_sw_map inversion (Montgomery's trick over
+    the map denominators).  Mixtures of valid points, infinity, points outside the subgroup, undecodable strings and points
+    with y = 0 (denominator zero: replaced by one, flagged) give what the point-by-point decode gives."""
+    rnd = random.Random(29)
+    t2 = _torsion2()
+    offx = next(x for x in range(2, 100) if vo.legendre((x ** 3 + bo.A * x + bo.B) % Q, Q) == -1)
+    pool = [bo.point_encode(bo.mul(rnd.randrange(1, R), bo.G)) for _ in range(12)]
+    pool += [bytes(32) + b"\x40", le(5) + b"\x40", bo.point_encode(bo.add(bo.mul(9, bo.G), t2[1])), le(t2[0][0]) + b"\x00",
+             le(t2[2][0]) + b"\x80", le(offx) + b"\x00", le(Q + 2) + b"\x00", pool[0][:32] + b"\xc0", pool[1][:32] + bytes([pool[1][32] | 0x11])]
+    for trial in range(60):
+        n = rnd.choice((1, 2, 3, 5, 8))
+        encs = [rnd.choice(pool) for _ in range(n)]
+        te, fl = ctypes.create_string_buffer(64 * n), ctypes.create_string_buffer(n)
+        hb.hb_decode_shared(b"".join(encs), n, te, fl)
+        for i, e in enumerate(encs):
+            f1, te1, _ = _hb_decode(hb, e)
+            assert fl.raw[i] == (f1 & 3), (trial, i)
+            if f1 & 1:
+                assert te.raw[64 * i:64 * i + 64] == te1, (trial, i)
+
+
 def test_host_build_hashes_and_try_and_increment_equal_the_oracle(hb):
     rnd = random.Random(23)
     for i in range(12):
