@@ -386,11 +386,31 @@ __global__ void __launch_bounds__(BLOCK, 2) k_bsw_ped_verify_decode(PedersenVeri
   uint32_t* pts = a.ws.pts + i * PROVE_PTS_WORDS;
   Enc33 enc[5];
   bool valid = true;
+  // The five points share ONE map inversion (bsw_core.cuh).  Their five 36-word slots sit where pk_com's tables go
+  // (tabs[4..5]: 576 words); the chain starts with pk_com, so the reverse pass meets it LAST -- Ok and R have gone to the
+  // results region, H's and Gamma's tables to tabs[0..3], and pk_com's slot is in registers before its tables overwrite it.
+  uint32_t* scr = tabs + 4 * WIN_TABLE_WORDS;
+  static_assert(2 * WIN_TABLE_WORDS >= 5 * BSW_SLOT, "decode scratch");
+  FeN run = fe_one();
+  uint32_t bits = 0;
 #pragma unroll 1
-  for (int p = 0; p < 5; ++p) {
+  for (int k = 0; k < 5; ++k) {
+    const int p = k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 1 : k;             // chain order: pk_com, H, Gamma, R, Ok
     const Enc33 e = load33(p == 0 ? a.h : p == 1 ? a.gamma : p == 2 ? a.pk_com : p == 3 ? a.r : a.ok, i);
+    bits |= bsw_in_a(scr + k * BSW_SLOT, run, e, a.T.sq) << (2 * k);
+    const Enc33 ce = enc33_canonical(e);
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      if (q == p) enc[q] = ce;
+  }
+  FeN inv = fe_inv(run);
+#pragma unroll 1
+  for (int k = 4; k >= 0; --k) {
+    const int p = k == 0 ? 2 : k == 1 ? 0 : k == 2 ? 1 : k;
+    const uint32_t st = (bits >> (2 * k)) & 3u;
     FeN x, y;
-    valid = bsw_decode<BswS>(x, y, e, a.T.sq) && valid;
+    bsw_in_b(x, y, inv, scr + k * BSW_SLOT, (st & BSW_A_INF) != 0);
+    valid = valid && (st & BSW_A_OK) != 0;
     // check_mask: H is an input, Gamma an output, pk_com / R / Ok proof points
     if (a.check_mask & (p == 0 ? CHK_INPUT : p == 1 ? CHK_OUTPUT : CHK_PROOF)) valid = in_prime_subgroup<BswS>(x, y, a.T.sq) && valid;
     if (p < 3) {
@@ -400,10 +420,6 @@ __global__ void __launch_bounds__(BLOCK, 2) k_bsw_ped_verify_decode(PedersenVeri
       fe_store(dst, x);
       fe_store(dst + NL, y);
     }
-    const Enc33 ce = enc33_canonical(e);
-#pragma unroll
-    for (int q = 0; q < 5; ++q)
-      if (q == p) enc[q] = ce;
   }
   const uint8_t* ad; uint32_t ad_len;
   bytes_get(a.ad, i, ad, ad_len);
