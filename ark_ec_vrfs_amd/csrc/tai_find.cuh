@@ -7,6 +7,11 @@
 
 VRF_NS_BEGIN
 
+// lanes of a wave that must hold a candidate before the wave runs the Jacobi symbol
+#ifndef TAI_READY_MIN
+#define TAI_READY_MIN 48
+#endif
+
 // stage 0 for try-and-increment suites: find every item's first counter whose candidate decodes.  A lane that
 // loops until ITS item succeeds makes the wave pay the maximum over 64 geometric trials (about 7 attempts for
 // an expected 2).  Here the lanes of a persistent wave draw items from a global queue: a lane whose attempt
@@ -24,9 +29,10 @@ __global__ void __launch_bounds__(64, 2) k_tai_find(size_t n, BytesView msg, uin
   constexpr size_t NONE = ~size_t(0);
   const int lane = threadIdx.x;
   size_t item = NONE;
-  uint32_t ctr = 0;
-  bool ready = false;                                      // this lane holds a candidate that awaits its Jacobi symbol
-  FeN w = fe_zero();
+  uint32_t next = 0;                                       // the item's next counter to hash
+  bool ready = false, has2 = false;                        // candidate A awaits its Jacobi symbol; B is the one after it
+  uint32_t ca = 0, cb = 0;
+  FeN wa = fe_zero(), wb = fe_zero();
   bool drained = false;                                    // the queue has no items left (wave-uniform)
   while (true) {
     const bool need = item == NONE && !drained;
@@ -37,31 +43,37 @@ __global__ void __launch_bounds__(64, 2) k_tai_find(size_t n, BytesView msg, uin
       unsigned long long base = 0;
       if (lane == 0) base = atomicAdd(queue, (unsigned long long)cnt);
       base = __shfl(base, 0, 64);
-      if (need && base + rank < n) { item = (size_t)(base + rank); ctr = 0; ready = false; }
+      if (need && base + rank < n) { item = (size_t)(base + rank); next = 0; ready = false; has2 = false; }
       if (base + cnt >= n) drained = true;
     }
     if (!__any(item != NONE)) break;                       // every lane idle and nothing left to draw
-    if (item != NONE && !ready) {                          // the cheap half
+    // The cheap half.  A lane that already holds a candidate does not sit the trip out: it hashes on and keeps the NEXT
+    // counter that passes (B), so that a failed symbol of A is followed by B's at once (the order of the counters is kept:
+    // the first one whose candidate decodes still wins).
+    if (item != NONE && !has2 && next < 256) {
       const uint8_t* m; uint32_t len;
       bytes_get(msg, item, m, len);
-      if (tai_attempt_candidate<S>(w, m, len, ctr, T)) {
-        ready = true;
-      } else if (ctr == 255) {
-        ctr_out[item] = 255;                               // hash_to_curve_tai reports the failure
-        item = NONE;
-      } else {
-        ++ctr;
+      FeN w;
+      if (tai_attempt_candidate<S>(w, m, len, next, T)) {
+        if (!ready) { wa = w; ca = next; ready = true; }
+        else { wb = w; cb = next; has2 = true; }
       }
+      ++next;
+    }
+    if (item != NONE && !ready && next >= 256) {           // out of counters with nothing to test:
+      ctr_out[item] = 255;                                 // hash_to_curve_tai reports the failure
+      item = NONE;
     }
     const unsigned long long rmask = __ballot(ready), hmask = __ballot(item != NONE && !ready);
-    if (__popcll(rmask) >= 48 || (rmask && !hmask)) {      // the expensive half, for the lanes that wait for it
+    if (__popcll(rmask) >= TAI_READY_MIN || (rmask && !hmask)) {      // the expensive half, for the lanes that hold a candidate
       if (ready) {
-        ready = false;
-        if (fe_is_square_or_zero(w, T) || ctr == 255) {
-          ctr_out[item] = (uint8_t)ctr;
-          item = NONE;
+        if (fe_is_square_or_zero(wa, T) || ca == 255) {
+          ctr_out[item] = (uint8_t)ca;
+          item = NONE; ready = false; has2 = false;
+        } else if (has2) {
+          wa = wb; ca = cb; has2 = false;                  // B moves up; the lane stays ready
         } else {
-          ++ctr;
+          ready = false;
         }
       }
     }

@@ -1,7 +1,10 @@
 """hash-to-curve alone (the try-and-increment search + the decode of the found candidate) on every try-and-increment suite, 2^20
-messages: the workload tools/profile_lane_util.sh counts active lanes on.  usage (GPU box): python tools/gpu_h2c_only.py"""
+messages: the workload tools/profile_lane_util.sh counts active lanes on.  usage (GPU box): python tools/gpu_h2c_only.py [libvrfhip variant .so]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ark_ec_vrfs_amd import _lib as _l0
+if len(sys.argv) > 1:
+    _l0.LIB_PATH = os.path.abspath(sys.argv[1])          # an A/B build of the library
 import torch
 from ark_ec_vrfs_amd import (BabyJubJubSha512Tai, BandersnatchSwSha512Tai, Context, Ed25519Sha512Tai, JubJubSha512Tai,
                              Secp256r1Sha256Tai, _lib)
